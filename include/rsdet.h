@@ -1,0 +1,163 @@
+/* rsdet.h -- C ABI of librsdet_hip.so: the MI355X (gfx950) oriented-detection
+ * hot path that replaces JDet's jt.code() native-op seam.
+ *
+ * Boundary rules (every entry point):
+ *   - extern "C", plain pointers + sizes, int status return (0 = RSDET_OK);
+ *   - all pointers are DEVICE pointers unless the name says host;
+ *   - never allocates or frees device memory, never synchronises: outputs and
+ *     workspaces are caller-provided, work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream);
+ *   - re-entrant, no global state; graph-capturable.
+ *   - tensors are dense row-major fp32 unless stated.
+ *
+ * Each declaration cites the reference interface it replaces; paths are
+ * relative to /root/reference/python/jdet/.  The reference bakes scalar
+ * parameters (thresholds, conv geometry, BOX_LENGTH) into JIT source strings
+ * (ops/nms_rotated.py:498-503, ops/dcn_v1.py:314-338); here they are arguments.
+ */
+#ifndef RSDET_H_
+#define RSDET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSDET_OK 0
+#define RSDET_EINVAL (-22)  /* bad argument (shape, stride, null pointer, workspace too small) */
+#define RSDET_ELAUNCH (-5)  /* HIP reported a launch error */
+
+/* ABI version of this header (bumped on any signature change). */
+int rsdet_abi_version(void);
+
+/* ---- a1/a2  rotated IoU -------------------------------------------------------
+ * Replaces box_iou_rotated / box_iou_rotated_v1:
+ *   ops/box_iou_rotated.py:502-509 (jt.code call), kernel :413-461, CPU :487-500;
+ *   ops/box_iou_rotated_v1.py:507-524.
+ * boxes (n, stride>=5) rows = (cx, cy, w, h, theta[rad], ...); ious (n1, n2).
+ * version 0 / 1 selects the vertex convention (v1 = y-down angle, _v1.py:69-72).
+ * The v1 wrapper's "too small" post-filter (_v1.py:515-522) is host-side logic. */
+int rsdet_box_iou_rotated_f32(const float* boxes1, int n1, int stride1, const float* boxes2,
+                              int n2, int stride2, int version, float* ious, void* stream);
+
+/* Batched form used by the assigner (one launch for all images of a batch):
+ * rows [row_offsets[g], row_offsets[g+1]) of boxes1/ious belong to group g and
+ * are compared with boxes2 + g*group_stride2 (floats; 0 = one shared column set).
+ * row_offsets: n_groups+1 device ints; max_rows_per_group: host-known bound.
+ * Replaces the per-image loop models/boxes/anchor_target.py:60-72 ->
+ * assigner.py:94 -> iou_calculator.py:157-162. */
+int rsdet_box_iou_rotated_grouped_f32(const float* boxes1, int n1, int stride1,
+                                      const int* row_offsets, int n_groups,
+                                      int max_rows_per_group, const float* boxes2, int n2,
+                                      int stride2, long long group_stride2, int version,
+                                      float* ious, void* stream);
+
+/* ---- a16  rotated NMS -----------------------------------------------------------
+ * Replaces nms_rotated_cpu / nms_rotated_cuda: ops/nms_rotated.py:495-512
+ * (kernels :353-411 + host sweep :450-493, CPU loop :414-449).
+ * dets (n, box_len) with box_len 5, or 6 (6th column = class label: boxes of
+ * different labels never suppress each other, :283-286).  order (n) int32 =
+ * indices by descending score.  A box is suppressed when its IoU with an earlier
+ * kept box is >= thr (CPU-path predicate :444; ge=0 selects the CUDA-path `>` :403).
+ * keep (n) uint8, indexed like dets (jt.where(keep) gives ascending indices, :525).
+ * Workspace: rsdet_nms_rotated_ws_size(n) bytes, 16-byte aligned, device. */
+size_t rsdet_nms_rotated_ws_size(int n);
+int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, const int* order, float thr,
+                          int ge, uint8_t* keep, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a4  MaxIoUAssigner.assign_wrt_overlaps ---------------------------------------
+ * Replaces models/boxes/assigner.py:111-170 (incl. the per-gt Python loop :151-160)
+ * for a whole batch.  overlaps (n1, A) as produced by the grouped IoU; group g
+ * owns rows [row_offsets[g], row_offsets[g+1]).  Outputs per group g, each (A):
+ *   gt_inds[g*A + j]  -1 ignore / 0 negative / (row - row_offsets[g]) + 1
+ *   max_overlaps[g*A + j]
+ *   labels[g*A + j]   gt_labels[row] for positives else labels_filled (NULL gt_labels: skipped)
+ * Tie rule: first index of the maximum.  gt_max_assign_all semantics: every
+ * column whose IoU EQUALS the row maximum is given to that row, rows applied in
+ * ascending order (later rows overwrite).  A group with no rows gets gt_inds = 0
+ * (all negative) and max_overlaps = 0; the reference raises there
+ * (assigner.py:91-92) and the host-side mirror keeps that raise.
+ * Workspace: rsdet_assign_ws_size(n1) bytes. */
+size_t rsdet_assign_ws_size(int n1);
+int rsdet_assign_wrt_overlaps_f32(const float* overlaps, int n1, int A, const int* row_offsets,
+                                  int n_groups, int max_rows_per_group, float pos_iou_thr,
+                                  float neg_iou_lo, float neg_iou_hi, float min_pos_iou,
+                                  int match_low_quality, int gt_max_assign_all,
+                                  const int* gt_labels, int labels_filled, int* gt_inds,
+                                  float* max_overlaps, int* labels, void* ws, size_t ws_bytes,
+                                  void* stream);
+
+/* ---- a7/a9  DeltaXYWHA box coder -----------------------------------------------------
+ * Replaces bbox2delta_rotated / delta2bbox_rotated: models/boxes/box_ops.py:184-230,
+ * :233-289 (norm_angle 'le135' :176-182).  All arrays (n, 5).  means/stds: 5 HOST floats.
+ * max_ratio = |log(wh_ratio_clip)| (16/1000 default, 1e-6 in bbox_decode
+ * models/roi_heads/s2anet_head.py:631-654). */
+int rsdet_bbox2delta_rotated_f32(const float* proposals, const float* gt, int n,
+                                 const float* means_host, const float* stds_host, float* deltas,
+                                 void* stream);
+int rsdet_delta2bbox_rotated_f32(const float* rois, const float* deltas, int n,
+                                 const float* means_host, const float* stds_host,
+                                 float max_ratio, float* boxes, void* stream);
+
+/* ---- a9+a10  fused bbox_decode + AlignConv.get_offset ---------------------------------
+ * Replaces bbox_decode (s2anet_head.py:631-654) followed by AlignConv.get_offset
+ * (:676-713) and their per-image Python loops (:646-653, :717-720).
+ * bbox_pred (B,5,H,W) NCHW deltas; anchors (H*W,5); outputs
+ * refined (B,H,W,5) and offset (B, 2*ks*ks, H, W) ordered (y,x) per tap. */
+int rsdet_s2a_refine_and_offset_f32(const float* bbox_pred, const float* anchors, int B, int H,
+                                    int W, float stride_px, int ks, const float* means_host,
+                                    const float* stds_host, float max_ratio, float* refined,
+                                    float* offset, void* stream);
+
+/* ---- a12  Active Rotating Filter ---------------------------------------------------------
+ * Replaces arf_forward / arf_backward: ops/orn.py:260-280 (kernels :17-72, CPU :138-211).
+ * weight (O, I, nOri, kH, kW); indices (nOri*kH*kW, nRot) uint8, 1-based;
+ * out / grad_out (O*nRot, I*nOri, kH, kW); grad_weight like weight. */
+int rsdet_arf_forward_f32(const float* weight, const uint8_t* indices, int O, int I, int nOri,
+                          int kH, int kW, int nRot, float* out, void* stream);
+int rsdet_arf_backward_f32(const uint8_t* indices, const float* grad_out, int O, int I, int nOri,
+                           int kH, int kW, int nRot, float* grad_weight, void* stream);
+
+/* ---- a11  deformable convolution v1 (AlignConv) ---------------------------------------------
+ * Replaces deformable_im2col / deformable_col2im / deformable_col2im_coord:
+ * ops/dcn_v1.py:309-410 (kernels :132-306).  Geometry = the reference's argument list.
+ * im (B,C,H,W); offset (B, dg*2*kh*kw, Ho, Wo); col (C*kh*kw, B, Ho, Wo).
+ * col2im ACCUMULATES into grad_im with float atomics (zero it first, :405);
+ * col2im_coord writes grad_offset (B, dg*2*kh*kw, Ho, Wo). */
+typedef struct rsdet_dcn_geom {
+  int C, H, W;    /* input channels / height / width */
+  int kh, kw;     /* kernel */
+  int ph, pw;     /* padding */
+  int sh, sw;     /* stride */
+  int dh, dw;     /* dilation */
+  int B;          /* images in this call (the reference's parallel_imgs / im2col_step) */
+  int dg;         /* deformable groups */
+} rsdet_dcn_geom;
+int rsdet_deform_im2col_f32(const float* im, const float* offset, const rsdet_dcn_geom* g,
+                            float* col, void* stream);
+int rsdet_deform_col2im_f32(const float* col, const float* offset, const rsdet_dcn_geom* g,
+                            float* grad_im, void* stream);
+int rsdet_deform_col2im_coord_f32(const float* col, const float* im, const float* offset,
+                                  const rsdet_dcn_geom* g, float* grad_offset, void* stream);
+
+/* ---- a18  ROIAlignRotated_v1 -----------------------------------------------------------------
+ * Replaces _RotatedROIAlign_v1.execute / .grad: ops/roi_align_rotated_v1.py:300-351
+ * (kernels :71-147, :193-298).  feat (N,C,H,W); rois (R,6) = (batch, cx, cy, w, h, theta);
+ * out / grad_out (R,C,PH,PW).  backward ACCUMULATES into grad_feat (zero it first, :345). */
+int rsdet_rroi_align_v1_forward_f32(const float* feat, const float* rois, int R, int C, int H,
+                                    int W, int PH, int PW, float spatial_scale, int sample_num,
+                                    float* out, void* stream);
+int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const float* rois, int R, int C,
+                                     int H, int W, int PH, int PW, float spatial_scale,
+                                     int sample_num, float* grad_feat, void* stream);
+
+/* ---- a17  rotated_box_to_poly ------------------------------------------------------------------
+ * Replaces models/boxes/box_ops.py:633-654.  boxes (n,5) -> polys (n,8). */
+int rsdet_rotated_box_to_poly_f32(const float* boxes, int n, float* polys, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSDET_H_ */

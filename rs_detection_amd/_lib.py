@@ -1,0 +1,115 @@
+"""ctypes binding of librsdet_hip.so (the C ABI declared in include/rsdet.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+is absent, importing an op raises.  Nothing under oracle/ is ever imported here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsdet_hip.so")
+
+RSDET_OK = 0
+RSDET_EINVAL = -22
+RSDET_ELAUNCH = -5
+
+c_void_p, c_int, c_float, c_size_t, c_ll = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                            ctypes.c_size_t, ctypes.c_longlong)
+
+
+class DcnGeom(ctypes.Structure):
+    """struct rsdet_dcn_geom (include/rsdet.h)."""
+    _fields_ = [(n, c_int) for n in ("C", "H", "W", "kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw", "B", "dg")]
+
+
+# name -> (restype, argtypes); must list every symbol include/rsdet.h declares.
+SIGNATURES = {
+    "rsdet_abi_version": (c_int, []),
+    "rsdet_box_iou_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_box_iou_rotated_grouped_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                                  c_int, c_ll, c_int, c_void_p, c_void_p]),
+    "rsdet_nms_rotated_ws_size": (c_size_t, [c_int]),
+    "rsdet_nms_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    "rsdet_assign_ws_size": (c_size_t, [c_int]),
+    "rsdet_assign_wrt_overlaps_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_float,
+                                              c_float, c_float, c_int, c_int, c_void_p, c_int, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_bbox2delta_rotated_f32": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
+                                             ctypes.POINTER(c_float), c_void_p, c_void_p]),
+    "rsdet_delta2bbox_rotated_f32": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
+                                             ctypes.POINTER(c_float), c_float, c_void_p, c_void_p]),
+    "rsdet_s2a_refine_and_offset_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
+                                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float,
+                                                c_void_p, c_void_p, c_void_p]),
+    "rsdet_arf_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p]),
+    "rsdet_arf_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                       c_void_p]),
+    "rsdet_deform_im2col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),
+    "rsdet_deform_col2im_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),
+    "rsdet_deform_col2im_coord_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
+                                              c_void_p]),
+    "rsdet_rroi_align_v1_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_float, c_int, c_void_p, c_void_p]),
+    "rsdet_rroi_align_v1_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                 c_float, c_int, c_void_p, c_void_p]),
+    "rsdet_rotated_box_to_poly_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class RsdetError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly when it is missing (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RsdetError(
+            "librsdet_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C rs_detection_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != RSDET_OK:
+        kind = {RSDET_EINVAL: "invalid argument", RSDET_ELAUNCH: "HIP launch failure"}.get(rc, "error")
+        raise RsdetError("%s failed: %s (status %d)" % (what, kind, rc))
+
+
+def stream_ptr():
+    """Current torch HIP stream as void* (ops enqueue there; no hidden syncs)."""
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def host5(vals, default):
+    vals = tuple(vals) if vals is not None else (default,) * 5
+    assert len(vals) == 5
+    return (c_float * 5)(*[float(v) for v in vals])
+
+
+def require_cuda_f32(*tensors):
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RsdetError("rs_detection_amd ops run on the GPU only (got a %s tensor); no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise RsdetError("expected float32, got %s" % t.dtype)

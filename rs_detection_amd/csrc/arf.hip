@@ -1,0 +1,98 @@
+// arf.hip -- Active Rotating Filter forward / backward for gfx950.
+//
+// Replaces: arf_forward / arf_backward
+//   /root/reference/python/jdet/ops/orn.py:260-280; CUDA kernels :17-72 (the
+//   intended semantics -- the CPU kernels :138-211 index with uint16 and wrap
+//   past 65535 weights); ORConv2d.rotate_arf :680-681.
+//
+// Pure data movement (S2ANet: 73 728 weights -> 589 824): one thread per source
+// weight, index table (<= 9*8 bytes for 3x3) staged in LDS.  int64-safe indexing.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsdet_api_internal.h"
+
+namespace rsdet {
+
+constexpr int ARF_MAX_TABLE = 4096;  // nEntry * nRot bytes kept in LDS
+
+__global__ void arf_forward_kernel(const float* __restrict__ weight,
+                                   const uint8_t* __restrict__ indices, long long total, int I,
+                                   int nEntry, int nRot, float* __restrict__ out) {
+  __shared__ uint8_t s_idx[ARF_MAX_TABLE];
+  for (int t = threadIdx.x; t < nEntry * nRot; t += blockDim.x) s_idx[t] = indices[t];
+  __syncthreads();
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
+       n += (long long)gridDim.x * blockDim.x) {
+    int l = (int)(n % nEntry);
+    long long oc = n / nEntry;
+    int c = (int)(oc % I);
+    long long o = oc / I;
+    float v = weight[n];
+    for (int k = 0; k < nRot; ++k) {
+      int idx = (int)s_idx[l * nRot + k] - 1;
+      out[((o * nRot + k) * I + c) * nEntry + idx] = v;
+    }
+  }
+}
+
+__global__ void arf_backward_kernel(const uint8_t* __restrict__ indices,
+                                    const float* __restrict__ grad_out, long long total, int I,
+                                    int nEntry, int nRot, float* __restrict__ grad_w) {
+  __shared__ uint8_t s_idx[ARF_MAX_TABLE];
+  for (int t = threadIdx.x; t < nEntry * nRot; t += blockDim.x) s_idx[t] = indices[t];
+  __syncthreads();
+  for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < total;
+       n += (long long)gridDim.x * blockDim.x) {
+    int l = (int)(n % nEntry);
+    long long oc = n / nEntry;
+    int c = (int)(oc % I);
+    long long o = oc / I;
+    float acc = 0.f;
+    for (int k = 0; k < nRot; ++k) {  // ascending k, as orn.py:62-69
+      int idx = (int)s_idx[l * nRot + k] - 1;
+      acc = acc + grad_out[((o * nRot + k) * I + c) * nEntry + idx];
+    }
+    grad_w[n] = acc;
+  }
+}
+
+}  // namespace rsdet
+
+using namespace rsdet;
+
+static int arf_check(int O, int I, int nOri, int kH, int kW, int nRot) {
+  if (O < 0 || I < 0 || nOri < 1 || kH < 1 || kW < 1 || nRot < 1) return RSDET_EINVAL;
+  if ((long long)nOri * kH * kW > 255) return RSDET_EINVAL;  // uint8 1-based index table
+  if ((long long)nOri * kH * kW * nRot > ARF_MAX_TABLE) return RSDET_EINVAL;
+  return RSDET_OK;
+}
+
+extern "C" int rsdet_arf_forward_f32(const float* weight, const uint8_t* indices, int O, int I,
+                                     int nOri, int kH, int kW, int nRot, float* out, void* stream) {
+  int rc = arf_check(O, I, nOri, kH, kW, nRot);
+  if (rc) return rc;
+  const int nEntry = nOri * kH * kW;
+  long long total = (long long)O * I * nEntry;
+  if (total == 0) return RSDET_OK;
+  if (!weight || !indices || !out) return RSDET_EINVAL;
+  int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(arf_forward_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, weight,
+                     indices, total, I, nEntry, nRot, out);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_arf_backward_f32(const uint8_t* indices, const float* grad_out, int O, int I,
+                                      int nOri, int kH, int kW, int nRot, float* grad_weight,
+                                      void* stream) {
+  int rc = arf_check(O, I, nOri, kH, kW, nRot);
+  if (rc) return rc;
+  const int nEntry = nOri * kH * kW;
+  long long total = (long long)O * I * nEntry;
+  if (total == 0) return RSDET_OK;
+  if (!grad_out || !indices || !grad_weight) return RSDET_EINVAL;
+  int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(arf_backward_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, indices,
+                     grad_out, total, I, nEntry, nRot, grad_weight);
+  return rsdet_launch_status();
+}

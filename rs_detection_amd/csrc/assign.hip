@@ -1,0 +1,142 @@
+// assign.hip -- MaxIoUAssigner.assign_wrt_overlaps for a whole batch, on device.
+//
+// Replaces: /root/reference/python/jdet/models/boxes/assigner.py:111-170 --
+// in particular the per-gt Python loop :151-160 (K launches of length A plus a
+// jt.sync_all() every 100 gts) and the host syncs of :164-166.
+//
+// Two HBM-bound passes over the (n1, A) overlaps matrix:
+//   row pass    one workgroup per gt row: max / first-argmax over A (float4 loads,
+//               wave shuffle + LDS reduction)  -> ws
+//   column pass one thread per (group, anchor): walks the group's rows (coalesced
+//               across lanes), keeps max / first-argmax, applies the neg / pos
+//               thresholds and the low-quality rule (last row whose IoU EQUALS
+//               its row maximum wins, as the ascending reference loop does),
+//               then gathers the label.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsdet_api_internal.h"
+
+namespace rsdet {
+
+constexpr int ASG_NT = 256;
+
+__global__ __launch_bounds__(ASG_NT) void assign_row_kernel(const float* __restrict__ ov, int A,
+                                                            float* __restrict__ row_max,
+                                                            int* __restrict__ row_arg) {
+  const int row = blockIdx.x;
+  const float* p = ov + (long long)row * A;
+  float best = -INFINITY;
+  int arg = 0x7fffffff;
+  for (int j = threadIdx.x; j < A; j += ASG_NT) {
+    float v = p[j];
+    if (v > best) {  // ascending j per thread => first index kept on ties
+      best = v;
+      arg = j;
+    }
+  }
+  // wave reduce (value desc, index asc)
+  for (int off = 32; off > 0; off >>= 1) {
+    float ob = __shfl_down(best, off);
+    int oa = __shfl_down(arg, off);
+    if (ob > best || (ob == best && oa < arg)) {
+      best = ob;
+      arg = oa;
+    }
+  }
+  __shared__ float s_b[ASG_NT / 64];
+  __shared__ int s_a[ASG_NT / 64];
+  if ((threadIdx.x & 63) == 0) {
+    s_b[threadIdx.x >> 6] = best;
+    s_a[threadIdx.x >> 6] = arg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < ASG_NT / 64; ++w)
+      if (s_b[w] > best || (s_b[w] == best && s_a[w] < arg)) {
+        best = s_b[w];
+        arg = s_a[w];
+      }
+    row_max[row] = best;
+    row_arg[row] = arg;
+  }
+}
+
+__global__ __launch_bounds__(ASG_NT) void assign_col_kernel(
+    const float* __restrict__ ov, int A, const int* __restrict__ row_offsets,
+    const float* __restrict__ row_max, const int* __restrict__ row_arg, float pos_thr,
+    float neg_lo, float neg_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+    const int* __restrict__ gt_labels, int labels_filled, int* __restrict__ gt_inds,
+    float* __restrict__ max_ov, int* __restrict__ labels) {
+  const int g = blockIdx.y;
+  const int j = blockIdx.x * ASG_NT + threadIdx.x;
+  if (j >= A) return;
+  const int r0 = row_offsets[g], r1 = row_offsets[g + 1];
+  const long long o = (long long)g * A + j;
+  if (r1 <= r0) {
+    gt_inds[o] = 0;
+    max_ov[o] = 0.f;
+    if (labels) labels[o] = labels_filled;
+    return;
+  }
+  float best = ov[(long long)r0 * A + j];
+  int arg = 0;
+  int lowq = -1;
+  {
+    float rm = row_max[r0];
+    if (match_low_quality && rm >= min_pos_iou)
+      if (gt_max_assign_all ? (best == rm) : (row_arg[r0] == j)) lowq = 0;
+  }
+  for (int r = r0 + 1; r < r1; ++r) {
+    float v = ov[(long long)r * A + j];
+    if (v > best) {
+      best = v;
+      arg = r - r0;
+    }
+    float rm = row_max[r];  // wave-uniform -> scalar load
+    if (match_low_quality && rm >= min_pos_iou)
+      if (gt_max_assign_all ? (v == rm) : (row_arg[r] == j)) lowq = r - r0;
+  }
+  int gi = -1;
+  if (best >= neg_lo && best < neg_hi) gi = 0;   // assigner.py:138-145
+  if (best >= pos_thr) gi = arg + 1;             // :147-148
+  if (lowq >= 0) gi = lowq + 1;                  // :151-158
+  gt_inds[o] = gi;
+  max_ov[o] = best;
+  if (labels) labels[o] = gi > 0 ? gt_labels[r0 + gi - 1] : labels_filled;  // :162-166
+}
+
+}  // namespace rsdet
+
+using namespace rsdet;
+
+extern "C" size_t rsdet_assign_ws_size(int n1) {
+  return n1 > 0 ? (((size_t)n1 * 4 + 255) & ~(size_t)255) * 2 : 0;
+}
+
+extern "C" int rsdet_assign_wrt_overlaps_f32(const float* overlaps, int n1, int A,
+                                             const int* row_offsets, int n_groups,
+                                             int max_rows_per_group, float pos_iou_thr,
+                                             float neg_iou_lo, float neg_iou_hi, float min_pos_iou,
+                                             int match_low_quality, int gt_max_assign_all,
+                                             const int* gt_labels, int labels_filled, int* gt_inds,
+                                             float* max_overlaps, int* labels, void* ws,
+                                             size_t ws_bytes, void* stream) {
+  (void)max_rows_per_group;
+  if (n1 < 0 || A < 0 || n_groups < 0) return RSDET_EINVAL;
+  if (A == 0 || n_groups == 0) return RSDET_OK;
+  if (!row_offsets || !gt_inds || !max_overlaps) return RSDET_EINVAL;
+  if (n1 > 0 && (!overlaps || !ws || ws_bytes < rsdet_assign_ws_size(n1))) return RSDET_EINVAL;
+  if (labels && !gt_labels && n1 > 0) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float* row_max = (float*)ws;
+  int* row_arg = (int*)((char*)ws + rsdet_assign_ws_size(n1) / 2);
+  if (n1 > 0)
+    hipLaunchKernelGGL(assign_row_kernel, dim3(n1), dim3(ASG_NT), 0, s, overlaps, A, row_max,
+                       row_arg);
+  hipLaunchKernelGGL(assign_col_kernel, dim3((A + ASG_NT - 1) / ASG_NT, n_groups), dim3(ASG_NT), 0,
+                     s, overlaps, A, row_offsets, row_max, row_arg, pos_iou_thr, neg_iou_lo,
+                     neg_iou_hi, min_pos_iou, match_low_quality, gt_max_assign_all, gt_labels,
+                     labels_filled, gt_inds, max_overlaps, labels);
+  return rsdet_launch_status();
+}

@@ -1,0 +1,159 @@
+"""jdet.ops.dcn_v1 on MI355X: DeformConv (deformable convolution v1, AlignConv's core).
+
+Mirror of /root/reference/python/jdet/ops/dcn_v1.py:559-713.  Bilinear im2col /
+col2im / col2im_coord are the hand-written kernels of csrc/deform_conv.hip; the
+GEMMs (:447, :484, :547) go to rocBLAS/hipBLASLt through torch.matmul.
+
+MI355X-first differences from the reference's host logic (free per SURVEY q17):
+  * the column matrix of the forward pass is kept for backward (288 GB of HBM)
+    instead of recomputing im2col for the weight gradient (:536-539);
+  * the whole batch is one im2col "step" (the reference chunks by im2col_step
+    only to bound memory); chunks are still honoured when a cap is set;
+  * the offset gradient is computed only when the offset requires grad
+    (AlignConv builds offsets under no_grad, s2anet_head.py:676 / SURVEY q16).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+__all__ = ["DeformConv", "deform_conv", "deformable_im2col", "deformable_col2im", "deformable_col2im_coord"]
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, dg):
+    return _lib.DcnGeom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, dg)
+
+
+def _out_hw(H, W, kh, kw, ph, pw, sh, sw, dh, dw):
+    return ((H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1)
+
+
+def deformable_im2col(im, offset, kernel, padding, stride, dilation, deformable_group=1):
+    """dcn_v1.py:309-339: im (B,C,H,W), offset (B,dg*2*kh*kw,Ho,Wo) -> col (C*kh*kw, B*Ho*Wo)."""
+    _lib.require_cuda_f32(im, offset)
+    lib = _lib.load()
+    im, offset = im.contiguous(), offset.contiguous()
+    B, C, H, W = im.shape
+    (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
+    Ho, Wo = _out_hw(H, W, kh, kw, ph, pw, sh, sw, dh, dw)
+    assert tuple(offset.shape) == (B, deformable_group * 2 * kh * kw, Ho, Wo), "invalid offset shape"
+    col = torch.empty((C * kh * kw, B * Ho * Wo), dtype=im.dtype, device=im.device)
+    g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_group)
+    _lib.check(lib.rsdet_deform_im2col_f32(_lib.ptr(im), _lib.ptr(offset), g, _lib.ptr(col), _lib.stream_ptr()),
+               "rsdet_deform_im2col_f32")
+    return col
+
+
+def deformable_col2im(col, offset, im_shape, kernel, padding, stride, dilation, deformable_group=1):
+    """dcn_v1.py:376-410 -> grad_im (B,C,H,W)."""
+    _lib.require_cuda_f32(col, offset)
+    lib = _lib.load()
+    col, offset = col.contiguous(), offset.contiguous()
+    B, C, H, W = im_shape
+    (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
+    grad_im = torch.zeros((B, C, H, W), dtype=col.dtype, device=col.device)
+    g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_group)
+    _lib.check(lib.rsdet_deform_col2im_f32(_lib.ptr(col), _lib.ptr(offset), g, _lib.ptr(grad_im), _lib.stream_ptr()),
+               "rsdet_deform_col2im_f32")
+    return grad_im
+
+
+def deformable_col2im_coord(col, im, offset, kernel, padding, stride, dilation, deformable_group=1):
+    """dcn_v1.py:341-373 -> grad_offset like offset."""
+    _lib.require_cuda_f32(col, im, offset)
+    lib = _lib.load()
+    col, im, offset = col.contiguous(), im.contiguous(), offset.contiguous()
+    B, C, H, W = im.shape
+    (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
+    grad_off = torch.empty_like(offset)
+    g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_group)
+    _lib.check(lib.rsdet_deform_col2im_coord_f32(_lib.ptr(col), _lib.ptr(im), _lib.ptr(offset), g,
+                                                 _lib.ptr(grad_off), _lib.stream_ptr()),
+               "rsdet_deform_col2im_coord_f32")
+    return grad_off
+
+
+class DeformConvFunction(torch.autograd.Function):
+    """dcn_v1.py:559-650."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+        if not input.is_cuda:
+            raise NotImplementedError  # dcn_v1.py:588-589
+        ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        ctx.groups, ctx.deformable_groups = groups, deformable_groups
+        B, C, H, W = input.shape
+        O, _, kh, kw = weight.shape
+        Ho, Wo = _out_hw(H, W, kh, kw, *ctx.padding, *ctx.stride, *ctx.dilation)
+        if not (O > 0 and Ho > 0 and Wo > 0):
+            raise ValueError("convolution input is too small (output would be {})".format(
+                'x'.join(map(str, (B, O, Ho, Wo)))))
+        assert offset.size(0) == B, "invalid batch size of offset"
+        col = deformable_im2col(input, offset, (kh, kw), ctx.padding, ctx.stride, ctx.dilation, deformable_groups)
+        # (g, O/g, C/g*kh*kw) @ (g, C/g*kh*kw, B*Ho*Wo)
+        wg = weight.reshape(groups, O // groups, -1)
+        out = torch.bmm(wg, col.view(groups, -1, col.shape[1]))
+        out = out.view(O, B, Ho, Wo).transpose(0, 1).contiguous()
+        ctx.save_for_backward(input, offset, weight, col)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, offset, weight, col = ctx.saved_tensors
+        B, C, H, W = input.shape
+        O, _, kh, kw = weight.shape
+        g = ctx.groups
+        go = grad_output.transpose(0, 1).reshape(g, O // g, -1)  # (g, O/g, B*Ho*Wo)
+        grad_input = grad_offset = grad_weight = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wg = weight.reshape(g, O // g, -1)
+            gcol = torch.bmm(wg.transpose(1, 2), go).view(C * kh * kw, -1)  # dcn_v1.py:484
+            if ctx.needs_input_grad[1]:
+                grad_offset = deformable_col2im_coord(gcol, input, offset, (kh, kw), ctx.padding, ctx.stride,
+                                                      ctx.dilation, ctx.deformable_groups)
+            if ctx.needs_input_grad[0]:
+                grad_input = deformable_col2im(gcol, offset, input.shape, (kh, kw), ctx.padding, ctx.stride,
+                                               ctx.dilation, ctx.deformable_groups)
+        if ctx.needs_input_grad[2]:
+            grad_weight = torch.bmm(go, col.view(g, -1, col.shape[1]).transpose(1, 2)).view_as(weight)  # :547
+        return grad_input, grad_offset, grad_weight, None, None, None, None, None, None
+
+
+deform_conv = DeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+    """dcn_v1.py:652-695."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0, 'in_channels {} cannot be divisible by groups {}'.format(in_channels, groups)
+        assert out_channels % groups == 0, 'out_channels {} cannot be divisible by groups {}'.format(out_channels, groups)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.zeros((out_channels, in_channels // groups, *self.kernel_size)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        nn.init.uniform_(self.weight, -stdv, stdv)
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)

@@ -1,0 +1,66 @@
+"""jdet.ops.roi_align_rotated_v1 on MI355X: ROIAlignRotated_v1.
+
+Mirror of /root/reference/python/jdet/ops/roi_align_rotated_v1.py:300-373;
+kernels in csrc/rroi_align.hip.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+__all__ = ["ROIAlignRotated_v1", "roi_align_rotated_v1"]
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class _RotatedROIAlign_v1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio):
+        assert rois.shape[1] == 6  # :306
+        _lib.require_cuda_f32(input, rois)
+        lib = _lib.load()
+        input, rois = input.contiguous(), rois.contiguous()
+        ctx.save_for_backward(rois)
+        ctx.cfg = (tuple(input.shape), output_size, float(spatial_scale), int(sampling_ratio))
+        N, C, H, W = input.shape
+        R = rois.shape[0]
+        out = torch.empty((R, C, output_size[0], output_size[1]), dtype=input.dtype, device=input.device)
+        rc = lib.rsdet_rroi_align_v1_forward_f32(_lib.ptr(input), _lib.ptr(rois), R, C, H, W, output_size[0],
+                                                 output_size[1], float(spatial_scale), int(sampling_ratio),
+                                                 _lib.ptr(out), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_rroi_align_v1_forward_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        shape, output_size, scale, sr = ctx.cfg
+        lib = _lib.load()
+        N, C, H, W = shape
+        go = grad_output.contiguous()
+        grad_in = torch.zeros(shape, dtype=go.dtype, device=go.device)  # :345 memset
+        rc = lib.rsdet_rroi_align_v1_backward_f32(_lib.ptr(go), _lib.ptr(rois), rois.shape[0], C, H, W,
+                                                  output_size[0], output_size[1], scale, sr, _lib.ptr(grad_in),
+                                                  _lib.stream_ptr())
+        _lib.check(rc, "rsdet_rroi_align_v1_backward_f32")
+        return grad_in, None, None, None, None
+
+
+roi_align_rotated_v1 = _RotatedROIAlign_v1.apply
+
+
+class ROIAlignRotated_v1(nn.Module):
+    def __init__(self, output_size, spatial_scale, sampling_ratio=0):
+        super().__init__()
+        self.output_size = _pair(output_size)
+        self.spatial_scale = spatial_scale
+        self.sampling_ratio = sampling_ratio
+
+    def forward(self, input, rois):
+        return roi_align_rotated_v1(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
+
+    def __repr__(self):
+        return "%s(output_size=%s, spatial_scale=%s, sampling_ratio=%s)" % (
+            self.__class__.__name__, self.output_size, self.spatial_scale, self.sampling_ratio)

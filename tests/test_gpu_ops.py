@@ -1,0 +1,214 @@
+"""GPU parity: ARF, deformable conv pieces, ROIAlignRotated_v1, box coder, fused refine+offset."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import dota_boxes
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ---------------------------------------------------------------- ARF (a12)
+@pytest.mark.parametrize("O,I,nOri,nRot,k", [(4, 3, 1, 8, 3), (32, 256, 1, 8, 3), (5, 2, 4, 8, 3), (6, 7, 8, 4, 1)])
+def test_arf_forward_backward_exact(cuda, oracle_c, O, I, nOri, nRot, k):
+    from rs_detection_amd.ops import arf_forward, arf_backward
+    from rs_detection_amd.ops.orn import arf_indices
+    rng = np.random.default_rng(O + I)
+    idx = arf_indices(nOri, nRot, (k, k)).numpy()
+    w = rng.standard_normal((O, I, nOri, k, k)).astype(np.float32)
+    out = arf_forward(_t(w, cuda), _t(idx, cuda)).cpu().numpy()
+    assert (out == oracle_c.arf_forward(w, idx)).all()  # pure copy: exact
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    gw = arf_backward(_t(idx, cuda), _t(go, cuda)).cpu().numpy()
+    assert (gw == oracle_c.arf_backward(idx, go)).all()  # same summation order: exact
+
+
+def test_orconv2d_autograd(cuda):
+    from rs_detection_amd.ops import ORConv2d
+    torch.manual_seed(0)
+    m = ORConv2d(16, 4, kernel_size=3, padding=1, arf_config=(1, 8)).to(cuda)
+    x = torch.randn(2, 16, 9, 9, device=cuda, requires_grad=True)
+    y = m(x)
+    assert y.shape == (2, 32, 9, 9)
+    y.square().sum().backward()
+    # gradient of the ARF expansion == transpose of a gather: check against autograd on an index_select twin
+    idx = m.indices.long() - 1  # (1,3,3,8)
+    w = m.weight.detach().clone().requires_grad_(True)
+    O, I = w.shape[:2]
+    wf = w.view(O, I, 9)
+    inv = torch.empty(8, 9, dtype=torch.long, device=cuda)
+    for k in range(8):
+        inv[k, idx.view(9, 8)[:, k]] = torch.arange(9, device=cuda)
+    rot = torch.stack([wf[:, :, inv[k]] for k in range(8)], 1).reshape(O * 8, I, 3, 3)
+    y2 = torch.nn.functional.conv2d(x.detach(), rot, m.bias, 1, 1)
+    torch.testing.assert_close(y2, y.detach(), atol=1e-5, rtol=1e-5)
+    y2.square().sum().backward()
+    torch.testing.assert_close(w.grad, m.weight.grad, atol=1e-3, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- deformable conv (a11)
+GEOMS = [
+    dict(B=2, C=4, H=6, W=5, kh=3, kw=3, ph=1, pw=1, sh=1, sw=1, dh=1, dw=1, dg=1),
+    dict(B=1, C=6, H=9, W=11, kh=3, kw=3, ph=1, pw=1, sh=2, sw=2, dh=1, dw=1, dg=2),
+    dict(B=3, C=8, H=16, W=16, kh=3, kw=3, ph=2, pw=2, sh=1, sw=1, dh=2, dw=2, dg=1),
+    dict(B=2, C=32, H=32, W=32, kh=3, kw=3, ph=1, pw=1, sh=1, sw=1, dh=1, dw=1, dg=1),
+]
+
+
+def _dcn_inputs(g, seed):
+    rng = np.random.default_rng(seed)
+    Ho, Wo = oracle._COracle.out_hw(g["H"], g["W"], *[g[k] for k in ("kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw")])
+    im = rng.standard_normal((g["B"], g["C"], g["H"], g["W"])).astype(np.float32)
+    off = (rng.standard_normal((g["B"], g["dg"] * 2 * g["kh"] * g["kw"], Ho, Wo)) * 2.5).astype(np.float32)
+    return im, off, Ho, Wo
+
+
+@pytest.mark.parametrize("gi", range(len(GEOMS)))
+def test_deform_im2col_col2im_coord(cuda, oracle_c, gi):
+    from rs_detection_amd.ops import deformable_im2col, deformable_col2im, deformable_col2im_coord
+    g = GEOMS[gi]
+    im, off, Ho, Wo = _dcn_inputs(g, gi)
+    k, p, s, d = (g["kh"], g["kw"]), (g["ph"], g["pw"]), (g["sh"], g["sw"]), (g["dh"], g["dw"])
+    col = deformable_im2col(_t(im, cuda), _t(off, cuda), k, p, s, d, g["dg"]).cpu().numpy()
+    want = oracle_c.deform_im2col(im, off, g, g["dg"]).reshape(col.shape)
+    assert np.abs(col - want).max() <= TOL
+    rng = np.random.default_rng(99 + gi)
+    gcol = rng.standard_normal(col.shape).astype(np.float32)
+    gim = deformable_col2im(_t(gcol, cuda), _t(off, cuda), im.shape, k, p, s, d, g["dg"]).cpu().numpy()
+    want = oracle_c.deform_col2im(gcol, off, im.shape, g, g["dg"])
+    assert np.abs(gim - want).max() <= 1e-4 * max(1.0, np.abs(want).max())  # atomics: order differs
+    goff = deformable_col2im_coord(_t(gcol, cuda), _t(im, cuda), _t(off, cuda), k, p, s, d, g["dg"]).cpu().numpy()
+    want = oracle_c.deform_col2im_coord(gcol, im, off, g, g["dg"])
+    assert np.abs(goff - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_deform_conv_zero_offset_is_conv2d(cuda):
+    """Independent pin: with zero offsets DeformConv must equal a plain convolution (fwd + grads)."""
+    from rs_detection_amd.ops import DeformConv
+    torch.manual_seed(1)
+    m = DeformConv(16, 24, 3, padding=1).to(cuda)
+    x = torch.randn(2, 16, 20, 17, device=cuda, requires_grad=True)
+    off = torch.zeros(2, 18, 20, 17, device=cuda)
+    y = m(x, off)
+    x2 = x.detach().clone().requires_grad_(True)
+    w2 = m.weight.detach().clone().requires_grad_(True)
+    y2 = torch.nn.functional.conv2d(x2, w2, None, 1, 1)
+    torch.testing.assert_close(y, y2, atol=1e-4, rtol=1e-4)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    y2.backward(gy)
+    torch.testing.assert_close(x.grad, x2.grad, atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(m.weight.grad, w2.grad, atol=1e-3, rtol=1e-4)
+
+
+def test_deform_conv_offset_grad_finite_difference(cuda):
+    from rs_detection_amd.ops import deform_conv
+    torch.manual_seed(2)
+    x = torch.randn(1, 4, 7, 7, device=cuda)
+    w = torch.randn(3, 4, 3, 3, device=cuda)
+    off = (torch.rand(1, 18, 7, 7, device=cuda) * 0.6 + 0.2).requires_grad_(True)  # stay inside one cell
+    y = deform_conv(x, off, w, 1, 1, 1, 1, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    eps = 1e-2
+    for idx in [(0, 0, 3, 3), (0, 7, 2, 5), (0, 17, 6, 6)]:
+        o2 = off.detach().clone()
+        o2[idx] += eps
+        o3 = off.detach().clone()
+        o3[idx] -= eps
+        fd = ((deform_conv(x, o2, w, 1, 1, 1, 1, 1) - deform_conv(x, o3, w, 1, 1, 1, 1, 1)) * gy).sum() / (2 * eps)
+        assert abs(float(fd) - float(off.grad[idx])) <= 2e-2 * max(1.0, abs(float(fd)))
+
+
+# ---------------------------------------------------------------- RROIAlign (a18)
+def _rois(rng, R, N, span):
+    b = dota_boxes(rng, R, span, 8, 120, 60)
+    return np.concatenate([rng.integers(0, N, (R, 1)).astype(np.float32), b], 1)
+
+
+@pytest.mark.parametrize("N,C,H,W,R,scale,sr", [(2, 3, 16, 20, 5, 0.25, 2), (1, 8, 32, 32, 17, 0.125, 2),
+                                                 (2, 4, 24, 24, 6, 0.25, 0), (2, 16, 64, 64, 40, 1 / 16., 2)])
+def test_rroi_align_forward_backward(cuda, oracle_c, N, C, H, W, R, scale, sr):
+    from rs_detection_amd.ops import roi_align_rotated_v1
+    rng = np.random.default_rng(R)
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = _rois(rng, R, N, W / scale)
+    rois[0, 1:3] = [-30, -30]  # partially outside
+    rois[1, 3:5] = [0.5, 0.5]  # malformed -> forced to 1x1 (:101-102)
+    ft = _t(feat, cuda).requires_grad_(True)
+    out = roi_align_rotated_v1(ft, _t(rois, cuda), (7, 7), scale, sr)
+    want = oracle_c.rroi_align_v1_forward(feat, rois, (7, 7), scale, sr)
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= TOL
+    go = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(_t(go, cuda))
+    wantg = oracle_c.rroi_align_v1_backward(go, rois, feat.shape, scale, sr)
+    assert np.abs(ft.grad.cpu().numpy() - wantg).max() <= 1e-4 * max(1.0, np.abs(wantg).max())
+
+
+def test_rroi_align_grad_sum_property(cuda):
+    """Reference's own smoke property: inside RoIs, sum(grad) = R*C*49 for ones."""
+    from rs_detection_amd.ops import ROIAlignRotated_v1
+    feat = torch.randn(2, 3, 64, 64, device=cuda, requires_grad=True)
+    rois = torch.tensor([[0, 300, 400, 200, 100, 0.3], [1, 500, 500, 150, 80, -0.7]], device=cuda)
+    out = ROIAlignRotated_v1((7, 7), 1 / 16., 2)(feat, rois)
+    out.sum().backward()
+    assert abs(float(feat.grad.sum()) - 2 * 3 * 49) < 1e-2
+
+
+# ---------------------------------------------------------------- coder / offsets (a7, a9, a10, a17)
+def test_box_coder_roundtrip_and_oracle(cuda):
+    from rs_detection_amd import ops
+    rng = np.random.default_rng(0)
+    prop, gt = dota_boxes(rng, 5000), dota_boxes(rng, 5000)
+    stds = (0.1, 0.1, 0.2, 0.2, 0.1)
+    want = oracle.np_bbox2delta_rotated(prop, gt, (0,) * 5, stds)
+    got = ops.bbox2delta_rotated(_t(prop, cuda), _t(gt, cuda), (0,) * 5, stds)
+    # targets reach |1e3| (far-apart random pairs / std 0.1): 1e-4 relative to max(1,|x|)
+    assert np.abs((got.cpu().numpy() - want) / np.maximum(np.abs(want), 1)).max() <= TOL
+    back = ops.delta2bbox_rotated(_t(prop, cuda), got, (0,) * 5, stds, wh_ratio_clip=1e-6).cpu().numpy()
+    wantb = oracle.np_delta2bbox_rotated(prop, want, (0,) * 5, stds, 1e-6)
+    assert np.abs(back - wantb).max() <= 2e-3  # coordinates up to 1024 px in fp32
+    # decode(encode(gt)) == gt up to angle normalisation
+    assert np.abs(back[:, :4] - gt[:, :4]).max() <= 2e-2
+    d = rng.standard_normal((5000, 5)).astype(np.float32) * 0.3
+    got = ops.delta2bbox_rotated(_t(prop, cuda), _t(d, cuda)).cpu().numpy()
+    want = oracle.np_delta2bbox_rotated(prop, d)
+    assert np.abs(got - want).max() <= 1e-3 and np.abs((got - want) / np.maximum(np.abs(want), 1)).max() <= TOL
+
+
+@pytest.mark.parametrize("H,W,stride", [(8, 8, 128), (16, 12, 64), (128, 128, 8)])
+def test_refine_and_offset_vs_oracle(cuda, H, W, stride):
+    from rs_detection_amd import ops
+    rng = np.random.default_rng(H)
+    B = 2
+    anchors = oracle.np_s2anet_grid_anchors((H, W), stride)
+    pred = (rng.standard_normal((B, 5, H, W)) * 0.2).astype(np.float32)
+    refined, offset = ops.s2a_refine_and_offset(_t(pred, cuda), _t(anchors, cuda), stride)
+    for b in range(B):
+        d = pred[b].transpose(1, 2, 0).reshape(-1, 5)
+        want_r = oracle.np_delta2bbox_rotated(anchors, d, wh_ratio_clip=1e-6)
+        got_r = refined[b].cpu().numpy().reshape(-1, 5)
+        assert np.abs((got_r - want_r) / np.maximum(np.abs(want_r), 1)).max() <= TOL
+        want_o = oracle.np_align_conv_offset(want_r, (H, W), stride)
+        assert np.abs(offset[b].cpu().numpy() - want_o).max() <= 1e-3
+
+
+def test_rotated_box_to_poly(cuda):
+    from rs_detection_amd import ops
+    b = dota_boxes(np.random.default_rng(4), 1000)
+    got = ops.rotated_box_to_poly(_t(b, cuda)).cpu().numpy()
+    assert np.abs(got - oracle.np_rotated_box_to_poly(b)).max() <= 1e-3
+    assert ops.rotated_box_to_poly(torch.zeros((0, 5), device=cuda)).shape == (0, 8)
+
+
+def test_ops_refuse_cpu_tensors(cuda):
+    """No CPU fallback anywhere in the product path."""
+    from rs_detection_amd import ops, _lib
+    with pytest.raises(_lib.RsdetError):
+        ops.box_iou_rotated(torch.zeros(2, 5), torch.zeros(2, 5))
