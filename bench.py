@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- S2ANet-R50-FPN training throughput (1024x1024 tiles/s) on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
+  Prints ONE JSON line from rank 0.
+
+A "step" = one full training step of BASELINE.json configs[1]: S2ANet-R50-FPN, 4 synthetic
+1024x1024 DOTA-shaped tiles per GPU, fp32: backbone+FPN (MIOpen), S2ANetHead with the
+hand-written HIP hot path (fused refine+offset, deformable im2col/col2im, ARF, batched rotated
+IoU + MaxIoU assignment), focal/smooth-L1 losses, backward, RCCL gradient all-reduce (DDP),
+grad-clip 35, SGD update.  Inputs (tiles and targets) are resident in HBM before the timed
+region.  Weak scaling: 4 tiles per GPU at every N.
+
+Extra objects on the same JSON line:
+  roofline      dominant hand-written kernel of the north-star metric (batched rotated IoU at
+                the step's own shape), HIP-event timed in this process
+  kernels       the same measurement for every other hand-written kernel on the path
+  cpu_baseline  the reference's own CPU rotated-IoU source (oracle/_ref, kind "reference";
+                falls back to the oracle restatement, kind "port") on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive conv search on a fresh box
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+TILE = 1024
+BATCH_PER_GPU = 4
+
+
+def s2anet_cfg():
+    """configs/s2anet/s2anet_r50_fpn_1x_dota.py of the reference, model + optimiser part
+    (kept in-repo as data so the GPU box needs no /root/reference)."""
+    from rs_detection_amd.config import Config
+    return Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
+
+
+def event_time(fn, iters, warmup=3):
+    """Average device time of fn() in seconds, HIP events on torch's current stream
+    (the stream every rsdet_* launch goes to)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / iters
+
+
+def kernel_rooflines(device, targets):
+    """HIP-event timing of each hand-written kernel at the shapes of this very step."""
+    from rs_detection_amd import ops
+    from rs_detection_amd.utils import synthetic as syn
+    out = {}
+    anchors = torch.from_numpy(syn.s2anet_anchor_grid()).to(device)
+    A = anchors.shape[0]
+    ks = [int(t["rboxes"].shape[0]) for t in targets]
+    gt = torch.cat([t["rboxes"] for t in targets]).to(device)
+    lab = torch.cat([t["labels"] for t in targets]).to(device).int()
+    ro = torch.tensor(np.concatenate([[0], np.cumsum(ks)]), dtype=torch.int32, device=device)
+    n1 = sum(ks)
+    ov = torch.empty((n1, A), device=device)
+
+    # -- batched rotated IoU (a1): bytes = 20*(N1+N2) + 4*N1*N2
+    t = event_time(lambda: ops.box_iou_rotated_grouped(gt, ro, max(ks), anchors, out=ov), 50)
+    by = 20 * (n1 + A) + 4 * n1 * A
+    out["box_iou_rotated_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6,
+                                         mpairs_per_s=n1 * A / t / 1e6, shape="sumK=%d x A=%d (B=%d)" % (n1, A, len(ks)))
+    # -- assignment (a4): two passes over the matrix + outputs
+    t = event_time(lambda: ops.assign_wrt_overlaps(ov, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0), 50)
+    by = 2 * 4 * n1 * A + 12 * len(ks) * A
+    out["assign_row+col_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+    # -- deformable im2col / col2im at pyramid level 0 (a11): bytes = 4*(C*HW*B + 18*HW*B + 9*C*HW*B)
+    B, C, H = len(ks), 256, TILE // 8
+    x = torch.randn(B, C, H, H, device=device)
+    off = torch.randn(B, 18, H, H, device=device)
+    t = event_time(lambda: ops.deformable_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
+    by = 4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B)
+    out["deform_im2col_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                       frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+    col = ops.deformable_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1))
+    t = event_time(lambda: ops.deformable_col2im(col, off, x.shape, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
+    out["deform_col2im_kernel"] = dict(bound="hbm(atomics)", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                       frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+    del col, x, off
+    # -- rotated NMS (a16), SURVEY 8d micro-bench shape M=5344, 6 columns, thr 0.1
+    d, s, l = syn.nms_cluster_boxes(5344)
+    d6 = torch.from_numpy(np.concatenate([d, l[:, None].astype(np.float32)], 1)).to(device)
+    order = torch.argsort(torch.from_numpy(s).to(device), descending=True, stable=True).int()
+    t = event_time(lambda: ops.nms_rotated_keep_mask(d6, order, 0.1, 6), 10, 2)
+    M = 5344
+    by = 4 * 6 * M + 2 * 8 * M * ((M + 63) // 64) + M
+    out["nms_rotated(3 kernels)"] = dict(bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6,
+                                         mboxes_per_s=M / t / 1e6)
+    return out
+
+
+def cpu_baseline(budget_s=12.0):
+    """Reference CPU rotated IoU (single thread, as box_iou_rotated.py:495-499) on a bounded sample."""
+    import oracle
+    from rs_detection_amd.utils import synthetic as syn
+    ref = oracle.ref()
+    kind, impl = ("reference", ref) if ref.available else ("port", oracle.c())
+    anchors = syn.s2anet_anchor_grid()
+    gts = syn.dota_gt_boxes(np.random.default_rng(1234), 100)
+    pairs, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        impl.box_iou_rotated(gts, anchors, 0)
+        pairs += gts.shape[0] * anchors.shape[0]
+    dt = time.perf_counter() - t0
+    return dict(value=pairs / dt / 1e6, unit="Mpairs/s (rotated IoU; the reference has no CPU path for the full "
+                "S2ANet step: DeformConv is CUDA-only, dcn_v1.py:588-589)", cores=1, kind=kind,
+                sample="K=100 gt x A=21824 S2ANet anchors, repeated for %.0f s (%d calls)" % (dt, pairs // (100 * 21824)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    args = ap.parse_args()
+
+    from rs_detection_amd.utils import dist as rdist
+    from rs_detection_amd.utils import synthetic as syn
+    rank, local_rank, world = rdist.init_distributed()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the HIP hot path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    from rs_detection_amd import _lib
+    _lib.load()
+
+    from rs_detection_amd.runner.runner import Runner
+    torch.manual_seed(0)  # same initial weights on every rank (DDP also broadcasts)
+    runner = Runner(s2anet_cfg(), device=device)
+    # synthetic DOTA-shaped batch, resident in HBM before the timed region
+    g = torch.Generator(device="cpu").manual_seed(0 + rank)
+    images = torch.randn(BATCH_PER_GPU, 3, TILE, TILE, generator=g).to(device)
+    targets = []
+    for t in syn.synthetic_targets(BATCH_PER_GPU, rank=rank, it=0):
+        t = dict(t)
+        t["rboxes"] = torch.from_numpy(t["rboxes"]).to(device)
+        t["labels"] = torch.from_numpy(t["labels"]).to(device)
+        targets.append(t)
+
+    for _ in range(args.warmup):
+        runner.train_step(images, targets)
+    rdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = runner.train_step(images, targets)
+    torch.cuda.synchronize()
+    rdist.barrier()
+    dt = time.perf_counter() - t0
+    dt = rdist.all_reduce_max(dt, device)
+    loss_v = float(loss)
+    assert np.isfinite(loss_v), "non-finite loss"
+
+    if rank != 0:
+        return
+    kernels = {} if args.no_kernels else kernel_rooflines(device, targets)
+    roof = kernels.get("box_iou_rotated_kernel")
+    tiles = BATCH_PER_GPU * world * args.steps
+    line = {
+        "metric": "1024x1024 tiles/sec S2ANet-R50-FPN train",
+        "value": tiles / dt,
+        "unit": "tiles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "S2ANet-R50-FPN train step, %d x 1024x1024 DOTA-shaped tiles per GPU, fp32, "
+                               "K gts/tile cycle [16,100,400,40], A=21824 anchors/tile" % BATCH_PER_GPU,
+                   "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world},
+        "final_loss": loss_v,
+        "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
+        "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
+            "kernel": "box_iou_rotated_kernel", "us_per_launch": roof["us"], "shape": roof["shape"]}) if roof else None,
+        "kernels": kernels,
+        "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

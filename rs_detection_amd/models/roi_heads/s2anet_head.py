@@ -1,0 +1,339 @@
+"""S2ANetHead on MI355X (/root/reference/python/jdet/models/roi_heads/s2anet_head.py:20-723).
+
+Same constructor arguments, parameter names, init, losses and outputs as the
+reference; the per-image / per-gt Python loops are replaced by batched device work:
+
+  forward_single  fam convs (MIOpen) -> [bbox_decode + AlignConv.get_offset] fused in ONE
+                  HIP kernel for the whole batch (:631-654 + :676-713) -> DeformConv
+                  (csrc/deform_conv.hip + rocBLAS GEMM) -> ORConv2d (csrc/arf.hip + MIOpen)
+                  -> RotationInvariantPooling -> odm convs.
+  loss            FAM and ODM targets each by ONE grouped rotated-IoU launch + ONE
+                  assignment call for all images (anchor_target_batched); losses on the
+                  level-concatenated tensors; no host synchronisation anywhere.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from rs_detection_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedS2ANet
+from rs_detection_amd.models.boxes.anchor_target import anchor_target_batched
+from rs_detection_amd.models.utils.modules import ConvModule
+from rs_detection_amd.models.utils.weight_init import normal_init, bias_init_with_prob
+from rs_detection_amd.ops import (DeformConv, ORConv2d, RotationInvariantPooling, multiclass_nms_rotated,
+                                  delta2bbox_rotated, rotated_box_to_poly, s2a_refine_and_offset)
+from rs_detection_amd.utils.registry import HEADS, LOSSES, BOXES, build_from_cfg
+
+_DEFAULT_TRAIN_PART = dict(
+    assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1,
+                  iou_calculator=dict(type='BboxOverlaps2D_rotated')),
+    bbox_coder=dict(type='DeltaXYWHABBoxCoder', target_means=(0., 0., 0., 0., 0.),
+                    target_stds=(1., 1., 1., 1., 1.), clip_border=True),
+    allowed_border=-1, pos_weight=-1, debug=False)
+
+
+def bbox_decode(bbox_preds, anchors, means=(0, 0, 0, 0, 0), stds=(1, 1, 1, 1, 1)):
+    """s2anet_head.py:631-654: (N,5,H,W) deltas + (H*W,5) anchors -> (N,H,W,5), wh_ratio_clip=1e-6."""
+    refined, _ = s2a_refine_and_offset(bbox_preds, anchors, 1.0, 3, means, stds, 1e-6, want_offset=False)
+    return refined
+
+
+class AlignConv(nn.Module):
+    """s2anet_head.py:657-723."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, deformable_groups=1):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.deform_conv = DeformConv(in_channels, out_channels, kernel_size=kernel_size,
+                                      padding=(kernel_size - 1) // 2, deformable_groups=deformable_groups)
+        self.relu = nn.ReLU(inplace=True)
+
+    def init_weights(self):
+        normal_init(self.deform_conv, std=0.01)
+
+    @torch.no_grad()
+    def get_offset(self, anchors, featmap_size, stride):
+        """Reference signature (:676): one image's (H*W,5) anchors -> (2*ks*ks, H, W).
+        (Pure torch, used by tests/tools; the training path uses the fused kernel.)"""
+        feat_h, feat_w = featmap_size
+        ks = self.kernel_size
+        pad = (ks - 1) // 2
+        idx = torch.arange(-pad, pad + 1, dtype=anchors.dtype, device=anchors.device)
+        yy, xx = torch.meshgrid(idx, idx, indexing="ij")
+        xx, yy = xx.reshape(-1), yy.reshape(-1)
+        yc, xc = torch.meshgrid(torch.arange(feat_h, dtype=anchors.dtype, device=anchors.device),
+                                torch.arange(feat_w, dtype=anchors.dtype, device=anchors.device), indexing="ij")
+        x_conv, y_conv = xc.reshape(-1)[:, None] + xx, yc.reshape(-1)[:, None] + yy
+        x_ctr, y_ctr, w, h, a = torch.unbind(anchors, dim=1)
+        x_ctr, y_ctr, w, h = x_ctr / stride, y_ctr / stride, w / stride, h / stride
+        cos, sin = torch.cos(a), torch.sin(a)
+        x, y = (w / ks)[:, None] * xx, (h / ks)[:, None] * yy
+        xr = cos[:, None] * x - sin[:, None] * y
+        yr = sin[:, None] * x + cos[:, None] * y
+        off_x = xr + x_ctr[:, None] - x_conv
+        off_y = yr + y_ctr[:, None] - y_conv
+        off = torch.stack([off_y, off_x], dim=-1)
+        return off.reshape(anchors.size(0), -1).permute(1, 0).reshape(-1, feat_h, feat_w)
+
+    def forward(self, x, anchors, stride, offset=None):
+        if offset is None:
+            num_imgs, H, W = anchors.shape[:3]
+            offset = torch.stack([self.get_offset(anchors[i].reshape(-1, 5), (H, W), stride)
+                                  for i in range(num_imgs)], dim=0)
+        return self.relu(self.deform_conv(x, offset))
+
+
+@HEADS.register_module()
+class S2ANetHead(nn.Module):
+    def __init__(self, num_classes, in_channels, feat_channels=256, stacked_convs=2, with_orconv=True,
+                 anchor_scales=[4], anchor_ratios=[1.0], anchor_strides=[8, 16, 32, 64, 128], anchor_base_sizes=None,
+                 target_means=(.0, .0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0, 1.0),
+                 loss_fam_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_fam_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 loss_odm_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_odm_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 test_cfg=dict(nms_pre=2000, min_bbox_size=0, score_thr=0.05,
+                               nms=dict(type='nms_rotated', iou_thr=0.1), max_per_img=2000),
+                 train_cfg=dict(fam_cfg=_DEFAULT_TRAIN_PART, odm_cfg=_DEFAULT_TRAIN_PART)):
+        super().__init__()
+        self.num_classes, self.in_channels, self.feat_channels = num_classes, in_channels, feat_channels
+        self.stacked_convs, self.with_orconv = stacked_convs, with_orconv
+        self.anchor_scales, self.anchor_ratios, self.anchor_strides = anchor_scales, anchor_ratios, list(anchor_strides)
+        self.anchor_base_sizes = list(anchor_strides) if anchor_base_sizes is None else anchor_base_sizes
+        self.target_means, self.target_stds = tuple(target_means), tuple(target_stds)
+        self.use_sigmoid_cls = loss_odm_cls.get('use_sigmoid', False)
+        self.sampling = loss_odm_cls['type'] not in ['FocalLoss', 'GHMC']
+        self.cls_out_channels = num_classes - 1 if self.use_sigmoid_cls else num_classes
+        if self.cls_out_channels <= 0:
+            raise ValueError('num_classes={} is too small'.format(num_classes))
+        self.loss_fam_cls = build_from_cfg(loss_fam_cls, LOSSES)
+        self.loss_fam_bbox = build_from_cfg(loss_fam_bbox, LOSSES)
+        self.loss_odm_cls = build_from_cfg(loss_odm_cls, LOSSES)
+        self.loss_odm_bbox = build_from_cfg(loss_odm_bbox, LOSSES)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.anchor_generators = [AnchorGeneratorRotatedS2ANet(b, anchor_scales, anchor_ratios)
+                                  for b in self.anchor_base_sizes]
+        self.base_anchors = dict()  # anchor cache, keyed (level, featmap_size, device)
+        self._built = {}
+        self._init_layers()
+
+    def _init_layers(self):
+        fc = self.feat_channels
+        self.relu = nn.ReLU(inplace=True)
+        self.fam_reg_convs, self.fam_cls_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else fc
+            self.fam_reg_convs.append(ConvModule(chn, fc, 3, stride=1, padding=1))
+            self.fam_cls_convs.append(ConvModule(chn, fc, 3, stride=1, padding=1))
+        self.fam_reg = nn.Conv2d(fc, 5, 1)
+        self.fam_cls = nn.Conv2d(fc, self.cls_out_channels, 1)
+        self.align_conv = AlignConv(fc, fc, kernel_size=3)
+        if self.with_orconv:
+            self.or_conv = ORConv2d(fc, int(fc / 8), kernel_size=3, padding=1, arf_config=(1, 8))
+        else:
+            self.or_conv = nn.Conv2d(fc, fc, 3, padding=1)
+        self.or_pool = RotationInvariantPooling(256, 8)
+        self.odm_reg_convs, self.odm_cls_convs = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = int(fc / 8) if i == 0 and self.with_orconv else fc
+            self.odm_reg_convs.append(ConvModule(fc, fc, 3, stride=1, padding=1))
+            self.odm_cls_convs.append(ConvModule(chn, fc, 3, stride=1, padding=1))
+        self.odm_cls = nn.Conv2d(fc, self.cls_out_channels, 3, padding=1)
+        self.odm_reg = nn.Conv2d(fc, 5, 3, padding=1)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in list(self.fam_reg_convs) + list(self.fam_cls_convs):
+            normal_init(m.conv, std=0.01)
+        bias_cls = bias_init_with_prob(0.01)
+        normal_init(self.fam_reg, std=0.01)
+        normal_init(self.fam_cls, std=0.01, bias=bias_cls)
+        self.align_conv.init_weights()
+        normal_init(self.or_conv, std=0.01)
+        for m in list(self.odm_reg_convs) + list(self.odm_cls_convs):
+            normal_init(m.conv, std=0.01)
+        normal_init(self.odm_cls, std=0.01, bias=bias_cls)
+        normal_init(self.odm_reg, std=0.01)
+
+    def _anchors(self, level, featmap_size, device):
+        key = (level, tuple(featmap_size), str(device))
+        if key not in self.base_anchors:
+            self.base_anchors[key] = self.anchor_generators[level].grid_anchors(
+                featmap_size, self.anchor_strides[level], device=device)
+        return self.base_anchors[key]
+
+    def forward_single(self, x, stride):
+        fam_reg_feat = x
+        for conv in self.fam_reg_convs:
+            fam_reg_feat = conv(fam_reg_feat)
+        fam_bbox_pred = self.fam_reg(fam_reg_feat)
+        if self.training:  # only forward during training (:214-218)
+            fam_cls_feat = x
+            for conv in self.fam_cls_convs:
+                fam_cls_feat = conv(fam_cls_feat)
+            fam_cls_score = self.fam_cls(fam_cls_feat)
+        else:
+            fam_cls_score = None
+        level = self.anchor_strides.index(stride)
+        featmap_size = tuple(fam_bbox_pred.shape[-2:])
+        init_anchors = self._anchors(level, featmap_size, x.device)
+        # bbox_decode(fam_bbox_pred.detach(), ...) + AlignConv.get_offset, fused, whole batch
+        refine_anchor, offset = s2a_refine_and_offset(fam_bbox_pred.detach().float(), init_anchors, stride, 3,
+                                                      self.target_means, self.target_stds, 1e-6)
+        align_feat = self.align_conv(x, refine_anchor, stride, offset=offset)
+        or_feat = self.or_conv(align_feat)
+        odm_reg_feat = or_feat
+        odm_cls_feat = self.or_pool(or_feat) if self.with_orconv else or_feat
+        for conv in self.odm_reg_convs:
+            odm_reg_feat = conv(odm_reg_feat)
+        for conv in self.odm_cls_convs:
+            odm_cls_feat = conv(odm_cls_feat)
+        return fam_cls_score, fam_bbox_pred, refine_anchor, self.odm_cls(odm_cls_feat), self.odm_reg(odm_reg_feat)
+
+    # ---- targets -------------------------------------------------------------------
+    def _valid_flags(self, featmap_sizes, img_metas, device):
+        """None when every anchor of every image is valid (the common, padded-to-stride case)."""
+        need = False
+        per_img = []
+        for meta in img_metas:
+            w, h = meta['pad_shape'][:2]  # (w,h) convention kept
+            flags = []
+            for i, (fh, fw) in enumerate(featmap_sizes):
+                s = self.anchor_strides[i]
+                vh, vw = min(int(np.ceil(h / s)), fh), min(int(np.ceil(w / s)), fw)
+                need |= (vh < fh) or (vw < fw)
+                flags.append((fh, fw, vh, vw))
+            per_img.append(flags)
+        if not need:
+            return None
+        out = []
+        for flags in per_img:
+            out.append(torch.cat([self.anchor_generators[i].valid_flags((fh, fw), (vh, vw), device)
+                                  for i, (fh, fw, vh, vw) in enumerate(flags)]))
+        return torch.stack(out)
+
+    def _cfg_objs(self, name):
+        if name not in self._built:
+            cfg = self.train_cfg[name]
+            coder_cfg = cfg.get('bbox_coder', '')
+            coder = build_from_cfg(dict(type='DeltaXYWHABBoxCoder') if coder_cfg == '' else coder_cfg, BOXES)
+            self._built[name] = (build_from_cfg(cfg.get('assigner', ''), BOXES), coder)
+        return self._built[name]
+
+    @staticmethod
+    def _flatten(preds, ch):
+        """list of (B,ch,H,W) per level -> (B, A, ch) level-concatenated, anchor order = (h, w)."""
+        return torch.cat([p.permute(0, 2, 3, 1).reshape(p.shape[0], -1, ch) for p in preds], dim=1)
+
+    def _level_losses(self, cls_loss, bbox_loss, cls_score, bbox_pred, labels, label_weights, bbox_targets,
+                      bbox_weights, num_level_anchors, avg):
+        """Per-level loss lists like the reference's multi_apply(loss_*_single) (:430-508)."""
+        l_cls, l_box, s = [], [], 0
+        C = self.cls_out_channels
+        for n in num_level_anchors:
+            sl = slice(s, s + n)
+            l_cls.append(cls_loss(cls_score[:, sl].reshape(-1, C), labels[:, sl].reshape(-1),
+                                  label_weights[:, sl].reshape(-1), avg_factor=avg))
+            l_box.append(bbox_loss(bbox_pred[:, sl].reshape(-1, 5), bbox_targets[:, sl].reshape(-1, 5),
+                                   bbox_weights[:, sl].reshape(-1, 5), avg_factor=avg))
+            s += n
+        return l_cls, l_box
+
+    def loss(self, fam_cls_scores, fam_bbox_preds, refine_anchors, odm_cls_scores, odm_bbox_preds, gt_bboxes,
+             gt_labels, img_metas, gt_bboxes_ignore=None):
+        device = odm_cls_scores[0].device
+        featmap_sizes = [tuple(f.shape[-2:]) for f in odm_cls_scores]
+        assert len(featmap_sizes) == len(self.anchor_generators)
+        num_level_anchors = [h * w for h, w in featmap_sizes]
+        ks = [int(g.shape[0]) for g in gt_bboxes]
+        if min(ks) == 0:
+            raise ValueError('No gt or bboxes')  # assigner.py:91-92
+        gt_cat = torch.cat([g.to(device=device, dtype=torch.float32) for g in gt_bboxes])
+        lab_cat = torch.cat([l.to(device=device, dtype=torch.int32) for l in gt_labels])
+        row_offsets = torch.tensor(np.concatenate([[0], np.cumsum(ks)]), dtype=torch.int32).to(device, non_blocking=True)
+        valid = self._valid_flags(featmap_sizes, img_metas, device)
+        C = self.cls_out_channels
+
+        # Feature Alignment Module: shared grid anchors
+        init_anchors = torch.cat([self._anchors(i, featmap_sizes[i], device) for i in range(len(featmap_sizes))])
+        assigner, coder = self._cfg_objs('fam_cfg')
+        labels, lw, bt, bw, npos, nneg = anchor_target_batched(init_anchors, gt_cat, lab_cat, row_offsets, max(ks),
+                                                               self.train_cfg['fam_cfg'], assigner, coder, valid)
+        avg = npos + nneg if self.sampling else npos
+        losses_fam_cls, losses_fam_bbox = self._level_losses(
+            self.loss_fam_cls, self.loss_fam_bbox, self._flatten(fam_cls_scores, C), self._flatten(fam_bbox_preds, 5),
+            labels, lw, bt, bw, num_level_anchors, avg)
+
+        # Oriented Detection Module: per-image refined anchors
+        refined = torch.cat([r.reshape(r.shape[0], -1, 5) for r in refine_anchors], dim=1)
+        assigner, coder = self._cfg_objs('odm_cfg')
+        labels, lw, bt, bw, npos, nneg = anchor_target_batched(refined, gt_cat, lab_cat, row_offsets, max(ks),
+                                                               self.train_cfg['odm_cfg'], assigner, coder, valid)
+        avg = npos + nneg if self.sampling else npos
+        losses_odm_cls, losses_odm_bbox = self._level_losses(
+            self.loss_odm_cls, self.loss_odm_bbox, self._flatten(odm_cls_scores, C), self._flatten(odm_bbox_preds, 5),
+            labels, lw, bt, bw, num_level_anchors, avg)
+        return dict(loss_fam_cls=losses_fam_cls, loss_fam_bbox=losses_fam_bbox, loss_odm_cls=losses_odm_cls,
+                    loss_odm_bbox=losses_odm_bbox)
+
+    # ---- inference -----------------------------------------------------------------
+    def get_bboxes(self, fam_cls_scores, fam_bbox_preds, refine_anchors, odm_cls_scores, odm_bbox_preds, img_metas,
+                   rescale=True):
+        assert len(odm_cls_scores) == len(odm_bbox_preds)
+        cfg = self.test_cfg
+        num_levels = len(odm_cls_scores)
+        results = []
+        for img_id in range(len(img_metas)):
+            cls_list = [odm_cls_scores[i][img_id].detach() for i in range(num_levels)]
+            box_list = [odm_bbox_preds[i][img_id].detach() for i in range(num_levels)]
+            anchors = [refine_anchors[i][img_id].reshape(-1, 5) for i in range(num_levels)]
+            results.append(self.get_bboxes_single(cls_list, box_list, anchors, img_metas[img_id]['img_shape'],
+                                                  img_metas[img_id]['scale_factor'], cfg, rescale))
+        return results
+
+    def get_bboxes_single(self, cls_score_list, bbox_pred_list, mlvl_anchors, img_shape, scale_factor, cfg,
+                          rescale=False):
+        assert len(cls_score_list) == len(bbox_pred_list) == len(mlvl_anchors)
+        mlvl_bboxes, mlvl_scores = [], []
+        for cls_score, bbox_pred, anchors in zip(cls_score_list, bbox_pred_list, mlvl_anchors):
+            assert cls_score.shape[-2:] == bbox_pred.shape[-2:]
+            cls_score = cls_score.permute(1, 2, 0).reshape(-1, self.cls_out_channels)
+            scores = cls_score.sigmoid() if self.use_sigmoid_cls else cls_score.softmax(-1)
+            bbox_pred = bbox_pred.permute(1, 2, 0).reshape(-1, 5)
+            nms_pre = cfg.get('nms_pre', -1)
+            if nms_pre > 0 and scores.shape[0] > nms_pre:
+                max_scores = scores.max(dim=1)[0] if self.use_sigmoid_cls else scores[:, 1:].max(dim=1)[0]
+                _, topk = max_scores.topk(nms_pre)
+                anchors, bbox_pred, scores = anchors[topk, :], bbox_pred[topk, :], scores[topk, :]
+            mlvl_bboxes.append(delta2bbox_rotated(anchors, bbox_pred.float(), self.target_means, self.target_stds,
+                                                  img_shape))
+            mlvl_scores.append(scores)
+        mlvl_bboxes = torch.cat(mlvl_bboxes)
+        if rescale:
+            mlvl_bboxes[..., :4] /= scale_factor
+        mlvl_scores = torch.cat(mlvl_scores)
+        if self.use_sigmoid_cls:
+            mlvl_scores = torch.cat([mlvl_scores.new_zeros(mlvl_scores.shape[0], 1), mlvl_scores], dim=1)
+        det_bboxes, det_labels = multiclass_nms_rotated(mlvl_bboxes, mlvl_scores.float(), cfg['score_thr'], cfg['nms'],
+                                                        cfg['max_per_img'])
+        boxes, scores = det_bboxes[:, :5], det_bboxes[:, 5]
+        return rotated_box_to_poly(boxes.contiguous()), scores, det_labels
+
+    def parse_targets(self, targets, is_train=True):
+        img_metas, gt_bboxes, gt_bboxes_ignore, gt_labels = [], [], [], []
+        for t in targets:
+            if is_train:
+                gt_bboxes.append(torch.as_tensor(t["rboxes"]))
+                gt_labels.append(torch.as_tensor(t["labels"]))
+                gt_bboxes_ignore.append(t.get("rboxes_ignore"))
+            img_metas.append(dict(img_shape=tuple(t["img_size"])[::-1], scale_factor=t["scale_factor"],
+                                  pad_shape=t["pad_shape"]))
+        if not is_train:
+            return img_metas
+        return gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore
+
+    def forward(self, feats, targets):
+        outs = [self.forward_single(f, s) for f, s in zip(feats, self.anchor_strides)]
+        outs = tuple(map(list, zip(*outs)))
+        if self.training:
+            return self.loss(*outs, *self.parse_targets(targets))
+        return self.get_bboxes(*outs, self.parse_targets(targets, is_train=False))

@@ -1,0 +1,76 @@
+"""Minimal Runner: build model / optimizer / scheduler from a JDet config and step it.
+
+Counterpart of /root/reference/python/jdet/runner/runner.py:23-179 restricted to what the
+hot path needs: ``train_step`` (forward, parse_losses, backward, grad all-reduce via DDP,
+clip 35, SGD update, LR schedule -- :131-179) and ``test_time`` (:105-129: warm-up then timed
+iterations on one cached batch, prints FPS).  Datasets, checkpoints, loggers, eval: out of scope.
+"""
+import time
+
+import torch
+
+import rs_detection_amd.models  # noqa: F401  (registers everything)
+from rs_detection_amd.optims import optimizer as _o, lr_scheduler as _s  # noqa: F401
+from rs_detection_amd.utils import dist as rdist
+from rs_detection_amd.utils.general import parse_losses
+from rs_detection_amd.utils.registry import MODELS, OPTIMS, SCHEDULERS, build_from_cfg
+
+
+class Runner:
+    def __init__(self, cfg, device=None, distributed=None, memory_format=None, amp_dtype=None):
+        self.cfg = cfg
+        self.rank, self.local_rank, self.world = rdist.env_world()
+        if device is None:
+            device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
+        self.model = build_from_cfg(cfg.model, MODELS).to(device)
+        if memory_format is not None:
+            self.model = self.model.to(memory_format=memory_format)
+        self.memory_format = memory_format
+        self.amp_dtype = amp_dtype
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.optimizer = build_from_cfg(cfg.optimizer, OPTIMS, params=params) if cfg.optimizer else None
+        self.scheduler = build_from_cfg(cfg.scheduler, SCHEDULERS, optimizer=self.optimizer) \
+            if (cfg.scheduler and self.optimizer) else None
+        if distributed is None:
+            distributed = self.world > 1
+        self.ddp = rdist.wrap_ddp(self.model, device) if distributed else self.model
+        self.iter, self.epoch = 0, 0
+
+    def train_step(self, images, targets):
+        self.model.train()
+        if self.memory_format is not None:
+            images = images.contiguous(memory_format=self.memory_format)
+        if self.amp_dtype is not None:
+            with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype):
+                losses = self.ddp(images, targets)
+        else:
+            losses = self.ddp(images, targets)
+        total, parsed = parse_losses(losses)
+        self.optimizer.zero_grad(set_to_none=True)
+        total.backward()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step(self.iter, self.epoch, by_epoch=True)
+        self.iter += 1
+        return total, parsed
+
+    @torch.no_grad()
+    def predict(self, images, targets):
+        self.model.eval()
+        return self.model(images, targets)
+
+    def test_time(self, images, targets, warmup=10, iters=100):
+        for _ in range(warmup):
+            self.train_step(images, targets)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(iters):
+            self.train_step(images, targets)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        dt = time.time() - t0
+        fps = images.shape[0] * self.world * iters / dt
+        print("FPS:", fps)
+        return fps

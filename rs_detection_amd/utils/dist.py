@@ -1,0 +1,65 @@
+"""One process per GPU over torch.distributed (backend "nccl" == RCCL on ROCm, xGMI intra-node).
+
+Replaces Jittor's MPI launcher + in-optimizer gradient all-reduce
+(/root/reference/python/jdet/optims/optimizer.py:30-31 -> jittor Optimizer.pre_step;
+metric sync /root/reference/python/jdet/utils/general.py:30-48).  The path shards by
+image (pure data parallelism): each rank draws its own tiles; the only
+collective is the bucketed gradient all-reduce DDP overlaps with backward.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(backend=None):
+    """Initialise the default process group from torchrun env vars (no-op for world size 1)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def wrap_ddp(model, device, bucket_cap_mb=64):
+    """DDP with gradient-as-bucket-view; 64 MB buckets: the 145 MB fp32 gradient set of
+    S2ANet-R50 goes out as ~3 large all-reduces (per-link-bound ring over xGMI favours few,
+    large messages) that overlap with the backbone backward."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    ids = [device.index] if device.type == "cuda" else None
+    return DDP(model, device_ids=ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
+               broadcast_buffers=False, find_unused_parameters=False)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def all_reduce_max(value, device):
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sync_mean(values, device):
+    """utils/general.py:30-48 ``sync``: mean-all-reduce a dict of scalars, return Python floats."""
+    keys = sorted(values)
+    t = torch.stack([values[k].detach().float().reshape(()) for k in keys]).to(device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t)
+        t /= dist.get_world_size()
+    return dict(zip(keys, t.tolist()))

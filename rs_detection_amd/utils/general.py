@@ -1,0 +1,34 @@
+"""multi_apply / unmap / parse_losses with the reference semantics
+(/root/reference/python/jdet/utils/general.py:50-79) on torch tensors."""
+from functools import partial
+
+import torch
+
+
+def multi_apply(func, *args, **kwargs):
+    pfunc = partial(func, **kwargs) if kwargs else func
+    return tuple(map(list, zip(*map(pfunc, *args))))
+
+
+def unmap(data, count, inds, fill=0):
+    """Scatter a subset (selected by bool mask ``inds``) back into ``count`` rows."""
+    if data.dim() == 1:
+        ret = torch.full((count,), fill, dtype=data.dtype, device=data.device)
+        ret[inds] = data
+    else:
+        ret = torch.full((count,) + tuple(data.shape[1:]), fill, dtype=data.dtype, device=data.device)
+        ret[inds, :] = data
+    return ret
+
+
+def parse_losses(losses):
+    out = {}
+    for name, value in losses.items():
+        if isinstance(value, torch.Tensor):
+            out[name] = value.mean()
+        elif isinstance(value, list):
+            out[name] = sum(v.mean() for v in value)
+        else:
+            raise TypeError('{} is not a tensor or list of tensors'.format(name))
+    total = sum(v for k, v in out.items() if 'loss' in k)
+    return total, out
