@@ -97,7 +97,16 @@ def kernel_rooflines(device, targets):
     t = event_time(lambda: ops.deformable_col2im(col, off, x.shape, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
     out["deform_col2im_kernel"] = dict(bound="hbm(atomics)", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                        frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
-    del col, x, off
+    del col
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    t = event_time(lambda: ops.deformable_im2col_nhwc(xn, off, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
+    out["deform_im2col_nhwc_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                            frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+    colT = ops.deformable_im2col_nhwc(xn, off, (3, 3), (1, 1), (1, 1), (1, 1))
+    t = event_time(lambda: ops.deformable_col2im_nhwc(colT, off, xn.shape, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
+    out["deform_col2im_nhwc_kernel"] = dict(bound="hbm(atomics)", achieved=by / t / 1e9, peak=HBM_PEAK_GBS,
+                                            unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+    del colT, xn, x, off
     # -- rotated NMS (a16), SURVEY 8d micro-bench shape M=5344, 6 columns, thr 0.1
     d, s, l = syn.nms_cluster_boxes(5344)
     d6 = torch.from_numpy(np.concatenate([d, l[:, None].astype(np.float32)], 1)).to(device)
@@ -136,6 +145,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--memory-format", choices=["channels_last", "contiguous"], default="contiguous",
+                    help="activation layout of the torch/MIOpen part (measured r1: NCHW 68.7 ms/step, channels_last 494 ms/step; "
+                         "and the channels-last AlignConv kernels consume without transposes)")
     args = ap.parse_args()
 
     from rs_detection_amd.utils import dist as rdist
@@ -151,10 +163,13 @@ def main():
 
     from rs_detection_amd.runner.runner import Runner
     torch.manual_seed(0)  # same initial weights on every rank (DDP also broadcasts)
-    runner = Runner(s2anet_cfg(), device=device)
+    mf = torch.channels_last if args.memory_format == "channels_last" else None
+    runner = Runner(s2anet_cfg(), device=device, memory_format=mf)
     # synthetic DOTA-shaped batch, resident in HBM before the timed region
     g = torch.Generator(device="cpu").manual_seed(0 + rank)
     images = torch.randn(BATCH_PER_GPU, 3, TILE, TILE, generator=g).to(device)
+    if mf is not None:
+        images = images.contiguous(memory_format=mf)
     targets = []
     for t in syn.synthetic_targets(BATCH_PER_GPU, rank=rank, it=0):
         t = dict(t)
@@ -173,7 +188,7 @@ def main():
     rdist.barrier()
     dt = time.perf_counter() - t0
     dt = rdist.all_reduce_max(dt, device)
-    loss_v = float(loss)
+    loss_v = float(loss.detach())
     assert np.isfinite(loss_v), "non-finite loss"
 
     if rank != 0:
@@ -196,7 +211,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "S2ANet-R50-FPN train step, %d x 1024x1024 DOTA-shaped tiles per GPU, fp32, "
                                "K gts/tile cycle [16,100,400,40], A=21824 anchors/tile" % BATCH_PER_GPU,
-                   "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world},
+                   "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
+                   "memory_format": args.memory_format},
         "final_loss": loss_v,
         "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
         "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {

@@ -142,6 +142,16 @@ int rsdet_deform_col2im_f32(const float* col, const float* offset, const rsdet_d
 int rsdet_deform_col2im_coord_f32(const float* col, const float* im, const float* offset,
                                   const rsdet_dcn_geom* g, float* grad_offset, void* stream);
 
+/* Channels-last forms of the two kernels above (same arithmetic, MI355X-first layout):
+ * im / grad_im (B,H,W,C); colT (B*Ho*Wo, kh*kw, C) so that the convolution is the plain GEMM
+ * out(B*Ho*Wo, O) = colT x W(kh*kw*C, O) with NHWC output; offset stays (B, dg*2*kh*kw, Ho, Wo).
+ * One wave per output position, lanes over channels: every access, incl. the fp32 atomics of
+ * col2im, is a contiguous 256-B / 1-KiB segment per wave-instruction. */
+int rsdet_deform_im2col_nhwc_f32(const float* im, const float* offset, const rsdet_dcn_geom* g,
+                                 float* colT, void* stream);
+int rsdet_deform_col2im_nhwc_f32(const float* colT, const float* offset, const rsdet_dcn_geom* g,
+                                 float* grad_im, void* stream);
+
 /* ---- a18  ROIAlignRotated_v1 -----------------------------------------------------------------
  * Replaces _RotatedROIAlign_v1.execute / .grad: ops/roi_align_rotated_v1.py:300-351
  * (kernels :71-147, :193-298).  feat (N,C,H,W); rois (R,6) = (batch, cx, cy, w, h, theta);

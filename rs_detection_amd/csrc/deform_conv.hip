@@ -196,6 +196,130 @@ __global__ __launch_bounds__(DCN_NT) void deform_col2im_coord_kernel(
   grad_offset[idx] = val;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Channels-last ("NHWC") forms -- the MI355X-first layout of the AlignConv hot path.
+//
+//   im      (B, H, W, C)            x as MIOpen's NHWC igemm kernels already hold it
+//   colT    (B*Ho*Wo, kh*kw, C)     one row per output position, K index = tap*C + c
+//   grad_im (B, H, W, C)
+//
+// One wave owns one output position: its 2*kh*kw offsets are wave-uniform, the
+// bilinear footprint of a tap is derived once per wave, and the 64 lanes sweep the
+// channel axis, so every global access of a wave-instruction is one contiguous
+// 256-B (dword) or 1-KiB (dwordx4) segment -- gathers, column stores and, in
+// col2im, the fp32 atomics (the shape MI355X_MICROARCH.md "Global float atomics"
+// prices at the full chip-wide rate; the NCHW kernel's one-lane-per-row atomics are
+// ~17x slower).  The GEMM consumes colT directly: out(npos, O) = colT @ W(kh*kw*C, O).
+constexpr int DCN_WAVES = 4;  // waves (= positions in flight) per workgroup
+
+struct TapFoot {
+  long long o1, o2, o3, o4;  // element offsets of the corner pixels' channel vectors, -1 = outside
+  float w1, w2, w3, w4;
+};
+
+__device__ __forceinline__ void nhwc_position(const Geom& g, long long pos, int& b, int& ho, int& wo,
+                                              int& hw) {
+  const long long plane = (long long)g.Ho * g.Wo;
+  b = (int)(pos / plane);
+  hw = (int)(pos - (long long)b * plane);
+  ho = hw / g.Wo;
+  wo = hw - ho * g.Wo;
+}
+
+template <bool COL2IM>
+__device__ __forceinline__ TapFoot nhwc_tap_foot(const float* __restrict__ offset, const Geom& g,
+                                                 int b, int grp, int ho, int wo, int hw, int tap) {
+  const long long plane = (long long)g.Ho * g.Wo;
+  const int i = tap / g.kw, j = tap - i * g.kw;
+  const float* offp = offset + ((long long)b * g.dg + grp) * 2 * g.kh * g.kw * plane;
+  float oh = offp[(long long)(2 * tap) * plane + hw];
+  float ow = offp[(long long)(2 * tap + 1) * plane + hw];
+  float h = (ho * g.sh - g.ph) + i * g.dh + oh;
+  float w = (wo * g.sw - g.pw) + j * g.dw + ow;
+  Foot f = COL2IM ? col2im_foot(h, w, g.H, g.W) : im2col_foot(h, w, g.H, g.W);
+  const long long base = (long long)b * g.H * g.W;
+  TapFoot t;
+  t.o1 = f.o1 >= 0 ? (base + f.o1) * g.C : -1;
+  t.o2 = f.o2 >= 0 ? (base + f.o2) * g.C : -1;
+  t.o3 = f.o3 >= 0 ? (base + f.o3) * g.C : -1;
+  t.o4 = f.o4 >= 0 ? (base + f.o4) * g.C : -1;
+  t.w1 = f.w1; t.w2 = f.w2; t.w3 = f.w3; t.w4 = f.w4;
+  return t;
+}
+
+// VEC4: C % 4 == 0 and one deformable group -> dwordx4 path (1 KiB per wave-instruction)
+template <bool VEC4>
+__global__ __launch_bounds__(64 * DCN_WAVES) void deform_im2col_nhwc_kernel(
+    const float* __restrict__ im, const float* __restrict__ offset, Geom g, float* __restrict__ colT) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long npos = (long long)g.B * g.Ho * g.Wo;
+  const int taps = g.kh * g.kw;
+  const int cpg = g.C / g.dg;
+  for (long long pos = (long long)blockIdx.x * DCN_WAVES + wave; pos < npos;
+       pos += (long long)gridDim.x * DCN_WAVES) {
+    int b, ho, wo, hw;
+    nhwc_position(g, pos, b, ho, wo, hw);
+    float* dst = colT + pos * taps * g.C;
+    for (int tap = 0; tap < taps; ++tap) {
+      if (VEC4) {
+        TapFoot t = nhwc_tap_foot<false>(offset, g, b, 0, ho, wo, hw, tap);
+        for (int c = lane * 4; c < g.C; c += 256) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          // same summation order as the reference: w1*v1 + w2*v2 + w3*v3 + w4*v4
+          float4 a = t.o1 >= 0 ? *reinterpret_cast<const float4*>(im + t.o1 + c) : v;
+          float4 bq = t.o2 >= 0 ? *reinterpret_cast<const float4*>(im + t.o2 + c) : v;
+          float4 cq = t.o3 >= 0 ? *reinterpret_cast<const float4*>(im + t.o3 + c) : v;
+          float4 d = t.o4 >= 0 ? *reinterpret_cast<const float4*>(im + t.o4 + c) : v;
+          v.x = t.w1 * a.x + t.w2 * bq.x + t.w3 * cq.x + t.w4 * d.x;
+          v.y = t.w1 * a.y + t.w2 * bq.y + t.w3 * cq.y + t.w4 * d.y;
+          v.z = t.w1 * a.z + t.w2 * bq.z + t.w3 * cq.z + t.w4 * d.z;
+          v.w = t.w1 * a.w + t.w2 * bq.w + t.w3 * cq.w + t.w4 * d.w;
+          *reinterpret_cast<float4*>(dst + (long long)tap * g.C + c) = v;
+        }
+      } else {
+        for (int c = lane; c < g.C; c += 64) {
+          TapFoot t = nhwc_tap_foot<false>(offset, g, b, c / cpg, ho, wo, hw, tap);
+          float a = t.o1 >= 0 ? im[t.o1 + c] : 0.f, bq = t.o2 >= 0 ? im[t.o2 + c] : 0.f;
+          float cq = t.o3 >= 0 ? im[t.o3 + c] : 0.f, d = t.o4 >= 0 ? im[t.o4 + c] : 0.f;
+          dst[(long long)tap * g.C + c] = t.w1 * a + t.w2 * bq + t.w3 * cq + t.w4 * d;
+        }
+      }
+    }
+  }
+}
+
+template <bool UNIFORM>
+__global__ __launch_bounds__(64 * DCN_WAVES) void deform_col2im_nhwc_kernel(
+    const float* __restrict__ colT, const float* __restrict__ offset, Geom g,
+    float* __restrict__ grad_im) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long npos = (long long)g.B * g.Ho * g.Wo;
+  const int taps = g.kh * g.kw;
+  const int cpg = g.C / g.dg;
+  for (long long pos = (long long)blockIdx.x * DCN_WAVES + wave; pos < npos;
+       pos += (long long)gridDim.x * DCN_WAVES) {
+    int b, ho, wo, hw;
+    nhwc_position(g, pos, b, ho, wo, hw);
+    const float* src = colT + pos * taps * g.C;
+    for (int tap = 0; tap < taps; ++tap) {
+      TapFoot t{};
+      if (UNIFORM) t = nhwc_tap_foot<true>(offset, g, b, 0, ho, wo, hw, tap);
+      // lanes stride the channel axis by 1: each atomic wave-instruction = 256 contiguous bytes
+      for (int c = lane; c < g.C; c += 64) {
+        if (!UNIFORM) t = nhwc_tap_foot<true>(offset, g, b, c / cpg, ho, wo, hw, tap);
+        float top = src[(long long)tap * g.C + c];
+        if (t.o1 >= 0) atomicAdd(grad_im + t.o1 + c, t.w1 * top);
+        if (t.o2 >= 0) atomicAdd(grad_im + t.o2 + c, t.w2 * top);
+        if (t.o3 >= 0) atomicAdd(grad_im + t.o3 + c, t.w3 * top);
+        if (t.o4 >= 0) atomicAdd(grad_im + t.o4 + c, t.w4 * top);
+      }
+    }
+  }
+}
+
 static int make_geom(const rsdet_dcn_geom* s, Geom* g) {
   if (!s) return RSDET_EINVAL;
   if (s->C < 0 || s->H < 0 || s->W < 0 || s->B < 0 || s->kh < 1 || s->kw < 1 || s->sh < 1 ||
@@ -268,5 +392,47 @@ extern "C" int rsdet_deform_col2im_coord_f32(const float* col, const float* im,
   if (!col || !im || !offset || !grad_offset) return RSDET_EINVAL;
   hipLaunchKernelGGL(deform_col2im_coord_kernel, dim3((unsigned)((total + DCN_NT - 1) / DCN_NT)),
                      dim3(DCN_NT), 0, (hipStream_t)stream, col, im, offset, g, grad_offset);
+  return rsdet_launch_status();
+}
+
+static int nhwc_grid(long long npos) {
+  long long blocks = (npos + DCN_WAVES - 1) / DCN_WAVES;
+  const long long cap = 256LL * 8 * 4;  // 256 CUs x 8 workgroups, then grid-stride
+  return (int)(blocks < cap ? blocks : cap);
+}
+
+extern "C" int rsdet_deform_im2col_nhwc_f32(const float* im, const float* offset,
+                                            const rsdet_dcn_geom* geom, float* colT, void* stream) {
+  Geom g;
+  int rc = make_geom(geom, &g);
+  if (rc) return rc;
+  long long npos = (long long)g.B * g.Ho * g.Wo;
+  if (npos == 0 || g.C == 0) return RSDET_OK;
+  if (!im || !offset || !colT) return RSDET_EINVAL;
+  bool vec4 = (g.C % 4 == 0) && g.dg == 1 && (((uintptr_t)im | (uintptr_t)colT) % 16 == 0);
+  if (vec4)
+    hipLaunchKernelGGL(deform_im2col_nhwc_kernel<true>, dim3(nhwc_grid(npos)), dim3(64 * DCN_WAVES), 0,
+                       (hipStream_t)stream, im, offset, g, colT);
+  else
+    hipLaunchKernelGGL(deform_im2col_nhwc_kernel<false>, dim3(nhwc_grid(npos)), dim3(64 * DCN_WAVES),
+                       0, (hipStream_t)stream, im, offset, g, colT);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_deform_col2im_nhwc_f32(const float* colT, const float* offset,
+                                            const rsdet_dcn_geom* geom, float* grad_im,
+                                            void* stream) {
+  Geom g;
+  int rc = make_geom(geom, &g);
+  if (rc) return rc;
+  long long npos = (long long)g.B * g.Ho * g.Wo;
+  if (npos == 0 || g.C == 0) return RSDET_OK;
+  if (!colT || !offset || !grad_im) return RSDET_EINVAL;
+  if (g.dg == 1)
+    hipLaunchKernelGGL(deform_col2im_nhwc_kernel<true>, dim3(nhwc_grid(npos)), dim3(64 * DCN_WAVES), 0,
+                       (hipStream_t)stream, colT, offset, g, grad_im);
+  else
+    hipLaunchKernelGGL(deform_col2im_nhwc_kernel<false>, dim3(nhwc_grid(npos)), dim3(64 * DCN_WAVES),
+                       0, (hipStream_t)stream, colT, offset, g, grad_im);
   return rsdet_launch_status();
 }

@@ -2,7 +2,8 @@
 from .box_iou_rotated import box_iou_rotated, box_iou_rotated_v1, box_iou_rotated_grouped
 from .nms_rotated import nms_rotated, ml_nms_rotated, multiclass_nms_rotated, nms_rotated_keep_mask
 from .orn import ORConv2d, RotationInvariantPooling, active_rotating_filter, arf_forward, arf_backward
-from .dcn_v1 import DeformConv, deform_conv, deformable_im2col, deformable_col2im, deformable_col2im_coord
+from .dcn_v1 import (DeformConv, deform_conv, deformable_im2col, deformable_col2im, deformable_col2im_coord,
+                     deformable_im2col_nhwc, deformable_col2im_nhwc)
 from .roi_align_rotated_v1 import ROIAlignRotated_v1, roi_align_rotated_v1
 from .box_coder import (bbox2delta_rotated, delta2bbox_rotated, s2a_refine_and_offset, rotated_box_to_poly,
                         assign_wrt_overlaps)

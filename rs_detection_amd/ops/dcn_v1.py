@@ -19,7 +19,8 @@ import torch.nn as nn
 
 from .. import _lib
 
-__all__ = ["DeformConv", "deform_conv", "deformable_im2col", "deformable_col2im", "deformable_col2im_coord"]
+__all__ = ["DeformConv", "deform_conv", "deformable_im2col", "deformable_col2im", "deformable_col2im_coord",
+           "deformable_im2col_nhwc", "deformable_col2im_nhwc"]
 
 
 def _pair(x):
@@ -79,8 +80,90 @@ def deformable_col2im_coord(col, im, offset, kernel, padding, stride, dilation, 
     return grad_off
 
 
+def deformable_im2col_nhwc(im_nhwc, offset, kernel, padding, stride, dilation, deformable_group=1):
+    """Channels-last form: im (B,H,W,C) contiguous, offset (B,dg*2*kh*kw,Ho,Wo) -> colT (B*Ho*Wo, kh*kw*C)."""
+    _lib.require_cuda_f32(im_nhwc, offset)
+    lib = _lib.load()
+    assert im_nhwc.is_contiguous()
+    offset = offset.contiguous()
+    B, H, W, C = im_nhwc.shape
+    (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
+    Ho, Wo = _out_hw(H, W, kh, kw, ph, pw, sh, sw, dh, dw)
+    assert tuple(offset.shape) == (B, deformable_group * 2 * kh * kw, Ho, Wo), "invalid offset shape"
+    colT = torch.empty((B * Ho * Wo, kh * kw * C), dtype=im_nhwc.dtype, device=im_nhwc.device)
+    g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_group)
+    _lib.check(lib.rsdet_deform_im2col_nhwc_f32(_lib.ptr(im_nhwc), _lib.ptr(offset), g, _lib.ptr(colT),
+                                                _lib.stream_ptr()), "rsdet_deform_im2col_nhwc_f32")
+    return colT
+
+
+def deformable_col2im_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride, dilation, deformable_group=1):
+    """colT (B*Ho*Wo, kh*kw*C) -> grad_im (B,H,W,C) (fp32 atomics, contiguous 256-B segments)."""
+    _lib.require_cuda_f32(colT, offset)
+    lib = _lib.load()
+    colT, offset = colT.contiguous(), offset.contiguous()
+    B, H, W, C = im_shape_nhwc
+    (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
+    grad_im = torch.zeros((B, H, W, C), dtype=colT.dtype, device=colT.device)
+    g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_group)
+    _lib.check(lib.rsdet_deform_col2im_nhwc_f32(_lib.ptr(colT), _lib.ptr(offset), g, _lib.ptr(grad_im),
+                                                _lib.stream_ptr()), "rsdet_deform_col2im_nhwc_f32")
+    return grad_im
+
+
+class DeformConvFunctionNHWC(torch.autograd.Function):
+    """groups == 1 fast path of DeformConvFunction (offset needs no gradient).
+
+    Forward keeps the reference column layout (col (C*kh*kw, B*Ho*Wo), csrc deform_im2col) and
+    writes each image's output with one GEMM straight into the NCHW result (no transposes).
+    Backward is channels-last where it matters: gcolT[b] = gO[b]^T @ W(O, kh*kw*C) is a GEMM on
+    strided views (no copies) and col2im runs the NHWC kernel, whose fp32 atomics are contiguous
+    256-B segments per wave-instruction (7x faster than one-lane-per-row atomics at level 0).
+    The forward column matrix is kept for the weight gradient instead of recomputed
+    (dcn_v1.py:536-539; 288 GB of HBM make the 0.6 GB cheap)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride, padding, dilation, deformable_groups):
+        ctx.cfg = (_pair(stride), _pair(padding), _pair(dilation), deformable_groups)
+        B, C, H, W = input.shape
+        O, _, kh, kw = weight.shape
+        Ho, Wo = _out_hw(H, W, kh, kw, *ctx.cfg[1], *ctx.cfg[0], *ctx.cfg[2])
+        col = deformable_im2col(input, offset, (kh, kw), ctx.cfg[1], ctx.cfg[0], ctx.cfg[2], deformable_groups)
+        out = torch.empty((B, O, Ho, Wo), dtype=input.dtype, device=input.device)
+        w_flat = weight.reshape(O, C * kh * kw)
+        hw = Ho * Wo
+        for b in range(B):
+            torch.mm(w_flat, col[:, b * hw:(b + 1) * hw], out=out[b].view(O, hw))
+        ctx.save_for_backward(offset, weight, col)
+        ctx.in_shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        offset, weight, col = ctx.saved_tensors
+        stride, padding, dilation, dg = ctx.cfg
+        B, C, H, W = ctx.in_shape
+        O, _, kh, kw = weight.shape
+        go = grad_output.contiguous().view(B, O, -1)  # (B, O, Ho*Wo)
+        hw = go.shape[2]
+        grad_input = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            w_ok = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C)  # K index = tap*C + c
+            gcolT = torch.empty((B * hw, kh * kw * C), dtype=go.dtype, device=go.device)
+            for b in range(B):
+                torch.mm(go[b].t(), w_ok, out=gcolT[b * hw:(b + 1) * hw])
+            gi = deformable_col2im_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation, dg)
+            grad_input = gi.permute(0, 3, 1, 2).contiguous()
+        if ctx.needs_input_grad[2]:
+            gw = torch.zeros((O, C * kh * kw), dtype=go.dtype, device=go.device)
+            for b in range(B):
+                gw.addmm_(go[b], col[:, b * hw:(b + 1) * hw].t())
+            grad_weight = gw.view_as(weight)
+        return grad_input, None, grad_weight, None, None, None, None
+
+
 class DeformConvFunction(torch.autograd.Function):
-    """dcn_v1.py:559-650."""
+    """dcn_v1.py:559-650 (reference column layout; used for groups > 1 or when the offset needs a gradient)."""
 
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
@@ -128,7 +211,13 @@ class DeformConvFunction(torch.autograd.Function):
         return grad_input, grad_offset, grad_weight, None, None, None, None, None, None
 
 
-deform_conv = DeformConvFunction.apply
+def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+    """dcn_v1.py:650 ``deform_conv = DeformConvFunction.apply`` (same positional signature)."""
+    if groups == 1 and not offset.requires_grad and input is not None and input.dim() == 4 and input.is_cuda:
+        return DeformConvFunctionNHWC.apply(input, offset, weight, stride, padding, dilation, deformable_groups)
+    return DeformConvFunction.apply(input, offset, weight, stride, padding, dilation, groups, deformable_groups,
+                                    im2col_step)
 
 
 class DeformConv(nn.Module):

@@ -25,7 +25,10 @@ class Runner:
         self.device = device
         self.model = build_from_cfg(cfg.model, MODELS).to(device)
         if memory_format is not None:
-            self.model = self.model.to(memory_format=memory_format)
+            # only rank-4 parameters have a channels_last form (the ARF weight is rank 5)
+            for p in self.model.parameters():
+                if p.dim() == 4:
+                    p.data = p.data.contiguous(memory_format=memory_format)
         self.memory_format = memory_format
         self.amp_dtype = amp_dtype
         params = [p for p in self.model.parameters() if p.requires_grad]

@@ -88,6 +88,47 @@ def test_deform_im2col_col2im_coord(cuda, oracle_c, gi):
     assert np.abs(goff - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("gi", range(len(GEOMS)))
+def test_deform_nhwc_kernels_vs_oracle(cuda, oracle_c, gi):
+    """Channels-last kernels: same numbers as the reference-layout oracle, transposed."""
+    from rs_detection_amd.ops import deformable_im2col_nhwc, deformable_col2im_nhwc
+    g = GEOMS[gi]
+    im, off, Ho, Wo = _dcn_inputs(g, gi)
+    k, p, s, d = (g["kh"], g["kw"]), (g["ph"], g["pw"]), (g["sh"], g["sw"]), (g["dh"], g["dw"])
+    B, C, taps = g["B"], g["C"], g["kh"] * g["kw"]
+    x = _t(im, cuda).permute(0, 2, 3, 1).contiguous()
+    colT = deformable_im2col_nhwc(x, _t(off, cuda), k, p, s, d, g["dg"]).cpu().numpy()
+    want = oracle_c.deform_im2col(im, off, g, g["dg"])  # (C*taps, B, Ho, Wo)
+    wantT = want.reshape(C, taps, B * Ho * Wo).transpose(2, 1, 0).reshape(B * Ho * Wo, taps * C)
+    assert np.abs(colT - wantT).max() <= TOL
+    rng = np.random.default_rng(7 + gi)
+    gcolT = rng.standard_normal(colT.shape).astype(np.float32)
+    gim = deformable_col2im_nhwc(_t(gcolT, cuda), _t(off, cuda), (B, g["H"], g["W"], C), k, p, s, d, g["dg"])
+    gcol = gcolT.reshape(B * Ho * Wo, taps, C).transpose(2, 1, 0).reshape(C * taps, B * Ho * Wo)
+    want = oracle_c.deform_col2im(gcol, off, im.shape, g, g["dg"])
+    got = gim.permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_deform_conv_nhwc_path_equals_reference_layout_path(cuda):
+    """DeformConv fast path (channels-last) == reference-layout path, forward and both gradients."""
+    from rs_detection_amd.ops.dcn_v1 import DeformConvFunction, DeformConvFunctionNHWC
+    torch.manual_seed(3)
+    x = torch.randn(2, 32, 24, 20, device=cuda)
+    off = torch.randn(2, 18, 24, 20, device=cuda) * 2
+    w = torch.randn(16, 32, 3, 3, device=cuda) * 0.1
+    outs = []
+    for fn, extra, fmt in ((DeformConvFunction, (1, 1, 64), torch.contiguous_format),
+                           (DeformConvFunctionNHWC, (1,), torch.channels_last)):
+        xi = x.clone().requires_grad_(True)
+        wi = w.clone().requires_grad_(True)
+        y = fn.apply(xi, off, wi, 1, 1, 1, *extra)
+        y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
+        outs.append((y.detach(), xi.grad, wi.grad))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a.contiguous(), b.contiguous(), atol=2e-4, rtol=1e-4)
+
+
 def test_deform_conv_zero_offset_is_conv2d(cuda):
     """Independent pin: with zero offsets DeformConv must equal a plain convolution (fwd + grads)."""
     from rs_detection_amd.ops import DeformConv
