@@ -1,0 +1,90 @@
+"""GPU parity against the committed golden vectors (tests/golden/*.npz, produced from the reference's
+own sources -- see tests/golden/make_golden.py), through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+GEOM_KEYS = ("B", "C", "H", "W", "kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw", "dg")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("v", [0, 1])
+def test_iou_golden(cuda, v):
+    from rs_detection_amd.ops.box_iou_rotated import _iou
+    d = np.load(os.path.join(G, "iou_v%d.npz" % v))
+    for a, b, want in ((d["boxes1"], d["boxes2"], d["ious"]), (d["gts"], d["anchors"], d["ious_anchor"])):
+        got = _iou(_t(a, cuda), _t(b, cuda), v).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4
+        assert ((got == 0) == (want == 0)).all()
+        assert (got.view(np.int32) == want.view(np.int32)).mean() > 0.999
+
+
+@pytest.mark.parametrize("bl", [5, 6])
+def test_nms_golden_keep_exact(cuda, bl):
+    from rs_detection_amd.ops import nms_rotated_keep_mask
+    d = np.load(os.path.join(G, "nms%d.npz" % bl))
+    for thr in (0.1, 0.3, 0.8):
+        got = nms_rotated_keep_mask(_t(d["dets"], cuda), _t(d["order"], cuda), thr, bl).cpu().numpy()
+        assert (got == d["keep_%g" % thr]).all()
+    got = nms_rotated_keep_mask(_t(d["known_dets"], cuda), _t(d["known_order"], cuda), 0.3, bl).cpu().numpy()
+    assert (got == d["known_keep"]).all()
+
+
+def test_arf_golden(cuda):
+    from rs_detection_amd.ops import arf_forward, arf_backward
+    d = np.load(os.path.join(G, "arf.npz"))
+    for t in "abc":
+        assert (arf_forward(_t(d[t + "_w"], cuda), _t(d[t + "_idx"], cuda)).cpu().numpy() == d[t + "_fwd"]).all()
+        assert (arf_backward(_t(d[t + "_idx"], cuda), _t(d[t + "_go"], cuda)).cpu().numpy() == d[t + "_bwd"]).all()
+
+
+def test_dcn_golden(cuda):
+    from rs_detection_amd import ops
+    d = np.load(os.path.join(G, "dcn.npz"))
+    for t in "abc":
+        g = dict(zip(GEOM_KEYS, d[t + "_geom"].tolist()))
+        k, p, s, dl = (g["kh"], g["kw"]), (g["ph"], g["pw"]), (g["sh"], g["sw"]), (g["dh"], g["dw"])
+        im, off, gcol = _t(d[t + "_im"], cuda), _t(d[t + "_off"], cuda), _t(d[t + "_gcol"], cuda)
+        col = ops.deformable_im2col(im, off, k, p, s, dl, g["dg"]).cpu().numpy()
+        assert np.abs(col - d[t + "_col"].reshape(col.shape)).max() <= 1e-4
+        gcol2 = gcol.reshape(col.shape)
+        gim = ops.deformable_col2im(gcol2, off, im.shape, k, p, s, dl, g["dg"]).cpu().numpy()
+        assert np.abs(gim - d[t + "_gim"]).max() <= 1e-4 * max(1, np.abs(d[t + "_gim"]).max())
+        goff = ops.deformable_col2im_coord(gcol2, im, off, k, p, s, dl, g["dg"]).cpu().numpy()
+        assert np.abs(goff - d[t + "_goff"]).max() <= 1e-4 * max(1, np.abs(d[t + "_goff"]).max())
+
+
+def test_rroi_golden(cuda):
+    from rs_detection_amd.ops import roi_align_rotated_v1
+    d = np.load(os.path.join(G, "rroi.npz"))
+    for t in "abc":
+        sc, sr = d[t + "_cfg"]
+        feat = _t(d[t + "_feat"], cuda).requires_grad_(True)
+        out = roi_align_rotated_v1(feat, _t(d[t + "_rois"], cuda), (7, 7), float(sc), int(sr))
+        assert np.abs(out.detach().cpu().numpy() - d[t + "_out"]).max() <= 1e-4
+        out.backward(_t(d[t + "_go"], cuda))
+        assert np.abs(feat.grad.cpu().numpy() - d[t + "_gfeat"]).max() <= 1e-4 * max(1, np.abs(d[t + "_gfeat"]).max())
+
+
+def test_assign_and_coder_golden(cuda):
+    from rs_detection_amd import ops
+    d = np.load(os.path.join(G, "assign.npz"))
+    K = d["gts"].shape[0]
+    ro = torch.tensor([0, K], dtype=torch.int32, device=cuda)
+    ov = ops.box_iou_rotated_grouped(_t(d["gts"], cuda), ro, K, _t(d["anchors"], cuda))
+    gi, mo, lb = ops.assign_wrt_overlaps(ov, ro, K, 0.5, 0.4, 0.0, True, True, _t(d["gt_labels"], cuda), 0)
+    assert (gi[0].cpu().numpy() == d["gt_inds"]).all()          # bit-exact anchor indices
+    assert (lb[0].cpu().numpy() == d["labels"]).all()
+    assert np.abs(mo[0].cpu().numpy() - d["max_overlaps"]).max() <= 1e-4
+    c = np.load(os.path.join(G, "coder.npz"))
+    enc = ops.bbox2delta_rotated(_t(c["proposals"], cuda), _t(c["gt"], cuda)).cpu().numpy()
+    assert np.abs((enc - c["encoded"]) / np.maximum(np.abs(c["encoded"]), 1)).max() <= 1e-4
+    dec = ops.delta2bbox_rotated(_t(c["proposals"], cuda), _t(c["deltas"], cuda)).cpu().numpy()
+    assert np.abs((dec - c["decoded"]) / np.maximum(np.abs(c["decoded"]), 1)).max() <= 1e-4
