@@ -38,13 +38,18 @@ int rsdet_abi_version(void);
  *   ops/box_iou_rotated_v1.py:507-524.
  * boxes (n, stride>=5) rows = (cx, cy, w, h, theta[rad], ...); ious (n1, n2).
  * version 0 / 1 selects the vertex convention (v1 = y-down angle, _v1.py:69-72).
- * The v1 wrapper's "too small" post-filter (_v1.py:515-522) is host-side logic. */
+ * The v1 wrapper's "too small" post-filter (_v1.py:515-522) is host-side logic.
+ * Workspace: rsdet_box_iou_rotated_ws_size(n1, n2_total, n2) bytes, 16-byte aligned: prepared
+ * boxes (fp64 sincos once per box; n2_total = n2, or n_groups*n2 for per-group column sets) and
+ * the sharded global work queue of overlapping pairs (about min(n1*n2, 4 Mi) x 16 B). */
+size_t rsdet_box_iou_rotated_ws_size(int n1, long long n2_total, int n2);
 int rsdet_box_iou_rotated_f32(const float* boxes1, int n1, int stride1, const float* boxes2,
-                              int n2, int stride2, int version, float* ious, void* stream);
+                              int n2, int stride2, int version, float* ious, void* ws,
+                              size_t ws_bytes, void* stream);
 
 /* Batched form used by the assigner (one launch for all images of a batch):
  * rows [row_offsets[g], row_offsets[g+1]) of boxes1/ious belong to group g and
- * are compared with boxes2 + g*group_stride2 (floats; 0 = one shared column set).
+ * are compared with boxes2 + g*group_stride2 (floats; 0 = one shared column set, else n2*stride2).
  * row_offsets: n_groups+1 device ints; max_rows_per_group: host-known bound.
  * Replaces the per-image loop models/boxes/anchor_target.py:60-72 ->
  * assigner.py:94 -> iou_calculator.py:157-162. */
@@ -52,7 +57,7 @@ int rsdet_box_iou_rotated_grouped_f32(const float* boxes1, int n1, int stride1,
                                       const int* row_offsets, int n_groups,
                                       int max_rows_per_group, const float* boxes2, int n2,
                                       int stride2, long long group_stride2, int version,
-                                      float* ious, void* stream);
+                                      float* ious, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a16  rotated NMS -----------------------------------------------------------
  * Replaces nms_rotated_cpu / nms_rotated_cuda: ops/nms_rotated.py:495-512

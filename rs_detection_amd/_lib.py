@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsdet_hip.so")
+LIB_PATH = os.environ.get("RSDET_LIB_PATH", os.path.join(_HERE, "librsdet_hip.so"))  # override: A/B kernel builds
 
 RSDET_OK = 0
 RSDET_EINVAL = -22
@@ -25,9 +25,11 @@ class DcnGeom(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol include/rsdet.h declares.
 SIGNATURES = {
     "rsdet_abi_version": (c_int, []),
-    "rsdet_box_iou_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_box_iou_rotated_ws_size": (c_size_t, [c_int, c_ll, c_int]),
+    "rsdet_box_iou_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_size_t, c_void_p]),
     "rsdet_box_iou_rotated_grouped_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                                                  c_int, c_ll, c_int, c_void_p, c_void_p]),
+                                                  c_int, c_ll, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_nms_rotated_ws_size": (c_size_t, [c_int]),
     "rsdet_nms_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),

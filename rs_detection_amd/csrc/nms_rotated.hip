@@ -27,7 +27,7 @@ namespace rsdet {
 struct NmsBox {
   BoxPre p;
   float label;
-  float pad[3];
+  float pad;
 };  // 48 B
 
 constexpr int NMS_NT = 256;
@@ -40,7 +40,7 @@ __global__ void nms_prepare_kernel(const float* __restrict__ dets, int n, int bo
   NmsBox o;
   o.p = prepare_box(b);
   o.label = box_len == 6 ? b[5] : 0.f;
-  o.pad[0] = o.pad[1] = o.pad[2] = 0.f;
+  o.pad = 0.f;
   sorted[p] = o;
 }
 
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
                                                           unsigned long long* __restrict__ mask) {
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;  // lower triangle never read by the sweep
-  __shared__ F2 s_pts[24 * NMS_NT];
+  __shared__ F2 s_pts[kQuadSlots * (NMS_NT / 4)];
   __shared__ NmsBox s_row[64];
   __shared__ NmsBox s_col[64];
   __shared__ unsigned long long s_mask[64];
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
     if (lane < cols) {
       bool later = (cbk > rb) || (lane > i);
       cand = later && s_row[i].label == s_col[lane].label &&
-             !surely_disjoint(s_row[i].p, s_col[lane].p);
+             !surely_disjoint(s_row[i].p, s_col[lane].p) && !sat_disjoint<0>(s_row[i].p, s_col[lane].p);
     }
     unsigned long long m = __ballot(cand);
     if (m) {
@@ -88,13 +88,14 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
   __syncthreads();
 
   const int total = s_count;
-  Scratch sc{s_pts + tid, NMS_NT};
-  for (int q = tid; q < total; q += NMS_NT) {
+  const int quad = tid >> 2;
+  F2* qscr = s_pts + quad * kQuadSlots;
+  for (int q = quad; q < total; q += NMS_NT / 4) {  // four lanes per pair (rsdet_geom.h)
     unsigned e = s_queue[q];
     int i = e >> 6, j = e & 63;
-    float v = pair_iou<0>(s_row[i].p, s_col[j].p, sc);  // box1 = earlier (kept) box, :443
+    float v = pair_iou_quad<0>(s_row[i].p, s_col[j].p, qscr, lane);  // box1 = earlier (kept) box, :443
     bool hit = GE ? (v >= thr) : (v > thr);
-    if (hit) atomicOr(&s_mask[i], 1ull << j);
+    if (hit && (tid & 3) == 0) atomicOr(&s_mask[i], 1ull << j);
   }
   __syncthreads();
   if (tid < rows) mask[(long long)(rb * 64 + tid) * col_blocks + cbk] = s_mask[tid];

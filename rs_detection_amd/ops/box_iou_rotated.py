@@ -20,8 +20,10 @@ def _iou(boxes1, boxes2, version):
     ious = torch.empty((n1, n2), dtype=torch.float32, device=b1.device)
     if n1 and n2:
         assert b1.dim() == 2 and b2.dim() == 2 and b1.shape[1] >= 5 and b2.shape[1] >= 5
+        ws_bytes = lib.rsdet_box_iou_rotated_ws_size(n1, n2, n2)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=b1.device)
         rc = lib.rsdet_box_iou_rotated_f32(_lib.ptr(b1), n1, b1.shape[1], _lib.ptr(b2), n2, b2.shape[1], version,
-                                           _lib.ptr(ious), _lib.stream_ptr())
+                                           _lib.ptr(ious), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
         _lib.check(rc, "rsdet_box_iou_rotated_f32")
     return ious
 
@@ -63,8 +65,12 @@ def box_iou_rotated_grouped(boxes1, row_offsets, max_rows, boxes2, version=0, ou
         A, gs = b2.shape[0], 0
     ious = out if out is not None else torch.empty((n1, A), dtype=torch.float32, device=b1.device)
     assert row_offsets.dtype == torch.int32 and row_offsets.is_cuda
+    if n1 == 0 or A == 0:
+        return ious
+    ws_bytes = lib.rsdet_box_iou_rotated_ws_size(n1, G * A if gs else A, A)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=b1.device)
     rc = lib.rsdet_box_iou_rotated_grouped_f32(_lib.ptr(b1), n1, b1.shape[-1], _lib.ptr(row_offsets), G, int(max_rows),
                                                _lib.ptr(b2), A, b2.shape[-1], gs, version, _lib.ptr(ious),
-                                               _lib.stream_ptr())
+                                               _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
     _lib.check(rc, "rsdet_box_iou_rotated_grouped_f32")
     return ious
