@@ -33,6 +33,8 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive conv search o
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+torch.backends.cudnn.benchmark = os.environ.get("RSDET_CUDNN_BENCHMARK", "0") == "1"
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 TILE = 1024
 BATCH_PER_GPU = 4
@@ -77,7 +79,7 @@ def kernel_rooflines(device, targets):
     # -- batched rotated IoU (a1): bytes = 20*(N1+N2) + 4*N1*N2
     t = event_time(lambda: ops.box_iou_rotated_grouped(gt, ro, max(ks), anchors, out=ov), 50)
     by = 20 * (n1 + A) + 4 * n1 * A
-    out["box_iou_rotated_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+    out["box_iou_rotated(prepare+filter+clip)"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                          frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6,
                                          mpairs_per_s=n1 * A / t / 1e6, shape="sumK=%d x A=%d (B=%d)" % (n1, A, len(ks)))
     # -- assignment (a4): two passes over the matrix + outputs
@@ -146,8 +148,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--memory-format", choices=["channels_last", "contiguous"], default="contiguous",
-                    help="activation layout of the torch/MIOpen part (measured r1: NCHW 68.7 ms/step, channels_last 494 ms/step; "
-                         "and the channels-last AlignConv kernels consume without transposes)")
+                    help="activation layout of the torch/MIOpen part (measured r1 on MI355X, fp32: "
+                         "NCHW 68.7 ms/step, channels_last 494 ms/step)")
     args = ap.parse_args()
 
     from rs_detection_amd.utils import dist as rdist
@@ -194,7 +196,7 @@ def main():
     if rank != 0:
         return
     kernels = {} if args.no_kernels else kernel_rooflines(device, targets)
-    roof = kernels.get("box_iou_rotated_kernel")
+    roof = kernels.get("box_iou_rotated(prepare+filter+clip)")
     tiles = BATCH_PER_GPU * world * args.steps
     line = {
         "metric": "1024x1024 tiles/sec S2ANet-R50-FPN train",
@@ -216,7 +218,7 @@ def main():
         "final_loss": loss_v,
         "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
         "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
-            "kernel": "box_iou_rotated_kernel", "us_per_launch": roof["us"], "shape": roof["shape"]}) if roof else None,
+            "kernel": "rsdet_box_iou_rotated_grouped_f32 = iou_prepare + iou_filter + iou_clip kernels", "us_per_launch": roof["us"], "shape": roof["shape"]}) if roof else None,
         "kernels": kernels,
         "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
     }

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
     WorkItem* __restrict__ queue, unsigned* __restrict__ counter, unsigned capacity) {
   __shared__ BoxPre s_row[IOU_TI];
   __shared__ unsigned short s_list[IOU_TI * IOU_NT];
-  __shared__ F2 s_pts[kQuadSlots * (IOU_NT / 4)];  // overflow path only
+  __shared__ F2 s_pts[kQuadSlots * 16];  // overflow path only: one wave (16 quads) clips
   __shared__ int s_count;
   __shared__ unsigned s_base;
 
@@ -134,9 +134,10 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
     queue[base + q] = w;
   }
   // ---- queue overflow: clip the rest here (same routine, worse balance)
+  if (tid >= 64) return;
   const int quad = tid >> 2;
   F2* qscr = s_pts + quad * kQuadSlots;
-  for (int q = fit + quad; q < total; q += IOU_NT / 4) {
+  for (int q = fit + quad; q < total; q += 16) {
     unsigned e = s_list[q];
     const int i = (int)(e >> 8), j = (int)(e & 255);
     const BoxPre bb = p2[col0 + j];
