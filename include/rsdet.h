@@ -72,6 +72,16 @@ size_t rsdet_nms_rotated_ws_size(int n);
 int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, const int* order, float thr,
                           int ge, uint8_t* keep, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- a20  horizontal-box NMS of the Oriented-RCNN proposal stage -------------------------------
+ * Replaces Jittor's built-in jt.nms (third-party, un-vendored; call sites
+ * models/roi_heads/oriented_rpn_head.py:219, ops/nms.py:9,44).  boxes_sorted (n,4) = (x1,y1,x2,y2)
+ * ALREADY in descending-score order; IoU uses the legacy "+1" convention when plus_one != 0;
+ * a box is suppressed when IoU > thr with an earlier kept box.  keep_sorted (n) uint8, by sorted
+ * position.  Workspace rsdet_nms_hbb_ws_size(n), 16-byte aligned. */
+size_t rsdet_nms_hbb_ws_size(int n);
+int rsdet_nms_hbb_sorted_f32(const float* boxes_sorted, int n, float thr, int plus_one,
+                             uint8_t* keep_sorted, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a4  MaxIoUAssigner.assign_wrt_overlaps ---------------------------------------
  * Replaces models/boxes/assigner.py:111-170 (incl. the per-gt Python loop :151-160)
  * for a whole batch.  overlaps (n1, A) as produced by the grouped IoU; group g

@@ -189,3 +189,73 @@ extern "C" int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, cons
                      keep);
   return rsdet_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Horizontal-box NMS (Oriented-RCNN proposal stage).  Replaces Jittor's built-in `jt.nms`
+// (third-party, call sites /root/reference/python/jdet/models/roi_heads/oriented_rpn_head.py:219,
+// ops/nms.py:9,44): boxes (x1,y1,x2,y2) already gathered in descending-score order, IoU with the
+// legacy "+1" pixel convention when plus_one != 0, suppression on IoU > thr.  Same mask + device
+// sweep structure as the rotated NMS above; keep[] is indexed by SORTED position.
+namespace rsdet {
+
+__global__ __launch_bounds__(64) void nms_hbb_mask_kernel(const float* __restrict__ boxes, int n, float thr,
+                                                          float one, int col_blocks,
+                                                          unsigned long long* __restrict__ mask) {
+  const int rb = blockIdx.y, cbk = blockIdx.x;
+  if (cbk < rb) return;
+  __shared__ float s_col[64 * 4];
+  const int tid = threadIdx.x;
+  const int cols = min(64, n - cbk * 64), rows = min(64, n - rb * 64);
+  if (tid < cols) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_col[tid * 4 + k] = boxes[(long long)(cbk * 64 + tid) * 4 + k];
+  }
+  __syncthreads();
+  if (tid >= rows) return;
+  const float* b = boxes + (long long)(rb * 64 + tid) * 4;
+  const float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+  const float area = (x2 - x1 + one) * (y2 - y1 + one);
+  unsigned long long bits = 0ull;
+  const int start = (rb == cbk) ? tid + 1 : 0;
+  for (int j = start; j < cols; ++j) {
+    const float* c = s_col + j * 4;
+    float w = fmaxf(0.f, fminf(x2, c[2]) - fmaxf(x1, c[0]) + one);
+    float h = fmaxf(0.f, fminf(y2, c[3]) - fmaxf(y1, c[1]) + one);
+    float inter = w * h;
+    float carea = (c[2] - c[0] + one) * (c[3] - c[1] + one);
+    if (inter / (area + carea - inter) > thr) bits |= 1ull << j;
+  }
+  mask[(long long)(rb * 64 + tid) * col_blocks + cbk] = bits;
+}
+
+__global__ void iota_kernel(int* p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+}  // namespace rsdet
+
+extern "C" size_t rsdet_nms_hbb_ws_size(int n) {
+  if (n <= 0) return 0;
+  size_t cb = ((size_t)n + 63) / 64;
+  return (((size_t)n * 4 + 255) & ~(size_t)255) + (size_t)n * cb * sizeof(unsigned long long);
+}
+
+extern "C" int rsdet_nms_hbb_sorted_f32(const float* boxes_sorted, int n, float thr, int plus_one,
+                                        uint8_t* keep_sorted, void* ws, size_t ws_bytes, void* stream) {
+  if (n < 0) return RSDET_EINVAL;
+  if (n == 0) return RSDET_OK;
+  if (!boxes_sorted || !keep_sorted || !ws || ws_bytes < rsdet_nms_hbb_ws_size(n) || ((uintptr_t)ws & 15))
+    return RSDET_EINVAL;
+  const int cb = (n + 63) / 64;
+  if (cb > rsdet::NMS_MAX_BLOCKS) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int* ident = (int*)ws;
+  unsigned long long* mask = (unsigned long long*)((char*)ws + (((size_t)n * 4 + 255) & ~(size_t)255));
+  hipLaunchKernelGGL(rsdet::iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ident, n);
+  hipLaunchKernelGGL(rsdet::nms_hbb_mask_kernel, dim3(cb, cb), dim3(64), 0, s, boxes_sorted, n, thr,
+                     plus_one ? 1.f : 0.f, cb, mask);
+  hipLaunchKernelGGL(rsdet::nms_sweep_kernel, dim3(1), dim3(rsdet::NMS_NT), (size_t)(cb + 1) * 8, s, mask, n, cb,
+                     ident, keep_sorted);
+  return rsdet_launch_status();
+}

@@ -57,3 +57,111 @@ class AnchorGeneratorRotatedS2ANet:
         vy[:valid_h] = True
         valid = vx.repeat(feat_h) & vy.view(-1, 1).repeat(1, feat_w).view(-1)
         return valid[:, None].expand(valid.size(0), self.num_base_anchors).reshape(-1)
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+@BOXES.register_module()
+class AnchorGenerator:
+    """Multi-level horizontal anchors (/root/reference/python/jdet/models/boxes/anchor_generator.py:93-492):
+    ``strides`` in (w, h) order, ``ratios`` = h/w, ``scales`` or octave scales, optional centers /
+    center_offset; ``grid_anchors(featmap_sizes)`` -> per level (H*W*A, 4) with x fastest, then base anchor."""
+
+    def __init__(self, strides, ratios, scales=None, base_sizes=None, scale_major=True, octave_base_scale=None,
+                 scales_per_octave=None, centers=None, center_offset=0.):
+        if center_offset != 0:
+            assert centers is None, f'center cannot be set when center_offset!=0, {centers} is given.'
+        if not (0 <= center_offset <= 1):
+            raise ValueError(f'center_offset should be in range [0, 1], {center_offset} is given.')
+        if centers is not None:
+            assert len(centers) == len(strides)
+        self.strides = [_pair(s) for s in strides]
+        self.base_sizes = [min(s) for s in self.strides] if base_sizes is None else base_sizes
+        assert len(self.base_sizes) == len(self.strides)
+        assert ((octave_base_scale is not None and scales_per_octave is not None) ^ (scales is not None)), \
+            'scales and octave_base_scale with scales_per_octave cannot be set at the same time'
+        if scales is not None:
+            self.scales = torch.tensor(scales, dtype=torch.float32)
+        else:
+            import numpy as np
+            octave = np.array([2 ** (i / scales_per_octave) for i in range(scales_per_octave)])
+            self.scales = torch.tensor(octave * octave_base_scale, dtype=torch.float32)
+        self.octave_base_scale, self.scales_per_octave = octave_base_scale, scales_per_octave
+        self.ratios = torch.tensor(ratios, dtype=torch.float32)
+        self.scale_major, self.centers, self.center_offset = scale_major, centers, center_offset
+        self.base_anchors = self.gen_base_anchors()
+        self._cache = {}
+
+    @property
+    def num_base_anchors(self):
+        return [b.size(0) for b in self.base_anchors]
+
+    num_base_priors = num_base_anchors
+
+    @property
+    def num_levels(self):
+        return len(self.strides)
+
+    def gen_base_anchors(self):
+        return [self.gen_single_level_base_anchors(b, self.scales, self.ratios,
+                                                   None if self.centers is None else self.centers[i])
+                for i, b in enumerate(self.base_sizes)]
+
+    def gen_single_level_base_anchors(self, base_size, scales, ratios, center=None):
+        w = h = base_size
+        x_c, y_c = (self.center_offset * w, self.center_offset * h) if center is None else center
+        h_ratios = torch.sqrt(ratios)
+        w_ratios = 1 / h_ratios
+        if self.scale_major:
+            ws = (w * w_ratios[:, None] * scales[None, :]).reshape(-1)
+            hs = (h * h_ratios[:, None] * scales[None, :]).reshape(-1)
+        else:
+            ws = (w * scales[:, None] * w_ratios[None, :]).reshape(-1)
+            hs = (h * scales[:, None] * h_ratios[None, :]).reshape(-1)
+        return torch.stack([x_c - 0.5 * ws, y_c - 0.5 * hs, x_c + 0.5 * ws, y_c + 0.5 * hs], dim=-1)
+
+    def single_level_grid_anchors(self, base_anchors, featmap_size, stride=(16, 16), device="cpu"):
+        feat_h, feat_w = featmap_size
+        base = base_anchors.to(device)
+        sx = torch.arange(0, feat_w, device=device, dtype=torch.float32) * stride[0]
+        sy = torch.arange(0, feat_h, device=device, dtype=torch.float32) * stride[1]
+        xx = sx.repeat(feat_h)
+        yy = sy.view(-1, 1).repeat(1, feat_w).view(-1)
+        shifts = torch.stack([xx, yy, xx, yy], dim=-1)
+        return (base[None, :, :] + shifts[:, None, :]).view(-1, 4)
+
+    def grid_anchors(self, featmap_sizes, device="cpu"):
+        assert self.num_levels == len(featmap_sizes)
+        key = (tuple(map(tuple, featmap_sizes)), str(device))
+        if key not in self._cache:
+            self._cache[key] = [self.single_level_grid_anchors(self.base_anchors[i], featmap_sizes[i],
+                                                               self.strides[i], device)
+                                for i in range(self.num_levels)]
+        return self._cache[key]
+
+    grid_priors = grid_anchors
+
+    def single_level_valid_flags(self, featmap_size, valid_size, num_base_anchors, device="cpu"):
+        feat_h, feat_w = featmap_size
+        valid_h, valid_w = valid_size
+        assert valid_h <= feat_h and valid_w <= feat_w
+        vx = torch.zeros(feat_w, dtype=torch.bool, device=device)
+        vy = torch.zeros(feat_h, dtype=torch.bool, device=device)
+        vx[:valid_w] = True
+        vy[:valid_h] = True
+        valid = vx.repeat(feat_h) & vy.view(-1, 1).repeat(1, feat_w).view(-1)
+        return valid[:, None].expand(valid.size(0), num_base_anchors).reshape(-1)
+
+    def valid_flags(self, featmap_sizes, pad_shape, device="cpu"):
+        import numpy as np
+        assert self.num_levels == len(featmap_sizes)
+        out = []
+        for i in range(self.num_levels):
+            stride = self.strides[i]
+            feat_h, feat_w = featmap_sizes[i]
+            h, w = pad_shape[:2]  # anchor_generator.py:442 (square tiles hide the (w,h)/(h,w) mix, SURVEY q9)
+            vh, vw = min(int(np.ceil(h / stride[1])), feat_h), min(int(np.ceil(w / stride[0])), feat_w)
+            out.append(self.single_level_valid_flags((feat_h, feat_w), (vh, vw), self.num_base_anchors[i], device))
+        return out

@@ -13,7 +13,7 @@ class SamplingResult:
         self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds].long() - 1
         if gt_bboxes.numel() == 0:
             assert self.pos_assigned_gt_inds.numel() == 0
-            self.pos_gt_bboxes = gt_bboxes.new_empty(gt_bboxes.shape).view(-1, 4)
+            self.pos_gt_bboxes = gt_bboxes.new_empty(gt_bboxes.shape).view(-1, max(gt_bboxes.shape[-1], 4))
         else:
             if gt_bboxes.dim() < 2:
                 gt_bboxes = gt_bboxes.view(-1, 4)
@@ -35,3 +35,59 @@ class PseudoSampler:
         neg_inds = torch.nonzero(assign_result.gt_inds == 0).squeeze(-1).unique()
         gt_flags = torch.zeros(bboxes.shape[0], dtype=torch.bool, device=bboxes.device)
         return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+
+
+class BaseSampler:
+    """sampler.py:39-112: positive/negative sampling with optional gt-as-proposal injection.
+    Index sets are data-dependent in size, so ``nonzero`` synchronises with the device here just
+    as ``jt.nonzero(...).numel()`` does in the reference."""
+    box_dim = 4
+
+    def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
+        self.num, self.pos_fraction = num, pos_fraction
+        self.neg_pos_ub, self.add_gt_as_proposals = neg_pos_ub, add_gt_as_proposals
+
+    def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kwargs):
+        gt_bboxes = gt_bboxes.to(torch.float32)
+        bboxes = bboxes.to(torch.float32)
+        if bboxes.dim() < 2:
+            bboxes = bboxes[None, :]
+        bboxes = bboxes[:, :self.box_dim]
+        gt_flags = torch.zeros(bboxes.shape[0], dtype=torch.bool, device=bboxes.device)
+        if self.add_gt_as_proposals:
+            bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+            assign_result.add_gt_(gt_labels)
+            gt_flags = torch.cat([torch.ones(gt_bboxes.shape[0], dtype=torch.bool, device=bboxes.device), gt_flags])
+        num_expected_pos = int(self.num * self.pos_fraction)
+        pos_inds = self._sample_pos(assign_result, num_expected_pos, bboxes=bboxes, **kwargs).unique()
+        num_expected_neg = self.num - pos_inds.numel()
+        if self.neg_pos_ub >= 0:
+            num_expected_neg = min(num_expected_neg, int(self.neg_pos_ub * max(1, pos_inds.numel())))
+        neg_inds = self._sample_neg(assign_result, num_expected_neg, bboxes=bboxes, **kwargs).unique()
+        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+
+
+@BOXES.register_module()
+class RandomSampler(BaseSampler):
+    """sampler.py:132-180.  ``jt.randperm`` is not reproducible across frameworks: compare distributions,
+    not indices."""
+
+    @staticmethod
+    def random_choice(gallery, num):
+        assert len(gallery) >= num
+        perm = torch.randperm(gallery.numel(), device=gallery.device)[:num]
+        return gallery[perm]
+
+    def _sample_pos(self, assign_result, num_expected, **kwargs):
+        pos_inds = torch.nonzero(assign_result.gt_inds > 0).squeeze(1)
+        return pos_inds if pos_inds.numel() <= num_expected else self.random_choice(pos_inds, num_expected)
+
+    def _sample_neg(self, assign_result, num_expected, **kwargs):
+        neg_inds = torch.nonzero(assign_result.gt_inds == 0).squeeze(1)
+        return neg_inds if len(neg_inds) <= num_expected else self.random_choice(neg_inds, num_expected)
+
+
+@BOXES.register_module()
+class RandomSamplerRotated(RandomSampler):
+    """sampler.py:182-232: identical except proposals keep 5 columns."""
+    box_dim = 5

@@ -1,0 +1,200 @@
+"""OrientedRPNHead (/root/reference/python/jdet/models/roi_heads/oriented_rpn_head.py:9-492).
+
+Same constructor, parameters (rpn_conv / rpn_cls / rpn_reg), losses and proposal routine.  gt theta is negated
+(:281-282); anchors are horizontal (611 072 per 1024^2 tile with 7 ratios); proposals go through the
+hbb NMS with per-level coordinate offsets (:213-219, the role of jt.nms)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from rs_detection_amd.models.boxes.anchor_target import images_to_levels, anchor_inside_flags
+from rs_detection_amd.ops.bbox_transforms import obb2hbb, get_bbox_type, get_bbox_dim, bbox2type
+from rs_detection_amd.ops.nms import nms as hbb_nms
+from rs_detection_amd.utils.general import multi_apply
+from rs_detection_amd.utils.registry import BOXES, LOSSES, HEADS, build_from_cfg
+
+
+@HEADS.register_module()
+class OrientedRPNHead(nn.Module):
+    def __init__(self, in_channels, num_classes=1, min_bbox_size=0, nms_thresh=0.8, nms_pre=2000, nms_post=2000,
+                 feat_channels=256, bbox_type='obb', reg_dim=6, background_label=0, reg_decoded_bbox=False,
+                 pos_weight=-1,
+                 anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0],
+                                       strides=[4, 8, 16, 32, 64]),
+                 bbox_coder=dict(type='MidpointOffsetCoder', target_means=[.0, .0, .0, .0, .0, .0],
+                                 target_stds=[1.0, 1.0, 1.0, 1.0, 0.5, 0.5]),
+                 loss_cls=dict(type='CrossEntropyLossForRcnn', use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3,
+                               ignore_iof_thr=-1, match_low_quality=True, assigned_labels_filled=-1),
+                 sampler=dict(type='RandomSampler', num=256, pos_fraction=0.5, neg_pos_ub=-1,
+                              add_gt_as_proposals=False)):
+        super().__init__()
+        self.min_bbox_size, self.nms_thresh, self.nms_pre, self.nms_post = min_bbox_size, nms_thresh, nms_pre, nms_post
+        self.in_channels, self.feat_channels, self.num_classes = in_channels, feat_channels, num_classes
+        self.unmap_outputs, self.bbox_type, self.reg_dim, self.pos_weight = True, bbox_type, reg_dim, pos_weight
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        self.sampling = loss_cls['type'] not in ['FocalLoss', 'GHMC', 'QualityFocalLoss']
+        self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
+        self.reg_decoded_bbox = reg_decoded_bbox
+        self.background_label = num_classes if background_label is None else background_label
+        assert self.background_label == 0 or self.background_label == num_classes
+        self.bbox_coder = build_from_cfg(bbox_coder, BOXES)
+        self.loss_cls = build_from_cfg(loss_cls, LOSSES)
+        self.loss_bbox = build_from_cfg(loss_bbox, LOSSES)
+        self.assigner = build_from_cfg(assigner, BOXES)
+        self.sampler = build_from_cfg(sampler, BOXES)
+        self.anchor_generator = build_from_cfg(anchor_generator, BOXES)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self._init_layers()
+
+    def _init_layers(self):
+        self.rpn_conv = nn.Conv2d(self.in_channels, self.feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv2d(self.feat_channels, self.num_anchors * self.num_classes, 1)
+        self.rpn_reg = nn.Conv2d(self.feat_channels, self.num_anchors * 6, 1)
+
+    @staticmethod
+    def unmap(data, count, inds, fill=0):
+        if data.dim() == 1:
+            ret = data.new_full((count,), fill)
+            ret[inds.bool()] = data
+        else:
+            ret = data.new_full((count,) + tuple(data.shape[1:]), fill)
+            ret[inds.bool(), :] = data
+        return ret
+
+    def forward_single(self, x):
+        x = F.relu(self.rpn_conv(x))
+        return self.rpn_cls(x), self.rpn_reg(x)
+
+    def _get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape):
+        level_ids, mlvl_scores, mlvl_valid_anchors, mlvl_bbox_pred = [], [], [], []
+        for idx in range(len(cls_scores)):
+            cls, reg = cls_scores[idx], bbox_preds[idx]
+            assert cls.shape[-2:] == reg.shape[-2:]
+            cls = cls.permute(1, 2, 0)
+            scores = cls.reshape(-1).sigmoid() if self.use_sigmoid_cls else cls.reshape(-1, 2).softmax(dim=1)[:, 1]
+            reg = reg.permute(1, 2, 0).reshape(-1, self.reg_dim)
+            anchors = mlvl_anchors[idx]
+            if self.nms_pre > 0 and scores.shape[0] > self.nms_pre:
+                ranked, rank_inds = scores.sort(descending=True, stable=True)
+                topk = rank_inds[:self.nms_pre]
+                scores, reg, anchors = ranked[:self.nms_pre], reg[topk, :], anchors[topk, :]
+            mlvl_scores.append(scores)
+            mlvl_bbox_pred.append(reg)
+            mlvl_valid_anchors.append(anchors)
+            level_ids.append(scores.new_full((scores.size(0),), idx, dtype=torch.long))
+        anchors, reg, scores = torch.cat(mlvl_valid_anchors), torch.cat(mlvl_bbox_pred), torch.cat(mlvl_scores)
+        proposals = self.bbox_coder.decode(anchors, reg.float(), max_shape=img_shape)
+        ids = torch.cat(level_ids)
+        if self.min_bbox_size >= 0:
+            valid = (proposals[:, 2] > self.min_bbox_size) & (proposals[:, 3] > self.min_bbox_size)
+            if not bool(valid.all()):
+                proposals, scores, ids = proposals[valid], scores[valid], ids[valid]
+        hprop = obb2hbb(proposals)
+        max_coordinate = hprop.max() - hprop.min()
+        hprop = hprop + (ids.to(hprop.dtype) * (max_coordinate + 1))[:, None]
+        keep = hbb_nms(torch.cat([hprop, scores.unsqueeze(1)], dim=1).float().contiguous(), self.nms_thresh)
+        dets = torch.cat([proposals, scores.unsqueeze(1)], dim=1)[keep, :]
+        return dets[:self.nms_post]
+
+    def get_bboxes(self, cls_scores, bbox_preds, targets):
+        assert len(cls_scores) == len(bbox_preds)
+        num_levels = len(cls_scores)
+        featmap_sizes = [tuple(cls_scores[i].shape[-2:]) for i in range(num_levels)]
+        mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=cls_scores[0].device)
+        out = []
+        for img_id, target in enumerate(targets):
+            cls_list = [cls_scores[i][img_id].detach() for i in range(num_levels)]
+            reg_list = [bbox_preds[i][img_id].detach() for i in range(num_levels)]
+            out.append(self._get_bboxes_single(cls_list, reg_list, mlvl_anchors, target['img_size']))
+        return out
+
+    def _get_targets_single(self, anchors_list, valid_flag_list, target):
+        dev = anchors_list[0].device
+        gt_bboxes = torch.as_tensor(target["rboxes"]).to(dev).float().clone()
+        gt_bboxes[:, -1] *= -1
+        ign = target.get("rboxes_ignore")
+        gt_ignore = None
+        if ign is not None and torch.as_tensor(ign).numel() > 0:
+            gt_ignore = torch.as_tensor(ign).to(dev).float().clone()
+            gt_ignore[:, -1] *= -1
+        gt_labels = None
+        flat_anchors, valid_flags = torch.cat(anchors_list), torch.cat(valid_flag_list)
+        inside = anchor_inside_flags(flat_anchors, valid_flags, target["img_size"][:2], allowed_border=0)
+        if not bool(inside.any()):
+            return (None,) * 7
+        anchors = flat_anchors[inside, :]
+        a_type, g_type = get_bbox_type(anchors), get_bbox_type(gt_bboxes)
+        tgt = bbox2type(gt_bboxes, a_type)
+        tgt_ign = None if gt_ignore is None else bbox2type(gt_ignore, a_type)
+        assign_result = self.assigner.assign(anchors, tgt, tgt_ign, None if self.sampling else gt_labels)
+        sampling_result = self.sampler.sample(assign_result, anchors, tgt)
+        if a_type != g_type:
+            if gt_bboxes.numel() == 0:
+                sampling_result.pos_gt_bboxes = gt_bboxes.new_empty((0, get_bbox_dim(g_type)))
+            else:
+                sampling_result.pos_gt_bboxes = gt_bboxes[sampling_result.pos_assigned_gt_inds, :]
+        n = anchors.shape[0]
+        bbox_targets = anchors.new_zeros((n, self.reg_dim))
+        bbox_weights = anchors.new_zeros((n, self.reg_dim))
+        labels = anchors.new_full((n,), self.background_label, dtype=torch.long)
+        label_weights = anchors.new_zeros((n,))
+        pos_inds, neg_inds = sampling_result.pos_inds, sampling_result.neg_inds
+        if len(pos_inds) > 0:
+            pos_t = sampling_result.pos_gt_bboxes if self.reg_decoded_bbox else \
+                self.bbox_coder.encode(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes)
+            bbox_targets[pos_inds, :] = pos_t
+            bbox_weights[pos_inds, :] = 1.0
+            labels[pos_inds] = 1  # only the RPN passes gt_labels=None: FG is 1 (:323-325)
+            label_weights[pos_inds] = 1.0 if self.pos_weight <= 0 else self.pos_weight
+        if len(neg_inds) > 0:
+            label_weights[neg_inds] = 1.0
+        if self.unmap_outputs:
+            total = flat_anchors.size(0)
+            labels = self.unmap(labels, total, inside, fill=self.background_label)
+            label_weights = self.unmap(label_weights, total, inside)
+            bbox_targets = self.unmap(bbox_targets, total, inside)
+            bbox_weights = self.unmap(bbox_weights, total, inside)
+        return labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds, sampling_result
+
+    def get_targets(self, anchor_list, valid_flag_list, targets):
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        (all_labels, all_lw, all_bt, all_bw, pos_l, neg_l, _) = multi_apply(self._get_targets_single, anchor_list,
+                                                                             valid_flag_list, targets)
+        num_total_pos = sum(max(i.numel(), 1) for i in pos_l)
+        num_total_neg = sum(max(i.numel(), 1) for i in neg_l)
+        return (images_to_levels(all_labels, num_level_anchors), images_to_levels(all_lw, num_level_anchors),
+                images_to_levels(all_bt, num_level_anchors), images_to_levels(all_bw, num_level_anchors),
+                num_total_pos, num_total_neg)
+
+    def loss_single(self, cls_score, bbox_pred, anchors, labels, label_weights, bbox_targets, bbox_weights,
+                    num_total_samples):
+        labels, label_weights = labels.reshape(-1), label_weights.reshape(-1)
+        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
+        bbox_targets, bbox_weights = bbox_targets.reshape(-1, self.reg_dim), bbox_weights.reshape(-1, self.reg_dim)
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, self.reg_dim)
+        if self.reg_decoded_bbox:
+            bbox_pred = self.bbox_coder.decode(anchors.reshape(-1, anchors.size(-1)), bbox_pred)
+        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
+        return loss_cls, loss_bbox
+
+    def loss(self, cls_scores, bbox_preds, targets):
+        featmap_sizes = [tuple(f.shape[-2:]) for f in cls_scores]
+        assert len(featmap_sizes) == self.anchor_generator.num_levels
+        dev = cls_scores[0].device
+        mla = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
+        anchor_list = [mla for _ in range(len(targets))]
+        valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, t['pad_shape'], device=dev) for t in targets]
+        (labels_list, lw_list, bt_list, bw_list, npos, nneg) = self.get_targets(anchor_list, valid_flag_list, targets)
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        all_anchor_list = images_to_levels([torch.cat(a) for a in anchor_list], num_level_anchors)
+        losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list,
+                                              lw_list, bt_list, bw_list, num_total_samples=npos + nneg)
+        return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
+
+    def forward(self, features, targets):
+        outs = multi_apply(self.forward_single, features)
+        losses = self.loss(*outs, targets) if self.training else dict()
+        return self.get_bboxes(*outs, targets), losses

@@ -1,0 +1,113 @@
+"""Box-format conversions of the Oriented-RCNN path, torch twins of
+/root/reference/python/jdet/ops/bbox_transforms.py:501-671 (pure tensor math in the reference too)."""
+import numpy as np
+import torch
+
+__all__ = ["regular_theta", "regular_obb", "get_bbox_type", "get_bbox_dim", "rectpoly2obb", "poly2hbb", "obb2poly",
+           "obb2hbb", "hbb2poly", "hbb2obb", "bbox2type", "get_bbox_areas"]
+
+
+def regular_theta(theta, mode='180', start=-np.pi / 2):
+    assert mode in ['360', '180']
+    cycle = 2 * np.pi if mode == '360' else np.pi
+    return torch.remainder(theta - start, cycle) + start  # Python-style mod (Jittor's is unpinned)
+
+
+def regular_obb(obboxes):
+    x, y, w, h, theta = obboxes.unbind(dim=-1)
+    wide = w > h
+    w_r, h_r = torch.where(wide, w, h), torch.where(wide, h, w)
+    theta_r = regular_theta(torch.where(wide, theta, theta + np.pi / 2))
+    return torch.stack([x, y, w_r, h_r, theta_r], dim=-1)
+
+
+def get_bbox_type(bboxes, with_score=False):
+    dim = bboxes.size(-1) - (1 if with_score else 0)
+    return {4: 'hbb', 5: 'obb', 8: 'poly'}.get(dim, 'notype')
+
+
+def get_bbox_dim(bbox_type, with_score=False):
+    try:
+        dim = {'hbb': 4, 'obb': 5, 'poly': 8}[bbox_type]
+    except KeyError:
+        raise ValueError(f"don't know {bbox_type} bbox dim")
+    return dim + (1 if with_score else 0)
+
+
+def rectpoly2obb(polys):
+    theta = torch.atan2(-(polys[..., 3] - polys[..., 1]), polys[..., 2] - polys[..., 0])
+    Cos, Sin = torch.cos(theta), torch.sin(theta)
+    M = torch.stack([Cos, -Sin, Sin, Cos], dim=-1).view(*theta.shape, 2, 2)
+    x, y = polys[..., 0::2].mean(-1), polys[..., 1::2].mean(-1)
+    center = torch.stack([x, y], dim=-1).unsqueeze(-2)
+    cp = polys.view(*polys.shape[:-1], 4, 2) - center
+    rot = torch.matmul(cp, M.transpose(-1, -2))
+    w = rot[..., :, 0].max(-1)[0] - rot[..., :, 0].min(-1)[0]
+    h = rot[..., :, 1].max(-1)[0] - rot[..., :, 1].min(-1)[0]
+    return regular_obb(torch.stack([x, y, w, h, theta], dim=-1))
+
+
+def poly2hbb(polys):
+    p = polys.view(*polys.shape[:-1], polys.size(-1) // 2, 2)
+    return torch.cat([p.min(dim=-2)[0], p.max(dim=-2)[0]], dim=-1)
+
+
+def obb2poly(obboxes):
+    center, w, h, theta = torch.split(obboxes, [2, 1, 1, 1], dim=-1)
+    Cos, Sin = torch.cos(theta), torch.sin(theta)
+    v1 = torch.cat([w / 2 * Cos, -w / 2 * Sin], dim=-1)
+    v2 = torch.cat([-h / 2 * Sin, -h / 2 * Cos], dim=-1)
+    return torch.cat([center + v1 + v2, center + v1 - v2, center - v1 - v2, center - v1 + v2], dim=-1)
+
+
+def obb2hbb(obboxes):
+    center, w, h, theta = torch.split(obboxes, [2, 1, 1, 1], dim=-1)
+    Cos, Sin = torch.cos(theta), torch.sin(theta)
+    bias = torch.cat([(w / 2 * Cos).abs() + (h / 2 * Sin).abs(), (w / 2 * Sin).abs() + (h / 2 * Cos).abs()], dim=-1)
+    return torch.cat([center - bias, center + bias], dim=-1)
+
+
+def hbb2poly(hbboxes):
+    l, t, r, b = hbboxes.unbind(-1)
+    return torch.stack([l, t, r, t, r, b, l, b], dim=-1)
+
+
+def hbb2obb(hbboxes):
+    x = (hbboxes[..., 0] + hbboxes[..., 2]) * 0.5
+    y = (hbboxes[..., 1] + hbboxes[..., 3]) * 0.5
+    w = hbboxes[..., 2] - hbboxes[..., 0]
+    h = hbboxes[..., 3] - hbboxes[..., 1]
+    theta = torch.zeros_like(x)
+    o1 = torch.stack([x, y, w, h, theta], dim=-1)
+    o2 = torch.stack([x, y, h, w, theta - np.pi / 2], dim=-1)
+    return torch.where((w >= h)[..., None], o1, o2)
+
+
+def _poly2obb(polys):
+    raise NotImplementedError("poly2obb needs cv2.minAreaRect (bbox_transforms.py:547-575); not on the S2ANet/ORCNN train path")
+
+
+_type_func_map = {('poly', 'obb'): _poly2obb, ('poly', 'hbb'): poly2hbb, ('obb', 'poly'): obb2poly,
+                  ('obb', 'hbb'): obb2hbb, ('hbb', 'poly'): hbb2poly, ('hbb', 'obb'): hbb2obb}
+
+
+def bbox2type(bboxes, to_type):
+    assert to_type in ['hbb', 'obb', 'poly']
+    ori = get_bbox_type(bboxes)
+    if ori == 'notype':
+        raise ValueError('Not a bbox type')
+    return bboxes if ori == to_type else _type_func_map[(ori, to_type)](bboxes)
+
+
+def get_bbox_areas(bboxes):
+    t = get_bbox_type(bboxes)
+    if t == 'hbb':
+        wh = bboxes[..., 2:] - bboxes[..., :2]
+        return wh[..., 0] * wh[..., 1]
+    if t == 'obb':
+        return bboxes[..., 2] * bboxes[..., 3]
+    if t == 'poly':
+        pts = bboxes.view(*bboxes.size()[:-1], 4, 2)
+        roll = torch.roll(pts, 1, dims=-2)
+        return 0.5 * (pts[..., 0] * roll[..., 1] - roll[..., 0] * pts[..., 1]).sum(-1).abs()
+    raise ValueError('The type of bboxes is notype')
