@@ -28,12 +28,20 @@ __global__ __launch_bounds__(ASG_NT) void assign_row_kernel(const float* __restr
   const float* p = ov + (long long)row * A;
   float best = -INFINITY;
   int arg = 0x7fffffff;
-  for (int j = threadIdx.x; j < A; j += ASG_NT) {
-    float v = p[j];
-    if (v > best) {  // ascending j per thread => first index kept on ties
-      best = v;
-      arg = j;
+  constexpr int U = 4;  // 4 independent loads in flight per thread, consumed in ascending j
+  for (int j0 = threadIdx.x; j0 < A; j0 += U * ASG_NT) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * ASG_NT;
+      v[u] = j < A ? p[j] : -INFINITY;
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (v[u] > best) {  // ascending j per thread => first index kept on ties
+        best = v[u];
+        arg = j0 + u * ASG_NT;
+      }
   }
   // wave reduce (value desc, index asc)
   for (int off = 32; off > 0; off >>= 1) {
@@ -79,23 +87,35 @@ __global__ __launch_bounds__(ASG_NT) void assign_col_kernel(
     if (labels) labels[o] = labels_filled;
     return;
   }
-  float best = ov[(long long)r0 * A + j];
+  // Rows are consumed strictly in order (first-index argmax, last-row low-quality match), but the
+  // loads of 8 consecutive rows are issued together: the loop was latency-bound (one dependent
+  // HBM round trip per row, 124 us for 1112 rows x 21 824 columns), now it streams.
+  float best = -INFINITY;
   int arg = 0;
   int lowq = -1;
-  {
-    float rm = row_max[r0];
-    if (match_low_quality && rm >= min_pos_iou)
-      if (gt_max_assign_all ? (best == rm) : (row_arg[r0] == j)) lowq = 0;
-  }
-  for (int r = r0 + 1; r < r1; ++r) {
-    float v = ov[(long long)r * A + j];
-    if (v > best) {
-      best = v;
-      arg = r - r0;
+  constexpr int U = 8;
+  for (int rb = r0; rb < r1; rb += U) {
+    float v[U], rm[U];
+    int ra[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = min(rb + u, r1 - 1);
+      v[u] = ov[(long long)r * A + j];
+      rm[u] = row_max[r];  // wave-uniform -> scalar loads
+      ra[u] = row_arg[r];
     }
-    float rm = row_max[r];  // wave-uniform -> scalar load
-    if (match_low_quality && rm >= min_pos_iou)
-      if (gt_max_assign_all ? (v == rm) : (row_arg[r] == j)) lowq = r - r0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + u;
+      if (r < r1) {
+        if (r == r0 || v[u] > best) {  // r == r0: seed with the first row (keeps NaN semantics of `>`)
+          best = v[u];
+          arg = r - r0;
+        }
+        if (match_low_quality && rm[u] >= min_pos_iou)
+          if (gt_max_assign_all ? (v[u] == rm[u]) : (ra[u] == j)) lowq = r - r0;
+      }
+    }
   }
   int gi = -1;
   if (best >= neg_lo && best < neg_hi) gi = 0;   // assigner.py:138-145
