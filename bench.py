@@ -47,13 +47,29 @@ def s2anet_cfg():
     return Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
 
 
-def event_time(fn, iters, warmup=3):
-    """Average device time of fn() in seconds, HIP events on torch's current stream
-    (the stream every rsdet_* launch goes to)."""
+def event_time(fn, iters, warmup=3, graph=True):
+    """Average device time of fn() in seconds: HIP events on torch's current stream (the stream every
+    rsdet_* launch goes to) around a replayed hipGraph of `iters` calls, so that the host-side cost of the
+    ctypes call / torch.empty (10-25 us, comparable to these kernels) is not billed to the kernel."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(iters):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            s.record()
+            g.replay()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e) * 1e-3 / iters
+        except Exception:  # capture not possible (e.g. an op syncs): fall back to eager timing
+            torch.cuda.synchronize()
     s.record()
     for _ in range(iters):
         fn()
@@ -80,7 +96,10 @@ def kernel_rooflines(device, targets):
     t = event_time(lambda: ops.box_iou_rotated_grouped(gt, ro, max(ks), anchors, out=ov), 50)
     by = 20 * (n1 + A) + 4 * n1 * A
     out["box_iou_rotated(prepare+filter+clip)"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6,
+                                         frac=by / t / 1e9 / HBM_PEAK_GBS,
+                                         # HBM bytes per launch from the rocprofv3 PMC passes of this very shape
+                                         # (profiles/r01_d_pmc_hbm_traffic.txt: WRITE 50.8+1.1+0.9 MB, FETCH 2x5.7 MB)
+                                         traffic=64.2e6 if (n1, A) == (556, 21824) else None, us=t * 1e6,
                                          mpairs_per_s=n1 * A / t / 1e6, shape="sumK=%d x A=%d (B=%d)" % (n1, A, len(ks)))
     # -- assignment (a4): two passes over the matrix + outputs
     t = event_time(lambda: ops.assign_wrt_overlaps(ov, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0), 50)
@@ -158,7 +177,7 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the HIP hot path")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())  # (% only matters for the 1-GPU gloo smoke test)
     torch.cuda.set_device(device)
     from rs_detection_amd import _lib
     _lib.load()
