@@ -6,22 +6,25 @@
 //   kernel :413-461, CPU loop :487-500;  _v1.py:507-524.
 //
 // Shape of the problem (S2ANet: K gts x 21 824 anchors, ~1.2 % of pairs overlap): a dense
-// fp32 matrix must be written (HBM-store-bound) but the arithmetic lives in a sparse,
-// badly balanced tail (a 16 x 256 tile holds anything from 0 to ~420 overlapping pairs).
-// Three launches on one stream, no host round trip:
-//   iou_prepare  fp64 sincos once per box -> 40-B "prepared box" (workspace); zeroes the
-//                global work-queue counter.
-//   iou_filter   tile = 16 rows x 256 columns per workgroup.  A thread owns a column, walks
-//                the prepared rows in LDS, applies a bounding-circle test then a separating-
-//                axis test and stores exact 0.0f for disjoint pairs (lanes = consecutive
-//                columns: coalesced 256-B stores).  Survivors are appended to an LDS list with
-//                wave ballot + popcount prefix and flushed to a GLOBAL work queue (64 shards) with
-//                one returning atomic per workgroup.
+// fp32 matrix must be written (HBM-store-bound, ~8 us for 48 MB) but the arithmetic lives in a
+// sparse tail (~2 800 lane-instructions per overlapping pair, ALU-bound) and everything in
+// between is latency.  Three launches on one stream, no host round trip:
+//   iou_prepare  fp64 sincos once per box -> 40-B "prepared box" (workspace) + the bounding box
+//                of every 64 consecutive column circles; zeroes the queue counters.
+//   iou_filter   tile = 16 rows x 256 columns per workgroup.  Issues the zero fill of the whole
+//                tile first (lanes = consecutive columns: 256-B stores) and never waits for it;
+//                underneath, whole (row, 64 columns) strips are culled against the column
+//                bounding box, live strips get the bounding-circle test, the circle survivors
+//                are compacted in LDS and get the separating-axis test on dense lanes.  What
+//                is left goes to a GLOBAL work queue (64 shards, one returning atomic per
+//                workgroup).
 //   iou_clip     a fixed grid drains the global queue, FOUR LANES PER PAIR (rsdet_geom.h):
 //                perfect balance whatever the tile densities were, ~1.5 us latency per pair
-//                instead of ~15 us for a one-thread clipper.
+//                instead of ~15 us for a one-thread clipper; overwrites the zeros of its pairs.
 // If the queue overflows (more than its capacity of overlapping pairs) the overflowing
 // workgroup clips its own survivors in place -- slower, still exact.
+// Tried and measured slower: one wave per 32 x 64 strip set without LDS, and the zero
+// fill moved into a store-only wave of iou_clip behind a live-strip bitmap.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,27 +49,59 @@ struct WorkItem {
   int pad;
 };
 
-__global__ void iou_prepare_kernel(const float* __restrict__ boxes1, long long n1, int stride1,
-                                   BoxPre* __restrict__ pre1, const float* __restrict__ boxes2,
-                                   long long n2, int stride2, BoxPre* __restrict__ pre2,
-                                   unsigned* __restrict__ counter) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < IOU_SHARDS) counter[i * 32] = 0u;
-  if (i < n1)
-    pre1[i] = prepare_box(boxes1 + i * stride1);
-  else if (i - n1 < n2)
-    pre2[i - n1] = prepare_box(boxes2 + (i - n1) * stride2);
+// One wave per 64 boxes.  Workgroups [0, nb1) prepare boxes1; the rest prepare boxes2, aligned to
+// the 64-column words of the IoU matrix (cw words per column slab), and also reduce the padded
+// bounding box of their 64 bounding circles: iou_filter rejects whole (row, 64 columns) strips
+// against it before any per-pair work.
+__global__ __launch_bounds__(64) void iou_prepare_kernel(
+    const float* __restrict__ boxes1, int n1, int stride1, BoxPre* __restrict__ pre1, int nb1,
+    const float* __restrict__ boxes2, int n2, int stride2, BoxPre* __restrict__ pre2, int cw,
+    float4* __restrict__ colbox, unsigned* __restrict__ counter) {
+  const int lane = threadIdx.x;
+  if (blockIdx.x == 0) counter[lane * 32] = 0u;
+  if ((int)blockIdx.x < nb1) {
+    const int i = blockIdx.x * 64 + lane;
+    if (i < n1) pre1[i] = prepare_box(boxes1 + (long long)i * stride1);
+    return;
+  }
+  const int word = blockIdx.x - nb1;  // slab * cw + k
+  const int slab = word / cw, k = word - slab * cw;
+  const int col = k * 64 + lane;
+  float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+  if (col < n2) {
+    const long long j = (long long)slab * n2 + col;
+    const BoxPre p = prepare_box(boxes2 + j * stride2);
+    pre2[j] = p;
+    const float pad = 1.001f * p.rad + 1e-5f * (fabsf(p.cx) + fabsf(p.cy));
+    const bool finite = fabsf(p.cx) < INFINITY && fabsf(p.cy) < INFINITY && pad < INFINITY;  // false for NaN too
+    x0 = finite ? p.cx - pad : -INFINITY;
+    y0 = finite ? p.cy - pad : -INFINITY;
+    x1 = finite ? p.cx + pad : INFINITY;
+    y1 = finite ? p.cy + pad : INFINITY;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    x0 = fminf(x0, __shfl_xor(x0, off));
+    y0 = fminf(y0, __shfl_xor(y0, off));
+    x1 = fmaxf(x1, __shfl_xor(x1, off));
+    y1 = fmaxf(y1, __shfl_xor(y1, off));
+  }
+  if (lane == 0) colbox[word] = make_float4(x0, y0, x1, y1);
 }
 
 template <int VERSION>
 __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
     const BoxPre* __restrict__ pre1, int n1, const BoxPre* __restrict__ pre2, int n2,
-    const int* __restrict__ row_offsets, long long group_stride2, float* __restrict__ out,
-    WorkItem* __restrict__ queue, unsigned* __restrict__ counter, unsigned capacity) {
+    const float4* __restrict__ colbox, int cw, const int* __restrict__ row_offsets,
+    long long group_stride2, float* __restrict__ out, WorkItem* __restrict__ queue,
+    unsigned* __restrict__ counter, unsigned capacity) {
   __shared__ BoxPre s_row[IOU_TI];
+  __shared__ BoxPre s_col[IOU_NT];
+  // pairs whose bounding circles touch; compacted IN PLACE to the pairs the separating-axis test
+  // could not reject (the survivors)
   __shared__ unsigned short s_list[IOU_TI * IOU_NT];
   __shared__ F2 s_pts[kQuadSlots * 16];  // overflow path only: one wave (16 quads) clips
-  __shared__ int s_count;
+  __shared__ int s_c1, s_c2;
   __shared__ unsigned s_base;
 
   const int tid = threadIdx.x;
@@ -78,49 +113,116 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
   // pre2 (group_stride2 boxes apart; 0: one column set shared by all).
   int row_begin = 0, row_end = n1;
   long long slab = 0;
+  int slab_word = 0;
   if (row_offsets) {
     row_begin = row_offsets[blockIdx.z];
     row_end = row_offsets[blockIdx.z + 1];
     slab = (long long)blockIdx.z * group_stride2;
+    if (group_stride2 != 0) slab_word = blockIdx.z * cw;
   }
   const BoxPre* p2 = pre2 + slab;
   const int row0 = row_begin + blockIdx.y * IOU_TI;
   if (row0 >= row_end) return;
   const int nrows = min(IOU_TI, row_end - row0);
-
-  if (tid == 0) s_count = 0;
-  if (tid < nrows) s_row[tid] = pre1[row0 + tid];
   const int col = col0 + tid;
   const bool col_ok = col < n2;
-  BoxPre mine;
-  if (col_ok) mine = p2[col];
-  __syncthreads();
 
-  // ---- zero-fill + survivor list (bounding circles, then separating axes)
-  for (int i = 0; i < nrows; ++i) {
+  // ---- stage the tile's boxes in LDS, then start the zero fill (every pair of the tile; survivors
+  // are rewritten by iou_clip in the next launch).  The stores are never waited for: all barriers
+  // below order LDS only (lds_barrier), so the store stream -- the HBM-bound part of the whole
+  // call -- drains underneath the latency-bound phases.  vmcnt retires in order, though, and the
+  // returning queue atomic would sit behind the stores: wave 0 owns that atomic and issues its
+  // share of the fill after it.
+  const BoxPre mine = p2[min(col, n2 - 1)];
+  const int kw = (col0 >> 6) + (tid >> 6);
+  float4 cb = colbox[slab_word + min(kw, cw - 1)];
+  if (kw >= cw) cb = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);  // empty strip
+  if (tid < nrows) s_row[tid] = pre1[row0 + tid];
+  if (col_ok) s_col[tid] = mine;
+  if (tid == 0) {
+    s_c1 = 0;
+    s_c2 = 0;
+  }
+  auto zero_fill = [&]() {
+    if (!col_ok) return;
+    float* o = out + (long long)row0 * n2 + col;
+    if (nrows == IOU_TI) {
+#pragma unroll
+      for (int i = 0; i < IOU_TI; ++i) o[(long long)i * n2] = 0.0f;
+    } else {
+      for (int i = 0; i < nrows; ++i) o[(long long)i * n2] = 0.0f;
+    }
+  };
+  // pin the strip box in registers here: a wait for it placed after the fill would be a vmcnt(0)
+  asm volatile("" : "+v"(cb.x), "+v"(cb.y), "+v"(cb.z), "+v"(cb.w));
+  const bool fill_late = tid < 64;
+  if (!fill_late) zero_fill();
+  lds_barrier();
+
+  // ---- strip culling: lane i < nrows tests row i's circle against the bounding box of this wave's
+  // 64 column circles (iou_prepare).  Both sides carry a 1e-3 relative pad, so a culled strip
+  // satisfies surely_disjoint() for each of its pairs; NaN/Inf boxes are never culled.
+  static_assert(IOU_TI <= 32, "row mask is 32 bits wide");
+  bool lv = false;
+  if (lane < nrows) {
+    const float rx = s_row[lane].cx, ry = s_row[lane].cy;
+    const float dx = fmaxf(fmaxf(cb.x - rx, rx - cb.z), 0.f), dy = fmaxf(fmaxf(cb.y - ry, ry - cb.w), 0.f);
+    const float thr = 1.001f * s_row[lane].rad + 1e-5f * (fabsf(rx) + fabsf(ry));
+    lv = !(dx * dx + dy * dy > thr * thr);
+  }
+  unsigned live = (unsigned)__ballot(lv);
+
+  // ---- pass A: bounding circles of the live strips (a handful of instructions per pair, no
+  // divergence).  The separating-axis test used to sit here: ~3.5 % of the pairs reach it, i.e.
+  // nearly every wave paid for it on nearly every row.
+  while (live) {
+    const int i = __builtin_ctz(live);
+    live &= live - 1u;
     bool cand = false;
     if (col_ok) {
-      const BoxPre r = s_row[i];
-      cand = !surely_disjoint(r, mine);
-      if (cand) cand = !sat_disjoint<VERSION>(r, mine);
-      if (!cand) out[(long long)(row0 + i) * n2 + col] = 0.0f;
+      const float dx = s_row[i].cx - mine.cx, dy = s_row[i].cy - mine.cy;
+      const float r = s_row[i].rad + mine.rad;
+      cand = !(dx * dx + dy * dy > r * r * 1.0001f);  // == !surely_disjoint(s_row[i], mine)
     }
     unsigned long long m = __ballot(cand);
     if (m) {
       int base = 0;
-      if (lane == 0) base = atomicAdd(&s_count, __popcll(m));
+      if (lane == 0) base = atomicAdd(&s_c1, __popcll(m));
       base = __shfl(base, 0);
       if (cand) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((i << 8) | tid);
     }
   }
-  __syncthreads();
+  lds_barrier();
+
+  // ---- pass B: separating axes on the compacted list (dense lanes).  In-place compaction is safe:
+  // by the barrier every entry below q0 + IOU_NT has been read, and at most that many were kept.
+  const int n_cand = s_c1;
+  for (int q0 = 0; q0 < n_cand; q0 += IOU_NT) {
+    const int q = q0 + tid;
+    unsigned e = 0;
+    if (q < n_cand) e = s_list[q];
+    lds_barrier();
+    const bool keep = q < n_cand && !sat_disjoint<VERSION>(s_row[e >> 8], s_col[e & 255]);
+    unsigned long long m = __ballot(keep);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_c2, __popcll(m));
+      base = __shfl(base, 0);
+      if (keep) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
+    }
+  }
+  lds_barrier();
 
   // ---- flush the survivors to the global work queue (one returning atomic per workgroup)
-  const int total = s_count;
-  if (total == 0) return;
+  const int total = s_c2;
+  if (total == 0) {
+    if (fill_late) zero_fill();
+    return;
+  }
   const unsigned shard = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u) % IOU_SHARDS;
   if (tid == 0) s_base = atomicAdd(counter + shard * 32, (unsigned)total);
-  __syncthreads();
+  lds_barrier();
+  if (fill_late) zero_fill();
   const unsigned base = s_base;  // capacity = entries per shard
   const int fit = base >= capacity ? 0 : (int)min((unsigned)total, capacity - base);
   queue += (size_t)shard * capacity;
@@ -133,15 +235,18 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
     w.pad = 0;
     queue[base + q] = w;
   }
-  // ---- queue overflow: clip the rest here (same routine, worse balance)
+  // ---- queue overflow: clip the rest here (same routine, worse balance).  __syncthreads() drains
+  // this workgroup's zero stores (s_waitcnt vmcnt(0) before s_barrier), so the values written
+  // below land after them.
+  if (fit == total) return;
+  __syncthreads();
   if (tid >= 64) return;
   const int quad = tid >> 2;
   F2* qscr = s_pts + quad * kQuadSlots;
   for (int q = fit + quad; q < total; q += 16) {
     unsigned e = s_list[q];
     const int i = (int)(e >> 8), j = (int)(e & 255);
-    const BoxPre bb = p2[col0 + j];
-    float v = pair_iou_quad<VERSION>(s_row[i], bb, qscr, lane);
+    float v = pair_iou_quad<VERSION>(s_row[i], s_col[j], qscr, lane);
     if ((tid & 3) == 0) out[(long long)(row0 + i) * n2 + col0 + j] = v;
   }
 }
@@ -154,6 +259,10 @@ __global__ __launch_bounds__(CLIP_NT) void iou_clip_kernel(
   __shared__ F2 s_pts[kQuadSlots * (CLIP_NT / 4)];
   __shared__ unsigned s_end[IOU_SHARDS];  // inclusive prefix sums of the shard fill levels
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef RSDET_POISON_LDS  // debug builds only: stale scratch must never reach a result
+  for (int k = tid; k < kQuadSlots * (CLIP_NT / 4); k += CLIP_NT) s_pts[k] = F2{RSDET_POISON_LDS, RSDET_POISON_LDS};
+  __syncthreads();
+#endif
   if (tid < 64) {
     static_assert(IOU_SHARDS == 64, "one wave scans the shard counters");
     unsigned c = min(counter[tid * 32], capacity);
@@ -194,10 +303,14 @@ static inline long long queue_cap(long long n1, long long n2) {
   long long tile = (long long)IOU_TI * IOU_NT;
   return per < tile ? (pairs < tile ? pairs : tile) : per;
 }
+static inline size_t colbox_bytes(long long n2_total, long long n2) {  // one float4 per (slab, 64 columns)
+  return ((size_t)(n2_total / n2) * (size_t)((n2 + 63) / 64) * 16 + 255) & ~(size_t)255;
+}
 
 extern "C" size_t rsdet_box_iou_rotated_ws_size(int n1, long long n2_total, int n2) {
   if (n1 <= 0 || n2_total <= 0 || n2 <= 0) return 0;
-  return pre_bytes(n1) + pre_bytes(n2_total) + IOU_SHARDS * 128 + (size_t)queue_cap(n1, n2) * IOU_SHARDS * sizeof(WorkItem);
+  return pre_bytes(n1) + pre_bytes(n2_total) + IOU_SHARDS * 128 + colbox_bytes(n2_total, n2) +
+         (size_t)queue_cap(n1, n2) * IOU_SHARDS * sizeof(WorkItem);
 }
 
 static int iou_launch(const float* boxes1, int n1, int stride1, const int* row_offsets, int n_groups,
@@ -207,26 +320,34 @@ static int iou_launch(const float* boxes1, int n1, int stride1, const int* row_o
   if (!ws || ((uintptr_t)ws & 15) || ws_bytes < rsdet_box_iou_rotated_ws_size(n1, n2_total, n2))
     return RSDET_EINVAL;
   char* w = (char*)ws;
-  BoxPre* pre1 = (BoxPre*)w;
-  BoxPre* pre2 = (BoxPre*)(w + pre_bytes(n1));
-  unsigned* counter = (unsigned*)(w + pre_bytes(n1) + pre_bytes(n2_total));
-  WorkItem* queue = (WorkItem*)(w + pre_bytes(n1) + pre_bytes(n2_total) + IOU_SHARDS * 128);
+  size_t off = 0;
+  BoxPre* pre1 = (BoxPre*)(w + off);
+  off += pre_bytes(n1);
+  BoxPre* pre2 = (BoxPre*)(w + off);
+  off += pre_bytes(n2_total);
+  unsigned* counter = (unsigned*)(w + off);
+  off += IOU_SHARDS * 128;
+  float4* colbox = (float4*)(w + off);
+  off += colbox_bytes(n2_total, n2);
+  WorkItem* queue = (WorkItem*)(w + off);
+  const int cw = (n2 + 63) / 64;
   const unsigned cap = (unsigned)queue_cap(n1, n2);
-  hipLaunchKernelGGL(iou_prepare_kernel, dim3((unsigned)((n1 + n2_total + 63) / 64)), dim3(64), 0, s, boxes1,
-                     (long long)n1, stride1, pre1, boxes2, n2_total, stride2, pre2, counter);
+  const int nb1 = (n1 + 63) / 64, nb2 = (int)(n2_total / n2) * cw;
+  hipLaunchKernelGGL(iou_prepare_kernel, dim3(nb1 + nb2), dim3(64), 0, s, boxes1, n1, stride1, pre1, nb1, boxes2,
+                     n2, stride2, pre2, cw, colbox, counter);
   dim3 grid((n2 + IOU_NT - 1) / IOU_NT, (max_rows + IOU_TI - 1) / IOU_TI, row_offsets ? n_groups : 1);
   const long long gs = (row_offsets && group_stride2 != 0) ? (long long)n2 : 0LL;
   // enough quads for the queue, at most the resident set of the chip
   long long need = ((long long)cap * IOU_SHARDS + CLIP_NT / 4 - 1) / (CLIP_NT / 4);
   const int clip_blocks = (int)(need < CLIP_BLOCKS ? need : CLIP_BLOCKS);
   if (version == 0) {
-    hipLaunchKernelGGL(iou_filter_kernel<0>, grid, dim3(IOU_NT), 0, s, pre1, n1, pre2, n2, row_offsets, gs, ious,
-                       queue, counter, cap);
+    hipLaunchKernelGGL(iou_filter_kernel<0>, grid, dim3(IOU_NT), 0, s, pre1, n1, pre2, n2, colbox, cw, row_offsets, gs,
+                       ious, queue, counter, cap);
     hipLaunchKernelGGL(iou_clip_kernel<0>, dim3(clip_blocks), dim3(CLIP_NT), 0, s, pre1, pre2, n2, queue, counter,
                        cap, ious);
   } else {
-    hipLaunchKernelGGL(iou_filter_kernel<1>, grid, dim3(IOU_NT), 0, s, pre1, n1, pre2, n2, row_offsets, gs, ious,
-                       queue, counter, cap);
+    hipLaunchKernelGGL(iou_filter_kernel<1>, grid, dim3(IOU_NT), 0, s, pre1, n1, pre2, n2, colbox, cw, row_offsets, gs,
+                       ious, queue, counter, cap);
     hipLaunchKernelGGL(iou_clip_kernel<1>, dim3(clip_blocks), dim3(CLIP_NT), 0, s, pre1, pre2, n2, queue, counter,
                        cap, ious);
   }

@@ -224,6 +224,11 @@ __device__ __forceinline__ void lds_wave_order() { asm volatile("" ::: "memory")
 // All 4 lanes of a quad must call this with the same (a, b); the result is quad-uniform.
 // No arrays of corners on purpose: an indexed corner table is demoted to private scratch memory
 // by the compiler (measured 3 us per pair, and its vmcnt waits drain every older global store).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global
+// store of the wave to be acknowledged (s_waitcnt vmcnt(0)), which would stall a kernel that keeps
+// a long zero-fill store stream in flight underneath its LDS phases.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kQuadSlots = 25;  // 24 used; stride 25 x 8 B = 50 dwords: the 16 quads of a wave hit distinct LDS banks
 
 template <int VERSION>
@@ -336,6 +341,7 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
       }
       if ((double)d[1] > 1e-8) {  // reference's k == 1 (:206-212); otherwise serial path
         F2* ring = qscr + 16;  // slots 16..23: sorted ring; 8..15: fan terms (both free when n <= 8)
+        unsigned used = 0u;    // ranks handed out by this lane
         // lane l ranks elements l and l + 4 of q[1..n)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -354,9 +360,18 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
           }
           if (kk == 0)
             ring[0] = q[0];
-          else if (kk < n)
+          else if (kk < n) {
             ring[1 + rank] = qk;
+            used |= 1u << rank;
+          }
         }
+        // The tolerance predicate is not a strict weak order: near-collinear points can form cycles
+        // (a < b < c < a).  A tournament is transitive iff its scores are all distinct, so unless the
+        // ranks of the quad are exactly {0 .. n-2} the ring has a slot written twice and a stale one:
+        // leave such pairs to the serial path, which replays the reference's insertion sort.
+        used |= (unsigned)__builtin_amdgcn_mov_dpp((int)used, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+        used |= (unsigned)__builtin_amdgcn_mov_dpp((int)used, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+        const bool ranks_ok = used == (1u << (n - 1)) - 1u;
         lds_wave_order();
         // ring[l-2 .. l+5] covers the neighbourhoods of both ranks owned by this lane
         F2 w[8];
@@ -367,7 +382,7 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
         bool pop = (l >= 2 && l < n && f2cross(f2sub(w[2], w[0]), f2sub(w[1], w[0])) >= 0) ||
                    (l + 4 < n && f2cross(f2sub(w[6], w[4]), f2sub(w[5], w[4])) >= 0);
         const unsigned popm = (unsigned)(__ballot(pop) >> qsh) & 15u;
-        if (popm == 0u) {
+        if (popm == 0u && ranks_ok) {
           float* terms = reinterpret_cast<float*>(qscr + 8);
           terms[l] = fabsf(f2cross(f2sub(w[2], s0), f2sub(w[3], s0)));
           terms[l + 4] = fabsf(f2cross(f2sub(w[6], s0), f2sub(w[7], s0)));

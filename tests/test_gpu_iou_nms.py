@@ -48,6 +48,34 @@ def test_iou_degenerate(cuda, oracle_c, version):
     assert np.abs(got - want).max() <= IOU_TOL
 
 
+@pytest.mark.parametrize("version", [0, 1])
+def test_iou_near_collinear_pairs_one_per_launch(cuda, oracle_c, version):
+    """Near-parallel boxes sharing edges: the reference's tolerance sort predicate is not transitive on
+    their (almost collinear) intersection points.  One pair per launch, so that the clipper's LDS scratch
+    holds whatever the previous kernel left there: a fast path that trusted an inconsistent ranking used
+    to read a stale slot (NaN / -1.0 on a freshly booted GPU).  Regression: [20,10,20,10,0] x
+    [10,10,20,10,1e-4] must give the reference's 6.2644885e-06."""
+    from rs_detection_amd.ops.box_iou_rotated import _iou
+    rng = np.random.default_rng(11)
+    a = [np.array([20., 10., 20., 10., 0.], np.float32)]
+    b = [np.array([10., 10., 20., 10., 1e-4], np.float32)]
+    for _ in range(40):
+        cx, cy, w, h = rng.uniform(5, 50, 4).astype(np.float32)
+        th = np.float32(rng.choice([0.0, np.pi / 2, rng.uniform(-3, 3)]))
+        eps = np.float32(rng.choice([1e-4, -1e-4, 3e-5, 1e-3]))
+        along = np.array([np.cos(th), np.sin(th)], np.float32) * w * np.float32(rng.choice([0.5, 1.0, 0.25]))
+        a.append(np.array([cx, cy, w, h, th], np.float32))
+        b.append(np.array([cx + along[0], cy + along[1], w, h, th + eps], np.float32))
+    a, b = np.stack(a), np.stack(b)
+    for i in range(len(a)):
+        want = oracle_c.box_iou_rotated(a[i:i + 1], b[i:i + 1], version)
+        got = _iou(_t(a[i:i + 1], cuda), _t(b[i:i + 1], cuda), version).cpu().numpy()
+        assert np.isfinite(got).all(), (i, a[i], b[i], got)
+        assert np.abs(got - want).max() <= IOU_TOL, (i, a[i], b[i], got, want)
+    want0 = oracle_c.box_iou_rotated(a[:1], b[:1], 0)
+    assert want0.view(np.int32)[0, 0] == np.float32(6.2644885e-06).view(np.int32)
+
+
 def test_iou_s2anet_anchor_grid(cuda, oracle_c):
     """gt x the exact 21 824-anchor S2ANet grid (SURVEY 8d micro-bench shape, K=16)."""
     from rs_detection_amd import ops
