@@ -10,12 +10,17 @@
 //   2. nms_mask    : upper-triangular 64x64 tiles.  Cheap pass (label gate +
 //                    bounding circles) fills an LDS queue via wave ballot /
 //                    popcount prefix; the queue is drained densely through the
-//                    exact clipper; hits set bits with LDS 64-bit atomicOr; one
-//                    u64 word per (row, column block) goes to HBM.
+//                    exact clipper; hits set bits with LDS 64-bit atomicOr.  Output is
+//                    SPARSE: the non-zero (row, column block) words of a tile are appended
+//                    to the row block's entry list (one returning atomic per tile) -- a
+//                    64-box block suppresses into a handful of column blocks, and the sweep,
+//                    which runs on ONE CU, is bound by what it has to pull through that
+//                    CU's memory pipe (dense rows: 64 KB per block step, measured 1.4 us).
+//                    The diagonal tile goes out transposed (diag_t) for the sweep's fixpoint.
 //   3. nms_sweep   : one workgroup walks the 64-box blocks in score order.  Wave 0
-//                    resolves the diagonal tile in registers (v_readlane chain),
-//                    then all waves OR the kept rows' words into the LDS `removed`
-//                    bitmap with coalesced reads.
+//                    resolves the diagonal tile as a fixpoint over wave ballots; all waves
+//                    OR the entries of the kept rows (prefetched two blocks ahead) into
+//                    the LDS `removed` bitmap.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,9 +37,17 @@ struct NmsBox {
 
 constexpr int NMS_NT = 256;
 
+struct NmsEntry {           // one non-zero 64-bit word of the suppression matrix
+  unsigned long long bits;  // bit j: the row's box suppresses box 64*cblock + j
+  int cblock;
+  int row;                  // row inside its 64-box block
+};  // 16 B
+
 __global__ void nms_prepare_kernel(const float* __restrict__ dets, int n, int box_len,
-                                   const int* __restrict__ order, NmsBox* __restrict__ sorted) {
+                                   const int* __restrict__ order, NmsBox* __restrict__ sorted,
+                                   unsigned* __restrict__ blk_cnt) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < (n + 63) / 64) blk_cnt[p] = 0u;
   if (p >= n) return;
   const float* b = dets + (long long)order[p] * box_len;
   NmsBox o;
@@ -44,10 +57,30 @@ __global__ void nms_prepare_kernel(const float* __restrict__ dets, int n, int bo
   sorted[p] = o;
 }
 
+// One wave: lane = row of tile (rb, cbk); append the non-zero words to row block rb's entry list.
+__device__ __forceinline__ void nms_emit_entries(unsigned long long word, int lane, int rb, int cbk, int col_blocks,
+                                                 NmsEntry* __restrict__ entries, unsigned* __restrict__ blk_cnt) {
+  const unsigned long long nz = __ballot(word != 0ull);
+  if (nz == 0ull) return;
+  unsigned base = 0u;
+  if (lane == 0) base = atomicAdd(blk_cnt + rb, (unsigned)__popcll(nz));
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  if (word != 0ull) {
+    NmsEntry e;
+    e.bits = word;
+    e.cblock = cbk;
+    e.row = lane;
+    // capacity of a row block's list: 64 rows x col_blocks words (the dense size), never exceeded
+    entries[(size_t)rb * 64 * col_blocks + base + __popcll(nz & ((1ull << lane) - 1ull))] = e;
+  }
+}
+
 template <bool GE>
 __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restrict__ sorted, int n,
                                                           float thr, int col_blocks,
-                                                          unsigned long long* __restrict__ mask) {
+                                                          NmsEntry* __restrict__ entries,
+                                                          unsigned* __restrict__ blk_cnt,
+                                                          unsigned long long* __restrict__ diag_t) {
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;  // lower triangle never read by the sweep
   __shared__ F2 s_pts[kQuadSlots * (NMS_NT / 4)];
@@ -55,7 +88,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
   __shared__ NmsBox s_col[64];
   __shared__ unsigned long long s_mask[64];
   __shared__ unsigned short s_queue[64 * 64];
-  __shared__ int s_count;
+  __shared__ int s_count, s_count2;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rows = min(64, n - rb * 64), cols = min(64, n - cbk * 64);
@@ -66,16 +99,20 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
     int c = tid - 64;
     if (c < cols) s_col[c] = sorted[cbk * 64 + c];
   }
-  if (tid == 0) s_count = 0;
+  if (tid == 0) {
+    s_count = 0;
+    s_count2 = 0;
+  }
   __syncthreads();
 
-  // cheap pass: wave w covers rows w, w+4, ...; lane = column
+  // pass A: wave w covers rows w, w+4, ...; lane = column.  Label gate + bounding circles only: a
+  // handful of instructions per pair and no divergence (the separating-axis test used to sit here
+  // and was paid by the whole wave whenever one lane reached it).
   for (int i = wave; i < rows; i += 4) {
     bool cand = false;
     if (lane < cols) {
       bool later = (cbk > rb) || (lane > i);
-      cand = later && s_row[i].label == s_col[lane].label &&
-             !surely_disjoint(s_row[i].p, s_col[lane].p) && !sat_disjoint<0>(s_row[i].p, s_col[lane].p);
+      cand = later && s_row[i].label == s_col[lane].label && !surely_disjoint(s_row[i].p, s_col[lane].p);
     }
     unsigned long long m = __ballot(cand);
     if (m) {
@@ -86,8 +123,26 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
     }
   }
   __syncthreads();
+  // pass B: separating axes on the compacted list (dense lanes), compacted in place: by the barrier
+  // every entry below q0 + NMS_NT has been read, and at most that many were kept.
+  const int n_cand = s_count;
+  for (int q0 = 0; q0 < n_cand; q0 += NMS_NT) {
+    const int q = q0 + tid;
+    unsigned e = 0;
+    if (q < n_cand) e = s_queue[q];
+    __syncthreads();
+    const bool keep = q < n_cand && !sat_disjoint<0>(s_row[e >> 6].p, s_col[e & 63].p);
+    unsigned long long m = __ballot(keep);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_count2, __popcll(m));
+      base = __shfl(base, 0);
+      if (keep) s_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
+    }
+  }
+  __syncthreads();
 
-  const int total = s_count;
+  const int total = s_count2;
   const int quad = tid >> 2;
   F2* qscr = s_pts + quad * kQuadSlots;
   for (int q = quad; q < total; q += NMS_NT / 4) {  // four lanes per pair (rsdet_geom.h)
@@ -98,58 +153,126 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
     if (hit && (tid & 3) == 0) atomicOr(&s_mask[i], 1ull << j);
   }
   __syncthreads();
-  if (tid < rows) mask[(long long)(rb * 64 + tid) * col_blocks + cbk] = s_mask[tid];
+  if (tid >= 64) return;
+  if (rb == cbk) {  // diagonal tile, transposed: bit i of word j = "box i suppresses box j"
+    unsigned long long col = 0ull;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) col |= ((s_mask[i] >> tid) & 1ull) << i;
+    diag_t[rb * 64 + tid] = col;
+    return;
+  }
+  nms_emit_entries(s_mask[tid], tid, rb, cbk, col_blocks, entries, blk_cnt);
 }
 
-// One workgroup; `removed` bitmap lives in LDS (n <= 64*NMS_MAX_BLOCKS boxes).
-constexpr int NMS_MAX_BLOCKS = 8192;  // 524288 boxes, 64 KB of LDS
+// One workgroup; the `removed` bitmap lives in LDS (n <= 64*NMS_MAX_BLOCKS boxes).  The walk over
+// the 64-box blocks is serial by nature, so the kernel is a latency chain and is built to keep
+// everything but the decision itself off that chain:
+//   * the transposed diagonal word, the `order` entries and the first SWEEP_PRE entries of block
+//     bk+2 are requested while block bk is being decided (three register buffers in rotation,
+//     never a vmcnt(0): the barriers order LDS only, the loads are unconditional so that the
+//     compiler can count them);
+//   * wave 0 resolves the diagonal tile as a fixpoint over wave ballots (0-6 rounds typically)
+//     instead of a 64-step serial chain;
+//   * every thread applies its prefetched entries of kept rows with 64-bit LDS ds_or.
+// History (M = 5 344, 84 blocks): one thread per word with one dependent load per kept row 9 us per
+// block; dense rows prefetched by 16 waves 1.4 us per block (64 KB per step through one CU's memory
+// pipe); sparse entries: see DESIGN.md.
+#ifdef RSDET_SWEEP_TRACE  // debug builds only (scratch/): per-step stage timestamps of wave 0, 100 MHz wall clock
+__device__ unsigned long long* g_sweep_trace;
+#define STRACE(bk, k, v)                                                                 \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && g_sweep_trace) g_sweep_trace[(size_t)(bk) * 8 + (k)] = (v);  \
+  } while (0)
+#else
+#define STRACE(bk, k, v)
+#endif
+constexpr int NMS_MAX_BLOCKS = 8192;  // 524288 boxes, 96 KB of LDS
+constexpr int SWEEP_NT = 512;
+constexpr int SWEEP_EPT = 2;                      // prefetched entries per thread
+constexpr int SWEEP_PRE = SWEEP_NT * SWEEP_EPT;   // entries of a block that come from the prefetch
 
-__global__ __launch_bounds__(NMS_NT) void nms_sweep_kernel(
-    const unsigned long long* __restrict__ mask, int n, int col_blocks,
+__global__ __launch_bounds__(SWEEP_NT) void nms_sweep_kernel(
+    const NmsEntry* __restrict__ entries, const unsigned* __restrict__ blk_cnt,
+    const unsigned long long* __restrict__ diag_t, int n, int col_blocks,
     const int* __restrict__ order, uint8_t* __restrict__ keep) {
-  extern __shared__ unsigned long long s_removed[];  // col_blocks words + 1 (kept word)
-  unsigned long long& s_kept = s_removed[col_blocks];
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int w = tid; w < col_blocks; w += NMS_NT) s_removed[w] = 0ull;
+  extern __shared__ unsigned long long s_removed[];  // col_blocks words, 1 kept word, col_blocks counts
+  unsigned long long* s_kept = s_removed + col_blocks;
+  unsigned* s_cnt = reinterpret_cast<unsigned*>(s_removed + col_blocks + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int w = tid; w < col_blocks; w += SWEEP_NT) {
+    s_removed[w] = 0ull;
+    s_cnt[w] = blk_cnt[w];
+  }
   __syncthreads();
 
-  for (int bk = 0; bk < col_blocks; ++bk) {
-    const int rows = min(64, n - bk * 64);
-    if (tid < 64) {
-      unsigned long long diag = 0ull;
-      if (lane < rows) diag = mask[(long long)(bk * 64 + lane) * col_blocks + bk];
-      unsigned long long cur = s_removed[bk];
-      unsigned long long kept = 0ull;
-      unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+  const size_t seg = (size_t)64 * col_blocks;  // entries reserved per row block
+  struct Pre {  // everything block bk needs from memory
+    uint4 ent[SWEEP_EPT];
+    unsigned long long diag;
+    int ord;
+  };
+  auto prefetch = [&](int bk, Pre& p) {
+    p.diag = diag_t[bk * 64 + lane];  // padded to whole blocks
+    p.ord = order[min(bk * 64 + lane, n - 1)];
+    const uint4* e = reinterpret_cast<const uint4*>(entries + (size_t)bk * seg);
 #pragma unroll
-      for (int r = 0; r < 64; ++r) {
-        // wave-uniform chain: row r survives iff no earlier kept row removed it
-        unsigned long long row =
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, r) << 32) |
-            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, r);  // readlane returns int
-        bool alive = r < rows && !((cur >> r) & 1ull);
-        if (alive) {
-          kept |= 1ull << r;
-          cur |= row;
-        }
+    for (int k = 0; k < SWEEP_EPT; ++k) p.ent[k] = e[k * SWEEP_NT + tid];  // seg >= SWEEP_PRE slots exist (ws slack)
+  };
+  // one block: `cur` was requested two steps ago (a step is shorter than a trip to memory), `fill`
+  // is requested now for block bk + 2 and first touched two steps on.  The loop is unrolled by
+  // three with the buffers rotated -- no register moves, so no wait for the loads in flight.
+  auto step = [&](int bk, const Pre& cur, Pre& fill) {
+    STRACE(bk, 0, wall_clock64());
+    prefetch(min(bk + 2, col_blocks - 1), fill);
+    const int rows = min(64, n - bk * 64);
+    if (wave == 0) {
+      const unsigned long long cur_v = s_removed[bk];
+      const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur_v);
+      const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v >> 32));
+      const unsigned long long pre = ((unsigned long long)cur_hi << 32) | cur_lo;  // wave-uniform: scalar registers
+      const unsigned long long cand = ~pre & (rows < 64 ? (1ull << rows) - 1ull : ~0ull);
+      // Greedy NMS inside the 64-box block as a fixpoint instead of a 64-step serial chain.  Lane j
+      // holds column j of the diagonal tile (bit i: box i < j suppresses box j).  K <- cand minus the
+      // boxes suppressed by a member of K: after t rounds the first t decisions are final, so the
+      // fixpoint is the greedy answer (unique: r is kept iff no earlier kept box suppresses it); a
+      // typical block needs 0-6 rounds, the worst case 64.
+      unsigned long long kept = cand;
+      for (int round = 0; round < 64; ++round) {
+        const unsigned long long hit = __ballot((cur.diag & kept) != 0ull);
+        const unsigned long long next = cand & ~hit;
+        if (next == kept) break;
+        kept = next;
       }
-      if (lane < rows) keep[order[bk * 64 + lane]] = (uint8_t)((kept >> lane) & 1ull);
-      if (lane == 0) s_kept = kept;
+      STRACE(bk, 1, wall_clock64());
+      if (lane < rows) keep[cur.ord] = (uint8_t)((kept >> lane) & 1ull);
+      if (lane == 0) *s_kept = kept;
     }
-    __syncthreads();
-    unsigned long long kept = s_kept;
-    // OR the kept rows into removed[bk+1 ..): thread owns words w = bk+1+tid, +NT, ...
-    for (int w = bk + 1 + tid; w < col_blocks; w += NMS_NT) {
-      unsigned long long acc = s_removed[w];
-      unsigned long long k = kept;
-      while (k) {
-        int r = __builtin_ctzll(k);
-        k &= k - 1;
-        acc |= mask[(long long)(bk * 64 + r) * col_blocks + w];
-      }
-      s_removed[w] = acc;
+    lds_barrier();
+    STRACE(bk, 2, wall_clock64());
+    const unsigned long long kept = *s_kept;
+    const unsigned cnt = s_cnt[bk];
+#pragma unroll
+    for (int k = 0; k < SWEEP_EPT; ++k) {
+      const uint4 e = cur.ent[k];  // {bits lo, bits hi, column block, row}
+      if ((unsigned)(k * SWEEP_NT + tid) < cnt && ((kept >> (e.w & 63u)) & 1ull))
+        atomicOr(&s_removed[e.z], ((unsigned long long)e.y << 32) | e.x);
     }
-    __syncthreads();
+    // a block with more than SWEEP_PRE non-zero words: the rest straight from memory
+    for (unsigned q = SWEEP_PRE + tid; q < cnt; q += SWEEP_NT) {
+      const NmsEntry e = entries[(size_t)bk * seg + q];
+      if ((kept >> e.row) & 1ull) atomicOr(&s_removed[e.cblock], e.bits);
+    }
+    lds_barrier();
+    STRACE(bk, 3, wall_clock64());
+  };
+
+  Pre A, B, C;
+  prefetch(0, A);
+  prefetch(min(1, col_blocks - 1), B);
+  for (int bk = 0; bk < col_blocks; bk += 3) {
+    step(bk, A, C);
+    if (bk + 1 < col_blocks) step(bk + 1, B, A);
+    if (bk + 2 < col_blocks) step(bk + 2, C, B);
   }
 }
 
@@ -157,12 +280,23 @@ __global__ __launch_bounds__(NMS_NT) void nms_sweep_kernel(
 
 using namespace rsdet;
 
+#ifdef RSDET_SWEEP_TRACE
+extern "C" void rsdet_debug_set_sweep_trace(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_trace), &p, sizeof(p)); }
+#endif
+
 static inline size_t nms_sorted_bytes(int n) { return ((size_t)n * sizeof(NmsBox) + 255) & ~(size_t)255; }
+
+// ws layout after the kernel-specific head: diag_t (64*cb words) | blk_cnt (cb) | entries (cb lists of 64*cb)
+static inline size_t nms_diag_bytes(int n) { return (((size_t)n + 63) / 64) * 64 * sizeof(unsigned long long); }
+static inline size_t nms_cnt_bytes(int n) { return ((((size_t)n + 63) / 64) * 4 + 255) & ~(size_t)255; }
+static inline size_t nms_entry_bytes(int n) {
+  size_t cb = ((size_t)n + 63) / 64;
+  return (cb * 64 * cb + rsdet::SWEEP_PRE) * sizeof(rsdet::NmsEntry);  // + slack: unconditional prefetch of the last list
+}
 
 extern "C" size_t rsdet_nms_rotated_ws_size(int n) {
   if (n <= 0) return 0;
-  size_t cb = ((size_t)n + 63) / 64;
-  return nms_sorted_bytes(n) + (size_t)n * cb * sizeof(unsigned long long);
+  return nms_sorted_bytes(n) + nms_diag_bytes(n) + nms_cnt_bytes(n) + nms_entry_bytes(n);
 }
 
 extern "C" int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, const int* order,
@@ -176,17 +310,20 @@ extern "C" int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, cons
   if (cb > NMS_MAX_BLOCKS) return RSDET_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   NmsBox* sorted = (NmsBox*)ws;
-  unsigned long long* mask = (unsigned long long*)((char*)ws + nms_sorted_bytes(n));
+  char* w = (char*)ws + nms_sorted_bytes(n);
+  unsigned long long* diag_t = (unsigned long long*)w;
+  unsigned* blk_cnt = (unsigned*)(w + nms_diag_bytes(n));
+  NmsEntry* entries = (NmsEntry*)(w + nms_diag_bytes(n) + nms_cnt_bytes(n));
   hipLaunchKernelGGL(nms_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dets, n, box_len,
-                     order, sorted);
+                     order, sorted, blk_cnt);
   if (ge)
     hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr, cb,
-                       mask);
+                       entries, blk_cnt, diag_t);
   else
     hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr,
-                       cb, mask);
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(NMS_NT), (size_t)(cb + 1) * 8, s, mask, n, cb, order,
-                     keep);
+                       cb, entries, blk_cnt, diag_t);
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_NT), (size_t)(cb + 1) * 8 + (size_t)cb * 4, s, entries,
+                     blk_cnt, diag_t, n, cb, order, keep);
   return rsdet_launch_status();
 }
 
@@ -200,10 +337,13 @@ namespace rsdet {
 
 __global__ __launch_bounds__(64) void nms_hbb_mask_kernel(const float* __restrict__ boxes, int n, float thr,
                                                           float one, int col_blocks,
-                                                          unsigned long long* __restrict__ mask) {
+                                                          NmsEntry* __restrict__ entries,
+                                                          unsigned* __restrict__ blk_cnt,
+                                                          unsigned long long* __restrict__ diag_t) {
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;
   __shared__ float s_col[64 * 4];
+  __shared__ unsigned long long s_rows[64];
   const int tid = threadIdx.x;
   const int cols = min(64, n - cbk * 64), rows = min(64, n - rb * 64);
   if (tid < cols) {
@@ -211,25 +351,36 @@ __global__ __launch_bounds__(64) void nms_hbb_mask_kernel(const float* __restric
     for (int k = 0; k < 4; ++k) s_col[tid * 4 + k] = boxes[(long long)(cbk * 64 + tid) * 4 + k];
   }
   __syncthreads();
-  if (tid >= rows) return;
-  const float* b = boxes + (long long)(rb * 64 + tid) * 4;
-  const float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
-  const float area = (x2 - x1 + one) * (y2 - y1 + one);
   unsigned long long bits = 0ull;
-  const int start = (rb == cbk) ? tid + 1 : 0;
-  for (int j = start; j < cols; ++j) {
-    const float* c = s_col + j * 4;
-    float w = fmaxf(0.f, fminf(x2, c[2]) - fmaxf(x1, c[0]) + one);
-    float h = fmaxf(0.f, fminf(y2, c[3]) - fmaxf(y1, c[1]) + one);
-    float inter = w * h;
-    float carea = (c[2] - c[0] + one) * (c[3] - c[1] + one);
-    if (inter / (area + carea - inter) > thr) bits |= 1ull << j;
+  if (tid < rows) {
+    const float* b = boxes + (long long)(rb * 64 + tid) * 4;
+    const float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+    const float area = (x2 - x1 + one) * (y2 - y1 + one);
+    const int start = (rb == cbk) ? tid + 1 : 0;
+    for (int j = start; j < cols; ++j) {
+      const float* c = s_col + j * 4;
+      float w = fmaxf(0.f, fminf(x2, c[2]) - fmaxf(x1, c[0]) + one);
+      float h = fmaxf(0.f, fminf(y2, c[3]) - fmaxf(y1, c[1]) + one);
+      float inter = w * h;
+      float carea = (c[2] - c[0] + one) * (c[3] - c[1] + one);
+      if (inter / (area + carea - inter) > thr) bits |= 1ull << j;
+    }
   }
-  mask[(long long)(rb * 64 + tid) * col_blocks + cbk] = bits;
+  if (rb != cbk) {
+    nms_emit_entries(bits, tid, rb, cbk, col_blocks, entries, blk_cnt);
+    return;
+  }
+  s_rows[tid] = bits;  // diagonal tile also transposed for the sweep (see nms_mask_kernel)
+  __syncthreads();
+  unsigned long long col = 0ull;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) col |= ((s_rows[i] >> tid) & 1ull) << i;
+  diag_t[rb * 64 + tid] = col;
 }
 
-__global__ void iota_kernel(int* p, int n) {
+__global__ void iota_kernel(int* p, int n, unsigned* blk_cnt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (n + 63) / 64) blk_cnt[i] = 0u;
   if (i < n) p[i] = i;
 }
 
@@ -237,8 +388,7 @@ __global__ void iota_kernel(int* p, int n) {
 
 extern "C" size_t rsdet_nms_hbb_ws_size(int n) {
   if (n <= 0) return 0;
-  size_t cb = ((size_t)n + 63) / 64;
-  return (((size_t)n * 4 + 255) & ~(size_t)255) + (size_t)n * cb * sizeof(unsigned long long);
+  return (((size_t)n * 4 + 255) & ~(size_t)255) + nms_diag_bytes(n) + nms_cnt_bytes(n) + nms_entry_bytes(n);
 }
 
 extern "C" int rsdet_nms_hbb_sorted_f32(const float* boxes_sorted, int n, float thr, int plus_one,
@@ -251,11 +401,15 @@ extern "C" int rsdet_nms_hbb_sorted_f32(const float* boxes_sorted, int n, float 
   if (cb > rsdet::NMS_MAX_BLOCKS) return RSDET_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   int* ident = (int*)ws;
-  unsigned long long* mask = (unsigned long long*)((char*)ws + (((size_t)n * 4 + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(rsdet::iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ident, n);
+  const size_t ident_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+  char* w = (char*)ws + ident_bytes;
+  unsigned long long* diag_t = (unsigned long long*)w;
+  unsigned* blk_cnt = (unsigned*)(w + nms_diag_bytes(n));
+  rsdet::NmsEntry* entries = (rsdet::NmsEntry*)(w + nms_diag_bytes(n) + nms_cnt_bytes(n));
+  hipLaunchKernelGGL(rsdet::iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ident, n, blk_cnt);
   hipLaunchKernelGGL(rsdet::nms_hbb_mask_kernel, dim3(cb, cb), dim3(64), 0, s, boxes_sorted, n, thr,
-                     plus_one ? 1.f : 0.f, cb, mask);
-  hipLaunchKernelGGL(rsdet::nms_sweep_kernel, dim3(1), dim3(rsdet::NMS_NT), (size_t)(cb + 1) * 8, s, mask, n, cb,
-                     ident, keep_sorted);
+                     plus_one ? 1.f : 0.f, cb, entries, blk_cnt, diag_t);
+  hipLaunchKernelGGL(rsdet::nms_sweep_kernel, dim3(1), dim3(rsdet::SWEEP_NT), (size_t)(cb + 1) * 8 + (size_t)cb * 4, s,
+                     entries, blk_cnt, diag_t, n, cb, ident, keep_sorted);
   return rsdet_launch_status();
 }
