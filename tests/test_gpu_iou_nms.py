@@ -145,6 +145,40 @@ def test_nms_vs_oracle_bit_exact(cuda, oracle_c, box_len, n, thr):
     assert (got == want).all(), (int((got != want).sum()), n)
 
 
+def test_nms_suppression_chains_and_dense_blocks(cuda, oracle_c):
+    """Shapes that stress the device sweep rather than the clipper:
+    (a) a chain -- box i overlaps only i+1 -- where the greedy answer alternates and the in-block
+        fixpoint needs one round per box (64 rounds per block, decisions crossing block borders);
+    (b) one dense pile: every box suppresses every later one, so a block's entry list is far longer
+        than the sweep's prefetch window and most blocks arrive already fully removed;
+    (c) chain and pile mixed under a random score order."""
+    from rs_detection_amd.ops import nms_rotated_keep_mask
+    n = 333
+    chain = np.zeros((n, 5), np.float32)
+    chain[:, 0] = np.arange(n) * 6.0   # 10-wide boxes, 6 apart: IoU(i,i+1)=0.25, IoU(i,i+2)=0
+    chain[:, 1] = 50
+    chain[:, 2], chain[:, 3] = 10, 10
+    order = np.arange(n, dtype=np.int32)                      # scores descending along the chain
+    want = oracle_c.nms_rotated(chain, order, 0.2)
+    assert want[::2].all() and not want[1::2].any()            # the oracle itself alternates
+    got = nms_rotated_keep_mask(_t(chain, cuda), _t(order, cuda), 0.2, 5).cpu().numpy()
+    assert (got == want).all()
+
+    rng = np.random.default_rng(5)
+    pile = np.tile(np.array([[300, 300, 80, 40, 0.3]], np.float32), (3000, 1))
+    pile[:, :2] += rng.normal(0, 1.0, (3000, 2)).astype(np.float32)
+    order = rng.permutation(3000).astype(np.int32)
+    want = oracle_c.nms_rotated(pile, order, 0.3)
+    got = nms_rotated_keep_mask(_t(pile, cuda), _t(order, cuda), 0.3, 5).cpu().numpy()
+    assert (got == want).all() and want.sum() == 1
+
+    both = np.concatenate([chain, pile[:1500]])
+    order = rng.permutation(both.shape[0]).astype(np.int32)
+    want = oracle_c.nms_rotated(both, order, 0.2)
+    got = nms_rotated_keep_mask(_t(both, cuda), _t(order, cuda), 0.2, 5).cpu().numpy()
+    assert (got == want).all(), int((got != want).sum())
+
+
 def test_nms_known_answer_and_api(cuda):
     from rs_detection_amd.ops import nms_rotated, ml_nms_rotated
     dets = _t(np.array([[0, 0, 1, 1, 0], [0, 0, .5, .5, .3], [0, 0, .9, .9, 0]], np.float32), cuda)
