@@ -1,4 +1,4 @@
-from .anchor_generator import AnchorGeneratorRotatedS2ANet, AnchorGenerator
+from .anchor_generator import AnchorGeneratorRotatedS2ANet, AnchorGenerator, AnchorGeneratorRotated
 from .assigner import MaxIoUAssigner, AssignResult
 from .sampler import PseudoSampler, SamplingResult, RandomSampler, RandomSamplerRotated
 from .coder import DeltaXYWHABBoxCoder, MidpointOffsetCoder, OrientedDeltaXYWHTCoder

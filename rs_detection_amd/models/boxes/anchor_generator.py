@@ -165,3 +165,69 @@ class AnchorGenerator:
             vh, vw = min(int(np.ceil(h / stride[1])), feat_h), min(int(np.ceil(w / stride[0])), feat_w)
             out.append(self.single_level_valid_flags((feat_h, feat_w), (vh, vw), self.num_base_anchors[i], device))
         return out
+
+
+@BOXES.register_module()
+class AnchorGeneratorRotated:
+    """RetinaNet anchors (/root/reference/python/jdet/models/boxes/anchor_generator.py:495-640): mode 'H' gives
+    (x0,y0,x1,y1) anchors, mode 'R' adds an angle column; ``center_offset`` 0.5 by default; x fastest, then the
+    base anchor (ratio-major when ``scale_major`` and mode 'R', scale-major otherwise -- :546-555 as written)."""
+
+    def __init__(self, strides, ratios, scales, base_sizes=None, angles=(0,), scale_major=True, centers=None,
+                 center_offset=0.5, mode='H'):
+        assert mode in ['H', 'R']
+        self.ratios = torch.tensor(ratios, dtype=torch.float32)
+        self.scales = torch.tensor(scales, dtype=torch.float32)
+        self.strides = [(s, s) for s in strides]
+        self.base_sizes = [min(s) for s in self.strides] if base_sizes is None else base_sizes
+        self.mode = mode
+        self.angles = torch.tensor(list(angles), dtype=torch.float32) if mode == 'R' else torch.tensor([0.])
+        self.scale_major, self.centers, self.center_offset = scale_major, centers, center_offset
+        self.base_anchors = [self.gen_single_level_base_anchors(b, self.scales, self.ratios, self.angles,
+                                                                None if centers is None else centers[i])
+                             for i, b in enumerate(self.base_sizes)]
+        self._cache = {}
+
+    @property
+    def num_base_anchors(self):
+        return [b.size(0) for b in self.base_anchors]
+
+    @property
+    def num_levels(self):
+        return len(self.strides)
+
+    def gen_single_level_base_anchors(self, base_size, scales, ratios, angles, centers):
+        w = h = base_size
+        x_ctr, y_ctr = (self.center_offset * w, self.center_offset * h) if centers is None else centers
+        h_ratios = torch.sqrt(ratios)
+        w_ratios = 1 / h_ratios
+        ones = torch.ones_like(angles)[None, None, :]
+        if self.scale_major and self.mode == 'R':
+            ws = (w * w_ratios[:, None, None] * scales[None, :, None] * ones).reshape(-1)
+            hs = (h * h_ratios[:, None, None] * scales[None, :, None] * ones).reshape(-1)
+        else:
+            ws = (w * scales[:, None, None] * w_ratios[None, :, None] * ones).reshape(-1)
+            hs = (h * scales[:, None, None] * h_ratios[None, :, None] * ones).reshape(-1)
+        ang = angles.repeat(len(scales) * len(ratios))
+        cols = [x_ctr - 0.5 * ws, y_ctr - 0.5 * hs, x_ctr + 0.5 * ws, y_ctr + 0.5 * hs]
+        if self.mode == 'R':
+            cols.append(ang)
+        return torch.stack(cols, dim=-1)
+
+    def single_level_grid_anchors(self, base_anchor, featmap_size, stride=(16, 16), device="cpu"):
+        feat_h, feat_w = featmap_size
+        sx = torch.arange(0, feat_w, device=device, dtype=torch.float32) * stride[0]
+        sy = torch.arange(0, feat_h, device=device, dtype=torch.float32) * stride[1]
+        xx = sx.repeat(feat_h)
+        yy = sy.view(-1, 1).repeat(1, feat_w).view(-1)
+        cols = [xx, yy, xx, yy] + ([torch.zeros_like(xx)] if self.mode == 'R' else [])
+        shifts = torch.stack(cols, dim=-1)
+        return (base_anchor.to(device)[None, :, :] + shifts[:, None, :]).view(-1, len(cols))
+
+    def grid_anchors(self, featmap_sizes, device="cpu"):
+        assert self.num_levels == len(featmap_sizes)
+        key = (tuple(map(tuple, featmap_sizes)), str(device))
+        if key not in self._cache:
+            self._cache[key] = [self.single_level_grid_anchors(self.base_anchors[i], featmap_sizes[i], self.strides[i],
+                                                               device) for i in range(self.num_levels)]
+        return self._cache[key]
