@@ -47,6 +47,9 @@ def s2anet_cfg():
     return Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
 
 
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md)
+
+
 def event_time(fn, iters, warmup=3, graph=True):
     """Average device time of fn() in seconds: HIP events on torch's current stream (the stream every
     rsdet_* launch goes to) around a replayed hipGraph of `iters` calls, so that the host-side cost of the
@@ -95,12 +98,19 @@ def kernel_rooflines(device, targets):
     # -- batched rotated IoU (a1): bytes = 20*(N1+N2) + 4*N1*N2
     t = event_time(lambda: ops.box_iou_rotated_grouped(gt, ro, max(ks), anchors, out=ov), 50)
     by = 20 * (n1 + A) + 4 * n1 * A
+    # SURVEY 8d also asks for the VALU view: the reference's algorithm costs ~0.3 kFLOP for a disjoint pair and
+    # ~0.8 kFLOP for an overlapping one; "valu_frac" prices THOSE flops (not the ones the early-outs leave) against
+    # the fp32 vector peak, i.e. how far the call is beyond a kernel that ran the clipper on every pair.
+    nz = int((ov != 0).sum())
+    alg_flops = 300.0 * (n1 * A - nz) + 800.0 * nz
     out["box_iou_rotated(prepare+filter+clip)"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                          frac=by / t / 1e9 / HBM_PEAK_GBS,
                                          # HBM bytes per launch from the rocprofv3 PMC passes of this very shape
                                          # (profiles/r01_d_pmc_hbm_traffic.txt: WRITE 50.8+1.1+0.9 MB, FETCH 2x5.7 MB)
                                          traffic=64.2e6 if (n1, A) == (556, 21824) else None, us=t * 1e6,
-                                         mpairs_per_s=n1 * A / t / 1e6, shape="sumK=%d x A=%d (B=%d)" % (n1, A, len(ks)))
+                                         mpairs_per_s=n1 * A / t / 1e6, shape="sumK=%d x A=%d (B=%d)" % (n1, A, len(ks)),
+                                         overlapping_pairs=nz, alg_gflop=alg_flops / 1e9,
+                                         valu_frac=alg_flops / t / 1e12 / FP32_VALU_PEAK_TFLOPS)
     # -- assignment (a4): two passes over the matrix + outputs
     t = event_time(lambda: ops.assign_wrt_overlaps(ov, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0), 50)
     by = 2 * 4 * n1 * A + 12 * len(ks) * A
@@ -151,9 +161,23 @@ def cpu_baseline(budget_s=12.0):
         impl.box_iou_rotated(gts, anchors, 0)
         pairs += gts.shape[0] * anchors.shape[0]
     dt = time.perf_counter() - t0
-    return dict(value=pairs / dt / 1e6, unit="Mpairs/s (rotated IoU; the reference has no CPU path for the full "
+    single = pairs / dt / 1e6
+    # the same source with its outer (gt) loop split over all host cores: ctypes releases the GIL during the call
+    from concurrent.futures import ThreadPoolExecutor
+    ncores = os.cpu_count() or 1
+    big = syn.dota_gt_boxes(np.random.default_rng(4321), 64 * ncores)
+    chunks = np.array_split(big, ncores)
+    calls, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(ncores) as pool:
+        while time.perf_counter() - t0 < budget_s / 2:
+            list(pool.map(lambda g: impl.box_iou_rotated(g, anchors, 0), chunks))
+            calls += 1
+    dt2 = time.perf_counter() - t0
+    return dict(value=single, unit="Mpairs/s (rotated IoU; the reference has no CPU path for the full "
                 "S2ANet step: DeformConv is CUDA-only, dcn_v1.py:588-589)", cores=1, kind=kind,
-                sample="K=100 gt x A=21824 S2ANet anchors, repeated for %.0f s (%d calls)" % (dt, pairs // (100 * 21824)))
+                sample="K=100 gt x A=21824 S2ANet anchors, repeated for %.0f s (%d calls)" % (dt, pairs // (100 * 21824)),
+                all_cores=dict(value=calls * big.shape[0] * anchors.shape[0] / dt2 / 1e6, cores=ncores,
+                               sample="K=%d gt split over %d threads, %.0f s" % (big.shape[0], ncores, dt2)))
 
 
 def main():
@@ -163,6 +187,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE config[1] (the metric); bf16 = torch.autocast over the MIOpen/rocBLAS part "
+                         "(configs[2]/[4]); the oriented-box kernels always compute in fp32")
     ap.add_argument("--memory-format", choices=["channels_last", "contiguous"], default="contiguous",
                     help="activation layout of the torch/MIOpen part (measured r1 on MI355X, fp32: "
                          "NCHW 68.7 ms/step, channels_last 494 ms/step)")
@@ -182,7 +209,8 @@ def main():
     from rs_detection_amd.runner.runner import Runner
     torch.manual_seed(0)  # same initial weights on every rank (DDP also broadcasts)
     mf = torch.channels_last if args.memory_format == "channels_last" else None
-    runner = Runner(s2anet_cfg(), device=device, memory_format=mf)
+    runner = Runner(s2anet_cfg(), device=device, memory_format=mf,
+                    amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     # synthetic DOTA-shaped batch, resident in HBM before the timed region
     g = torch.Generator(device="cpu").manual_seed(0 + rank)
     images = torch.randn(BATCH_PER_GPU, 3, TILE, TILE, generator=g).to(device)
@@ -225,16 +253,19 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "S2ANet-R50-FPN train step, %d x 1024x1024 DOTA-shaped tiles per GPU, fp32, "
-                               "K gts/tile cycle [16,100,400,40], A=21824 anchors/tile" % BATCH_PER_GPU,
+        "config": {"workload": "S2ANet-R50-FPN train step, %d x 1024x1024 DOTA-shaped tiles per GPU, %s, "
+                               "K gts/tile cycle [16,100,400,40], A=21824 anchors/tile"
+                               % (BATCH_PER_GPU, "fp32" if args.dtype == "f32" else "bf16 autocast (fp32 box kernels)"),
                    "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
                    "memory_format": args.memory_format},
         "final_loss": loss_v,
         "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
         "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
-            "kernel": "rsdet_box_iou_rotated_grouped_f32 = iou_prepare + iou_filter + iou_clip kernels", "us_per_launch": roof["us"], "shape": roof["shape"]}) if roof else None,
+            "kernel": "rsdet_box_iou_rotated_grouped_f32 = iou_prepare + iou_filter + iou_clip kernels",
+            "us_per_launch": roof["us"], "shape": roof["shape"], "valu_frac": roof["valu_frac"],
+            "alg_gflop": roof["alg_gflop"], "overlapping_pairs": roof["overlapping_pairs"]}) if roof else None,
         "kernels": kernels,
         "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
     }

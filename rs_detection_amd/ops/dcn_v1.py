@@ -123,6 +123,7 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
     (dcn_v1.py:536-539; 288 GB of HBM make the 0.6 GB cheap)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, input, offset, weight, stride, padding, dilation, deformable_groups):
         ctx.cfg = (_pair(stride), _pair(padding), _pair(dilation), deformable_groups)
         B, C, H, W = input.shape
@@ -139,6 +140,7 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad_output):
         offset, weight, col = ctx.saved_tensors
         stride, padding, dilation, dg = ctx.cfg
@@ -166,6 +168,7 @@ class DeformConvFunction(torch.autograd.Function):
     """dcn_v1.py:559-650 (reference column layout; used for groups > 1 or when the offset needs a gradient)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
                 im2col_step=64):
         if input is not None and input.dim() != 4:
@@ -190,6 +193,7 @@ class DeformConvFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad_output):
         input, offset, weight, col = ctx.saved_tensors
         B, C, H, W = input.shape

@@ -50,12 +50,14 @@ class _ActiveRotatingFilter(torch.autograd.Function):
     """orn.py:543-555."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, input, indices):
         indices = indices.to(torch.uint8)
         ctx.save_for_backward(indices)
         return arf_forward(input, indices)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad_output):
         (indices,) = ctx.saved_tensors
         return arf_backward(indices, grad_output), None

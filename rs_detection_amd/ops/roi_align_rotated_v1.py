@@ -17,6 +17,7 @@ def _pair(x):
 
 class _RotatedROIAlign_v1(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio):
         assert rois.shape[1] == 6  # :306
         _lib.require_cuda_f32(input, rois)
@@ -34,6 +35,7 @@ class _RotatedROIAlign_v1(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors
         shape, output_size, scale, sr = ctx.cfg
