@@ -182,6 +182,22 @@ int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const float* rois, i
  * Replaces models/boxes/box_ops.py:633-654.  boxes (n,5) -> polys (n,8). */
 int rsdet_rotated_box_to_poly_f32(const float* boxes, int n, float* polys, void* stream);
 
+/* ---- a21  eval-mode BatchNorm + residual add + ReLU (backbone Bottleneck tails) -----------------------
+ * Replaces the per-op sequence models/backbones/resnet.py:101-126 (bn -> (+ identity) -> relu) when the
+ * BatchNorm is in eval mode (norm_eval, :177-184): y = max(((x - mean) * rsqrt(var + eps)) * weight + bias
+ * (+ residual), 0) on NCHW fp32, one HBM pass.  weight / bias / residual may be NULL; relu 0 skips the max.
+ * Backward: g = grad_y * [y > 0] (relu) -> grad_residual = g, grad_x = g * rsqrt(var+eps) * weight,
+ * grad_weight[c] = sum g * xhat, grad_bias[c] = sum g (two-stage, fixed order: deterministic).  Any of the
+ * four outputs may be NULL; ws is only needed for grad_weight / grad_bias. */
+size_t rsdet_bn_act_backward_ws_size(int N, int C, int HW);
+int rsdet_bn_act_forward_f32(const float* x, const float* residual, const float* running_mean,
+                             const float* running_var, const float* weight, const float* bias, float eps, int N,
+                             int C, int HW, int relu, float* y, void* stream);
+int rsdet_bn_act_backward_f32(const float* grad_y, const float* y, const float* x, const float* running_mean,
+                              const float* running_var, const float* weight, float eps, int N, int C, int HW,
+                              int relu, float* grad_x, float* grad_residual, float* grad_weight, float* grad_bias,
+                              void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

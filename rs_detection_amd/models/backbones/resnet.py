@@ -11,6 +11,7 @@ here, so weights stay random-initialised (relu-invariant gaussian, fan_out).
 import torch
 import torch.nn as nn
 
+from rs_detection_amd.ops.bn_act import bn_act
 from rs_detection_amd.utils.registry import BACKBONES
 
 __all__ = ['ResNet', 'Resnet18', 'Resnet34', 'Resnet50', 'Resnet101', 'Resnet152']
@@ -39,9 +40,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        out = bn_act(self.conv1(x), self.bn1)
+        return bn_act(self.conv2(out), self.bn2, residual=idt)
 
 
 class Bottleneck(nn.Module):
@@ -57,11 +57,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        # bn -> (+ identity) -> relu as one pass each way when the BatchNorm is in eval mode (ops/bn_act.py)
+        idt = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+        out = bn_act(self.conv1(x), self.bn1)
+        out = bn_act(self.conv2(out), self.bn2)
+        return bn_act(self.conv3(out), self.bn3, residual=idt)
 
 
 @BACKBONES.register_module()
@@ -122,7 +122,7 @@ class ResNet(nn.Module):
         outs = []
         frozen_stem = self.frozen_stages >= 0
         with torch.set_grad_enabled(torch.is_grad_enabled() and not frozen_stem):
-            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            x = self.maxpool(bn_act(self.conv1(x), self.bn1))
         for i in range(1, 5):
             name = f"layer{i}"
             with torch.set_grad_enabled(torch.is_grad_enabled() and i > self.frozen_stages):

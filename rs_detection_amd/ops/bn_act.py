@@ -1,0 +1,68 @@
+"""Eval-mode BatchNorm + residual add + ReLU as ONE HBM pass each way (csrc/bn_act.hip).
+
+The backbone keeps every BatchNorm in eval mode (resnet.py:177-184, norm_eval), so ``bn -> (+ identity) -> relu``
+(resnet.py:101-126) is a per-channel affine followed by two elementwise ops: three kernels forward and three
+backward on the torch route, ~8 ms of a 68 ms S2ANet step.  ``bn_act(x, bn, residual, relu)`` fuses them when it
+can (CUDA, fp32, contiguous NCHW, ``bn`` in eval mode) and is the plain torch sequence otherwise (training-mode
+BatchNorm, bf16 autocast, CPU tensors of the RetinaNet plumbing case) -- both are the product path; there is no
+oracle or CPU restatement behind it."""
+import torch
+import torch.nn.functional as F
+
+from rs_detection_amd import _lib
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, mean, var, eps, relu):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        rc = lib.rsdet_bn_act_forward_f32(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(mean), _lib.ptr(var),
+                                          _lib.ptr(weight), _lib.ptr(bias), float(eps), N, C, H * W, int(relu),
+                                          _lib.ptr(y), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_bn_act_forward_f32")
+        ctx.save_for_backward(x, y, weight, mean, var)
+        ctx.eps, ctx.relu, ctx.has_res = float(eps), bool(relu), residual is not None
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, y, weight, mean, var = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gy = gy.contiguous()
+        need_x, need_res = ctx.needs_input_grad[0], ctx.has_res and ctx.needs_input_grad[1]
+        need_w = weight is not None and ctx.needs_input_grad[2]
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        gx = torch.empty_like(x) if need_x else None
+        # without a ReLU the residual's gradient IS grad_y: no copy
+        gres = (torch.empty_like(x) if ctx.relu else gy) if need_res else None
+        gw = torch.empty_like(weight) if need_w else None
+        gb = torch.empty_like(mean) if need_b else None
+        ws_bytes = lib.rsdet_bn_act_backward_ws_size(N, C, H * W) if (need_w or need_b) else 0
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes else None
+        rc = lib.rsdet_bn_act_backward_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(var),
+                                           _lib.ptr(weight), ctx.eps, N, C, H * W, int(ctx.relu), _lib.ptr(gx),
+                                           _lib.ptr(gres) if (need_res and ctx.relu) else None, _lib.ptr(gw),
+                                           _lib.ptr(gb), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+        _lib.check(rc, "rsdet_bn_act_backward_f32")
+        return gx, gres, gw, gb, None, None, None, None
+
+
+def _fusable(x, bn, residual):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not bn.training
+            and bn.running_mean is not None and not torch.is_autocast_enabled()
+            and (residual is None or (residual.dtype == torch.float32 and residual.shape == x.shape
+                                      and residual.is_contiguous())))
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """relu(bn(x) + residual) with ``bn`` an ``nn.BatchNorm2d``."""
+    if _fusable(x, bn, residual):
+        return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out) if relu else out

@@ -253,3 +253,71 @@ def test_ops_refuse_cpu_tensors(cuda):
     from rs_detection_amd import ops, _lib
     with pytest.raises(_lib.RsdetError):
         ops.box_iou_rotated(torch.zeros(2, 5), torch.zeros(2, 5))
+
+
+@pytest.mark.parametrize("shape,relu,with_res,affine", [((4, 64, 56, 56), True, True, True), ((2, 33, 7, 9), True, False, True),
+                                                       ((3, 16, 5, 5), False, True, True), ((2, 8, 12, 12), True, True, False),
+                                                       ((1, 256, 128, 128), True, True, True)])
+def test_bn_act_fused_equals_torch_sequence(cuda, shape, relu, with_res, affine):
+    """a21: eval-mode BatchNorm + residual + ReLU in one pass == the torch op sequence (resnet.py:101-126),
+    forward and all four gradients; parameter gradients are deterministic (two-stage reduction)."""
+    from rs_detection_amd.ops.bn_act import bn_act
+    torch.manual_seed(sum(shape))
+    N, C, H, W = shape
+    bn = torch.nn.BatchNorm2d(C, affine=affine).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 1)
+        bn.running_var.uniform_(0.5, 2)
+        if affine:
+            bn.weight.normal_(1, 0.3)
+            bn.bias.normal_(0, 0.3)
+    x = torch.randn(shape, device=cuda, requires_grad=True)
+    res = torch.randn(shape, device=cuda, requires_grad=True) if with_res else None
+    gy = torch.randn(shape, device=cuda)
+
+    def run(fused):
+        for t in (x, res) + tuple(bn.parameters()):
+            if t is not None:
+                t.grad = None
+        if fused:
+            y = bn_act(x, bn, res, relu)
+        else:
+            y = bn(x) if res is None else bn(x) + res
+            y = torch.relu(y) if relu else y
+        y.backward(gy)
+        return [y.detach()] + [None if t is None else t.grad.clone() for t in (x, res) + tuple(bn.parameters())]
+
+    want, got, again = run(False), run(True), run(True)
+    assert type(got[0].grad_fn).__name__ != "ReluBackward0"
+    for a, b, c in zip(want, got, again):
+        if a is None:
+            assert b is None
+            continue
+        scale = max(float(a.abs().max()), 1.0)
+        assert float((a - b).abs().max()) <= 2e-5 * scale * (10 if a.dim() == 1 else 1), (a.shape, float((a - b).abs().max()))
+        assert torch.equal(b, c)  # bitwise repeatable
+
+
+def test_resnet_bottleneck_uses_fused_path_and_matches_unfused(cuda):
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.models.backbones.resnet import Bottleneck
+    import rs_detection_amd.ops.bn_act as B
+    torch.manual_seed(0)
+    down = torch.nn.Sequential(torch.nn.Conv2d(64, 256, 1, bias=False), torch.nn.BatchNorm2d(256))
+    blk = Bottleneck(64, 64, 1, down).to(cuda).eval()   # eval-mode BatchNorm, gradients still flow (norm_eval)
+    x = torch.randn(2, 64, 32, 32, device=cuda, requires_grad=True)
+    y = blk(x)
+    y.sum().backward()
+    gx, gw = x.grad.clone(), blk.bn3.weight.grad.clone()
+    x.grad = None
+    blk.zero_grad()
+    orig = B._fusable
+    B._fusable = lambda *a: False
+    try:
+        y2 = blk(x)
+        y2.sum().backward()
+    finally:
+        B._fusable = orig
+    assert float((y - y2).abs().max()) <= 1e-4 * float(y2.abs().max())
+    assert float((gx - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
+    assert float((gw - blk.bn3.weight.grad).abs().max()) <= 1e-3 * float(blk.bn3.weight.grad.abs().max())
