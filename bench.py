@@ -225,6 +225,12 @@ def main():
 
     for _ in range(args.warmup):
         runner.train_step(images, targets)
+    step_flops = None
+    if rank == 0 and not args.no_kernels:  # one extra UNTIMED step under torch's flop counter (convs + GEMMs, fwd + bwd)
+        from torch.utils.flop_counter import FlopCounterMode
+        with FlopCounterMode(display=False) as fc:
+            runner.train_step(images, targets)
+        step_flops = float(fc.get_total_flops())
     rdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -266,6 +272,13 @@ def main():
             "kernel": "rsdet_box_iou_rotated_grouped_f32 = iou_prepare + iou_filter + iou_clip kernels",
             "us_per_launch": roof["us"], "shape": roof["shape"], "valu_frac": roof["valu_frac"],
             "alg_gflop": roof["alg_gflop"], "overlapping_pairs": roof["overlapping_pairs"]}) if roof else None,
+        # the conv / GEMM side of the step against the MFMA roofline: flops of one rank's step as counted
+        # by torch.utils.flop_counter, over the measured step time, over the dense peak of the compute dtype
+        "flop_roofline": None if step_flops is None else {
+            "bound": "mfma", "tflop_per_step_per_gpu": step_flops / 1e12,
+            "achieved": step_flops / (dt / args.steps) / 1e12, "unit": "TFLOP/s",
+            "peak": FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0,
+            "frac": step_flops / (dt / args.steps) / 1e12 / (FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0)},
         "kernels": kernels,
         "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
     }
