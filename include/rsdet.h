@@ -198,6 +198,17 @@ int rsdet_bn_act_backward_f32(const float* grad_y, const float* y, const float* 
                               int relu, float* grad_x, float* grad_residual, float* grad_weight, float* grad_bias,
                               void* ws, size_t ws_bytes, void* stream);
 
+/* ---- 8(f) rank 1  polygon IoU + tile-merge polygon NMS (evaluation side) ------------------------------------
+ * Replaces ops/nms_poly.py:247-252 (iou_poly: shapely intersection area, max(union, 0.01) in the denominator),
+ * data/devkits/result_merge.py:66-126 (py_cpu_nms_poly_fast) and the overlap loop of
+ * data/devkits/voc_eval.py:263-304.  Quadrilaterals are 8 doubles (x1,y1,...,x4,y4), either orientation; at least
+ * one polygon of a pair must be convex (detections are rectangles).  shapely is not available: parity unpinned.
+ * rsdet_nms_poly_sorted_f64: polys already in descending-score order; keep_sorted[i] = 1 if kept; horizontal-hull
+ * gate and `IoU > thr` suppression exactly as py_cpu_nms_poly_fast; ws sized by rsdet_nms_hbb_ws_size(n). */
+int rsdet_poly_iou_f64(const double* polys1, int n1, const double* polys2, int n2, double* ious, void* stream);
+int rsdet_nms_poly_sorted_f64(const double* polys_sorted, int n, double thr, uint8_t* keep_sorted, void* ws,
+                              size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,6 +284,12 @@ using namespace rsdet;
 extern "C" void rsdet_debug_set_sweep_trace(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_trace), &p, sizeof(p)); }
 #endif
 
+void rsdet_launch_nms_sweep(const void* entries, const unsigned* blk_cnt, const unsigned long long* diag_t, int n,
+                            int col_blocks, const int* order, unsigned char* keep, hipStream_t stream) {
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_NT), (size_t)(col_blocks + 1) * 8 + (size_t)col_blocks * 4,
+                     stream, (const NmsEntry*)entries, blk_cnt, diag_t, n, col_blocks, order, keep);
+}
+
 static inline size_t nms_sorted_bytes(int n) { return ((size_t)n * sizeof(NmsBox) + 255) & ~(size_t)255; }
 
 // ws layout after the kernel-specific head: diag_t (64*cb words) | blk_cnt (cb) | entries (cb lists of 64*cb)

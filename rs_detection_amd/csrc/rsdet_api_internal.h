@@ -11,4 +11,16 @@ static inline int rsdet_launch_status() {
   return e == hipSuccess ? RSDET_OK : RSDET_ELAUNCH;
 }
 
-static inline int rsdet_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int rsdet_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); // Shared by the rotated / horizontal / polygon NMS entry points (defined in nms_rotated.hip): the device sweep over
+// the sparse suppression entries.  `entries` holds col_blocks lists of 64*col_blocks 16-byte records
+// {u64 bits, int column block, int row}, `blk_cnt` their lengths, `diag_t` the transposed diagonal tiles.
+void rsdet_launch_nms_sweep(const void* entries, const unsigned* blk_cnt, const unsigned long long* diag_t, int n,
+                            int col_blocks, const int* order, unsigned char* keep, hipStream_t stream);
+
+}
+
+// Shared by the rotated / horizontal / polygon NMS entry points (defined in nms_rotated.hip): the device sweep over
+// the sparse suppression entries.  `entries` holds col_blocks lists of 64*col_blocks 16-byte records
+// {u64 bits, int column block, int row}, `blk_cnt` their lengths, `diag_t` the transposed diagonal tiles.
+void rsdet_launch_nms_sweep(const void* entries, const unsigned* blk_cnt, const unsigned long long* diag_t, int n,
+                            int col_blocks, const int* order, unsigned char* keep, hipStream_t stream);

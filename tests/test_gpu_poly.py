@@ -1,0 +1,96 @@
+"""GPU, SURVEY 8f rank 1: polygon IoU kernel, polygon NMS (py_cpu_nms_poly_fast), mergebypoly on files and the DOTA mAP
+driver -- each against the line-by-line CPU restatements in oracle/poly.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import poly as opoly
+from test_devkits_cpu import _rbox_poly, _sq, _synthetic_eval_set
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_quads(rng, n, span=600, convex_only=True):
+    out = []
+    for _ in range(n):
+        if convex_only or rng.random() < 0.8:
+            q = _rbox_poly(*rng.uniform(0, span, 2), rng.uniform(5, 150), rng.uniform(5, 80), rng.uniform(-np.pi, np.pi))
+            q = q + rng.normal(0, 1.5, 8)                     # a general convex quadrilateral, not a rectangle
+            if rng.random() < 0.5:
+                q = q.reshape(4, 2)[::-1].reshape(-1)         # clockwise
+        else:
+            x, y, s = rng.uniform(0, span), rng.uniform(0, span), rng.uniform(20, 100)
+            q = np.array([x, y, x + s, y + s / 2, x, y + s, x + 0.4 * s, y + s / 2])   # arrow head (concave)
+        out.append(q)
+    return np.stack(out)
+
+
+def test_poly_iou_matrix_vs_oracle(cuda):
+    from rs_detection_amd.ops import poly_iou_matrix, iou_poly
+    rng = np.random.default_rng(0)
+    a, b = _random_quads(rng, 70), _random_quads(rng, 90, convex_only=False)
+    got = poly_iou_matrix(a, b, device=cuda).cpu().numpy()
+    want = np.array([[opoly.iou_poly(x, y) for y in b] for x in a])
+    assert np.abs(got - want).max() <= 1e-9
+    assert ((got == 0) == (want == 0)).all()
+    assert iou_poly(_sq(0, 0, 10), _sq(5, 0, 10), device=cuda) == pytest.approx(50 / 150, abs=1e-15)
+    assert iou_poly(_sq(0, 0, 10), [5, -5, 15, 5, 5, 15, -5, 5], device=cuda) == pytest.approx(0.5, abs=1e-15)
+    same = poly_iou_matrix(a, a, device=cuda).cpu().numpy()
+    assert np.abs(np.diag(same) - 1).max() <= 1e-12 and np.abs(same - same.T).max() <= 1e-9   # self-IoU, symmetry
+    assert poly_iou_matrix(np.zeros((0, 8)), a, device=cuda).shape == (0, 70)
+
+
+@pytest.mark.parametrize("n,thr", [(1, 0.1), (64, 0.1), (65, 0.3), (700, 0.1), (2500, 0.3)])
+def test_nms_poly_vs_py_cpu_nms_poly_fast(cuda, n, thr):
+    from rs_detection_amd.ops import nms_poly
+    rng = np.random.default_rng(n)
+    centres = rng.uniform(0, 2000, (max(n // 8, 1), 2))
+    c = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 4, (n, 2))
+    polys = np.stack([_rbox_poly(c[i, 0], c[i, 1], rng.uniform(30, 90), rng.uniform(10, 40), rng.uniform(-1.5, 1.5))
+                      for i in range(n)])
+    dets = np.concatenate([polys, rng.uniform(0.05, 1, (n, 1))], 1)
+    want = opoly.py_cpu_nms_poly_fast(dets, thr)
+    got = nms_poly(dets, thr, device=cuda).cpu().numpy()
+    assert got.tolist() == [int(i) for i in want]          # same boxes in the same (descending score) order
+    assert nms_poly(np.zeros((0, 9)), thr, device=cuda).numel() == 0
+
+
+def test_mergebypoly_files_and_map_driver_on_gpu(cuda, tmp_path):
+    from rs_detection_amd.data.devkits import mergebypoly, evaluate_dota
+    rng = np.random.default_rng(9)
+    src, dst = tmp_path / "before_nms", tmp_path / "after_nms"
+    src.mkdir()
+    lines = {}
+    for cls in ("Ship", "Bridge"):
+        rows = []
+        for img in ("P1", "P2"):
+            for _ in range(60):
+                p = _rbox_poly(*rng.uniform(100, 1800, 2), rng.uniform(30, 80), rng.uniform(10, 30), rng.uniform(-1, 1))
+                for dx, dy in ((0, 0), (824, 0)):          # every object reported by two overlapping tiles
+                    rows.append(("%s__1__%d___%d" % (img, dx, dy), "%.4f" % rng.uniform(0.1, 1),
+                                 ["%.4f" % v for v in (p - np.tile([dx, dy], 4) + rng.normal(0, 0.5, 8))]))
+        lines[cls] = rows
+        with open(src / (cls + ".txt"), "w") as f:
+            for name, score, poly in rows:
+                f.write(" ".join([name, score] + poly) + "\n")
+    mergebypoly(str(src), str(dst), device=cuda)
+    from rs_detection_amd.data.devkits import merge_detections
+    for cls in lines:
+        want = merge_detections(lines[cls], 0.1, lambda d, t: opoly.py_cpu_nms_poly_fast(d, t))
+        got = {}
+        for l in open(dst / (cls + ".txt")).read().strip().splitlines():
+            t = l.split()
+            got.setdefault(t[0], []).append([float(v) for v in t[2:]] + [float(t[1])])
+        assert set(got) == set(want)
+        for img in want:
+            np.testing.assert_allclose(np.array(got[img]), np.array(want[img]), rtol=0, atol=1e-9)
+            assert 55 <= len(got[img]) <= 70               # duplicates from the second tile are gone
+    # DOTA mAP: GPU pairwise IoU == oracle pairwise IoU
+    results = _synthetic_eval_set(np.random.default_rng(3), n_img=12)
+    classes = ["a", "b", "c"]
+    want = evaluate_dota(results, classes, pairwise=lambda A, B: np.array([opoly.iou_poly(x, y) for x, y in zip(A, B)]))
+    got = evaluate_dota(results, classes, device=cuda)
+    for k in want:
+        assert got[k] == pytest.approx(want[k], abs=1e-12)
