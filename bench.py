@@ -106,8 +106,8 @@ def kernel_rooflines(device, targets):
     out["box_iou_rotated(prepare+filter+clip)"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                          frac=by / t / 1e9 / HBM_PEAK_GBS,
                                          # HBM bytes per launch from the rocprofv3 PMC passes of this very shape
-                                         # (profiles/r01_d_pmc_hbm_traffic.txt: WRITE 50.8+1.1+0.9 MB, FETCH 2x5.7 MB)
-                                         traffic=64.2e6 if (n1, A) == (556, 21824) else None, us=t * 1e6,
+                                         # (profiles/r01_g_pmc_hbm_traffic.txt: WRITE 51.0+1.1+0.9 MB, FETCH 2x5.7 MB)
+                                         traffic=64.4e6 if (n1, A) == (556, 21824) else None, us=t * 1e6,
                                          mpairs_per_s=n1 * A / t / 1e6, shape="sumK=%d x A=%d (B=%d)" % (n1, A, len(ks)),
                                          overlapping_pairs=nz, alg_gflop=alg_flops / 1e9,
                                          valu_frac=alg_flops / t / 1e12 / FP32_VALU_PEAK_TFLOPS)

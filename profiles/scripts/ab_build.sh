@@ -1,0 +1,10 @@
+#!/bin/bash
+# builds scratch/lib_<tag>.so with extra -D flags: ./ab_build.sh tag -DFOO
+set -e
+cd /root/repo/rs_detection_amd/csrc
+tag=$1; shift
+mkdir -p /tmp/ab_$tag
+for f in box_iou_rotated nms_rotated assign box_coder arf deform_conv rroi_align bn_act poly_iou; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c $f.hip -o /tmp/ab_$tag/$f.o &
+done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/scratch/lib_$tag.so /tmp/ab_$tag/*.o
