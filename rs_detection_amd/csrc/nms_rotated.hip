@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
 // History (M = 5 344, 84 blocks): one thread per word with one dependent load per kept row 9 us per
 // block; dense rows prefetched by 16 waves 1.4 us per block (64 KB per step through one CU's memory
 // pipe); sparse entries: see DESIGN.md.
-#ifdef RSDET_SWEEP_TRACE  // debug builds only (scratch/): per-step stage timestamps of wave 0, 100 MHz wall clock
+#ifdef RSDET_SWEEP_TRACE  // debug builds only (profiles/scripts/trace_sweep.py): per-step stage timestamps of wave 0, 100 MHz wall clock
 __device__ unsigned long long* g_sweep_trace;
 #define STRACE(bk, k, v)                                                                 \
   do {                                                                                   \

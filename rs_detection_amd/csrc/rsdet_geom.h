@@ -254,7 +254,7 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
     const float ox = odd ? p3.x : p2.x, oy = odd ? p3.y : p2.y;
     return F2{hi ? ox : ex, hi ? oy : ey};
   };
-#if defined(RSDET_AB_STAGE) && RSDET_AB_STAGE <= 1  // timing-only ablation builds (scratch/ab_build.sh)
+#if defined(RSDET_AB_STAGE) && RSDET_AB_STAGE <= 1  // timing-only ablation builds (profiles/scripts/ab_build.sh)
   return a0.x + b3.y;
 #endif
   // ---- edge l of box1 against edges 0..3 of box2
