@@ -89,6 +89,17 @@ __global__ __launch_bounds__(64) void iou_prepare_kernel(
   if (lane == 0) colbox[word] = make_float4(x0, y0, x1, y1);
 }
 
+#ifdef RSDET_FILTER_TRACE  // debug builds only (profiles/scripts/trace_filter.py): per-workgroup stage timestamps, 100 MHz
+__device__ unsigned long long* g_trace;
+#define TRACE(k)                                                                                     \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && g_trace)                                                                 \
+      g_trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define TRACE(k)
+#endif
+
 template <int VERSION>
 __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
     const BoxPre* __restrict__ pre1, int n1, const BoxPre* __restrict__ pre2, int n2,
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
   __shared__ int s_c1, s_c2;
   __shared__ unsigned s_base;
 
+  TRACE(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int col0 = blockIdx.x * IOU_NT;
@@ -155,9 +167,11 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
   };
   // pin the strip box in registers here: a wait for it placed after the fill would be a vmcnt(0)
   asm volatile("" : "+v"(cb.x), "+v"(cb.y), "+v"(cb.z), "+v"(cb.w));
+  TRACE(1);
   const bool fill_late = tid < 64;
   if (!fill_late) zero_fill();
   lds_barrier();
+  TRACE(2);
 
   // ---- strip culling: lane i < nrows tests row i's circle against the bounding box of this wave's
   // 64 column circles (iou_prepare).  Both sides carry a 1e-3 relative pad, so a culled strip
@@ -193,6 +207,7 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
     }
   }
   lds_barrier();
+  TRACE(3);
 
   // ---- pass B: separating axes on the compacted list (dense lanes).  In-place compaction is safe:
   // by the barrier every entry below q0 + IOU_NT has been read, and at most that many were kept.
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
     }
   }
   lds_barrier();
+  TRACE(4);
 
   // ---- flush the survivors to the global work queue (one returning atomic per workgroup)
   const int total = s_c2;
@@ -222,6 +238,7 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
   const unsigned shard = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u) % IOU_SHARDS;
   if (tid == 0) s_base = atomicAdd(counter + shard * 32, (unsigned)total);
   lds_barrier();
+  TRACE(5);
   if (fill_late) zero_fill();
   const unsigned base = s_base;  // capacity = entries per shard
   const int fit = base >= capacity ? 0 : (int)min((unsigned)total, capacity - base);
@@ -238,6 +255,7 @@ __global__ __launch_bounds__(IOU_NT) void iou_filter_kernel(
   // ---- queue overflow: clip the rest here (same routine, worse balance).  __syncthreads() drains
   // this workgroup's zero stores (s_waitcnt vmcnt(0) before s_barrier), so the values written
   // below land after them.
+  TRACE(6);
   if (fit == total) return;
   __syncthreads();
   if (tid >= 64) return;
@@ -293,6 +311,10 @@ __global__ __launch_bounds__(CLIP_NT) void iou_clip_kernel(
 }  // namespace rsdet
 
 using namespace rsdet;
+
+#ifdef RSDET_FILTER_TRACE
+extern "C" void rsdet_debug_set_trace(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }
+#endif
 
 static inline size_t pre_bytes(long long n) { return ((size_t)n * sizeof(BoxPre) + 255) & ~(size_t)255; }
 // entries per shard: a workgroup appends at most IOU_TI*IOU_NT pairs, so tiny problems still fit

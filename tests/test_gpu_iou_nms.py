@@ -121,6 +121,25 @@ def test_iou_properties_full_size(cuda):
     assert float(ops.box_iou_rotated(g, far).abs().max()) == 0.0
 
 
+def test_iou_work_queue_overflow_is_exact(cuda, oracle_c):
+    """More overlapping pairs than the work queue holds (4 Mi): 2 200 x 2 200 boxes from one tight pile, every pair
+    overlaps, so ~0.6 M pairs overflow their queue shard and are clipped by the filter workgroups themselves.
+    Every entry must still be the exact IoU: sampled rows against the oracle, the diagonal == 1."""
+    from rs_detection_amd import ops
+    rng = np.random.default_rng(21)
+    n = 2200
+    b = np.tile(np.array([[500, 500, 120, 60, 0.4]], np.float32), (n, 1))
+    b[:, :2] += rng.normal(0, 3, (n, 2)).astype(np.float32)
+    b[:, 2:4] *= np.exp(rng.normal(0, 0.05, (n, 2))).astype(np.float32)
+    b[:, 4] += rng.normal(0, 0.05, n).astype(np.float32)
+    got = ops.box_iou_rotated(_t(b, cuda), _t(b, cuda)).cpu().numpy()
+    assert (got > 0).all() and np.abs(np.diag(got) - 1).max() <= 1e-5
+    rows = rng.choice(n, 12, replace=False)
+    want = oracle_c.box_iou_rotated(b[rows], b, 0)
+    assert np.abs(got[rows] - want).max() <= IOU_TOL
+    assert (got[rows].view(np.int32) == want.view(np.int32)).mean() > 0.999
+
+
 def _clustered(rng, n, with_label):
     centres = dota_boxes(rng, max(n // 10, 1), 600)
     idx = rng.integers(0, centres.shape[0], n)
