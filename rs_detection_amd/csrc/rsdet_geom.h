@@ -122,10 +122,23 @@ struct Scratch {
   __device__ __forceinline__ void put(int k, F2 v) const { base[k * stride] = v; }
 };
 
+// The reference compares fp32 values against double literals (`(double)x < 1e-6` ...).  None of the literals is
+// representable in fp32, so each comparison is EXACTLY a fp32 comparison against a neighbouring float -- no
+// v_cvt_f64_f32 / v_cmp_f64 (quarter / half rate) in the clipper:
+//   (double)x <  1e-6   <=>  x <= 0x358637bd (9.99999997e-07, the largest float below 1e-6)
+//   (double)x >  1e-8   <=>  x >= 0x322bcc78 (1.00000008e-08, the smallest float above 1e-8)
+//   (double)x <  1e-14  <=>  x <= 0x283424dc (9.99999982e-15)
+//   (double)x >  1e-14  <=>  x >= 0x283424dd (1.00000007e-14)
+// (NaN fails both forms alike.)
+__device__ __forceinline__ bool lt_1e6(float x) { return x <= __uint_as_float(0x358637bdu); }
+__device__ __forceinline__ bool gt_1e8(float x) { return x >= __uint_as_float(0x322bcc78u); }
+__device__ __forceinline__ bool lt_1e14(float x) { return x <= __uint_as_float(0x283424dcu); }
+__device__ __forceinline__ bool gt_1e14(float x) { return x >= __uint_as_float(0x283424ddu); }
+
 // hull-sort predicate of the reference CPU path (box_iou_rotated.py:317-325)
 __device__ __forceinline__ bool hull_less(F2 A, F2 B) {
   float c = f2cross(A, B);
-  if (fabs((double)c) < 1e-6) return f2dot(A, A) < f2dot(B, B);
+  if (lt_1e6(fabsf(c))) return f2dot(A, A) < f2dot(B, B);
   return c > 0;
 }
 
@@ -148,7 +161,7 @@ __device__ __forceinline__ float hull_area_general(const Scratch sc, int n) {
     F2 q = f2sub(sc.get(i), best);
     if (i == t) q = f2sub(p0, best);
     sc.put(i, q);
-    if (k == n && (double)f2dot(q, q) > 1e-8) k = i;
+    if (k == n && gt_1e8(f2dot(q, q))) k = i;
   }
   sc.put(0, F2{best.x - best.x, best.y - best.y});
   // insertion sort of q[1..n), libstdc++ __insertion_sort order of comparisons
@@ -237,7 +250,7 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
   const int l = lane & 3;
   const int qsh = lane & 60;  // bit position of this quad inside a wave ballot
   float sx = (a.cx + b.cx) * 0.5f, sy = (a.cy + b.cy) * 0.5f;
-  if ((double)a.area < 1e-14 || (double)b.area < 1e-14) return 0.f;
+  if (lt_1e14(a.area) || lt_1e14(b.area)) return 0.f;
 
   // corners 0, 1 (VERSION 0: box_iou_rotated.py:64-67, VERSION 1: _v1.py:69-72); 2, 3 are their
   // mirrors through the centre (:68-71)
@@ -264,7 +277,7 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
   auto solve = [&](F2 P2, F2 P2n, F2& pt) -> bool {
     const F2 v2 = f2sub(P2n, P2);
     float det = f2cross(v2, v1);
-    if (!(fabs((double)det) > 1e-14)) return false;
+    if (!gt_1e14(fabsf(det))) return false;
     F2 d = f2sub(P2, P1);
     float c1 = f2cross(v2, d), c2 = f2cross(v1, d);
     // exact shortcut: skip the IEEE divisions when 0 <= t <= 1 is already decided with a margin
@@ -339,7 +352,7 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
         if (k == t) q[k] = q0old;
         d[k] = f2dot(q[k], q[k]);
       }
-      if ((double)d[1] > 1e-8) {  // reference's k == 1 (:206-212); otherwise serial path
+      if (gt_1e8(d[1])) {  // reference's k == 1 (:206-212); otherwise serial path
         F2* ring = qscr + 16;  // slots 16..23: sorted ring; 8..15: fan terms (both free when n <= 8)
         unsigned used = 0u;    // ranks handed out by this lane
         // lane l ranks elements l and l + 4 of q[1..n)
@@ -352,7 +365,7 @@ __device__ __forceinline__ float pair_iou_quad(const BoxPre& a, const BoxPre& b,
 #pragma unroll
           for (int jx = 1; jx < 8; ++jx) {
             float c = f2cross(qk, q[jx]);
-            bool tie = fabs((double)c) < 1e-6;
+            bool tie = lt_1e6(fabsf(c));
             bool j_first = tie ? (d[jx] < dk) : (c < 0);  // less(q[jx], qk)
             bool k_first = tie ? (dk < d[jx]) : (c > 0);  // less(qk, q[jx])
             bool precede = jx < kk ? !k_first : j_first;  // stable: earlier index wins ties
