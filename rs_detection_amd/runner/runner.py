@@ -3,7 +3,8 @@
 Counterpart of /root/reference/python/jdet/runner/runner.py:23-179 restricted to what the
 hot path needs: ``train_step`` (forward, parse_losses, backward, grad all-reduce via DDP,
 clip 35, SGD update, LR schedule -- :131-179) and ``test_time`` (:105-129: warm-up then timed
-iterations on one cached batch, prints FPS).  Datasets, checkpoints, loggers, eval: out of scope.
+iterations on one cached batch, prints FPS), ``save`` / ``load`` / ``resume`` in the reference's checkpoint
+layout (:251-290, runner/checkpoint.py).  Loggers and the epoch loop: out of scope.
 """
 import time
 
@@ -57,6 +58,38 @@ class Runner:
             self.scheduler.step(self.iter, self.epoch, by_epoch=True)
         self.iter += 1
         return total, parsed
+
+    # ---- checkpoints (:251-290) -----------------------------------------------------------
+    def save(self, path):
+        from .checkpoint import save_checkpoint
+        if self.rank != 0:
+            return None
+        return save_checkpoint(path, self.model, self.optimizer, self.scheduler,
+                               meta=dict(epoch=self.epoch, iter=self.iter, config=dict(self.cfg) if hasattr(self.cfg, "keys") else None))
+
+    def load(self, load_path, model_only=False):
+        from .checkpoint import read_checkpoint, model_parameters, load_parameters
+        data = read_checkpoint(load_path)
+        if not model_only and isinstance(data, dict):
+            meta = data.get("meta", dict())
+            self.epoch, self.iter = meta.get("epoch", self.epoch), meta.get("iter", self.iter)
+            if self.scheduler is not None:
+                self.scheduler.load_parameters(data.get("scheduler", dict()))
+            opt = data.get("optimizer")
+            if self.optimizer is not None and isinstance(opt, dict) and "param_groups" in opt:
+                import numpy as np
+                def back(o):
+                    if isinstance(o, np.ndarray):
+                        return torch.from_numpy(o)
+                    if isinstance(o, dict):
+                        return {k: back(v) for k, v in o.items()}
+                    if isinstance(o, list):
+                        return [back(v) for v in o]
+                    return o
+                self.optimizer.load_state_dict(back(opt))
+        return load_parameters(self.model, model_parameters(data))
+
+    resume = load
 
     @torch.no_grad()
     def predict(self, images, targets):
