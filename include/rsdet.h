@@ -135,6 +135,15 @@ int rsdet_arf_forward_f32(const float* weight, const uint8_t* indices, int O, in
 int rsdet_arf_backward_f32(const uint8_t* indices, const float* grad_out, int O, int I, int nOri,
                            int kH, int kW, int nRot, float* grad_weight, void* stream);
 
+/* ---- 8(f)4  rotation-invariant encoding ------------------------------------------------------
+ * Replaces rie_forward / rie_backward: ops/orn.py:516-540 (CPU kernels :290-363).  feature / aligned /
+ * grad (nBatch, nFeature*nOri) fp32 [H = W = 1]; direction (nBatch, nFeature) uint8 = first arg-max over
+ * the orientations; aligned[(l - direction + nOri) % nOri] = feature[l]; backward is the inverse shift. */
+int rsdet_rie_forward_f32(const float* feature, int nBatch, int nFeature, int nOri, uint8_t* direction,
+                          float* aligned, void* stream);
+int rsdet_rie_backward_f32(const uint8_t* direction, const float* grad_out, int nBatch, int nFeature, int nOri,
+                           float* grad_in, void* stream);
+
 /* ---- a11  deformable convolution v1 (AlignConv) ---------------------------------------------
  * Replaces deformable_im2col / deformable_col2im / deformable_col2im_coord:
  * ops/dcn_v1.py:309-410 (kernels :132-306).  Geometry = the reference's argument list.

@@ -100,6 +100,23 @@ class _COracle:
         self.lib.oracle_arf_backward(_up(indices), _fp(grad_out), O, I, nOri, kH, kW, nRot, _fp(gw))
         return gw
 
+    # 8(f)4 -- ops/orn.py:290-363: feature (N, nFeature*nOri) -> (direction (N, nFeature) uint8, aligned like feature)
+    def rie_forward(self, feature, nOri):
+        feature = _f32(feature)
+        N, C = feature.shape[:2]
+        F = C // nOri
+        d, out = np.zeros((N, F), np.uint8), np.zeros((N, C), np.float32)
+        self.lib.oracle_rie_forward(_fp(feature), N, F, nOri, _up(d), _fp(out))
+        return d, out.reshape(feature.shape)
+
+    def rie_backward(self, direction, grad_out, nOri):
+        direction = np.ascontiguousarray(direction, dtype=np.uint8)
+        grad_out = _f32(grad_out)
+        N, F = direction.shape
+        gi = np.zeros((N, F * nOri), np.float32)
+        self.lib.oracle_rie_backward(_up(direction), _fp(grad_out), N, F, nOri, _fp(gi))
+        return gi.reshape(grad_out.shape)
+
     @staticmethod
     def _geom(geom):
         return [int(geom[k]) for k in ("kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw")]
@@ -226,6 +243,21 @@ class _RefOracle:
         self.lib.ref_arf_backward(_up(indices), nOri, kH, kW, nRot, _fp(grad_out),
                                   grad_out.shape[0], grad_out.shape[1], _fp(gw))
         return gw
+
+    def rie_forward(self, feature, nOri):
+        feature = _f32(feature)
+        N, C = feature.shape[:2]
+        d, out = np.zeros((N, C // nOri), np.uint8), np.zeros((N, C), np.float32)
+        self.lib.ref_rie_forward(_fp(feature), N, C, nOri, _up(d), _fp(out))
+        return d, out.reshape(feature.shape)
+
+    def rie_backward(self, direction, grad_out, nOri):
+        direction = np.ascontiguousarray(direction, dtype=np.uint8)
+        grad_out = _f32(grad_out)
+        N, F = direction.shape
+        gi = np.zeros((N, F * nOri), np.float32)
+        self.lib.ref_rie_backward(_up(direction), N, F, nOri, _fp(grad_out), _fp(gi))
+        return gi.reshape(grad_out.shape)
 
 
 _c = None

@@ -30,6 +30,9 @@ Entry points of the .so (all arrays caller-allocated):
   ref_box_iou_rotated_v1(b1,n1,b2,n2,out)            ops/box_iou_rotated_v1.py:317-331,492-505
   ref_nms_rotated5/6    (dets,n,order,thr,keep)      ops/nms_rotated.py:314-328,414-449
   ref_arf_forward/backward                            ops/orn.py:132-257 (uint16 index quirk included)
+  ref_rie_forward/backward                            ops/orn.py:283-395 (forward: the embedded CPU_SRC body; backward: the
+                                                      header's RIE_backward_cpu_kernel called directly, because the embedded
+                                                      RIE_CPU_GRAD_SRC body misses a ';' at :383 and does not compile as written)
 """
 import ast
 import os
@@ -144,6 +147,29 @@ extern "C" void ref_arf_backward(unsigned char* in0_p, int in0_shape0, int in0_s
 """ % (hdr, fwd, bwd)
 
 
+def unit_rie(strings):
+    hdr = strings["RIE_CPU_HEADER"]
+    fwd = expand_alias(strings["RIE_CPU_SRC"].replace("aligned->size", "((size_t)in0_shape0*in0_shape1*sizeof(float))"),
+                       {"in0": 2})
+    return """
+namespace rie {
+%s
+}
+extern "C" void ref_rie_forward(float* in0_p, int in0_shape0, int in0_shape1, int nOri, unsigned char* out0_p,
+                                float* out1_p) {
+  using namespace rie;
+  const uint8 nOrientation = (uint8)nOri;
+  %s
+}
+extern "C" void ref_rie_backward(unsigned char* dir_p, int nBatch, int nFeature, int nOri, float* grad_out_p,
+                                 float* grad_in_p) {
+  using namespace rie;
+  std::memset(grad_in_p, 0, (size_t)nBatch * nFeature * nOri * sizeof(float));
+  RIE_backward_cpu_kernel<float>(dir_p, grad_out_p, (uint8)nOri, (uint16)nBatch, (uint16)nFeature, grad_in_p);
+}
+""" % (hdr, fwd)
+
+
 def main():
     if not os.path.isdir(REF_OPS):
         print("build_ref: %s not present -- using prebuilt oracle/_ref if any" % REF_OPS)
@@ -159,6 +185,7 @@ def main():
     tu += unit_nms(sn, 5)
     tu += unit_nms(sn, 6)
     tu += unit_arf(so)
+    tu += unit_rie(so)
     os.makedirs(OUT_DIR, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="jdet_ref_")
     try:

@@ -245,6 +245,36 @@ void oracle_arf_backward(const uint8_t* indices, const float* grad_out, int O, i
       }
 }
 
+// ---- 8(f)4: rotation-invariant encoding (ops/orn.py:290-363) -----------------
+// feature (nBatch, nFeature*nOri) [H = W = 1]; per (batch, feature): direction = first arg-max over the nOri
+// orientations (strict '>' from -FLT_MAX), aligned[(l - direction + nOri) % nOri] = feature[l].
+void oracle_rie_forward(const float* feature, int nBatch, int nFeature, int nOri, uint8_t* direction, float* aligned) {
+  for (int i = 0; i < nBatch; ++i)
+    for (int j = 0; j < nFeature; ++j) {
+      const float* src = feature + ((size_t)i * nFeature + j) * nOri;
+      float best = -3.402823466e+38F;
+      uint8_t d = 0;  // the reference leaves the uint8 untouched if nothing beats -FLT_MAX; its output buffer is zeroed
+      for (int l = 0; l < nOri; ++l)
+        if (src[l] > best) {
+          best = src[l];
+          d = (uint8_t)l;
+        }
+      direction[(size_t)i * nFeature + j] = d;
+      for (int l = 0; l < nOri; ++l) aligned[((size_t)i * nFeature + j) * nOri + (l - d + nOri) % nOri] = src[l];
+    }
+}
+
+// ops/orn.py:336-363: gradInput[(l + direction) % nOri] = gradOutput[l]
+void oracle_rie_backward(const uint8_t* direction, const float* grad_out, int nBatch, int nFeature, int nOri,
+                         float* grad_in) {
+  for (int i = 0; i < nBatch; ++i)
+    for (int j = 0; j < nFeature; ++j) {
+      const uint8_t d = direction[(size_t)i * nFeature + j];
+      for (int l = 0; l < nOri; ++l)
+        grad_in[((size_t)i * nFeature + j) * nOri + (l + d) % nOri] = grad_out[((size_t)i * nFeature + j) * nOri + l];
+    }
+}
+
 // ---- a11: deformable conv v1 pieces -----------------------------------------
 struct DcnGeom {
   int C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, dg, Ho, Wo;

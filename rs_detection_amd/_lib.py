@@ -50,6 +50,8 @@ SIGNATURES = {
                                       c_void_p]),
     "rsdet_arf_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
+    "rsdet_rie_forward_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rsdet_rie_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rsdet_deform_im2col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),
     "rsdet_deform_col2im_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),
     "rsdet_deform_im2col_nhwc_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),

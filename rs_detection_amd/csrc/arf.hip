@@ -57,9 +57,61 @@ __global__ void arf_backward_kernel(const uint8_t* __restrict__ indices,
   }
 }
 
+// ---- rotation-invariant encoding (ops/orn.py:283-540) -------------------------------------
+// One thread per (batch, feature): first arg-max over the nOri orientations, then the cyclic shift that brings
+// it to slot 0.  nOri <= 32: the group lives in registers.
+__global__ void rie_forward_kernel(const float* __restrict__ feature, long long groups, int nOri,
+                                   uint8_t* __restrict__ direction, float* __restrict__ aligned) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
+  const float* src = feature + g * nOri;
+  float best = -3.402823466e+38F;  // -FLT_MAX, strict '>' (orn.py:312-316)
+  int d = 0;
+  for (int l = 0; l < nOri; ++l) {
+    const float v = src[l];
+    if (v > best) {
+      best = v;
+      d = l;
+    }
+  }
+  direction[g] = (uint8_t)d;
+  float* dst = aligned + g * nOri;
+  for (int l = 0; l < nOri; ++l) dst[(l - d + nOri) % nOri] = src[l];
+}
+
+__global__ void rie_backward_kernel(const uint8_t* __restrict__ direction, const float* __restrict__ grad_out,
+                                    long long groups, int nOri, float* __restrict__ grad_in) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= groups) return;
+  const int d = direction[g];
+  for (int l = 0; l < nOri; ++l) grad_in[g * nOri + (l + d) % nOri] = grad_out[g * nOri + l];
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
+
+extern "C" int rsdet_rie_forward_f32(const float* feature, int nBatch, int nFeature, int nOri, uint8_t* direction,
+                                     float* aligned, void* stream) {
+  if (nBatch < 0 || nFeature < 0 || nOri < 1 || nOri > 255) return RSDET_EINVAL;
+  const long long groups = (long long)nBatch * nFeature;
+  if (groups == 0) return RSDET_OK;
+  if (!feature || !direction || !aligned) return RSDET_EINVAL;
+  hipLaunchKernelGGL(rie_forward_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     feature, groups, nOri, direction, aligned);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_rie_backward_f32(const uint8_t* direction, const float* grad_out, int nBatch, int nFeature,
+                                      int nOri, float* grad_in, void* stream) {
+  if (nBatch < 0 || nFeature < 0 || nOri < 1 || nOri > 255) return RSDET_EINVAL;
+  const long long groups = (long long)nBatch * nFeature;
+  if (groups == 0) return RSDET_OK;
+  if (!direction || !grad_out || !grad_in) return RSDET_EINVAL;
+  hipLaunchKernelGGL(rie_backward_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     direction, grad_out, groups, nOri, grad_in);
+  return rsdet_launch_status();
+}
 
 static int arf_check(int O, int I, int nOri, int kH, int kW, int nRot) {
   if (O < 0 || I < 0 || nOri < 1 || kH < 1 || kW < 1 || nRot < 1) return RSDET_EINVAL;

@@ -10,3 +10,4 @@ from .box_coder import (bbox2delta_rotated, delta2bbox_rotated, s2a_refine_and_o
 from .nms import nms
 from . import bbox_transforms
 from .nms_poly import iou_poly, poly_iou_matrix, nms_poly  # noqa: F401,E402
+from .orn import (rie_forward, rie_backward, rotation_invariant_encoding, RotationInvariantEncoding)  # noqa: F401,E402

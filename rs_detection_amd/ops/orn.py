@@ -66,6 +66,68 @@ class _ActiveRotatingFilter(torch.autograd.Function):
 active_rotating_filter = _ActiveRotatingFilter.apply
 
 
+def rie_forward(feature, nOrientation):
+    """orn.py:516-530: feature (N, C, 1, 1) -> (mainDirection (N, C/nOri) uint8, aligned like feature)."""
+    assert feature.dim() == 4, "only supports a batch of RIEs."
+    assert feature.size(2) == 1 and feature.size(3) == 1, "mH x mW should be 1x1."
+    _lib.require_cuda_f32(feature)
+    f = feature.contiguous()
+    N, C = f.shape[:2]
+    nF = C // nOrientation
+    d = torch.empty((N, nF), dtype=torch.uint8, device=f.device)
+    out = torch.empty_like(f)
+    rc = _lib.load().rsdet_rie_forward_f32(_lib.ptr(f), N, nF, int(nOrientation), _lib.ptr(d), _lib.ptr(out),
+                                           _lib.stream_ptr())
+    _lib.check(rc, "rsdet_rie_forward_f32")
+    return d, out
+
+
+def rie_backward(mainDirection, grad_output, nOrientation):
+    """orn.py:533-540."""
+    _lib.require_cuda_f32(grad_output)
+    g = grad_output.contiguous()
+    N, nF = mainDirection.shape
+    gi = torch.empty_like(g)
+    rc = _lib.load().rsdet_rie_backward_f32(_lib.ptr(mainDirection.contiguous()), _lib.ptr(g), N, nF, int(nOrientation),
+                                            _lib.ptr(gi), _lib.stream_ptr())
+    _lib.check(rc, "rsdet_rie_backward_f32")
+    return gi
+
+
+class _RotationInvariantEncoding(torch.autograd.Function):
+    """orn.py:557-567."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, input, nOrientation):
+        d, out = rie_forward(input, nOrientation)
+        ctx.nOrientation = nOrientation
+        ctx.save_for_backward(d)
+        ctx.mark_non_differentiable(d)
+        return out, d
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_output, _grad_direction=None):
+        (d,) = ctx.saved_tensors
+        return rie_backward(d, grad_output, ctx.nOrientation), None
+
+
+rotation_invariant_encoding = _RotationInvariantEncoding.apply
+
+
+class RotationInvariantEncoding(nn.Module):
+    """orn.py:582-593."""
+
+    def __init__(self, nOrientation, return_direction=False):
+        super().__init__()
+        self.nOrientation, self.return_direction = nOrientation, return_direction
+
+    def forward(self, input):
+        output, d = rotation_invariant_encoding(input, self.nOrientation)
+        return (output, d) if self.return_direction else output
+
+
 class RotationInvariantPooling(nn.Module):
     """orn.py:595-617: max over the orientation axis.  The 1x1 conv + BN members are
     parameters of the reference module that its forward bypasses (:615-616); they are

@@ -241,8 +241,31 @@ def main():
                         decoded=oracle.np_delta2bbox_rotated(prop, deltas),
                         decoded_clip1e6=oracle.np_delta2bbox_rotated(prop, deltas, wh_ratio_clip=1e-6),
                         provenance=prov("NumPy transcription of models/boxes/box_ops.py:176-289, seed 20240601"))
+    make_rie(ref)
     print("golden fixtures written to", HERE)
 
 
+def make_rie(ref):
+    """rie.npz: rotation-invariant encoding from the reference's own CPU source (ops/orn.py:290-363 compiled by
+    oracle/build_ref.py; the backward through the header kernel, see build_ref.py).  Own RNG: adding this fixture
+    did not change the others."""
+    rng = np.random.default_rng(20240602)
+    out = {}
+    for tag, (n, nf, nori) in {"a": (7, 32, 8), "b": (3, 5, 4), "c": (16, 64, 8)}.items():
+        f = rng.standard_normal((n, nf * nori, 1, 1)).astype(np.float32)
+        f[0, :nori, 0, 0] = 1.0                     # all equal: the first orientation wins (strict '>')
+        if nori >= 3:
+            f[1, :3, 0, 0] = [2.0, 5.0, 5.0]        # tie of the maximum: the first of them
+        d, al = ref.rie_forward(f, nori)
+        go = rng.standard_normal(f.shape).astype(np.float32)
+        out.update({tag + "_f": f, tag + "_nori": np.int32(nori), tag + "_dir": d, tag + "_aligned": al,
+                    tag + "_go": go, tag + "_gi": ref.rie_backward(d, go, nori)})
+    np.savez_compressed(os.path.join(HERE, "rie.npz"), provenance=prov("seed 20240602; reference CPU RIE"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rie":
+        import oracle as _o
+        make_rie(_o.ref())
+    else:
+        main()

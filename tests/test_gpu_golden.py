@@ -93,3 +93,21 @@ def test_assign_and_coder_golden(cuda):
     assert np.abs((enc - c["encoded"]) / np.maximum(np.abs(c["encoded"]), 1)).max() <= 1e-4
     dec = ops.delta2bbox_rotated(_t(c["proposals"], cuda), _t(c["deltas"], cuda)).cpu().numpy()
     assert np.abs((dec - c["decoded"]) / np.maximum(np.abs(c["decoded"]), 1)).max() <= 1e-4
+
+
+def test_rie_golden_and_autograd(cuda):
+    """HIP rotation-invariant encoding == the reference CPU source's fixtures, bit for bit."""
+    from rs_detection_amd.ops import rie_forward, rie_backward, RotationInvariantEncoding
+    d = np.load(os.path.join(G, "rie.npz"))
+    for tag in "abc":
+        nori = int(d[tag + "_nori"])
+        direction, aligned = rie_forward(_t(d[tag + "_f"], cuda), nori)
+        assert (direction.cpu().numpy() == d[tag + "_dir"]).all()
+        assert (aligned.cpu().numpy().view(np.int32) == d[tag + "_aligned"].view(np.int32)).all()
+        gi = rie_backward(direction, _t(d[tag + "_go"], cuda), nori)
+        assert (gi.cpu().numpy().view(np.int32) == d[tag + "_gi"].view(np.int32)).all()
+    x = _t(d["c_f"], cuda).requires_grad_(True)
+    out, dirs = RotationInvariantEncoding(8, return_direction=True)(x)
+    assert dirs.dtype == torch.uint8 and not dirs.requires_grad
+    out.backward(_t(d["c_go"], cuda))
+    assert (x.grad.cpu().numpy().view(np.int32) == d["c_gi"].view(np.int32)).all()

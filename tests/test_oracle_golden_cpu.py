@@ -143,3 +143,24 @@ def test_oracle_nms_equals_reference_build(oracle_c, oracle_ref):
         assert (oracle_c.nms_rotated(d, order, thr) == oracle_ref.nms_rotated(d, order, thr)).all()
     d6 = np.concatenate([d, rng.integers(0, 3, (400, 1)).astype(np.float32)], 1)
     assert (oracle_c.nms_rotated(d6, order, 0.2) == oracle_ref.nms_rotated(d6, order, 0.2)).all()
+
+
+def test_rie_oracle_matches_reference_cpu_source():
+    """rotation-invariant encoding, oracle restatement == fixtures from the reference's own CPU source
+    (ops/orn.py:290-363), forward (direction + aligned) and backward, bit for bit; first-maximum tie rule."""
+    import oracle
+    d = np.load(os.path.join(G, "rie.npz"))
+    c = oracle.c()
+    for tag in "abc":
+        nori = int(d[tag + "_nori"])
+        direction, aligned = c.rie_forward(d[tag + "_f"], nori)
+        assert (direction == d[tag + "_dir"]).all()
+        assert (aligned.view(np.int32) == d[tag + "_aligned"].view(np.int32)).all()
+        gi = c.rie_backward(d[tag + "_dir"], d[tag + "_go"], nori)
+        assert (gi.view(np.int32) == d[tag + "_gi"].view(np.int32)).all()
+        assert direction[0, 0] == 0                                   # all-equal group: first orientation
+        # the shift brings the maximum to slot 0, and backward inverts forward's permutation
+        f = d[tag + "_f"].reshape(direction.shape[0], -1, nori)
+        assert (aligned.reshape(f.shape)[:, :, 0] == f.max(-1)).all()
+        assert (c.rie_backward(direction, aligned, nori).reshape(f.shape) == f).all()
+    assert d["a_dir"][1, 0] == 1                                      # [2, 5, 5, ...]: the first of the two maxima
