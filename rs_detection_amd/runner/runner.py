@@ -4,7 +4,9 @@ Counterpart of /root/reference/python/jdet/runner/runner.py:23-179 restricted to
 hot path needs: ``train_step`` (forward, parse_losses, backward, grad all-reduce via DDP,
 clip 35, SGD update, LR schedule -- :131-179) and ``test_time`` (:105-129: warm-up then timed
 iterations on one cached batch, prints FPS), ``save`` / ``load`` / ``resume`` in the reference's checkpoint
-layout (:251-290, runner/checkpoint.py).  Loggers and the epoch loop: out of scope.
+layout (:251-290, runner/checkpoint.py), and the epoch loop ``run`` / ``train`` / ``val`` (:91-103, :131-208) over the
+``dataset.train`` / ``dataset.val`` sections of the config (data/).  Loggers are a print line; flip-test and the
+tile-merge submission of ``test`` live in data/devkits.
 """
 import time
 
@@ -40,6 +42,10 @@ class Runner:
             distributed = self.world > 1
         self.ddp = rdist.wrap_ddp(self.model, device) if distributed else self.model
         self.iter, self.epoch = 0, 0
+        self.max_epoch = cfg.max_epoch if hasattr(cfg, "max_epoch") else None
+        self.max_iter = cfg.max_iter if hasattr(cfg, "max_iter") else None
+        self.train_dataset = self.val_dataset = None
+        self.work_dir = None
 
     def train_step(self, images, targets):
         self.model.train()
@@ -58,6 +64,73 @@ class Runner:
             self.scheduler.step(self.iter, self.epoch, by_epoch=True)
         self.iter += 1
         return total, parsed
+
+    # ---- epoch loop (:86-103, :131-208) -----------------------------------------------------
+    def build_datasets(self, work_dir=None):
+        """``dataset.train`` / ``dataset.val`` of the config -> datasets, sharded over the ranks."""
+        import rs_detection_amd.data  # noqa: F401  (registers DATASETS / TRANSFORMS)
+        from rs_detection_amd.utils.registry import DATASETS
+        ds = self.cfg.dataset if hasattr(self.cfg, "dataset") and self.cfg.dataset else {}
+        if ds.get("train"):
+            self.train_dataset = build_from_cfg(ds["train"], DATASETS)
+            self.train_dataset.set_shard(self.rank, self.world)
+        if ds.get("val"):
+            self.val_dataset = build_from_cfg(ds["val"], DATASETS)
+        self.work_dir = work_dir
+        return self
+
+    @property
+    def finish(self):
+        if self.max_epoch:
+            return self.epoch >= self.max_epoch
+        return self.max_iter is not None and self.iter >= self.max_iter
+
+    def train(self, log_interval=50):
+        """One epoch over ``train_dataset`` (:131-179)."""
+        from rs_detection_amd.data import batch_to_device
+        self.train_dataset.set_epoch(self.epoch)
+        start, last = time.time(), None
+        for batch_idx, (images, targets) in enumerate(self.train_dataset):
+            images, targets = batch_to_device(images, targets, self.device)
+            total, losses = self.train_step(images, targets)      # train_step advances self.iter
+            last = total
+            if log_interval and self.iter % log_interval == 0 and self.rank == 0:
+                fps = len(targets) * self.world * (batch_idx + 1) / (time.time() - start)
+                print("epoch %d iter %d lr %.5f loss %.4f fps %.1f " % (self.epoch, self.iter, self.optimizer.cur_lr(),
+                                                                      float(total.detach()), fps) +
+                      " ".join("%s %.4f" % (k, float(v.detach())) for k, v in losses.items()))
+            if self.finish:
+                break
+        self.epoch += 1
+        return last
+
+    @torch.no_grad()
+    def val(self):
+        """:196-208 on rank 0: predictions of ``val_dataset`` -> ``val_dataset.evaluate`` (DOTA mAP on the GPU)."""
+        if self.val_dataset is None or self.rank != 0:
+            return None
+        from rs_detection_amd.data import batch_to_device
+        results = []
+        for images, targets in self.val_dataset:
+            timg, ttg = batch_to_device(images, targets, self.device)
+            for (polys, scores, labels), t in zip(self.predict(timg, ttg), targets):
+                results.append(((polys.double().cpu().numpy(), scores.cpu().numpy(), labels.long().cpu().numpy()), t))
+        return self.val_dataset.evaluate(results, self.work_dir, self.epoch, device=self.device)
+
+    def run(self, checkpoint_interval=None, eval_interval=None, log_interval=50):
+        """:91-103: train epochs until ``max_epoch``; checkpoint / evaluate at the config's intervals."""
+        import os
+        ci = checkpoint_interval if checkpoint_interval is not None else getattr(self.cfg, "checkpoint_interval", None)
+        ei = eval_interval if eval_interval is not None else getattr(self.cfg, "eval_interval", None)
+        evals = {}
+        while not self.finish:
+            self.train(log_interval)
+            if ci and self.epoch % ci == 0 and self.work_dir:
+                os.makedirs(os.path.join(self.work_dir, "checkpoints"), exist_ok=True)
+                self.save(os.path.join(self.work_dir, "checkpoints", "ckpt_%d.pkl" % self.epoch))
+            if ei and self.epoch % ei == 0:
+                evals[self.epoch] = self.val()
+        return evals
 
     # ---- checkpoints (:251-290) -----------------------------------------------------------
     def save(self, path):

@@ -171,3 +171,33 @@ def test_dota_dataset_feeds_the_model_and_the_map_driver(cuda, tmp_path):
             results.append(((polys.cpu().numpy().astype(np.float64), scores.cpu().numpy(), labels.cpu().numpy().astype(np.int64)), t))
     aps = ds.evaluate(results, device=cuda)
     assert "eval/0_meanAP" in aps and 0.0 <= aps["eval/0_meanAP"] <= 1.0
+
+
+def test_runner_epoch_loop_checkpoint_and_eval(cuda, tmp_path):
+    """The reference's run loop (runner.py:91-103) on a generated DOTA-format folder: two epochs, a checkpoint per
+    epoch in the reference's pickle layout, mAP after each epoch, then resume into a fresh runner."""
+    from test_data_pipeline_cpu import _make_dataset
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.runner.runner import Runner
+    data = tmp_path / "data"
+    data.mkdir()
+    _make_dataset(data, n=5)
+    tf = [dict(type="RotatedResize", min_size=256, max_size=256), dict(type="Pad", size_divisor=32),
+          dict(type="Normalize", mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_bgr=False)]
+    cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
+    cfg.dataset = dict(train=dict(type="DOTADataset", dataset_dir=str(data), batch_size=2, shuffle=True, transforms=tf),
+                       val=dict(type="DOTADataset", dataset_dir=str(data), batch_size=2, transforms=tf))
+    cfg.max_epoch, cfg.checkpoint_interval, cfg.eval_interval = 2, 1, 1
+    torch.manual_seed(0)
+    r = Runner(cfg, device=cuda, distributed=False).build_datasets(work_dir=str(tmp_path / "work"))
+    evals = r.run(log_interval=0)
+    assert r.epoch == 2 and r.iter == 4 and set(evals) == {1, 2}
+    assert all("eval/0_meanAP" in e for e in evals.values())
+    ck = tmp_path / "work" / "checkpoints"
+    assert sorted(os.listdir(ck)) == ["ckpt_1.pkl", "ckpt_2.pkl"]
+    torch.manual_seed(1)
+    r2 = Runner(cfg, device=cuda, distributed=False)
+    loaded, missing, unexpected, mismatched = r2.load(str(ck / "ckpt_2.pkl"))
+    assert not missing and not unexpected and not mismatched and (r2.epoch, r2.iter) == (2, 4)
+    for k, v in r.model.state_dict().items():
+        assert torch.equal(v, r2.model.state_dict()[k]), k
