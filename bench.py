@@ -226,7 +226,9 @@ def main():
     for _ in range(args.warmup):
         runner.train_step(images, targets)
     step_flops = None
-    if rank == 0 and not args.no_kernels:  # one extra UNTIMED step under torch's flop counter (convs + GEMMs, fwd + bwd)
+    if not args.no_kernels:
+        # one extra UNTIMED step under torch's flop counter (convs + GEMMs, fwd + bwd).  On EVERY rank: the step
+        # contains DDP's gradient all-reduce, a rank that skipped it would leave the others hanging.
         from torch.utils.flop_counter import FlopCounterMode
         with FlopCounterMode(display=False) as fc:
             runner.train_step(images, targets)
