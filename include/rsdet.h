@@ -175,6 +175,12 @@ int rsdet_deform_im2col_nhwc_f32(const float* im, const float* offset, const rsd
                                  float* colT, void* stream);
 int rsdet_deform_col2im_nhwc_f32(const float* colT, const float* offset, const rsdet_dcn_geom* g,
                                  float* grad_im, void* stream);
+/* Gather form of the channels-last col2im for ONE deformable group: the (position, tap, corner) -> input pixel map
+ * is inverted first (integer histogram / scan / fill in ws), then every input pixel sums its contributions from
+ * colT with plain loads and ONE store per element -- no floating-point atomics, grad_im need not be zeroed. */
+size_t rsdet_deform_col2im_gather_ws_size(const rsdet_dcn_geom* g);
+int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset, const rsdet_dcn_geom* g,
+                                        float* grad_im, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a18  ROIAlignRotated_v1 -----------------------------------------------------------------
  * Replaces _RotatedROIAlign_v1.execute / .grad: ops/roi_align_rotated_v1.py:300-351

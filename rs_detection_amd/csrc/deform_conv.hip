@@ -320,6 +320,195 @@ __global__ __launch_bounds__(64 * DCN_WAVES) void deform_col2im_nhwc_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Gather form of the channels-last col2im (one deformable group): no floating-point atomics.
+//
+// The scatter kernel above issues 4 corners x kh*kw taps x C channels atomic adds per position --
+// 2.4 GB of atomic traffic at pyramid level 0, the chip-wide fp32 atomic floor (1.84 ms).  The
+// footprints do not depend on the channel, so the scatter can be inverted once per call on
+// (position, tap, corner) triples -- 2.4 M integers instead of 2.4 GB of floats:
+//   dcn_idx_count   histogram of contributions per input pixel          (int atomics)
+//   dcn_idx_scan    exclusive prefix sum over the pixels                (chunk sums + per-chunk scan)
+//   dcn_idx_fill    each contribution takes a slot of its pixel: {colT row, bilinear weight}
+//   dcn_gather      one wave per input pixel, lanes over channels: grad_im[pixel] = sum_w * colT[row]
+//                   (1-KiB coalesced row reads, ONE plain store per element, no zero fill)
+// The order of the terms of a pixel's sum is the arrival order of dcn_idx_fill -- as free as the
+// order of the atomics it replaces (and of the reference's atomicAdd, dcn_v1.py:110-113).
+struct PixFoot {
+  long long p1, p2, p3, p4;  // linear input-pixel indices (b*H*W + y*W + x), -1 = outside
+  float w1, w2, w3, w4;
+};
+
+__device__ __forceinline__ PixFoot pix_foot(const float* __restrict__ offset, const Geom& g, long long item) {
+  const int taps = g.kh * g.kw;
+  const long long pos = item / taps;
+  const int tap = (int)(item - pos * taps);
+  int b, ho, wo, hw;
+  nhwc_position(g, pos, b, ho, wo, hw);
+  const long long plane = (long long)g.Ho * g.Wo;
+  const int i = tap / g.kw, j = tap - i * g.kw;
+  const float* offp = offset + (long long)b * g.dg * 2 * taps * plane;
+  const float h = (ho * g.sh - g.ph) + i * g.dh + offp[(long long)(2 * tap) * plane + hw];
+  const float w = (wo * g.sw - g.pw) + j * g.dw + offp[(long long)(2 * tap + 1) * plane + hw];
+  const Foot f = col2im_foot(h, w, g.H, g.W);
+  const long long base = (long long)b * g.H * g.W;
+  PixFoot t;
+  t.p1 = f.o1 >= 0 ? base + f.o1 : -1;
+  t.p2 = f.o2 >= 0 ? base + f.o2 : -1;
+  t.p3 = f.o3 >= 0 ? base + f.o3 : -1;
+  t.p4 = f.o4 >= 0 ? base + f.o4 : -1;
+  t.w1 = f.w1; t.w2 = f.w2; t.w3 = f.w3; t.w4 = f.w4;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void dcn_idx_count_kernel(const float* __restrict__ offset, Geom g,
+                                                            long long items, int* __restrict__ cnt) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  const PixFoot t = pix_foot(offset, g, item);
+  if (t.p1 >= 0) atomicAdd(cnt + t.p1, 1);
+  if (t.p2 >= 0) atomicAdd(cnt + t.p2, 1);
+  if (t.p3 >= 0) atomicAdd(cnt + t.p3, 1);
+  if (t.p4 >= 0) atomicAdd(cnt + t.p4, 1);
+}
+
+// exclusive scan of cnt[0..n) into start[0..n], start[n] = total, in two launches: per-chunk sums, then every
+// workgroup adds up the sums before its chunk and scans the chunk (also clears cnt for dcn_idx_fill).  A single
+// 1024-thread workgroup walking all pixels took 36 us per call.
+constexpr int SCAN_NT = 256, SCAN_PER = 16, SCAN_CHUNK = SCAN_NT * SCAN_PER;  // 4096 pixels per workgroup
+
+__device__ __forceinline__ int block_sum_256(int v, int* s_tmp) {  // all threads get the total
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int t = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(SCAN_NT) void dcn_idx_chunk_sum_kernel(const int* __restrict__ cnt, long long n,
+                                                                    int* __restrict__ chunk_sum) {
+  __shared__ int s_tmp[4];
+  const long long base = (long long)blockIdx.x * SCAN_CHUNK + (long long)threadIdx.x * SCAN_PER;
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; ++k)
+    if (base + k < n) sum += cnt[base + k];
+  const int t = block_sum_256(sum, s_tmp);
+  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(SCAN_NT) void dcn_idx_scan_kernel(int* __restrict__ cnt, long long n,
+                                                               const int* __restrict__ chunk_sum, int nchunks,
+                                                               int* __restrict__ start) {
+  __shared__ int s_tmp[4];
+  __shared__ int s_scan[SCAN_NT];
+  const int tid = threadIdx.x;
+  int before = 0;  // sum of the chunks in front of this one
+  for (int c = tid; c < (int)blockIdx.x; c += SCAN_NT) before += chunk_sum[c];
+  before = block_sum_256(before, s_tmp);
+  const long long base = (long long)blockIdx.x * SCAN_CHUNK + (long long)tid * SCAN_PER;
+  int v[SCAN_PER], sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; ++k) {
+    v[k] = base + k < n ? cnt[base + k] : 0;
+    sum += v[k];
+  }
+  s_scan[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < SCAN_NT; off <<= 1) {  // Hillis-Steele over the 256 thread sums
+    const int o = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += o;
+    __syncthreads();
+  }
+  int run = before + s_scan[tid] - sum;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; ++k)
+    if (base + k < n) {
+      start[base + k] = run;
+      cnt[base + k] = 0;
+      run += v[k];
+    }
+  if ((int)blockIdx.x == nchunks - 1 && tid == SCAN_NT - 1) start[n] = before + s_scan[SCAN_NT - 1];
+}
+
+__global__ __launch_bounds__(256) void dcn_idx_fill_kernel(const float* __restrict__ offset, Geom g, long long items,
+                                                           const int* __restrict__ start, int* __restrict__ fill,
+                                                           int* __restrict__ ent_row, float* __restrict__ ent_w) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  const PixFoot t = pix_foot(offset, g, item);
+#define RSDET_PUT(P, Wt)                                    \
+  if (P >= 0) {                                             \
+    const int slot = start[P] + atomicAdd(fill + P, 1);     \
+    ent_row[slot] = (int)item;                              \
+    ent_w[slot] = Wt;                                       \
+  }
+  RSDET_PUT(t.p1, t.w1)
+  RSDET_PUT(t.p2, t.w2)
+  RSDET_PUT(t.p3, t.w3)
+  RSDET_PUT(t.p4, t.w4)
+#undef RSDET_PUT
+}
+
+// one wave per input pixel; pixels are walked in 8x8 tiles so that the four pixels sharing a colT row
+// (the corners of one sampling point) are processed close together and the row is re-read from L2
+template <bool VEC4>
+__global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const float* __restrict__ colT,
+                                                                    const int* __restrict__ start,
+                                                                    const int* __restrict__ ent_row,
+                                                                    const float* __restrict__ ent_w, Geom g,
+                                                                    float* __restrict__ grad_im) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long npix = (long long)g.B * g.H * g.W;
+  long long wid = (long long)blockIdx.x * DCN_WAVES + wave;
+  if (wid >= npix) return;
+  long long pix = wid;
+  if ((g.H & 7) == 0 && (g.W & 7) == 0) {  // tile swizzle
+    const long long plane = (long long)g.H * g.W;
+    const int b = (int)(wid / plane);
+    const int r = (int)(wid - (long long)b * plane);
+    const int tile = r >> 6, in = r & 63, tpr = g.W >> 3;
+    const int y = (tile / tpr) * 8 + (in >> 3), x = (tile % tpr) * 8 + (in & 7);
+    pix = (long long)b * plane + (long long)y * g.W + x;
+  }
+  const int e0 = start[pix], e1 = start[pix + 1];
+  const int rowlen = g.C;  // colT row of (position, tap) = item * C
+  if (VEC4) {
+    for (int c = lane * 4; c < g.C; c += 256) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int e = e0;
+      for (; e + 4 <= e1; e += 4) {  // four independent row reads in flight
+        const int r0 = ent_row[e], r1 = ent_row[e + 1], r2 = ent_row[e + 2], r3 = ent_row[e + 3];
+        const float w0 = ent_w[e], w1 = ent_w[e + 1], w2 = ent_w[e + 2], w3 = ent_w[e + 3];
+        const float4 v0 = *reinterpret_cast<const float4*>(colT + (long long)r0 * rowlen + c);
+        const float4 v1 = *reinterpret_cast<const float4*>(colT + (long long)r1 * rowlen + c);
+        const float4 v2 = *reinterpret_cast<const float4*>(colT + (long long)r2 * rowlen + c);
+        const float4 v3 = *reinterpret_cast<const float4*>(colT + (long long)r3 * rowlen + c);
+        acc.x += w0 * v0.x; acc.y += w0 * v0.y; acc.z += w0 * v0.z; acc.w += w0 * v0.w;
+        acc.x += w1 * v1.x; acc.y += w1 * v1.y; acc.z += w1 * v1.z; acc.w += w1 * v1.w;
+        acc.x += w2 * v2.x; acc.y += w2 * v2.y; acc.z += w2 * v2.z; acc.w += w2 * v2.w;
+        acc.x += w3 * v3.x; acc.y += w3 * v3.y; acc.z += w3 * v3.z; acc.w += w3 * v3.w;
+      }
+      for (; e < e1; ++e) {
+        const int r0 = ent_row[e];
+        const float w0 = ent_w[e];
+        const float4 v0 = *reinterpret_cast<const float4*>(colT + (long long)r0 * rowlen + c);
+        acc.x += w0 * v0.x; acc.y += w0 * v0.y; acc.z += w0 * v0.z; acc.w += w0 * v0.w;
+      }
+      *reinterpret_cast<float4*>(grad_im + pix * g.C + c) = acc;
+    }
+  } else {
+    for (int c = lane; c < g.C; c += 64) {
+      float acc = 0.f;
+      for (int e = e0; e < e1; ++e) acc += ent_w[e] * colT[(long long)ent_row[e] * rowlen + c];
+      grad_im[pix * g.C + c] = acc;
+    }
+  }
+}
+
 static int make_geom(const rsdet_dcn_geom* s, Geom* g) {
   if (!s) return RSDET_EINVAL;
   if (s->C < 0 || s->H < 0 || s->W < 0 || s->B < 0 || s->kh < 1 || s->kw < 1 || s->sh < 1 ||
@@ -434,5 +623,56 @@ extern "C" int rsdet_deform_col2im_nhwc_f32(const float* colT, const float* offs
   else
     hipLaunchKernelGGL(deform_col2im_nhwc_kernel<false>, dim3(nhwc_grid(npos)), dim3(64 * DCN_WAVES),
                        0, (hipStream_t)stream, colT, offset, g, grad_im);
+  return rsdet_launch_status();
+}
+
+static inline size_t dcn_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t rsdet_deform_col2im_gather_ws_size(const rsdet_dcn_geom* geom) {
+  Geom g;
+  if (make_geom(geom, &g)) return 0;
+  const size_t npix = (size_t)g.B * g.H * g.W, ent = (size_t)g.B * g.Ho * g.Wo * g.kh * g.kw * 4;
+  return dcn_align256((npix + 1) * 4) * 2 + dcn_align256(ent * 4) * 2 +
+         dcn_align256((npix / 4096 + 1) * 4);  // cnt | start | ent_row | ent_w | chunk sums
+}
+
+extern "C" int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset,
+                                                   const rsdet_dcn_geom* geom, float* grad_im, void* ws,
+                                                   size_t ws_bytes, void* stream) {
+  Geom g;
+  int rc = make_geom(geom, &g);
+  if (rc) return rc;
+  if (g.dg != 1) return RSDET_EINVAL;  // footprints must not depend on the channel
+  const long long npos = (long long)g.B * g.Ho * g.Wo, npix = (long long)g.B * g.H * g.W;
+  if (npix == 0 || g.C == 0) return RSDET_OK;
+  if (!offset || !grad_im || (npos > 0 && !colT)) return RSDET_EINVAL;
+  const long long items = npos * g.kh * g.kw;
+  if (items * 4 > 0x7fffffffLL) return RSDET_EINVAL;  // int slots
+  if (!ws || ((uintptr_t)ws & 15) || ws_bytes < rsdet_deform_col2im_gather_ws_size(geom)) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)ws;
+  int* cnt = (int*)w;
+  int* start = (int*)(w + dcn_align256((npix + 1) * 4));
+  int* ent_row = (int*)(w + dcn_align256((npix + 1) * 4) * 2);
+  float* ent_w = (float*)(w + dcn_align256((npix + 1) * 4) * 2 + dcn_align256((size_t)items * 4 * 4));
+  if (hipMemsetAsync(cnt, 0, (size_t)(npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+  if (items > 0)
+    hipLaunchKernelGGL(dcn_idx_count_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, offset, g, items,
+                       cnt);
+  int* chunk_sum = (int*)(w + dcn_align256((npix + 1) * 4) * 2 + dcn_align256((size_t)items * 4 * 4) * 2);
+  const int nchunks = (int)((npix + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL(dcn_idx_chunk_sum_kernel, dim3(nchunks), dim3(SCAN_NT), 0, s, cnt, npix, chunk_sum);
+  hipLaunchKernelGGL(dcn_idx_scan_kernel, dim3(nchunks), dim3(SCAN_NT), 0, s, cnt, npix, chunk_sum, nchunks, start);
+  if (items > 0)
+    hipLaunchKernelGGL(dcn_idx_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, offset, g, items,
+                       start, cnt, ent_row, ent_w);
+  const bool vec4 = (g.C % 4 == 0) && (((uintptr_t)colT | (uintptr_t)grad_im) % 16 == 0);
+  const unsigned blocks = (unsigned)((npix + DCN_WAVES - 1) / DCN_WAVES);
+  if (vec4)
+    hipLaunchKernelGGL(dcn_gather_kernel<true>, dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start, ent_row, ent_w,
+                       g, grad_im);
+  else
+    hipLaunchKernelGGL(dcn_gather_kernel<false>, dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start, ent_row,
+                       ent_w, g, grad_im);
   return rsdet_launch_status();
 }

@@ -108,6 +108,24 @@ def test_deform_nhwc_kernels_vs_oracle(cuda, oracle_c, gi):
     want = oracle_c.deform_col2im(gcol, off, im.shape, g, g["dg"])
     got = gim.permute(0, 3, 1, 2).cpu().numpy()
     assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    if g["dg"] == 1:  # gather form (no floating-point atomics): same numbers, every element written exactly once
+        from rs_detection_amd.ops.dcn_v1 import deformable_col2im_gather_nhwc
+        gat = deformable_col2im_gather_nhwc(_t(gcolT, cuda), _t(off, cuda), (B, g["H"], g["W"], C), k, p, s, d)
+        got = gat.permute(0, 3, 1, 2).cpu().numpy()
+        assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_deform_col2im_gather_level0_shape_matches_scatter(cuda):
+    """The step's own shape (B=4, C=256, 128x128: 8x8 tile swizzle, float4 rows, 65 536-pixel scan over 64 chunks) and
+    an awkward one (odd sizes: no swizzle, scalar rows, one partial chunk)."""
+    from rs_detection_amd.ops.dcn_v1 import deformable_col2im_nhwc, deformable_col2im_gather_nhwc
+    torch.manual_seed(5)
+    for (B, C, H, W) in ((4, 256, 128, 128), (2, 30, 37, 21)):
+        off = torch.randn(B, 18, H, W, device=cuda) * 2.5
+        colT = torch.randn(B * H * W, 9 * C, device=cuda)
+        a = deformable_col2im_nhwc(colT, off, (B, H, W, C), (3, 3), (1, 1), (1, 1), (1, 1))
+        g = deformable_col2im_gather_nhwc(colT, off, (B, H, W, C), (3, 3), (1, 1), (1, 1), (1, 1))
+        assert float((a - g).abs().max()) <= 1e-4 * float(a.abs().max())
 
 
 def test_deform_conv_nhwc_path_equals_reference_layout_path(cuda):
