@@ -132,8 +132,14 @@ def kernel_rooflines(device, targets):
                                             frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
     colT = ops.deformable_im2col_nhwc(xn, off, (3, 3), (1, 1), (1, 1), (1, 1))
     t = event_time(lambda: ops.deformable_col2im_nhwc(colT, off, xn.shape, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
-    out["deform_col2im_nhwc_kernel"] = dict(bound="hbm(atomics)", achieved=by / t / 1e9, peak=HBM_PEAK_GBS,
-                                            unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+    out["deform_col2im_nhwc_kernel(atomics; several deformable groups only)"] = dict(
+        bound="hbm(atomics)", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+        traffic=None, us=t * 1e6)
+    from rs_detection_amd.ops.dcn_v1 import deformable_col2im_gather_nhwc
+    t = event_time(lambda: deformable_col2im_gather_nhwc(colT, off, xn.shape, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
+    out["dcn_idx_count+scan+fill+dcn_gather(col2im of the step)"] = dict(
+        bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+        traffic=None, us=t * 1e6)
     del colT, xn, x, off
     # -- rotated NMS (a16), SURVEY 8d micro-bench shape M=5344, 6 columns, thr 0.1
     d, s, l = syn.nms_cluster_boxes(5344)
