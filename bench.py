@@ -28,7 +28,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive conv search on a fresh box
+# MIOpen find mode (honoured if already set): FAST for the S2ANet line -- measured equal to NORMAL there (64.5 vs 64.4
+# ms/step) at 6 s instead of 30 s start-up on a fresh box; NORMAL for --model orcnn_van3, where FAST lands on im2col+GEMM
+# convolutions for the VAN backbone (347 vs 157 ms/step).
+os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL" if "orcnn_van3" in sys.argv else "FAST")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -196,6 +199,10 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE config[1] (the metric); bf16 = torch.autocast over the MIOpen/rocBLAS part "
                          "(configs[2]/[4]); the oriented-box kernels always compute in fp32")
+    ap.add_argument("--model", choices=["s2anet_r50", "orcnn_van3"], default="s2anet_r50",
+                    help="s2anet_r50 = BASELINE configs[1] (the metric, default); orcnn_van3 = the Oriented R-CNN + VAN-B3 "
+                         "model of configs[3] (RROIAlign + rotated NMS in the train step), 2 tiles per GPU as in the "
+                         "reference config; reported under its own workload name, no kernel table")
     ap.add_argument("--memory-format", choices=["channels_last", "contiguous"], default="contiguous",
                     help="activation layout of the torch/MIOpen part (measured r1 on MI355X, fp32: "
                          "NCHW 68.7 ms/step, channels_last 494 ms/step)")
@@ -215,18 +222,26 @@ def main():
     from rs_detection_amd.runner.runner import Runner
     torch.manual_seed(0)  # same initial weights on every rank (DDP also broadcasts)
     mf = torch.channels_last if args.memory_format == "channels_last" else None
-    runner = Runner(s2anet_cfg(), device=device, memory_format=mf,
+    if args.model == "orcnn_van3":
+        from rs_detection_amd.config import Config
+        cfg, batch, ncls = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")), 2, 10
+        args.no_kernels = True
+    else:
+        cfg, batch, ncls = s2anet_cfg(), BATCH_PER_GPU, 15
+    runner = Runner(cfg, device=device, memory_format=mf,
                     amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     # synthetic DOTA-shaped batch, resident in HBM before the timed region
     g = torch.Generator(device="cpu").manual_seed(0 + rank)
-    images = torch.randn(BATCH_PER_GPU, 3, TILE, TILE, generator=g).to(device)
+    images = torch.randn(batch, 3, TILE, TILE, generator=g).to(device)
     if mf is not None:
         images = images.contiguous(memory_format=mf)
     targets = []
-    for t in syn.synthetic_targets(BATCH_PER_GPU, rank=rank, it=0):
+    for t in syn.synthetic_targets(batch, rank=rank, it=0, num_classes=ncls):
         t = dict(t)
         t["rboxes"] = torch.from_numpy(t["rboxes"]).to(device)
         t["labels"] = torch.from_numpy(t["labels"]).to(device)
+        if args.model == "orcnn_van3":
+            t["hboxes"] = None
         targets.append(t)
 
     for _ in range(args.warmup):
@@ -255,9 +270,10 @@ def main():
         return
     kernels = {} if args.no_kernels else kernel_rooflines(device, targets)
     roof = kernels.get("box_iou_rotated(prepare+filter+clip)")
-    tiles = BATCH_PER_GPU * world * args.steps
+    tiles = batch * world * args.steps
     line = {
-        "metric": "1024x1024 tiles/sec S2ANet-R50-FPN train",
+        "metric": "1024x1024 tiles/sec S2ANet-R50-FPN train" if args.model == "s2anet_r50" else
+                  "1024x1024 tiles/sec Oriented-RCNN VAN-B3 train",
         "value": tiles / dt,
         "unit": "tiles/s",
         "n_gpus": world,
@@ -269,10 +285,12 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "S2ANet-R50-FPN train step, %d x 1024x1024 DOTA-shaped tiles per GPU, %s, "
-                               "K gts/tile cycle [16,100,400,40], A=21824 anchors/tile"
-                               % (BATCH_PER_GPU, "fp32" if args.dtype == "f32" else "bf16 autocast (fp32 box kernels)"),
-                   "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
+        "config": {"workload": ("S2ANet-R50-FPN train step, %d x 1024x1024 DOTA-shaped tiles per GPU, %s, "
+                                "K gts/tile cycle [16,100,400,40], A=21824 anchors/tile" if args.model == "s2anet_r50" else
+                                "Oriented R-CNN + VAN-B3 (orcnn_van3_7_anchor) train step, %d x 1024x1024 tiles per GPU, %s, "
+                                "K gts/tile cycle [16,100,400,40], 10 classes, 2000 proposals/tile -> 512 sampled RoIs")
+                               % (batch, "fp32" if args.dtype == "f32" else "bf16 autocast (fp32 box kernels)"),
+                   "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "memory_format": args.memory_format},
         "final_loss": loss_v,
         "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
