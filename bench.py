@@ -144,16 +144,24 @@ def kernel_rooflines(device, targets):
         bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
         traffic=None, us=t * 1e6)
     del colT, xn, x, off
-    # -- rotated NMS (a16), SURVEY 8d micro-bench shape M=5344, 6 columns, thr 0.1
+    # -- rotated NMS (a16), SURVEY 8d micro-bench shape M=5344, 6 columns (15 classes), thr 0.1.  Timed the way the
+    #    class-aware entry points call it (ops.ml_nms_rotated: label-major order, one concurrent sweep per label run)
+    #    and, for reference, in plain score order through one sweep.
     d, s, l = syn.nms_cluster_boxes(5344)
     d6 = torch.from_numpy(np.concatenate([d, l[:, None].astype(np.float32)], 1)).to(device)
-    order = torch.argsort(torch.from_numpy(s).to(device), descending=True, stable=True).int()
-    t = event_time(lambda: ops.nms_rotated_keep_mask(d6, order, 0.1, 6), 10, 2)
+    sc, lab = torch.from_numpy(s).to(device), torch.from_numpy(l).to(device)
+    from rs_detection_amd.ops.nms_rotated import _label_major_order
+    lorder = _label_major_order(sc, lab).int()
+    order = torch.argsort(sc, descending=True, stable=True).int()
     M = 5344
     by = 4 * 6 * M + 2 * 8 * M * ((M + 63) // 64) + M
-    out["nms_rotated(3 kernels)"] = dict(bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6,
-                                         mboxes_per_s=M / t / 1e6)
+    for name, fn in (("nms_rotated(3 kernels; label-major order, as ml_nms_rotated calls it)",
+                      lambda: ops.nms_rotated_keep_mask(d6, lorder, 0.1, 6, label_major=True)),
+                     ("nms_rotated(3 kernels; plain score order, one sweep)",
+                      lambda: ops.nms_rotated_keep_mask(d6, order, 0.1, 6))):
+        t = event_time(fn, 10, 2)
+        out[name] = dict(bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6, mboxes_per_s=M / t / 1e6)
     return out
 
 

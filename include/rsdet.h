@@ -64,10 +64,16 @@ int rsdet_box_iou_rotated_grouped_f32(const float* boxes1, int n1, int stride1,
  * (kernels :353-411 + host sweep :450-493, CPU loop :414-449).
  * dets (n, box_len) with box_len 5, or 6 (6th column = class label: boxes of
  * different labels never suppress each other, :283-286).  order (n) int32 =
- * indices by descending score.  A box is suppressed when its IoU with an earlier
+ * indices by descending score -- or any order that keeps the boxes of every label
+ * score-descending (e.g. label-major: tiles whose two 64-box blocks hold disjoint
+ * label ranges are skipped; if the caller PROMISES a label-major order by OR-ing
+ * RSDET_NMS_LABEL_MAJOR into `ge`, the runs of equal labels are also swept
+ * concurrently, one workgroup each).  A box is suppressed when its IoU with an earlier
  * kept box is >= thr (CPU-path predicate :444; ge=0 selects the CUDA-path `>` :403).
  * keep (n) uint8, indexed like dets (jt.where(keep) gives ascending indices, :525).
  * Workspace: rsdet_nms_rotated_ws_size(n) bytes, 16-byte aligned, device. */
+#define RSDET_NMS_GE 1          /* suppress on IoU >= thr (reference CPU path); 0: IoU > thr (CUDA path) */
+#define RSDET_NMS_LABEL_MAJOR 2 /* `order` is label-major: equal labels contiguous, score-descending inside */
 size_t rsdet_nms_rotated_ws_size(int n);
 int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, const int* order, float thr,
                           int ge, uint8_t* keep, void* ws, size_t ws_bytes, void* stream);

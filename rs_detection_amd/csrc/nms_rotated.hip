@@ -36,6 +36,7 @@ struct NmsBox {
 };  // 48 B
 
 constexpr int NMS_NT = 256;
+constexpr int NMS_MAX_SEGS = 4096;  // label runs the sweep can take apart; beyond that it falls back to one sweep
 
 struct NmsEntry {           // one non-zero 64-bit word of the suppression matrix
   unsigned long long bits;  // bit j: the row's box suppresses box 64*cblock + j
@@ -43,18 +44,43 @@ struct NmsEntry {           // one non-zero 64-bit word of the suppression matri
   int row;                  // row inside its 64-box block
 };  // 16 B
 
-__global__ void nms_prepare_kernel(const float* __restrict__ dets, int n, int box_len,
-                                   const int* __restrict__ order, NmsBox* __restrict__ sorted,
-                                   unsigned* __restrict__ blk_cnt) {
+// 256 threads = four 64-box blocks.  Besides the gather + fp64 sincos, every wave reduces the label range of its
+// block: nms_mask skips a tile whose row and column blocks cannot share a label -- with a label-major order
+// (ops/nms_rotated.py builds one for the class-aware entry points) that is ~14 of 15 tiles of a 15-class set.
+__global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restrict__ dets, int n, int box_len,
+                                                          const int* __restrict__ order,
+                                                          NmsBox* __restrict__ sorted, unsigned* __restrict__ blk_cnt,
+                                                          float2* __restrict__ blk_label, int label_major,
+                                                          int* __restrict__ segs) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < (n + 63) / 64) blk_cnt[p] = 0u;
-  if (p >= n) return;
-  const float* b = dets + (long long)order[p] * box_len;
-  NmsBox o;
-  o.p = prepare_box(b);
-  o.label = box_len == 6 ? b[5] : 0.f;
-  o.pad = 0.f;
-  sorted[p] = o;
+  float lo = INFINITY, hi = -INFINITY;
+  if (p < n) {
+    const float* b = dets + (long long)order[p] * box_len;
+    // segment table for the sweep: with a label-major order every run of equal labels is an independent NMS
+    bool starts = p == 0;
+    if (label_major && box_len == 6 && p > 0) starts = !(b[5] == dets[(long long)order[p - 1] * box_len + 5]);
+    if (starts) {
+      const int idx = atomicAdd(segs, 1);  // segs[0] was zeroed by the launcher
+      if (idx < NMS_MAX_SEGS) segs[1 + idx] = p;
+    }
+    NmsBox o;
+    o.p = prepare_box(b);
+    o.label = box_len == 6 ? b[5] : 0.f;
+    o.pad = 0.f;
+    sorted[p] = o;
+    lo = hi = o.label;
+    if (!(o.label == o.label)) {  // a NaN label never equals anything: keep the block's range open
+      lo = -INFINITY;
+      hi = INFINITY;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off));
+    hi = fmaxf(hi, __shfl_xor(hi, off));
+  }
+  if ((threadIdx.x & 63) == 0 && (p >> 6) < (n + 63) / 64) blk_label[p >> 6] = make_float2(lo, hi);
 }
 
 // One wave: lane = row of tile (rb, cbk); append the non-zero words to row block rb's entry list.
@@ -80,9 +106,14 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
                                                           float thr, int col_blocks,
                                                           NmsEntry* __restrict__ entries,
                                                           unsigned* __restrict__ blk_cnt,
-                                                          unsigned long long* __restrict__ diag_t) {
+                                                          unsigned long long* __restrict__ diag_t,
+                                                          const float2* __restrict__ blk_label) {
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;  // lower triangle never read by the sweep
+  if (cbk != rb) {       // label ranges apart: no pair of this tile passes the label gate (diagonal tiles always run:
+    const float2 lr = blk_label[rb], lc = blk_label[cbk];  // they own diag_t)
+    if (lr.x > lc.y || lc.x > lr.y) return;
+  }
   __shared__ F2 s_pts[kQuadSlots * (NMS_NT / 4)];
   __shared__ NmsBox s_row[64];
   __shared__ NmsBox s_col[64];
@@ -194,85 +225,112 @@ constexpr int SWEEP_PRE = SWEEP_NT * SWEEP_EPT;   // entries of a block that com
 __global__ __launch_bounds__(SWEEP_NT) void nms_sweep_kernel(
     const NmsEntry* __restrict__ entries, const unsigned* __restrict__ blk_cnt,
     const unsigned long long* __restrict__ diag_t, int n, int col_blocks,
-    const int* __restrict__ order, uint8_t* __restrict__ keep) {
+    const int* __restrict__ order, uint8_t* __restrict__ keep, const int* __restrict__ segs) {
   extern __shared__ unsigned long long s_removed[];  // col_blocks words, 1 kept word, col_blocks counts
   unsigned long long* s_kept = s_removed + col_blocks;
   unsigned* s_cnt = reinterpret_cast<unsigned*>(s_removed + col_blocks + 1);
+  __shared__ int s_end;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int w = tid; w < col_blocks; w += SWEEP_NT) {
-    s_removed[w] = 0ull;
-    s_cnt[w] = blk_cnt[w];
-  }
-  __syncthreads();
-
   const size_t seg = (size_t)64 * col_blocks;  // entries reserved per row block
-  struct Pre {  // everything block bk needs from memory
-    uint4 ent[SWEEP_EPT];
-    unsigned long long diag;
-    int ord;
-  };
-  auto prefetch = [&](int bk, Pre& p) {
-    p.diag = diag_t[bk * 64 + lane];  // padded to whole blocks
-    p.ord = order[min(bk * 64 + lane, n - 1)];
-    const uint4* e = reinterpret_cast<const uint4*>(entries + (size_t)bk * seg);
-#pragma unroll
-    for (int k = 0; k < SWEEP_EPT; ++k) p.ent[k] = e[k * SWEEP_NT + tid];  // seg >= SWEEP_PRE slots exist (ws slack)
-  };
-  // one block: `cur` was requested two steps ago (a step is shorter than a trip to memory), `fill`
-  // is requested now for block bk + 2 and first touched two steps on.  The loop is unrolled by
-  // three with the buffers rotated -- no register moves, so no wait for the loads in flight.
-  auto step = [&](int bk, const Pre& cur, Pre& fill) {
-    STRACE(bk, 0, wall_clock64());
-    prefetch(min(bk + 2, col_blocks - 1), fill);
-    const int rows = min(64, n - bk * 64);
-    if (wave == 0) {
-      const unsigned long long cur_v = s_removed[bk];
-      const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur_v);
-      const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v >> 32));
-      const unsigned long long pre = ((unsigned long long)cur_hi << 32) | cur_lo;  // wave-uniform: scalar registers
-      const unsigned long long cand = ~pre & (rows < 64 ? (1ull << rows) - 1ull : ~0ull);
-      // Greedy NMS inside the 64-box block as a fixpoint instead of a 64-step serial chain.  Lane j
-      // holds column j of the diagonal tile (bit i: box i < j suppresses box j).  K <- cand minus the
-      // boxes suppressed by a member of K: after t rounds the first t decisions are final, so the
-      // fixpoint is the greedy answer (unique: r is kept iff no earlier kept box suppresses it); a
-      // typical block needs 0-6 rounds, the worst case 64.
-      unsigned long long kept = cand;
-      for (int round = 0; round < 64; ++round) {
-        const unsigned long long hit = __ballot((cur.diag & kept) != 0ull);
-        const unsigned long long next = cand & ~hit;
-        if (next == kept) break;
-        kept = next;
-      }
-      STRACE(bk, 1, wall_clock64());
-      if (lane < rows) keep[cur.ord] = (uint8_t)((kept >> lane) & 1ull);
-      if (lane == 0) *s_kept = kept;
-    }
-    lds_barrier();
-    STRACE(bk, 2, wall_clock64());
-    const unsigned long long kept = *s_kept;
-    const unsigned cnt = s_cnt[bk];
-#pragma unroll
-    for (int k = 0; k < SWEEP_EPT; ++k) {
-      const uint4 e = cur.ent[k];  // {bits lo, bits hi, column block, row}
-      if ((unsigned)(k * SWEEP_NT + tid) < cnt && ((kept >> (e.w & 63u)) & 1ull))
-        atomicOr(&s_removed[e.z], ((unsigned long long)e.y << 32) | e.x);
-    }
-    // a block with more than SWEEP_PRE non-zero words: the rest straight from memory
-    for (unsigned q = SWEEP_PRE + tid; q < cnt; q += SWEEP_NT) {
-      const NmsEntry e = entries[(size_t)bk * seg + q];
-      if ((kept >> e.row) & 1ull) atomicOr(&s_removed[e.cblock], e.bits);
-    }
-    lds_barrier();
-    STRACE(bk, 3, wall_clock64());
-  };
 
-  Pre A, B, C;
-  prefetch(0, A);
-  prefetch(min(1, col_blocks - 1), B);
-  for (int bk = 0; bk < col_blocks; bk += 3) {
-    step(bk, A, C);
-    if (bk + 1 < col_blocks) step(bk + 1, B, A);
-    if (bk + 2 < col_blocks) step(bk + 2, C, B);
+  // Segments: runs of one label in a label-major order are independent NMS problems -- one workgroup each,
+  // concurrently (a 15-class set: 15 short walks instead of one long one).  No table / too many runs: one walk.
+  int nseg = segs ? segs[0] : 1;
+  const bool whole = !segs || nseg > NMS_MAX_SEGS;
+  if (whole) nseg = 1;
+  for (int si = blockIdx.x; si < nseg; si += gridDim.x) {
+    int s0 = 0, e0 = n;
+    if (!whole) {
+      s0 = segs[1 + si];
+      if (tid == 0) s_end = n;
+      __syncthreads();
+      int mine_end = n;
+      for (int k = tid; k < nseg; k += SWEEP_NT) {
+        const int st = segs[1 + k];
+        if (st > s0) mine_end = min(mine_end, st);
+      }
+      if (mine_end < n) atomicMin(&s_end, mine_end);
+      __syncthreads();
+      e0 = s_end;
+    }
+    const int b0 = s0 >> 6, b1 = (e0 - 1) >> 6;
+    for (int w = b0 + tid; w <= b1; w += SWEEP_NT) {
+      s_removed[w - b0] = 0ull;
+      s_cnt[w - b0] = blk_cnt[w];
+    }
+    __syncthreads();
+
+    struct Pre {  // everything block bk needs from memory
+      uint4 ent[SWEEP_EPT];
+      unsigned long long diag;
+      int ord;
+    };
+    auto prefetch = [&](int bk, Pre& p) {
+      p.diag = diag_t[bk * 64 + lane];  // padded to whole blocks
+      p.ord = order[min(bk * 64 + lane, n - 1)];
+      const uint4* e = reinterpret_cast<const uint4*>(entries + (size_t)bk * seg);
+#pragma unroll
+      for (int k = 0; k < SWEEP_EPT; ++k) p.ent[k] = e[k * SWEEP_NT + tid];  // seg >= SWEEP_PRE slots exist (ws slack)
+    };
+    // one block: `cur` was requested two steps ago (a step is shorter than a trip to memory), `fill`
+    // is requested now for block bk + 2 and first touched two steps on.  The loop is unrolled by
+    // three with the buffers rotated -- no register moves, so no wait for the loads in flight.
+    auto step = [&](int bk, const Pre& cur, Pre& fill) {
+      STRACE(bk, 0, wall_clock64());
+      prefetch(min(bk + 2, b1), fill);
+      // boxes of this block that belong to the segment (a block at a segment border is shared with its neighbour)
+      const int lo = max(s0 - bk * 64, 0), hi = min(e0 - bk * 64, 64);
+      const unsigned long long segmask = (hi >= 64 ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lo) - 1ull);
+      if (wave == 0) {
+        const unsigned long long cur_v = s_removed[bk - b0];
+        const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur_v);
+        const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v >> 32));
+        const unsigned long long pre = ((unsigned long long)cur_hi << 32) | cur_lo;  // wave-uniform: scalar registers
+        const unsigned long long cand = ~pre & segmask;
+        // Greedy NMS inside the 64-box block as a fixpoint instead of a 64-step serial chain.  Lane j
+        // holds column j of the diagonal tile (bit i: box i < j suppresses box j).  K <- cand minus the
+        // boxes suppressed by a member of K: after t rounds the first t decisions are final, so the
+        // fixpoint is the greedy answer (unique: r is kept iff no earlier kept box suppresses it); a
+        // typical block needs 0-6 rounds, the worst case 64.
+        unsigned long long kept = cand;
+        for (int round = 0; round < 64; ++round) {
+          const unsigned long long hit = __ballot((cur.diag & kept) != 0ull);
+          const unsigned long long next = cand & ~hit;
+          if (next == kept) break;
+          kept = next;
+        }
+        STRACE(bk, 1, wall_clock64());
+        if ((segmask >> lane) & 1ull) keep[cur.ord] = (uint8_t)((kept >> lane) & 1ull);
+        if (lane == 0) *s_kept = kept;
+      }
+      lds_barrier();
+      STRACE(bk, 2, wall_clock64());
+      const unsigned long long kept = *s_kept;
+      const unsigned cnt = s_cnt[bk - b0];
+#pragma unroll
+      for (int k = 0; k < SWEEP_EPT; ++k) {
+        const uint4 e = cur.ent[k];  // {bits lo, bits hi, column block, row}
+        if ((unsigned)(k * SWEEP_NT + tid) < cnt && ((kept >> (e.w & 63u)) & 1ull) && (int)e.z <= b1)
+          atomicOr(&s_removed[(int)e.z - b0], ((unsigned long long)e.y << 32) | e.x);
+      }
+      // a block with more than SWEEP_PRE non-zero words: the rest straight from memory
+      for (unsigned q = SWEEP_PRE + tid; q < cnt; q += SWEEP_NT) {
+        const NmsEntry e = entries[(size_t)bk * seg + q];
+        if (((kept >> e.row) & 1ull) && e.cblock <= b1) atomicOr(&s_removed[e.cblock - b0], e.bits);
+      }
+      lds_barrier();
+      STRACE(bk, 3, wall_clock64());
+    };
+
+    Pre A, B, C;
+    prefetch(b0, A);
+    prefetch(min(b0 + 1, b1), B);
+    for (int bk = b0; bk <= b1; bk += 3) {
+      step(bk, A, C);
+      if (bk + 1 <= b1) step(bk + 1, B, A);
+      if (bk + 2 <= b1) step(bk + 2, C, B);
+    }
+    __syncthreads();  // LDS is re-initialised for the next segment of this workgroup
   }
 }
 
@@ -287,22 +345,26 @@ extern "C" void rsdet_debug_set_sweep_trace(void* p) { (void)hipMemcpyToSymbol(H
 void rsdet_launch_nms_sweep(const void* entries, const unsigned* blk_cnt, const unsigned long long* diag_t, int n,
                             int col_blocks, const int* order, unsigned char* keep, hipStream_t stream) {
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_NT), (size_t)(col_blocks + 1) * 8 + (size_t)col_blocks * 4,
-                     stream, (const NmsEntry*)entries, blk_cnt, diag_t, n, col_blocks, order, keep);
+                     stream, (const NmsEntry*)entries, blk_cnt, diag_t, n, col_blocks, order, keep, (const int*)nullptr);
 }
 
 static inline size_t nms_sorted_bytes(int n) { return ((size_t)n * sizeof(NmsBox) + 255) & ~(size_t)255; }
 
 // ws layout after the kernel-specific head: diag_t (64*cb words) | blk_cnt (cb) | entries (cb lists of 64*cb)
 static inline size_t nms_diag_bytes(int n) { return (((size_t)n + 63) / 64) * 64 * sizeof(unsigned long long); }
-static inline size_t nms_cnt_bytes(int n) { return ((((size_t)n + 63) / 64) * 4 + 255) & ~(size_t)255; }
+static inline size_t nms_cnt_bytes(int n) {  // per 64-box block: entry count (u32) and label range (float2)
+  return (((((size_t)n + 63) / 64) * 4 + 255) & ~(size_t)255) + (((((size_t)n + 63) / 64) * 8 + 255) & ~(size_t)255);
+}
 static inline size_t nms_entry_bytes(int n) {
   size_t cb = ((size_t)n + 63) / 64;
   return (cb * 64 * cb + rsdet::SWEEP_PRE) * sizeof(rsdet::NmsEntry);  // + slack: unconditional prefetch of the last list
 }
 
+static inline size_t nms_seg_bytes() { return (((size_t)NMS_MAX_SEGS + 1) * 4 + 255) & ~(size_t)255; }
+
 extern "C" size_t rsdet_nms_rotated_ws_size(int n) {
   if (n <= 0) return 0;
-  return nms_sorted_bytes(n) + nms_diag_bytes(n) + nms_cnt_bytes(n) + nms_entry_bytes(n);
+  return nms_sorted_bytes(n) + nms_diag_bytes(n) + nms_cnt_bytes(n) + nms_seg_bytes() + nms_entry_bytes(n);
 }
 
 extern "C" int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, const int* order,
@@ -319,17 +381,23 @@ extern "C" int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, cons
   char* w = (char*)ws + nms_sorted_bytes(n);
   unsigned long long* diag_t = (unsigned long long*)w;
   unsigned* blk_cnt = (unsigned*)(w + nms_diag_bytes(n));
-  NmsEntry* entries = (NmsEntry*)(w + nms_diag_bytes(n) + nms_cnt_bytes(n));
+  float2* blk_label = (float2*)(w + nms_diag_bytes(n) + ((((size_t)cb * 4) + 255) & ~(size_t)255));
+  int* segs = (int*)(w + nms_diag_bytes(n) + nms_cnt_bytes(n));
+  NmsEntry* entries = (NmsEntry*)(w + nms_diag_bytes(n) + nms_cnt_bytes(n) + nms_seg_bytes());
+  const int label_major = (ge >> 1) & 1;  // RSDET_NMS_LABEL_MAJOR
+  ge &= 1;
+  if (hipMemsetAsync(segs, 0, sizeof(int), s) != hipSuccess) return RSDET_ELAUNCH;
   hipLaunchKernelGGL(nms_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dets, n, box_len,
-                     order, sorted, blk_cnt);
+                     order, sorted, blk_cnt, blk_label, label_major, segs);
   if (ge)
     hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr, cb,
-                       entries, blk_cnt, diag_t);
+                       entries, blk_cnt, diag_t, blk_label);
   else
     hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr,
-                       cb, entries, blk_cnt, diag_t);
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(SWEEP_NT), (size_t)(cb + 1) * 8 + (size_t)cb * 4, s, entries,
-                     blk_cnt, diag_t, n, cb, order, keep);
+                       cb, entries, blk_cnt, diag_t, blk_label);
+  // one workgroup per label run (at most 64 in flight; more runs are walked in turn); idle workgroups exit at once
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(label_major ? 64 : 1), dim3(SWEEP_NT),
+                     (size_t)(cb + 1) * 8 + (size_t)cb * 4, s, entries, blk_cnt, diag_t, n, cb, order, keep, segs);
   return rsdet_launch_status();
 }
 
@@ -415,7 +483,6 @@ extern "C" int rsdet_nms_hbb_sorted_f32(const float* boxes_sorted, int n, float 
   hipLaunchKernelGGL(rsdet::iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ident, n, blk_cnt);
   hipLaunchKernelGGL(rsdet::nms_hbb_mask_kernel, dim3(cb, cb), dim3(64), 0, s, boxes_sorted, n, thr,
                      plus_one ? 1.f : 0.f, cb, entries, blk_cnt, diag_t);
-  hipLaunchKernelGGL(rsdet::nms_sweep_kernel, dim3(1), dim3(rsdet::SWEEP_NT), (size_t)(cb + 1) * 8 + (size_t)cb * 4, s,
-                     entries, blk_cnt, diag_t, n, cb, ident, keep_sorted);
+  rsdet_launch_nms_sweep(entries, blk_cnt, diag_t, n, cb, ident, keep_sorted, s);
   return rsdet_launch_status();
 }

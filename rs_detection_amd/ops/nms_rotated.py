@@ -11,8 +11,10 @@ from .. import _lib
 __all__ = ["nms_rotated", "ml_nms_rotated", "multiclass_nms_rotated", "nms_rotated_keep_mask"]
 
 
-def nms_rotated_keep_mask(dets, order, iou_threshold, box_length=None, ge=True):
-    """Device twin of nms_rotated_cpu/_cuda (:495-512): dets (n,5|6), order (n) -> bool keep (n)."""
+def nms_rotated_keep_mask(dets, order, iou_threshold, box_length=None, ge=True, label_major=False):
+    """Device twin of nms_rotated_cpu/_cuda (:495-512): dets (n,5|6), order (n) -> bool keep (n).
+    ``label_major=True`` promises that ``order`` keeps equal labels contiguous and score-descending inside
+    (``_label_major_order``): the label runs are then swept concurrently."""
     _lib.require_cuda_f32(dets)
     lib = _lib.load()
     dets = dets.contiguous()
@@ -25,7 +27,8 @@ def nms_rotated_keep_mask(dets, order, iou_threshold, box_length=None, ge=True):
     order = order.to(torch.int32).contiguous()
     ws_bytes = lib.rsdet_nms_rotated_ws_size(n)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dets.device)
-    rc = lib.rsdet_nms_rotated_f32(_lib.ptr(dets), n, bl, _lib.ptr(order), float(iou_threshold), int(bool(ge)),
+    rc = lib.rsdet_nms_rotated_f32(_lib.ptr(dets), n, bl, _lib.ptr(order), float(iou_threshold),
+                                   int(bool(ge)) | (2 if (label_major and bl == 6) else 0),
                                    _lib.ptr(keep), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
     _lib.check(rc, "rsdet_nms_rotated_f32")
     return keep.bool()
@@ -36,12 +39,21 @@ def _order(scores):
     return torch.argsort(scores, dim=0, descending=True, stable=True)
 
 
+def _label_major_order(scores, labels):
+    """Score-descending inside each label, labels in ascending blocks.  Boxes of different labels never interact
+    (nms_rotated.py:285-286), so any order that keeps every label's boxes score-descending yields the keep set of
+    the global score order; grouping them lets nms_mask skip every tile whose two 64-box blocks hold different
+    labels (csrc/nms_rotated.hip)."""
+    by_score = torch.argsort(scores, dim=0, descending=True, stable=True)
+    return by_score[torch.argsort(labels[by_score], dim=0, stable=True)]
+
+
 def ml_nms_rotated(dets, scores, labels, iou_threshold):
     """nms_rotated.py:514-525: class-aware NMS; returns ascending kept indices."""
     assert dets.numel() > 0 and dets.dim() == 2
     assert dets.dtype == scores.dtype
     dets6 = torch.cat([dets, labels.to(dets.dtype).unsqueeze(1)], dim=1)
-    keep = nms_rotated_keep_mask(dets6, _order(scores), iou_threshold, 6)
+    keep = nms_rotated_keep_mask(dets6, _label_major_order(scores, labels), iou_threshold, 6, label_major=True)
     return torch.where(keep)[0]
 
 

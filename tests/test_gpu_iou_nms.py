@@ -198,6 +198,29 @@ def test_nms_suppression_chains_and_dense_blocks(cuda, oracle_c):
     assert (got == want).all(), int((got != want).sum())
 
 
+@pytest.mark.parametrize("n,n_labels", [(700, 3), (3000, 15), (3000, 200), (500, 1), (130, 130)])
+def test_nms_label_major_order_and_segmented_sweep(cuda, oracle_c, n, n_labels):
+    """Class-aware NMS with the label-major order (tiles of disjoint label ranges skipped, one concurrent sweep per
+    label run; 200 labels: more runs than sweep workgroups; runs sharing 64-box blocks) == the oracle's greedy loop
+    in plain score order."""
+    from rs_detection_amd.ops import nms_rotated_keep_mask, ml_nms_rotated
+    from rs_detection_amd.ops.nms_rotated import _label_major_order
+    rng = np.random.default_rng(n + n_labels)
+    d, s = _clustered(rng, n, False)
+    labels = rng.integers(0, n_labels, n)
+    d6 = np.concatenate([d, labels[:, None].astype(np.float32)], 1)
+    want = oracle_c.nms_rotated(d6, np.argsort(-s, kind="stable").astype(np.int32), 0.1)
+    lorder = _label_major_order(_t(s, cuda), torch.from_numpy(labels).to(cuda))
+    lab_sorted = labels[lorder.cpu().numpy()]
+    assert (np.diff(lab_sorted) >= 0).all()
+    got = nms_rotated_keep_mask(_t(d6, cuda), lorder, 0.1, 6, label_major=True).cpu().numpy()
+    assert (got == want).all(), int((got != want).sum())
+    got2 = nms_rotated_keep_mask(_t(d6, cuda), lorder, 0.1, 6, label_major=False).cpu().numpy()   # same order, one sweep
+    assert (got2 == want).all()
+    idx = ml_nms_rotated(_t(d, cuda), _t(s, cuda), torch.from_numpy(labels).to(cuda), 0.1).cpu().numpy()
+    assert (idx == np.nonzero(want)[0]).all()
+
+
 def test_nms_known_answer_and_api(cuda):
     from rs_detection_amd.ops import nms_rotated, ml_nms_rotated
     dets = _t(np.array([[0, 0, 1, 1, 0], [0, 0, .5, .5, .3], [0, 0, .9, .9, 0]], np.float32), cuda)
