@@ -199,6 +199,14 @@ int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const float* rois, i
                                      int H, int W, int PH, int PW, float spatial_scale,
                                      int sample_num, float* grad_feat, void* stream);
 
+/* Gather form of the backward for a fixed sample_num (> 0): grad_out_t is the output gradient in channels-last
+ * form (R, PH*PW, C), grad_feat_nhwc (N, H, W, C) is written completely (no zero fill, no fp32 atomics); the caller
+ * converts layouts.  (roi, bin, sample, corner) -> pixel is inverted on integers in ws first. */
+size_t rsdet_rroi_align_v1_backward_gather_ws_size(int R, int PH, int PW, int sample_num, int N, int H, int W);
+int rsdet_rroi_align_v1_backward_gather_f32(const float* grad_out_t, const float* rois, int R, int C, int N, int H,
+                                            int W, int PH, int PW, float spatial_scale, int sample_num,
+                                            float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a17  rotated_box_to_poly ------------------------------------------------------------------
  * Replaces models/boxes/box_ops.py:633-654.  boxes (n,5) -> polys (n,8). */
 int rsdet_rotated_box_to_poly_f32(const float* boxes, int n, float* polys, void* stream);

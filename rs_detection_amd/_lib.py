@@ -65,6 +65,9 @@ SIGNATURES = {
                                                 c_float, c_int, c_void_p, c_void_p]),
     "rsdet_rroi_align_v1_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                  c_float, c_int, c_void_p, c_void_p]),
+    "rsdet_rroi_align_v1_backward_gather_ws_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "rsdet_rroi_align_v1_backward_gather_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                        c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_rotated_box_to_poly_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_poly_iou_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_nms_poly_sorted_f64": (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p, c_size_t, c_void_p]),

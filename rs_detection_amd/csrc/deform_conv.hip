@@ -626,6 +626,12 @@ extern "C" int rsdet_deform_col2im_nhwc_f32(const float* colT, const float* offs
   return rsdet_launch_status();
 }
 
+void rsdet_launch_index_scan(int* cnt, long long n, int* chunk_sum, int* start, hipStream_t stream) {
+  const int nchunks = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL(dcn_idx_chunk_sum_kernel, dim3(nchunks), dim3(SCAN_NT), 0, stream, cnt, n, chunk_sum);
+  hipLaunchKernelGGL(dcn_idx_scan_kernel, dim3(nchunks), dim3(SCAN_NT), 0, stream, cnt, n, chunk_sum, nchunks, start);
+}
+
 static inline size_t dcn_align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" size_t rsdet_deform_col2im_gather_ws_size(const rsdet_dcn_geom* geom) {
@@ -660,9 +666,7 @@ extern "C" int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const floa
     hipLaunchKernelGGL(dcn_idx_count_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, offset, g, items,
                        cnt);
   int* chunk_sum = (int*)(w + dcn_align256((npix + 1) * 4) * 2 + dcn_align256((size_t)items * 4 * 4) * 2);
-  const int nchunks = (int)((npix + SCAN_CHUNK - 1) / SCAN_CHUNK);
-  hipLaunchKernelGGL(dcn_idx_chunk_sum_kernel, dim3(nchunks), dim3(SCAN_NT), 0, s, cnt, npix, chunk_sum);
-  hipLaunchKernelGGL(dcn_idx_scan_kernel, dim3(nchunks), dim3(SCAN_NT), 0, s, cnt, npix, chunk_sum, nchunks, start);
+  rsdet_launch_index_scan(cnt, npix, chunk_sum, start, s);
   if (items > 0)
     hipLaunchKernelGGL(dcn_idx_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, offset, g, items,
                        start, cnt, ent_row, ent_w);

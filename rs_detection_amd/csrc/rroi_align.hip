@@ -149,6 +149,112 @@ __global__ __launch_bounds__(RROI_NT) void rroi_backward_kernel(
   }
 }
 
+// ---- gather form of the backward (fixed sample_num): no floating-point atomics ---------------------------
+// The scatter kernel above issues R*C*PH*PW*gh*gw*4 fp32 atomics, lanes of a wave aiming at the same few cache
+// lines of one channel plane (120 M atomics, 3.1 ms for 600 RoIs on a 256 x 256 x 256 level).  The footprints do not
+// depend on the channel: invert (roi, bin, sample, corner) -> pixel once on integers (0.47 M entries), then one
+// wave per pixel sums its terms from the channels-last output gradient (R, PH*PW, C) -- 1-KiB coalesced reads,
+// one store per element of the channels-last input gradient (N, H, W, C), no zero fill.
+struct RroiItem {
+  long long p[4];  // input pixel index (batch*H + y)*W + x of the four corners, -1 = outside
+  float w[4];      // bilinear weight / samples per bin
+};
+
+__device__ __forceinline__ RroiItem rroi_item(const float* __restrict__ rois, long long item, int H, int W, int PH,
+                                             int PW, float scale, int sample_num) {
+  const int spb = sample_num * sample_num, bins = PH * PW;
+  const long long n = item / ((long long)bins * spb);
+  const int rem = (int)(item - n * bins * spb);
+  const int bin = rem / spb, smp = rem - bin * spb;
+  const int ph = bin / PW, pw = bin - ph * PW, iy = smp / sample_num, ix = smp - iy * sample_num;
+  const RoiFrame f = make_frame(rois + n * 6, scale, sample_num, PH, PW);
+  const float yy = f.start_h + ph * f.bin_h + (float)(iy + .5f) * f.bin_h / (float)f.gh;
+  const float xx = f.start_w + pw * f.bin_w + (float)(ix + .5f) * f.bin_w / (float)f.gw;
+  const float x = xx * f.cs + yy * f.sn + f.cw;
+  const float y = yy * f.cs - xx * f.sn + f.ch;
+  const Bil b = bilinear(H, W, y, x);
+  RroiItem t;
+  const float count = (float)(f.gh * f.gw);
+  const long long base = (long long)f.batch * H * W;
+  const bool in = b.yl >= 0;
+  t.p[0] = in ? base + b.yl * W + b.xl : -1;
+  t.p[1] = in ? base + b.yl * W + b.xh : -1;
+  t.p[2] = in ? base + b.yh * W + b.xl : -1;
+  t.p[3] = in ? base + b.yh * W + b.xh : -1;
+  t.w[0] = b.w1 / count;
+  t.w[1] = b.w2 / count;
+  t.w[2] = b.w3 / count;
+  t.w[3] = b.w4 / count;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void rroi_idx_count_kernel(const float* __restrict__ rois, long long items, int H,
+                                                             int W, int PH, int PW, float scale, int sample_num,
+                                                             long long npix, int* __restrict__ cnt) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  const RroiItem t = rroi_item(rois, item, H, W, PH, PW, scale, sample_num);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.p[k] >= 0 && t.p[k] < npix) atomicAdd(cnt + t.p[k], 1);
+}
+
+__global__ __launch_bounds__(256) void rroi_idx_fill_kernel(const float* __restrict__ rois, long long items, int H,
+                                                            int W, int PH, int PW, float scale, int sample_num,
+                                                            long long npix, const int* __restrict__ start,
+                                                            int* __restrict__ fill, int* __restrict__ ent_row,
+                                                            float* __restrict__ ent_w) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  const RroiItem t = rroi_item(rois, item, H, W, PH, PW, scale, sample_num);
+  const int row = (int)(item / (sample_num * sample_num));  // roi * PH*PW + bin: row of the (R, PH*PW, C) gradient
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.p[k] >= 0 && t.p[k] < npix) {
+      const int slot = start[t.p[k]] + atomicAdd(fill + t.p[k], 1);
+      ent_row[slot] = row;
+      ent_w[slot] = t.w[k];
+    }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void rroi_gather_kernel(const float* __restrict__ go_t, const int* __restrict__ start,
+                                                          const int* __restrict__ ent_row,
+                                                          const float* __restrict__ ent_w, long long npix, int C,
+                                                          float* __restrict__ grad_nhwc) {
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const int e0 = start[pix], e1 = start[pix + 1];
+  if (VEC4) {
+    for (int c = lane * 4; c < C; c += 256) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int e = e0;
+      for (; e + 2 <= e1; e += 2) {
+        const int r0 = ent_row[e], r1 = ent_row[e + 1];
+        const float w0 = ent_w[e], w1 = ent_w[e + 1];
+        const float4 v0 = *reinterpret_cast<const float4*>(go_t + (long long)r0 * C + c);
+        const float4 v1 = *reinterpret_cast<const float4*>(go_t + (long long)r1 * C + c);
+        acc.x += w0 * v0.x; acc.y += w0 * v0.y; acc.z += w0 * v0.z; acc.w += w0 * v0.w;
+        acc.x += w1 * v1.x; acc.y += w1 * v1.y; acc.z += w1 * v1.z; acc.w += w1 * v1.w;
+      }
+      if (e < e1) {
+        const int r0 = ent_row[e];
+        const float w0 = ent_w[e];
+        const float4 v0 = *reinterpret_cast<const float4*>(go_t + (long long)r0 * C + c);
+        acc.x += w0 * v0.x; acc.y += w0 * v0.y; acc.z += w0 * v0.z; acc.w += w0 * v0.w;
+      }
+      *reinterpret_cast<float4*>(grad_nhwc + pix * C + c) = acc;
+    }
+  } else {
+    for (int c = lane; c < C; c += 64) {
+      float acc = 0.f;
+      for (int e = e0; e < e1; ++e) acc += ent_w[e] * go_t[(long long)ent_row[e] * C + c];
+      grad_nhwc[pix * C + c] = acc;
+    }
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -185,5 +291,54 @@ extern "C" int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const flo
   int gy = per_roi < 8 ? per_roi : 8;
   hipLaunchKernelGGL(rroi_backward_kernel, dim3(R, gy), dim3(RROI_NT), 0, (hipStream_t)stream,
                      grad_out, rois, C, H, W, PH, PW, spatial_scale, sample_num, grad_feat);
+  return rsdet_launch_status();
+}
+
+static inline size_t rroi_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t rsdet_rroi_align_v1_backward_gather_ws_size(int R, int PH, int PW, int sample_num, int N, int H,
+                                                              int W) {
+  if (R <= 0 || PH < 1 || PW < 1 || sample_num < 1 || N < 1 || H < 1 || W < 1) return 0;
+  const size_t npix = (size_t)N * H * W, ent = (size_t)R * PH * PW * sample_num * sample_num * 4;
+  return rroi_align256((npix + 1) * 4) * 2 + rroi_align256(ent * 4) * 2 + rroi_align256((npix / 4096 + 1) * 4);
+}
+
+extern "C" int rsdet_rroi_align_v1_backward_gather_f32(const float* grad_out_t, const float* rois, int R, int C, int N,
+                                                       int H, int W, int PH, int PW, float spatial_scale,
+                                                       int sample_num, float* grad_feat_nhwc, void* ws,
+                                                       size_t ws_bytes, void* stream) {
+  int rc = rroi_check(R, C, H, W, PH, PW);
+  if (rc) return rc;
+  if (sample_num < 1 || N < 1) return RSDET_EINVAL;  // adaptive sampling (sample_num <= 0): use the scatter form
+  const long long npix = (long long)N * H * W;
+  if (C == 0) return RSDET_OK;
+  if (!grad_feat_nhwc || (R > 0 && (!grad_out_t || !rois))) return RSDET_EINVAL;
+  const long long items = (long long)R * PH * PW * sample_num * sample_num;
+  if (items * 4 > 0x7fffffffLL) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (R == 0) return hipMemsetAsync(grad_feat_nhwc, 0, (size_t)npix * C * 4, s) == hipSuccess ? RSDET_OK : RSDET_ELAUNCH;
+  if (!ws || ((uintptr_t)ws & 15) || ws_bytes < rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sample_num, N, H, W))
+    return RSDET_EINVAL;
+  char* w = (char*)ws;
+  int* cnt = (int*)w;
+  int* start = (int*)(w + rroi_align256((npix + 1) * 4));
+  int* ent_row = (int*)(w + rroi_align256((npix + 1) * 4) * 2);
+  float* ent_w = (float*)(w + rroi_align256((npix + 1) * 4) * 2 + rroi_align256((size_t)items * 16));
+  int* chunk_sum = (int*)(w + rroi_align256((npix + 1) * 4) * 2 + rroi_align256((size_t)items * 16) * 2);
+  if (hipMemsetAsync(cnt, 0, (size_t)(npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+  const unsigned ib = (unsigned)((items + 255) / 256);
+  hipLaunchKernelGGL(rroi_idx_count_kernel, dim3(ib), dim3(256), 0, s, rois, items, H, W, PH, PW, spatial_scale,
+                     sample_num, npix, cnt);
+  rsdet_launch_index_scan(cnt, npix, chunk_sum, start, s);
+  hipLaunchKernelGGL(rroi_idx_fill_kernel, dim3(ib), dim3(256), 0, s, rois, items, H, W, PH, PW, spatial_scale,
+                     sample_num, npix, start, cnt, ent_row, ent_w);
+  const bool vec4 = (C % 4 == 0) && (((uintptr_t)grad_out_t | (uintptr_t)grad_feat_nhwc) % 16 == 0);
+  const unsigned gb = (unsigned)((npix + 3) / 4);
+  if (vec4)
+    hipLaunchKernelGGL(rroi_gather_kernel<true>, dim3(gb), dim3(256), 0, s, grad_out_t, start, ent_row, ent_w, npix, C,
+                       grad_feat_nhwc);
+  else
+    hipLaunchKernelGGL(rroi_gather_kernel<false>, dim3(gb), dim3(256), 0, s, grad_out_t, start, ent_row, ent_w, npix, C,
+                       grad_feat_nhwc);
   return rsdet_launch_status();
 }

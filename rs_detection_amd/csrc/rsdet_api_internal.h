@@ -24,3 +24,7 @@ void rsdet_launch_nms_sweep(const void* entries, const unsigned* blk_cnt, const 
 // {u64 bits, int column block, int row}, `blk_cnt` their lengths, `diag_t` the transposed diagonal tiles.
 void rsdet_launch_nms_sweep(const void* entries, const unsigned* blk_cnt, const unsigned long long* diag_t, int n,
                             int col_blocks, const int* order, unsigned char* keep, hipStream_t stream);
+
+// Exclusive prefix sum of n int counters (defined in deform_conv.hip, used by the gather-form backward kernels):
+// start[0..n] <- scan(cnt[0..n)), start[n] = total; cnt is cleared; chunk_sum needs n / 4096 + 1 ints.
+void rsdet_launch_index_scan(int* cnt, long long n, int* chunk_sum, int* start, hipStream_t stream);
