@@ -89,6 +89,82 @@ __global__ __launch_bounds__(DCN_NT) void deform_im2col_kernel(const float* __re
   }
 }
 
+// 3x3 form of the kernel above: one thread per POSITION keeps the nine bilinear footprints in registers and walks
+// a chunk of channels with the nine taps innermost.  The kernel above gives every tap its own wave, so the nine
+// taps of a position re-read the same neighbourhood of a channel plane from beyond L2 (PMC: >= 1 GB fetched for
+// a 67 MB input); here a fetched line serves all the taps (and corners) that touch it while it is still in L1.
+// Same arithmetic, same output.  grid: (ceil(B*Ho*Wo / NT), C / c_chunk), a chunk never straddles a deformable group.
+// The two corners of a footprint row are neighbours in memory, so each row is ONE 8-byte load of the pixel pair
+// (xs, xs + 1), xs = clamp(floor(w), 0, W - 2): half the vector-memory instructions of four scalar gathers (the
+// kernel is bound by the texture-addresser rate: 16 clocks per 64-lane gather).  sel says which half of the pair
+// is the left / right corner (or none: 0.f), so the sum is the reference's w1*v1 + w2*v2 + w3*v3 + w4*v4 exactly.
+struct PairFoot {
+  int lo, hi;        // element offset of the pixel pair in the upper / lower footprint row, -1 = row outside
+  float w1, w2, w3, w4;
+  int sel;           // bits 0-1: left corner 0 = none, 1 = pair.x, 2 = pair.y; bits 2-3: right corner
+};
+
+__device__ __forceinline__ PairFoot pair_foot(float h, float w, int H, int W) {
+  PairFoot f{-1, -1, 0.f, 0.f, 0.f, 0.f, 0};
+  if (!(h > -1 && w > -1 && h < H && w < W)) return f;
+  const int hl = (int)floorf(h), wl = (int)floorf(w);
+  const int hh = hl + 1, wh = wl + 1;
+  const float lh = h - hl, lw = w - wl;
+  const float uh = 1 - lh, uw = 1 - lw;
+  const int xs = min(max(wl, 0), W - 2);
+  if (hl >= 0) f.lo = hl * W + xs;
+  if (hh <= H - 1) f.hi = hh * W + xs;
+  const int left = wl >= 0 ? (wl == xs ? 1 : 2) : 0;        // wl in [-1, W-1]
+  const int right = wh <= W - 1 ? (wh == xs + 1 ? 2 : 1) : 0;
+  f.sel = left | (right << 2);
+  f.w1 = uh * uw;
+  f.w2 = uh * lw;
+  f.w3 = lh * uw;
+  f.w4 = lh * lw;
+  return f;
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(DCN_NT) void deform_im2col_taps_kernel(const float* __restrict__ im,
+                                                                    const float* __restrict__ offset, Geom g,
+                                                                    int c_chunk, float* __restrict__ col) {
+  const long long plane = (long long)g.Ho * g.Wo;
+  const long long npos = (long long)g.B * plane;
+  const long long pos = (long long)blockIdx.x * DCN_NT + threadIdx.x;
+  if (pos >= npos) return;
+  const int b = (int)(pos / plane);
+  const int hw = (int)(pos - (long long)b * plane);
+  const int ho = hw / g.Wo, wo = hw - ho * g.Wo;
+  const int cpg = g.C / g.dg;
+  const int c0 = blockIdx.y * c_chunk, c1 = min(g.C, c0 + c_chunk);
+  const int grp = c0 / cpg;
+  const float* offp = offset + ((long long)b * g.dg + grp) * 2 * TAPS * plane;
+  PairFoot f[TAPS];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int i = tap / g.kw, j = tap - i * g.kw;
+    const float oh = offp[(long long)(2 * tap) * plane + hw];
+    const float ow = offp[(long long)(2 * tap + 1) * plane + hw];
+    f[tap] = pair_foot((ho * g.sh - g.ph) + i * g.dh + oh, (wo * g.sw - g.pw) + j * g.dw + ow, g.H, g.W);
+  }
+  const long long HW = (long long)g.H * g.W;
+  for (int c = c0; c < c1; ++c) {
+    const float* imp = im + ((long long)b * g.C + c) * HW;
+    float* cp = col + (long long)c * TAPS * npos + pos;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load at dword alignment
+      pair_t a = {0.f, 0.f}, d = {0.f, 0.f};
+      if (f[tap].lo >= 0) a = *reinterpret_cast<const pair_t*>(imp + f[tap].lo);
+      if (f[tap].hi >= 0) d = *reinterpret_cast<const pair_t*>(imp + f[tap].hi);
+      const int l = f[tap].sel & 3, r = f[tap].sel >> 2;
+      const float v1 = l == 1 ? a.x : (l == 2 ? a.y : 0.f), v2 = r == 2 ? a.y : (r == 1 ? a.x : 0.f);
+      const float v3 = l == 1 ? d.x : (l == 2 ? d.y : 0.f), v4 = r == 2 ? d.y : (r == 1 ? d.x : 0.f);
+      cp[(long long)tap * npos] = f[tap].w1 * v1 + f[tap].w2 * v2 + f[tap].w3 * v3 + f[tap].w4 * v4;
+    }
+  }
+}
+
 // dcn_v1.py:58-84 evaluated at the (<= 4) pixels the reference's 5x5 window admits:
 // |h - y| < 1 and |w - x| < 1 leave y in {floor(h), floor(h)+1}, x likewise.
 __device__ __forceinline__ Foot col2im_foot(float h, float w, int H, int W) {
@@ -547,6 +623,16 @@ extern "C" int rsdet_deform_im2col_f32(const float* im, const float* offset,
   if (npos == 0 || g.C == 0) return RSDET_OK;
   if (!im || !offset || !col) return RSDET_EINVAL;
   long long pb = (npos + DCN_NT - 1) / DCN_NT;
+  const int cpg = g.C / g.dg;
+#ifndef RSDET_IM2COL_CHUNK
+#define RSDET_IM2COL_CHUNK 16
+#endif
+  constexpr int kChunk = RSDET_IM2COL_CHUNK;  // channels per workgroup row
+  if (g.kh * g.kw == 9 && cpg % kChunk == 0 && g.W >= 2) {  // the AlignConv shape: nine taps per thread
+    hipLaunchKernelGGL(deform_im2col_taps_kernel<9>, dim3((unsigned)pb, g.C / kChunk), dim3(DCN_NT), 0,
+                       (hipStream_t)stream, im, offset, g, kChunk, col);
+    return rsdet_launch_status();
+  }
   int cc = pick_c_chunk(g, pb);
   dim3 grid((unsigned)pb, g.kh * g.kw, (g.C + cc - 1) / cc);
   hipLaunchKernelGGL(deform_im2col_kernel, grid, dim3(DCN_NT), 0, (hipStream_t)stream, im, offset,
