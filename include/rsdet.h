@@ -207,6 +207,57 @@ int rsdet_rroi_align_v1_backward_gather_f32(const float* grad_out_t, const float
                                             int W, int PH, int PW, float spatial_scale, int sample_num,
                                             float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- f4  ROIAlignRotated (v0) -----------------------------------------------------------------
+ * Replaces _RotatedROIAlign.execute / .grad: ops/roi_align_rotated.py:256-309 (kernels :59-126, :170-254).
+ * Same tensors and calling rules as the v1 entries above; differs in the RoI frame only (no -0.5 pixel shift of
+ * the centre :76-77, opposite rotation sense :116-117).  The gather form uses
+ * rsdet_rroi_align_v1_backward_gather_ws_size for its workspace. */
+int rsdet_rroi_align_v0_forward_f32(const float* feat, const float* rois, int R, int C, int H,
+                                    int W, int PH, int PW, float spatial_scale, int sample_num,
+                                    float* out, void* stream);
+int rsdet_rroi_align_v0_backward_f32(const float* grad_out, const float* rois, int R, int C,
+                                     int H, int W, int PH, int PW, float spatial_scale,
+                                     int sample_num, float* grad_feat, void* stream);
+int rsdet_rroi_align_v0_backward_gather_f32(const float* grad_out_t, const float* rois, int R, int C, int N, int H,
+                                            int W, int PH, int PW, float spatial_scale, int sample_num,
+                                            float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- f4  FeatureRefine (R3Det) --------------------------------------------------------------------
+ * Replaces feature_refine_forward / feature_refine_backward: ops/fr.py:234-252 (kernels :113-173, :175-232).
+ * feat / out (N,C,H,W); best_bboxes (N,H,W,5); points in {1, 5} (:261).  out = feat + sum over the points of the
+ * bilinear sample of the same channel; box entry 0 is the ROW coordinate, entry 1 the COLUMN (:131-133, kept).
+ * Backward takes and returns CHANNELS-LAST gradients (N,H,W,C) (the caller converts): the point -> pixel map is
+ * inverted on integers in ws, then every pixel sums its terms -- no fp32 atomics, grad_in written exactly once. */
+int rsdet_feature_refine_forward_f32(const float* feat, const float* best_bboxes, int N, int C, int H, int W,
+                                     float spatial_scale, int points, float* out, void* stream);
+size_t rsdet_feature_refine_backward_ws_size(int N, int H, int W, int points);
+int rsdet_feature_refine_backward_nhwc_f32(const float* grad_out_nhwc, const float* best_bboxes, int N, int C,
+                                           int H, int W, float spatial_scale, int points, float* grad_in_nhwc,
+                                           void* ws, size_t ws_bytes, void* stream);
+
+/* ---- f4  convex_sort ---------------------------------------------------------------------------------
+ * Replaces convex_sort (ops/convex_sort.py:67-201; caller models/losses/poly_iou_loss.py:23): for each of nbs
+ * point sets pts (nbs, npts, 2) with masks (nbs, npts) (a point takes part iff mask >= 0.5) the indices of the
+ * convex hull in scan order, starting at the lowest valid point, closed by the start index when `circular`;
+ * convex_index (nbs, circular ? npts + 1 : npts) int32, unused slots -1.  The masked argmin, the cosine keys, the
+ * descending sort (:159-176) and the Graham scan (:5-64) run in one launch.  Tie rules (Jittor's are unpinned):
+ * first index for the argmin, stable order for equal keys.  ws: rsdet_convex_sort_ws_size bytes (0 for npts <= 56). */
+size_t rsdet_convex_sort_ws_size(int nbs, int npts);
+int rsdet_convex_sort_f32(const float* pts, const float* masks, int nbs, int npts, int circular, int* convex_index,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* ---- f4  poly_nms (in-model polygon NMS, fp32) -------------------------------------------------------
+ * Replaces poly_nms: ops/nms_poly.py:186-210 (mask kernel :135-183, quadrilateral IoU devPolyIoU :17-132, host
+ * sweep :195-207); caller multiclass_poly_nms :212-224 <- roi_heads/gliding_head.py:181.
+ * dets_sorted (n, 9) = x1,y1,...,x4,y4,score in descending-score order; keep_sorted[i] = 1 iff kept; box i
+ * suppresses a later box j when IoU(i, j) > thr (:179).  The IoU is the reference's float arithmetic restated
+ * operation by operation (its cancellation noise decides borderline pairs, so nothing is gated or reordered).
+ * ws: rsdet_nms_hbb_ws_size(n) bytes.  rsdet_poly_iou_f32: the same IoU as a dense (n1, n2) matrix over (n, 8)
+ * quadrilaterals. */
+int rsdet_poly_nms_sorted_f32(const float* dets_sorted, int n, float thr, uint8_t* keep_sorted, void* ws,
+                              size_t ws_bytes, void* stream);
+int rsdet_poly_iou_f32(const float* polys1, int n1, const float* polys2, int n2, float* ious, void* stream);
+
 /* ---- a17  rotated_box_to_poly ------------------------------------------------------------------
  * Replaces models/boxes/box_ops.py:633-654.  boxes (n,5) -> polys (n,8). */
 int rsdet_rotated_box_to_poly_f32(const float* boxes, int n, float* polys, void* stream);

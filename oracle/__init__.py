@@ -155,27 +155,78 @@ class _COracle:
         return goff
 
     # a18 -- ops/roi_align_rotated_v1.py:71-147
-    def rroi_align_v1_forward(self, feat, rois, out_hw, scale, sample_num):
+    def rroi_align_v1_forward(self, feat, rois, out_hw, scale, sample_num, variant="v1"):
+        """variant "v0": ops/roi_align_rotated.py:59-126 (f4)."""
         feat, rois = _f32(feat), _f32(rois)
         N, C, H, W = feat.shape
         R = rois.shape[0]
         PH, PW = out_hw
         out = np.zeros((R, C, PH, PW), np.float32)
         if R:
-            self.lib.oracle_rroi_align_v1_forward(_fp(feat), _fp(rois), R, C, H, W, PH, PW,
-                                                  ctypes.c_float(scale), int(sample_num), _fp(out))
+            getattr(self.lib, "oracle_rroi_align_%s_forward" % variant)(
+                _fp(feat), _fp(rois), R, C, H, W, PH, PW, ctypes.c_float(scale), int(sample_num), _fp(out))
         return out
 
     # ops/roi_align_rotated_v1.py:193-298
-    def rroi_align_v1_backward(self, grad_out, rois, feat_shape, scale, sample_num):
+    def rroi_align_v1_backward(self, grad_out, rois, feat_shape, scale, sample_num, variant="v1"):
         grad_out, rois = _f32(grad_out), _f32(rois)
         N, C, H, W = feat_shape
         R, _, PH, PW = grad_out.shape
         gf = np.zeros((N, C, H, W), np.float32)
         if R:
-            self.lib.oracle_rroi_align_v1_backward(_fp(grad_out), _fp(rois), R, C, H, W, PH, PW,
-                                                   ctypes.c_float(scale), int(sample_num), _fp(gf))
+            getattr(self.lib, "oracle_rroi_align_%s_backward" % variant)(
+                _fp(grad_out), _fp(rois), R, C, H, W, PH, PW, ctypes.c_float(scale), int(sample_num), _fp(gf))
         return gf
+
+    # f4 -- ops/fr.py:113-232
+    def feature_refine_forward(self, feat, boxes, scale, points=1):
+        feat, boxes = _f32(feat), _f32(boxes)
+        N, C, H, W = feat.shape
+        assert boxes.size == N * H * W * 5 and points in (1, 5)
+        out = np.zeros_like(feat)
+        if feat.size:
+            self.lib.oracle_feature_refine_forward(_fp(feat), _fp(boxes), N, C, H, W, ctypes.c_float(scale),
+                                                   int(points), _fp(out))
+        return out
+
+    def feature_refine_backward(self, top, boxes, scale, points=1):
+        top, boxes = _f32(top), _f32(boxes)
+        N, C, H, W = top.shape
+        gi = np.zeros_like(top)
+        if top.size:
+            self.lib.oracle_feature_refine_backward(_fp(top), _fp(boxes), N, C, H, W, ctypes.c_float(scale),
+                                                    int(points), _fp(gi))
+        return gi
+
+    # f4 -- ops/convex_sort.py:93-154
+    def convex_sort_scan(self, x, y, m, start, order, circular=True):
+        x, y, m = _f32(x), _f32(y), _f32(m)
+        nbs, npts = x.shape
+        start = np.ascontiguousarray(start, dtype=np.int32).reshape(nbs)
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        out = np.full((nbs, npts + 1 if circular else npts), -1, np.int32)
+        if nbs and npts:
+            self.lib.oracle_convex_sort_scan(_fp(x), _fp(y), _fp(m), _ip(start), _ip(order), nbs, npts,
+                                             int(circular), _ip(out))
+        return out
+
+    # f4 -- ops/nms_poly.py:17-210 (fp32 in-model polygon NMS)
+    def poly_iou_f32(self, p1, p2):
+        p1, p2 = _f32(p1), _f32(p2)
+        out = np.zeros((p1.shape[0], p2.shape[0]), np.float32)
+        if out.size:
+            self.lib.oracle_poly_iou_f32(_fp(p1), p1.shape[0], _fp(p2), p2.shape[0], _fp(out))
+        return out
+
+    def poly_nms(self, boxes, thr):
+        """poly_nms (:186-210): kept original indices in descending-score order (stable argsort)."""
+        boxes = _f32(boxes)
+        order = np.argsort(-boxes[:, 8], kind="stable")
+        d = np.ascontiguousarray(boxes[order])
+        keep = np.zeros(len(d), np.uint8)
+        if len(d):
+            self.lib.oracle_poly_nms_sorted(_fp(d), len(d), ctypes.c_float(thr), _up(keep))
+        return order[keep.astype(bool)]
 
     # a4 -- models/boxes/assigner.py:111-170
     def assign_wrt_overlaps(self, overlaps, pos_thr=0.5, neg_thr=0.4, min_pos_iou=0.0,
@@ -222,6 +273,18 @@ class _RefOracle:
         if n:
             fn(_fp(dets), n, _ip(order), ctypes.c_float(thr), _up(keep))
         return keep.astype(bool)
+
+    def convex_sort_scan(self, x, y, m, start, order, circular=True):
+        """The reference's own Graham-scan loop (ops/convex_sort.py:93-154) on prepared start / order arrays."""
+        x, y, m = _f32(x), _f32(y), _f32(m)
+        nbs, npts = x.shape
+        start = np.ascontiguousarray(start, dtype=np.int32).reshape(nbs)
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        out = np.full((nbs, npts + 1 if circular else npts), -1, np.int32)
+        if nbs and npts:
+            self.lib.ref_convex_sort(_fp(x), _fp(y), _fp(m), _ip(start), _ip(order), nbs, npts, int(circular),
+                                     _ip(out))
+        return out
 
     def arf_forward(self, weight, indices):
         weight = _f32(weight)
@@ -284,6 +347,33 @@ def ref():
 # ----------------------------------------------------------------------------
 F32 = np.float32
 PI32 = np.float32(np.pi)
+
+
+def np_convex_sort_prepare(pts, masks):
+    """The tensor code in front of the Graham scan (ops/convex_sort.py:67-84 == :159-176), fp32 NumPy:
+    lowest valid point (first index on ties), cosine of every point's direction from it, descending order.
+    Jittor's argmin / argsort tie rules are not pinned by anything in the reference: FIRST index and a STABLE
+    descending sort are adopted (what torch.argmin / torch.argsort(stable=True) do)."""
+    pts = _f32(pts)
+    INF, EPS = np.float32(10000000), np.float32(0.000001)
+    m = np.asarray(masks).astype(np.float32)
+    x, y = np.ascontiguousarray(pts[:, :, 0]), np.ascontiguousarray(pts[:, :, 1])
+    masked_y = m * y + (np.float32(1) - m) * INF
+    nbs, npts = x.shape
+    if npts == 0:
+        return x, y, m, np.zeros((nbs,), np.int32), np.zeros((nbs, 0), np.int32)
+    start = masked_y.argmin(1).astype(np.int32)
+    sx = np.take_along_axis(x, start[:, None].astype(np.int64), 1)
+    sy = np.take_along_axis(y, start[:, None].astype(np.int64), 1)
+    cos = (x - sx) / np.sqrt((x - sx) * (x - sx) + (y - sy) * (y - sy) + EPS)
+    order = np.argsort(-cos, axis=1, kind="stable").astype(np.int32)
+    return x, y, m, start, order
+
+
+def np_convex_sort(pts, masks, circular=True, scan=None):
+    """convex_sort (ops/convex_sort.py:196-201) = prepare + scan; `scan` defaults to the C restatement."""
+    x, y, m, start, order = np_convex_sort_prepare(pts, masks)
+    return (scan or c().convex_sort_scan)(x, y, m, start, order, circular)
 
 
 def np_norm_angle(angle, version="le135"):

@@ -33,6 +33,9 @@ Entry points of the .so (all arrays caller-allocated):
   ref_rie_forward/backward                            ops/orn.py:283-395 (forward: the embedded CPU_SRC body; backward: the
                                                       header's RIE_backward_cpu_kernel called directly, because the embedded
                                                       RIE_CPU_GRAD_SRC body misses a ';' at :383 and does not compile as written)
+  ref_convex_sort       (x,y,m,start,order,nbs,npts,circular,out)  ops/convex_sort.py:93-154 (the Graham-scan loop of
+                                                      convex_sort_cpu; the tensor code before it -- argmin / argsort --
+                                                      is Jittor and is restated in NumPy by the caller)
 """
 import ast
 import os
@@ -170,6 +173,39 @@ extern "C" void ref_rie_backward(unsigned char* dir_p, int nBatch, int nFeature,
 """ % (hdr, fwd)
 
 
+def function_raw_string(path, func, var):
+    """The plain-string operand(s) of `var = f"..." + r"..."` inside function `func` (no evaluation of the f-string:
+    its only content is the four scalar declarations, which the wrapper below supplies as parameters)."""
+    tree = ast.parse(open(path).read())
+    for st in tree.body:
+        if isinstance(st, ast.FunctionDef) and st.name == func:
+            for sub in ast.walk(st):
+                if isinstance(sub, ast.Assign) and getattr(sub.targets[0], "id", None) == var:
+                    parts = []
+
+                    def walk(node):
+                        if isinstance(node, ast.BinOp):
+                            walk(node.left)
+                            walk(node.right)
+                        elif isinstance(node, ast.Constant) and isinstance(node.value, str):
+                            parts.append(node.value)
+                    walk(sub.value)
+                    return "".join(parts)
+    raise KeyError((func, var))
+
+
+def unit_convex(path):
+    body = function_raw_string(path, "convex_sort_cpu", "SRC")
+    return """
+extern "C" void ref_convex_sort(float* in0_p, float* in1_p, float* in2_p, int* in3_p, int* in4_p, int nbs, int npts,
+                                int circular_i, int* out0_p) {
+  const int index_size = circular_i ? npts + 1 : npts;
+  const bool circular = circular_i != 0;
+  %s
+}
+""" % body
+
+
 def main():
     if not os.path.isdir(REF_OPS):
         print("build_ref: %s not present -- using prebuilt oracle/_ref if any" % REF_OPS)
@@ -186,6 +222,7 @@ def main():
     tu += unit_nms(sn, 6)
     tu += unit_arf(so)
     tu += unit_rie(so)
+    tu += unit_convex(os.path.join(REF_OPS, "convex_sort.py"))
     os.makedirs(OUT_DIR, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="jdet_ref_")
     try:

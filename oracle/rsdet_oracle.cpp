@@ -476,12 +476,14 @@ struct RoiFrame {
   int gh, gw;
 };
 
-// ops/roi_align_rotated_v1.py:84-118
-static RoiFrame roi_frame(const float* roi, float scale, int sample_num, int PH, int PW) {
+// ops/roi_align_rotated_v1.py:84-118; v0 = ops/roi_align_rotated.py:72-101 (centre without the -0.5 shift :76-77,
+// frame rotated the other way :116-117 -- written below as sn = -sin so that both variants share the expressions
+// x = xx*cs + yy*sn, y = yy*cs - xx*sn, which are bit-identical to v0's xx*cs - yy*sin, xx*sin + yy*cs).
+static RoiFrame roi_frame(const float* roi, float scale, int sample_num, int PH, int PW, int v0) {
   RoiFrame f;
   f.batch = (int)roi[0];
-  f.cw = roi[1] * scale - 0.5f;
-  f.ch = roi[2] * scale - 0.5f;
+  f.cw = roi[1] * scale - (v0 ? 0.f : 0.5f);
+  f.ch = roi[2] * scale - (v0 ? 0.f : 0.5f);
   f.rw = std::max(roi[3] * scale, 1.f);
   f.rh = std::max(roi[4] * scale, 1.f);
   float theta = roi[5];
@@ -492,17 +494,17 @@ static RoiFrame roi_frame(const float* roi, float scale, int sample_num, int PH,
   f.start_h = (float)(-f.rh / 2.0);
   f.start_w = (float)(-f.rw / 2.0);
   f.cs = std::cos(theta);  // float overloads, as scalar_t=float in the reference
-  f.sn = std::sin(theta);
+  f.sn = v0 ? -std::sin(theta) : std::sin(theta);
   return f;
 }
 
 // ops/roi_align_rotated_v1.py:71-147.  feat (N,C,H,W); rois (R,6)=(batch,cx,cy,w,h,theta);
 // out (R,C,PH,PW).
-void oracle_rroi_align_v1_forward(const float* feat, const float* rois, int R, int C, int H,
-                                  int W, int PH, int PW, float scale, int sample_num,
-                                  float* out) {
+static void rroi_align_forward(const float* feat, const float* rois, int R, int C, int H,
+                               int W, int PH, int PW, float scale, int sample_num, int v0,
+                               float* out) {
   for (int n = 0; n < R; ++n) {
-    RoiFrame f = roi_frame(rois + (size_t)n * 6, scale, sample_num, PH, PW);
+    RoiFrame f = roi_frame(rois + (size_t)n * 6, scale, sample_num, PH, PW, v0);
     const float count = (float)std::max(f.gh * f.gw, 1);
     for (int c = 0; c < C; ++c) {
       const float* fp = feat + ((size_t)f.batch * C + c) * H * W;
@@ -531,11 +533,11 @@ void oracle_rroi_align_v1_forward(const float* feat, const float* rois, int R, i
 
 // ops/roi_align_rotated_v1.py:193-298.  grad_feat must be zeroed by the caller
 // (:345 cudaMemsetAsync); sums run in ascending output-index order.
-void oracle_rroi_align_v1_backward(const float* grad_out, const float* rois, int R, int C, int H,
-                                   int W, int PH, int PW, float scale, int sample_num,
-                                   float* grad_feat) {
+static void rroi_align_backward(const float* grad_out, const float* rois, int R, int C, int H,
+                                int W, int PH, int PW, float scale, int sample_num, int v0,
+                                float* grad_feat) {
   for (int n = 0; n < R; ++n) {
-    RoiFrame f = roi_frame(rois + (size_t)n * 6, scale, sample_num, PH, PW);
+    RoiFrame f = roi_frame(rois + (size_t)n * 6, scale, sample_num, PH, PW, v0);
     const float count = (float)(f.gh * f.gw);
     for (int c = 0; c < C; ++c) {
       float* gp = grad_feat + ((size_t)f.batch * C + c) * H * W;
@@ -561,6 +563,225 @@ void oracle_rroi_align_v1_backward(const float* grad_out, const float* rois, int
           }
         }
     }
+  }
+}
+
+void oracle_rroi_align_v1_forward(const float* feat, const float* rois, int R, int C, int H, int W, int PH, int PW,
+                                  float scale, int sample_num, float* out) {
+  rroi_align_forward(feat, rois, R, C, H, W, PH, PW, scale, sample_num, 0, out);
+}
+void oracle_rroi_align_v1_backward(const float* grad_out, const float* rois, int R, int C, int H, int W, int PH,
+                                   int PW, float scale, int sample_num, float* grad_feat) {
+  rroi_align_backward(grad_out, rois, R, C, H, W, PH, PW, scale, sample_num, 0, grad_feat);
+}
+// f4: ROIAlignRotated (v0), ops/roi_align_rotated.py:59-126 / :170-254
+void oracle_rroi_align_v0_forward(const float* feat, const float* rois, int R, int C, int H, int W, int PH, int PW,
+                                  float scale, int sample_num, float* out) {
+  rroi_align_forward(feat, rois, R, C, H, W, PH, PW, scale, sample_num, 1, out);
+}
+void oracle_rroi_align_v0_backward(const float* grad_out, const float* rois, int R, int C, int H, int W, int PH,
+                                   int PW, float scale, int sample_num, float* grad_feat) {
+  rroi_align_backward(grad_out, rois, R, C, H, W, PH, PW, scale, sample_num, 1, grad_feat);
+}
+
+// ---- f4: FeatureRefine (R3Det) ---------------------------------------------------
+// ops/fr.py:113-173 (forward), :175-232 (backward).  feat (N,C,H,W); boxes (N,H,W,5); points in {1,5}.
+// Entry 0 of the box is the ROW coordinate and entry 1 the COLUMN (:131-133), as written in the reference.
+static void fr_points(const float* b, float scale, int points, float* px, float* py) {
+  float roi_y = b[0] * scale, roi_x = b[1] * scale;
+  for (int i = 0; i < 5; ++i) px[i] = py[i] = 0.f;
+  px[0] = roi_x;
+  py[0] = roi_y;
+  if (points > 1) {
+    float roi_w = b[2] * scale, roi_h = b[3] * scale, roi_a = b[4];
+    float w_2 = roi_w / 2, h_2 = roi_h / 2;
+    float cosa = cosf(roi_a), sina = sinf(roi_a);
+    float wx = cosa * w_2, wy = sina * w_2;
+    float hx = -sina * h_2, hy = cosa * h_2;
+    px[1] = roi_x + wx + hx; py[1] = roi_y + wy + hy;
+    px[2] = roi_x - wx + hx; py[2] = roi_y - wy + hy;
+    px[3] = roi_x - wx - hx; py[3] = roi_y - wy - hy;
+    px[4] = roi_x + wx - hx; py[4] = roi_y + wy - hy;
+  }
+}
+
+void oracle_feature_refine_forward(const float* feat, const float* boxes, int N, int C, int H, int W, float scale,
+                                   int points, float* out) {
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      const float* fp = feat + ((size_t)n * C + c) * H * W;
+      for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+          float px[5], py[5];
+          fr_points(boxes + (((size_t)n * H + h) * W + w) * 5, scale, points, px, py);
+          float v = fp[h * W + w];
+          for (int i = 0; i < points; ++i) {
+            Bil b = rroi_bilinear(H, W, py[i], px[i]);  // same function as fr.py:18-66
+            if (b.ok)
+              v += b.w1 * fp[b.yl * W + b.xl] + b.w2 * fp[b.yl * W + b.xh] + b.w3 * fp[b.yh * W + b.xl] +
+                   b.w4 * fp[b.yh * W + b.xh];
+          }
+          out[((size_t)n * C + c) * H * W + h * W + w] = v;
+        }
+    }
+}
+
+// grad_in must be zeroed by the caller (fr.py:245 jt.zeros_like); sums in ascending index order.
+void oracle_feature_refine_backward(const float* top, const float* boxes, int N, int C, int H, int W, float scale,
+                                    int points, float* grad_in) {
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      float* gp = grad_in + ((size_t)n * C + c) * H * W;
+      for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+          float px[5], py[5];
+          fr_points(boxes + (((size_t)n * H + h) * W + w) * 5, scale, points, px, py);
+          float t = top[((size_t)n * C + c) * H * W + h * W + w];
+          gp[h * W + w] += t;
+          for (int i = 0; i < points; ++i) {
+            Bil b = rroi_bilinear(H, W, py[i], px[i]);
+            if (b.ok) {
+              gp[b.yl * W + b.xl] += t * b.w1;
+              gp[b.yl * W + b.xh] += t * b.w2;
+              gp[b.yh * W + b.xl] += t * b.w3;
+              gp[b.yh * W + b.xh] += t * b.w4;
+            }
+          }
+        }
+    }
+}
+
+// ---- f4: convex_sort (Graham scan over prepared order) ------------------------------
+// ops/convex_sort.py:93-154 (CPU loop; the CUDA kernel :5-64 is the same statement sequence).
+// x, y, m (nbs, npts); start (nbs); order (nbs, npts); out (nbs, index_size) prefilled with -1 by the caller.
+void oracle_convex_sort_scan(const float* x, const float* y, const float* m, const int* start, const int* order,
+                             int nbs, int npts, int circular, int* out) {
+  const int index_size = circular ? npts + 1 : npts;
+  for (int i = 0; i < nbs; ++i) {
+    const float *sx = x + (size_t)i * npts, *sy = y + (size_t)i * npts, *sm = m + (size_t)i * npts;
+    const int* so = order + (size_t)i * npts;
+    int* hull = out + (size_t)i * index_size;
+    const int s0 = start[i];
+    hull[0] = s0;
+    int top = 0;
+    for (int k = 0; k < npts; ++k) {
+      const int j = so[k];
+      if (j == s0 || sm[j] < 0.5) continue;
+      const float x0 = sx[j], y0 = sy[j];
+      float x1 = sx[hull[top]], y1 = sy[hull[top]];
+      const float d = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+      if (d < 0.000001) continue;  // double literal: the float is widened for the comparison (:112)
+      if (top < 2) {
+        hull[++top] = j;
+        continue;
+      }
+      float x2 = sx[hull[top - 1]], y2 = sy[hull[top - 1]];
+      for (;;) {
+        const float t = (x1 - x2) * (y0 - y2) - (y1 - y2) * (x0 - x2);
+        if (t >= 0) {
+          hull[++top] = j;
+          break;
+        }
+        if (top <= 1) {
+          hull[top] = j;
+          break;
+        }
+        --top;
+        x1 = sx[hull[top]];
+        y1 = sy[hull[top]];
+        x2 = sx[hull[top - 1]];
+        y2 = sy[hull[top - 1]];
+      }
+    }
+    if (circular) hull[++top] = hull[0];
+  }
+}
+
+// ---- f4: poly_nms (in-model, fp32) ----------------------------------------------------------
+// ops/nms_poly.py:17-132 (devPolyIoU), :135-183 (mask), :195-207 (sweep).  Plain float arithmetic in the order the
+// reference writes it (compile with -ffp-contract=off: see Makefile).  The staging ring `pp` of one quadrilateral
+// pair starts from zeros (the reference's is uninitialised stack memory that is read only after a failed
+// lineCross).
+namespace polyf {
+struct P2 {
+  float x, y;
+};
+static inline int sig(float d) { return (d > 1e-8) - (d < -1e-8); }
+static inline bool same(P2 a, P2 b) { return sig(a.x - b.x) == 0 && sig(a.y - b.y) == 0; }
+static inline float cross(P2 o, P2 a, P2 b) { return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y); }
+static float area(P2* ps, int n) {
+  ps[n] = ps[0];
+  float res = 0;
+  for (int i = 0; i < n; ++i) res += ps[i].x * ps[i + 1].y - ps[i].y * ps[i + 1].x;
+  return (float)(res / 2.0);
+}
+static void cut(P2* p, int& n, P2 a, P2 b, P2* pp) {
+  int m = 0;
+  p[n] = p[0];
+  for (int i = 0; i < n; ++i) {
+    float s1 = cross(a, b, p[i]), s2 = cross(a, b, p[i + 1]);
+    if (sig(s1) > 0) pp[m++] = p[i];
+    if (sig(s1) != sig(s2)) {
+      if (!(sig(s1) == 0 && sig(s2) == 0) && sig(s2 - s1) != 0) {
+        pp[m].x = (p[i].x * s2 - p[i + 1].x * s1) / (s2 - s1);
+        pp[m].y = (p[i].y * s2 - p[i + 1].y * s1) / (s2 - s1);
+      }
+      ++m;
+    }
+  }
+  n = 0;
+  for (int i = 0; i < m; ++i)
+    if (!i || !same(pp[i], pp[i - 1])) p[n++] = pp[i];
+  while (n > 1 && same(p[n - 1], p[0])) --n;
+}
+static float tri(P2 a, P2 b, P2 c, P2 d, P2* pp) {
+  P2 o{0, 0};
+  int s1 = sig(cross(o, a, b)), s2 = sig(cross(o, c, d));
+  if (s1 == 0 || s2 == 0) return 0.f;
+  if (s1 == -1) std::swap(a, b);
+  if (s2 == -1) std::swap(c, d);
+  P2 p[12] = {o, a, b};
+  int n = 3;
+  cut(p, n, o, c, pp);
+  cut(p, n, c, d, pp);
+  cut(p, n, d, o, pp);
+  float res = std::fabs(area(p, n));
+  if (s1 * s2 == -1) res = -res;
+  return res;
+}
+static float quad_iou(const float* q1, const float* q2) {
+  P2 a[6], b[6], pp[12];
+  for (int i = 0; i < 4; ++i) {
+    a[i] = P2{q1[2 * i], q1[2 * i + 1]};
+    b[i] = P2{q2[2 * i], q2[2 * i + 1]};
+  }
+  for (int i = 0; i < 12; ++i) pp[i] = P2{0, 0};
+  if (area(a, 4) < 0) std::reverse(a, a + 4);
+  if (area(b, 4) < 0) std::reverse(b, b + 4);
+  a[4] = a[0];
+  b[4] = b[0];
+  float inter = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) inter += tri(a[i], a[i + 1], b[j], b[j + 1], pp);
+  float uni = std::fabs(area(a, 4)) + std::fabs(area(b, 4)) - inter;
+  return uni == 0 ? (inter + 1) / (uni + 1) : inter / uni;
+}
+}  // namespace polyf
+
+void oracle_poly_iou_f32(const float* p1, int n1, const float* p2, int n2, float* out) {
+  for (int i = 0; i < n1; ++i)
+    for (int j = 0; j < n2; ++j) out[(size_t)i * n2 + j] = polyf::quad_iou(p1 + (size_t)i * 8, p2 + (size_t)j * 8);
+}
+
+// dets_sorted (n, 9) descending score; keep[i] = 1 iff kept; suppression on iou > thr (:179), greedy (:197-206)
+void oracle_poly_nms_sorted(const float* dets, int n, float thr, unsigned char* keep) {
+  std::vector<unsigned char> removed(n > 0 ? n : 1, 0);
+  for (int i = 0; i < n; ++i) {
+    keep[i] = 0;
+    if (removed[i]) continue;
+    keep[i] = 1;
+    for (int j = i + 1; j < n; ++j)
+      if (polyf::quad_iou(dets + (size_t)i * 9, dets + (size_t)j * 9) > thr) removed[j] = 1;
   }
 }
 

@@ -68,6 +68,22 @@ SIGNATURES = {
     "rsdet_rroi_align_v1_backward_gather_ws_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "rsdet_rroi_align_v1_backward_gather_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                         c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_rroi_align_v0_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_float, c_int, c_void_p, c_void_p]),
+    "rsdet_rroi_align_v0_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                 c_float, c_int, c_void_p, c_void_p]),
+    "rsdet_rroi_align_v0_backward_gather_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                        c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_feature_refine_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                                 c_void_p, c_void_p]),
+    "rsdet_feature_refine_backward_ws_size": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rsdet_feature_refine_backward_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_convex_sort_ws_size": (c_size_t, [c_int, c_int]),
+    "rsdet_convex_sort_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
+    "rsdet_poly_nms_sorted_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_poly_iou_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_rotated_box_to_poly_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_poly_iou_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_nms_poly_sorted_f64": (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,226 @@
+// feature_refine.hip -- FeatureRefine (R3Det) forward / backward for gfx950.
+//
+// Replaces: feature_refine_forward / feature_refine_backward
+//   /root/reference/python/jdet/ops/fr.py:234-252, kernels :113-173 (forward) and :175-232 (backward).
+//
+//   out[n,c,h,w] = feat[n,c,h,w] + sum_{i < points} bilinear(feat[n,c], py_i, px_i)
+// where the `points` (1 or 5: centre, then the four corners) come from best_bboxes[n,h,w,:] -- and are the same
+// for every channel.  The reference recomputes them (2 transcendental calls, 20 corner weights) once per (n,c,h,w)
+// element; here one thread owns a position, derives its footprints once into registers and walks the channels,
+// so the per-element work is 4*points loads + 1 store and consecutive lanes read / write consecutive w.
+//
+// Reference quirk kept (fr.py:131-133): entry 0 of the box is used as the ROW coordinate and entry 1 as the COLUMN
+// (`roi_y = bbox[0] * scale; roi_x = bbox[1] * scale`) although the boxes are (x_ctr, y_ctr, w, h, angle).
+//
+// Backward = gather form (as col2im / RROIAlign backward): the (position, point, corner) -> pixel map is inverted
+// on integers, then one wave per pixel sums its terms from the channels-last gradient.  No fp32 atomics (the
+// reference issues 1 + 4*points per element), deterministic, grad_in written exactly once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsdet_api_internal.h"
+#include "rsdet_bilinear.h"
+
+namespace rsdet {
+
+constexpr int FR_MAX_POINTS = 5;
+
+struct FrPoints {
+  float py[FR_MAX_POINTS], px[FR_MAX_POINTS];
+};
+
+// fr.py:128-152
+__device__ __forceinline__ FrPoints fr_points(const float* __restrict__ b, float scale, int points) {
+  FrPoints p;
+  const float roi_y = b[0] * scale;
+  const float roi_x = b[1] * scale;
+#pragma unroll
+  for (int i = 0; i < FR_MAX_POINTS; ++i) {
+    p.px[i] = 0.f;
+    p.py[i] = 0.f;
+  }
+  p.px[0] = roi_x;
+  p.py[0] = roi_y;
+  if (points > 1) {
+    const float roi_w = b[2] * scale, roi_h = b[3] * scale, roi_a = b[4];
+    const float w_2 = roi_w / 2, h_2 = roi_h / 2;
+    const float cosa = cosf(roi_a), sina = sinf(roi_a);
+    const float wx = cosa * w_2, wy = sina * w_2;
+    const float hx = -sina * h_2, hy = cosa * h_2;
+    p.px[1] = roi_x + wx + hx; p.py[1] = roi_y + wy + hy;
+    p.px[2] = roi_x - wx + hx; p.py[2] = roi_y - wy + hy;
+    p.px[3] = roi_x - wx - hx; p.py[3] = roi_y - wy - hy;
+    p.px[4] = roi_x + wx - hx; p.py[4] = roi_y + wy - hy;
+  }
+  return p;
+}
+
+// grid (ceil(H*W / 256), N, channel slices); POINTS is 1 or 5 at compile time so the footprints stay in registers.
+template <int POINTS>
+__global__ __launch_bounds__(256) void fr_forward_kernel(const float* __restrict__ feat,
+                                                         const float* __restrict__ boxes, float scale, int C, int H,
+                                                         int W, float* __restrict__ out) {
+  const int HW = H * W;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= HW) return;
+  const int n = blockIdx.y;
+  const FrPoints p = fr_points(boxes + ((long long)n * HW + pos) * 5, scale, POINTS);
+  int o00[POINTS], o01[POINTS], o10[POINTS], o11[POINTS];
+  float w1[POINTS], w2[POINTS], w3[POINTS], w4[POINTS];
+#pragma unroll
+  for (int i = 0; i < POINTS; ++i) {
+    const Bil b = bilinear(H, W, p.py[i], p.px[i]);
+    const bool in = b.yl >= 0;  // outside: weight 0 on a valid address (fr.py:26-28 returns 0)
+    o00[i] = in ? b.yl * W + b.xl : 0;
+    o01[i] = in ? b.yl * W + b.xh : 0;
+    o10[i] = in ? b.yh * W + b.xl : 0;
+    o11[i] = in ? b.yh * W + b.xh : 0;
+    w1[i] = b.w1; w2[i] = b.w2; w3[i] = b.w3; w4[i] = b.w4;
+  }
+  for (int c = blockIdx.z; c < C; c += gridDim.z) {
+    const float* fp = feat + ((long long)n * C + c) * HW;
+    float acc = fp[pos];
+#pragma unroll
+    for (int i = 0; i < POINTS; ++i)
+      acc += w1[i] * fp[o00[i]] + w2[i] * fp[o01[i]] + w3[i] * fp[o10[i]] + w4[i] * fp[o11[i]];  // :55-63, :166-169
+    out[((long long)n * C + c) * HW + pos] = acc;
+  }
+}
+
+// ---- backward: invert (position, point, corner) -> pixel ---------------------------------------------------
+// item = position * (points + 1) + k; k == points is the identity term (fr.py:213 atomicAdd(bottom_diff + index)).
+struct FrItem {
+  long long p[4];
+  float w[4];
+};
+
+__device__ __forceinline__ FrItem fr_item(const float* __restrict__ boxes, long long item, int H, int W, float scale,
+                                          int points) {
+  const long long pos = item / (points + 1);
+  const int k = (int)(item - pos * (points + 1));
+  FrItem t;
+  t.p[1] = t.p[2] = t.p[3] = -1;
+  t.w[1] = t.w[2] = t.w[3] = 0.f;
+  if (k == points) {
+    t.p[0] = pos;
+    t.w[0] = 1.f;
+    return t;
+  }
+  const FrPoints p = fr_points(boxes + pos * 5, scale, points);
+  float py = p.py[0], px = p.px[0];
+#pragma unroll
+  for (int i = 1; i < FR_MAX_POINTS; ++i)
+    if (k == i) {
+      py = p.py[i];
+      px = p.px[i];
+    }
+  const Bil b = bilinear(H, W, py, px);
+  const long long base = pos / ((long long)H * W) * ((long long)H * W);
+  const bool in = b.yl >= 0;
+  t.p[0] = in ? base + b.yl * W + b.xl : -1;
+  t.p[1] = in ? base + b.yl * W + b.xh : -1;
+  t.p[2] = in ? base + b.yh * W + b.xl : -1;
+  t.p[3] = in ? base + b.yh * W + b.xh : -1;
+  t.w[0] = b.w1; t.w[1] = b.w2; t.w[2] = b.w3; t.w[3] = b.w4;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void fr_idx_count_kernel(const float* __restrict__ boxes, long long items, int H,
+                                                           int W, float scale, int points, int* __restrict__ cnt) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  const FrItem t = fr_item(boxes, item, H, W, scale, points);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.p[k] >= 0) atomicAdd(cnt + t.p[k], 1);
+}
+
+__global__ __launch_bounds__(256) void fr_idx_fill_kernel(const float* __restrict__ boxes, long long items, int H,
+                                                          int W, float scale, int points,
+                                                          const int* __restrict__ start, int* __restrict__ fill,
+                                                          int* __restrict__ ent_row, float* __restrict__ ent_w) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  const FrItem t = fr_item(boxes, item, H, W, scale, points);
+  const int row = (int)(item / (points + 1));  // position = row of the channels-last gradient (N*H*W, C)
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.p[k] >= 0) {
+      const int slot = start[t.p[k]] + atomicAdd(fill + t.p[k], 1);
+      ent_row[slot] = row;
+      ent_w[slot] = t.w[k];
+    }
+}
+
+}  // namespace rsdet
+
+using namespace rsdet;
+
+static int fr_check(int N, int C, int H, int W, int points) {
+  if (N < 0 || C < 0 || H < 1 || W < 1) return RSDET_EINVAL;
+  if (points != 1 && points != 5) return RSDET_EINVAL;  // fr.py:261 assert points in [1, 5]
+  if ((long long)H * W > 0x7fffffffLL || N > 65535) return RSDET_EINVAL;
+  return RSDET_OK;
+}
+
+extern "C" int rsdet_feature_refine_forward_f32(const float* feat, const float* best_bboxes, int N, int C, int H,
+                                                int W, float spatial_scale, int points, float* out, void* stream) {
+  int rc = fr_check(N, C, H, W, points);
+  if (rc) return rc;
+  if (N == 0 || C == 0) return RSDET_OK;
+  if (!feat || !best_bboxes || !out) return RSDET_EINVAL;
+  const int HW = H * W;
+  const int bx = (HW + 255) / 256;
+  // enough workgroups for 256 CUs, but never fewer than 8 channels per thread (the footprints are amortised over them)
+  int cz = 2048 / (bx * N > 0 ? bx * N : 1);
+  cz = cz < 1 ? 1 : cz;
+  const int cz_max = (C + 7) / 8;
+  cz = cz > cz_max ? cz_max : cz;
+  const dim3 grid(bx, N, cz);
+  if (points == 1)
+    hipLaunchKernelGGL(fr_forward_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, feat, best_bboxes,
+                       spatial_scale, C, H, W, out);
+  else
+    hipLaunchKernelGGL(fr_forward_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, feat, best_bboxes,
+                       spatial_scale, C, H, W, out);
+  return rsdet_launch_status();
+}
+
+static inline size_t fr_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t rsdet_feature_refine_backward_ws_size(int N, int H, int W, int points) {
+  if (N < 1 || H < 1 || W < 1 || (points != 1 && points != 5)) return 0;
+  const size_t npix = (size_t)N * H * W, ent = npix * (4 * (size_t)points + 1);
+  return fr_align256((npix + 1) * 4) * 2 + fr_align256(ent * 4) * 2 + fr_align256((npix / 4096 + 1) * 4);
+}
+
+extern "C" int rsdet_feature_refine_backward_nhwc_f32(const float* grad_out_nhwc, const float* best_bboxes, int N,
+                                                      int C, int H, int W, float spatial_scale, int points,
+                                                      float* grad_in_nhwc, void* ws, size_t ws_bytes, void* stream) {
+  int rc = fr_check(N, C, H, W, points);
+  if (rc) return rc;
+  if (N == 0 || C == 0) return RSDET_OK;
+  if (!grad_out_nhwc || !best_bboxes || !grad_in_nhwc) return RSDET_EINVAL;
+  const long long npix = (long long)N * H * W;
+  const long long items = npix * (points + 1);
+  if (npix * (4 * points + 1) > 0x7fffffffLL) return RSDET_EINVAL;
+  if (!ws || ((uintptr_t)ws & 15) || ws_bytes < rsdet_feature_refine_backward_ws_size(N, H, W, points))
+    return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t ent = (size_t)npix * (4 * points + 1);
+  char* w = (char*)ws;
+  int* cnt = (int*)w;
+  int* start = (int*)(w + fr_align256((npix + 1) * 4));
+  int* ent_row = (int*)(w + fr_align256((npix + 1) * 4) * 2);
+  float* ent_w = (float*)(w + fr_align256((npix + 1) * 4) * 2 + fr_align256(ent * 4));
+  int* chunk_sum = (int*)(w + fr_align256((npix + 1) * 4) * 2 + fr_align256(ent * 4) * 2);
+  if (hipMemsetAsync(cnt, 0, (size_t)(npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+  const unsigned ib = (unsigned)((items + 255) / 256);
+  hipLaunchKernelGGL(fr_idx_count_kernel, dim3(ib), dim3(256), 0, s, best_bboxes, items, H, W, spatial_scale, points,
+                     cnt);
+  rsdet_launch_index_scan(cnt, npix, chunk_sum, start, s);
+  hipLaunchKernelGGL(fr_idx_fill_kernel, dim3(ib), dim3(256), 0, s, best_bboxes, items, H, W, spatial_scale, points,
+                     start, cnt, ent_row, ent_w);
+  rsdet_launch_pixel_gather(grad_out_nhwc, start, ent_row, ent_w, npix, C, grad_in_nhwc, s);
+  return rsdet_launch_status();
+}

@@ -112,6 +112,35 @@ struct NmsEntry {  // same record as nms_rotated.hip
   int row;
 };
 
+// Tail shared by the mask kernels of this file: off-diagonal tiles append their non-zero rows to the row block's
+// entry list (one returning atomic per tile), the diagonal tile is stored transposed for the sweep's fixpoint.
+__device__ __forceinline__ void poly_emit_tile(unsigned long long bits, int rb, int cbk, int tid, int col_blocks,
+                                               NmsEntry* __restrict__ entries, unsigned* __restrict__ blk_cnt,
+                                               unsigned long long* __restrict__ diag_t,
+                                               unsigned long long* s_rows) {
+  if (rb != cbk) {
+    const unsigned long long nz = __ballot(bits != 0ull);
+    if (nz == 0ull) return;
+    unsigned base = 0u;
+    if (tid == 0) base = atomicAdd(blk_cnt + rb, (unsigned)__popcll(nz));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (bits != 0ull) {
+      NmsEntry e;
+      e.bits = bits;
+      e.cblock = cbk;
+      e.row = tid;
+      entries[(size_t)rb * 64 * col_blocks + base + __popcll(nz & ((1ull << tid) - 1ull))] = e;
+    }
+    return;
+  }
+  s_rows[tid] = bits;
+  __syncthreads();
+  unsigned long long col = 0ull;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) col |= ((s_rows[i] >> tid) & 1ull) << i;
+  diag_t[rb * 64 + tid] = col;
+}
+
 // one wave per 64x64 tile; lane = row of the tile
 __global__ __launch_bounds__(64) void nms_poly_mask_kernel(const double* __restrict__ polys, int n, double thr,
                                                            int col_blocks, NmsEntry* __restrict__ entries,
@@ -165,27 +194,179 @@ __global__ __launch_bounds__(64) void nms_poly_mask_kernel(const double* __restr
       if (!(ovr <= thr)) bits |= 1ull << j;           // :117 keeps `ovr <= thresh`; NaN suppresses, as there
     }
   }
-  if (rb != cbk) {
-    const unsigned long long nz = __ballot(bits != 0ull);
-    if (nz == 0ull) return;
-    unsigned base = 0u;
-    if (tid == 0) base = atomicAdd(blk_cnt + rb, (unsigned)__popcll(nz));
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (bits != 0ull) {
-      NmsEntry e;
-      e.bits = bits;
-      e.cblock = cbk;
-      e.row = tid;
-      entries[(size_t)rb * 64 * col_blocks + base + __popcll(nz & ((1ull << tid) - 1ull))] = e;
-    }
-    return;
+  poly_emit_tile(bits, rb, cbk, tid, col_blocks, entries, blk_cnt, diag_t, s_rows);
+}
+
+// ---- in-model polygon NMS, fp32 (ops/nms_poly.py:135-245, caller roi_heads/gliding_head.py:181) -------------------
+// The reference's quadrilateral IoU (nms_poly.py:17-132) sums SIGNED intersections of origin-anchored triangles
+// (o, a_i, a_i+1) x (o, b_j, b_j+1), each cut by three half-planes, all in float.  With image coordinates (plus the
+// per-class offset of multiclass_poly_nms :213-216) the triangles are ~1e6 px^2 and the cancellation noise of that
+// sum is part of the reference's keep decisions, so the arithmetic is restated operation by operation (same order,
+// no FMA: -ffp-contract=off) and EVERY pair is evaluated -- a horizontal-hull gate would change results.
+// One wave per 64x64 tile, lane = row.  The two vertex rings of the cutter (10 + 10 float2 per lane) are indexed
+// by data-dependent counters: they live in LDS in [slot][lane] layout (conflict-free, no scratch memory).
+struct F2 {
+  float x, y;
+};
+
+__device__ __forceinline__ int psig(float d) { return ((double)d > 1e-8) - ((double)d < -1e-8); }  // :17-19
+__device__ __forceinline__ bool peq(F2 a, F2 b) { return psig(a.x - b.x) == 0 && psig(a.y - b.y) == 0; }
+__device__ __forceinline__ float pcross(F2 o, F2 a, F2 b) {  // :39-41
+  return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y);
+}
+
+constexpr int PN_SLOTS = 10;  // maxn (:14)
+
+// ring accessors: slot k of this lane
+#define PN_AT(ring, k) ring[(k) * 64 + lane]
+
+// :42-49 -- closes the ring (slot n <- slot 0) and returns the signed area
+__device__ __forceinline__ float pn_area(F2* ring, int n, int lane) {
+  PN_AT(ring, n) = PN_AT(ring, 0);
+  float res = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const F2 a = PN_AT(ring, i), b = PN_AT(ring, i + 1);
+    res += a.x * b.y - a.y * b.x;
   }
-  s_rows[tid] = bits;
+  return res * 0.5f;  // res / 2.0 evaluated in double and rounded back: the same value
+}
+
+// :61-76 -- keep the part of ring p (n vertices) left of a->b; pp is the staging ring
+__device__ __forceinline__ void pn_cut(F2* p, int& n, F2 a, F2 b, F2* pp, int lane) {
+  int m = 0;
+  PN_AT(p, n) = PN_AT(p, 0);
+  for (int i = 0; i < n; ++i) {
+    const F2 u = PN_AT(p, i), v = PN_AT(p, i + 1);
+    const float su = pcross(a, b, u), sv = pcross(a, b, v);
+    if (psig(su) > 0) {
+      PN_AT(pp, m) = u;
+      ++m;
+    }
+    if (psig(su) != psig(sv)) {
+      // lineCross (:50-59): s1 = su, s2 = sv.  The two "no crossing" exits leave the staging slot as it is.
+      if (!(psig(su) == 0 && psig(sv) == 0) && psig(sv - su) != 0) {
+        F2 x;
+        x.x = (u.x * sv - v.x * su) / (sv - su);
+        x.y = (u.y * sv - v.y * su) / (sv - su);
+        PN_AT(pp, m) = x;
+      }
+      ++m;
+    }
+  }
+  n = 0;
+  for (int i = 0; i < m; ++i)
+    if (!i || !peq(PN_AT(pp, i), PN_AT(pp, i - 1))) {
+      PN_AT(p, n) = PN_AT(pp, i);
+      ++n;
+    }
+  while (n > 1 && peq(PN_AT(p, n - 1), PN_AT(p, 0))) --n;
+}
+
+// :80-98 -- signed intersection area of triangles (o,a,b) and (o,c,d), o = origin
+__device__ __forceinline__ float pn_tri(F2 a, F2 b, F2 c, F2 d, F2* p, F2* pp, int lane) {
+  const F2 o{0.f, 0.f};
+  const int s1 = psig(pcross(o, a, b)), s2 = psig(pcross(o, c, d));
+  if (s1 == 0 || s2 == 0) return 0.f;
+  if (s1 == -1) { const F2 t = a; a = b; b = t; }
+  if (s2 == -1) { const F2 t = c; c = d; d = t; }
+  PN_AT(p, 0) = o;
+  PN_AT(p, 1) = a;
+  PN_AT(p, 2) = b;
+  int n = 3;
+  pn_cut(p, n, o, c, pp, lane);
+  pn_cut(p, n, c, d, pp, lane);
+  pn_cut(p, n, d, o, pp, lane);
+  float res = fabsf(pn_area(p, n, lane));
+  if (s1 * s2 == -1) res = -res;
+  return res;
+}
+
+// :100-132 -- devPolyIoU of two quadrilaterals given as 4 vertices each (q1 = the row = higher score)
+__device__ float pn_quad_iou(const float* __restrict__ q1, const float* __restrict__ q2, F2* p, F2* pp, int lane) {
+  F2 a[5], b[5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = F2{q1[2 * i], q1[2 * i + 1]};
+    b[i] = F2{q2[2 * i], q2[2 * i + 1]};
+  }
+  // area() of a 4-ring in registers (same summation order as pn_area)
+  auto area4 = [](const F2* r) {
+    float res = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const F2 u = r[i], v = r[(i + 1) & 3];
+      res += u.x * v.y - u.y * v.x;
+    }
+    return res * 0.5f;
+  };
+  if (area4(a) < 0) {  // point_reverse (:31-37): 0<->3, 1<->2
+    F2 t = a[0]; a[0] = a[3]; a[3] = t;
+    t = a[1]; a[1] = a[2]; a[2] = t;
+  }
+  if (area4(b) < 0) {
+    F2 t = b[0]; b[0] = b[3]; b[3] = t;
+    t = b[1]; b[1] = b[2]; b[2] = t;
+  }
+  a[4] = a[0];
+  b[4] = b[0];
+  // staging ring starts from zeros for every quad pair (the reference's is uninitialised stack memory; it is only
+  // ever read after a failed lineCross, which needs cross products within 1e-8 of each other)
+  for (int k = 0; k < PN_SLOTS; ++k) PN_AT(pp, k) = F2{0.f, 0.f};
+  float inter = 0.f;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i)
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) inter += pn_tri(a[i], a[i + 1], b[j], b[j + 1], p, pp, lane);
+  const float uni = fabsf(area4(a)) + fabsf(area4(b)) - inter;
+  return uni == 0 ? (inter + 1) / (uni + 1) : inter / uni;  // :125-129
+}
+
+__global__ __launch_bounds__(64) void nms_poly_f32_mask_kernel(const float* __restrict__ polys, int stride, int n,
+                                                               float thr, int col_blocks,
+                                                               NmsEntry* __restrict__ entries,
+                                                               unsigned* __restrict__ blk_cnt,
+                                                               unsigned long long* __restrict__ diag_t) {
+  const int rb = blockIdx.y, cbk = blockIdx.x;
+  if (cbk < rb) return;
+  __shared__ float s_col[64 * 8];
+  __shared__ F2 s_p[PN_SLOTS * 64], s_pp[PN_SLOTS * 64];
+  __shared__ unsigned long long s_rows[64];
+  const int tid = threadIdx.x;
+  const int cols = min(64, n - cbk * 64), rows = min(64, n - rb * 64);
+  if (tid < cols) {
+    const float* q = polys + (long long)(cbk * 64 + tid) * stride;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_col[tid * 8 + k] = q[k];
+  }
   __syncthreads();
-  unsigned long long col = 0ull;
-#pragma unroll 8
-  for (int i = 0; i < 64; ++i) col |= ((s_rows[i] >> tid) & 1ull) << i;
-  diag_t[rb * 64 + tid] = col;
+  unsigned long long bits = 0ull;
+  if (tid < rows) {
+    float q[8];
+    const float* g = polys + (long long)(rb * 64 + tid) * stride;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = g[k];
+    const int start = (rb == cbk) ? tid + 1 : 0;
+    for (int j = start; j < cols; ++j)
+      if (pn_quad_iou(q, s_col + j * 8, s_p, s_pp, tid) > thr) bits |= 1ull << j;  // :179
+  }
+  poly_emit_tile(bits, rb, cbk, tid, col_blocks, entries, blk_cnt, diag_t, s_rows);
+}
+
+// dense (n1, n2) matrix of the same IoU: one wave per 64 pairs (used by tests and by callers that want the values)
+__global__ __launch_bounds__(64) void poly_iou_f32_kernel(const float* __restrict__ polys1, int n1,
+                                                          const float* __restrict__ polys2, int n2,
+                                                          float* __restrict__ out) {
+  __shared__ F2 s_p[PN_SLOTS * 64], s_pp[PN_SLOTS * 64];
+  const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (idx >= (long long)n1 * n2) return;
+  const int i = (int)(idx / n2), j = (int)(idx - (long long)i * n2);
+  float a[8], b[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = polys1[(long long)i * 8 + k];
+    b[k] = polys2[(long long)j * 8 + k];
+  }
+  out[idx] = pn_quad_iou(a, b, s_p, s_pp, threadIdx.x);
 }
 
 __global__ void poly_iota_kernel(int* p, int n, unsigned* blk_cnt) {
@@ -232,6 +413,42 @@ extern "C" int rsdet_nms_poly_sorted_f64(const double* polys_sorted, int n, doub
   hipLaunchKernelGGL(poly_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ident, n, blk_cnt);
   hipLaunchKernelGGL(nms_poly_mask_kernel, dim3(cb, cb), dim3(64), 0, s, polys_sorted, n, thr, cb, entries, blk_cnt,
                      diag_t);
+  rsdet_launch_nms_sweep(entries, blk_cnt, diag_t, n, cb, ident, keep_sorted, s);
+  return rsdet_launch_status();
+}
+
+// ---- f4: poly_nms (fp32, in-model) -------------------------------------------------------------------------
+extern "C" int rsdet_poly_iou_f32(const float* polys1, int n1, const float* polys2, int n2, float* ious,
+                                  void* stream) {
+  if (n1 < 0 || n2 < 0) return RSDET_EINVAL;
+  if (n1 == 0 || n2 == 0) return RSDET_OK;
+  if (!polys1 || !polys2 || !ious) return RSDET_EINVAL;
+  const long long total = (long long)n1 * n2;
+  hipLaunchKernelGGL(poly_iou_f32_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     polys1, n1, polys2, n2, ious);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_poly_nms_sorted_f32(const float* dets_sorted, int n, float thr, uint8_t* keep_sorted, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  if (n < 0) return RSDET_EINVAL;
+  if (n == 0) return RSDET_OK;
+  if (!dets_sorted || !keep_sorted || !ws || ws_bytes < rsdet_nms_hbb_ws_size(n) || ((uintptr_t)ws & 15))
+    return RSDET_EINVAL;
+  const int cb = (n + 63) / 64;
+  if (cb > 8192) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t ident_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+  const size_t diag_bytes = (size_t)cb * 64 * sizeof(unsigned long long);
+  const size_t cnt_bytes = ((size_t)cb * 4 + 255) & ~(size_t)255;
+  int* ident = (int*)ws;
+  char* w = (char*)ws + ident_bytes;
+  unsigned long long* diag_t = (unsigned long long*)w;
+  unsigned* blk_cnt = (unsigned*)(w + diag_bytes);
+  NmsEntry* entries = (NmsEntry*)(w + diag_bytes + cnt_bytes);
+  hipLaunchKernelGGL(poly_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ident, n, blk_cnt);
+  hipLaunchKernelGGL(nms_poly_f32_mask_kernel, dim3(cb, cb), dim3(64), 0, s, dets_sorted, 9, n, thr, cb, entries,
+                     blk_cnt, diag_t);
   rsdet_launch_nms_sweep(entries, blk_cnt, diag_t, n, cb, ident, keep_sorted, s);
   return rsdet_launch_status();
 }

@@ -1,9 +1,13 @@
-// rroi_align.hip -- ROIAlignRotated_v1 forward / backward for gfx950.
+// rroi_align.hip -- ROIAlignRotated_v1 and ROIAlignRotated (v0) forward / backward for gfx950.
 //
 // Replaces: _RotatedROIAlign_v1.execute / .grad
 //   /root/reference/python/jdet/ops/roi_align_rotated_v1.py:300-351,
 //   kernels ROIAlignRotatedForward :71-147, ROIAlignBackward :193-298,
-//   bilinear helpers :24-68, :149-190.
+//   bilinear helpers :24-68, :149-190;
+// and _RotatedROIAlign.execute / .grad of ops/roi_align_rotated.py:256-309 (kernels :59-126, :170-254), which
+// differ from v1 in two places only: the RoI centre has no -0.5 pixel shift (:76-77 vs v1 :89-90) and the frame is
+// rotated the other way (:116-117 vs v1 :133-134, i.e. sin(theta) enters with the opposite sign).  `v0` below
+// selects that variant; everything else is shared.
 //
 // One workgroup per RoI.  The RoI frame (centre, bin size, sin/cos) is derived
 // once per workgroup into LDS instead of once per output element; threads then
@@ -14,6 +18,7 @@
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
+#include "rsdet_bilinear.h"
 
 namespace rsdet {
 
@@ -23,11 +28,15 @@ struct RoiFrame {
 };
 
 __device__ __forceinline__ RoiFrame make_frame(const float* roi, float scale, int sample_num,
-                                               int PH, int PW) {
+                                               int PH, int PW, int v0) {
   RoiFrame f;
   f.batch = (int)roi[0];
-  f.cw = roi[1] * scale - 0.5f;  // :89-90 "do not round"
-  f.ch = roi[2] * scale - 0.5f;
+  f.cw = roi[1] * scale;  // :89-90 "do not round"
+  f.ch = roi[2] * scale;
+  if (!v0) {
+    f.cw -= 0.5f;
+    f.ch -= 0.5f;
+  }
   float rw = fmaxf(roi[3] * scale, 1.f);
   float rh = fmaxf(roi[4] * scale, 1.f);
   float theta = roi[5];
@@ -38,55 +47,18 @@ __device__ __forceinline__ RoiFrame make_frame(const float* roi, float scale, in
   f.start_h = -rh / 2.0f;
   f.start_w = -rw / 2.0f;
   f.cs = cosf(theta);
-  f.sn = sinf(theta);
+  f.sn = v0 ? -sinf(theta) : sinf(theta);  // x = xx*cs + yy*sn, y = yy*cs - xx*sn below
   return f;
-}
-
-struct Bil {
-  float w1, w2, w3, w4;
-  int xl, xh, yl, yh;
-};
-
-// :24-68 / :149-190 ; yl == -1 marks "outside"
-__device__ __forceinline__ Bil bilinear(int H, int W, float y, float x) {
-  Bil r{0.f, 0.f, 0.f, 0.f, -1, -1, -1, -1};
-  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return r;
-  if (y < 0) y = 0;
-  if (x < 0) x = 0;
-  int yl = (int)y, xl = (int)x, yh, xh;
-  if (yl >= H - 1) {
-    yh = yl = H - 1;
-    y = (float)yl;
-  } else {
-    yh = yl + 1;
-  }
-  if (xl >= W - 1) {
-    xh = xl = W - 1;
-    x = (float)xl;
-  } else {
-    xh = xl + 1;
-  }
-  float ly = y - yl, lx = x - xl;
-  float hy = 1.f - ly, hx = 1.f - lx;
-  r.w1 = hy * hx;
-  r.w2 = hy * lx;
-  r.w3 = ly * hx;
-  r.w4 = ly * lx;
-  r.xl = xl;
-  r.xh = xh;
-  r.yl = yl;
-  r.yh = yh;
-  return r;
 }
 
 constexpr int RROI_NT = 256;
 
 __global__ __launch_bounds__(RROI_NT) void rroi_forward_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, int C, int H, int W, int PH,
-    int PW, float scale, int sample_num, float* __restrict__ out) {
+    int PW, float scale, int sample_num, int v0, float* __restrict__ out) {
   __shared__ RoiFrame s_f;
   const int n = blockIdx.x;
-  if (threadIdx.x == 0) s_f = make_frame(rois + (long long)n * 6, scale, sample_num, PH, PW);
+  if (threadIdx.x == 0) s_f = make_frame(rois + (long long)n * 6, scale, sample_num, PH, PW, v0);
   __syncthreads();
   const RoiFrame f = s_f;
   const int bins = PH * PW;
@@ -117,10 +89,10 @@ __global__ __launch_bounds__(RROI_NT) void rroi_forward_kernel(
 
 __global__ __launch_bounds__(RROI_NT) void rroi_backward_kernel(
     const float* __restrict__ grad_out, const float* __restrict__ rois, int C, int H, int W, int PH,
-    int PW, float scale, int sample_num, float* __restrict__ grad_feat) {
+    int PW, float scale, int sample_num, int v0, float* __restrict__ grad_feat) {
   __shared__ RoiFrame s_f;
   const int n = blockIdx.x;
-  if (threadIdx.x == 0) s_f = make_frame(rois + (long long)n * 6, scale, sample_num, PH, PW);
+  if (threadIdx.x == 0) s_f = make_frame(rois + (long long)n * 6, scale, sample_num, PH, PW, v0);
   __syncthreads();
   const RoiFrame f = s_f;
   const int bins = PH * PW;
@@ -161,13 +133,13 @@ struct RroiItem {
 };
 
 __device__ __forceinline__ RroiItem rroi_item(const float* __restrict__ rois, long long item, int H, int W, int PH,
-                                             int PW, float scale, int sample_num) {
+                                             int PW, float scale, int sample_num, int v0) {
   const int spb = sample_num * sample_num, bins = PH * PW;
   const long long n = item / ((long long)bins * spb);
   const int rem = (int)(item - n * bins * spb);
   const int bin = rem / spb, smp = rem - bin * spb;
   const int ph = bin / PW, pw = bin - ph * PW, iy = smp / sample_num, ix = smp - iy * sample_num;
-  const RoiFrame f = make_frame(rois + n * 6, scale, sample_num, PH, PW);
+  const RoiFrame f = make_frame(rois + n * 6, scale, sample_num, PH, PW, v0);
   const float yy = f.start_h + ph * f.bin_h + (float)(iy + .5f) * f.bin_h / (float)f.gh;
   const float xx = f.start_w + pw * f.bin_w + (float)(ix + .5f) * f.bin_w / (float)f.gw;
   const float x = xx * f.cs + yy * f.sn + f.cw;
@@ -190,10 +162,10 @@ __device__ __forceinline__ RroiItem rroi_item(const float* __restrict__ rois, lo
 
 __global__ __launch_bounds__(256) void rroi_idx_count_kernel(const float* __restrict__ rois, long long items, int H,
                                                              int W, int PH, int PW, float scale, int sample_num,
-                                                             long long npix, int* __restrict__ cnt) {
+                                                             int v0, long long npix, int* __restrict__ cnt) {
   const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
   if (item >= items) return;
-  const RroiItem t = rroi_item(rois, item, H, W, PH, PW, scale, sample_num);
+  const RroiItem t = rroi_item(rois, item, H, W, PH, PW, scale, sample_num, v0);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (t.p[k] >= 0 && t.p[k] < npix) atomicAdd(cnt + t.p[k], 1);
@@ -201,12 +173,12 @@ __global__ __launch_bounds__(256) void rroi_idx_count_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void rroi_idx_fill_kernel(const float* __restrict__ rois, long long items, int H,
                                                             int W, int PH, int PW, float scale, int sample_num,
-                                                            long long npix, const int* __restrict__ start,
+                                                            int v0, long long npix, const int* __restrict__ start,
                                                             int* __restrict__ fill, int* __restrict__ ent_row,
                                                             float* __restrict__ ent_w) {
   const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
   if (item >= items) return;
-  const RroiItem t = rroi_item(rois, item, H, W, PH, PW, scale, sample_num);
+  const RroiItem t = rroi_item(rois, item, H, W, PH, PW, scale, sample_num, v0);
   const int row = (int)(item / (sample_num * sample_num));  // roi * PH*PW + bin: row of the (R, PH*PW, C) gradient
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -265,9 +237,8 @@ static int rroi_check(int R, int C, int H, int W, int PH, int PW) {
   return RSDET_OK;
 }
 
-extern "C" int rsdet_rroi_align_v1_forward_f32(const float* feat, const float* rois, int R, int C,
-                                               int H, int W, int PH, int PW, float spatial_scale,
-                                               int sample_num, float* out, void* stream) {
+static int rroi_forward(const float* feat, const float* rois, int R, int C, int H, int W, int PH, int PW,
+                        float spatial_scale, int sample_num, int v0, float* out, void* stream) {
   int rc = rroi_check(R, C, H, W, PH, PW);
   if (rc) return rc;
   if (R == 0 || C == 0) return RSDET_OK;
@@ -275,14 +246,12 @@ extern "C" int rsdet_rroi_align_v1_forward_f32(const float* feat, const float* r
   int per_roi = (C * PH * PW + RROI_NT - 1) / RROI_NT;
   int gy = per_roi < 8 ? per_roi : 8;  // >= 8 workgroups per RoI keeps small R busy
   hipLaunchKernelGGL(rroi_forward_kernel, dim3(R, gy), dim3(RROI_NT), 0, (hipStream_t)stream, feat,
-                     rois, C, H, W, PH, PW, spatial_scale, sample_num, out);
+                     rois, C, H, W, PH, PW, spatial_scale, sample_num, v0, out);
   return rsdet_launch_status();
 }
 
-extern "C" int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const float* rois, int R,
-                                                int C, int H, int W, int PH, int PW,
-                                                float spatial_scale, int sample_num,
-                                                float* grad_feat, void* stream) {
+static int rroi_backward(const float* grad_out, const float* rois, int R, int C, int H, int W, int PH, int PW,
+                         float spatial_scale, int sample_num, int v0, float* grad_feat, void* stream) {
   int rc = rroi_check(R, C, H, W, PH, PW);
   if (rc) return rc;
   if (R == 0 || C == 0) return RSDET_OK;
@@ -290,8 +259,20 @@ extern "C" int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const flo
   int per_roi = (C * PH * PW + RROI_NT - 1) / RROI_NT;
   int gy = per_roi < 8 ? per_roi : 8;
   hipLaunchKernelGGL(rroi_backward_kernel, dim3(R, gy), dim3(RROI_NT), 0, (hipStream_t)stream,
-                     grad_out, rois, C, H, W, PH, PW, spatial_scale, sample_num, grad_feat);
+                     grad_out, rois, C, H, W, PH, PW, spatial_scale, sample_num, v0, grad_feat);
   return rsdet_launch_status();
+}
+
+void rsdet_launch_pixel_gather(const float* rows, const int* start, const int* ent_row, const float* ent_w,
+                               long long npix, int C, float* out_nhwc, hipStream_t s) {
+  const bool vec4 = (C % 4 == 0) && (((uintptr_t)rows | (uintptr_t)out_nhwc) % 16 == 0);
+  const unsigned gb = (unsigned)((npix + 3) / 4);
+  if (vec4)
+    hipLaunchKernelGGL(rroi_gather_kernel<true>, dim3(gb), dim3(256), 0, s, rows, start, ent_row, ent_w, npix, C,
+                       out_nhwc);
+  else
+    hipLaunchKernelGGL(rroi_gather_kernel<false>, dim3(gb), dim3(256), 0, s, rows, start, ent_row, ent_w, npix, C,
+                       out_nhwc);
 }
 
 static inline size_t rroi_align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -303,10 +284,9 @@ extern "C" size_t rsdet_rroi_align_v1_backward_gather_ws_size(int R, int PH, int
   return rroi_align256((npix + 1) * 4) * 2 + rroi_align256(ent * 4) * 2 + rroi_align256((npix / 4096 + 1) * 4);
 }
 
-extern "C" int rsdet_rroi_align_v1_backward_gather_f32(const float* grad_out_t, const float* rois, int R, int C, int N,
-                                                       int H, int W, int PH, int PW, float spatial_scale,
-                                                       int sample_num, float* grad_feat_nhwc, void* ws,
-                                                       size_t ws_bytes, void* stream) {
+static int rroi_backward_gather(const float* grad_out_t, const float* rois, int R, int C, int N, int H, int W, int PH,
+                                int PW, float spatial_scale, int sample_num, int v0, float* grad_feat_nhwc, void* ws,
+                                size_t ws_bytes, void* stream) {
   int rc = rroi_check(R, C, H, W, PH, PW);
   if (rc) return rc;
   if (sample_num < 1 || N < 1) return RSDET_EINVAL;  // adaptive sampling (sample_num <= 0): use the scatter form
@@ -328,17 +308,30 @@ extern "C" int rsdet_rroi_align_v1_backward_gather_f32(const float* grad_out_t, 
   if (hipMemsetAsync(cnt, 0, (size_t)(npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
   const unsigned ib = (unsigned)((items + 255) / 256);
   hipLaunchKernelGGL(rroi_idx_count_kernel, dim3(ib), dim3(256), 0, s, rois, items, H, W, PH, PW, spatial_scale,
-                     sample_num, npix, cnt);
+                     sample_num, v0, npix, cnt);
   rsdet_launch_index_scan(cnt, npix, chunk_sum, start, s);
   hipLaunchKernelGGL(rroi_idx_fill_kernel, dim3(ib), dim3(256), 0, s, rois, items, H, W, PH, PW, spatial_scale,
-                     sample_num, npix, start, cnt, ent_row, ent_w);
-  const bool vec4 = (C % 4 == 0) && (((uintptr_t)grad_out_t | (uintptr_t)grad_feat_nhwc) % 16 == 0);
-  const unsigned gb = (unsigned)((npix + 3) / 4);
-  if (vec4)
-    hipLaunchKernelGGL(rroi_gather_kernel<true>, dim3(gb), dim3(256), 0, s, grad_out_t, start, ent_row, ent_w, npix, C,
-                       grad_feat_nhwc);
-  else
-    hipLaunchKernelGGL(rroi_gather_kernel<false>, dim3(gb), dim3(256), 0, s, grad_out_t, start, ent_row, ent_w, npix, C,
-                       grad_feat_nhwc);
+                     sample_num, v0, npix, start, cnt, ent_row, ent_w);
+  rsdet_launch_pixel_gather(grad_out_t, start, ent_row, ent_w, npix, C, grad_feat_nhwc, s);
   return rsdet_launch_status();
 }
+
+#define RSDET_RROI_ENTRY(tag, v0)                                                                                     \
+  extern "C" int rsdet_rroi_align_##tag##_forward_f32(const float* feat, const float* rois, int R, int C, int H,      \
+                                                      int W, int PH, int PW, float spatial_scale, int sample_num,    \
+                                                      float* out, void* stream) {                                    \
+    return rroi_forward(feat, rois, R, C, H, W, PH, PW, spatial_scale, sample_num, v0, out, stream);                 \
+  }                                                                                                                   \
+  extern "C" int rsdet_rroi_align_##tag##_backward_f32(const float* grad_out, const float* rois, int R, int C,        \
+                                                       int H, int W, int PH, int PW, float spatial_scale,            \
+                                                       int sample_num, float* grad_feat, void* stream) {             \
+    return rroi_backward(grad_out, rois, R, C, H, W, PH, PW, spatial_scale, sample_num, v0, grad_feat, stream);      \
+  }                                                                                                                   \
+  extern "C" int rsdet_rroi_align_##tag##_backward_gather_f32(                                                        \
+      const float* grad_out_t, const float* rois, int R, int C, int N, int H, int W, int PH, int PW,                  \
+      float spatial_scale, int sample_num, float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream) {         \
+    return rroi_backward_gather(grad_out_t, rois, R, C, N, H, W, PH, PW, spatial_scale, sample_num, v0,              \
+                                grad_feat_nhwc, ws, ws_bytes, stream);                                               \
+  }
+RSDET_RROI_ENTRY(v1, 0)
+RSDET_RROI_ENTRY(v0, 1)

@@ -11,3 +11,7 @@ from .nms import nms
 from . import bbox_transforms
 from .nms_poly import iou_poly, poly_iou_matrix, nms_poly  # noqa: F401,E402
 from .orn import (rie_forward, rie_backward, rotation_invariant_encoding, RotationInvariantEncoding)  # noqa: F401,E402
+from .nms_poly import poly_nms, multiclass_poly_nms, poly_iou_f32  # noqa: F401,E402
+from .roi_align_rotated import ROIAlignRotated  # noqa: F401,E402
+from .fr import feature_refine, FR, FeatureRefineModule  # noqa: F401,E402
+from .convex_sort import convex_sort  # noqa: F401,E402

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import _lib
 
-__all__ = ["ROIAlignRotated_v1", "roi_align_rotated_v1"]
+__all__ = ["ROIAlignRotated_v1", "roi_align_rotated_v1", "rroi_align"]
 
 
 def _pair(x):
@@ -16,29 +16,33 @@ def _pair(x):
 
 
 class _RotatedROIAlign_v1(torch.autograd.Function):
+    """`variant` = "v1" (this module's reference) or "v0" (ops/roi_align_rotated.py, see roi_align_rotated.py here):
+    the two share kernels and differ in the RoI frame only."""
+
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio):
+    def forward(ctx, input, rois, output_size, spatial_scale, sampling_ratio, variant="v1"):
         assert rois.shape[1] == 6  # :306
+        assert variant in ("v0", "v1")
         _lib.require_cuda_f32(input, rois)
         lib = _lib.load()
         input, rois = input.contiguous(), rois.contiguous()
         ctx.save_for_backward(rois)
-        ctx.cfg = (tuple(input.shape), output_size, float(spatial_scale), int(sampling_ratio))
+        ctx.cfg = (tuple(input.shape), output_size, float(spatial_scale), int(sampling_ratio), variant)
         N, C, H, W = input.shape
         R = rois.shape[0]
         out = torch.empty((R, C, output_size[0], output_size[1]), dtype=input.dtype, device=input.device)
-        rc = lib.rsdet_rroi_align_v1_forward_f32(_lib.ptr(input), _lib.ptr(rois), R, C, H, W, output_size[0],
-                                                 output_size[1], float(spatial_scale), int(sampling_ratio),
-                                                 _lib.ptr(out), _lib.stream_ptr())
-        _lib.check(rc, "rsdet_rroi_align_v1_forward_f32")
+        name = "rsdet_rroi_align_%s_forward_f32" % variant
+        rc = getattr(lib, name)(_lib.ptr(input), _lib.ptr(rois), R, C, H, W, output_size[0], output_size[1],
+                                float(spatial_scale), int(sampling_ratio), _lib.ptr(out), _lib.stream_ptr())
+        _lib.check(rc, name)
         return out
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors
-        shape, output_size, scale, sr = ctx.cfg
+        shape, output_size, scale, sr, variant = ctx.cfg
         lib = _lib.load()
         N, C, H, W = shape
         go = grad_output.contiguous()
@@ -49,20 +53,24 @@ class _RotatedROIAlign_v1(torch.autograd.Function):
             g_nhwc = torch.empty((N, H, W, C), dtype=go.dtype, device=go.device)
             ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
-            rc = lib.rsdet_rroi_align_v1_backward_gather_f32(_lib.ptr(go_t), _lib.ptr(rois), R, C, N, H, W, PH, PW,
-                                                             scale, sr, _lib.ptr(g_nhwc), _lib.ptr(ws), ws_bytes,
-                                                             _lib.stream_ptr())
-            _lib.check(rc, "rsdet_rroi_align_v1_backward_gather_f32")
-            return g_nhwc.permute(0, 3, 1, 2).contiguous(), None, None, None, None
+            name = "rsdet_rroi_align_%s_backward_gather_f32" % variant
+            rc = getattr(lib, name)(_lib.ptr(go_t), _lib.ptr(rois), R, C, N, H, W, PH, PW, scale, sr,
+                                    _lib.ptr(g_nhwc), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+            _lib.check(rc, name)
+            return g_nhwc.permute(0, 3, 1, 2).contiguous(), None, None, None, None, None
         grad_in = torch.zeros(shape, dtype=go.dtype, device=go.device)  # :345 memset
-        rc = lib.rsdet_rroi_align_v1_backward_f32(_lib.ptr(go), _lib.ptr(rois), rois.shape[0], C, H, W,
-                                                  output_size[0], output_size[1], scale, sr, _lib.ptr(grad_in),
-                                                  _lib.stream_ptr())
-        _lib.check(rc, "rsdet_rroi_align_v1_backward_f32")
-        return grad_in, None, None, None, None
+        name = "rsdet_rroi_align_%s_backward_f32" % variant
+        rc = getattr(lib, name)(_lib.ptr(go), _lib.ptr(rois), rois.shape[0], C, H, W, output_size[0], output_size[1],
+                                scale, sr, _lib.ptr(grad_in), _lib.stream_ptr())
+        _lib.check(rc, name)
+        return grad_in, None, None, None, None, None
 
 
-roi_align_rotated_v1 = _RotatedROIAlign_v1.apply
+rroi_align = _RotatedROIAlign_v1.apply
+
+
+def roi_align_rotated_v1(input, rois, output_size, spatial_scale, sampling_ratio):
+    return rroi_align(input, rois, output_size, spatial_scale, sampling_ratio, "v1")
 
 
 class ROIAlignRotated_v1(nn.Module):

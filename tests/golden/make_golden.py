@@ -106,6 +106,15 @@ extern "C" void ref_rroi_bwd(const float* gout, const float* rois, int R, int C,
 '''
 
 
+def build_shim_one(tmp, name, text):
+    """Compile one shimmed translation unit (reference CUDA text as host C++) and load it."""
+    cpp = os.path.join(tmp, name + ".cpp")
+    open(cpp, "w").write(text)
+    so = os.path.join(tmp, name + ".so")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-o", so, cpp])
+    return ctypes.CDLL(so)
+
+
 def build_shim_lib(tmp):
     dcn = module_string(os.path.join(REF_OPS, "dcn_v1.py"), "HEADER")
     dcn = re.sub(r"#include\s*<\s*executor\.h\s*>", "", dcn)
@@ -242,6 +251,10 @@ def main():
                         decoded_clip1e6=oracle.np_delta2bbox_rotated(prop, deltas, wh_ratio_clip=1e-6),
                         provenance=prov("NumPy transcription of models/boxes/box_ops.py:176-289, seed 20240601"))
     make_rie(ref)
+    make_rroi_v0()
+    make_fr()
+    make_convex(ref)
+    make_poly_nms()
     print("golden fixtures written to", HERE)
 
 
@@ -263,9 +276,211 @@ def make_rie(ref):
     np.savez_compressed(os.path.join(HERE, "rie.npz"), provenance=prov("seed 20240602; reference CPU RIE"), **out)
 
 
+def make_rroi_v0():
+    """rroi_v0.npz: ROIAlignRotated (ops/roi_align_rotated.py CUDA_HEADER :7-254) through the host shim, fixed and
+    adaptive sampling grids, RoIs outside the map and smaller than one pixel.  Own RNG."""
+    rng = np.random.default_rng(20240603)
+    tmp = tempfile.mkdtemp(prefix="jdet_shim_")
+    try:
+        text = module_string(os.path.join(REF_OPS, "roi_align_rotated.py"), "CUDA_HEADER")
+        lib = build_shim_one(tmp, "rroi0", SHIM + "namespace rroi {" + text + "}\nusing namespace rroi;\n" + WRAP_RROI)
+        out = {}
+        for tag, (N, C, H, W, R, scale, sr) in {"a": (2, 3, 16, 20, 7, 0.25, 2), "b": (1, 5, 32, 32, 9, 0.125, 0),
+                                                "c": (2, 4, 24, 24, 6, 1 / 16., 3)}.items():
+            feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+            b = dota_boxes(rng, R, W / scale, 8, 120, 60)
+            rois = np.concatenate([rng.integers(0, N, (R, 1)).astype(np.float32), b], 1)
+            rois[0, 1:3] = [-30, -30]
+            rois[1, 3:5] = [0.5, 0.5]
+            o = np.zeros((R, C, 7, 7), np.float32)
+            lib.ref_rroi_fwd(fp(feat), fp(rois), R, C, H, W, 7, 7, ctypes.c_float(scale), sr, fp(o))
+            go = rng.standard_normal(o.shape).astype(np.float32)
+            gf = np.zeros_like(feat)
+            lib.ref_rroi_bwd(fp(go), fp(rois), R, C, H, W, 7, 7, ctypes.c_float(scale), sr, fp(gf))
+            out.update({tag + "_feat": feat, tag + "_rois": rois, tag + "_cfg": np.array([scale, sr], np.float64),
+                        tag + "_out": o, tag + "_go": go, tag + "_gfeat": gf})
+        np.savez_compressed(os.path.join(HERE, "rroi_v0.npz"),
+                            provenance=prov("seed 20240603; reference CUDA text on host via macro shim"), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+WRAP_FR = r'''
+extern "C" void ref_fr_fwd(const float* feat, const float* boxes, int N, int C, int H, int W, float scale, int points,
+    float* out) {
+  feature_refine_forward_kernel<float>(N * C * H * W, points, feat, boxes, scale, C, H, W, out);
+}
+extern "C" void ref_fr_bwd(const float* top, const float* boxes, int N, int C, int H, int W, float scale, int points,
+    float* gin) {
+  feature_refine_backward_kernel<float>(N * C * H * W, points, top, boxes, scale, C, H, W, gin);
+}
+'''
+
+
+def make_fr():
+    """fr.npz: FeatureRefine (ops/fr.py HEADER :5-232) through the host shim; boxes drawn as the reference's own
+    test does (fr.py:349-377: centres on the stride grid + noise, log-normal sizes, angle in (-pi/2, 0]), so many
+    sample points fall outside the map.  points = 1 and 5.  Own RNG."""
+    rng = np.random.default_rng(20240604)
+    tmp = tempfile.mkdtemp(prefix="jdet_shim_")
+    try:
+        text = module_string(os.path.join(REF_OPS, "fr.py"), "HEADER")
+        lib = build_shim_one(tmp, "fr", SHIM + "namespace fr {" + text + "}\nusing namespace fr;\n" + WRAP_FR)
+        out = {}
+        for tag, (N, C, H, W, stride, points) in {"a": (2, 4, 16, 16, 8.0, 1), "b": (2, 3, 12, 20, 8.0, 5),
+                                                  "c": (1, 6, 9, 7, 16.0, 5)}.items():
+            feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+            base = 4.0 * stride
+            yc, xc = np.meshgrid(stride * np.arange(H), stride * np.arange(W), indexing="ij")
+            xc = xc[None] + base * rng.standard_normal((N, H, W))
+            yc = yc[None] + base * rng.standard_normal((N, H, W))
+            w = base * np.exp(rng.standard_normal((N, H, W)))
+            h = base * np.exp(rng.standard_normal((N, H, W)))
+            a = -np.pi / 2 * rng.random((N, H, W))
+            # entry 0 is consumed as the ROW coordinate (fr.py:131): put yc first so that most points land inside
+            boxes = np.stack([yc, xc, w, h, a], -1).astype(np.float32)
+            o = np.zeros_like(feat)
+            lib.ref_fr_fwd(fp(feat), fp(boxes), N, C, H, W, ctypes.c_float(1.0 / stride), points, fp(o))
+            go = rng.standard_normal(o.shape).astype(np.float32)
+            gi = np.zeros_like(feat)
+            lib.ref_fr_bwd(fp(go), fp(boxes), N, C, H, W, ctypes.c_float(1.0 / stride), points, fp(gi))
+            out.update({tag + "_feat": feat, tag + "_boxes": boxes, tag + "_cfg": np.array([1.0 / stride, points]),
+                        tag + "_out": o, tag + "_go": go, tag + "_gin": gi})
+        np.savez_compressed(os.path.join(HERE, "fr.npz"),
+                            provenance=prov("seed 20240604; reference CUDA text on host via macro shim"), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def convex_cases(rng):
+    """Point sets for convex_sort: (i) random clouds with random masks, (ii) the poly_iou_loss shape (24 points:
+    16 edge intersections + 2 x 4 vertices, most of them masked off), (iii) integer lattice points (collinear runs,
+    exact duplicates, equal cosine keys), (iv) all points masked off / a single valid point, (v) npts = 100 (the
+    global-workspace variant of the kernel)."""
+    cases = {}
+    pts = (rng.standard_normal((300, 24, 2)) * 20).astype(np.float32)
+    cases["a"] = (pts, rng.random((300, 24)) > 0.3, True)
+    pts = (rng.standard_normal((200, 8, 2)) * 50).astype(np.float32)
+    cases["b"] = (pts, np.ones((200, 8), bool), False)
+    pts = rng.integers(-3, 4, (400, 24, 2)).astype(np.float32)
+    cases["c"] = (pts, rng.random((400, 24)) > 0.2, True)
+    pts = (rng.standard_normal((70, 12, 2))).astype(np.float32)
+    m = rng.random((70, 12)) > 0.5
+    m[:10] = False
+    m[10:20] = False
+    m[10:20, 3] = True
+    cases["d"] = (pts, m, True)
+    pts = (rng.standard_normal((130, 100, 2)) * 5).astype(np.float32)
+    cases["e"] = (pts, rng.random((130, 100)) > 0.1, True)
+    return cases
+
+
+def make_convex(ref):
+    """convex.npz: the reference's own CPU Graham-scan loop (ops/convex_sort.py:93-154, compiled by
+    oracle/build_ref.py) on start / order arrays prepared by oracle.np_convex_sort_prepare (the Jittor tensor code
+    :67-84 restated in NumPy; its tie rules are unpinned).  Own RNG."""
+    rng = np.random.default_rng(20240605)
+    out = {}
+    for tag, (pts, m, circ) in convex_cases(rng).items():
+        x, y, mf, start, order = oracle.np_convex_sort_prepare(pts, m)
+        out.update({tag + "_pts": pts, tag + "_masks": m, tag + "_circular": np.bool_(circ), tag + "_start": start,
+                    tag + "_order": order, tag + "_index": ref.convex_sort_scan(x, y, mf, start, order, circ)})
+    np.savez_compressed(os.path.join(HERE, "convex.npz"),
+                        provenance=prov("seed 20240605; reference CPU convex_sort loop"), **out)
+
+
+SHIM_POLY = r'''
+#include <vector>
+#include <iostream>
+struct float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+#define __shared__ static
+static inline void __syncthreads() {}
+'''
+
+WRAP_POLY = r'''
+extern "C" void ref_poly_iou(const float* p1, int n1, const float* p2, int n2, float* out) {
+  for (int i = 0; i < n1; ++i)
+    for (int j = 0; j < n2; ++j) out[(size_t)i * n2 + j] = devPolyIoU(p1 + (size_t)i * 8, p2 + (size_t)j * 8);
+}
+'''
+
+
+def poly_nms_cases(rng):
+    """Quadrilateral detections for the fp32 in-model polygon NMS: (a) clustered rotated rectangles at image scale
+    (the Gliding-Vertex use), (b) the same with the per-class coordinate offset of multiclass_poly_nms (large
+    coordinates: this is where the float cancellation noise of the reference shows), (c) general convex / skewed
+    quadrilaterals with both orientations, identical and degenerate (zero-area) ones."""
+    from conftest import dota_boxes
+    import oracle as _o
+    cases = {}
+    centres = dota_boxes(rng, 30, 800)
+    b = centres[rng.integers(0, 30, 400)].copy()
+    b[:, :2] += rng.normal(0, 4, (400, 2)).astype(np.float32)
+    b[:, 4] += rng.normal(0, 0.1, 400).astype(np.float32)
+    polys = _o.np_rotated_box_to_poly(b).astype(np.float32)
+    sc = rng.uniform(0.05, 1, 400).astype(np.float32)
+    cases["a"] = np.concatenate([polys, sc[:, None]], 1)
+    lab = rng.integers(0, 15, 400).astype(np.float32)
+    off = lab * (polys.max() - polys.min() + 1)
+    cases["b"] = np.concatenate([polys + off[:, None], sc[:, None]], 1).astype(np.float32)
+    q = (rng.uniform(0, 60, (150, 1, 2)) + rng.uniform(-15, 15, (150, 4, 2))
+         + np.array([[0, 0], [30, 0], [30, 30], [0, 30]])).astype(np.float32)
+    q[::2] = q[::2, ::-1]          # clockwise ones
+    q[5] = q[4]                    # identical pair
+    q[7] = 12.0                    # all four vertices equal: zero area
+    q[8] = 40.0
+    cases["c"] = np.concatenate([q.reshape(150, 8), rng.uniform(0.05, 1, (150, 1)).astype(np.float32)], 1)
+    return cases
+
+
+def make_poly_nms():
+    """poly_nms.npz: devPolyIoU of ops/nms_poly.py HEADER (:4-184) through the host shim (dense IoU matrices), and the
+    keep lists of the greedy sweep (:195-207 restated here in NumPy on those matrices, `> thr`).  Own RNG."""
+    rng = np.random.default_rng(20240606)
+    tmp = tempfile.mkdtemp(prefix="jdet_shim_")
+    try:
+        text = module_string(os.path.join(REF_OPS, "nms_poly.py"), "HEADER")
+        text = re.sub(r"#include\s*<\s*executor\.h\s*>", "", text)
+        lib = build_shim_one(tmp, "polynms", SHIM + SHIM_POLY + "namespace pn {" + text + "}\nusing namespace pn;\n"
+                             + WRAP_POLY)
+        out = {}
+        for tag, dets in poly_nms_cases(rng).items():
+            order = np.argsort(-dets[:, 8], kind="stable")
+            d = np.ascontiguousarray(dets[order])
+            n = len(d)
+            p = np.ascontiguousarray(d[:, :8])
+            iou = np.zeros((n, n), np.float32)
+            lib.ref_poly_iou(fp(p), n, fp(p), n, fp(iou))
+            out[tag + "_dets"], out[tag + "_iou_sorted"] = dets, iou[:96, :96].copy()  # corner: keeps the file small
+            for thr in (0.1, 0.5):
+                removed = np.zeros(n, bool)
+                keep = []
+                for i in range(n):
+                    if removed[i]:
+                        continue
+                    keep.append(i)
+                    removed[i + 1:] |= iou[i, i + 1:] > np.float32(thr)
+                out["%s_keep_%g" % (tag, thr)] = order[np.array(keep, np.int64)]
+        np.savez_compressed(os.path.join(HERE, "poly_nms.npz"),
+                            provenance=prov("seed 20240606; reference CUDA text (devPolyIoU) on host via macro shim"),
+                            **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "rie":
+    if len(sys.argv) > 1 and sys.argv[1] == "poly_nms":
+        make_poly_nms()
+    elif len(sys.argv) > 1 and sys.argv[1] == "convex":
+        import oracle as _o
+        make_convex(_o.ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "fr":
+        make_fr()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rie":
         import oracle as _o
         make_rie(_o.ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "rroi_v0":
+        make_rroi_v0()
     else:
         main()

@@ -78,6 +78,56 @@ def test_rroi_golden(cuda):
         assert np.abs(feat.grad.cpu().numpy() - d[t + "_gfeat"]).max() <= 1e-4 * max(1, np.abs(d[t + "_gfeat"]).max())
 
 
+def test_rroi_v0_golden(cuda):
+    from rs_detection_amd.ops.roi_align_rotated import roi_align
+    d = np.load(os.path.join(G, "rroi_v0.npz"))
+    for t in "abc":
+        sc, sr = d[t + "_cfg"]
+        feat = _t(d[t + "_feat"], cuda).requires_grad_(True)
+        out = roi_align(feat, _t(d[t + "_rois"], cuda), (7, 7), float(sc), int(sr))
+        assert np.abs(out.detach().cpu().numpy() - d[t + "_out"]).max() <= 1e-4
+        out.backward(_t(d[t + "_go"], cuda))
+        assert np.abs(feat.grad.cpu().numpy() - d[t + "_gfeat"]).max() <= 1e-4 * max(1, np.abs(d[t + "_gfeat"]).max())
+
+
+def test_feature_refine_golden(cuda):
+    from rs_detection_amd.ops.fr import feature_refine
+    d = np.load(os.path.join(G, "fr.npz"))
+    for t in "abc":
+        sc, pt = d[t + "_cfg"]
+        feat = _t(d[t + "_feat"], cuda).requires_grad_(True)
+        out = feature_refine(feat, _t(d[t + "_boxes"], cuda), float(sc), int(pt))
+        assert np.abs(out.detach().cpu().numpy() - d[t + "_out"]).max() <= 1e-4
+        out.backward(_t(d[t + "_go"], cuda))
+        assert np.abs(feat.grad.cpu().numpy() - d[t + "_gin"]).max() <= 1e-4 * max(1, np.abs(d[t + "_gin"]).max())
+
+
+def test_convex_sort_golden(cuda):
+    """Hull indices are integer work: bit-exact against the reference's CPU loop (fixture), stale slots included."""
+    from rs_detection_amd.ops.convex_sort import convex_sort
+    d = np.load(os.path.join(G, "convex.npz"))
+    for t in "abcde":
+        got = convex_sort(_t(d[t + "_pts"], cuda), torch.from_numpy(d[t + "_masks"]).to(cuda),
+                          bool(d[t + "_circular"]))
+        assert got.dtype == torch.int32 and (got.cpu().numpy() == d[t + "_index"]).all(), t
+
+
+def test_poly_nms_golden(cuda):
+    """fp32 in-model polygon NMS: IoU values bit-identical to the reference arithmetic (fixture), keep lists equal."""
+    from rs_detection_amd.ops import poly_nms, poly_iou_f32
+    d = np.load(os.path.join(G, "poly_nms.npz"))
+    for t in "abc":
+        dets = d[t + "_dets"]
+        order = np.argsort(-dets[:, 8], kind="stable")
+        p = _t(np.ascontiguousarray(dets[order][:96, :8]), cuda)
+        got = poly_iou_f32(p, p).cpu().numpy()
+        assert (got == d[t + "_iou_sorted"]).all(), (t, np.abs(got - d[t + "_iou_sorted"]).max())
+        for thr in (0.1, 0.5):
+            keep = poly_nms(_t(dets, cuda), thr).cpu().numpy()
+            want = d["%s_keep_%g" % (t, thr)]
+            assert len(keep) == len(want) and (keep == want).all(), (t, thr)
+
+
 def test_assign_and_coder_golden(cuda):
     from rs_detection_amd import ops
     d = np.load(os.path.join(G, "assign.npz"))

@@ -210,6 +210,38 @@ def test_rroi_align_forward_backward(cuda, oracle_c, N, C, H, W, R, scale, sr):
     assert np.abs(ft.grad.cpu().numpy() - wantg).max() <= 1e-4 * max(1.0, np.abs(wantg).max())
 
 
+@pytest.mark.parametrize("N,C,H,W,R,scale,sr", [(2, 3, 16, 20, 5, 0.25, 2), (1, 8, 32, 32, 17, 0.125, 0),
+                                                 (2, 16, 64, 64, 40, 1 / 16., 2), (1, 256, 64, 64, 64, 0.125, 2)])
+def test_rroi_align_v0_forward_backward(cuda, oracle_c, N, C, H, W, R, scale, sr):
+    """f4: ROIAlignRotated (ops/roi_align_rotated.py); sr=0 runs the adaptive grid + scatter backward, sr>0 the gather."""
+    from rs_detection_amd.ops.roi_align_rotated import ROIAlignRotated
+    rng = np.random.default_rng(100 + R)
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = _rois(rng, R, N, W / scale)
+    rois[0, 1:3] = [-30, -30]
+    rois[1, 3:5] = [0.5, 0.5]
+    ft = _t(feat, cuda).requires_grad_(True)
+    out = ROIAlignRotated((7, 7), scale, sr)(ft, _t(rois, cuda))
+    want = oracle_c.rroi_align_v1_forward(feat, rois, (7, 7), scale, sr, "v0")
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= TOL
+    go = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(_t(go, cuda))
+    wantg = oracle_c.rroi_align_v1_backward(go, rois, feat.shape, scale, sr, "v0")
+    assert np.abs(ft.grad.cpu().numpy() - wantg).max() <= 1e-4 * max(1.0, np.abs(wantg).max())
+
+
+def test_rroi_align_v0_reference_smoke_shape(cuda):
+    """The reference's own smoke test (roi_align_rotated.py:332-339): (2,1024,64,64) feature, two RoIs, 1/16 scale,
+    default adaptive sampling; output shape and a finite gradient of exp(output)."""
+    from rs_detection_amd.ops.roi_align_rotated import ROIAlignRotated
+    feat = torch.randn(2, 1024, 64, 64, device=cuda, requires_grad=True)
+    roi = torch.tensor([[0, 20, 120, 80, 195.5, 0.3], [1, 23, 56, 200, 300.5, 0.2]], device=cuda)
+    out = ROIAlignRotated((7, 7), 1 / 16.)(feat, roi)
+    assert tuple(out.shape) == (2, 1024, 7, 7)
+    (g,) = torch.autograd.grad(out.exp().sum(), feat)
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
 def test_rroi_align_grad_sum_property(cuda):
     """Reference's own smoke property: inside RoIs, sum(grad) = R*C*49 for ones."""
     from rs_detection_amd.ops import ROIAlignRotated_v1
@@ -218,6 +250,110 @@ def test_rroi_align_grad_sum_property(cuda):
     out = ROIAlignRotated_v1((7, 7), 1 / 16., 2)(feat, rois)
     out.sum().backward()
     assert abs(float(feat.grad.sum()) - 2 * 3 * 49) < 1e-2
+
+
+# ---------------------------------------------------------------- FeatureRefine (f4)
+def _fr_boxes(rng, N, H, W, stride):
+    """Boxes as the reference's own test draws them (fr.py:349-377)."""
+    base = 4.0 * stride
+    yc, xc = np.meshgrid(stride * np.arange(H), stride * np.arange(W), indexing="ij")
+    xc = xc[None] + base * rng.standard_normal((N, H, W))
+    yc = yc[None] + base * rng.standard_normal((N, H, W))
+    w = base * np.exp(rng.standard_normal((N, H, W)))
+    h = base * np.exp(rng.standard_normal((N, H, W)))
+    a = -np.pi / 2 * rng.random((N, H, W))
+    return np.stack([xc, yc, w, h, a], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("N,C,H,W,stride,points", [(2, 16, 32, 32, 8.0, 1), (2, 16, 32, 32, 8.0, 5),
+                                                    (1, 7, 13, 29, 16.0, 5), (2, 256, 64, 64, 16.0, 1),
+                                                    (1, 256, 128, 128, 8.0, 5)])
+def test_feature_refine_forward_backward(cuda, oracle_c, N, C, H, W, stride, points):
+    from rs_detection_amd.ops.fr import FR
+    rng = np.random.default_rng(7 * H + points)
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    boxes = _fr_boxes(rng, N, H, W, stride)
+    ft = _t(feat, cuda).requires_grad_(True)
+    out = FR(1.0 / stride, points)(ft, _t(boxes, cuda))
+    want = oracle_c.feature_refine_forward(feat, boxes, 1.0 / stride, points)
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= TOL
+    go = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(_t(go, cuda))
+    wantg = oracle_c.feature_refine_backward(go, boxes, 1.0 / stride, points)
+    assert np.abs(ft.grad.cpu().numpy() - wantg).max() <= 1e-4 * max(1.0, np.abs(wantg).max())
+    # gather-form backward: bit-identical on a second call (no atomics)
+    ft2 = _t(feat, cuda).requires_grad_(True)
+    FR(1.0 / stride, points)(ft2, _t(boxes, cuda)).backward(_t(go, cuda))
+    assert torch.equal(ft.grad, ft2.grad)
+
+
+def test_feature_refine_module_and_linearity(cuda):
+    """FeatureRefineModule (fr.py:291-347) steps; FR is linear in the features: FR(a+b) = FR(a) + FR(b)."""
+    from rs_detection_amd.ops.fr import FR, FeatureRefineModule
+    rng = np.random.default_rng(3)
+    strides = [8, 16]
+    xs = [torch.randn(2, 32, 1024 // s // 8, 1024 // s // 8, device=cuda, requires_grad=True) for s in strides]
+    best = [[_t(_fr_boxes(rng, 1, x.shape[2], x.shape[3], float(s))[0].reshape(-1, 5), cuda)
+             for x, s in zip(xs, strides)] for _ in range(2)]
+    m = FeatureRefineModule(32, strides).to(cuda)
+    outs = m(xs, best)
+    assert [tuple(o.shape) for o in outs] == [tuple(x.shape) for x in xs]
+    sum(o.square().mean() for o in outs).backward()
+    assert all(torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0 for x in xs)
+    assert all(p.grad is not None for p in m.parameters())
+    a, b = torch.randn(2, 8, 16, 16, device=cuda), torch.randn(2, 8, 16, 16, device=cuda)
+    bx = _t(_fr_boxes(rng, 2, 16, 16, 8.0), cuda)
+    f = FR(1 / 8., 5)
+    assert float((f(a + b, bx) - f(a, bx) - f(b, bx)).abs().max()) <= 1e-4
+    with pytest.raises(AssertionError):
+        FR(1 / 8., 3)(a, bx)
+
+
+# ---------------------------------------------------------------- convex_sort (f4)
+@pytest.mark.parametrize("nbs,npts,circular", [(1, 8, True), (63, 24, True), (5000, 24, True), (4097, 8, False),
+                                               (300, 56, True), (130, 57, True), (3, 200, False)])
+def test_convex_sort_vs_oracle(cuda, oracle_c, nbs, npts, circular):
+    """Random clouds with random masks, plus lattice points (ties, duplicates, collinear runs): indices bit-exact."""
+    from rs_detection_amd.ops.convex_sort import convex_sort
+    rng = np.random.default_rng(nbs + npts)
+    for kind in ("cloud", "lattice"):
+        pts = ((rng.standard_normal((nbs, npts, 2)) * 20) if kind == "cloud"
+               else rng.integers(-3, 4, (nbs, npts, 2))).astype(np.float32)
+        m = rng.random((nbs, npts)) > 0.3
+        got = convex_sort(_t(pts, cuda), torch.from_numpy(m).to(cuda), circular).cpu().numpy()
+        want = oracle.np_convex_sort(pts, m, circular)
+        assert (got == want).all(), kind
+
+
+def test_convex_sort_edges_and_poly_iou_shape(cuda, oracle_c):
+    from rs_detection_amd.ops.convex_sort import convex_sort
+    # empty batch, no points (:179-180 returns the -1 table), everything masked off, one valid point
+    assert tuple(convex_sort(torch.zeros(0, 24, 2, device=cuda), torch.zeros(0, 24, device=cuda)).shape) == (0, 25)
+    z = convex_sort(torch.zeros(4, 0, 2, device=cuda), torch.zeros(4, 0, device=cuda))
+    assert tuple(z.shape) == (4, 1) and (z == -1).all()
+    pts = torch.randn(3, 6, 2, device=cuda)
+    m = torch.zeros(3, 6, dtype=torch.bool, device=cuda)
+    m[1, 4] = True
+    got = convex_sort(pts, m).cpu().numpy()
+    assert (got == oracle.np_convex_sort(pts.cpu().numpy(), m.cpu().numpy())).all()
+    assert got[1, 0] == 4 and got[1, 1] == 4 and (got[1, 2:] == -1).all()
+    # the caller's use (poly_iou_loss.py:21-37): area of the intersection of two overlapping squares
+    sq1 = np.array([[0, 0], [2, 0], [2, 2], [0, 2]], np.float32)
+    sq2 = sq1 + 1
+    inter = np.array([[2, 1], [1, 2]], np.float32)
+    allp = np.concatenate([inter, np.zeros((14, 2), np.float32), sq1, sq2])[None]
+    mask = np.zeros((1, 24), bool)
+    mask[0, [0, 1]] = True          # the two edge intersections
+    mask[0, 16 + 2] = True          # (2,2) of sq1 lies inside sq2
+    mask[0, 20 + 0] = True          # (1,1) of sq2 lies inside sq1
+    idx = convex_sort(_t(allp, cuda), torch.from_numpy(mask).to(cuda)).cpu().numpy()[0]
+    idx = np.where(idx == -1, 24, idx)
+    ext = np.concatenate([allp[0], np.zeros((1, 2), np.float32)])
+    poly = ext[idx]
+    area = 0.5 * abs(np.sum(poly[:-1, 0] * poly[1:, 1] - poly[:-1, 1] * poly[1:, 0]))
+    assert abs(area - 1.0) < 1e-6
+    with pytest.raises(Exception):
+        convex_sort(torch.zeros(2, 4, 2), torch.zeros(2, 4))   # CPU tensors: no fallback
 
 
 # ---------------------------------------------------------------- coder / offsets (a7, a9, a10, a17)

@@ -94,3 +94,52 @@ def test_mergebypoly_files_and_map_driver_on_gpu(cuda, tmp_path):
     got = evaluate_dota(results, classes, device=cuda)
     for k in want:
         assert got[k] == pytest.approx(want[k], abs=1e-12)
+
+
+# ---------------------------------------------------------------- f4: in-model fp32 polygon NMS (ops/nms_poly.py:186-224)
+@pytest.mark.parametrize("n,span,thr", [(1, 500, 0.1), (64, 300, 0.1), (65, 300, 0.3), (1000, 900, 0.1),
+                                        (3000, 1024, 0.1), (700, 200, 0.5)])
+def test_poly_nms_f32_vs_oracle(cuda, n, span, thr):
+    """Bit-exact keep lists against the oracle's restatement of the reference's float arithmetic, and bit-identical
+    IoU values on a sample of pairs (general quadrilaterals, both orientations, concave ones included)."""
+    import oracle
+    from rs_detection_amd.ops import poly_nms, poly_iou_f32
+    rng = np.random.default_rng(n)
+    q = _random_quads(rng, n, span, convex_only=False).astype(np.float32)
+    dets = np.concatenate([q, rng.uniform(0.05, 1, (n, 1)).astype(np.float32)], 1)
+    dets[::7, 8] = dets[0, 8]                           # score ties: index order decides (stable)
+    c = oracle.c()
+    keep = poly_nms(torch.from_numpy(dets).to(cuda), thr).cpu().numpy()
+    want = c.poly_nms(dets, thr)
+    assert len(keep) == len(want) and (keep == want).all()
+    m = min(n, 128)
+    got = poly_iou_f32(torch.from_numpy(q[:m]).to(cuda), torch.from_numpy(q[-m:]).to(cuda)).cpu().numpy()
+    assert (got == c.poly_iou_f32(q[:m], q[-m:])).all()
+
+
+def test_multiclass_poly_nms_and_edges(cuda):
+    import oracle
+    from rs_detection_amd.ops import multiclass_poly_nms, poly_nms
+    rng = np.random.default_rng(5)
+    n = 900
+    q = _random_quads(rng, n, 800).astype(np.float32)
+    scores = rng.uniform(0.05, 1, n).astype(np.float32)
+    labels = rng.integers(0, 15, n)
+    dets, lab = multiclass_poly_nms(torch.from_numpy(q).to(cuda), torch.from_numpy(scores).to(cuda),
+                                    torch.from_numpy(labels).to(cuda), 0.1)
+    # the same thing with the oracle: the offsets are computed in float32 exactly as nms_poly.py:213-216 does
+    mc = np.float32(q.max() - q.min())
+    off = labels.astype(np.float32) * (mc + np.float32(1))
+    keep = oracle.c().poly_nms(np.concatenate([q + off[:, None], scores[:, None]], 1).astype(np.float32), 0.1)
+    assert (lab.cpu().numpy() == labels[keep]).all()
+    assert (dets.cpu().numpy() == np.concatenate([q[keep], scores[keep][:, None]], 1)).all()
+    assert (np.diff(dets[:, 8].cpu().numpy()) <= 0).all()          # descending score, `order_t[keep]`
+    # empty input, CPU tensors (no fallback), wrong width
+    e, el = multiclass_poly_nms(torch.zeros(0, 8, device=cuda), torch.zeros(0, device=cuda),
+                                torch.zeros(0, dtype=torch.int64, device=cuda), 0.1)
+    assert tuple(e.shape) == (0, 9) and el.numel() == 0
+    assert poly_nms(torch.zeros(0, 9, device=cuda), 0.1).numel() == 0
+    with pytest.raises(Exception):
+        poly_nms(torch.zeros(4, 9), 0.1)
+    with pytest.raises(AssertionError):
+        poly_nms(torch.zeros(4, 8, device=cuda), 0.1)

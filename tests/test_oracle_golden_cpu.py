@@ -77,6 +77,76 @@ def test_rroi_golden(oracle_c):
         assert np.abs(gf - d[t + "_gfeat"]).max() <= 1e-5
 
 
+def test_rroi_v0_golden(oracle_c):
+    """ROIAlignRotated (ops/roi_align_rotated.py) restatement vs the shimmed reference text (make_golden.make_rroi_v0)."""
+    d = load("rroi_v0.npz")
+    for t in "abc":
+        sc, sr = d[t + "_cfg"]
+        out = oracle_c.rroi_align_v1_forward(d[t + "_feat"], d[t + "_rois"], (7, 7), float(sc), int(sr), "v0")
+        assert np.abs(out - d[t + "_out"]).max() <= 1e-5
+        gf = oracle_c.rroi_align_v1_backward(d[t + "_go"], d[t + "_rois"], d[t + "_feat"].shape, float(sc), int(sr),
+                                             "v0")
+        assert np.abs(gf - d[t + "_gfeat"]).max() <= 1e-5
+        # v0 differs from v1 (guards against the variant flag being dropped on the way)
+        assert np.abs(out - oracle_c.rroi_align_v1_forward(d[t + "_feat"], d[t + "_rois"], (7, 7), float(sc),
+                                                           int(sr))).max() > 1e-3
+
+
+def test_feature_refine_golden(oracle_c):
+    """FeatureRefine (ops/fr.py) restatement vs the shimmed reference text (make_golden.make_fr): exact."""
+    d = load("fr.npz")
+    for t in "abc":
+        sc, pt = d[t + "_cfg"]
+        out = oracle_c.feature_refine_forward(d[t + "_feat"], d[t + "_boxes"], float(sc), int(pt))
+        assert np.abs(out - d[t + "_out"]).max() == 0
+        gi = oracle_c.feature_refine_backward(d[t + "_go"], d[t + "_boxes"], float(sc), int(pt))
+        assert np.abs(gi - d[t + "_gin"]).max() <= 1e-6
+
+
+def test_convex_sort_golden(oracle_c):
+    """convex_sort: the C restatement of the scan == the reference's CPU loop (fixture), bit for bit, including the
+    stale stack slots the reference leaves behind; the hull it describes has the area scipy's ConvexHull finds."""
+    d = load("convex.npz")
+    for t in "abcde":
+        pts, m, circ = d[t + "_pts"], d[t + "_masks"], bool(d[t + "_circular"])
+        x, y, mf, start, order = oracle.np_convex_sort_prepare(pts, m)
+        assert (start == d[t + "_start"]).all() and (order == d[t + "_order"]).all()
+        got = oracle_c.convex_sort_scan(x, y, mf, start, order, circ)
+        assert (got == d[t + "_index"]).all()
+    from scipy.spatial import ConvexHull
+    pts, m, idx = d["a_pts"], d["a_masks"], d["a_index"]
+    for i in range(60):
+        n = int(np.argmax(idx[i, 1:] == idx[i, 0])) + 1   # closing index
+        P = pts[i][idx[i, :n]].astype(np.float64)
+        area = 0.5 * abs(np.sum(P[:, 0] * np.roll(P[:, 1], -1) - np.roll(P[:, 0], -1) * P[:, 1]))
+        if m[i].sum() >= 3:
+            assert abs(area - ConvexHull(pts[i][m[i]].astype(np.float64)).volume) <= 1e-3 * area
+
+
+def test_poly_nms_golden(oracle_c):
+    """In-model fp32 polygon NMS (ops/nms_poly.py:17-210): the restated float arithmetic equals the reference's
+    devPolyIoU (through the host shim) bit for bit -- including its cancellation noise (IoU < 0 and > 1 in case b) --
+    so the keep lists are identical."""
+    d = load("poly_nms.npz")
+    for t in "abc":
+        dets = d[t + "_dets"]
+        order = np.argsort(-dets[:, 8], kind="stable")
+        p = np.ascontiguousarray(dets[order][:96, :8])
+        assert (oracle_c.poly_iou_f32(p, p) == d[t + "_iou_sorted"]).all()
+        for thr in (0.1, 0.5):
+            want = d["%s_keep_%g" % (t, thr)]
+            got = oracle_c.poly_nms(dets, thr)
+            assert len(got) == len(want) and (got == want).all()
+    assert d["b_iou_sorted"].max() > 1.0 and d["b_iou_sorted"].min() < 0.0   # the noise is really there
+    # known answers: unit square vs itself / half-shifted / disjoint, both orientations
+    sq = np.array([[0, 0, 1, 0, 1, 1, 0, 1]], np.float32)
+    cw = sq.reshape(1, 4, 2)[:, ::-1].reshape(1, 8).copy()
+    sh = sq + np.array([0.5, 0] * 4, np.float32)
+    far = sq + 5
+    iou = oracle_c.poly_iou_f32(np.concatenate([sq, cw]), np.concatenate([sq, sh, far]))
+    assert np.abs(iou - np.array([[1, 1 / 3., 0], [1, 1 / 3., 0]], np.float32)).max() < 1e-6
+
+
 def test_assign_golden(oracle_c):
     d = load("assign.npz")
     gi, mo, lb = oracle_c.assign_wrt_overlaps(d["overlaps"], 0.5, 0.4, 0.0, True, True, d["gt_labels"], 0)
