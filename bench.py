@@ -162,6 +162,69 @@ def kernel_rooflines(device, targets):
         t = event_time(fn, 10, 2)
         out[name] = dict(bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6, mboxes_per_s=M / t / 1e6)
+    out.update(next_row_kernels(device))
+    return out
+
+
+def next_row_kernels(device):
+    """SURVEY 8(f) rows (RROIAlign of the Oriented R-CNN head, and the rank-4 ops): same HIP-event timing."""
+    from rs_detection_amd import ops
+    from rs_detection_amd.utils import synthetic as syn
+    out = {}
+
+    def row(name, by, t, bound="hbm", **kw):
+        out[name] = dict(bound=bound, achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6, **kw)
+
+    rng = np.random.default_rng(3)
+    # -- ROIAlignRotated_v1 / v0 (a18, f4): 512 RoIs on the stride-4 level of two 1024^2 tiles, 7x7 bins, 2x2 samples;
+    #    bytes = 4*R*C*49*(1 out + 16 gathered in) (SURVEY 8d)
+    N, C, H, R = 2, 256, TILE // 4, 512
+    feat = torch.randn(N, C, H, H, device=device, requires_grad=True)
+    b = syn.dota_gt_boxes(rng, R).astype(np.float32)
+    rois = torch.from_numpy(np.concatenate([rng.integers(0, N, (R, 1)).astype(np.float32), b], 1)).to(device)
+    by = 4 * R * C * 49 * 17
+    for tag, fn in (("v1", ops.roi_align_rotated_v1), ("v0", ops.roi_align_rotated.roi_align)):
+        t = event_time(lambda: fn(feat.detach(), rois, (7, 7), 0.25, 2), 10, 2)
+        row("rroi_forward_kernel(%s; 512 RoIs x 256 ch)" % tag, by, t)
+    y = ops.roi_align_rotated_v1(feat, rois, (7, 7), 0.25, 2)
+    go = torch.randn_like(y)
+    t = event_time(lambda: torch.autograd.grad(y, feat, go, retain_graph=True), 10, 2, graph=False)
+    row("rroi_idx_count+scan+fill+rroi_gather(backward; incl. the two layout permutes and a %d MB output)"
+        % (N * C * H * H * 4 // 2 ** 20), 4 * (R * C * 49 + N * C * H * H), t)
+    del feat, y, go
+    # -- FeatureRefine (f4): R3Det level 0 of two tiles, 256 channels; bytes = read + write every element once
+    N, C, H = 2, 256, TILE // 8
+    f = torch.randn(N, C, H, H, device=device, requires_grad=True)
+    yc, xc = np.meshgrid(8.0 * np.arange(H), 8.0 * np.arange(H), indexing="ij")
+    bx = np.stack([xc[None] + 32 * rng.standard_normal((N, H, H)), yc[None] + 32 * rng.standard_normal((N, H, H)),
+                   32 * np.exp(rng.standard_normal((N, H, H))), 32 * np.exp(rng.standard_normal((N, H, H))),
+                   -np.pi / 2 * rng.random((N, H, H))], -1).astype(np.float32)
+    bx = torch.from_numpy(bx).to(device)
+    by = 4 * (2 * N * C * H * H + 5 * N * H * H)
+    for pts in (1, 5):
+        t = event_time(lambda: ops.feature_refine(f.detach(), bx, 0.125, pts), 10, 2)
+        row("fr_forward_kernel<%d>" % pts, by, t)
+        y = ops.feature_refine(f, bx, 0.125, pts)
+        go = torch.randn_like(y)
+        t = event_time(lambda: torch.autograd.grad(y, f, go, retain_graph=True), 10, 2, graph=False)
+        row("fr_idx_count+scan+fill+gather<%d>(backward; incl. the two layout permutes)" % pts, by, t)
+    del f, y, go
+    # -- convex_sort (f4): the poly_iou_loss shape, 24 candidate points per pair, 20 000 pairs
+    nbs, npts = 20000, 24
+    p = torch.randn(nbs, npts, 2, device=device) * 20
+    m = torch.rand(nbs, npts, device=device) > 0.6
+    t = event_time(lambda: ops.convex_sort(p, m), 10, 2)
+    row("convex_sort_kernel(20000 sets x 24 points)", nbs * (npts * 12 + (npts + 1) * 4), t, bound="latency/alu",
+        msets_per_s=nbs / t / 1e6)
+    # -- poly_nms (f4): 2000 quadrilaterals of the NMS micro-bench clusters, fp32 reference arithmetic on every pair
+    d, sc, _ = syn.nms_cluster_boxes(2000)
+    from rs_detection_amd.ops.box_coder import rotated_box_to_poly
+    q = rotated_box_to_poly(torch.from_numpy(d).to(device))
+    dets = torch.cat([q, torch.from_numpy(sc).to(device)[:, None]], 1).contiguous()
+    t = event_time(lambda: ops.poly_nms(dets, 0.1), 5, 1, graph=False)
+    row("poly_nms(iota + mask + sweep; 2000 quads, all pairs)", 36 * 2000, t, bound="alu",
+        mpairs_per_s=2000 * 1999 / 2 / t / 1e6)
     return out
 
 

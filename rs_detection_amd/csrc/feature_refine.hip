@@ -14,7 +14,8 @@
 //
 // Backward = gather form (as col2im / RROIAlign backward): the (position, point, corner) -> pixel map is inverted
 // on integers, then one wave per pixel sums its terms from the channels-last gradient.  No fp32 atomics (the
-// reference issues 1 + 4*points per element), deterministic, grad_in written exactly once.
+// reference issues 1 + 4*points per element), grad_in written exactly once.  (The order of a pixel's terms follows
+// the integer atomics of the fill stage, so the last bit of a sum can differ between runs, as with atomicAdd.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -77,13 +78,34 @@ __global__ __launch_bounds__(256) void fr_forward_kernel(const float* __restrict
     o11[i] = in ? b.yh * W + b.xh : 0;
     w1[i] = b.w1; w2[i] = b.w2; w3[i] = b.w3; w4[i] = b.w4;
   }
-  for (int c = blockIdx.z; c < C; c += gridDim.z) {
-    const float* fp = feat + ((long long)n * C + c) * HW;
-    float acc = fp[pos];
+  // FR_U channels per trip: all their loads are issued before the first use (the gathers are independent), which is
+  // what hides the ~2 us HBM latency of a trip; the tail trips clamp the channel and drop the store.
+  constexpr int FR_U = POINTS == 1 ? 8 : 4;
+  const int cstep = gridDim.z;
+  for (int c0 = blockIdx.z; c0 < C; c0 += FR_U * cstep) {
+    float v[FR_U][4 * POINTS + 1];
 #pragma unroll
-    for (int i = 0; i < POINTS; ++i)
-      acc += w1[i] * fp[o00[i]] + w2[i] * fp[o01[i]] + w3[i] * fp[o10[i]] + w4[i] * fp[o11[i]];  // :55-63, :166-169
-    out[((long long)n * C + c) * HW + pos] = acc;
+    for (int u = 0; u < FR_U; ++u) {
+      const int c = min(c0 + u * cstep, C - 1);
+      const float* fp = feat + ((long long)n * C + c) * HW;
+      v[u][4 * POINTS] = fp[pos];
+#pragma unroll
+      for (int i = 0; i < POINTS; ++i) {
+        v[u][4 * i + 0] = fp[o00[i]];
+        v[u][4 * i + 1] = fp[o01[i]];
+        v[u][4 * i + 2] = fp[o10[i]];
+        v[u][4 * i + 3] = fp[o11[i]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < FR_U; ++u) {
+      const int c = c0 + u * cstep;
+      float acc = v[u][4 * POINTS];
+#pragma unroll
+      for (int i = 0; i < POINTS; ++i)  // :55-63, :166-169
+        acc += w1[i] * v[u][4 * i] + w2[i] * v[u][4 * i + 1] + w3[i] * v[u][4 * i + 2] + w4[i] * v[u][4 * i + 3];
+      if (c < C) out[((long long)n * C + c) * HW + pos] = acc;
+    }
   }
 }
 

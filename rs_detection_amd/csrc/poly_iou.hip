@@ -240,8 +240,8 @@ __device__ __forceinline__ void pn_cut(F2* p, int& n, F2 a, F2 b, F2* pp, int la
     const float su = pcross(a, b, u), sv = pcross(a, b, v);
     if (psig(su) > 0) {
       PN_AT(pp, m) = u;
-      ++m;
-    }
+      m += m < PN_SLOTS - 1;  // the reference's rings hold maxn = 10 points and are never checked; a triangle cut
+    }                         // by three lines stays below that, the clamp only keeps a pathological input in bounds
     if (psig(su) != psig(sv)) {
       // lineCross (:50-59): s1 = su, s2 = sv.  The two "no crossing" exits leave the staging slot as it is.
       if (!(psig(su) == 0 && psig(sv) == 0) && psig(sv - su) != 0) {
@@ -250,7 +250,7 @@ __device__ __forceinline__ void pn_cut(F2* p, int& n, F2 a, F2 b, F2* pp, int la
         x.y = (u.y * sv - v.y * su) / (sv - su);
         PN_AT(pp, m) = x;
       }
-      ++m;
+      m += m < PN_SLOTS - 1;
     }
   }
   n = 0;
@@ -321,22 +321,30 @@ __device__ float pn_quad_iou(const float* __restrict__ q1, const float* __restri
   return uni == 0 ? (inter + 1) / (uni + 1) : inter / uni;  // :125-129
 }
 
-__global__ __launch_bounds__(64) void nms_poly_f32_mask_kernel(const float* __restrict__ polys, int stride, int n,
-                                                               float thr, int col_blocks,
-                                                               NmsEntry* __restrict__ entries,
-                                                               unsigned* __restrict__ blk_cnt,
-                                                               unsigned long long* __restrict__ diag_t) {
+// PN_WAVES waves per 64x64 tile: wave w takes the columns j = w (mod PN_WAVES), every wave with its own pair of rings
+// (a lone wave per tile walks 64 columns x 16 triangle pairs serially and 2000 boxes give only ~500 tiles: ~2 waves
+// per CU, 4.9 ms; 8 waves per tile: see DESIGN.md).  The waves OR their bits together in LDS.
+constexpr int PN_WAVES = 8;
+
+__global__ __launch_bounds__(64 * PN_WAVES) void nms_poly_f32_mask_kernel(const float* __restrict__ polys, int stride,
+                                                                         int n, float thr, int col_blocks,
+                                                                         NmsEntry* __restrict__ entries,
+                                                                         unsigned* __restrict__ blk_cnt,
+                                                                         unsigned long long* __restrict__ diag_t) {
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;
   __shared__ float s_col[64 * 8];
-  __shared__ F2 s_p[PN_SLOTS * 64], s_pp[PN_SLOTS * 64];
+  __shared__ F2 s_ring[PN_WAVES * 2 * PN_SLOTS * 64];  // per wave: ring p, then staging ring pp
   __shared__ unsigned long long s_rows[64];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cols = min(64, n - cbk * 64), rows = min(64, n - rb * 64);
-  if (tid < cols) {
-    const float* q = polys + (long long)(cbk * 64 + tid) * stride;
+  if (wave == 0) {
+    s_rows[tid] = 0ull;
+    if (tid < cols) {
+      const float* q = polys + (long long)(cbk * 64 + tid) * stride;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s_col[tid * 8 + k] = q[k];
+      for (int k = 0; k < 8; ++k) s_col[tid * 8 + k] = q[k];
+    }
   }
   __syncthreads();
   unsigned long long bits = 0ull;
@@ -346,9 +354,15 @@ __global__ __launch_bounds__(64) void nms_poly_f32_mask_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < 8; ++k) q[k] = g[k];
     const int start = (rb == cbk) ? tid + 1 : 0;
-    for (int j = start; j < cols; ++j)
-      if (pn_quad_iou(q, s_col + j * 8, s_p, s_pp, tid) > thr) bits |= 1ull << j;  // :179
+    for (int j = wave; j < cols; j += PN_WAVES)
+      if (j >= start && pn_quad_iou(q, s_col + j * 8, s_ring + wave * 2 * PN_SLOTS * 64,
+                                   s_ring + (wave * 2 + 1) * PN_SLOTS * 64, tid) > thr) bits |= 1ull << j;  // :179
   }
+  if (bits) atomicOr(&s_rows[tid], bits);
+  __syncthreads();
+  if (wave != 0) return;
+  bits = s_rows[tid];
+  __syncthreads();  // (one wave left: orders the read above before poly_emit_tile reuses s_rows)
   poly_emit_tile(bits, rb, cbk, tid, col_blocks, entries, blk_cnt, diag_t, s_rows);
 }
 
@@ -447,7 +461,7 @@ extern "C" int rsdet_poly_nms_sorted_f32(const float* dets_sorted, int n, float 
   unsigned* blk_cnt = (unsigned*)(w + diag_bytes);
   NmsEntry* entries = (NmsEntry*)(w + diag_bytes + cnt_bytes);
   hipLaunchKernelGGL(poly_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ident, n, blk_cnt);
-  hipLaunchKernelGGL(nms_poly_f32_mask_kernel, dim3(cb, cb), dim3(64), 0, s, dets_sorted, 9, n, thr, cb, entries,
+  hipLaunchKernelGGL(nms_poly_f32_mask_kernel, dim3(cb, cb), dim3(64 * PN_WAVES), 0, s, dets_sorted, 9, n, thr, cb, entries,
                      blk_cnt, diag_t);
   rsdet_launch_nms_sweep(entries, blk_cnt, diag_t, n, cb, ident, keep_sorted, s);
   return rsdet_launch_status();
