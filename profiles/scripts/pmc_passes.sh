@@ -5,6 +5,6 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 for c in WRITE_SIZE FETCH_SIZE; do
   rm -rf $O/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/profiles/scripts/pmc_iou.py > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 $R/profiles/scripts/pmc_kernels.py > /dev/null 2>&1
 done
 python3 $R/profiles/scripts/pmc_summary.py $O/pmc_WRITE_SIZE $O/pmc_FETCH_SIZE
