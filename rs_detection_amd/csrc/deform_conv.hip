@@ -529,7 +529,9 @@ __global__ __launch_bounds__(256) void dcn_idx_fill_kernel(const float* __restri
 }
 
 // one wave per input pixel; pixels are walked in 8x8 tiles so that the four pixels sharing a colT row
-// (the corners of one sampling point) are processed close together and the row is re-read from L2
+// (the corners of one sampling point) are processed close together, and the workgroup ids are renumbered so that an
+// XCD owns a contiguous run of tiles (rsdet_xcd_contiguous): round-robin placement would put the four on four
+// different L2s and the row would be fetched again by each
 template <bool VEC4>
 __global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const float* __restrict__ colT,
                                                                     const int* __restrict__ start,
@@ -539,10 +541,10 @@ __global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const float*
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long npix = (long long)g.B * g.H * g.W;
-  long long wid = (long long)blockIdx.x * DCN_WAVES + wave;
+  long long wid = (long long)rsdet_xcd_contiguous(blockIdx.x, gridDim.x) * DCN_WAVES + wave;
   if (wid >= npix) return;
   long long pix = wid;
-  if ((g.H & 7) == 0 && (g.W & 7) == 0) {  // tile swizzle
+  if ((g.H & 7) == 0 && (g.W & 7) == 0) {  // tile swizzle (16x16 tiles measure the same)
     const long long plane = (long long)g.H * g.W;
     const int b = (int)(wid / plane);
     const int r = (int)(wid - (long long)b * plane);

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(const float* __restric
                                                           const float* __restrict__ ent_w, long long npix, int C,
                                                           float* __restrict__ grad_nhwc) {
   const int lane = threadIdx.x & 63;
-  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // XCD-contiguous workgroup order: neighbouring pixels share gradient rows, keep them on one L2
+  const long long pix = (long long)rsdet_xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (pix >= npix) return;
   const int e0 = start[pix], e1 = start[pix + 1];
   if (VEC4) {
