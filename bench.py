@@ -28,13 +28,19 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# MIOpen find mode (honoured if already set): FAST for the S2ANet line -- measured equal to NORMAL there (64.5 vs 64.4
-# ms/step) at 6 s instead of 30 s start-up on a fresh box; NORMAL for --model orcnn_van3, where FAST lands on im2col+GEMM
-# convolutions for the VAN backbone (347 vs 157 ms/step).
-os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL" if "orcnn_van3" in sys.argv else "FAST")
+# MIOpen find mode (honoured if already set).  With the packaged solver records (rs_detection_amd/miopen_db, see
+# utils/miopen_db.py) FAST answers from those records for every shipped config in seconds.  Without them
+# (RSDET_NO_MIOPEN_DB=1 or another MIOpen build) FAST equals NORMAL for the S2ANet line (64.5 vs 64.4 ms/step) but
+# lands on im2col+GEMM convolutions for the VAN backbone of --model orcnn_van3 (347 vs 157 ms/step): NORMAL there.
+_no_db = os.environ.get("RSDET_NO_MIOPEN_DB", "0") == "1"
+os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL" if ("orcnn_van3" in sys.argv and _no_db) else "FAST")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+# tuned MIOpen solver records for the shipped configs (rs_detection_amd/miopen_db, 140 KB of text): see the module
+from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db  # noqa: E402
+MIOPEN_DB_DIR = use_packaged_miopen_db()
 
 torch.backends.cudnn.benchmark = os.environ.get("RSDET_CUDNN_BENCHMARK", "0") == "1"
 

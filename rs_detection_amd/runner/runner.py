@@ -22,6 +22,8 @@ from rs_detection_amd.utils.registry import MODELS, OPTIMS, SCHEDULERS, build_fr
 class Runner:
     def __init__(self, cfg, device=None, distributed=None, memory_format=None, amp_dtype=None):
         self.cfg = cfg
+        from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db
+        use_packaged_miopen_db()  # tuned MIOpen solver records of the shipped configs (before the first convolution)
         self.rank, self.local_rank, self.world = rdist.env_world()
         if device is None:
             device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
