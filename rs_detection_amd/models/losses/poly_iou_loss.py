@@ -155,6 +155,6 @@ class PolyGIoULoss(_PolyLossBase):
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
         if weight is not None and not bool((weight > 0).any()) and reduction != 'none':
-            return (pred * weight).sum()  # 0 (:224-226)
+            return (pred * (weight if weight.dim() == pred.dim() else weight[..., None])).sum()  # 0 (:224-226)
         return self.loss_weight * poly_giou_loss(pred, target, weight=self._weight(pred, weight), eps=self.eps,
                                                  reduction=reduction, avg_factor=avg_factor, **kwargs)
