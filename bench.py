@@ -124,7 +124,10 @@ def kernel_rooflines(device, targets):
     t = event_time(lambda: ops.assign_wrt_overlaps(ov, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0), 50)
     by = 2 * 4 * n1 * A + 12 * len(ks) * A
     out["assign_row+col_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                        frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+                                        frac=by / t / 1e9 / HBM_PEAK_GBS, us=t * 1e6,
+                                        # profiles/r01_k_pmc_hbm_traffic.txt: each pass fetches the matrix once
+                                        # (FETCH 2 x 23.2 MiB, doubled per the guide's gfx950 rule) + 1.0 MiB written
+                                        traffic=98.3e6 if (n1, A) == (556, 21824) else None)
     # -- deformable im2col / col2im at pyramid level 0 (a11): bytes = 4*(C*HW*B + 18*HW*B + 9*C*HW*B)
     B, C, H = len(ks), 256, TILE // 8
     x = torch.randn(B, C, H, H, device=device)
@@ -132,7 +135,9 @@ def kernel_rooflines(device, targets):
     t = event_time(lambda: ops.deformable_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
     by = 4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B)
     out["deform_im2col_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                                       frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6)
+                                       frac=by / t / 1e9 / HBM_PEAK_GBS, us=t * 1e6,
+                                       # r01_k PMC: WRITE 576 MiB (the columns) + FETCH 167.5 MiB as reported
+                                       traffic=779.6e6 if (B, C, H) == (4, 256, 128) else None)
     # (the reference-layout col2im -- one lane per column row, 13.2 ms here -- is kept for API parity only; the step
     #  uses the channels-last pair below, so it is not timed: it would dominate the rocprof summary of this command)
     xn = x.permute(0, 2, 3, 1).contiguous()
@@ -148,7 +153,10 @@ def kernel_rooflines(device, targets):
     t = event_time(lambda: deformable_col2im_gather_nhwc(colT, off, xn.shape, (3, 3), (1, 1), (1, 1), (1, 1)), 10, 2)
     out["dcn_idx_count+scan+fill+dcn_gather(col2im of the step)"] = dict(
         bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
-        traffic=None, us=t * 1e6)
+        us=t * 1e6,
+        # r01_k PMC, as reported: gather FETCH 746.6 + WRITE 64 MiB; count / fill / scan WRITE 34.8 + 143.7 + 0.5,
+        # FETCH 4.5 + 9.7 MiB
+        traffic=1052.7e6 if (B, C, H) == (4, 256, 128) else None)
     del colT, xn, x, off
     # -- rotated NMS (a16), SURVEY 8d micro-bench shape M=5344, 6 columns (15 classes), thr 0.1.  Timed the way the
     #    class-aware entry points call it (ops.ml_nms_rotated: label-major order, one concurrent sweep per label run)
