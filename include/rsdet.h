@@ -262,6 +262,21 @@ int rsdet_poly_iou_f32(const float* polys1, int n1, const float* polys2, int n2,
  * Replaces models/boxes/box_ops.py:633-654.  boxes (n,5) -> polys (n,8). */
 int rsdet_rotated_box_to_poly_f32(const float* boxes, int n, float* polys, void* stream);
 
+/* ---- a20  depthwise convolutions of the VAN backbone ---------------------------------------------------
+ * Replaces nn.Conv2d(dim, dim, k, groups=dim) at models/backbones/van.py:32 (3x3), :56 (5x5), :57 (7x7, dilation 3)
+ * on the Oriented R-CNN + VAN path: stride 1, "same" padding dilation*(K-1)/2, (K, dilation) in {(3,1), (5,1), (7,3)}
+ * (anything else: RSDET_EINVAL -- the host module then keeps torch's convolution).  x / y / grad (N,C,H,W),
+ * weight (C,1,K,K) = (C,K,K) contiguous, bias (C) or NULL.  backward_weight also returns the bias gradient
+ * (grad_bias may be NULL); its sums run in a fixed order (two stages through ws, no float atomics). */
+int rsdet_dwconv2d_forward_f32(const float* x, const float* weight, const float* bias, int N, int C, int H, int W,
+                               int K, int dilation, float* y, void* stream);
+int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float* weight, int N, int C, int H, int W, int K,
+                                     int dilation, float* grad_x, void* stream);
+size_t rsdet_dwconv2d_backward_weight_ws_size(int N, int C, int H, int W, int K);
+int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, int N, int C, int H, int W, int K,
+                                       int dilation, float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes,
+                                       void* stream);
+
 /* ---- a21  eval-mode BatchNorm + residual add + ReLU (backbone Bottleneck tails) -----------------------
  * Replaces the per-op sequence models/backbones/resnet.py:101-126 (bn -> (+ identity) -> relu) when the
  * BatchNorm is in eval mode (norm_eval, :177-184): y = max(((x - mean) * rsqrt(var + eps)) * weight + bias

@@ -1,0 +1,248 @@
+// dwconv.hip -- depthwise 2-D convolution ("same" padding, stride 1) forward / backward for gfx950.
+//
+// Replaces, on the Oriented R-CNN + VAN path, the depthwise convolutions of the VAN backbone:
+//   /root/reference/python/jdet/models/backbones/van.py:32 (DWConv 3x3 on the MLP's hidden width),
+//   :56 (LKA conv0 5x5), :57 (LKA conv_spatial 7x7, dilation 3)  -- nn.Conv2d(dim, dim, k, groups=dim).
+// MIOpen serves these fp32 shapes with its naive direct kernels and im2col (`naive_conv_ab_nonpacked_*`,
+// `Im2d2Col_v2`: 36 of 143 ms of kernel time per VAN-B3 step), torch's own depthwise kernels take another 12 ms.
+// The op is a stencil: every input element is needed K*K times by neighbouring outputs of ONE channel plane and by
+// nothing else, so it is HBM-bound if a plane tile is staged once in LDS.
+//
+//   forward / backward-data   one workgroup per (plane, 32 x 64 output tile): the tile plus its halo (up to 9 on each
+//                             side for 7x7 dilation 3) goes to LDS with coalesced loads; a thread owns one column and
+//                             8 rows, walks the K kernel columns, keeps the column window in registers and reuses
+//                             it for the K vertical taps.  backward-data is the same stencil with the taps
+//                             mirrored (same padding => same geometry).
+//   backward-weight           same staging of x; a thread holds its 8 output-gradient values and accumulates
+//                             K*K (+1 for the bias) partial sums, reduced over the workgroup (wave shuffles + LDS)
+//                             into a partial row per workgroup, then summed in a fixed order by a second kernel
+//                             (deterministic, no float atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsdet_api_internal.h"
+
+namespace rsdet {
+
+constexpr int DW_TH = 32, DW_TW = 64, DW_NT = 256, DW_ROWS = DW_TH / (DW_NT / DW_TW);  // 8 rows per thread
+
+template <int K, int D>
+struct DwGeom {
+  static constexpr int halo = D * (K - 1) / 2;
+  static constexpr int LH = DW_TH + 2 * halo, LW = DW_TW + 2 * halo;
+  static constexpr int LWP = LW | 1;  // odd row pitch: rows of a column land on different banks
+  static constexpr int WIN = DW_ROWS + (K - 1) * D;
+  // the kernel-column loop stays rolled for 7x7: unrolled, the compiler keeps all seven 26-value column windows live
+  // (235 VGPRs, two waves per SIMD); rolled it is one window at a time
+  static constexpr int KW_UNROLL = K >= 7 ? 1 : K;
+};
+
+// coalesced staging of the (tile + halo) window of one plane, zero outside the plane
+template <int K, int D>
+__device__ __forceinline__ void dw_stage(const float* __restrict__ plane, int H, int W, int y0, int x0,
+                                         float* __restrict__ s) {
+  using G = DwGeom<K, D>;
+  for (int i = threadIdx.x; i < G::LH * G::LW; i += DW_NT) {
+    const int r = i / G::LW, c = i - r * G::LW;
+    const int y = y0 - G::halo + r, x = x0 - G::halo + c;
+    s[r * G::LWP + c] = (y >= 0 && y < H && x >= 0 && x < W) ? plane[(long long)y * W + x] : 0.f;
+  }
+}
+
+// grid: (N * C planes, tiles_x * tiles_y).  Neighbouring tiles of a plane are N * C workgroup ids apart -- a multiple
+// of 8 for every VAN width, i.e. on the same XCD, where their shared halo rows meet in L2.  FLIP mirrors the taps
+// (backward-data).
+template <int K, int D, bool FLIP>
+__global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ bias, int C, int H, int W,
+                                                               int tiles_x, float* __restrict__ y) {
+  using G = DwGeom<K, D>;
+  __shared__ float s[G::LH * G::LWP];
+  __shared__ float s_w[K * K];
+  const int plane = blockIdx.x, c = plane % C;
+  const int ty0 = (blockIdx.y / tiles_x) * DW_TH, tx0 = (blockIdx.y % tiles_x) * DW_TW;
+  if (threadIdx.x < K * K) s_w[threadIdx.x] = w[c * K * K + (FLIP ? K * K - 1 - threadIdx.x : threadIdx.x)];
+  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s);
+  __syncthreads();
+  const int tx = threadIdx.x % DW_TW, tr = (threadIdx.x / DW_TW) * DW_ROWS;
+  float acc[DW_ROWS];
+  const float b = (!FLIP && bias) ? bias[c] : 0.f;
+#pragma unroll
+  for (int r = 0; r < DW_ROWS; ++r) acc[r] = b;
+#pragma unroll G::KW_UNROLL
+  for (int kw = 0; kw < K; ++kw) {
+    float win[G::WIN];
+#pragma unroll
+    for (int i = 0; i < G::WIN; ++i) win[i] = s[(tr + i) * G::LWP + tx + kw * D];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      const float wv = s_w[kh * K + kw];
+#pragma unroll
+      for (int r = 0; r < DW_ROWS; ++r) acc[r] += wv * win[r + kh * D];
+    }
+  }
+  const int ox = tx0 + tx;
+  if (ox < W) {
+    float* yp = y + (long long)plane * H * W;
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r) {
+      const int oy = ty0 + tr + r;
+      if (oy < H) yp[(long long)oy * W + ox] = acc[r];
+    }
+  }
+}
+
+// partial[(c * nslots + slot) * (K*K + 1) + t], slot = n * tiles + tile; t = K*K is the bias gradient
+template <int K, int D>
+__global__ __launch_bounds__(DW_NT) void dwconv_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                             int C, int H, int W, int tiles_x, int nslots,
+                                                             float* __restrict__ partial) {
+  using G = DwGeom<K, D>;
+  constexpr int T = K * K + 1;
+  __shared__ float s[G::LH * G::LWP];
+  __shared__ float s_red[DW_NT / 64][T];
+  const int plane = blockIdx.x, c = plane % C, n = plane / C;
+  const int ty0 = (blockIdx.y / tiles_x) * DW_TH, tx0 = (blockIdx.y % tiles_x) * DW_TW;
+  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s);
+  const int tx = threadIdx.x % DW_TW, tr = (threadIdx.x / DW_TW) * DW_ROWS;
+  float g[DW_ROWS];
+  {
+    const int ox = tx0 + tx;
+    const float* gp = gy + (long long)plane * H * W;
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r) {
+      const int oy = ty0 + tr + r;
+      g[r] = (ox < W && oy < H) ? gp[(long long)oy * W + ox] : 0.f;
+    }
+  }
+  __syncthreads();
+  // per kernel column: K partial sums (one per kernel row) over this thread's 8 outputs, reduced over the wave with
+  // butterflies and parked in LDS; the bias gradient rides along as one more value
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r) v += g[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) s_red[wave][K * K] = v;
+  }
+#pragma unroll G::KW_UNROLL
+  for (int kw = 0; kw < K; ++kw) {
+    float win[G::WIN];
+#pragma unroll
+    for (int i = 0; i < G::WIN; ++i) win[i] = s[(tr + i) * G::LWP + tx + kw * D];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < DW_ROWS; ++r) v += g[r] * win[r + kh * D];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) s_red[wave][kh * K + kw] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < T) {
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < DW_NT / 64; ++wv) v += s_red[wv][threadIdx.x];
+    const int slot = n * gridDim.y + blockIdx.y;
+    partial[((long long)c * nslots + slot) * T + threadIdx.x] = v;
+  }
+}
+
+// one wave per channel: fixed-order sum of its nslots partial rows
+__global__ __launch_bounds__(64) void dwconv_wgrad_finish_kernel(const float* __restrict__ partial, int nslots, int T,
+                                                                 float* __restrict__ gw, float* __restrict__ gb) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (t >= T) return;
+  const float* p = partial + (long long)c * nslots * T + t;
+  float v = 0.f;
+  for (int sl = 0; sl < nslots; ++sl) v += p[(long long)sl * T];
+  if (t < T - 1)
+    gw[c * (T - 1) + t] = v;
+  else if (gb)
+    gb[c] = v;
+}
+
+}  // namespace rsdet
+
+using namespace rsdet;
+
+static int dw_check(int N, int C, int H, int W, int K, int dil) {
+  if (N < 0 || C < 0 || H < 1 || W < 1) return RSDET_EINVAL;
+  if (!((K == 3 && dil == 1) || (K == 5 && dil == 1) || (K == 7 && dil == 3))) return RSDET_EINVAL;
+  if ((long long)N * C > 0x7fffffffLL) return RSDET_EINVAL;
+  if ((long long)((W + DW_TW - 1) / DW_TW) * ((H + DW_TH - 1) / DW_TH) > 65535) return RSDET_EINVAL;  // gridDim.y
+  return RSDET_OK;
+}
+
+template <bool FLIP>
+static int dw_stencil(const float* x, const float* w, const float* bias, int N, int C, int H, int W, int K, int dil,
+                      float* y, hipStream_t s) {
+  const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH;
+  const dim3 grid(N * C, tx * ty);
+  if (K == 3)
+    hipLaunchKernelGGL((dwconv_stencil_kernel<3, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, C, H, W, tx, y);
+  else if (K == 5)
+    hipLaunchKernelGGL((dwconv_stencil_kernel<5, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, C, H, W, tx, y);
+  else
+    hipLaunchKernelGGL((dwconv_stencil_kernel<7, 3, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, C, H, W, tx, y);
+  (void)dil;
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_dwconv2d_forward_f32(const float* x, const float* weight, const float* bias, int N, int C, int H,
+                                          int W, int K, int dilation, float* y, void* stream) {
+  int rc = dw_check(N, C, H, W, K, dilation);
+  if (rc) return rc;
+  if (N == 0 || C == 0) return RSDET_OK;
+  if (!x || !weight || !y) return RSDET_EINVAL;
+  return dw_stencil<false>(x, weight, bias, N, C, H, W, K, dilation, y, (hipStream_t)stream);
+}
+
+extern "C" int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float* weight, int N, int C, int H, int W,
+                                                int K, int dilation, float* grad_x, void* stream) {
+  int rc = dw_check(N, C, H, W, K, dilation);
+  if (rc) return rc;
+  if (N == 0 || C == 0) return RSDET_OK;
+  if (!grad_y || !weight || !grad_x) return RSDET_EINVAL;
+  return dw_stencil<true>(grad_y, weight, nullptr, N, C, H, W, K, dilation, grad_x, (hipStream_t)stream);
+}
+
+extern "C" size_t rsdet_dwconv2d_backward_weight_ws_size(int N, int C, int H, int W, int K) {
+  if (N <= 0 || C <= 0 || H < 1 || W < 1 || K < 1) return 0;
+  const size_t tiles = (size_t)((W + DW_TW - 1) / DW_TW) * ((H + DW_TH - 1) / DW_TH);
+  return (size_t)C * N * tiles * (K * K + 1) * sizeof(float);
+}
+
+extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, int N, int C, int H, int W,
+                                                  int K, int dilation, float* grad_weight, float* grad_bias, void* ws,
+                                                  size_t ws_bytes, void* stream) {
+  int rc = dw_check(N, C, H, W, K, dilation);
+  if (rc) return rc;
+  if (C == 0) return RSDET_OK;
+  if (!grad_weight) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) {
+    if (hipMemsetAsync(grad_weight, 0, (size_t)C * K * K * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+    if (grad_bias && hipMemsetAsync(grad_bias, 0, (size_t)C * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+    return RSDET_OK;
+  }
+  if (!grad_y || !x || !ws || ws_bytes < rsdet_dwconv2d_backward_weight_ws_size(N, C, H, W, K)) return RSDET_EINVAL;
+  const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH;
+  const int nslots = N * tx * ty;
+  const dim3 grid(N * C, tx * ty);
+  float* partial = (float*)ws;
+  if (K == 3)
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<3, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, C, H, W, tx, nslots, partial);
+  else if (K == 5)
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<5, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, C, H, W, tx, nslots, partial);
+  else
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 3>), grid, dim3(DW_NT), 0, s, grad_y, x, C, H, W, tx, nslots, partial);
+  hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, partial, nslots, K * K + 1, grad_weight,
+                     grad_bias);
+  return rsdet_launch_status();
+}

@@ -1,13 +1,15 @@
 """Visual Attention Network backbones (van_b0..b3) with the reference's module names / state_dict keys
 (/root/reference/python/jdet/models/backbones/van.py:140-483): overlap patch embed (7x7 s4, then 3x3 s2) + BN,
 blocks = BN -> LKA attention (1x1, GELU, depthwise 5x5, depthwise 7x7 dilation 3, 1x1, gate) and BN -> MLP
-(1x1, depthwise 3x3, GELU, 1x1) with layer-scale, LayerNorm per stage.  Dense convs run in MIOpen via torch.
+(1x1, depthwise 3x3, GELU, 1x1) with layer-scale, LayerNorm per stage.  Dense convs run in MIOpen via torch, the
+depthwise ones in the LDS-tiled HIP stencil of csrc/dwconv.hip (ops/dwconv.py).
 ``pretrained=True`` would download ImageNet weights (no network here): weights stay random-initialised."""
 import math
 
 import torch
 import torch.nn as nn
 
+from rs_detection_amd.ops.dwconv import DepthwiseConv2d
 from rs_detection_amd.utils.registry import BACKBONES
 
 
@@ -29,7 +31,7 @@ def _init(m):
 class DWConv(nn.Module):
     def __init__(self, dim=768):
         super().__init__()
-        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+        self.dwconv = DepthwiseConv2d(dim, 3, padding=1, bias=True)  # van.py:32; HIP stencil on the GPU (ops/dwconv.py)
 
     def forward(self, x):
         return self.dwconv(x)
@@ -53,8 +55,8 @@ class Mlp(nn.Module):
 class AttentionModule(nn.Module):
     def __init__(self, dim):
         super().__init__()
-        self.conv0 = nn.Conv2d(dim, dim, 5, padding=2, groups=dim)
-        self.conv_spatial = nn.Conv2d(dim, dim, 7, stride=1, padding=9, groups=dim, dilation=3)
+        self.conv0 = DepthwiseConv2d(dim, 5, padding=2)                         # van.py:56
+        self.conv_spatial = DepthwiseConv2d(dim, 7, padding=9, dilation=3)      # van.py:57
         self.conv1 = nn.Conv2d(dim, dim, 1)
 
     def forward(self, x):

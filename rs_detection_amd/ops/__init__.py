@@ -15,3 +15,4 @@ from .nms_poly import poly_nms, multiclass_poly_nms, poly_iou_f32  # noqa: F401,
 from .roi_align_rotated import ROIAlignRotated  # noqa: F401,E402
 from .fr import feature_refine, FR, FeatureRefineModule  # noqa: F401,E402
 from .convex_sort import convex_sort  # noqa: F401,E402
+from .dwconv import DepthwiseConv2d, dwconv2d  # noqa: F401,E402

@@ -474,3 +474,45 @@ def test_resnet_bottleneck_uses_fused_path_and_matches_unfused(cuda):
     assert float((y - y2).abs().max()) <= 1e-4 * float(y2.abs().max())
     assert float((gx - x.grad).abs().max()) <= 1e-4 * float(x.grad.abs().max())
     assert float((gw - blk.bn3.weight.grad).abs().max()) <= 1e-3 * float(blk.bn3.weight.grad.abs().max())
+
+
+# ---------------------------------------------------------------- depthwise convolution of the VAN backbone (a20)
+@pytest.mark.parametrize("N,C,H,W,K,D,bias", [(2, 8, 32, 64, 3, 1, True), (1, 5, 37, 71, 5, 1, True),
+                                               (2, 16, 64, 64, 7, 3, True), (1, 3, 9, 7, 7, 3, False),
+                                               (2, 64, 100, 132, 3, 1, True), (1, 32, 256, 256, 7, 3, True)])
+def test_dwconv_matches_torch_conv2d(cuda, N, C, H, W, K, D, bias):
+    """fp32 reference of the same op: torch's conv2d in float64 on the CPU.  Forward 1e-5, gradients 1e-4 relative."""
+    from rs_detection_amd.ops.dwconv import DepthwiseConv2d
+    torch.manual_seed(K * 100 + C)
+    m = DepthwiseConv2d(C, K, padding=D * (K - 1) // 2, dilation=D, bias=bias).to(cuda)
+    x = torch.randn(N, C, H, W, device=cuda, requires_grad=True)
+    y = m(x)
+    go = torch.randn_like(y)
+    y.backward(go)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    wd = m.weight.detach().double().cpu().requires_grad_(True)
+    bd = m.bias.detach().double().cpu().requires_grad_(True) if bias else None
+    yd = torch.nn.functional.conv2d(xd, wd, bd, 1, D * (K - 1) // 2, D, C)
+    yd.backward(go.double().cpu())
+    assert float((y.detach().double().cpu() - yd).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max()))
+    for got, want in ((x.grad, xd.grad), (m.weight.grad, wd.grad)) + (((m.bias.grad, bd.grad),) if bias else ()):
+        assert float((got.double().cpu() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def test_dwconv_module_is_a_conv2d_and_falls_back_to_torch_where_not_covered(cuda):
+    from rs_detection_amd.ops.dwconv import DepthwiseConv2d, dwconv2d
+    m = DepthwiseConv2d(6, 3, padding=1)
+    assert isinstance(m, torch.nn.Conv2d) and m.groups == 6 and tuple(m.weight.shape) == (6, 1, 3, 3)
+    assert sorted(m.state_dict().keys()) == ["bias", "weight"]          # checkpoint keys of nn.Conv2d
+    x = torch.randn(1, 6, 8, 8)
+    assert torch.allclose(m(x), torch.nn.functional.conv2d(x, m.weight, m.bias, 1, 1, 1, 6))   # CPU: torch's conv
+    s2 = DepthwiseConv2d(6, 3, padding=1, stride=2).to(cuda)                                    # stride 2: not covered
+    xs = torch.randn(1, 6, 8, 8, device=cuda)
+    assert tuple(s2(xs).shape) == (1, 6, 4, 4)
+    with pytest.raises(Exception):
+        dwconv2d(xs, torch.randn(6, 1, 9, 9, device=cuda), None, 1)      # 9x9: the C ABI says RSDET_EINVAL, loudly
+    # bf16 autocast: inputs are cast to fp32 for the stencil
+    mm = DepthwiseConv2d(6, 5, padding=2).to(cuda)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = mm(xs)
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
