@@ -207,6 +207,20 @@ def next_row_kernels(device):
     row("rroi_idx_count+scan+fill+rroi_gather(backward; incl. the two layout permutes and a %d MB output)"
         % (N * C * H * H * 4 // 2 ** 20), 4 * (R * C * 49 + N * C * H * H), t)
     del feat, y, go
+    # -- depthwise convolutions of the VAN backbone (a20): stage-1 shapes of VAN-B3 on two 1024^2 tiles;
+    #    bytes = one read + one write of the tensor (forward / backward-data), two reads (backward-weight)
+    from rs_detection_amd.ops.dwconv import dwconv2d
+    for (Cd, Hd, K, D) in ((512, 256, 3, 1), (64, 256, 5, 1), (64, 256, 7, 3)):
+        xd = torch.randn(2, Cd, Hd, Hd, device=device, requires_grad=True)
+        wd = torch.randn(Cd, 1, K, K, device=device, requires_grad=True)
+        bd = torch.zeros(Cd, device=device, requires_grad=True)
+        t = event_time(lambda: dwconv2d(xd.detach(), wd.detach(), bd.detach(), D), 10, 2)
+        row("dwconv_stencil_kernel<%d,%d>(forward; 2x%dx%dx%d)" % (K, D, Cd, Hd, Hd), 8 * xd.numel(), t)
+        yd = dwconv2d(xd, wd, bd, D)
+        god = torch.randn_like(yd)
+        t = event_time(lambda: torch.autograd.grad(yd, (xd, wd, bd), god, retain_graph=True), 10, 2, graph=False)
+        row("dwconv backward-data + backward-weight<%d,%d>" % (K, D), 16 * xd.numel(), t)
+        del xd, yd, god
     # -- FeatureRefine (f4): R3Det level 0 of two tiles, 256 channels; bytes = read + write every element once
     N, C, H = 2, 256, TILE // 8
     f = torch.randn(N, C, H, H, device=device, requires_grad=True)

@@ -9,6 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
+from rs_detection_amd.ops.bn_act import scale_residual
 from rs_detection_amd.ops.dwconv import DepthwiseConv2d
 from rs_detection_amd.utils.registry import BACKBONES
 
@@ -100,8 +101,10 @@ class Block(nn.Module):
         self.layer_scale_2 = nn.Parameter(1e-2 * torch.ones(dim))
 
     def forward(self, x):
-        x = x + self.drop_path(self.layer_scale_1[:, None, None] * self.attn(self.norm1(x)))
-        return x + self.drop_path(self.layer_scale_2[:, None, None] * self.mlp(self.norm2(x)))
+        # x + drop_path(layer_scale * f) (van.py:121-122); the per-sample drop-path factor commutes with the per-channel
+        # scale, so it is applied to f and scale + residual run as one fused pass (ops/bn_act.py: scale_residual)
+        x = scale_residual(x, self.drop_path(self.attn(self.norm1(x))), self.layer_scale_1)
+        return scale_residual(x, self.drop_path(self.mlp(self.norm2(x))), self.layer_scale_2)
 
 
 class OverlapPatchEmbed(nn.Module):

@@ -66,3 +66,22 @@ def bn_act(x, bn, residual=None, relu=True):
     if residual is not None:
         out = out + residual
     return F.relu(out) if relu else out
+
+
+_UNIT = {}
+
+
+def scale_residual(x, f, scale):
+    """x + scale[:, None, None] * f  (layer scale + residual of the VAN block, van.py:121-122 of the reference) through
+    the same fused kernels: a per-channel affine with mean 0, variance 1, eps 0 and no bias, plus the residual -- one
+    pass forward, one backward (grad_f, and the deterministic two-stage sum for grad_scale) instead of two and four
+    torch kernels.  Falls back to the torch expression where the fused path does not apply."""
+    if (x.is_cuda and x.dtype == torch.float32 and f.dtype == torch.float32 and x.dim() == 4 and x.shape == f.shape
+            and x.is_contiguous() and f.is_contiguous() and scale.dtype == torch.float32
+            and not torch.is_autocast_enabled()):
+        key = (x.device, x.shape[1])
+        if key not in _UNIT:
+            _UNIT[key] = (torch.zeros(x.shape[1], device=x.device), torch.ones(x.shape[1], device=x.device))
+        mean, var = _UNIT[key]
+        return _BNAct.apply(f, x, scale, None, mean, var, 0.0, False)
+    return x + scale[:, None, None] * f

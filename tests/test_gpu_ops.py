@@ -516,3 +516,22 @@ def test_dwconv_module_is_a_conv2d_and_falls_back_to_torch_where_not_covered(cud
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = mm(xs)
     assert out.dtype == torch.float32 and torch.isfinite(out).all()
+
+
+def test_scale_residual_matches_torch(cuda):
+    """Layer scale + residual of the VAN block through the fused affine kernels: values and all three gradients."""
+    from rs_detection_amd.ops.bn_act import scale_residual
+    torch.manual_seed(0)
+    x = torch.randn(2, 24, 33, 17, device=cuda, requires_grad=True)
+    f = torch.randn(2, 24, 33, 17, device=cuda, requires_grad=True)
+    s = (1e-2 * torch.randn(24, device=cuda)).requires_grad_(True)
+    y = scale_residual(x, f, s)
+    ref = x + s[:, None, None] * f
+    assert torch.equal(y, ref)                      # same two roundings: f * s, then + x
+    go = torch.randn_like(y)
+    g = torch.autograd.grad(y, (x, f, s), go)
+    gr = torch.autograd.grad(ref, (x, f, s), go)
+    assert torch.equal(g[0], gr[0]) and torch.equal(g[1], gr[1])
+    assert float((g[2] - gr[2]).abs().max()) <= 1e-4 * float(gr[2].abs().max())
+    xc, fc, sc = x.detach().cpu(), f.detach().cpu(), s.detach().cpu()
+    assert torch.equal(scale_residual(xc, fc, sc), xc + sc[:, None, None] * fc)   # CPU tensors: the torch expression
