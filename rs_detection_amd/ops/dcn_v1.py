@@ -167,21 +167,25 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
         go = grad_output.contiguous().view(B, O, -1)  # (B, O, Ho*Wo)
         hw = go.shape[2]
         grad_input = grad_weight = None
+        # one (O, B*hw) copy of the output gradient (17 MB at level 0) turns both backward products into single
+        # launches over the whole batch: measured 734 -> 630 us (data) and 771 -> 585 us (weight) at level 0
+        go2 = go.transpose(0, 1).reshape(O, B * hw)
         if ctx.needs_input_grad[0]:
             w_ok = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C)  # K index = tap*C + c
-            gcolT = torch.empty((B * hw, kh * kw * C), dtype=go.dtype, device=go.device)
-            for b in range(B):
-                torch.mm(go[b].t(), w_ok, out=gcolT[b * hw:(b + 1) * hw])
+            gcolT = torch.mm(go2.t(), w_ok)  # (B*hw, kh*kw*C): channels-last column gradient
             if dg == 1:  # gather form: no floating-point atomics (3.4x faster at pyramid level 0)
                 gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation)
             else:
                 gi = deformable_col2im_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation, dg)
             grad_input = gi.permute(0, 3, 1, 2).contiguous()
         if ctx.needs_input_grad[2]:
-            gw = torch.zeros((O, C * kh * kw), dtype=go.dtype, device=go.device)
-            for b in range(B):
-                gw.addmm_(go[b], col[:, b * hw:(b + 1) * hw].t())
-            grad_weight = gw.view_as(weight)
+            # gw (O, C*kh*kw) = go2 @ col^T has only 36 output tiles of 128 x 128 for K = B*hw up to 65 536: split K into
+            # J slices as a strided-batched product (views, no copies) and add the J partial results
+            n = B * hw
+            J = 16 if n % 16 == 0 and n >= 4096 else 1
+            k = n // J
+            parts = torch.bmm(go2.view(O, J, k).permute(1, 0, 2), col.view(C * kh * kw, J, k).permute(1, 2, 0))
+            grad_weight = parts.sum(0).view_as(weight) if J > 1 else parts[0].view_as(weight)
         return grad_input, None, grad_weight, None, None, None, None
 
 
