@@ -292,6 +292,16 @@ int rsdet_bn_act_backward_f32(const float* grad_y, const float* y, const float* 
                               const float* running_var, const float* weight, float eps, int N, int C, int HW,
                               int relu, float* grad_x, float* grad_residual, float* grad_weight, float* grad_bias,
                               void* ws, size_t ws_bytes, void* stream);
+/* The same two passes for bf16 activations (the autocast step of BASELINE configs 2 and 4; same reference lines):
+ * x / residual / y / grad_* tensors are bf16 (16-bit storage), the arithmetic, the parameters and the parameter
+ * gradients fp32; stores round to nearest even. */
+int rsdet_bn_act_forward_bf16(const uint16_t* x, const uint16_t* residual, const float* running_mean,
+                              const float* running_var, const float* weight, const float* bias, float eps, int N,
+                              int C, int HW, int relu, uint16_t* y, void* stream);
+int rsdet_bn_act_backward_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* x,
+                               const float* running_mean, const float* running_var, const float* weight, float eps,
+                               int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
+                               float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- 8(f) rank 1  polygon IoU + tile-merge polygon NMS (evaluation side) ------------------------------------
  * Replaces ops/nms_poly.py:247-252 (iou_poly: shapely intersection area, max(union, 0.01) in the denominator),

@@ -1,4 +1,6 @@
-// bn_act.hip -- eval-mode BatchNorm + residual add + ReLU in one pass (forward and backward), NCHW fp32.
+// bn_act.hip -- eval-mode BatchNorm + residual add + ReLU in one pass (forward and backward), NCHW; activations
+// fp32 or bf16 (the autocast step: loads widen to fp32, the arithmetic and the parameter sums are fp32, stores round
+// to nearest even), parameters always fp32.
 //
 // Replaces, on the backbone part of the path (a21): the three Jittor ops per Bottleneck tail
 //   /root/reference/python/jdet/models/backbones/resnet.py:101-126 (bn -> (+ identity) -> relu) with
@@ -17,13 +19,40 @@ namespace rsdet {
 
 constexpr int BN_NT = 256;
 
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(BN_NT) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+typedef uint16_t bf16_t;  // storage only
+
+// four consecutive activations <-> float4
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even; NaN stays NaN
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  uint2 r;
+  r.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+  r.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+__device__ __forceinline__ float ld1(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = f2bf(v); }
+
+template <bool RELU, bool RES, typename T>
+__global__ __launch_bounds__(BN_NT) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ var,
                                                           const float* __restrict__ weight,
                                                           const float* __restrict__ bias, float eps, int C,
-                                                          int HW, float* __restrict__ y) {
+                                                          int HW, T* __restrict__ y) {
   const int plane = blockIdx.y;  // n * C + c
   const int c = plane % C;
   const float m = mean[c], is = 1.0f / sqrtf(var[c] + eps);
@@ -32,14 +61,14 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_kernel(const float* __restri
   const int i = (blockIdx.x * BN_NT + threadIdx.x) * 4;
   if (i >= HW) return;
   if (((HW & 3) == 0)) {  // planes stay 16-byte aligned
-    const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+    const float4 v = ld4(x + base + i);
     float4 o;
     o.x = ((v.x - m) * is) * g + b;
     o.y = ((v.y - m) * is) * g + b;
     o.z = ((v.z - m) * is) * g + b;
     o.w = ((v.w - m) * is) * g + b;
     if (RES) {
-      const float4 r = *reinterpret_cast<const float4*>(res + base + i);
+      const float4 r = ld4(res + base + i);
       o.x += r.x;
       o.y += r.y;
       o.z += r.z;
@@ -51,13 +80,13 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_kernel(const float* __restri
       o.z = fmaxf(o.z, 0.f);
       o.w = fmaxf(o.w, 0.f);
     }
-    *reinterpret_cast<float4*>(y + base + i) = o;
+    st4(y + base + i, o);
   } else {
     for (int k = i; k < min(i + 4, HW); ++k) {
-      float o = ((x[base + k] - m) * is) * g + b;
-      if (RES) o += res[base + k];
+      float o = ((ld1(x + base + k) - m) * is) * g + b;
+      if (RES) o += ld1(res + base + k);
       if (RELU) o = fmaxf(o, 0.f);
-      y[base + k] = o;
+      st1(y + base + k, o);
     }
   }
 }
@@ -65,11 +94,11 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_kernel(const float* __restri
 // grid (S, C): block (s, c) walks slice s of channel c's N*HW elements (float4 granules), writes
 // g = dy * [y > 0] (the residual's gradient) and/or dx = g * invstd * weight, and leaves its partial
 // sums of g and g * xhat in `partial` for the deterministic second stage.
-template <bool RELU>
+template <bool RELU, typename T>
 __global__ __launch_bounds__(BN_NT) void bn_act_bwd_kernel(
-    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+    const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ weight, float eps,
-    int N, int C, int HW, float* __restrict__ dx, float* __restrict__ dres, float* __restrict__ partial) {
+    int N, int C, int HW, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial) {
   const int c = blockIdx.y, S = gridDim.x, s = blockIdx.x;
   const float m = mean[c], is = 1.0f / sqrtf(var[c] + eps);
   const float scale = is * (weight ? weight[c] : 1.0f);
@@ -83,31 +112,31 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_kernel(
     const int n = (int)(q / q_per_plane), i = (int)(q - (long long)n * q_per_plane) * 4;
     const long long base = ((long long)n * C + c) * HW + i;
     if (vec) {
-      float4 g = *reinterpret_cast<const float4*>(dy + base);
+      float4 g = ld4(dy + base);
       if (RELU) {
-        const float4 o = *reinterpret_cast<const float4*>(y + base);
+        const float4 o = ld4(y + base);
         g.x = o.x > 0.f ? g.x : 0.f;
         g.y = o.y > 0.f ? g.y : 0.f;
         g.z = o.z > 0.f ? g.z : 0.f;
         g.w = o.w > 0.f ? g.w : 0.f;
       }
       if (partial) {
-        const float4 v = *reinterpret_cast<const float4*>(x + base);
+        const float4 v = ld4(x + base);
         sum_g += (g.x + g.y) + (g.z + g.w);
         sum_gx += (g.x * ((v.x - m) * is) + g.y * ((v.y - m) * is)) + (g.z * ((v.z - m) * is) + g.w * ((v.w - m) * is));
       }
-      if (dres) *reinterpret_cast<float4*>(dres + base) = g;
-      if (dx) *reinterpret_cast<float4*>(dx + base) = make_float4(g.x * scale, g.y * scale, g.z * scale, g.w * scale);
+      if (dres) st4(dres + base, g);
+      if (dx) st4(dx + base, make_float4(g.x * scale, g.y * scale, g.z * scale, g.w * scale));
     } else {
       for (int k = 0; k < 4 && i + k < HW; ++k) {
-        float g = dy[base + k];
-        if (RELU) g = y[base + k] > 0.f ? g : 0.f;
+        float g = ld1(dy + base + k);
+        if (RELU) g = ld1(y + base + k) > 0.f ? g : 0.f;
         if (partial) {
           sum_g += g;
-          sum_gx += g * ((x[base + k] - m) * is);
+          sum_gx += g * ((ld1(x + base + k) - m) * is);
         }
-        if (dres) dres[base + k] = g;
-        if (dx) dx[base + k] = g * scale;
+        if (dres) st1(dres + base + k, g);
+        if (dx) st1(dx + base + k, g * scale);
       }
     }
   }
@@ -164,9 +193,10 @@ extern "C" size_t rsdet_bn_act_backward_ws_size(int N, int C, int HW) {
   return (size_t)C * bn_slices(N, C, HW) * 2 * sizeof(float);
 }
 
-extern "C" int rsdet_bn_act_forward_f32(const float* x, const float* residual, const float* running_mean,
-                                        const float* running_var, const float* weight, const float* bias, float eps,
-                                        int N, int C, int HW, int relu, float* y, void* stream) {
+template <typename T>
+static int bn_act_forward(const T* x, const T* residual, const float* running_mean, const float* running_var,
+                          const float* weight, const float* bias, float eps, int N, int C, int HW, int relu, T* y,
+                          void* stream) {
   if (N < 0 || C <= 0 || HW < 0) return RSDET_EINVAL;
   if (N == 0 || HW == 0) return RSDET_OK;
   if (!x || !running_mean || !running_var || !y) return RSDET_EINVAL;
@@ -174,8 +204,8 @@ extern "C" int rsdet_bn_act_forward_f32(const float* x, const float* residual, c
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((HW + BN_NT * 4 - 1) / (BN_NT * 4), N * C);
   if (grid.y > 65535u * 1024u) return RSDET_EINVAL;
-#define RSDET_BN_FWD(R, A)                                                                                     \
-  hipLaunchKernelGGL((bn_act_fwd_kernel<R, A>), grid, dim3(BN_NT), 0, s, x, residual, running_mean, running_var, \
+#define RSDET_BN_FWD(R, A)                                                                                          \
+  hipLaunchKernelGGL((bn_act_fwd_kernel<R, A, T>), grid, dim3(BN_NT), 0, s, x, residual, running_mean, running_var, \
                      weight, bias, eps, C, HW, y)
   if (relu) {
     if (residual) RSDET_BN_FWD(true, true); else RSDET_BN_FWD(true, false);
@@ -186,10 +216,11 @@ extern "C" int rsdet_bn_act_forward_f32(const float* x, const float* residual, c
   return rsdet_launch_status();
 }
 
-extern "C" int rsdet_bn_act_backward_f32(const float* grad_y, const float* y, const float* x, const float* running_mean,
-                                         const float* running_var, const float* weight, float eps, int N, int C,
-                                         int HW, int relu, float* grad_x, float* grad_residual, float* grad_weight,
-                                         float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
+template <typename T>
+static int bn_act_backward(const T* grad_y, const T* y, const T* x, const float* running_mean,
+                           const float* running_var, const float* weight, float eps, int N, int C, int HW, int relu,
+                           T* grad_x, T* grad_residual, float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes,
+                           void* stream) {
   if (N < 0 || C <= 0 || HW < 0) return RSDET_EINVAL;
   if (N == 0 || HW == 0) return RSDET_OK;
   if (!grad_y || !running_mean || !running_var || (relu && !y)) return RSDET_EINVAL;
@@ -199,13 +230,43 @@ extern "C" int rsdet_bn_act_backward_f32(const float* grad_y, const float* y, co
   const int S = bn_slices(N, C, HW);
   float* partial = need_param ? (float*)ws : nullptr;
   if (relu)
-    hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(S, C), dim3(BN_NT), 0, s, grad_y, y, x, running_mean, running_var,
-                       weight, eps, N, C, HW, grad_x, grad_residual, partial);
+    hipLaunchKernelGGL((bn_act_bwd_kernel<true, T>), dim3(S, C), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
+                       running_var, weight, eps, N, C, HW, grad_x, grad_residual, partial);
   else
-    hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(S, C), dim3(BN_NT), 0, s, grad_y, y, x, running_mean, running_var,
-                       weight, eps, N, C, HW, grad_x, grad_residual, partial);
+    hipLaunchKernelGGL((bn_act_bwd_kernel<false, T>), dim3(S, C), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
+                       running_var, weight, eps, N, C, HW, grad_x, grad_residual, partial);
   if (need_param)
     hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, S, grad_weight,
                        grad_bias);
   return rsdet_launch_status();
+}
+
+extern "C" int rsdet_bn_act_forward_f32(const float* x, const float* residual, const float* running_mean,
+                                        const float* running_var, const float* weight, const float* bias, float eps,
+                                        int N, int C, int HW, int relu, float* y, void* stream) {
+  return bn_act_forward<float>(x, residual, running_mean, running_var, weight, bias, eps, N, C, HW, relu, y, stream);
+}
+
+extern "C" int rsdet_bn_act_backward_f32(const float* grad_y, const float* y, const float* x, const float* running_mean,
+                                         const float* running_var, const float* weight, float eps, int N, int C,
+                                         int HW, int relu, float* grad_x, float* grad_residual, float* grad_weight,
+                                         float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
+  return bn_act_backward<float>(grad_y, y, x, running_mean, running_var, weight, eps, N, C, HW, relu, grad_x,
+                                grad_residual, grad_weight, grad_bias, ws, ws_bytes, stream);
+}
+
+// bf16 activations (uint16 storage), fp32 parameters / parameter gradients: the autocast step
+extern "C" int rsdet_bn_act_forward_bf16(const uint16_t* x, const uint16_t* residual, const float* running_mean,
+                                         const float* running_var, const float* weight, const float* bias, float eps,
+                                         int N, int C, int HW, int relu, uint16_t* y, void* stream) {
+  return bn_act_forward<bf16_t>(x, residual, running_mean, running_var, weight, bias, eps, N, C, HW, relu, y, stream);
+}
+
+extern "C" int rsdet_bn_act_backward_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* x,
+                                          const float* running_mean, const float* running_var, const float* weight,
+                                          float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
+                                          uint16_t* grad_residual, float* grad_weight, float* grad_bias, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  return bn_act_backward<bf16_t>(grad_y, y, x, running_mean, running_var, weight, eps, N, C, HW, relu, grad_x,
+                                 grad_residual, grad_weight, grad_bias, ws, ws_bytes, stream);
 }

@@ -3,8 +3,8 @@
 The backbone keeps every BatchNorm in eval mode (resnet.py:177-184, norm_eval), so ``bn -> (+ identity) -> relu``
 (resnet.py:101-126) is a per-channel affine followed by two elementwise ops: three kernels forward and three
 backward on the torch route, ~8 ms of a 68 ms S2ANet step.  ``bn_act(x, bn, residual, relu)`` fuses them when it
-can (CUDA, fp32, contiguous NCHW, ``bn`` in eval mode) and is the plain torch sequence otherwise (training-mode
-BatchNorm, bf16 autocast, CPU tensors of the RetinaNet plumbing case) -- both are the product path; there is no
+can (CUDA, contiguous NCHW, fp32 activations or the bf16 ones of an autocast step, ``bn`` in eval mode) and is the
+plain torch sequence otherwise (training-mode BatchNorm, CPU tensors of the RetinaNet plumbing case) -- both are the product path; there is no
 oracle or CPU restatement behind it."""
 import torch
 import torch.nn.functional as F
@@ -18,10 +18,10 @@ class _BNAct(torch.autograd.Function):
         lib = _lib.load()
         N, C, H, W = x.shape
         y = torch.empty_like(x)
-        rc = lib.rsdet_bn_act_forward_f32(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(mean), _lib.ptr(var),
-                                          _lib.ptr(weight), _lib.ptr(bias), float(eps), N, C, H * W, int(relu),
-                                          _lib.ptr(y), _lib.stream_ptr())
-        _lib.check(rc, "rsdet_bn_act_forward_f32")
+        name = "rsdet_bn_act_forward_" + ("bf16" if x.dtype == torch.bfloat16 else "f32")
+        rc = getattr(lib, name)(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(weight),
+                                _lib.ptr(bias), float(eps), N, C, H * W, int(relu), _lib.ptr(y), _lib.stream_ptr())
+        _lib.check(rc, name)
         ctx.save_for_backward(x, y, weight, mean, var)
         ctx.eps, ctx.relu, ctx.has_res = float(eps), bool(relu), residual is not None
         ctx.has_bias = bias is not None
@@ -32,7 +32,7 @@ class _BNAct(torch.autograd.Function):
         lib = _lib.load()
         x, y, weight, mean, var = ctx.saved_tensors
         N, C, H, W = x.shape
-        gy = gy.contiguous()
+        gy = gy.contiguous().to(x.dtype)
         need_x, need_res = ctx.needs_input_grad[0], ctx.has_res and ctx.needs_input_grad[1]
         need_w = weight is not None and ctx.needs_input_grad[2]
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
@@ -43,18 +43,23 @@ class _BNAct(torch.autograd.Function):
         gb = torch.empty_like(mean) if need_b else None
         ws_bytes = lib.rsdet_bn_act_backward_ws_size(N, C, H * W) if (need_w or need_b) else 0
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes else None
-        rc = lib.rsdet_bn_act_backward_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(var),
-                                           _lib.ptr(weight), ctx.eps, N, C, H * W, int(ctx.relu), _lib.ptr(gx),
-                                           _lib.ptr(gres) if (need_res and ctx.relu) else None, _lib.ptr(gw),
-                                           _lib.ptr(gb), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
-        _lib.check(rc, "rsdet_bn_act_backward_f32")
+        name = "rsdet_bn_act_backward_" + ("bf16" if x.dtype == torch.bfloat16 else "f32")
+        rc = getattr(lib, name)(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(var),
+                                _lib.ptr(weight), ctx.eps, N, C, H * W, int(ctx.relu), _lib.ptr(gx),
+                                _lib.ptr(gres) if (need_res and ctx.relu) else None, _lib.ptr(gw),
+                                _lib.ptr(gb), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+        _lib.check(rc, name)
         return gx, gres, gw, gb, None, None, None, None
 
 
 def _fusable(x, bn, residual):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not bn.training
-            and bn.running_mean is not None and not torch.is_autocast_enabled()
-            and (residual is None or (residual.dtype == torch.float32 and residual.shape == x.shape
+    # fp32 activations outside autocast, or bf16 activations (what the convolutions emit under bf16 autocast); the
+    # BatchNorm parameters and running statistics are fp32 in both cases
+    ok_dtype = (x.dtype == torch.float32 and not torch.is_autocast_enabled()) or x.dtype == torch.bfloat16
+    return (x.is_cuda and ok_dtype and x.dim() == 4 and x.is_contiguous() and not bn.training
+            and bn.running_mean is not None and bn.running_mean.dtype == torch.float32
+            and (bn.weight is None or bn.weight.dtype == torch.float32)
+            and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
                                       and residual.is_contiguous())))
 
 

@@ -535,3 +535,44 @@ def test_scale_residual_matches_torch(cuda):
     assert float((g[2] - gr[2]).abs().max()) <= 1e-4 * float(gr[2].abs().max())
     xc, fc, sc = x.detach().cpu(), f.detach().cpu(), s.detach().cpu()
     assert torch.equal(scale_residual(xc, fc, sc), xc + sc[:, None, None] * fc)   # CPU tensors: the torch expression
+
+
+@pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, True)])
+def test_bn_act_bf16_matches_fp32_math_on_the_same_inputs(cuda, relu, res):
+    """bf16 activations (the autocast step): the fused pass computes in fp32 and rounds once, so it must sit within
+    one bf16 ulp of the fp32 formula evaluated on the same bf16 inputs; parameter gradients are fp32 sums."""
+    from rs_detection_amd.ops.bn_act import bn_act, _fusable
+    torch.manual_seed(3)
+    N, C, H, W = 2, 24, 20, 36
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_(1, 0.2)
+        bn.bias.normal_(0, 0.2)
+    x = torch.randn(N, C, H, W, device=cuda).bfloat16().requires_grad_(True)
+    r = torch.randn(N, C, H, W, device=cuda).bfloat16().requires_grad_(True) if res else None
+    assert _fusable(x, bn, r)
+    y = bn_act(x, bn, r, relu)
+    assert y.dtype == torch.bfloat16
+    xf = x.detach().float().requires_grad_(True)
+    rf = r.detach().float().requires_grad_(True) if res else None
+    w, b = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    yf = ((xf - bn.running_mean[None, :, None, None]) / torch.sqrt(bn.running_var + bn.eps)[None, :, None, None]) \
+        * w[None, :, None, None] + b[None, :, None, None]
+    if res:
+        yf = yf + rf
+    if relu:
+        yf = torch.relu(yf)
+    assert float((y.float() - yf).abs().max()) <= 2 ** -7 * max(1.0, float(yf.abs().max()))
+    go = torch.randn_like(yf).bfloat16()
+    y.backward(go)
+    # reference gradient: the ReLU mask from the bf16 output the kernel really produced
+    yf2 = yf if not relu else yf * (y.float() > 0)
+    yf2.backward(go.float())
+    assert float((x.grad.float() - xf.grad).abs().max()) <= 2 ** -7 * max(1.0, float(xf.grad.abs().max()))
+    if res:
+        assert float((r.grad.float() - rf.grad).abs().max()) <= 2 ** -7 * max(1.0, float(rf.grad.abs().max()))
+    assert bn.weight.grad.dtype == torch.float32
+    assert float((bn.weight.grad - w.grad).abs().max()) <= 2e-2 * max(1.0, float(w.grad.abs().max()))
+    assert float((bn.bias.grad - b.grad).abs().max()) <= 2e-2 * max(1.0, float(b.grad.abs().max()))
