@@ -121,9 +121,11 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_kernel(
         g.w = o.w > 0.f ? g.w : 0.f;
       }
       if (partial) {
-        const float4 v = ld4(x + base);
         sum_g += (g.x + g.y) + (g.z + g.w);
-        sum_gx += (g.x * ((v.x - m) * is) + g.y * ((v.y - m) * is)) + (g.z * ((v.z - m) * is) + g.w * ((v.w - m) * is));
+        if (x) {  // x == nullptr: only the bias gradient is wanted (bias + ReLU epilogue of a convolution)
+          const float4 v = ld4(x + base);
+          sum_gx += (g.x * ((v.x - m) * is) + g.y * ((v.y - m) * is)) + (g.z * ((v.z - m) * is) + g.w * ((v.w - m) * is));
+        }
       }
       if (dres) st4(dres + base, g);
       if (dx) st4(dx + base, make_float4(g.x * scale, g.y * scale, g.z * scale, g.w * scale));
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_kernel(
         if (RELU) g = ld1(y + base + k) > 0.f ? g : 0.f;
         if (partial) {
           sum_g += g;
-          sum_gx += g * ((ld1(x + base + k) - m) * is);
+          if (x) sum_gx += g * ((ld1(x + base + k) - m) * is);
         }
         if (dres) st1(dres + base + k, g);
         if (dx) st1(dx + base + k, g * scale);
@@ -225,7 +227,9 @@ static int bn_act_backward(const T* grad_y, const T* y, const T* x, const float*
   if (N == 0 || HW == 0) return RSDET_OK;
   if (!grad_y || !running_mean || !running_var || (relu && !y)) return RSDET_EINVAL;
   const bool need_param = grad_weight || grad_bias;
-  if (need_param && (!x || !ws || ws_bytes < rsdet_bn_act_backward_ws_size(N, C, HW))) return RSDET_EINVAL;
+  if (need_param && ((grad_weight && !x) || !ws || ws_bytes < rsdet_bn_act_backward_ws_size(N, C, HW)))
+    return RSDET_EINVAL;
+  if (!grad_weight) x = nullptr;  // the kernel then skips the x stream
   hipStream_t s = (hipStream_t)stream;
   const int S = bn_slices(N, C, HW);
   float* partial = need_param ? (float*)ws : nullptr;

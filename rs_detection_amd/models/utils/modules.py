@@ -2,12 +2,18 @@
 
 conv -> norm -> act bundle; ``bias='auto'`` means "bias iff no norm"; default
 activation ReLU; kaiming init (callers such as S2ANetHead overwrite it)."""
+import os
 import warnings
 
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from rs_detection_amd.ops.bn_act import bias_act
 from rs_detection_amd.utils.registry import BRICKS, build_from_cfg
 from .weight_init import kaiming_init, constant_init
+
+_FUSE_BIAS_RELU = os.environ.get("RSDET_NO_FUSED_BIAS_RELU", "0") != "1"  # A/B switch
 
 BRICKS.register_module(name="Conv2d", module=nn.Conv2d)
 BRICKS.register_module(name="ReLU", module=nn.ReLU)
@@ -82,7 +88,22 @@ class ConvModule(nn.Module):
         if self.with_norm:
             constant_init(getattr(self, self.norm), 1, bias=0)
 
+    def _fused_bias_relu(self, x, activate):
+        """conv (bias) -> ReLU, the S2ANet head towers: run the convolution without its bias and apply bias + ReLU as one
+        fused pass (ops/bn_act.py: bias_act).  Only for the plain case; anything else takes the generic loop."""
+        conv = self.conv
+        return (_FUSE_BIAS_RELU and activate and self.with_activation and not self.with_norm
+                and self.order.index('conv') == 0
+                and type(conv) is nn.Conv2d and conv.bias is not None and conv.padding_mode == 'zeros'
+                and isinstance(getattr(self, 'activate', None), nn.ReLU) and x.is_cuda
+                and x.dtype == torch.float32 and not torch.is_autocast_enabled())  # bf16 autocast: measured slower
+                                                                                   # (40.5 vs 32.9 ms/step), torch path kept
+
     def forward(self, x, activate=True, norm=True):
+        if self._fused_bias_relu(x, activate):
+            conv = self.conv
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            return bias_act(y, conv.bias, relu=True)
         for layer in self.order:
             if layer == 'conv':
                 x = self.conv(x)

@@ -22,7 +22,9 @@ class _BNAct(torch.autograd.Function):
         rc = getattr(lib, name)(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(weight),
                                 _lib.ptr(bias), float(eps), N, C, H * W, int(relu), _lib.ptr(y), _lib.stream_ptr())
         _lib.check(rc, name)
-        ctx.save_for_backward(x, y, weight, mean, var)
+        # x is only needed for the weight gradient (sum of g * xhat)
+        ctx.save_for_backward(x if weight is not None else None, y, weight, mean, var)
+        ctx.shape = tuple(x.shape)
         ctx.eps, ctx.relu, ctx.has_res = float(eps), bool(relu), residual is not None
         ctx.has_bias = bias is not None
         return y
@@ -31,19 +33,19 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, gy):
         lib = _lib.load()
         x, y, weight, mean, var = ctx.saved_tensors
-        N, C, H, W = x.shape
-        gy = gy.contiguous().to(x.dtype)
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous().to(y.dtype)
         need_x, need_res = ctx.needs_input_grad[0], ctx.has_res and ctx.needs_input_grad[1]
         need_w = weight is not None and ctx.needs_input_grad[2]
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
-        gx = torch.empty_like(x) if need_x else None
+        gx = torch.empty_like(y) if need_x else None
         # without a ReLU the residual's gradient IS grad_y: no copy
-        gres = (torch.empty_like(x) if ctx.relu else gy) if need_res else None
+        gres = (torch.empty_like(y) if ctx.relu else gy) if need_res else None
         gw = torch.empty_like(weight) if need_w else None
         gb = torch.empty_like(mean) if need_b else None
         ws_bytes = lib.rsdet_bn_act_backward_ws_size(N, C, H * W) if (need_w or need_b) else 0
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes else None
-        name = "rsdet_bn_act_backward_" + ("bf16" if x.dtype == torch.bfloat16 else "f32")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=y.device) if ws_bytes else None
+        name = "rsdet_bn_act_backward_" + ("bf16" if y.dtype == torch.bfloat16 else "f32")
         rc = getattr(lib, name)(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(var),
                                 _lib.ptr(weight), ctx.eps, N, C, H * W, int(ctx.relu), _lib.ptr(gx),
                                 _lib.ptr(gres) if (need_res and ctx.relu) else None, _lib.ptr(gw),
@@ -90,3 +92,18 @@ def scale_residual(x, f, scale):
         mean, var = _UNIT[key]
         return _BNAct.apply(f, x, scale, None, mean, var, 0.0, False)
     return x + scale[:, None, None] * f
+
+
+def bias_act(x, bias, relu=True):
+    """relu(x + bias[:, None, None]): the epilogue of a convolution launched without its bias (ConvModule of the
+    detection heads).  One pass forward, one backward that also yields the bias gradient (deterministic two-stage
+    sum) -- instead of MIOpen's bias kernel + clamp forward and threshold + reduction backward."""
+    if (x.is_cuda and x.dim() == 4 and x.is_contiguous() and bias is not None and bias.dtype == torch.float32
+            and ((x.dtype == torch.float32 and not torch.is_autocast_enabled()) or x.dtype == torch.bfloat16)):
+        key = (x.device, x.shape[1])
+        if key not in _UNIT:
+            _UNIT[key] = (torch.zeros(x.shape[1], device=x.device), torch.ones(x.shape[1], device=x.device))
+        mean, var = _UNIT[key]
+        return _BNAct.apply(x, None, None, bias, mean, var, 0.0, relu)
+    out = x + bias.to(x.dtype)[None, :, None, None]
+    return F.relu(out) if relu else out

@@ -576,3 +576,27 @@ def test_bn_act_bf16_matches_fp32_math_on_the_same_inputs(cuda, relu, res):
     assert bn.weight.grad.dtype == torch.float32
     assert float((bn.weight.grad - w.grad).abs().max()) <= 2e-2 * max(1.0, float(w.grad.abs().max()))
     assert float((bn.bias.grad - b.grad).abs().max()) <= 2e-2 * max(1.0, float(b.grad.abs().max()))
+
+
+def test_conv_module_fused_bias_relu_matches_unfused(cuda):
+    """ConvModule(conv + bias -> ReLU) through bias_act == the generic conv / ReLU sequence: values and all gradients."""
+    from rs_detection_amd.models.utils.modules import ConvModule
+    torch.manual_seed(1)
+    m = ConvModule(16, 24, 3, stride=1, padding=1).to(cuda)
+    with torch.no_grad():
+        m.conv.bias.normal_(0, 0.5)
+    x = torch.randn(2, 16, 20, 28, device=cuda, requires_grad=True)
+    assert m._fused_bias_relu(x, True)
+    y = m(x)
+    ref = torch.relu(torch.nn.functional.conv2d(x, m.conv.weight, m.conv.bias, 1, 1))
+    assert float((y - ref).abs().max()) <= 1e-5
+    go = torch.randn_like(y)
+    g = torch.autograd.grad(y, (x, m.conv.weight, m.conv.bias), go)
+    gr = torch.autograd.grad(ref, (x, m.conv.weight, m.conv.bias), go)
+    for a, b in zip(g, gr):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    # no activation requested / CPU tensors: the generic loop
+    assert not m._fused_bias_relu(x, False) and not m._fused_bias_relu(x.detach().cpu(), True)
+    mc = ConvModule(16, 24, 3, padding=1)
+    xc = torch.randn(1, 16, 8, 8)
+    assert torch.allclose(mc(xc), torch.relu(torch.nn.functional.conv2d(xc, mc.conv.weight, mc.conv.bias, 1, 1)))
