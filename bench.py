@@ -43,6 +43,8 @@ from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db  # noqa: E40
 MIOPEN_DB_DIR = use_packaged_miopen_db()
 
 torch.backends.cudnn.benchmark = os.environ.get("RSDET_CUDNN_BENCHMARK", "0") == "1"
+if os.environ.get("RSDET_BLAS_LIB"):  # A/B switch: "hipblas" (rocBLAS) or "hipblaslt"
+    torch.backends.cuda.preferred_blas_library(os.environ["RSDET_BLAS_LIB"])
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 TILE = 1024

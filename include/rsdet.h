@@ -188,6 +188,16 @@ size_t rsdet_deform_col2im_gather_ws_size(const rsdet_dcn_geom* g);
 int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset, const rsdet_dcn_geom* g,
                                         float* grad_im, void* ws, size_t ws_bytes, void* stream);
 
+/* bf16 column matrices for the autocast step (BASELINE configs 2 / 4): the products that consume / produce them run
+ * on bf16 MFMA through rocBLAS, the images, offsets, interpolation weights, sums and grad_im stay fp32.
+ * im2col_bf16col: same as rsdet_deform_im2col_f32 (dcn_v1.py:309-339) with col stored as bf16 (round to nearest
+ * even); only the AlignConv geometry (3x3 taps, channels per deformable group a multiple of 16), else RSDET_EINVAL.
+ * col2im_gather_nhwc_bf16col: same as rsdet_deform_col2im_gather_nhwc_f32 with colT read as bf16. */
+int rsdet_deform_im2col_bf16col_f32(const float* im, const float* offset, const rsdet_dcn_geom* g, uint16_t* col,
+                                    void* stream);
+int rsdet_deform_col2im_gather_nhwc_bf16col_f32(const uint16_t* colT, const float* offset, const rsdet_dcn_geom* g,
+                                                float* grad_im, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a18  ROIAlignRotated_v1 -----------------------------------------------------------------
  * Replaces _RotatedROIAlign_v1.execute / .grad: ops/roi_align_rotated_v1.py:300-351
  * (kernels :71-147, :193-298).  feat (N,C,H,W); rois (R,6) = (batch, cx, cy, w, h, theta);

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
+#include "rsdet_bf16.h"
 
 namespace rsdet {
 
@@ -124,10 +125,10 @@ __device__ __forceinline__ PairFoot pair_foot(float h, float w, int H, int W) {
   return f;
 }
 
-template <int TAPS>
+template <int TAPS, typename TCOL>
 __global__ __launch_bounds__(DCN_NT) void deform_im2col_taps_kernel(const float* __restrict__ im,
                                                                     const float* __restrict__ offset, Geom g,
-                                                                    int c_chunk, float* __restrict__ col) {
+                                                                    int c_chunk, TCOL* __restrict__ col) {
   const long long plane = (long long)g.Ho * g.Wo;
   const long long npos = (long long)g.B * plane;
   const long long pos = (long long)blockIdx.x * DCN_NT + threadIdx.x;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(DCN_NT) void deform_im2col_taps_kernel(const float*
   const long long HW = (long long)g.H * g.W;
   for (int c = c0; c < c1; ++c) {
     const float* imp = im + ((long long)b * g.C + c) * HW;
-    float* cp = col + (long long)c * TAPS * npos + pos;
+    TCOL* cp = col + (long long)c * TAPS * npos + pos;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load at dword alignment
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(DCN_NT) void deform_im2col_taps_kernel(const float*
       const int l = f[tap].sel & 3, r = f[tap].sel >> 2;
       const float v1 = l == 1 ? a.x : (l == 2 ? a.y : 0.f), v2 = r == 2 ? a.y : (r == 1 ? a.x : 0.f);
       const float v3 = l == 1 ? d.x : (l == 2 ? d.y : 0.f), v4 = r == 2 ? d.y : (r == 1 ? d.x : 0.f);
-      cp[(long long)tap * npos] = f[tap].w1 * v1 + f[tap].w2 * v2 + f[tap].w3 * v3 + f[tap].w4 * v4;
+      st1(cp + (long long)tap * npos, f[tap].w1 * v1 + f[tap].w2 * v2 + f[tap].w3 * v3 + f[tap].w4 * v4);
     }
   }
 }
@@ -532,8 +533,8 @@ __global__ __launch_bounds__(256) void dcn_idx_fill_kernel(const float* __restri
 // (the corners of one sampling point) are processed close together, and the workgroup ids are renumbered so that an
 // XCD owns a contiguous run of tiles (rsdet_xcd_contiguous): round-robin placement would put the four on four
 // different L2s and the row would be fetched again by each
-template <bool VEC4>
-__global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const float* __restrict__ colT,
+template <bool VEC4, typename TROW>
+__global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const TROW* __restrict__ colT,
                                                                     const int* __restrict__ start,
                                                                     const int* __restrict__ ent_row,
                                                                     const float* __restrict__ ent_w, Geom g,
@@ -561,10 +562,10 @@ __global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const float*
       for (; e + 4 <= e1; e += 4) {  // four independent row reads in flight
         const int r0 = ent_row[e], r1 = ent_row[e + 1], r2 = ent_row[e + 2], r3 = ent_row[e + 3];
         const float w0 = ent_w[e], w1 = ent_w[e + 1], w2 = ent_w[e + 2], w3 = ent_w[e + 3];
-        const float4 v0 = *reinterpret_cast<const float4*>(colT + (long long)r0 * rowlen + c);
-        const float4 v1 = *reinterpret_cast<const float4*>(colT + (long long)r1 * rowlen + c);
-        const float4 v2 = *reinterpret_cast<const float4*>(colT + (long long)r2 * rowlen + c);
-        const float4 v3 = *reinterpret_cast<const float4*>(colT + (long long)r3 * rowlen + c);
+        const float4 v0 = ld4(colT + (long long)r0 * rowlen + c);
+        const float4 v1 = ld4(colT + (long long)r1 * rowlen + c);
+        const float4 v2 = ld4(colT + (long long)r2 * rowlen + c);
+        const float4 v3 = ld4(colT + (long long)r3 * rowlen + c);
         acc.x += w0 * v0.x; acc.y += w0 * v0.y; acc.z += w0 * v0.z; acc.w += w0 * v0.w;
         acc.x += w1 * v1.x; acc.y += w1 * v1.y; acc.z += w1 * v1.z; acc.w += w1 * v1.w;
         acc.x += w2 * v2.x; acc.y += w2 * v2.y; acc.z += w2 * v2.z; acc.w += w2 * v2.w;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const float*
       for (; e < e1; ++e) {
         const int r0 = ent_row[e];
         const float w0 = ent_w[e];
-        const float4 v0 = *reinterpret_cast<const float4*>(colT + (long long)r0 * rowlen + c);
+        const float4 v0 = ld4(colT + (long long)r0 * rowlen + c);
         acc.x += w0 * v0.x; acc.y += w0 * v0.y; acc.z += w0 * v0.z; acc.w += w0 * v0.w;
       }
       *reinterpret_cast<float4*>(grad_im + pix * g.C + c) = acc;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const float*
   } else {
     for (int c = lane; c < g.C; c += 64) {
       float acc = 0.f;
-      for (int e = e0; e < e1; ++e) acc += ent_w[e] * colT[(long long)ent_row[e] * rowlen + c];
+      for (int e = e0; e < e1; ++e) acc += ent_w[e] * ld1(colT + (long long)ent_row[e] * rowlen + c);
       grad_im[pix * g.C + c] = acc;
     }
   }
@@ -631,7 +632,7 @@ extern "C" int rsdet_deform_im2col_f32(const float* im, const float* offset,
 #endif
   constexpr int kChunk = RSDET_IM2COL_CHUNK;  // channels per workgroup row
   if (g.kh * g.kw == 9 && cpg % kChunk == 0 && g.W >= 2) {  // the AlignConv shape: nine taps per thread
-    hipLaunchKernelGGL(deform_im2col_taps_kernel<9>, dim3((unsigned)pb, g.C / kChunk), dim3(DCN_NT), 0,
+    hipLaunchKernelGGL((deform_im2col_taps_kernel<9, float>), dim3((unsigned)pb, g.C / kChunk), dim3(DCN_NT), 0,
                        (hipStream_t)stream, im, offset, g, kChunk, col);
     return rsdet_launch_status();
   }
@@ -639,6 +640,24 @@ extern "C" int rsdet_deform_im2col_f32(const float* im, const float* offset,
   dim3 grid((unsigned)pb, g.kh * g.kw, (g.C + cc - 1) / cc);
   hipLaunchKernelGGL(deform_im2col_kernel, grid, dim3(DCN_NT), 0, (hipStream_t)stream, im, offset,
                      g, cc, col);
+  return rsdet_launch_status();
+}
+
+// bf16 column matrix for the autocast step (the GEMMs that consume it run on bf16 MFMA): same kernel, the store rounds
+// to nearest even.  Only the AlignConv geometry (3x3 taps, channels per deformable group a multiple of 16).
+extern "C" int rsdet_deform_im2col_bf16col_f32(const float* im, const float* offset, const rsdet_dcn_geom* geom,
+                                               uint16_t* col, void* stream) {
+  Geom g;
+  int rc = make_geom(geom, &g);
+  if (rc) return rc;
+  long long npos = (long long)g.B * g.Ho * g.Wo;
+  if (npos == 0 || g.C == 0) return RSDET_OK;
+  if (!im || !offset || !col) return RSDET_EINVAL;
+  const long long pb = (npos + DCN_NT - 1) / DCN_NT;
+  const int cpg = g.C / g.dg;
+  if (!(g.kh * g.kw == 9 && cpg % RSDET_IM2COL_CHUNK == 0 && g.W >= 2)) return RSDET_EINVAL;
+  hipLaunchKernelGGL((deform_im2col_taps_kernel<9, bf16_t>), dim3((unsigned)pb, g.C / RSDET_IM2COL_CHUNK), dim3(DCN_NT),
+                     0, (hipStream_t)stream, im, offset, g, RSDET_IM2COL_CHUNK, col);
   return rsdet_launch_status();
 }
 
@@ -730,9 +749,9 @@ extern "C" size_t rsdet_deform_col2im_gather_ws_size(const rsdet_dcn_geom* geom)
          dcn_align256((npix / 4096 + 1) * 4);  // cnt | start | ent_row | ent_w | chunk sums
 }
 
-extern "C" int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset,
-                                                   const rsdet_dcn_geom* geom, float* grad_im, void* ws,
-                                                   size_t ws_bytes, void* stream) {
+template <typename TROW>
+static int dcn_col2im_gather(const TROW* colT, const float* offset, const rsdet_dcn_geom* geom, float* grad_im,
+                             void* ws, size_t ws_bytes, void* stream) {
   Geom g;
   int rc = make_geom(geom, &g);
   if (rc) return rc;
@@ -758,13 +777,27 @@ extern "C" int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const floa
   if (items > 0)
     hipLaunchKernelGGL(dcn_idx_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, offset, g, items,
                        start, cnt, ent_row, ent_w);
-  const bool vec4 = (g.C % 4 == 0) && (((uintptr_t)colT | (uintptr_t)grad_im) % 16 == 0);
+  // four consecutive channels per lane: 16-byte (fp32) / 8-byte (bf16) row loads, 16-byte stores
+  const bool vec4 = (g.C % 4 == 0) && ((uintptr_t)colT % (4 * sizeof(TROW)) == 0) && ((uintptr_t)grad_im % 16 == 0);
   const unsigned blocks = (unsigned)((npix + DCN_WAVES - 1) / DCN_WAVES);
   if (vec4)
-    hipLaunchKernelGGL(dcn_gather_kernel<true>, dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start, ent_row, ent_w,
-                       g, grad_im);
-  else
-    hipLaunchKernelGGL(dcn_gather_kernel<false>, dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start, ent_row,
+    hipLaunchKernelGGL((dcn_gather_kernel<true, TROW>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start, ent_row,
                        ent_w, g, grad_im);
+  else
+    hipLaunchKernelGGL((dcn_gather_kernel<false, TROW>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start,
+                       ent_row, ent_w, g, grad_im);
   return rsdet_launch_status();
+}
+
+extern "C" int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset,
+                                                   const rsdet_dcn_geom* geom, float* grad_im, void* ws,
+                                                   size_t ws_bytes, void* stream) {
+  return dcn_col2im_gather<float>(colT, offset, geom, grad_im, ws, ws_bytes, stream);
+}
+
+// the column gradient in bf16 (output of a bf16 GEMM in the autocast step); sums and grad_im stay fp32
+extern "C" int rsdet_deform_col2im_gather_nhwc_bf16col_f32(const uint16_t* colT, const float* offset,
+                                                           const rsdet_dcn_geom* geom, float* grad_im, void* ws,
+                                                           size_t ws_bytes, void* stream) {
+  return dcn_col2im_gather<bf16_t>(colT, offset, geom, grad_im, ws, ws_bytes, stream);
 }

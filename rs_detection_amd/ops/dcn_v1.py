@@ -13,6 +13,7 @@ MI355X-first differences from the reference's host logic (free per SURVEY q17):
     (AlignConv builds offsets under no_grad, s2anet_head.py:676 / SURVEY q16).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -21,6 +22,9 @@ from .. import _lib
 
 __all__ = ["DeformConv", "deform_conv", "deformable_im2col", "deformable_col2im", "deformable_col2im_coord",
            "deformable_im2col_nhwc", "deformable_col2im_nhwc"]
+
+
+_LOWP_ALIGNCONV = os.environ.get("RSDET_ALIGNCONV_BF16", "0") == "1"
 
 
 def _pair(x):
@@ -35,8 +39,9 @@ def _out_hw(H, W, kh, kw, ph, pw, sh, sw, dh, dw):
     return ((H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1)
 
 
-def deformable_im2col(im, offset, kernel, padding, stride, dilation, deformable_group=1):
-    """dcn_v1.py:309-339: im (B,C,H,W), offset (B,dg*2*kh*kw,Ho,Wo) -> col (C*kh*kw, B*Ho*Wo)."""
+def deformable_im2col(im, offset, kernel, padding, stride, dilation, deformable_group=1, col_dtype=None):
+    """dcn_v1.py:309-339: im (B,C,H,W), offset (B,dg*2*kh*kw,Ho,Wo) -> col (C*kh*kw, B*Ho*Wo).
+    ``col_dtype=torch.bfloat16``: the columns are stored as bf16 (autocast step; 3x3 AlignConv geometry only)."""
     _lib.require_cuda_f32(im, offset)
     lib = _lib.load()
     im, offset = im.contiguous(), offset.contiguous()
@@ -44,10 +49,11 @@ def deformable_im2col(im, offset, kernel, padding, stride, dilation, deformable_
     (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
     Ho, Wo = _out_hw(H, W, kh, kw, ph, pw, sh, sw, dh, dw)
     assert tuple(offset.shape) == (B, deformable_group * 2 * kh * kw, Ho, Wo), "invalid offset shape"
-    col = torch.empty((C * kh * kw, B * Ho * Wo), dtype=im.dtype, device=im.device)
+    lowp = col_dtype == torch.bfloat16
+    col = torch.empty((C * kh * kw, B * Ho * Wo), dtype=torch.bfloat16 if lowp else im.dtype, device=im.device)
     g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_group)
-    _lib.check(lib.rsdet_deform_im2col_f32(_lib.ptr(im), _lib.ptr(offset), g, _lib.ptr(col), _lib.stream_ptr()),
-               "rsdet_deform_im2col_f32")
+    name = "rsdet_deform_im2col_bf16col_f32" if lowp else "rsdet_deform_im2col_f32"
+    _lib.check(getattr(lib, name)(_lib.ptr(im), _lib.ptr(offset), g, _lib.ptr(col), _lib.stream_ptr()), name)
     return col
 
 
@@ -114,18 +120,19 @@ def deformable_col2im_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride,
 def deformable_col2im_gather_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride, dilation):
     """colT (B*Ho*Wo, kh*kw*C) -> grad_im (B,H,W,C) without floating-point atomics (one deformable group):
     the scatter map is inverted on integers first, then every input pixel gathers its terms."""
-    _lib.require_cuda_f32(colT, offset)
+    lowp = colT.dtype == torch.bfloat16  # column gradient out of a bf16 GEMM (autocast step); grad_im stays fp32
+    _lib.require_cuda_f32(None if lowp else colT, offset)
     lib = _lib.load()
     colT, offset = colT.contiguous(), offset.contiguous()
     B, H, W, C = im_shape_nhwc
     (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
-    grad_im = torch.empty((B, H, W, C), dtype=colT.dtype, device=colT.device)
+    grad_im = torch.empty((B, H, W, C), dtype=torch.float32, device=colT.device)
     g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, 1)
     ws_bytes = lib.rsdet_deform_col2im_gather_ws_size(g)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=colT.device)
-    _lib.check(lib.rsdet_deform_col2im_gather_nhwc_f32(_lib.ptr(colT), _lib.ptr(offset), g, _lib.ptr(grad_im),
-                                                       _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
-               "rsdet_deform_col2im_gather_nhwc_f32")
+    name = "rsdet_deform_col2im_gather_nhwc_bf16col_f32" if lowp else "rsdet_deform_col2im_gather_nhwc_f32"
+    _lib.check(getattr(lib, name)(_lib.ptr(colT), _lib.ptr(offset), g, _lib.ptr(grad_im), _lib.ptr(ws), ws_bytes,
+                                  _lib.stream_ptr()), name)
     return grad_im
 
 
@@ -142,17 +149,25 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, input, offset, weight, stride, padding, dilation, deformable_groups):
+    def forward(ctx, input, offset, weight, stride, padding, dilation, deformable_groups, lowp=False):
         ctx.cfg = (_pair(stride), _pair(padding), _pair(dilation), deformable_groups)
         B, C, H, W = input.shape
         O, _, kh, kw = weight.shape
         Ho, Wo = _out_hw(H, W, kh, kw, *ctx.cfg[1], *ctx.cfg[0], *ctx.cfg[2])
-        col = deformable_im2col(input, offset, (kh, kw), ctx.cfg[1], ctx.cfg[0], ctx.cfg[2], deformable_groups)
-        out = torch.empty((B, O, Ho, Wo), dtype=input.dtype, device=input.device)
-        w_flat = weight.reshape(O, C * kh * kw)
+        # lowp (bf16 autocast step): bilinear sampling in fp32, columns stored as bf16, the three products on bf16 MFMA
+        # with fp32 accumulation -- what autocast does to every other convolution of the step
+        lowp = bool(lowp) and kh * kw == 9 and (C // deformable_groups) % 16 == 0 and W >= 2
+        ctx.lowp = lowp
+        cdt = torch.bfloat16 if lowp else input.dtype
+        col = deformable_im2col(input, offset, (kh, kw), ctx.cfg[1], ctx.cfg[0], ctx.cfg[2], deformable_groups,
+                                col_dtype=cdt)
+        w_flat = weight.reshape(O, C * kh * kw).to(cdt)
         hw = Ho * Wo
-        for b in range(B):
-            torch.mm(w_flat, col[:, b * hw:(b + 1) * hw], out=out[b].view(O, hw))
+        # one strided-batched product over the images, straight into the NCHW result: col (K, B*hw) is viewed as
+        # (B, K, hw) with strides (hw, B*hw, 1) -- no copies, one launch (and one library call) per level
+        out = torch.empty((B, O, Ho, Wo), dtype=cdt, device=input.device)  # returned as is (callers apply ReLU in place)
+        torch.bmm(w_flat.unsqueeze(0).expand(B, O, C * kh * kw), col.view(C * kh * kw, B, hw).permute(1, 0, 2),
+                  out=out.view(B, O, hw))
         ctx.save_for_backward(offset, weight, col)
         ctx.in_shape = (B, C, H, W)
         return out
@@ -164,14 +179,15 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
         stride, padding, dilation, dg = ctx.cfg
         B, C, H, W = ctx.in_shape
         O, _, kh, kw = weight.shape
-        go = grad_output.contiguous().view(B, O, -1)  # (B, O, Ho*Wo)
+        cdt = torch.bfloat16 if ctx.lowp else weight.dtype
+        go = grad_output.contiguous().to(cdt).view(B, O, -1)  # (B, O, Ho*Wo)
         hw = go.shape[2]
         grad_input = grad_weight = None
         # one (O, B*hw) copy of the output gradient (17 MB at level 0) turns both backward products into single
         # launches over the whole batch: measured 734 -> 630 us (data) and 771 -> 585 us (weight) at level 0
         go2 = go.transpose(0, 1).reshape(O, B * hw)
         if ctx.needs_input_grad[0]:
-            w_ok = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C)  # K index = tap*C + c
+            w_ok = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C).to(cdt)  # K index = tap*C + c
             gcolT = torch.mm(go2.t(), w_ok)  # (B*hw, kh*kw*C): channels-last column gradient
             if dg == 1:  # gather form: no floating-point atomics (3.4x faster at pyramid level 0)
                 gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation)
@@ -185,8 +201,8 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
             J = 16 if n % 16 == 0 and n >= 4096 else 1
             k = n // J
             parts = torch.bmm(go2.view(O, J, k).permute(1, 0, 2), col.view(C * kh * kw, J, k).permute(1, 2, 0))
-            grad_weight = parts.sum(0).view_as(weight) if J > 1 else parts[0].view_as(weight)
-        return grad_input, None, grad_weight, None, None, None, None
+            grad_weight = (parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()).view_as(weight)
+        return grad_input, None, grad_weight, None, None, None, None, None
 
 
 class DeformConvFunction(torch.autograd.Function):
@@ -244,7 +260,12 @@ def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1
                 im2col_step=64):
     """dcn_v1.py:650 ``deform_conv = DeformConvFunction.apply`` (same positional signature)."""
     if groups == 1 and not offset.requires_grad and input is not None and input.dim() == 4 and input.is_cuda:
-        return DeformConvFunctionNHWC.apply(input, offset, weight, stride, padding, dilation, deformable_groups)
+        # bf16 columns + bf16 products under autocast save 2.9 ms of GPU time per S2ANet step (34.3 -> 31.4 ms of kernels),
+        # but the bf16 step is bound by the host's dispatch rate (31-34 ms/step either way, +-3 ms run to run): no
+        # wall-clock gain until the step runs from a captured graph, so it stays opt-in (RSDET_ALIGNCONV_BF16=1)
+        lowp = (_LOWP_ALIGNCONV and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        return DeformConvFunctionNHWC.apply(input, offset, weight, stride, padding, dilation, deformable_groups, lowp)
     return DeformConvFunction.apply(input, offset, weight, stride, padding, dilation, groups, deformable_groups,
                                     im2col_step)
 

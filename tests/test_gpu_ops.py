@@ -600,3 +600,27 @@ def test_conv_module_fused_bias_relu_matches_unfused(cuda):
     mc = ConvModule(16, 24, 3, padding=1)
     xc = torch.randn(1, 16, 8, 8)
     assert torch.allclose(mc(xc), torch.relu(torch.nn.functional.conv2d(xc, mc.conv.weight, mc.conv.bias, 1, 1)))
+
+
+def test_deform_conv_bf16_autocast_path_tracks_fp32(cuda):
+    """Under bf16 autocast AlignConv's columns are bf16 and its three products run on bf16 MFMA: output and both
+    gradients stay within bf16 accuracy of the fp32 path (relative to the largest value), and the output is bf16."""
+    from rs_detection_amd.ops import dcn_v1
+    from rs_detection_amd.ops.dcn_v1 import DeformConv
+    dcn_v1._LOWP_ALIGNCONV = True        # opt-in path (RSDET_ALIGNCONV_BF16=1)
+    torch.manual_seed(5)
+    B, C, O, H, W = 2, 32, 48, 24, 40
+    m = DeformConv(C, O, 3, padding=1).to(cuda)
+    x = torch.randn(B, C, H, W, device=cuda, requires_grad=True)
+    off = (torch.randn(B, 18, H, W, device=cuda) * 1.5)
+    y32 = m(x, off)
+    go = torch.randn_like(y32)
+    gx32, gw32 = torch.autograd.grad(y32, (x, m.weight), go)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = m(x, off)
+    assert y16.dtype == torch.bfloat16
+    gx16, gw16 = torch.autograd.grad(y16, (x, m.weight), go.bfloat16())
+    assert gx16.dtype == torch.float32 and gw16.dtype == torch.float32
+    dcn_v1._LOWP_ALIGNCONV = False
+    for a, b in ((y16.float(), y32), (gx16, gx32), (gw16, gw32)):
+        assert float((a - b).abs().max()) <= 3e-2 * float(b.abs().max())
