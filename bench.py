@@ -392,7 +392,8 @@ def main():
                                 "K gts/tile cycle [16,100,400,40], 10 classes, 2000 proposals/tile -> 512 sampled RoIs")
                                % (batch, "fp32" if args.dtype == "f32" else "bf16 autocast (fp32 box kernels)"),
                    "global_batch": batch * world, "parallelism": "dp%d" % world,
-                   "memory_format": args.memory_format},
+                   "memory_format": args.memory_format,
+                   "miopen_records": "packaged (rs_detection_amd/miopen_db)" if MIOPEN_DB_DIR else "none / user-provided"},
         "final_loss": loss_v,
         "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
         "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
