@@ -408,7 +408,8 @@ def main():
             "peak": FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0,
             "frac": step_flops / (dt / args.steps) / 1e12 / (FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0)},
         "kernels": kernels,
-        "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+        # the CPU baseline is timed on rank 0 of a single-GPU run only (SURVEY 8d / bench contract)
+        "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),
     }
     print(json.dumps(line))
 
