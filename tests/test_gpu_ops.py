@@ -624,3 +624,32 @@ def test_deform_conv_bf16_autocast_path_tracks_fp32(cuda):
     dcn_v1._LOWP_ALIGNCONV = False
     for a, b in ((y16.float(), y32), (gx16, gx32), (gw16, gw32)):
         assert float((a - b).abs().max()) <= 3e-2 * float(b.abs().max())
+
+
+def test_f4_ops_empty_and_degenerate_inputs(cuda):
+    """Edge cases of the 8(f) rank-4 ops and the depthwise stencil: empty batches / no RoIs return empty results of
+    the right shape (and zero gradients), nothing launches on zero elements, wrong geometry fails loudly."""
+    from rs_detection_amd.ops.roi_align_rotated import ROIAlignRotated
+    from rs_detection_amd.ops.fr import FR, feature_refine
+    from rs_detection_amd.ops.dwconv import dwconv2d
+    from rs_detection_amd import _lib
+    feat = torch.randn(1, 4, 8, 8, device=cuda, requires_grad=True)
+    out = ROIAlignRotated((7, 7), 0.5, 2)(feat, torch.zeros(0, 6, device=cuda))
+    assert tuple(out.shape) == (0, 4, 7, 7)
+    out.sum().backward()
+    assert float(feat.grad.abs().sum()) == 0.0
+    # FeatureRefine: empty batch; a box far outside the map adds nothing (fr.py:26-28)
+    e = feature_refine(torch.zeros(0, 4, 8, 8, device=cuda), torch.zeros(0, 8, 8, 5, device=cuda), 0.125, 1)
+    assert tuple(e.shape) == (0, 4, 8, 8)
+    f = torch.randn(1, 3, 6, 6, device=cuda)
+    far = torch.full((1, 6, 6, 5), 1e6, device=cuda)
+    assert torch.equal(FR(1.0, 5)(f, far), f)
+    with pytest.raises(_lib.RsdetError):
+        feature_refine(f, torch.zeros(1, 5, 5, 5, device=cuda), 1.0, 1)     # boxes do not match the feature map
+    # depthwise stencil: empty batch, 1x1 plane (all halo), unsupported kernel size
+    w = torch.randn(3, 1, 3, 3, device=cuda)
+    assert tuple(dwconv2d(torch.zeros(0, 3, 5, 5, device=cuda), w, None, 1).shape) == (0, 3, 5, 5)
+    one = torch.randn(2, 3, 1, 1, device=cuda)
+    assert torch.allclose(dwconv2d(one, w, None, 1), one * w[None, :, 0, 1:2, 1:2].reshape(1, 3, 1, 1), atol=1e-6)
+    with pytest.raises(_lib.RsdetError):
+        dwconv2d(one, torch.randn(3, 1, 3, 3, device=cuda), None, 2)       # (3, dilation 2) is not a covered geometry
