@@ -38,7 +38,10 @@ if graphed:
     m.forward = fwd
 for it in range(5): runner.train_step(images, targets(it))
 torch.cuda.synchronize(); t0 = time.time()
-N = 30
-for it in range(N): runner.train_step(images, targets(5 + it))
+N = 40
+losses = []
+for it in range(N):
+    l, _ = runner.train_step(images, targets(5 + it))
+    if it % 5 == 4: losses.append(float(l))
 torch.cuda.synchronize(); dtm = (time.time() - t0) / N
-print("dtype %s graphed %s: %.2f ms/step" % (dt, graphed, dtm * 1e3))
+print("dtype %s graphed %s: %.2f ms/step  losses %s" % (dt, graphed, dtm * 1e3, ["%.3f" % v for v in losses]))

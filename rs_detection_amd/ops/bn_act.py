@@ -6,6 +6,8 @@ backward on the torch route, ~8 ms of a 68 ms S2ANet step.  ``bn_act(x, bn, resi
 can (CUDA, contiguous NCHW, fp32 activations or the bf16 ones of an autocast step, ``bn`` in eval mode) and is the
 plain torch sequence otherwise (training-mode BatchNorm, CPU tensors of the RetinaNet plumbing case) -- both are the product path; there is no
 oracle or CPU restatement behind it."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -54,7 +56,12 @@ class _BNAct(torch.autograd.Function):
         return gx, gres, gw, gb, None, None, None, None
 
 
+_NO_FUSED_BN = os.environ.get("RSDET_NO_FUSED_BN", "0") == "1"  # A/B switch
+
+
 def _fusable(x, bn, residual):
+    if _NO_FUSED_BN:
+        return False
     # fp32 activations outside autocast, or bf16 activations (what the convolutions emit under bf16 autocast); the
     # BatchNorm parameters and running statistics are fp32 in both cases
     ok_dtype = (x.dtype == torch.float32 and not torch.is_autocast_enabled()) or x.dtype == torch.bfloat16
