@@ -359,11 +359,28 @@ __global__ __launch_bounds__(64 * PN_WAVES) void nms_poly_f32_mask_kernel(const 
                                    s_ring + (wave * 2 + 1) * PN_SLOTS * 64, tid) > thr) bits |= 1ull << j;  // :179
   }
   if (bits) atomicOr(&s_rows[tid], bits);
-  __syncthreads();
+  __syncthreads();  // the last barrier of the kernel: every wave reaches it, s_rows is complete afterwards
   if (wave != 0) return;
   bits = s_rows[tid];
-  __syncthreads();  // (one wave left: orders the read above before poly_emit_tile reuses s_rows)
-  poly_emit_tile(bits, rb, cbk, tid, col_blocks, entries, blk_cnt, diag_t, s_rows);
+  if (rb != cbk) {  // off-diagonal tile: append the non-zero rows to the row block's entry list
+    const unsigned long long nz = __ballot(bits != 0ull);
+    if (nz == 0ull) return;
+    unsigned base = 0u;
+    if (tid == 0) base = atomicAdd(blk_cnt + rb, (unsigned)__popcll(nz));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (bits != 0ull) {
+      NmsEntry e;
+      e.bits = bits;
+      e.cblock = cbk;
+      e.row = tid;
+      entries[(size_t)rb * 64 * col_blocks + base + __popcll(nz & ((1ull << tid) - 1ull))] = e;
+    }
+    return;
+  }
+  unsigned long long col = 0ull;  // diagonal tile: stored transposed for the sweep's fixpoint
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) col |= ((s_rows[i] >> tid) & 1ull) << i;
+  diag_t[rb * 64 + tid] = col;
 }
 
 // dense (n1, n2) matrix of the same IoU: one wave per 64 pairs (used by tests and by callers that want the values)
