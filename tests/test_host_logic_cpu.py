@@ -116,3 +116,37 @@ def test_synthetic_stream_is_deterministic_and_dota_shaped():
         assert x["labels"].min() >= 1 and x["labels"].max() <= 15
     assert not (a[0]["rboxes"] == syn.synthetic_targets(4, rank=0, it=3)[0]["rboxes"]).all()  # ranks differ
     assert syn.s2anet_anchor_grid().shape == (21824, 5)
+
+
+def test_xcd_workgroup_renumbering_is_a_bijection():
+    """The two XCD-aware workgroup renumberings of csrc/rsdet_api_internal.h (rsdet_xcd_contiguous, rsdet_xcd_band),
+    restated in Python: every logical item is produced exactly once, ids that share an XCD (equal id % 8) map to one
+    contiguous run / band -- for totals that are and are not multiples of 8."""
+    def contiguous(i, total):
+        q, r, xcd, slot = total >> 3, total & 7, i & 7, i >> 3
+        return xcd * q + min(xcd, r) + slot
+
+    for total in (1, 7, 8, 9, 63, 64, 1000, 4097):
+        out = [contiguous(i, total) for i in range(total)]
+        assert sorted(out) == list(range(total))
+        for xcd in range(8):
+            mine = sorted(out[i] for i in range(total) if i % 8 == xcd)
+            assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True
+
+    def band(i, n_outer, n_inner):
+        xcd, slot = i & 7, i >> 3
+        o0, o1 = n_outer * xcd // 8, n_outer * (xcd + 1) // 8
+        ln = o1 - o0
+        if ln <= 0 or slot >= ln * n_inner:
+            return None
+        inner = slot // ln
+        return (o0 + slot - inner * ln, inner)
+
+    for n_outer, n_inner in ((1, 1), (5, 3), (8, 16), (13, 7), (128, 16), (257, 2)):
+        grid = 8 * ((n_outer + 7) // 8) * n_inner
+        items = [band(i, n_outer, n_inner) for i in range(grid)]
+        got = sorted(x for x in items if x is not None)
+        assert got == sorted((o, k) for o in range(n_outer) for k in range(n_inner))
+        for xcd in range(8):
+            outers = sorted({x[0] for i, x in enumerate(items) if x is not None and i % 8 == xcd})
+            assert outers == list(range(outers[0], outers[0] + len(outers))) if outers else True
