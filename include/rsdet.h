@@ -276,16 +276,23 @@ int rsdet_rotated_box_to_poly_f32(const float* boxes, int n, float* polys, void*
  * Replaces nn.Conv2d(dim, dim, k, groups=dim) at models/backbones/van.py:32 (3x3), :56 (5x5), :57 (7x7, dilation 3)
  * on the Oriented R-CNN + VAN path: stride 1, "same" padding dilation*(K-1)/2, (K, dilation) in {(3,1), (5,1), (7,3)}
  * (anything else: RSDET_EINVAL -- the host module then keeps torch's convolution).  x / y / grad (N,C,H,W),
- * weight (C,1,K,K) = (C,K,K) contiguous, bias (C) or NULL.  backward_weight also returns the bias gradient
- * (grad_bias may be NULL); its sums run in a fixed order (two stages through ws, no float atomics). */
-int rsdet_dwconv2d_forward_f32(const float* x, const float* weight, const float* bias, int N, int C, int H, int W,
-                               int K, int dilation, float* y, void* stream);
+ * weight (C,1,K,K) = (C,K,K) contiguous, bias (C) or NULL.
+ * in_bias (C) or NULL: a per-channel constant added to x before the convolution (zero padding stays zero) -- the bias
+ * of the 1x1 convolution in front of the depthwise one in the VAN MLP (van.py:43-51: fc1 -> dwconv), which then runs
+ * without its bias kernel; backward_data returns that bias' gradient = sum(grad_x) in grad_in_bias (NULL: not wanted;
+ * ws of rsdet_dwconv2d_backward_data_ws_size bytes only when it is).  backward_weight takes the same in_bias, also
+ * returns the bias gradient of the depthwise convolution itself (grad_bias may be NULL).  All sums run in a fixed order
+ * (two stages through ws, no float atomics). */
+int rsdet_dwconv2d_forward_f32(const float* x, const float* in_bias, const float* weight, const float* bias, int N,
+                               int C, int H, int W, int K, int dilation, float* y, void* stream);
+size_t rsdet_dwconv2d_backward_data_ws_size(int N, int C, int H, int W);
 int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float* weight, int N, int C, int H, int W, int K,
-                                     int dilation, float* grad_x, void* stream);
+                                     int dilation, float* grad_x, float* grad_in_bias, void* ws, size_t ws_bytes,
+                                     void* stream);
 size_t rsdet_dwconv2d_backward_weight_ws_size(int N, int C, int H, int W, int K);
-int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, int N, int C, int H, int W, int K,
-                                       int dilation, float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes,
-                                       void* stream);
+int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, const float* in_bias, int N, int C, int H,
+                                       int W, int K, int dilation, float* grad_weight, float* grad_bias, void* ws,
+                                       size_t ws_bytes, void* stream);
 
 /* ---- a21  eval-mode BatchNorm + residual add + ReLU (backbone Bottleneck tails) -----------------------
  * Replaces the per-op sequence models/backbones/resnet.py:101-126 (bn -> (+ identity) -> relu) when the

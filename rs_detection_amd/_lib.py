@@ -87,13 +87,14 @@ SIGNATURES = {
                                       c_void_p]),
     "rsdet_poly_nms_sorted_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_poly_iou_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "rsdet_dwconv2d_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                           c_void_p, c_void_p]),
+    "rsdet_dwconv2d_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p, c_void_p]),
+    "rsdet_dwconv2d_backward_data_ws_size": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rsdet_dwconv2d_backward_data_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                                 c_void_p, c_void_p]),
+                                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_dwconv2d_backward_weight_ws_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "rsdet_dwconv2d_backward_weight_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_dwconv2d_backward_weight_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                   c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_rotated_box_to_poly_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_poly_iou_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_nms_poly_sorted_f64": (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -40,30 +40,37 @@ struct DwGeom {
 // coalesced staging of the (tile + halo) window of one plane, zero outside the plane
 template <int K, int D>
 __device__ __forceinline__ void dw_stage(const float* __restrict__ plane, int H, int W, int y0, int x0,
-                                         float* __restrict__ s) {
+                                         float* __restrict__ s, float add = 0.f) {
+  // `add`: a per-channel constant the PRODUCER of this tensor owed it (the bias of the 1x1 convolution in front of
+  // the depthwise one, ops/dwconv.py in_bias): added to the in-bounds elements only, the zero padding stays zero
   using G = DwGeom<K, D>;
   for (int i = threadIdx.x; i < G::LH * G::LW; i += DW_NT) {
     const int r = i / G::LW, c = i - r * G::LW;
     const int y = y0 - G::halo + r, x = x0 - G::halo + c;
-    s[r * G::LWP + c] = (y >= 0 && y < H && x >= 0 && x < W) ? plane[(long long)y * W + x] : 0.f;
+    s[r * G::LWP + c] = (y >= 0 && y < H && x >= 0 && x < W) ? plane[(long long)y * W + x] + add : 0.f;
   }
 }
 
 // grid: (N * C planes, tiles_x * tiles_y).  Neighbouring tiles of a plane are N * C workgroup ids apart -- a multiple
 // of 8 for every VAN width, i.e. on the same XCD, where their shared halo rows meet in L2.  FLIP mirrors the taps
 // (backward-data).
+// in_bias (forward only): see dw_stage.  out_sum (backward-data only): per-workgroup sum of the tile it wrote, i.e. a
+// partial of sum(grad_x) per channel = the gradient of that producer bias; out_sum[(c * nslots + slot)].
 template <int K, int D, bool FLIP>
 __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ w,
-                                                               const float* __restrict__ bias, int C, int H, int W,
-                                                               int tiles_x, float* __restrict__ y) {
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ in_bias, int C, int H, int W,
+                                                               int tiles_x, float* __restrict__ y,
+                                                               float* __restrict__ out_sum) {
   using G = DwGeom<K, D>;
   __shared__ float s[G::LH * G::LWP];
   __shared__ float s_w[K * K];
+  __shared__ float s_sum[DW_NT / 64];
   const int plane = blockIdx.x, c = plane % C;
   const int ty0 = (blockIdx.y / tiles_x) * DW_TH, tx0 = (blockIdx.y % tiles_x) * DW_TW;
   if (threadIdx.x < K * K) s_w[threadIdx.x] = w[c * K * K + (FLIP ? K * K - 1 - threadIdx.x : threadIdx.x)];
-  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s);
+  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s, (!FLIP && in_bias) ? in_bias[c] : 0.f);
   __syncthreads();
   const int tx = threadIdx.x % DW_TW, tr = (threadIdx.x / DW_TW) * DW_ROWS;
   float acc[DW_ROWS];
@@ -83,12 +90,26 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
     }
   }
   const int ox = tx0 + tx;
+  float tile_sum = 0.f;
   if (ox < W) {
     float* yp = y + (long long)plane * H * W;
 #pragma unroll
     for (int r = 0; r < DW_ROWS; ++r) {
       const int oy = ty0 + tr + r;
-      if (oy < H) yp[(long long)oy * W + ox] = acc[r];
+      if (oy < H) {
+        yp[(long long)oy * W + ox] = acc[r];
+        tile_sum += acc[r];
+      }
+    }
+  }
+  if (FLIP && out_sum) {  // uniform branch: fixed-order reduction of the tile (wave butterflies, then four waves)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tile_sum += __shfl_xor(tile_sum, off);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = tile_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int n = plane / C, nslots = (gridDim.x / C) * gridDim.y;
+      out_sum[(long long)c * nslots + n * gridDim.y + blockIdx.y] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
     }
   }
 }
@@ -96,15 +117,15 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
 // partial[(c * nslots + slot) * (K*K + 1) + t], slot = n * tiles + tile; t = K*K is the bias gradient
 template <int K, int D>
 __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                             int C, int H, int W, int tiles_x, int nslots,
-                                                             float* __restrict__ partial) {
+                                                             const float* __restrict__ in_bias, int C, int H, int W,
+                                                             int tiles_x, int nslots, float* __restrict__ partial) {
   using G = DwGeom<K, D>;
   constexpr int T = K * K + 1;
   __shared__ float s[G::LH * G::LWP];
   __shared__ float s_red[DW_NT / 64][T];
   const int plane = blockIdx.x, c = plane % C, n = plane / C;
   const int ty0 = (blockIdx.y / tiles_x) * DW_TH, tx0 = (blockIdx.y % tiles_x) * DW_TW;
-  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s);
+  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s, in_bias ? in_bias[c] : 0.f);
   const int tx = threadIdx.x % DW_TW, tr = (threadIdx.x / DW_TW) * DW_ROWS;
   float g[DW_ROWS];
   {
@@ -180,47 +201,72 @@ static int dw_check(int N, int C, int H, int W, int K, int dil) {
 }
 
 template <bool FLIP>
-static int dw_stencil(const float* x, const float* w, const float* bias, int N, int C, int H, int W, int K, int dil,
-                      float* y, hipStream_t s) {
+static int dw_stencil(const float* x, const float* w, const float* bias, const float* in_bias, int N, int C, int H,
+                      int W, int K, int dil, float* y, float* out_sum, hipStream_t s) {
   const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH;
   const dim3 grid(N * C, tx * ty);
   if (K == 3)
-    hipLaunchKernelGGL((dwconv_stencil_kernel<3, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, C, H, W, tx, y);
+    hipLaunchKernelGGL((dwconv_stencil_kernel<3, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
+                       y, out_sum);
   else if (K == 5)
-    hipLaunchKernelGGL((dwconv_stencil_kernel<5, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, C, H, W, tx, y);
+    hipLaunchKernelGGL((dwconv_stencil_kernel<5, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
+                       y, out_sum);
   else
-    hipLaunchKernelGGL((dwconv_stencil_kernel<7, 3, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, C, H, W, tx, y);
+    hipLaunchKernelGGL((dwconv_stencil_kernel<7, 3, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
+                       y, out_sum);
   (void)dil;
   return rsdet_launch_status();
 }
 
-extern "C" int rsdet_dwconv2d_forward_f32(const float* x, const float* weight, const float* bias, int N, int C, int H,
-                                          int W, int K, int dilation, float* y, void* stream) {
+extern "C" int rsdet_dwconv2d_forward_f32(const float* x, const float* in_bias, const float* weight, const float* bias,
+                                          int N, int C, int H, int W, int K, int dilation, float* y, void* stream) {
   int rc = dw_check(N, C, H, W, K, dilation);
   if (rc) return rc;
   if (N == 0 || C == 0) return RSDET_OK;
   if (!x || !weight || !y) return RSDET_EINVAL;
-  return dw_stencil<false>(x, weight, bias, N, C, H, W, K, dilation, y, (hipStream_t)stream);
+  return dw_stencil<false>(x, weight, bias, in_bias, N, C, H, W, K, dilation, y, nullptr, (hipStream_t)stream);
+}
+
+// floats of workspace per output of the reductions: one partial per (plane, tile)
+static inline size_t dw_slots(int N, int C, int H, int W) {
+  return (size_t)C * N * ((W + DW_TW - 1) / DW_TW) * ((H + DW_TH - 1) / DW_TH);
+}
+
+extern "C" size_t rsdet_dwconv2d_backward_data_ws_size(int N, int C, int H, int W) {
+  if (N <= 0 || C <= 0 || H < 1 || W < 1) return 0;
+  return dw_slots(N, C, H, W) * sizeof(float);
 }
 
 extern "C" int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float* weight, int N, int C, int H, int W,
-                                                int K, int dilation, float* grad_x, void* stream) {
+                                                int K, int dilation, float* grad_x, float* grad_in_bias, void* ws,
+                                                size_t ws_bytes, void* stream) {
   int rc = dw_check(N, C, H, W, K, dilation);
   if (rc) return rc;
-  if (N == 0 || C == 0) return RSDET_OK;
+  if (C == 0) return RSDET_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) {
+    if (grad_in_bias && hipMemsetAsync(grad_in_bias, 0, (size_t)C * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+    return RSDET_OK;
+  }
   if (!grad_y || !weight || !grad_x) return RSDET_EINVAL;
-  return dw_stencil<true>(grad_y, weight, nullptr, N, C, H, W, K, dilation, grad_x, (hipStream_t)stream);
+  if (grad_in_bias && (!ws || ws_bytes < rsdet_dwconv2d_backward_data_ws_size(N, C, H, W))) return RSDET_EINVAL;
+  rc = dw_stencil<true>(grad_y, weight, nullptr, nullptr, N, C, H, W, K, dilation, grad_x,
+                        grad_in_bias ? (float*)ws : nullptr, s);
+  if (rc || !grad_in_bias) return rc;
+  const int nslots = (int)(dw_slots(N, C, H, W) / C);
+  hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, (const float*)ws, nslots, 1,
+                     (float*)nullptr, grad_in_bias);
+  return rsdet_launch_status();
 }
 
 extern "C" size_t rsdet_dwconv2d_backward_weight_ws_size(int N, int C, int H, int W, int K) {
   if (N <= 0 || C <= 0 || H < 1 || W < 1 || K < 1) return 0;
-  const size_t tiles = (size_t)((W + DW_TW - 1) / DW_TW) * ((H + DW_TH - 1) / DW_TH);
-  return (size_t)C * N * tiles * (K * K + 1) * sizeof(float);
+  return dw_slots(N, C, H, W) * (K * K + 1) * sizeof(float);
 }
 
-extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, int N, int C, int H, int W,
-                                                  int K, int dilation, float* grad_weight, float* grad_bias, void* ws,
-                                                  size_t ws_bytes, void* stream) {
+extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, const float* in_bias, int N,
+                                                  int C, int H, int W, int K, int dilation, float* grad_weight,
+                                                  float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
   int rc = dw_check(N, C, H, W, K, dilation);
   if (rc) return rc;
   if (C == 0) return RSDET_OK;
@@ -237,11 +283,14 @@ extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const flo
   const dim3 grid(N * C, tx * ty);
   float* partial = (float*)ws;
   if (K == 3)
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<3, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, C, H, W, tx, nslots, partial);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<3, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, nslots,
+                       partial);
   else if (K == 5)
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<5, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, C, H, W, tx, nslots, partial);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<5, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, nslots,
+                       partial);
   else
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 3>), grid, dim3(DW_NT), 0, s, grad_y, x, C, H, W, tx, nslots, partial);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 3>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, nslots,
+                       partial);
   hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, partial, nslots, K * K + 1, grad_weight,
                      grad_bias);
   return rsdet_launch_status();

@@ -8,6 +8,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from rs_detection_amd.ops.bn_act import scale_residual
 from rs_detection_amd.ops.dwconv import DepthwiseConv2d
@@ -34,8 +35,8 @@ class DWConv(nn.Module):
         super().__init__()
         self.dwconv = DepthwiseConv2d(dim, 3, padding=1, bias=True)  # van.py:32; HIP stencil on the GPU (ops/dwconv.py)
 
-    def forward(self, x):
-        return self.dwconv(x)
+    def forward(self, x, in_bias=None):
+        return self.dwconv(x, in_bias)
 
 
 class Mlp(nn.Module):
@@ -50,7 +51,10 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.dwconv(self.fc1(x))))))
+        # fc1's bias is applied inside the depthwise kernel's load (ops/dwconv.py in_bias) instead of as a separate
+        # pass over the hidden-width tensor (8x / 4x the block width); its gradient comes back from that kernel too
+        h = F.conv2d(x, self.fc1.weight, None)
+        return self.drop(self.fc2(self.drop(self.act(self.dwconv(h, self.fc1.bias)))))
 
 
 class AttentionModule(nn.Module):

@@ -497,6 +497,22 @@ def test_dwconv_matches_torch_conv2d(cuda, N, C, H, W, K, D, bias):
     assert float((y.detach().double().cpu() - yd).abs().max()) <= 1e-5 * max(1.0, float(yd.abs().max()))
     for got, want in ((x.grad, xd.grad), (m.weight.grad, wd.grad)) + (((m.bias.grad, bd.grad),) if bias else ()):
         assert float((got.double().cpu() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    # in_bias: conv(x + b_in) with the zero padding left at zero; its gradient = sum of grad_x per channel
+    b_in = torch.randn(C, device=cuda, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    for p in m.parameters():
+        p.grad = None
+    y2 = m(x2, b_in)
+    y2.backward(go)
+    xd2 = x.detach().double().cpu().requires_grad_(True)
+    bind = b_in.detach().double().cpu().requires_grad_(True)
+    wd2 = m.weight.detach().double().cpu().requires_grad_(True)
+    yd2 = torch.nn.functional.conv2d(xd2 + bind[None, :, None, None], wd2, bd.detach() if bias else None, 1,
+                                     D * (K - 1) // 2, D, C)
+    yd2.backward(go.double().cpu())
+    assert float((y2.detach().double().cpu() - yd2).abs().max()) <= 1e-5 * max(1.0, float(yd2.abs().max()))
+    for got, want in ((x2.grad, xd2.grad), (b_in.grad, bind.grad), (m.weight.grad, wd2.grad)):
+        assert float((got.double().cpu() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
 
 
 def test_dwconv_module_is_a_conv2d_and_falls_back_to_torch_where_not_covered(cuda):
