@@ -47,7 +47,7 @@ if os.environ.get("RSDET_BLAS_LIB"):  # A/B switch: "hipblas" (rocBLAS) or "hipb
     torch.backends.cuda.preferred_blas_library(os.environ["RSDET_BLAS_LIB"])
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-TILE = 1024
+TILE = int(os.environ.get("RSDET_BENCH_TILE", "1024"))  # 1024 = the metric; smaller only for the self-launch test (named in config.workload)
 BATCH_PER_GPU = 4
 
 
@@ -59,6 +59,16 @@ def s2anet_cfg():
 
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md)
+WORKLOADS = {
+    "s2anet_r50": "S2ANet-R50-FPN train step, %d x %dx%d DOTA-shaped tiles per GPU, %s, K gts/tile cycle "
+                  "[16,100,400,40], one anchor per cell over strides 8..128 (A=21824 per 1024^2 tile)",
+    "s2anet_r101": "S2ANet-R101-FPN (s2anet_r101_fpn_1x_dota_rotate_balance_ms) train step, %d x %dx%d DOTA-shaped "
+                   "tiles per GPU, %s, K gts/tile cycle [16,100,400,40], A=21824 per 1024^2 tile",
+    "orcnn_van3": "Oriented R-CNN + VAN-B3 (orcnn_van3_7_anchor) train step, %d x %dx%d tiles per GPU, %s, K gts/tile "
+                  "cycle [16,100,400,40], 10 classes, 2000 proposals/tile -> 512 sampled RoIs",
+}
+METRICS = {"s2anet_r50": "1024x1024 tiles/sec S2ANet-R50-FPN train", "s2anet_r101": "1024x1024 tiles/sec S2ANet-R101-FPN train",
+           "orcnn_van3": "1024x1024 tiles/sec Oriented-RCNN VAN-B3 train"}
 
 
 def event_time(fn, iters, warmup=3, graph=True):
@@ -300,7 +310,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE config[1] (the metric); bf16 = torch.autocast over the MIOpen/rocBLAS part "
                          "(configs[2]/[4]); the oriented-box kernels always compute in fp32")
-    ap.add_argument("--model", choices=["s2anet_r50", "orcnn_van3"], default="s2anet_r50",
+    ap.add_argument("--model", choices=["s2anet_r50", "s2anet_r101", "orcnn_van3"], default="s2anet_r50",
                     help="s2anet_r50 = BASELINE configs[1] (the metric, default); orcnn_van3 = the Oriented R-CNN + VAN-B3 "
                          "model of configs[3] (RROIAlign + rotated NMS in the train step), 2 tiles per GPU as in the "
                          "reference config; reported under its own workload name, no kernel table")
@@ -311,8 +321,20 @@ def main():
 
     from rs_detection_amd.utils import dist as rdist
     from rs_detection_amd.utils import synthetic as syn
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (the reference's `mpirun -np N`,
+        # README_competition.md:79-80).  It has not touched the GPU (device_count() does not initialise HIP) and
+        # never will: the N ranks are child processes, rank 0's JSON line is relayed, the exit code is theirs.
+        if torch.cuda.device_count() < args.gpus:
+            # fewer GPUs than ranks (the 1-GPU test box): ranks share devices, which RCCL refuses -> gloo
+            os.environ.setdefault("RSDET_DIST_BACKEND", "gloo")
+        rc, out = rdist.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        raise SystemExit(rc)
     rank, local_rank, world = rdist.init_distributed()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the HIP hot path")
     device = torch.device("cuda", local_rank % torch.cuda.device_count())  # (% only matters for the 1-GPU gloo smoke test)
@@ -327,6 +349,12 @@ def main():
         from rs_detection_amd.config import Config
         cfg, batch, ncls = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")), 2, 10
         args.no_kernels = True
+    elif args.model == "s2anet_r101":
+        # BASELINE configs[4]: same head, Resnet101 trunk; reported under its own workload name, no kernel table
+        from rs_detection_amd.config import Config
+        cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r101_fpn_1x_dota_rotate_balance_ms.py"))
+        batch, ncls = BATCH_PER_GPU, 15
+        args.no_kernels = True
     else:
         cfg, batch, ncls = s2anet_cfg(), BATCH_PER_GPU, 15
     runner = Runner(cfg, device=device, memory_format=mf,
@@ -337,7 +365,7 @@ def main():
     if mf is not None:
         images = images.contiguous(memory_format=mf)
     targets = []
-    for t in syn.synthetic_targets(batch, rank=rank, it=0, num_classes=ncls):
+    for t in syn.synthetic_targets(batch, rank=rank, it=0, num_classes=ncls, img=TILE):
         t = dict(t)
         t["rboxes"] = torch.from_numpy(t["rboxes"]).to(device)
         t["labels"] = torch.from_numpy(t["labels"]).to(device)
@@ -368,13 +396,14 @@ def main():
     assert np.isfinite(loss_v), "non-finite loss"
 
     if rank != 0:
+        rdist.barrier()          # rank 0 is still timing its kernel table: leave the group together
+        rdist.shutdown()
         return
     kernels = {} if args.no_kernels else kernel_rooflines(device, targets)
     roof = kernels.get("box_iou_rotated(prepare+filter+clip)")
     tiles = batch * world * args.steps
     line = {
-        "metric": "1024x1024 tiles/sec S2ANet-R50-FPN train" if args.model == "s2anet_r50" else
-                  "1024x1024 tiles/sec Oriented-RCNN VAN-B3 train",
+        "metric": METRICS[args.model],
         "value": tiles / dt,
         "unit": "tiles/s",
         "n_gpus": world,
@@ -386,11 +415,9 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": ("S2ANet-R50-FPN train step, %d x 1024x1024 DOTA-shaped tiles per GPU, %s, "
-                                "K gts/tile cycle [16,100,400,40], A=21824 anchors/tile" if args.model == "s2anet_r50" else
-                                "Oriented R-CNN + VAN-B3 (orcnn_van3_7_anchor) train step, %d x 1024x1024 tiles per GPU, %s, "
-                                "K gts/tile cycle [16,100,400,40], 10 classes, 2000 proposals/tile -> 512 sampled RoIs")
-                               % (batch, "fp32" if args.dtype == "f32" else "bf16 autocast (fp32 box kernels)"),
+        "config": {"workload": (WORKLOADS[args.model] % (batch, TILE, TILE, "fp32" if args.dtype == "f32" else
+                                                             "bf16 autocast (fp32 box kernels)")
+                                + "; one cached batch per rank, resident in HBM, replayed every step"),
                    "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "memory_format": args.memory_format,
                    "miopen_records": "packaged (rs_detection_amd/miopen_db)" if MIOPEN_DB_DIR else "none / user-provided"},
@@ -411,7 +438,9 @@ def main():
         # the CPU baseline is timed on rank 0 of a single-GPU run only (SURVEY 8d / bench contract)
         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),
     }
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
+    rdist.barrier()
+    rdist.shutdown()
 
 
 if __name__ == "__main__":

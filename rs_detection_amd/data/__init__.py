@@ -3,6 +3,9 @@ on the GPU (ops/nms_poly.py).  Datasets and transforms of the reference are out 
 from . import transforms  # noqa: F401,E402  (registers TRANSFORMS)
 from .custom import CustomDataset  # noqa: F401,E402
 from .dota import DOTADataset  # noqa: F401,E402
+from .synthetic import SyntheticDOTADataset  # noqa: F401,E402
+from .fair import FAIR1M_1_5_Dataset, FAIRDataset  # noqa: F401,E402
+from .image import ImageDataset  # noqa: F401,E402
 
 
 def batch_to_device(images, targets, device):

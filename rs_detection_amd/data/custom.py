@@ -45,8 +45,10 @@ class CustomDataset:
     def set_epoch(self, epoch):
         self.epoch = epoch
 
-    def set_shard(self, rank, world_size):
-        self.rank, self.world_size = rank, world_size
+    def set_shard(self, rank, world_size, keep_all=False):
+        """``keep_all``: evaluation sharding -- every image exactly once, ranks may get unequal counts (no collective
+        runs per batch there); training trims to whole global batches."""
+        self.rank, self.world_size, self.shard_keep_all = rank, world_size, keep_all
 
     def _read_ann_info(self, idx):
         while True:
@@ -91,8 +93,15 @@ class CustomDataset:
         if self.shuffle:
             np.random.default_rng(self.seed + self.epoch).shuffle(idx)
         per = self.batch_size * self.world_size
-        n = (len(idx) // per) * per if (self.drop_last or self.world_size > 1) else len(idx)
-        idx = idx[:n] if n else idx
+        if self.world_size > 1 and not getattr(self, "shard_keep_all", False):
+            # every rank must run the same number of steps (DDP's all-reduce is collective): trim to whole global
+            # batches, and refuse a dataset that cannot fill even one
+            if len(idx) < per:
+                raise ValueError("dataset of %d images cannot fill one batch of %d on each of %d ranks"
+                                 % (len(idx), self.batch_size, self.world_size))
+            idx = idx[:(len(idx) // per) * per]
+        elif self.drop_last:
+            idx = idx[:(len(idx) // per) * per]
         return idx[self.rank::self.world_size] if self.world_size > 1 else idx
 
     def __iter__(self):

@@ -1,0 +1,75 @@
+"""ImageDataset (/root/reference/python/jdet/data/image.py:14-110): a folder (or list) of images WITHOUT ground
+truth, for ``Runner.test`` -- the tile stream whose detections ``data_merge_result`` stitches back into whole-image
+submissions.  Same iteration / sharding protocol as CustomDataset."""
+import os
+import pickle
+
+import numpy as np
+from PIL import Image
+
+from rs_detection_amd.utils.registry import DATASETS
+from .transforms import Compose
+
+_IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".tif", ".tiff")
+_DEFAULT_TF = (dict(type="Resize", min_size=[800], max_size=1333), dict(type="Pad", size_divisor=32),
+               dict(type="Normalize", mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375]))
+
+
+@DATASETS.register_module()
+class ImageDataset:
+    def __init__(self, images_file=None, images_dir="", dataset_type="DOTA", transforms=_DEFAULT_TF, batch_size=1,
+                 num_workers=0, shuffle=False):
+        self.images_file = self._load_images(images_file, images_dir)
+        self.total_len, self.dataset_type = len(self.images_file), dataset_type
+        self.batch_size, self.num_workers, self.shuffle = batch_size, num_workers, shuffle
+        if isinstance(transforms, (list, tuple)):
+            transforms = Compose(list(transforms))
+        if transforms is not None and not callable(transforms):
+            raise TypeError("transforms must be list or callable")
+        self.transforms = transforms
+        self.rank, self.world_size = 0, 1
+
+    @staticmethod
+    def _load_images(images_file, images_dir):
+        if not images_file:
+            names = sorted(n for n in os.listdir(images_dir) if n.lower().endswith(_IMG_EXT))
+        elif isinstance(images_file, (list, tuple)):
+            names = list(images_file)
+        elif isinstance(images_file, str):
+            assert os.path.exists(images_file), f"{images_file} must be a file or list"
+            with open(images_file, "rb") as f:
+                names = [i["filename"] if isinstance(i, dict) else i for i in pickle.load(f)]
+        else:
+            raise NotImplementedError
+        return [os.path.join(images_dir, n) for n in names]
+
+    def __len__(self):
+        return self.total_len
+
+    def set_epoch(self, epoch):
+        pass
+
+    def set_shard(self, rank, world_size, keep_all=True):
+        self.rank, self.world_size = rank, world_size
+
+    def __getitem__(self, index):
+        if "BATCH_IDX" in os.environ:
+            index = int(os.environ['BATCH_IDX'])
+        img = Image.open(self.images_file[index]).convert("RGB")
+        targets = dict(ori_img_size=img.size, img_size=img.size, scale_factor=1., img_file=self.images_file[index])
+        if self.transforms:
+            img, targets = self.transforms(img, targets)
+        return img, targets
+
+    def collate_batch(self, batch):
+        imgs, anns = [b[0] for b in batch], [b[1] for b in batch]
+        mh, mw = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+        out = np.zeros((len(imgs), 3, mh, mw), np.float32)
+        for i, im in enumerate(imgs):
+            out[i, :, :im.shape[-2], :im.shape[-1]] = im
+        return out, anns
+
+    def __iter__(self):
+        idx = np.arange(self.total_len)[self.rank::self.world_size]
+        for s in range(0, len(idx), self.batch_size):
+            yield self.collate_batch([self[int(i)] for i in idx[s:s + self.batch_size]])

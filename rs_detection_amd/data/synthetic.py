@@ -1,0 +1,111 @@
+"""SyntheticDOTADataset: the deterministic DOTA-shaped tile stream of SURVEY 8(d) behind the dataset protocol of
+data/custom.py (``set_shard`` / ``set_epoch`` / ``__iter__`` yielding ``(images ndarray, target dicts)``).
+
+Two kinds of pixels: ``render=False`` -- N(0,1) noise, what the throughput metric is defined on (the step time does
+not depend on the pixel values); ``render=True`` -- every ground-truth box is painted as a filled rotated rectangle in
+its class colour over a dim noise background, so a detector can actually LEARN the set (tests/test_gpu_learning.py:
+the stand-in for the reference's mAP gate, DOTA itself being unavailable offline).  ``evaluate`` is DOTADataset's
+(polygon IoU + VOC AP on the GPU)."""
+import numpy as np
+
+from rs_detection_amd.utils import synthetic as syn
+from rs_detection_amd.utils.registry import DATASETS
+from .box_np import rotated_box_to_poly_np
+
+# 16 well separated colours (normalised units: roughly what Normalize leaves of 0..255 pixels)
+_PALETTE = np.array([[2.0, -1.5, -1.5], [-1.5, 2.0, -1.5], [-1.5, -1.5, 2.0], [2.0, 2.0, -1.5], [2.0, -1.5, 2.0],
+                     [-1.5, 2.0, 2.0], [2.0, 0.3, -1.5], [0.3, -1.5, 2.0], [-1.5, 0.3, 0.3], [2.0, 2.0, 2.0],
+                     [0.3, 2.0, -1.5], [-1.5, -1.5, -1.5], [1.2, -0.5, 0.6], [-0.5, 1.2, 0.6], [0.6, 0.6, -1.5],
+                     [1.0, 1.0, 0.0]], np.float32)
+
+
+def render_tile(rboxes, labels, size, rng):
+    """(3,size,size) float32: dim noise + one filled rotated rectangle per box (PIL polygon fill), later boxes on top."""
+    from PIL import Image, ImageDraw
+    img = (0.15 * rng.standard_normal((3, size, size))).astype(np.float32)
+    if len(rboxes) == 0:
+        return img
+    polys = rotated_box_to_poly_np(np.asarray(rboxes, np.float32), 'le135') if rboxes.shape[1] == 5 else rboxes
+    mask = Image.new("I", (size, size), 0)
+    draw = ImageDraw.Draw(mask)
+    for i, p in enumerate(polys):
+        draw.polygon([(float(p[2 * j]), float(p[2 * j + 1])) for j in range(4)], fill=int(labels[i]))
+    m = np.asarray(mask, dtype=np.int32)
+    on = m > 0
+    col = _PALETTE[(m[on] - 1) % len(_PALETTE)]
+    for c in range(3):
+        img[c][on] = col[:, c] + 0.05 * img[c][on]
+    return img
+
+
+@DATASETS.register_module()
+class SyntheticDOTADataset:
+    def __init__(self, tile=1024, batch_size=4, num_classes=15, k_cycle=(16, 100, 400, 40), num_images=None,
+                 seed=1234, render=False, shuffle=False, drop_last=False, min_size=(10, 5), max_size=(160, 64),
+                 version='1', transforms=None, num_workers=0):
+        self.tile, self.batch_size, self.num_classes = int(tile), int(batch_size), int(num_classes)
+        self.k_cycle = tuple(int(k) for k in k_cycle)
+        self.total_len = int(num_images) if num_images is not None else 4 * self.batch_size * len(self.k_cycle)
+        self.seed, self.render, self.shuffle, self.drop_last = seed, render, shuffle, drop_last
+        self.min_size, self.max_size = min_size, max_size
+        from rs_detection_amd.config.constant import get_classes_by_name
+        self.CLASSES = get_classes_by_name('DOTA' + version)[:self.num_classes]
+        self.epoch, self.rank, self.world_size = 0, 0, 1
+
+    def __len__(self):
+        return self.total_len
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def set_shard(self, rank, world_size, keep_all=False):
+        self.rank, self.world_size, self.shard_keep_all = rank, world_size, keep_all
+
+    def _boxes(self, rng, k):
+        s = float(self.tile)
+        w = rng.uniform(self.min_size[0], min(self.max_size[0], s / 2), k)
+        h = rng.uniform(self.min_size[1], np.minimum(w, self.max_size[1]))
+        return np.stack([rng.uniform(0, s, k), rng.uniform(0, s, k), w, h,
+                         rng.uniform(-np.pi / 4, 3 * np.pi / 4, k)], 1).astype(np.float32)
+
+    def __getitem__(self, idx):
+        """Image ``idx`` is a pure function of (seed, idx): every epoch and every rank sees the same image for it."""
+        rng = np.random.default_rng([self.seed, int(idx)])
+        k = self.k_cycle[int(idx) % len(self.k_cycle)]
+        rboxes = self._boxes(rng, k)
+        labels = rng.integers(1, self.num_classes + 1, k).astype(np.int32)
+        if self.render:
+            img = render_tile(rboxes, labels, self.tile, rng)
+        else:
+            img = rng.standard_normal((3, self.tile, self.tile), dtype=np.float32)
+        from .box_np import rotated_box_to_bbox_np
+        hboxes, polys = rotated_box_to_bbox_np(rboxes)
+        name = "synthetic_%06d" % int(idx)
+        tgt = dict(rboxes=rboxes, hboxes=hboxes.astype(np.float32), polys=polys.astype(np.float32), labels=labels,
+                   rboxes_ignore=np.zeros((0, 5), np.float32), classes=self.CLASSES,
+                   ori_img_size=(self.tile, self.tile), img_size=(self.tile, self.tile),
+                   pad_shape=(self.tile, self.tile), scale_factor=1.0, filename=name + ".png", img_file=name)
+        return img, tgt
+
+    def _indices(self):
+        idx = np.arange(self.total_len)
+        if self.shuffle:
+            np.random.default_rng(self.seed + 7919 * (self.epoch + 1)).shuffle(idx)
+        per = self.batch_size * self.world_size
+        if (self.world_size > 1 and not getattr(self, "shard_keep_all", False)) or self.drop_last:
+            if len(idx) < per:
+                raise ValueError("dataset of %d images cannot fill one batch of %d on each of %d ranks"
+                                 % (len(idx), self.batch_size, self.world_size))
+            idx = idx[:(len(idx) // per) * per]
+        return idx[self.rank::self.world_size] if self.world_size > 1 else idx
+
+    def __iter__(self):
+        idx = self._indices()
+        for s in range(0, len(idx), self.batch_size):
+            chunk = idx[s:s + self.batch_size]
+            items = [self[int(i)] for i in chunk]
+            yield np.stack([i[0] for i in items]), [i[1] for i in items]
+
+    def evaluate(self, results, work_dir=None, epoch=0, logger=None, device="cuda", pairwise=None):
+        from .devkits import evaluate_dota
+        return evaluate_dota(results, self.CLASSES, device=device, pairwise=pairwise)

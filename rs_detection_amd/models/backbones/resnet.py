@@ -148,7 +148,9 @@ class ResNet(nn.Module):
 def _factory(block, layers, hub):
     def make(pretrained=False, **kwargs):
         model = ResNet(block, layers, **kwargs)
-        model.pretrained_source = f"jittorhub://{hub}.pkl" if pretrained else None  # no network: not fetched
+        model.pretrained_source = f"jittorhub://{hub}.pkl" if pretrained else None
+        from rs_detection_amd.runner.checkpoint import load_pretrained
+        model.pretrained_report = load_pretrained(model, hub, pretrained)   # warns loudly when nothing is available
         return model
     return make
 

@@ -155,15 +155,17 @@ class VAN(nn.Module):
         return outs
 
 
-def _variant(dims, ratios, depths):
+def _variant(dims, ratios, depths, name=None):
     def make(pretrained=False, **kwargs):
         m = VAN(embed_dims=dims, mlp_ratios=ratios, norm_layer=nn.LayerNorm, depths=depths, **kwargs)
-        m.pretrained_requested = bool(pretrained)  # no network: ImageNet weights are not fetched
+        m.pretrained_requested = bool(pretrained)
+        from rs_detection_amd.runner.checkpoint import load_pretrained
+        m.pretrained_report = load_pretrained(m, name or "van", pretrained)   # warns loudly when nothing is available
         return m
     return make
 
 
-van_b0 = BACKBONES.register_module(name="van_b0", module=_variant([32, 64, 160, 256], [8, 8, 4, 4], [3, 3, 5, 2]))
-van_b1 = BACKBONES.register_module(name="van_b1", module=_variant([64, 128, 320, 512], [8, 8, 4, 4], [2, 2, 4, 2]))
-van_b2 = BACKBONES.register_module(name="van_b2", module=_variant([64, 128, 320, 512], [8, 8, 4, 4], [3, 3, 12, 3]))
-van_b3 = BACKBONES.register_module(name="van_b3", module=_variant([64, 128, 320, 512], [8, 8, 4, 4], [3, 5, 27, 3]))
+van_b0 = BACKBONES.register_module(name="van_b0", module=_variant([32, 64, 160, 256], [8, 8, 4, 4], [3, 3, 5, 2], "van_b0"))
+van_b1 = BACKBONES.register_module(name="van_b1", module=_variant([64, 128, 320, 512], [8, 8, 4, 4], [2, 2, 4, 2], "van_b1"))
+van_b2 = BACKBONES.register_module(name="van_b2", module=_variant([64, 128, 320, 512], [8, 8, 4, 4], [3, 3, 12, 3], "van_b2"))
+van_b3 = BACKBONES.register_module(name="van_b3", module=_variant([64, 128, 320, 512], [8, 8, 4, 4], [3, 5, 27, 3], "van_b3"))

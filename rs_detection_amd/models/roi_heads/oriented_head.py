@@ -271,7 +271,9 @@ class OrientedHead(nn.Module):
             return self.loss(scores, deltas, rois, *self.get_bboxes_targets(sampling_results))
         result = []
         for i in range(len(targets)):
-            scores, deltas, rois = self.forward_single(x, [proposal_list[i]], test=True)
+            # arb2roi numbers the RoIs of a one-element list as image 0: hand it image i's slice of the pyramid (the
+            # reference passes the whole batch, oriented_head.py:610-613, which pools images i>0 from image 0)
+            scores, deltas, rois = self.forward_single([f[i:i + 1] for f in x], [proposal_list[i]], test=True)
             det, labels = self.get_bboxes(rois, scores, deltas, targets[i]['img_size'], targets[i]['scale_factor'],
                                           rescale=True)
             result.append((det[:, :8], det[:, 8], labels))

@@ -76,10 +76,41 @@ class StepLR(WarmUpLR):
 
 
 @SCHEDULERS.register_module()
-class CosineAnnealingLR(WarmUpLR):
-    def __init__(self, max_steps, min_lr=0., **kwargs):
-        self.max_steps, self.min_lr = max_steps, min_lr
+class CosineAnnealingLR:
+    """The SWA phase's schedule (lr_scheduler.py:274-320): built as ``(optimizer, min_lr | min_lr_ratio)`` and stepped
+    with ``step(factor)``, ``factor = batch_idx / batches_per_epoch`` in [0, 1) -- one cosine half-wave from the base
+    learning rate down to the target within EVERY epoch (runner.py:142-146), no warm-up."""
+
+    def __init__(self, optimizer, min_lr=None, min_lr_ratio=None):
+        self.optimizer, self.min_lr, self.min_lr_ratio = optimizer, min_lr, min_lr_ratio
+        self.base_lr = optimizer.lr
+        self.base_lr_pg = [pg.get("lr", optimizer.lr) for pg in optimizer.param_groups]
+        self.step(0, 0)
+
+    def get_lr(self, base_lr, factor):
+        target = base_lr * self.min_lr_ratio if self.min_lr_ratio is not None else self.min_lr
+        return target + 0.5 * (base_lr - target) * (math.cos(math.pi * factor) + 1)
+
+    def step(self, factor, placeholder=None, **_):
+        self.optimizer.lr = self.get_lr(self.base_lr, factor)
+        for i, pg in enumerate(self.optimizer.param_groups):
+            pg["lr"] = self.get_lr(self.base_lr_pg[i], factor)
+
+    def parameters(self):
+        return {k: v for k, v in self.__dict__.items() if k != 'optimizer'}
+
+    def load_parameters(self, data):
+        if isinstance(data, dict):
+            for k, v in data.items():
+                if k in self.__dict__:
+                    self.__dict__[k] = v
+
+
+@SCHEDULERS.register_module()
+class ExpLR(WarmUpLR):
+    def __init__(self, gamma, **kwargs):
+        self.gamma = gamma
         super().__init__(**kwargs)
 
     def get_lr(self, base_lr, steps):
-        return self.min_lr + 0.5 * (base_lr - self.min_lr) * (1 + math.cos(math.pi * min(steps, self.max_steps) / self.max_steps))
+        return base_lr * self.gamma ** steps

@@ -90,3 +90,31 @@ def average_checkpoints(paths):
                     acc[k] = acc[k] + np.asarray(v, dtype=np.float64)
         n += 1
     return {k: (v / n).astype(np.float32) if v.dtype == np.float64 else v for k, v in acc.items()}
+
+
+def load_pretrained(model, name, pretrained):
+    """``pretrained=...`` of a backbone factory (resnet.py:206-209 ``jittorhub://resnet50.pkl``, van.py ``load_model``).
+    ``pretrained`` may be a path to a ``.pkl`` / ``.pth`` parameter dict; ``True`` looks for ``$RSDET_PRETRAINED_DIR/<name>.pkl``
+    (there is no network to download from).  When nothing can be loaded the weights stay at random init and that is
+    said LOUDLY -- an accuracy run on random backbones is not what the config asked for."""
+    import os
+    import warnings
+    if not pretrained:
+        return None
+    path = pretrained if isinstance(pretrained, str) else None
+    if path is None and os.environ.get("RSDET_PRETRAINED_DIR"):
+        for ext in (".pkl", ".pth"):
+            cand = os.path.join(os.environ["RSDET_PRETRAINED_DIR"], name + ext)
+            if os.path.isfile(cand):
+                path = cand
+                break
+    if path is None or not os.path.isfile(path):
+        warnings.warn("pretrained=%r requested for %s but no weight file is available offline (set RSDET_PRETRAINED_DIR "
+                      "or pass a path; Runner.load(<converted .pkl>, model_only=True) also works): the backbone stays at "
+                      "RANDOM initialisation" % (pretrained, name), RuntimeWarning, stacklevel=3)
+        return None
+    data = torch.load(path, map_location="cpu") if path.endswith(".pth") else read_checkpoint(path)
+    rep = load_parameters(model, model_parameters(data))
+    if not rep[0]:
+        warnings.warn("pretrained file %s matched no parameter of %s" % (path, name), RuntimeWarning, stacklevel=3)
+    return rep

@@ -20,7 +20,7 @@ from rs_detection_amd.utils.registry import MODELS, OPTIMS, SCHEDULERS, build_fr
 
 
 class Runner:
-    def __init__(self, cfg, device=None, distributed=None, memory_format=None, amp_dtype=None):
+    def __init__(self, cfg, device=None, distributed=None, memory_format=None, amp_dtype=None, grad_dtype="auto"):
         self.cfg = cfg
         from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db
         use_packaged_miopen_db()  # tuned MIOpen solver records of the shipped configs (before the first convolution)
@@ -40,16 +40,26 @@ class Runner:
         self.optimizer = build_from_cfg(cfg.optimizer, OPTIMS, params=params) if cfg.optimizer else None
         self.scheduler = build_from_cfg(cfg.scheduler, SCHEDULERS, optimizer=self.optimizer) \
             if (cfg.scheduler and self.optimizer) else None
+        # the SWA phase (runner.py:51-53): its own optimizer + per-epoch cosine schedule over the same parameters
+        self.swa_start_epoch = getattr(cfg, "swa_start_epoch", None)
+        self.optimizer_swa = build_from_cfg(cfg.optimizer_swa, OPTIMS, params=params) \
+            if getattr(cfg, "optimizer_swa", None) else None
+        self.scheduler_swa = build_from_cfg(cfg.scheduler_swa, SCHEDULERS, optimizer=self.optimizer_swa) \
+            if (getattr(cfg, "scheduler_swa", None) and self.optimizer_swa) else None
         if distributed is None:
             distributed = self.world > 1
-        self.ddp = rdist.wrap_ddp(self.model, device) if distributed else self.model
+        # gradient buckets travel in bf16 when the step computes in bf16 (BASELINE configs[2..4]); fp32 otherwise
+        self.grad_dtype = (amp_dtype if amp_dtype == torch.bfloat16 else None) if grad_dtype == "auto" else grad_dtype
+        self.ddp = rdist.wrap_ddp(self.model, device, grad_dtype=self.grad_dtype) if distributed else self.model
         self.iter, self.epoch = 0, 0
         self.max_epoch = cfg.max_epoch if hasattr(cfg, "max_epoch") else None
         self.max_iter = cfg.max_iter if hasattr(cfg, "max_iter") else None
-        self.train_dataset = self.val_dataset = None
+        self.train_dataset = self.val_dataset = self.test_dataset = None
         self.work_dir = None
 
-    def train_step(self, images, targets):
+    def train_step(self, images, targets, swa_factor=None):
+        """One iteration (:138-150).  ``swa_factor`` = batch_idx / batches_per_epoch switches to the SWA optimizer and
+        its schedule (:142-146); None = the main optimizer + ``scheduler.step(iter, epoch)``."""
         # model.train() walks ~570 modules and re-applies norm_eval / frozen stages: 2.3 ms of host time, so it runs on
         # the first step and whenever something (val(), a caller) has put the model into eval mode, not on every step
         if not (self.model.training and getattr(self, "_train_mode_applied", False)):
@@ -63,10 +73,15 @@ class Runner:
         else:
             losses = self.ddp(images, targets)
         total, parsed = parse_losses(losses)
-        self.optimizer.zero_grad(set_to_none=True)
+        swa = swa_factor is not None and self.optimizer_swa is not None
+        opt = self.optimizer_swa if swa else self.optimizer
+        opt.zero_grad(set_to_none=True)
         total.backward()
-        self.optimizer.step()
-        if self.scheduler is not None:
+        opt.step()
+        if swa:
+            if self.scheduler_swa is not None:
+                self.scheduler_swa.step(swa_factor)
+        elif self.scheduler is not None:
             self.scheduler.step(self.iter, self.epoch, by_epoch=True)
         self.iter += 1
         return total, parsed
@@ -82,6 +97,8 @@ class Runner:
             self.train_dataset.set_shard(self.rank, self.world)
         if ds.get("val"):
             self.val_dataset = build_from_cfg(ds["val"], DATASETS)
+        if ds.get("test"):
+            self.test_dataset = build_from_cfg(ds["test"], DATASETS)
         self.work_dir = work_dir
         return self
 
@@ -95,14 +112,19 @@ class Runner:
         """One epoch over ``train_dataset`` (:131-179)."""
         from rs_detection_amd.data import batch_to_device
         self.train_dataset.set_epoch(self.epoch)
+        self.model.train()                                        # once per epoch, as :133
+        self._train_mode_applied = True
         start, last = time.time(), None
+        swa = self.swa_start_epoch is not None and self.epoch >= self.swa_start_epoch and self.optimizer_swa is not None
+        n_batches = max(len(self.train_dataset._indices()) // max(self.train_dataset.batch_size, 1), 1)
         for batch_idx, (images, targets) in enumerate(self.train_dataset):
             images, targets = batch_to_device(images, targets, self.device)
-            total, losses = self.train_step(images, targets)      # train_step advances self.iter
+            # train_step advances self.iter
+            total, losses = self.train_step(images, targets, swa_factor=batch_idx / n_batches if swa else None)
             last = total
             if log_interval and self.iter % log_interval == 0 and self.rank == 0:
                 fps = len(targets) * self.world * (batch_idx + 1) / (time.time() - start)
-                print("epoch %d iter %d lr %.5f loss %.4f fps %.1f " % (self.epoch, self.iter, self.optimizer.cur_lr(),
+                print("epoch %d iter %d lr %.5f loss %.4f fps %.1f " % (self.epoch, self.iter, (self.optimizer_swa if swa else self.optimizer).cur_lr(),
                                                                       float(total.detach()), fps) +
                       " ".join("%s %.4f" % (k, float(v.detach())) for k, v in losses.items()))
             if self.finish:
@@ -111,16 +133,41 @@ class Runner:
         return last
 
     @torch.no_grad()
-    def val(self):
-        """:196-208 on rank 0: predictions of ``val_dataset`` -> ``val_dataset.evaluate`` (DOTA mAP on the GPU)."""
-        if self.val_dataset is None or self.rank != 0:
-            return None
+    def _predict_dataset(self, dataset, flip_test=()):
+        """Predictions of this rank's shard of ``dataset`` (every image exactly once over the ranks), gathered on every
+        rank: [((polys, scores, labels) as NumPy, target)] in dataset order of each shard.  ``flip_test`` adds the
+        predictions of the 'H' / 'V' / 'HV' flipped images, tagged ``flip_mode`` (:221-235)."""
+        import copy
         from rs_detection_amd.data import batch_to_device
+        dataset.set_shard(self.rank, self.world, keep_all=True)
         results = []
-        for images, targets in self.val_dataset:
+
+        def to_np(pred):
+            polys, scores, labels = pred
+            return polys.double().cpu().numpy(), scores.cpu().numpy(), labels.long().cpu().numpy()
+
+        for images, targets in dataset:
             timg, ttg = batch_to_device(images, targets, self.device)
-            for (polys, scores, labels), t in zip(self.predict(timg, ttg), targets):
-                results.append(((polys.double().cpu().numpy(), scores.cpu().numpy(), labels.long().cpu().numpy()), t))
+            for pred, t in zip(self.predict(timg, ttg), targets):
+                results.append((to_np(pred), t))
+            for mode in flip_test:
+                dims = {"H": (3,), "V": (2,), "HV": (2, 3)}[mode]
+                for pred, t in zip(self.predict(torch.flip(timg, dims), ttg), targets):
+                    t = copy.deepcopy(t)
+                    t["flip_mode"] = mode
+                    results.append((to_np(pred), t))
+        gathered = rdist.gather_objects(results)    # also the barrier that keeps the ranks together after a long eval
+        return [r for part in gathered for r in part]
+
+    def val(self):
+        """:196-208: predictions of ``val_dataset`` -> ``val_dataset.evaluate`` (DOTA mAP on the GPU).  The reference
+        evaluates on rank 0 alone while the others wait; here the images are sharded over the ranks and gathered, so
+        no rank sits in the next epoch's all-reduce while another is still evaluating."""
+        if self.val_dataset is None:
+            return None
+        results = self._predict_dataset(self.val_dataset)
+        if self.rank != 0:
+            return None
         return self.val_dataset.evaluate(results, self.work_dir, self.epoch, device=self.device)
 
     def run(self, checkpoint_interval=None, eval_interval=None, log_interval=50):

@@ -2,11 +2,18 @@
 
 Replaces Jittor's MPI launcher + in-optimizer gradient all-reduce
 (/root/reference/python/jdet/optims/optimizer.py:30-31 -> jittor Optimizer.pre_step;
-metric sync /root/reference/python/jdet/utils/general.py:30-48).  The path shards by
-image (pure data parallelism): each rank draws its own tiles; the only
-collective is the bucketed gradient all-reduce DDP overlaps with backward.
+metric sync /root/reference/python/jdet/utils/general.py:30-48; launcher ``mpirun -np 8 python tools/run_net.py``,
+/root/reference/README_competition.md:79-80).  The path shards by image (pure data parallelism): each rank
+draws its own tiles; the only collective is the bucketed gradient all-reduce DDP overlaps with backward.
+
+``launch_ranks`` is the launcher half: it starts one child process per rank BEFORE the calling process has touched
+the GPU (a process that has initialised HIP must never be replaced or forked into ranks) and relays rank 0's output.
 """
+import datetime
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -16,7 +23,26 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed(backend=None):
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def pick_backend():
+    """RCCL when every rank has a GPU of its own; gloo when ranks have to share a device (RCCL refuses two ranks on
+    one GPU) or there is none.  ``RSDET_DIST_BACKEND`` overrides.  ``device_count`` does not initialise HIP."""
+    forced = os.environ.get("RSDET_DIST_BACKEND")
+    if forced:
+        return forced
+    _, _, world = env_world()
+    n = torch.cuda.device_count()
+    return "nccl" if (n >= world and n > 0) else "gloo"
+
+
+def init_distributed(backend=None, timeout_s=1800):
     """Initialise the default process group from torchrun env vars (no-op for world size 1)."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
@@ -24,23 +50,43 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = os.environ.get("RSDET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = pick_backend()
         if backend == "nccl":
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s))
     return rank, local_rank, world
 
 
-def wrap_ddp(model, device, bucket_cap_mb=64):
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_parameters=False):
     """DDP with gradient-as-bucket-view; 64 MB buckets: the 145 MB fp32 gradient set of
     S2ANet-R50 goes out as ~3 large all-reduces (per-link-bound ring over xGMI favours few,
-    large messages) that overlap with the backbone backward."""
+    large messages) that overlap with the backbone backward.
+
+    ``grad_dtype=torch.bfloat16`` (the bf16 configs, BASELINE configs[2..4]): every bucket is rounded to bf16 for the
+    wire and widened again before the optimizer sees it (torch's ``bf16_compress_hook``), which halves the bytes per
+    xGMI link (72 MB instead of 145 MB per step); the master gradients and the SGD update stay fp32.
+
+    The model's only graph-less parameters (RotationInvariantPooling's unused conv/BN) are frozen
+    (``requires_grad=False``), so DDP never waits for them and ``find_unused_parameters`` can stay off."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if device.type == "cuda" else None
-    return DDP(model, device_ids=ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
-               broadcast_buffers=False, find_unused_parameters=False)
+    ddp = DDP(model, device_ids=ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
+              broadcast_buffers=False, find_unused_parameters=find_unused_parameters)
+    if grad_dtype == torch.bfloat16:
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
+    elif grad_dtype == torch.float16:
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        ddp.register_comm_hook(None, default_hooks.fp16_compress_hook)
+    return ddp
 
 
 def barrier():
@@ -63,3 +109,55 @@ def sync_mean(values, device):
         dist.all_reduce(t)
         t /= dist.get_world_size()
     return dict(zip(keys, t.tolist()))
+
+
+def gather_objects(obj):
+    """Every rank's picklable ``obj`` as a list on every rank (the sharded evaluation of Runner.val)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def launch_ranks(nproc, argv, env=None, timeout=None):
+    """Start ``nproc`` ranks of ``python argv...`` as CHILD processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    rendezvous on 127.0.0.1), wait for all of them and return ``(worst exit code, rank 0's stdout)``.
+
+    The mpirun of the reference (README_competition.md:79-80).  Must be called before the calling process has
+    initialised the GPU: the children are fresh interpreters, nothing is exec'ed over or forked from a HIP process.
+    Ranks 1.. inherit stderr; their stdout is discarded (rank 0 prints the results)."""
+    import tempfile
+    import time
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.update(WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+                LOCAL_WORLD_SIZE=str(nproc))
+    procs, rc = [], 0
+    with tempfile.TemporaryFile() as out0:
+        for r in range(nproc):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=e,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        t0 = time.time()
+        try:
+            while any(p.poll() is None for p in procs):
+                bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+                if bad:
+                    rc = bad[0]  # a failed rank leaves the others inside a collective
+                    break
+                if timeout is not None and time.time() - t0 > timeout:
+                    rc = 124
+                    break
+                time.sleep(0.05)
+        finally:
+            for p in procs:      # end exactly the processes started here, never by pattern
+                if p.poll() is None:
+                    p.kill()
+                p.wait()
+        for p in procs:
+            if p.returncode != 0 and rc == 0:
+                rc = p.returncode
+        out0.seek(0)
+        text = out0.read().decode(errors="replace")
+    return rc, text

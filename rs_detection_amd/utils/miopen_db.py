@@ -19,6 +19,30 @@ import tempfile
 _PKG_DB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miopen_db")
 
 
+def _private_dir():
+    """A directory only this user can write: ``$XDG_CACHE_HOME|~/.cache/rsdet/miopen_db`` (mode 0700, owned by us, not
+    a symlink); a fresh ``mkdtemp`` when the home directory is not writable.  A predictable name under /tmp would let
+    another local user pre-create or symlink it and choose the solver records MIOpen loads (or where it appends)."""
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    dst = os.path.join(base, "rsdet", "miopen_db")
+    try:
+        os.makedirs(dst, mode=0o700, exist_ok=True)
+        st = os.lstat(dst)
+        import stat
+        if stat.S_ISLNK(st.st_mode) or not stat.S_ISDIR(st.st_mode):
+            raise OSError("not a plain directory")
+        if hasattr(os, "getuid") and st.st_uid != os.getuid():
+            raise OSError("owned by another user")
+        if st.st_mode & 0o022:
+            os.chmod(dst, 0o700)
+        return dst
+    except OSError:
+        try:
+            return tempfile.mkdtemp(prefix="rsdet_miopen_db_")   # 0700, unpredictable name
+        except OSError:
+            return None
+
+
 def use_packaged_miopen_db():
     """Call before the first convolution of the process (MIOpen reads the variable when its handle is created).
     Returns the directory in use, or None when nothing was changed."""
@@ -27,10 +51,10 @@ def use_packaged_miopen_db():
     files = sorted(glob.glob(os.path.join(_PKG_DB, "*db.txt")))
     if not files:
         return None
-    uid = os.getuid() if hasattr(os, "getuid") else 0
-    dst = os.path.join(tempfile.gettempdir(), "rsdet_miopen_db_%d" % uid)
+    dst = _private_dir()
+    if dst is None:
+        return None
     try:
-        os.makedirs(dst, exist_ok=True)
         for f in files:  # MIOpen appends to its user database: never hand it the packaged originals
             t = os.path.join(dst, os.path.basename(f))
             if not os.path.exists(t) or os.path.getsize(t) < os.path.getsize(f):

@@ -11,6 +11,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "launcher: starts child ranks; scheduled before the tests that initialise HIP")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests that launch child ranks run first, while the pytest process itself has not touched the GPU."""
+    items.sort(key=lambda it: 0 if it.get_closest_marker("launcher") else 1)
 
 
 @pytest.fixture(scope="session")

@@ -83,3 +83,71 @@ def test_single_process_is_a_noop():
     m = torch.nn.Linear(2, 2)
     assert rdist.wrap_ddp(m, torch.device("cpu")) is m
     assert rdist.all_reduce_max(3.5, torch.device("cpu")) == 3.5
+
+
+def test_launch_ranks_relays_rank0_and_reports_the_failing_rank():
+    from rs_detection_amd.utils import dist as rdist
+    rc, out = rdist.launch_ranks(2, ["-c", "import os; print('rank', os.environ['RANK'], 'of', os.environ['WORLD_SIZE'])"])
+    assert rc == 0 and out.strip() == "rank 0 of 2"          # only rank 0's stdout is relayed
+    # a rank that dies takes the job down with ITS exit code; the survivor (stuck in a 'collective') is ended
+    code = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(60)"
+    rc, _ = rdist.launch_ranks(2, ["-c", code], timeout=30)
+    assert rc == 7
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_self_launches_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher around it: the parent must start the ranks itself (round 1 died on
+    an assert here).  On this GPU-less container every rank then refuses to run (no CPU fallback) -> non-zero exit."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present: covered by tests/test_gpu_dist.py")
+    assert p.returncode != 0 and "AssertionError" not in p.stderr
+    assert "needs an MI355X" in p.stderr
+
+
+def _bf16_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from rs_detection_amd.utils import dist as rdist
+    rdist.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Linear(64, 64)
+    ddp = rdist.wrap_ddp(model, torch.device("cpu"), bucket_cap_mb=1, grad_dtype=torch.bfloat16)
+    x = torch.randn(8, 64, generator=torch.Generator().manual_seed(rank))
+    ddp(x).square().mean().backward()
+    g = model.weight.grad.clone()
+    # reference: fp32 mean of both ranks' gradients
+    ref = torch.nn.Linear(64, 64)
+    ref.load_state_dict(model.state_dict())
+    tot = 0
+    for r in range(world):
+        ref.zero_grad()
+        ref(torch.randn(8, 64, generator=torch.Generator().manual_seed(r))).square().mean().backward()
+        tot = tot + ref.weight.grad
+    q.put((rank, g.dtype == torch.float32, float((g - tot / world).abs().max() / (tot / world).abs().max()),
+           bool((g == g.bfloat16().float()).all())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bf16_gradient_buckets():
+    """configs[2..4]: buckets cross the wire in bf16 (half the bytes per xGMI link), gradients come back fp32."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, is_f32, rel, on_grid in out:
+        assert is_f32 and rel < 2e-2          # bf16 has 8 significant bits
+        assert on_grid                        # every value is a bf16 number: the hook really compressed the bucket

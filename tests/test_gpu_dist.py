@@ -1,0 +1,65 @@
+"""GPU: the N>1 path on real hardware with the REAL models.  The box has one GPU, so two ranks share cuda:0 and
+talk through gloo (RCCL refuses two ranks on one device; with >= 2 GPUs the same test runs over RCCL).  The ranks are
+child processes started by rs_detection_amd.utils.dist.launch_ranks -- nothing is exec'ed over or forked from a
+process that has initialised HIP -- and conftest.py schedules this module before every other GPU test so that the
+launching process itself is still GPU-free."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.launcher]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _need_gpu():
+    if torch.cuda.device_count() == 0:       # does not initialise HIP
+        pytest.skip("no GPU")
+
+
+def _run(model, dtype, tmp_path, size=256, world=2):
+    from rs_detection_amd.utils import dist as rdist
+    env = dict(os.environ)
+    if torch.cuda.device_count() < world:
+        env["RSDET_DIST_BACKEND"] = "gloo"
+    out = str(tmp_path / "res")
+    rc, text = rdist.launch_ranks(world, [WORKER, model, dtype, out, str(size)], env=env, timeout=900)
+    assert rc == 0, "a rank failed (rc %d)\n%s" % (rc, text[-2000:])
+    return [json.load(open("%s.rank%d.json" % (out, r))) for r in range(world)]
+
+
+@pytest.mark.timeout(1000)
+@pytest.mark.parametrize("model,dtype,tol", [("s2anet", "f32", 2e-4), ("s2anet", "bf16", 3e-2),
+                                             ("orcnn", "f32", 2e-4), ("orcnn", "bf16", 5e-2)])
+def test_two_rank_ddp_real_model(model, dtype, tol, tmp_path):
+    _need_gpu()
+    res = _run(model, dtype, tmp_path)
+    for r in res:
+        assert r["world"] == 2 and r["finite"]
+        # all-reduced gradients == mean of the per-shard single-process gradients (bf16: bucket rounding + autocast)
+        assert r["grad_rel_err"] < tol, r
+        assert r["param_spread"] == 0.0, r           # bit-identical parameters on both ranks after two steps
+        assert r["grad_norm"] > 0 and r["n_grad"] > 1e6
+    assert res[0]["loss"] != res[1]["loss"]          # the ranks really worked on different shards
+
+
+@pytest.mark.timeout(1000)
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE): the parent starts two child ranks and relays rank 0's
+    single JSON line (the driver's N>1 contract); exit code 0."""
+    _need_gpu()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["RSDET_BENCH_TILE"] = "256"                  # two S2ANet replicas on one GPU: keep the tiles small
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-kernels"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["global_batch"] == 2 * line["config"]["global_batch"] // 2
+    assert line["cpu_baseline"] is None              # timed at N=1 only

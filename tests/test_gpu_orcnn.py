@@ -100,3 +100,32 @@ def test_oriented_rcnn_train_step_and_eval(cuda):
     assert len(res) == 2
     polys, scores, labels = res[0]
     assert polys.shape[1] == 8 and polys.shape[0] == scores.shape[0] == labels.shape[0]
+
+
+def test_batched_inference_equals_per_image_inference(cuda):
+    """Every image pools its RoI features from ITS OWN pyramid slice (the reference hands the whole batch to a
+    per-image call whose RoIs all carry batch index 0, oriented_head.py:610-613: images i>0 then read image 0)."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.utils.registry import MODELS, build_from_cfg
+    from rs_detection_amd.utils import synthetic as syn
+    cfg = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")).dump()["model"]
+    cfg["backbone"] = dict(type="van_b0", img_size=256, num_stages=4, out_indices=(0, 1, 2, 3))
+    cfg["neck"]["in_channels"] = [32, 64, 160, 256]
+    cfg["bbox_head"]["score_thresh"] = 0.0          # random weights: keep detections to compare
+    torch.manual_seed(0)
+    model = build_from_cfg(cfg, MODELS).to(cuda).eval()
+    images = torch.randn(2, 3, 256, 256, device=cuda)
+    images[1] += 2.0 * torch.randn(1, 3, 1, 1, device=cuda)          # clearly different second image
+    targets = [dict(t, hboxes=None) for t in syn.synthetic_targets(2, img=256, num_classes=10)]
+    with torch.no_grad():
+        both = model(images, targets)
+        single = [model(images[i:i + 1], targets[i:i + 1])[0] for i in range(2)]
+    for i in range(2):
+        (p, s, l), (p1, s1, l1) = both[i], single[i]
+        assert p.shape == p1.shape and p.shape[0] > 0
+        torch.testing.assert_close(s, s1, atol=2e-4, rtol=1e-3)
+        torch.testing.assert_close(p, p1, atol=5e-2, rtol=1e-3)
+        assert (l == l1).all()
+    # and the two images do NOT give the same detections (the bug made image 1 a copy of image 0's features)
+    assert both[0][0].shape != both[1][0].shape or not torch.allclose(both[0][1], both[1][1])
