@@ -329,8 +329,8 @@ def main():
             # fewer GPUs than ranks (the 1-GPU test box): ranks share devices, which RCCL refuses -> gloo
             os.environ.setdefault("RSDET_DIST_BACKEND", "gloo")
         rc, out = rdist.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
-        sys.stdout.write(out)
-        sys.stdout.flush()
+        for ln in out.splitlines():     # ONE JSON line on stdout; anything else a rank printed (gloo's banner) -> stderr
+            print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr, flush=True)
         raise SystemExit(rc)
     rank, local_rank, world = rdist.init_distributed()
     if world != args.gpus:

@@ -1,0 +1,95 @@
+"""GPU: BASELINE configs[4] -- S2ANet-R101-FPN, bf16, multi-scale data.  In the reference "ms" is offline (images
+rescaled 0.5 / 1.0 / 1.5, then cut into 1024^2 tiles); the kernels are nevertheless exercised here at the three anchor
+counts a 512^2 / 1024^2 / 1536^2 input gives (A = 5 456 / 21 824 / 49 104): the grouped IoU + assignment against the
+NumPy twin of anchor_target at the largest one, and the whole Resnet101 model through bf16 train steps at all three."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import dota_boxes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs", "s2anet", "s2anet_r101_fpn_1x_dota_rotate_balance_ms.py")
+
+
+def _grid(size):
+    return np.concatenate([oracle.np_s2anet_grid_anchors((-(-size // s), -(-size // s)), s) for s in (8, 16, 32, 64, 128)])
+
+
+@pytest.mark.parametrize("size,A", [(512, 5456), (1536, 49104)])
+def test_anchor_target_twin_at_ms_shapes(cuda, oracle_c, size, A):
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.models.boxes.anchor_target import anchor_target_batched
+    from test_gpu_s2anet import FAM, _np_anchor_target
+    anchors = _grid(size)
+    assert anchors.shape[0] == A
+    rng = np.random.default_rng(size)
+    ks = [60, 7, 150]
+    gts = [dota_boxes(rng, k, span=float(size)) for k in ks]
+    labs = [rng.integers(1, 16, k).astype(np.int32) for k in ks]
+    t = lambda a: torch.from_numpy(np.array(a)).to(cuda)
+    ro = torch.tensor(np.concatenate([[0], np.cumsum(ks)]), dtype=torch.int32, device=cuda)
+    got = anchor_target_batched(t(anchors), t(np.concatenate(gts)), t(np.concatenate(labs)), ro, max(ks), FAM)
+    labels, lw, bt, bw, npos, nneg = [g.cpu().numpy() for g in got]
+    tot = 0
+    for i in range(len(ks)):
+        wl, wlw, wbt, wbw, p, q = _np_anchor_target(oracle_c, anchors, gts[i], labs[i])
+        tot += max(p, 1)
+        assert (labels[i] == wl).all() and (lw[i] == wlw).all() and (bw[i] == wbw).all()
+        np.testing.assert_allclose(bt[i], wbt, rtol=1e-5, atol=1e-5)
+        assert p > 0
+    assert int(npos) == tot
+
+
+def _targets(cuda, n, size, k):
+    from rs_detection_amd.utils import synthetic as syn
+    out = []
+    for t in syn.synthetic_targets(n, img=size):
+        t = dict(t)
+        t["rboxes"] = torch.from_numpy(t["rboxes"][:k]).to(cuda)
+        t["labels"] = torch.from_numpy(t["labels"][:k]).to(cuda)
+        out.append(t)
+    return out
+
+
+def test_config4_builds_resnet101():
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.utils.registry import MODELS, build_from_cfg
+    import rs_detection_amd.models  # noqa: F401
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        m = build_from_cfg(Config(CFG).model, MODELS)
+    assert len(m.backbone.layer3) == 23                       # Resnet101: [3, 4, 23, 3]
+    trainable = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert abs(trainable / 1e6 - 55.2) < 0.1                  # 55.2 M for R101
+
+
+@pytest.mark.parametrize("size,batch", [(512, 2), (1024, 2), (1536, 1)])
+def test_r101_bf16_train_step_at_ms_shapes(cuda, size, batch):
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.runner.runner import Runner
+    import warnings
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        runner = Runner(Config(CFG), device=cuda, distributed=False, amp_dtype=torch.bfloat16)
+    images = torch.randn(batch, 3, size, size, device=cuda)
+    targets = _targets(cuda, batch, size, 40)
+    first = None
+    for _ in range(2):
+        total, parsed = runner.train_step(images, targets)
+        assert np.isfinite(float(total)), parsed
+        first = first if first is not None else float(total)
+    head = runner.model.bbox_head
+    for p in (head.align_conv.deform_conv.weight, head.or_conv.weight, head.odm_reg.weight,
+              runner.model.backbone.layer3[22].conv2.weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+    runner.model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        res = runner.model(images, targets)
+    assert len(res) == batch and all(r[0].shape[1] == 8 for r in res)
