@@ -59,6 +59,76 @@ int rsdet_box_iou_rotated_grouped_f32(const float* boxes1, int n1, int stride1,
                                       int stride2, long long group_stride2, int version,
                                       float* ious, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- a1/a4/a5/a6/a7  rotated IoU in one launch, and the fused (sparse) anchor targets ---------------
+ * (csrc/anchor_target.hip)
+ *
+ * Prepared column sets: fp64 sincos once per box -> 40-byte prepared boxes + the bounding box of
+ * every 64 consecutive bounding circles.  Cacheable by the caller: S2ANet's FAM anchor grid never
+ * changes (s2anet_head.py:224-228 caches the grid itself for the same reason).  boxes (n_total,
+ * stride>=5) = n_total / n_per_group slabs of n_per_group boxes (one slab per image for per-image
+ * anchors).  prepared: rsdet_iou_prepared_bytes() bytes, 16-byte aligned. */
+size_t rsdet_iou_prepared_bytes(long long n_total, int n_per_group);
+int rsdet_iou_prepare_f32(const float* boxes, long long n_total, int n_per_group, int stride,
+                          void* prepared, size_t prepared_bytes, void* stream);
+
+/* Dense IoU matrix, ONE launch: every 16 x 256 tile is detected, zero-filled and clipped by the
+ * workgroup that owns it (each element stored exactly once).  Same values as
+ * rsdet_box_iou_rotated_f32 (same clipper), which keeps the three-launch form.
+ * Replaces ops/box_iou_rotated.py:502-509 and the per-image loop anchor_target.py:60-72.
+ * row_offsets (n_groups+1 device ints) groups the rows of boxes1 / ious; NULL = one group.
+ * tile_table: optional n_row_tiles x {group, first row, rows (<=16), first row of the group} device
+ * ints, built by a caller that knows the gt counts on the host (no empty workgroups); NULL = a
+ * n_groups x ceil(max_rows_per_group / 16) grid with early exits.
+ * prepared2 = rsdet_iou_prepare_f32 of the columns; per_group != 0: one column slab per group.
+ * prepared1 = rsdet_iou_prepare_f32(boxes1, n1, n1, ...) or NULL (then every workgroup runs the fp64
+ * sincos of its 16 rows itself).
+ * heavy_from_col: performance hint, never correctness -- columns >= it hold LARGE boxes (the anchors of
+ * the top pyramid levels overlap ~10x more gts); their tiles are cut into four 4-row sub-tiles so that
+ * no single workgroup becomes the tail of the launch.  n2 (or any value >= n2): no such columns. */
+int rsdet_box_iou_rotated_tiled_f32(const float* boxes1, int n1, int stride1, const int* row_offsets,
+                                    int n_groups, int max_rows_per_group, const int* tile_table,
+                                    int n_row_tiles, const void* prepared1, const void* prepared2, int n2,
+                                    int per_group, int heavy_from_col, int version, float* ious,
+                                    void* stream);
+
+/* anchor_target for a whole batch WITHOUT the (K, A) matrix: rotated IoU of the surviving pairs only
+ * (1.2 % at S2ANet shapes) -> MaxIoUAssigner (column max / first argmax, thresholds, low-quality
+ * rule with gt_max_assign_all = True: the LAST gt whose IoU equals its row maximum; a gt that
+ * overlaps no anchor has row maximum 0 and, with min_pos_iou <= 0, claims every anchor) ->
+ * PseudoSampler -> DeltaXYWHA encode of the positives -> labels / weights / counts.  Two launches
+ * (tiles: detect + clip; column maxima by device-scope 64-bit atomic max, row maxima, and the few
+ * pairs that equal their row's maximum inside the tile as entries; finish: one workgroup per
+ * (256 anchors, image) applies the low-quality rule to those entries and writes the targets).
+ * Replaces anchor_target.py:18-180, assigner.py:65-170, sampler.py:114-130, box_ops.py:184-230,
+ * box_iou_rotated.py:502-509 for the batch.  Results equal the dense path's
+ * (rsdet_box_iou_rotated_grouped_f32 -> rsdet_assign_wrt_overlaps_f32 -> rsdet_bbox2delta_rotated_f32)
+ * bit for bit on finite boxes.
+ *   gt_boxes (n1, stride1), gt_labels (n1) or NULL (then positives get label 1),
+ *   anchors (n2, stride2) shared, or (n_groups, n2, stride2) when per_group != 0; prepared2 as above;
+ *   prepared_gt = rsdet_iou_prepare_f32(gt_boxes, n1, n1, ...) or NULL (prepared inside);
+ *   valid (n_groups, n2) uint8 or NULL: anchors outside it are ignored (gt_inds -1, weights 0) and
+ *   take no part in the row maxima (anchor_target.py:124-130 subsets them away);
+ *   tile_table / n_row_tiles / heavy_from_col as for rsdet_box_iou_rotated_tiled_f32; group_tile0
+ *   (n_groups+1 device ints: first row tile of each group) goes with tile_table: both or neither.
+ * Outputs, each optional (NULL): gt_inds / max_overlaps / labels / label_weights (n_groups, n2),
+ * bbox_targets / bbox_weights (n_groups, n2, 5), totals[2] = { sum_g max(#pos_g, 1),
+ * sum_g max(#neg_g, 1) } (anchor_target.py:79-80).
+ *   state: rsdet_anchor_target_rotated_state_bytes(n1, n2, n_groups) bytes that MUST be zero on entry;
+ *          the call leaves them zero again (counters reset by its last workgroups), so one zeroed
+ *          buffer serves every later call on the same stream.
+ *   ws:    rsdet_anchor_target_rotated_ws_size(n2, n_groups, n_row_tiles) bytes of scratch (worst
+ *          case sized: one 32 KiB entry slice per 16 x 256 tile; only the used part is touched). */
+size_t rsdet_anchor_target_rotated_state_bytes(int n1, int n2, int n_groups);
+size_t rsdet_anchor_target_rotated_ws_size(int n2, int n_groups, int n_row_tiles);
+int rsdet_anchor_target_rotated_f32(
+    const float* gt_boxes, int n1, int stride1, const int* gt_labels, const int* row_offsets, int n_groups,
+    int max_rows_per_group, const int* tile_table, int n_row_tiles, const int* group_tile0, const float* anchors,
+    int n2, int stride2, int per_group, const void* prepared2, const void* prepared_gt, int heavy_from_col,
+    const unsigned char* valid, int version, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int match_low_quality,
+    int labels_filled, float pos_weight, int reg_decoded_bbox, const float* means_host, const float* stds_host,
+    int* gt_inds, float* max_overlaps, int* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
+    float* totals, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a16  rotated NMS -----------------------------------------------------------
  * Replaces nms_rotated_cpu / nms_rotated_cuda: ops/nms_rotated.py:495-512
  * (kernels :353-411 + host sweep :450-493, CPU loop :414-449).

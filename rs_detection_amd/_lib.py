@@ -30,6 +30,19 @@ SIGNATURES = {
                                           c_size_t, c_void_p]),
     "rsdet_box_iou_rotated_grouped_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                   c_int, c_ll, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_iou_prepared_bytes": (c_size_t, [c_ll, c_int]),
+    "rsdet_iou_prepare_f32": (c_int, [c_void_p, c_ll, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "rsdet_box_iou_rotated_tiled_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_anchor_target_rotated_state_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rsdet_anchor_target_rotated_ws_size": (c_size_t, [c_int, c_int, c_int]),
+    "rsdet_anchor_target_rotated_f32": (c_int, [
+        c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+        c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+        c_float, c_float, c_float, c_float, c_int, c_int, c_float, c_int,
+        ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+        c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "rsdet_nms_rotated_ws_size": (c_size_t, [c_int]),
     "rsdet_nms_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),

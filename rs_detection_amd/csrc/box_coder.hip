@@ -11,40 +11,9 @@
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
+#include "rsdet_coder.h"
 
 namespace rsdet {
-
-struct F5 {
-  float v[5];
-};
-
-constexpr float kPi = 3.14159265358979323846f;
-
-// norm_angle(a,'le135') = (a + pi/4) mod pi - pi/4 with Python-style mod (box_ops.py:176-182)
-__device__ __forceinline__ float norm_angle_le135(float a) {
-  const float lo = -0.78539816339744830962f;
-  float x = a - lo;
-  float r = fmodf(x, kPi);
-  if (r != 0.f && r < 0.f) r += kPi;
-  return r + lo;
-}
-
-__device__ __forceinline__ void decode_one(const float* roi, const float* d, const F5& mean,
-                                           const F5& stdv, float max_ratio, float* o) {
-  float dx = d[0] * stdv.v[0] + mean.v[0];
-  float dy = d[1] * stdv.v[1] + mean.v[1];
-  float dw = d[2] * stdv.v[2] + mean.v[2];
-  float dh = d[3] * stdv.v[3] + mean.v[3];
-  float da = d[4] * stdv.v[4] + mean.v[4];
-  dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
-  dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
-  float c = cosf(roi[4]), s = sinf(roi[4]);
-  o[0] = dx * roi[2] * c - dy * roi[3] * s + roi[0];
-  o[1] = dx * roi[2] * s + dy * roi[3] * c + roi[1];
-  o[2] = roi[2] * expf(dw);
-  o[3] = roi[3] * expf(dh);
-  o[4] = norm_angle_le135(kPi * da + roi[4]);
-}
 
 __global__ void delta2bbox_kernel(const float* __restrict__ rois, const float* __restrict__ deltas,
                                   int n, F5 mean, F5 stdv, float max_ratio,
@@ -66,19 +35,10 @@ __global__ void bbox2delta_kernel(const float* __restrict__ prop, const float* _
                                   int n, F5 mean, F5 stdv, float* __restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float* p = prop + (long long)i * 5;
-  const float* g = gt + (long long)i * 5;
-  float c = cosf(p[4]), s = sinf(p[4]);
-  float cx = g[0] - p[0], cy = g[1] - p[1];
-  float d[5];
-  d[0] = (c * cx + s * cy) / p[2];
-  d[1] = (-s * cx + c * cy) / p[3];
-  // jt.safe_log: log of the argument clamped to [1e-30, 1e30]
-  d[2] = logf(fminf(fmaxf(g[2] / p[2], 1e-30f), 1e30f));
-  d[3] = logf(fminf(fmaxf(g[3] / p[3], 1e-30f), 1e30f));
-  d[4] = norm_angle_le135(g[4] - p[4]) / kPi;
+  float o[5];
+  encode_one(prop + (long long)i * 5, gt + (long long)i * 5, mean, stdv, o);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) out[(long long)i * 5 + k] = (d[k] - mean.v[k]) / stdv.v[k];
+  for (int k = 0; k < 5; ++k) out[(long long)i * 5 + k] = o[k];
 }
 
 // One thread per (b, h, w).  bbox_pred is NCHW so lanes (consecutive w) read
@@ -144,12 +104,6 @@ __global__ void box_to_poly_kernel(const float* __restrict__ boxes, int n, float
     o[2 * k] = c * xs[k] + (-s) * ys[k] + r[0];
     o[2 * k + 1] = s * xs[k] + c * ys[k] + r[1];
   }
-}
-
-static inline F5 load5(const float* host, float dflt) {
-  F5 f;
-  for (int k = 0; k < 5; ++k) f.v[k] = host ? host[k] : dflt;
-  return f;
 }
 
 }  // namespace rsdet

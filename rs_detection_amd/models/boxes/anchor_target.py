@@ -100,14 +100,41 @@ def anchor_target(anchor_list, valid_flag_list, gt_bboxes_list, img_metas, targe
             images_to_levels(all_bbox_weights, num_level_anchors), num_total_pos, num_total_neg)
 
 
+def _fused_ok(assigner, coder, cfg):
+    """The sparse two-launch path (csrc/anchor_target.hip) covers: a rotated IoU calculator, gt_max_assign_all, no
+    ignore regions, the DeltaXYWHA coder.  Anything else takes the dense chain below (same results, more launches)."""
+    import os
+    from .coder import DeltaXYWHABBoxCoder
+    if os.environ.get("RSDET_DENSE_ANCHOR_TARGET", "0") == "1":
+        return False
+    return (getattr(assigner.iou_calculator, "version", None) in (0, 1) and assigner.gt_max_assign_all
+            and type(coder) is DeltaXYWHABBoxCoder)
+
+
 def anchor_target_batched(anchors, gt_cat, gt_labels_cat, row_offsets, max_k, cfg, assigner=None, coder=None,
-                          valid=None):
+                          valid=None, ks=None, cache_anchors=False, heavy_from=None):
     """anchors (A,5) shared or (B,A,5); gt_cat (sumK,5); gt_labels_cat (sumK,) int; row_offsets (B+1) i32.
     -> labels (B,A) i32, label_weights (B,A), bbox_targets (B,A,5), bbox_weights (B,A,5),
-       num_total_pos (device scalar, float), num_total_neg (device scalar, float)."""
+       num_total_pos (device scalar, float), num_total_neg (device scalar, float).
+
+    ``ks`` (the gt counts as Python ints, which every caller has: they are tensor shapes) selects the fused sparse
+    path: rotated IoU of the overlapping pairs only -> assignment -> encode -> weights / counts in TWO launches
+    (ops/anchor_target.py), no (K, A) matrix.  ``cache_anchors``: the anchors are the same tensor every step (the FAM
+    grid) -- their prepared form is kept; ``heavy_from``: first anchor index of the large pyramid levels (hint)."""
     assigner = assigner or build_from_cfg(cfg.get('assigner', ''), BOXES)
     coder = coder or _coder(cfg)
     B = row_offsets.numel() - 1
+    if ks is not None and _fused_ok(assigner, coder, cfg) and gt_labels_cat is not None:
+        from rs_detection_amd.ops import anchor_target as _at
+        prep = _at.prepare_boxes(anchors, cache=cache_anchors, heavy_from=None if cache_anchors else heavy_from)
+        out = _at.anchor_target_rotated(
+            anchors, gt_cat, gt_labels_cat.to(torch.int32), row_offsets, list(ks), assigner.pos_iou_thr,
+            assigner._neg(), assigner.min_pos_iou, assigner.match_low_quality, assigner.assigned_labels_filled,
+            float(cfg.get('pos_weight', -1)), bool(cfg.get('reg_decoded_bbox', False)), coder.means, coder.stds,
+            valid, assigner.iou_calculator.version, prepared=prep,
+            prepared_gt=_at.prepare_boxes(gt_cat, cache=True, heavy_from=gt_cat.shape[0]) if gt_cat.shape[0] else None)
+        return (out["labels"], out["label_weights"], out["bbox_targets"], out["bbox_weights"], out["totals"][0],
+                out["totals"][1])
     gt_inds, _, labels = assigner.assign_batch(anchors, gt_cat, row_offsets, max_k, gt_labels_cat, valid)
     A = gt_inds.shape[1]
     pos = gt_inds > 0

@@ -114,6 +114,7 @@ class S2ANetHead(nn.Module):
                                   for b in self.anchor_base_sizes]
         self.base_anchors = dict()  # anchor cache, keyed (level, featmap_size, device)
         self._built = {}
+        self._init_anchor_cat = {}   # level-concatenated grid per (featmap sizes, device)
         self._init_layers()
 
     def _init_layers(self):
@@ -253,11 +254,17 @@ class S2ANetHead(nn.Module):
         valid = self._valid_flags(featmap_sizes, img_metas, device)
         C = self.cls_out_channels
 
-        # Feature Alignment Module: shared grid anchors
-        init_anchors = torch.cat([self._anchors(i, featmap_sizes[i], device) for i in range(len(featmap_sizes))])
+        # Feature Alignment Module: shared grid anchors (one tensor per pyramid geometry, kept: its prepared form --
+        # fp64 sincos, strip boxes -- is then computed once per process, ops/anchor_target.prepare_boxes)
+        akey = (tuple(featmap_sizes), str(device))
+        if akey not in self._init_anchor_cat:
+            self._init_anchor_cat[akey] = torch.cat([self._anchors(i, featmap_sizes[i], device)
+                                                     for i in range(len(featmap_sizes))])
+        init_anchors = self._init_anchor_cat[akey]
         assigner, coder = self._cfg_objs('fam_cfg')
         labels, lw, bt, bw, npos, nneg = anchor_target_batched(init_anchors, gt_cat, lab_cat, row_offsets, max(ks),
-                                                               self.train_cfg['fam_cfg'], assigner, coder, valid)
+                                                               self.train_cfg['fam_cfg'], assigner, coder, valid,
+                                                               ks=ks, cache_anchors=True)
         avg = npos + nneg if self.sampling else npos
         losses_fam_cls, losses_fam_bbox = self._level_losses(
             self.loss_fam_cls, self.loss_fam_bbox, self._flatten(fam_cls_scores, C), self._flatten(fam_bbox_preds, 5),
@@ -266,8 +273,11 @@ class S2ANetHead(nn.Module):
         # Oriented Detection Module: per-image refined anchors
         refined = torch.cat([r.reshape(r.shape[0], -1, 5) for r in refine_anchors], dim=1)
         assigner, coder = self._cfg_objs('odm_cfg')
+        from rs_detection_amd.ops.anchor_target import prepare_boxes
+        heavy = prepare_boxes(init_anchors, cache=True).heavy_from     # the refinements keep the grid's level layout
         labels, lw, bt, bw, npos, nneg = anchor_target_batched(refined, gt_cat, lab_cat, row_offsets, max(ks),
-                                                               self.train_cfg['odm_cfg'], assigner, coder, valid)
+                                                               self.train_cfg['odm_cfg'], assigner, coder, valid,
+                                                               ks=ks, heavy_from=heavy)
         avg = npos + nneg if self.sampling else npos
         losses_odm_cls, losses_odm_bbox = self._level_losses(
             self.loss_odm_cls, self.loss_odm_bbox, self._flatten(odm_cls_scores, C), self._flatten(odm_bbox_preds, 5),

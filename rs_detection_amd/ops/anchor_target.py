@@ -1,0 +1,198 @@
+"""Rotated IoU in one launch and the fused (sparse) anchor targets -- host side of csrc/anchor_target.hip.
+
+``anchor_target_rotated`` is what ``models/boxes/anchor_target.anchor_target_batched`` runs for the S2ANet heads: the
+per-image loop of /root/reference/python/jdet/models/boxes/anchor_target.py:60-87 (IoU -> MaxIoUAssigner ->
+PseudoSampler -> bbox2delta -> labels / weights / counts) as TWO launches for the whole batch, without the (K, A) matrix.
+
+Host-side helpers kept here:
+  * prepared column sets are cached per anchor tensor (``data_ptr`` + version counter): the FAM grid of a head is the
+    same tensor every step, so its fp64 sincos run once per process, not once per step;
+  * the row-tile table (which 16 gts each workgroup row owns) is built from the HOST-known gt counts and cached per
+    count tuple -- the launch then holds no empty workgroups and there is no device->host sync anywhere;
+  * the small zero-initialised ``state`` buffer the kernels leave zeroed again is kept per device and only ever grows.
+"""
+import torch
+
+from .. import _lib
+
+__all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "anchor_target_rotated"]
+
+_TI = 16  # rows per tile (csrc/anchor_target.hip T_TI)
+_prepared_cache = {}
+_tile_cache = {}
+_state = {}
+
+
+class PreparedBoxes:
+    """Device buffer of rsdet_iou_prepare_f32 + the geometry it was made for."""
+    __slots__ = ("buf", "n_total", "n_per_group", "groups", "heavy_from")
+
+    def __init__(self, buf, n_total, n_per_group, heavy_from=None):
+        self.buf, self.n_total, self.n_per_group = buf, n_total, n_per_group
+        self.groups = n_total // n_per_group if n_per_group else 1
+        self.heavy_from = n_per_group if heavy_from is None else int(heavy_from)
+
+
+def heavy_from_boxes(boxes):
+    """First column from which the boxes are LARGE (bounding radius > 1/10 of the extent of the set) -- the hint
+    ``heavy_from_col`` of the tile kernels (their tiles are cut into 4-row sub-tiles).  Reads the device once: call it
+    for anchor sets that are cached (the FAM grid), and pass the value on for sets that share their layout (the ODM
+    refinements of that grid).  Only meaningful when box size grows with the index (pyramid levels, small to large)."""
+    b = boxes.reshape(-1, boxes.shape[-1])[:boxes.shape[-2]]
+    if b.shape[0] == 0:
+        return 0
+    ext = (b[:, :2].max(0)[0] - b[:, :2].min(0)[0]).max().clamp(min=1.0)
+    big = (0.5 * (b[:, 2].abs() + b[:, 3].abs()) > 0.1 * ext).to(torch.int32)
+    # first index from which every box is big (a suffix); n when there is no such suffix
+    suffix_small = (1 - big).flip(0).cumsum(0).flip(0)
+    return int((suffix_small > 0).sum().item())
+
+
+def prepare_boxes(boxes, cache=False, heavy_from=None):
+    """boxes (A, s>=5) or (G, A, s): -> PreparedBoxes.  ``cache=True`` keeps the result for this very tensor (same
+    storage, same version counter) -- for anchors that do not change between steps -- and measures ``heavy_from``
+    (one device read, once)."""
+    _lib.require_cuda_f32(boxes)
+    lib = _lib.load()
+    b = boxes.contiguous()
+    per = b.shape[-2]
+    total = b.numel() // b.shape[-1]
+    key = (b.data_ptr(), tuple(b.shape), b._version, b.device.index) if cache else None
+    if key is not None:
+        hit = _prepared_cache.get(key)
+        if hit is not None and hit[0]() is b:
+            return hit[1]
+    nbytes = lib.rsdet_iou_prepared_bytes(total, per) if total else 0
+    buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=b.device)
+    if total:
+        rc = lib.rsdet_iou_prepare_f32(_lib.ptr(b), total, per, b.shape[-1], _lib.ptr(buf), nbytes, _lib.stream_ptr())
+        _lib.check(rc, "rsdet_iou_prepare_f32")
+    if heavy_from is None and cache and total:
+        heavy_from = heavy_from_boxes(b)
+    prep = PreparedBoxes(buf, total, per, heavy_from)
+    if key is not None:
+        import weakref
+        if len(_prepared_cache) > 64:
+            _prepared_cache.clear()
+        _prepared_cache[key] = (weakref.ref(b), prep)
+    return prep
+
+
+def row_tile_table(ks, device):
+    """Host-known gt counts per image -> (tile table (T,4) int32 on ``device``, group_tile0 (G+1) int32, T)."""
+    key = (tuple(int(k) for k in ks), str(device))
+    hit = _tile_cache.get(key)
+    if hit is not None:
+        return hit
+    rows, tile0, r0 = [], [0], 0
+    for g, k in enumerate(key[0]):
+        for y in range(0, k, _TI):
+            rows.append((g, r0 + y, min(_TI, k - y), r0))
+        tile0.append(len(rows))
+        r0 += k
+    n = len(rows)
+    table = torch.tensor(rows if rows else [(0, 0, 0, 0)], dtype=torch.int32).to(device, non_blocking=True)
+    t0 = torch.tensor(tile0, dtype=torch.int32).to(device, non_blocking=True)
+    if len(_tile_cache) > 256:
+        _tile_cache.clear()
+    _tile_cache[key] = (table, t0, n)
+    return _tile_cache[key]
+
+
+def _zero_state(device, nbytes):
+    cur = _state.get(device)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.zeros((max(nbytes, 4096) * 2,), dtype=torch.uint8, device=device)   # grow-only, zeroed once
+        _state[device] = cur
+    return cur
+
+
+def box_iou_rotated_tiled(boxes1, boxes2, row_offsets=None, ks=None, max_rows=None, version=0, out=None,
+                          prepared=None, cache_prepared=False, prepared1=None):
+    """Dense (n1, A) IoU in one launch.  ``boxes2`` (A,5) shared or (G,A,5) per group; ``row_offsets`` (G+1) int32
+    device tensor (None: a single group); ``ks``: host-known rows per group (enables the exact tile table)."""
+    _lib.require_cuda_f32(boxes1, boxes2)
+    lib = _lib.load()
+    b1, b2 = boxes1.contiguous(), boxes2.contiguous()
+    n1, A = b1.shape[0], b2.shape[-2]
+    per_group = 1 if b2.dim() == 3 else 0
+    G = (row_offsets.numel() - 1) if row_offsets is not None else 1
+    ious = out if out is not None else torch.empty((n1, A), dtype=torch.float32, device=b1.device)
+    if n1 == 0 or A == 0:
+        return ious
+    prep = prepared if prepared is not None else prepare_boxes(b2, cache=cache_prepared)
+    assert prep.n_per_group == A and prep.groups == (G if per_group else 1)
+    if ks is not None:
+        table, _, nt = row_tile_table(ks, b1.device)
+        tptr, mr = _lib.ptr(table), max(ks)
+    else:
+        tptr, nt, mr = None, 0, int(max_rows if max_rows is not None else n1)
+    if prepared1 is not None:
+        assert prepared1.n_total == n1 and prepared1.groups == 1
+    rc = lib.rsdet_box_iou_rotated_tiled_f32(_lib.ptr(b1), n1, b1.shape[1], _lib.ptr(row_offsets), G, mr, tptr, nt,
+                                             _lib.ptr(prepared1.buf) if prepared1 is not None else None,
+                                             _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,
+                                             _lib.ptr(ious), _lib.stream_ptr())
+    _lib.check(rc, "rsdet_box_iou_rotated_tiled_f32")
+    return ious
+
+
+def anchor_target_rotated(anchors, gt_cat, gt_labels_cat, row_offsets, ks, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0,
+                          match_low_quality=True, labels_filled=0, pos_weight=-1.0, reg_decoded_bbox=False,
+                          target_means=None, target_stds=None, valid=None, version=0, cache_prepared=False,
+                          prepared=None, prepared_gt=None, want_gt_inds=False, want_targets=True):
+    """-> dict(labels (G,A) i32, label_weights (G,A), bbox_targets (G,A,5), bbox_weights (G,A,5), totals (2,) =
+    [sum_img max(#pos,1), sum_img max(#neg,1)], and gt_inds / max_overlaps when ``want_gt_inds``).
+
+    anchors (A,5) shared or (G,A,5) per image; gt_cat (sumK,5); gt_labels_cat (sumK,) int32 or None;
+    row_offsets (G+1) int32 on the device; ks: the same counts as Python ints (host-known, no sync)."""
+    _lib.require_cuda_f32(anchors, gt_cat)
+    lib = _lib.load()
+    an, gt = anchors.contiguous(), gt_cat.contiguous()
+    dev = an.device
+    G = len(ks)
+    assert row_offsets.dtype == torch.int32 and row_offsets.is_cuda and row_offsets.numel() == G + 1
+    A = an.shape[-2]
+    per_group = 1 if an.dim() == 3 else 0
+    n1 = gt.shape[0]
+    assert n1 == sum(ks)
+    prep = prepared if prepared is not None else prepare_boxes(an, cache=cache_prepared)
+    assert prep.n_per_group == A and prep.groups == (G if per_group else 1)
+    if prepared_gt is not None:
+        assert prepared_gt.n_total == n1 and (prepared_gt.groups == 1 or n1 == 0)
+    table, tile0, nt = row_tile_table(ks, dev)
+    if isinstance(neg_iou_thr, (tuple, list)):
+        neg_lo, neg_hi = float(neg_iou_thr[0]), float(neg_iou_thr[1])
+    else:
+        neg_lo, neg_hi = 0.0, float(neg_iou_thr)
+    lab = gt_labels_cat.contiguous() if gt_labels_cat is not None else None
+    if lab is not None:
+        assert lab.dtype == torch.int32 and lab.numel() == n1
+    if valid is not None:
+        valid = valid.to(torch.uint8).contiguous()
+        assert tuple(valid.shape) == (G, A)
+    out = dict(labels=torch.empty((G, A), dtype=torch.int32, device=dev),
+               label_weights=torch.empty((G, A), dtype=torch.float32, device=dev),
+               totals=torch.empty((2,), dtype=torch.float32, device=dev))
+    if want_targets:
+        out["bbox_targets"] = torch.empty((G, A, 5), dtype=torch.float32, device=dev)
+        out["bbox_weights"] = torch.empty((G, A, 5), dtype=torch.float32, device=dev)
+    if want_gt_inds:
+        out["gt_inds"] = torch.empty((G, A), dtype=torch.int32, device=dev)
+        out["max_overlaps"] = torch.empty((G, A), dtype=torch.float32, device=dev)
+    state_bytes = lib.rsdet_anchor_target_rotated_state_bytes(n1, A, G)
+    state = _zero_state(dev, state_bytes)
+    ws_bytes = lib.rsdet_anchor_target_rotated_ws_size(A, G, max(nt, 1))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    rc = lib.rsdet_anchor_target_rotated_f32(
+        _lib.ptr(gt), n1, gt.shape[1] if n1 else 5, _lib.ptr(lab), _lib.ptr(row_offsets), G, max(max(ks), 1),
+        _lib.ptr(table), nt, _lib.ptr(tile0), _lib.ptr(an), A, an.shape[-1], per_group, _lib.ptr(prep.buf),
+        _lib.ptr(prepared_gt.buf) if (prepared_gt is not None and n1) else None, prep.heavy_from, _lib.ptr(valid),
+        version, float(pos_iou_thr), neg_lo, neg_hi, float(min_pos_iou), int(bool(match_low_quality)),
+        int(labels_filled), float(pos_weight), int(bool(reg_decoded_bbox)),
+        _lib.host5(target_means, 0.0), _lib.host5(target_stds, 1.0),
+        _lib.ptr(out.get("gt_inds")), _lib.ptr(out.get("max_overlaps")), _lib.ptr(out["labels"]),
+        _lib.ptr(out["label_weights"]), _lib.ptr(out.get("bbox_targets")), _lib.ptr(out.get("bbox_weights")),
+        _lib.ptr(out["totals"]), _lib.ptr(state), state.numel(), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+    _lib.check(rc, "rsdet_anchor_target_rotated_f32")
+    return out

@@ -57,12 +57,14 @@ def test_anchor_target_batched_vs_reference_shaped_vs_numpy(cuda, oracle_c, ks):
     ref = np.stack([anchors + np.concatenate([rng.normal(0, 4, (A, 2)), np.zeros((A, 3))], 1).astype(np.float32) for _ in ks])
     ref[:, :, 2:4] *= np.exp(rng.normal(0, 0.2, (len(ks), A, 2))).astype(np.float32)
     ref[:, :, 4] += rng.normal(0, 0.3, (len(ks), A)).astype(np.float32)
-    for per_image in (False, True):
+    for per_image, fused in ((False, False), (True, False), (False, True), (True, True)):
         anc_np = ref if per_image else np.broadcast_to(anchors, (len(ks), A, 5))
         t = lambda a: torch.from_numpy(np.array(a)).to(cuda)
         ro = torch.tensor(np.concatenate([[0], np.cumsum(ks)]), dtype=torch.int32, device=cuda)
+        # fused = the sparse two-launch path the head runs (ks known on the host); otherwise the dense chain
         got = anchor_target_batched(t(ref) if per_image else t(anchors), t(np.concatenate(gts)), t(np.concatenate(labs)),
-                                    ro, max(max(ks), 1), FAM)
+                                    ro, max(max(ks), 1), FAM, ks=ks if fused else None,
+                                    heavy_from=20480 if fused else None)
         labels, lw, bt, bw, npos, nneg = [g.cpu().numpy() for g in got]
         # reference-shaped per-image form (single pyramid "level" holding all anchors).  Like the reference
         # (assigner.py:92-93) it raises on an image without gts -- the batched form treats it as all-negative.
