@@ -40,12 +40,23 @@ namespace rsdet {
 
 #ifdef RSDET_TILE_TRACE  // debug builds only (profiles/scripts/trace_tiles.py): per-workgroup stage timestamps, 100 MHz
 __device__ unsigned long long* g_tile_trace;
-#define TTRACE(k)                                                                       \
+#define TTRACE_REAL(k)                                                                  \
   do {                                                                                  \
     if (threadIdx.x == 0 && g_tile_trace) g_tile_trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
   } while (0)
+#ifdef RSDET_TRACE_FINISH_ONLY
+#define TTRACE(k)
+#else
+#define TTRACE(k) TTRACE_REAL(k)
+#endif
+#define FTRACE(k)                                                                       \
+  do {                                                                                  \
+    if (threadIdx.x == 0 && g_tile_trace)                                               \
+      g_tile_trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); \
+  } while (0)
 #else
 #define TTRACE(k)
+#define FTRACE(k)
 #endif
 
 constexpr int T_NT = 256;  // columns per tile = threads per workgroup
@@ -450,7 +461,7 @@ struct FinishArgs {
   float* bbox_targets;
   float* bbox_weights;
   float* totals;        // [0] = sum_g max(#pos_g, 1), [1] = sum_g max(#neg_g, 1)
-  unsigned* state;      // [0] finished workgroups, [1 + 2g] pos_g, [2 + 2g] neg_g: zero on entry, zeroed on exit
+  unsigned* state;      // 64-bit words: [0] batch, [1 + g] image g = packed {pos, neg, arrivals}: zero on entry / exit
   unsigned* rowmax_rw;  // same array as rowmax: cleared by the last workgroup
 };
 
@@ -465,6 +476,7 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int xt = blockIdx.x, g = blockIdx.y;
   const int col = xt * T_NT + tid;
+  FTRACE(0);
   // The kernel is a chain of dependent global round trips on 344 workgroups (1.3 per CU): everything that does not
   // depend on the entries is requested up front -- this column's accumulator, validity flag and anchor.
   const long long o = (long long)g * a.n2 + min(col, a.n2 - 1);
@@ -486,6 +498,7 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
     s_cnt[1] = 0;
   }
   __syncthreads();
+  FTRACE(1);
   if (K > 0 && a.match_low_quality) {
     // gts that overlap nothing: their row maximum is 0 and every anchor "equals" it (assigner.py:155)
     const bool zero_rows = 0.0f >= a.min_pos_iou;
@@ -528,6 +541,7 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
     }
   }
   __syncthreads();
+  FTRACE(2);
   bool pos = false, neg = false;
   if (col < a.n2) {
     int gi;
@@ -578,7 +592,11 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
       }
     }
   }
-  // ---- counts: sum_img max(#pos, 1) and the same for negatives (anchor_target.py:79-80)
+  FTRACE(3);
+  // ---- counts: sum_img max(#pos, 1) and the same for negatives (anchor_target.py:79-80).  One returning 64-bit
+  // atomic per workgroup carries its counts AND its arrival (pos : 24 | neg : 24 | arrivals : 16): the workgroup
+  // whose add completes the image holds the image's totals in the returned value -- no second counter to order
+  // against, no wait for acknowledgements.  The same again over the images (26 | 26 | 12).
   const int np = __popcll(__ballot(pos)), nn = __popcll(__ballot(neg));
   if (lane == 0) {
     if (np) atomicAdd(&s_cnt[0], np);
@@ -586,29 +604,32 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
   }
   __syncthreads();
   if (tid == 0) {
-    if (s_cnt[0]) atomicAdd(a.state + 1 + 2 * g, (unsigned)s_cnt[0]);
-    if (s_cnt[1]) atomicAdd(a.state + 2 + 2 * g, (unsigned)s_cnt[1]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the count atomics are acknowledged before "done" moves
-    const unsigned done = atomicAdd(a.state, 1u);
-    s_last = done == gridDim.x * gridDim.y - 1u;
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(a.state);
+    const unsigned long long mine = ((unsigned long long)(unsigned)s_cnt[0] << 40) |
+                                    ((unsigned long long)(unsigned)s_cnt[1] << 16) | 1ull;
+    const unsigned long long now = atomicAdd(words + 1 + g, mine) + mine;
+    int last = 0;
+    if ((now & 0xFFFFull) == (unsigned long long)gridDim.x) {  // this image is complete
+      atomicExch(words + 1 + g, 0ull);
+      const unsigned long long p = now >> 40, n = (now >> 16) & 0xFFFFFFull;
+      const unsigned long long img = ((p ? p : 1ull) << 38) | ((n ? n : 1ull) << 12) | 1ull;
+      const unsigned long long all = atomicAdd(words, img) + img;
+      if ((all & 0xFFFull) == (unsigned long long)gridDim.y) {  // ... and so is the batch
+        atomicExch(words, 0ull);
+        if (a.totals) {
+          a.totals[0] = (float)(all >> 38);
+          a.totals[1] = (float)((all >> 12) & 0x3FFFFFFull);
+        }
+        last = 1;
+      }
+    }
+    s_last = last;
   }
   __syncthreads();
+  FTRACE(4);
   if (!s_last) return;
-  // ---- the last workgroup: totals, and the state goes back to zero for the next call (the counters are only ever
-  // touched by device-scope atomics, so no fence is needed: an L2 write-back per workgroup would serialise them)
-  if (tid == 0) {
-    float tp = 0.f, tn = 0.f;
-    for (int i = 0; i < a.n_groups; ++i) {
-      const unsigned p = atomicExch(a.state + 1 + 2 * i, 0u), n = atomicExch(a.state + 2 + 2 * i, 0u);
-      tp += (float)max(p, 1u);
-      tn += (float)max(n, 1u);
-    }
-    if (a.totals) {
-      a.totals[0] = tp;
-      a.totals[1] = tn;
-    }
-    atomicExch(a.state, 0u);
-  }
+  // ---- the last workgroup: the row maxima go back to zero for the next call (every workgroup has read them before
+  // its arrival above; the counters are only ever touched by device-scope atomics, so no fence is needed anywhere)
   for (int r = tid; r < a.n1; r += T_NT) a.rowmax_rw[r] = 0u;
 }
 
@@ -696,7 +717,7 @@ extern "C" int rsdet_box_iou_rotated_tiled_f32(const float* boxes1, int n1, int 
 //                                            rowmax (n1 words) | colkey (n_groups * n2 u64)
 // ws (scratch, no initialisation needed):     dir (nx * n_row_tiles * T_SUB words) |
 //                                            list (nx * n_row_tiles slices of T_TI * T_NT entries)
-static inline size_t at_counters_bytes(int n_groups) { return up256((1 + 2 * (size_t)n_groups) * 4); }
+static inline size_t at_counters_bytes(int n_groups) { return up256((1 + (size_t)n_groups) * 8); }
 
 extern "C" size_t rsdet_anchor_target_rotated_state_bytes(int n1, int n2, int n_groups) {
   if (n_groups <= 0 || n2 <= 0) return 0;
@@ -720,6 +741,8 @@ extern "C" int rsdet_anchor_target_rotated_f32(
     void* ws, size_t ws_bytes, void* stream) {
   if (n1 < 0 || n2 <= 0 || n_groups < 1 || stride1 < 5 || stride2 < 5 || (version != 0 && version != 1))
     return RSDET_EINVAL;
+  // packed counters of at_finish: 24 bits of anchors per image, 16 of column tiles, 12 of images, 26 of anchors in all
+  if (n2 >= (1 << 24) || n_groups >= (1 << 12) || (long long)n2 * n_groups >= (1LL << 26)) return RSDET_EINVAL;
   if (!row_offsets || !anchors || !prepared2 || !ws || ((uintptr_t)ws & 15) || !state || ((uintptr_t)state & 15))
     return RSDET_EINVAL;
   if (n1 > 0 && !gt_boxes) return RSDET_EINVAL;
