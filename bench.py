@@ -102,6 +102,21 @@ def event_time(fn, iters, warmup=3, graph=True):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
+ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r02_roofline.json")
+
+
+def pmc_traffic(call, shape_ok):
+    """HBM bytes per launch of a C-ABI call from the committed counter table (profiles/r02_roofline.json, produced by
+    profiles/scripts/roofline.sh: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes + kernel trace + code-object notes of
+    the same kernels at the same shapes) -- never a literal in this file.  None when the table is absent or the shape
+    differs from the one it was measured at."""
+    if not shape_ok or not os.path.exists(ROOFLINE_FILE):
+        return None
+    with open(ROOFLINE_FILE) as f:
+        c = json.load(f).get("calls", {}).get(call)
+    return c["traffic_bytes"] if c else None
+
+
 def kernel_rooflines(device, targets):
     """HIP-event timing of each hand-written kernel at the shapes of this very step."""
     from rs_detection_amd import ops
@@ -126,20 +141,34 @@ def kernel_rooflines(device, targets):
     alg_flops = 300.0 * (n1 * A - nz) + 800.0 * nz
     out["box_iou_rotated(prepare+filter+clip)"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                          frac=by / t / 1e9 / HBM_PEAK_GBS,
-                                         # HBM bytes per launch from the rocprofv3 PMC passes of this very shape
-                                         # (profiles/r01_g_pmc_hbm_traffic.txt: WRITE 51.0+1.1+0.9 MB, FETCH 2x5.7 MB)
-                                         traffic=64.4e6 if (n1, A) == (556, 21824) else None, us=t * 1e6,
+                                         traffic=pmc_traffic("box_iou_rotated (3 launches)", (n1, A) == (556, 21824)),
+                                         us=t * 1e6,
                                          mpairs_per_s=n1 * A / t / 1e6, shape="sumK=%d x A=%d (B=%d)" % (n1, A, len(ks)),
                                          overlapping_pairs=nz, alg_gflop=alg_flops / 1e9,
                                          valu_frac=alg_flops / t / 1e12 / FP32_VALU_PEAK_TFLOPS)
+    # -- the same matrix in ONE launch (csrc/anchor_target.hip: each 16 x 256 tile detected, zero-filled and clipped by
+    #    the workgroup that owns it), prepared anchors cached as the FAM grid's are
+    prep = ops.prepare_boxes(anchors, cache=True)
+    pgt = ops.prepare_boxes(gt, heavy_from=n1)
+    t1 = event_time(lambda: ops.box_iou_rotated_tiled(gt, anchors, ro, ks=ks, out=ov, prepared=prep, prepared1=pgt), 50)
+    out["box_iou_rotated_tiled(1 launch; prepared anchors cached)"] = dict(
+        bound="hbm", achieved=by / t1 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t1 / 1e9 / HBM_PEAK_GBS,
+        traffic=pmc_traffic("box_iou_rotated_tiled (1 launch)", (n1, A) == (556, 21824)), us=t1 * 1e6)
+    # -- what the train step runs since round 2: fused sparse anchor targets (IoU of the overlapping pairs only ->
+    #    assignment -> encode -> weights / counts, no matrix): bytes = boxes in + 56 B of targets per anchor out
+    t2 = event_time(lambda: ops.anchor_target_rotated(anchors, gt, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep,
+                                                      prepared_gt=pgt), 50)
+    by2 = 20 * (n1 + A) + 56 * len(ks) * A
+    out["anchor_target_rotated(fused: IoU + assign + encode + weights; 2 launches)"] = dict(
+        bound="latency/alu", achieved=by2 / t2 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by2 / t2 / 1e9 / HBM_PEAK_GBS,
+        traffic=pmc_traffic("anchor_target_rotated (2 launches)", (n1, A) == (556, 21824)), us=t2 * 1e6,
+        replaces="box_iou_rotated_grouped + assign_wrt_overlaps + ~15 torch kernels of anchor_target_batched")
     # -- assignment (a4): two passes over the matrix + outputs
     t = event_time(lambda: ops.assign_wrt_overlaps(ov, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0), 50)
     by = 2 * 4 * n1 * A + 12 * len(ks) * A
     out["assign_row+col_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                         frac=by / t / 1e9 / HBM_PEAK_GBS, us=t * 1e6,
-                                        # profiles/r01_k_pmc_hbm_traffic.txt: each pass fetches the matrix once
-                                        # (FETCH 2 x 23.2 MiB, doubled per the guide's gfx950 rule) + 1.0 MiB written
-                                        traffic=98.3e6 if (n1, A) == (556, 21824) else None)
+                                        traffic=pmc_traffic("assign_wrt_overlaps", (n1, A) == (556, 21824)))
     # -- deformable im2col / col2im at pyramid level 0 (a11): bytes = 4*(C*HW*B + 18*HW*B + 9*C*HW*B)
     B, C, H = len(ks), 256, TILE // 8
     x = torch.randn(B, C, H, H, device=device)
@@ -148,8 +177,7 @@ def kernel_rooflines(device, targets):
     by = 4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B)
     out["deform_im2col_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                        frac=by / t / 1e9 / HBM_PEAK_GBS, us=t * 1e6,
-                                       # r01_k PMC: WRITE 576 MiB (the columns) + FETCH 167.5 MiB as reported
-                                       traffic=779.6e6 if (B, C, H) == (4, 256, 128) else None)
+                                       traffic=pmc_traffic("deform_im2col", (B, C, H) == (4, 256, 128)))
     # (the reference-layout col2im -- one lane per column row, 13.2 ms here -- is kept for API parity only; the step
     #  uses the channels-last pair below, so it is not timed: it would dominate the rocprof summary of this command)
     xn = x.permute(0, 2, 3, 1).contiguous()
@@ -166,9 +194,7 @@ def kernel_rooflines(device, targets):
     out["dcn_idx_count+scan+fill+dcn_gather(col2im of the step)"] = dict(
         bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
         us=t * 1e6,
-        # r01_k PMC, as reported: gather FETCH 746.6 + WRITE 64 MiB; count / fill / scan WRITE 34.8 + 143.7 + 0.5,
-        # FETCH 4.5 + 9.7 MiB
-        traffic=1052.7e6 if (B, C, H) == (4, 256, 128) else None)
+        traffic=pmc_traffic("deform_col2im (gather form, 5 launches)", (B, C, H) == (4, 256, 128)))
     del colT, xn, x, off
     # -- rotated NMS (a16), SURVEY 8d micro-bench shape M=5344, 6 columns (15 classes), thr 0.1.  Timed the way the
     #    class-aware entry points call it (ops.ml_nms_rotated: label-major order, one concurrent sweep per label run)
@@ -425,6 +451,8 @@ def main():
         "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
         "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
             "kernel": "rsdet_box_iou_rotated_grouped_f32 = iou_prepare + iou_filter + iou_clip kernels",
+            "traffic_source": "profiles/r02_roofline.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
+                              "profiles/scripts/roofline.sh); occupancy of every kernel: profiles/r02_occupancy.json",
             "us_per_launch": roof["us"], "shape": roof["shape"], "valu_frac": roof["valu_frac"],
             "alg_gflop": roof["alg_gflop"], "overlapping_pairs": roof["overlapping_pairs"]}) if roof else None,
         # the conv / GEMM side of the step against the MFMA roofline: flops of one rank's step as counted

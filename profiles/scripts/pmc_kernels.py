@@ -15,9 +15,46 @@ g = torch.from_numpy(np.concatenate([syn.dota_gt_boxes(rng, k) for k in ks])).to
 ro = torch.tensor(np.concatenate([[0], np.cumsum(ks)]), dtype=torch.int32, device=dev)
 out = torch.empty((sum(ks), a.shape[0]), device=dev)
 lab = torch.ones(sum(ks), dtype=torch.int32, device=dev)
+prep = ops.prepare_boxes(a, heavy_from=20480)
+pgt = ops.prepare_boxes(g)
 for _ in range(4):
     ops.box_iou_rotated_grouped(g, ro, max(ks), a, out=out)
     ops.assign_wrt_overlaps(out, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0)
+    ops.box_iou_rotated_tiled(g, a, ro, ks=ks, out=out, prepared=prep, prepared1=pgt)
+    ops.anchor_target_rotated(a, g, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep, prepared_gt=pgt)
+    ops.prepare_boxes(a)
+# algorithmic bytes per launch of the kernels this driver runs, keyed by a substring of the kernel name;
+# kernels that share one figure (the launches of one C-ABI call) carry the same "call" tag and are summed by roofline.py
+n1, A = sum(ks), a.shape[0]
+iou_b = 20 * (n1 + A) + 4 * n1 * A
+ALG = {
+    "iou_prepare_kernel": dict(call="box_iou_rotated (3 launches)", bytes=iou_b),
+    "iou_filter_kernel": dict(call="box_iou_rotated (3 launches)", bytes=iou_b),
+    "iou_clip_kernel": dict(call="box_iou_rotated (3 launches)", bytes=iou_b),
+    "iou_tile_kernel<0, 0>": dict(call="box_iou_rotated_tiled (1 launch)", bytes=iou_b),
+    "assign_row_kernel": dict(call="assign_wrt_overlaps", bytes=2 * 4 * n1 * A + 12 * len(ks) * A),
+    "assign_col_kernel": dict(call="assign_wrt_overlaps", bytes=2 * 4 * n1 * A + 12 * len(ks) * A),
+    # fused anchor targets: boxes in, 56 B of targets per anchor out, no matrix
+    "iou_tile_kernel<0, 1>": dict(call="anchor_target_rotated (2 launches)", bytes=20 * (n1 + A) + 56 * len(ks) * A),
+    "at_finish_kernel": dict(call="anchor_target_rotated (2 launches)", bytes=20 * (n1 + A) + 56 * len(ks) * A),
+    "at_prepare_kernel": dict(call="iou_prepare", bytes=(20 + 40) * A),
+}
+B, C, H = 4, 256, 128
+ALG["deform_im2col_taps_kernel"] = dict(call="deform_im2col", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
+ALG["deform_im2col_nhwc_kernel"] = dict(call="deform_im2col_nhwc", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
+for k in ("dcn_idx_count_kernel", "dcn_idx_scan_kernel", "dcn_idx_chunk_sum_kernel", "dcn_idx_fill_kernel", "dcn_gather_kernel"):
+    ALG[k] = dict(call="deform_col2im (gather form, 5 launches)", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
+M = 5344
+for k in ("nms_prepare_kernel", "nms_mask_kernel", "nms_sweep_kernel"):
+    ALG[k] = dict(call="nms_rotated (3 launches)", bytes=4 * 6 * M + 2 * 8 * M * ((M + 63) // 64) + M)
+ALG["rroi_forward_kernel"] = dict(call="rroi_align_v1 forward", bytes=4 * 512 * 256 * 49 * 17)
+for k in ("rroi_idx_count_kernel", "rroi_idx_fill_kernel", "rroi_gather_kernel"):
+    ALG[k] = dict(call="rroi_align_v1 backward (gather form)", bytes=4 * (512 * 49 * 256 + 2 * 256 * 256 * 256))
+ALG["fr_forward_kernel"] = dict(call="feature_refine forward", bytes=4 * (2 * 2 * 256 * 128 * 128 + 5 * 2 * 128 * 128))
+ALG["convex_sort_kernel"] = dict(call="convex_sort", bytes=20000 * (24 * 12 + 25 * 4))
+import json
+os.makedirs(os.environ.get("RSDET_ROOFLINE_DIR", "."), exist_ok=True)
+json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
 B, C, H = 4, 256, 128
 x = torch.randn(B, C, H, H, device=dev)
 off = torch.randn(B, 18, H, H, device=dev)
