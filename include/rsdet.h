@@ -129,6 +129,31 @@ int rsdet_anchor_target_rotated_f32(
     int* gt_inds, float* max_overlaps, int* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
     float* totals, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- a15  focal + smooth-L1 of one S2ANet module (FAM or ODM), all pyramid levels, one pass each way ----
+ * (csrc/losses.hip)  Replaces FocalLoss / sigmoid_focal_loss (models/losses/focal_loss.py:5-96), SmoothL1Loss
+ * (models/losses/smooth_l1_loss.py:5-54) and the per-level reshapes of loss_fam_single / loss_odm_single
+ * (models/roi_heads/s2anet_head.py:430-508): 2 x n_levels loss calls of ~10 elementwise kernels each.
+ * cls_maps / box_maps: HOST arrays of n_levels device pointers to the prediction maps as the convolutions
+ * leave them, (B, C, H_l, W_l) and (B, 5, H_l, W_l), fp32 or (bf16_maps != 0) bf16; hw_host[l] = H_l * W_l.
+ * labels (B, A) int32 1-based (0 = background), label_weights (B, A), bbox_targets / bbox_weights (B, A, 5)
+ * with A = sum_l hw[l], anchors level-major (the layout rsdet_anchor_target_rotated_f32 writes).
+ * avg_factor: one device float (num_total_pos).  losses (2, n_levels): row 0 = w_cls * focal sums / avg,
+ * row 1 = w_box * smooth-L1 sums / avg -- deterministic (fixed summation order).  alpha < 0: no alpha weighting.
+ * ws: rsdet_s2a_loss_ws_size() bytes whose first word is zero on entry (left zero again on exit).
+ * backward: grad_losses (2, n_levels) upstream; grad_cls / grad_box: host arrays of device pointers with the
+ * layouts and storage type of the inputs, every element written. */
+size_t rsdet_s2a_loss_ws_size(const int* hw_host, int n_levels, int B);
+int rsdet_s2a_loss_forward(const void* const* cls_maps, const void* const* box_maps, int bf16_maps,
+                           const int* hw_host, int n_levels, int B, int C, const int* labels,
+                           const float* label_weights, const float* bbox_targets, const float* bbox_weights,
+                           const float* avg_factor, float alpha, float gamma, float beta, float w_cls, float w_box,
+                           float* losses, void* ws, size_t ws_bytes, void* stream);
+int rsdet_s2a_loss_backward(const void* const* cls_maps, const void* const* box_maps, int bf16_maps,
+                            const int* hw_host, int n_levels, int B, int C, const int* labels,
+                            const float* label_weights, const float* bbox_targets, const float* bbox_weights,
+                            const float* avg_factor, const float* grad_losses, float alpha, float gamma, float beta,
+                            float w_cls, float w_box, void* const* grad_cls, void* const* grad_box, void* stream);
+
 /* ---- a16  rotated NMS -----------------------------------------------------------
  * Replaces nms_rotated_cpu / nms_rotated_cuda: ops/nms_rotated.py:495-512
  * (kernels :353-411 + host sweep :450-493, CPU loop :414-449).

@@ -43,6 +43,15 @@ SIGNATURES = {
         ctypes.POINTER(c_float), ctypes.POINTER(c_float),
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
         c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "rsdet_s2a_loss_ws_size": (c_size_t, [ctypes.POINTER(c_int), c_int, c_int]),
+    "rsdet_s2a_loss_forward": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_int),
+                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
+    "rsdet_s2a_loss_backward": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int,
+                                        ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float,
+                                        ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p]),
     "rsdet_nms_rotated_ws_size": (c_size_t, [c_int]),
     "rsdet_nms_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),

@@ -225,6 +225,30 @@ class S2ANetHead(nn.Module):
         """list of (B,ch,H,W) per level -> (B, A, ch) level-concatenated, anchor order = (h, w)."""
         return torch.cat([p.permute(0, 2, 3, 1).reshape(p.shape[0], -1, ch) for p in preds], dim=1)
 
+    def _fused_losses(self, cls_loss, bbox_loss, cls_maps, box_maps, labels, label_weights, bbox_targets, bbox_weights,
+                      avg, cfg):
+        """Both losses of one module over all levels as one HIP pass each way (ops/s2a_loss.py, csrc/losses.hip) --
+        when the configured modules are the sigmoid FocalLoss + SmoothL1Loss with 'mean' reduction, the maps are on the
+        GPU in one storage type, and the regression loss is on the encoded deltas.  None otherwise."""
+        import os
+        from rs_detection_amd.models.losses.focal_loss import FocalLoss
+        from rs_detection_amd.models.losses.smooth_l1_loss import SmoothL1Loss
+        if os.environ.get("RSDET_NO_FUSED_LOSS", "0") == "1":
+            return None
+        if type(cls_loss) is not FocalLoss or type(bbox_loss) is not SmoothL1Loss:
+            return None
+        if cls_loss.reduction != 'mean' or bbox_loss.reduction != 'mean' or cfg.get('reg_decoded_bbox', False):
+            return None
+        dt = cls_maps[0].dtype
+        if not cls_maps[0].is_cuda or dt not in (torch.float32, torch.bfloat16) or \
+                any(m.dtype != dt for m in list(cls_maps) + list(box_maps)):
+            return None
+        from rs_detection_amd.ops.s2a_loss import s2a_level_losses
+        out = s2a_level_losses(cls_maps, box_maps, labels, label_weights, bbox_targets, bbox_weights, avg,
+                               cls_loss.alpha, cls_loss.gamma, bbox_loss.beta, cls_loss.loss_weight,
+                               bbox_loss.loss_weight)
+        return list(out[0].unbind(0)), list(out[1].unbind(0))
+
     def _level_losses(self, cls_loss, bbox_loss, cls_score, bbox_pred, labels, label_weights, bbox_targets,
                       bbox_weights, num_level_anchors, avg):
         """Per-level loss lists like the reference's multi_apply(loss_*_single) (:430-508)."""
@@ -266,7 +290,9 @@ class S2ANetHead(nn.Module):
                                                                self.train_cfg['fam_cfg'], assigner, coder, valid,
                                                                ks=ks, cache_anchors=True)
         avg = npos + nneg if self.sampling else npos
-        losses_fam_cls, losses_fam_bbox = self._level_losses(
+        fused = self._fused_losses(self.loss_fam_cls, self.loss_fam_bbox, fam_cls_scores, fam_bbox_preds, labels, lw, bt,
+                                   bw, avg, self.train_cfg['fam_cfg'])
+        losses_fam_cls, losses_fam_bbox = fused if fused is not None else self._level_losses(
             self.loss_fam_cls, self.loss_fam_bbox, self._flatten(fam_cls_scores, C), self._flatten(fam_bbox_preds, 5),
             labels, lw, bt, bw, num_level_anchors, avg)
 
@@ -279,7 +305,9 @@ class S2ANetHead(nn.Module):
                                                                self.train_cfg['odm_cfg'], assigner, coder, valid,
                                                                ks=ks, heavy_from=heavy)
         avg = npos + nneg if self.sampling else npos
-        losses_odm_cls, losses_odm_bbox = self._level_losses(
+        fused = self._fused_losses(self.loss_odm_cls, self.loss_odm_bbox, odm_cls_scores, odm_bbox_preds, labels, lw, bt,
+                                   bw, avg, self.train_cfg['odm_cfg'])
+        losses_odm_cls, losses_odm_bbox = fused if fused is not None else self._level_losses(
             self.loss_odm_cls, self.loss_odm_bbox, self._flatten(odm_cls_scores, C), self._flatten(odm_bbox_preds, 5),
             labels, lw, bt, bw, num_level_anchors, avg)
         return dict(loss_fam_cls=losses_fam_cls, loss_fam_bbox=losses_fam_bbox, loss_odm_cls=losses_odm_cls,

@@ -18,3 +18,4 @@ from .convex_sort import convex_sort  # noqa: F401,E402
 from .dwconv import DepthwiseConv2d, dwconv2d  # noqa: F401,E402
 from .anchor_target import (prepare_boxes, row_tile_table, box_iou_rotated_tiled,  # noqa: F401,E402
                             anchor_target_rotated)
+from .s2a_loss import s2a_level_losses  # noqa: F401,E402

@@ -669,3 +669,64 @@ def test_f4_ops_empty_and_degenerate_inputs(cuda):
     assert torch.allclose(dwconv2d(one, w, None, 1), one * w[None, :, 0, 1:2, 1:2].reshape(1, 3, 1, 1), atol=1e-6)
     with pytest.raises(_lib.RsdetError):
         dwconv2d(one, torch.randn(3, 1, 3, 3, device=cuda), None, 2)       # (3, dilation 2) is not a covered geometry
+
+
+# ---- fused focal + smooth-L1 of one S2ANet module (csrc/losses.hip) ---------------------------------------------
+@pytest.mark.parametrize("dtype,B,size", [(torch.float32, 2, 256), (torch.float32, 3, 136), (torch.bfloat16, 2, 256)])
+def test_s2a_level_losses_vs_oracle_and_torch(cuda, dtype, B, size):
+    """(2, L) per-level losses == the oracle's focal / smooth-L1 (focal_loss.py:5-96, smooth_l1_loss.py:5-54) on the
+    permuted maps, == the torch modules of the product; gradients == torch autograd of those modules."""
+    import oracle
+    from rs_detection_amd import ops
+    from rs_detection_amd.models.losses.focal_loss import FocalLoss
+    from rs_detection_amd.models.losses.smooth_l1_loss import SmoothL1Loss
+    rng = np.random.default_rng(B * size)
+    C, strides = 15, (8, 16, 32, 64, 128)
+    hws = [(-(-size // s)) ** 2 for s in strides]
+    A = sum(hws)
+    cls = [torch.from_numpy(rng.normal(-2, 2, (B, C, int(h ** 0.5), int(h ** 0.5))).astype(np.float32)).to(cuda).to(dtype)
+           for h in hws]
+    box = [torch.from_numpy(rng.normal(0, 0.5, (B, 5, int(h ** 0.5), int(h ** 0.5))).astype(np.float32)).to(cuda).to(dtype)
+           for h in hws]
+    labels = rng.integers(0, C + 1, (B, A)).astype(np.int32)
+    labels[rng.random((B, A)) < 0.9] = 0
+    lw = (rng.random((B, A)) < 0.95).astype(np.float32)
+    bw = np.repeat((labels > 0)[..., None], 5, -1).astype(np.float32)
+    bt = (rng.normal(0, 0.5, (B, A, 5)) * bw).astype(np.float32)
+    avg = float(max((labels > 0).sum(), 1))
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    for m in cls + box:
+        m.requires_grad_(True)
+    got = ops.s2a_level_losses(cls, box, t(labels), t(lw), t(bt), t(bw), torch.tensor(avg, device=cuda), 0.25, 2.0, 1 / 9,
+                               1.0, 1.0)
+    assert got.shape == (2, 5)
+    again = ops.s2a_level_losses(cls, box, t(labels), t(lw), t(bt), t(bw), torch.tensor(avg, device=cuda), 0.25, 2.0,
+                                 1 / 9, 1.0, 1.0)
+    assert torch.equal(got, again)                       # deterministic reduction order
+    focal, sl1 = FocalLoss(True, 2.0, 0.25), SmoothL1Loss(1 / 9)
+    want_t, s = [], 0
+    for l, h in enumerate(hws):
+        cs = cls[l].float().permute(0, 2, 3, 1).reshape(-1, C)
+        bp = box[l].float().permute(0, 2, 3, 1).reshape(-1, 5)
+        sl = slice(s, s + h)
+        a = focal(cs, t(labels)[:, sl].reshape(-1), t(lw)[:, sl].reshape(-1), avg_factor=avg)
+        b = sl1(bp, t(bt)[:, sl].reshape(-1, 5), t(bw)[:, sl].reshape(-1, 5), avg_factor=avg)
+        want_t.append((a, b))
+        # oracle (float64 restatement) on the values the kernel saw
+        oa = oracle.np_sigmoid_focal_loss(cs.detach().cpu().numpy(), labels[:, sl].reshape(-1), lw[:, sl].reshape(-1), 2.0,
+                                          0.25, avg)
+        ob = oracle.np_smooth_l1_loss(bp.detach().cpu().numpy(), bt[:, sl].reshape(-1, 5), bw[:, sl].reshape(-1, 5), 1 / 9,
+                                      avg)
+        assert abs(float(got[0, l]) - oa) <= 1e-5 * max(abs(oa), 1e-3) + 1e-6, (l, float(got[0, l]), oa)
+        assert abs(float(got[1, l]) - ob) <= 1e-5 * max(abs(ob), 1e-3) + 1e-6, (l, float(got[1, l]), ob)
+        s += h
+    # gradients: random upstream weights per scalar
+    up = torch.from_numpy(rng.uniform(0.5, 1.5, (2, 5)).astype(np.float32)).to(cuda)
+    g_mine = torch.autograd.grad((got * up).sum(), cls + box)
+    ref = sum(a * up[0, l] + b * up[1, l] for l, (a, b) in enumerate(want_t))
+    g_ref = torch.autograd.grad(ref, cls + box)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for gm, gr in zip(g_mine, g_ref):
+        assert gm.dtype == gr.dtype == dtype and gm.shape == gr.shape
+        scale = float(gr.float().abs().max()) + 1e-12
+        assert float((gm.float() - gr.float()).abs().max()) <= tol * scale + 1e-9
