@@ -75,9 +75,15 @@ def test_r101_bf16_train_step_at_ms_shapes(cuda, size, batch):
     from rs_detection_amd.runner.runner import Runner
     import warnings
     torch.manual_seed(0)
+    cfg = Config(CFG)
+    # No ImageNet weights offline: with BatchNorm frozen at identity statistics (norm_eval, the config's default for a
+    # PRETRAINED trunk) a randomly initialised 101-layer trunk multiplies its activations up to ~1e6, the FAM
+    # regression explodes and AlignConv samples outside the map (measured: loss 9.5e5, ODM gradients exactly 0, fp32
+    # and bf16 alike).  Let the statistics adapt so that the step is a meaningful one.
+    cfg.model["backbone"].update(pretrained=False, norm_eval=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
-        runner = Runner(Config(CFG), device=cuda, distributed=False, amp_dtype=torch.bfloat16)
+        runner = Runner(cfg, device=cuda, distributed=False, amp_dtype=torch.bfloat16)
     images = torch.randn(batch, 3, size, size, device=cuda)
     targets = _targets(cuda, batch, size, 40)
     first = None
