@@ -311,6 +311,12 @@ size_t rsdet_rroi_align_v1_backward_gather_ws_size(int R, int PH, int PW, int sa
 int rsdet_rroi_align_v1_backward_gather_f32(const float* grad_out_t, const float* rois, int R, int C, int N, int H,
                                             int W, int PH, int PW, float spatial_scale, int sample_num,
                                             float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream);
+/* ... and with the result written in NCHW (N, C, H, W), the layout of the features and of the convolution that
+ * receives the gradient: every element written exactly once, no (N,H,W,C) intermediate, no transposes of the
+ * feature-sized gradient (workgroup = 64 pixels, 64-channel chunks transposed through LDS). */
+int rsdet_rroi_align_v1_backward_gather_nchw_f32(const float* grad_out_t, const float* rois, int R, int C, int N,
+                                                 int H, int W, int PH, int PW, float spatial_scale, int sample_num,
+                                                 float* grad_feat_nchw, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- f4  ROIAlignRotated (v0) -----------------------------------------------------------------
  * Replaces _RotatedROIAlign.execute / .grad: ops/roi_align_rotated.py:256-309 (kernels :59-126, :170-254).
@@ -326,6 +332,9 @@ int rsdet_rroi_align_v0_backward_f32(const float* grad_out, const float* rois, i
 int rsdet_rroi_align_v0_backward_gather_f32(const float* grad_out_t, const float* rois, int R, int C, int N, int H,
                                             int W, int PH, int PW, float spatial_scale, int sample_num,
                                             float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream);
+int rsdet_rroi_align_v0_backward_gather_nchw_f32(const float* grad_out_t, const float* rois, int R, int C, int N,
+                                                 int H, int W, int PH, int PW, float spatial_scale, int sample_num,
+                                                 float* grad_feat_nchw, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- f4  FeatureRefine (R3Det) --------------------------------------------------------------------
  * Replaces feature_refine_forward / feature_refine_backward: ops/fr.py:234-252 (kernels :113-173, :175-232).

@@ -93,6 +93,12 @@ SIGNATURES = {
     "rsdet_rroi_align_v1_backward_gather_ws_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "rsdet_rroi_align_v1_backward_gather_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                         c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_rroi_align_v1_backward_gather_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                             c_int, c_float, c_int, c_void_p, c_void_p, c_size_t,
+                                                             c_void_p]),
+    "rsdet_rroi_align_v0_backward_gather_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                             c_int, c_float, c_int, c_void_p, c_void_p, c_size_t,
+                                                             c_void_p]),
     "rsdet_rroi_align_v0_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 c_float, c_int, c_void_p, c_void_p]),
     "rsdet_rroi_align_v0_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -228,6 +228,51 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(const float* __restric
   }
 }
 
+// The same gather with the result written in NCHW -- what the convolution before the RoI head wants -- so that the
+// caller needs neither a (N,H,W,C) -> (N,C,H,W) transpose of the whole feature gradient (128 MB each way for a
+// 2 x 256 x 256 x 256 level) nor a pre-zeroed output.  A workgroup owns 64 consecutive pixels; per chunk of 64
+// channels each wave sums its 16 pixels (lanes = channels: the 256-byte rows of go_t are read coalesced), parks the
+// sums in an LDS tile, and the tile goes out transposed: lanes = pixels, one coalesced 256-byte store per channel.
+__global__ __launch_bounds__(256) void rroi_gather_nchw_kernel(const float* __restrict__ go_t, const int* __restrict__ start,
+                                                               const int* __restrict__ ent_row,
+                                                               const float* __restrict__ ent_w, long long npix, int C,
+                                                               int HW, float* __restrict__ grad_nchw) {
+  __shared__ float s_tile[64][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long p0 = (long long)rsdet_xcd_contiguous(blockIdx.x, gridDim.x) * 64;
+  // this lane's pixel in the write phase
+  const long long pw = p0 + lane;
+  const long long n_w = pw / HW;
+  const long long hw_w = pw - n_w * HW;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    for (int k = 0; k < 16; ++k) {
+      const int pl = wave * 16 + k;
+      const long long pix = p0 + pl;
+      float acc = 0.f;
+      if (pix < npix && c < C) {
+        const int e0 = start[pix], e1 = start[pix + 1];
+        int e = e0;
+        for (; e + 2 <= e1; e += 2) {
+          const float v0 = go_t[(long long)ent_row[e] * C + c], v1 = go_t[(long long)ent_row[e + 1] * C + c];
+          acc += ent_w[e] * v0;
+          acc += ent_w[e + 1] * v1;
+        }
+        if (e < e1) acc += ent_w[e] * go_t[(long long)ent_row[e] * C + c];
+      }
+      s_tile[pl][lane] = acc;
+    }
+    __syncthreads();
+    if (pw < npix) {
+      for (int k = 0; k < 16; ++k) {
+        const int ch = wave * 16 + k;
+        if (c0 + ch < C) grad_nchw[(n_w * C + c0 + ch) * HW + hw_w] = s_tile[lane][ch];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -276,6 +321,12 @@ void rsdet_launch_pixel_gather(const float* rows, const int* start, const int* e
                        out_nhwc);
 }
 
+static void launch_pixel_gather_nchw(const float* rows, const int* start, const int* ent_row, const float* ent_w,
+                                     long long npix, int C, int HW, float* out_nchw, hipStream_t s) {
+  hipLaunchKernelGGL(rroi_gather_nchw_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, s, rows, start, ent_row,
+                     ent_w, npix, C, HW, out_nchw);
+}
+
 static inline size_t rroi_align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" size_t rsdet_rroi_align_v1_backward_gather_ws_size(int R, int PH, int PW, int sample_num, int N, int H,
@@ -287,7 +338,7 @@ extern "C" size_t rsdet_rroi_align_v1_backward_gather_ws_size(int R, int PH, int
 
 static int rroi_backward_gather(const float* grad_out_t, const float* rois, int R, int C, int N, int H, int W, int PH,
                                 int PW, float spatial_scale, int sample_num, int v0, float* grad_feat_nhwc, void* ws,
-                                size_t ws_bytes, void* stream) {
+                                size_t ws_bytes, void* stream, bool nchw = false) {
   int rc = rroi_check(R, C, H, W, PH, PW);
   if (rc) return rc;
   if (sample_num < 1 || N < 1) return RSDET_EINVAL;  // adaptive sampling (sample_num <= 0): use the scatter form
@@ -313,7 +364,10 @@ static int rroi_backward_gather(const float* grad_out_t, const float* rois, int 
   rsdet_launch_index_scan(cnt, npix, chunk_sum, start, s);
   hipLaunchKernelGGL(rroi_idx_fill_kernel, dim3(ib), dim3(256), 0, s, rois, items, H, W, PH, PW, spatial_scale,
                      sample_num, v0, npix, start, cnt, ent_row, ent_w);
-  rsdet_launch_pixel_gather(grad_out_t, start, ent_row, ent_w, npix, C, grad_feat_nhwc, s);
+  if (nchw)
+    launch_pixel_gather_nchw(grad_out_t, start, ent_row, ent_w, npix, C, H * W, grad_feat_nhwc, s);
+  else
+    rsdet_launch_pixel_gather(grad_out_t, start, ent_row, ent_w, npix, C, grad_feat_nhwc, s);
   return rsdet_launch_status();
 }
 
@@ -333,6 +387,12 @@ static int rroi_backward_gather(const float* grad_out_t, const float* rois, int 
       float spatial_scale, int sample_num, float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream) {         \
     return rroi_backward_gather(grad_out_t, rois, R, C, N, H, W, PH, PW, spatial_scale, sample_num, v0,              \
                                 grad_feat_nhwc, ws, ws_bytes, stream);                                               \
+  }                                                                                                                   \
+  extern "C" int rsdet_rroi_align_##tag##_backward_gather_nchw_f32(                                                   \
+      const float* grad_out_t, const float* rois, int R, int C, int N, int H, int W, int PH, int PW,                  \
+      float spatial_scale, int sample_num, float* grad_feat_nchw, void* ws, size_t ws_bytes, void* stream) {         \
+    return rroi_backward_gather(grad_out_t, rois, R, C, N, H, W, PH, PW, spatial_scale, sample_num, v0,              \
+                                grad_feat_nchw, ws, ws_bytes, stream, true);                                         \
   }
 RSDET_RROI_ENTRY(v1, 0)
 RSDET_RROI_ENTRY(v0, 1)

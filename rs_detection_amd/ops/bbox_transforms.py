@@ -83,9 +83,63 @@ def hbb2obb(hbboxes):
     return torch.where((w >= h)[..., None], o1, o2)
 
 
-def _poly2obb(polys):
-    raise NotImplementedError("poly2obb needs cv2.minAreaRect (bbox_transforms.py:547-575); not on the S2ANet/ORCNN train path")
+def min_area_rect(pts):
+    """Minimum-area enclosing rectangle of a point set (n, 2) by rotating calipers over the convex hull -- the role of
+    ``cv2.minAreaRect`` (OpenCV is not available; third-party, PARITY UNPINNED: among rectangles of equal area OpenCV's
+    choice of edge is not reproduced).  -> (cx, cy, w, h, theta) with w >= h and theta in [-pi/2, pi/2), theta measured
+    like the reference's obb angle after its `poly2obb` sign handling (bbox_transforms.py:556-563)."""
+    p = np.unique(np.asarray(pts, np.float64).reshape(-1, 2), axis=0)
+    if len(p) == 1:
+        return float(p[0, 0]), float(p[0, 1]), 0.0, 0.0, 0.0
+    # Andrew monotone chain
+    p = p[np.lexsort((p[:, 1], p[:, 0]))]
 
+    def half(points):
+        h = []
+        for q in points:
+            while len(h) >= 2 and np.cross(h[-1] - h[-2], q - h[-2]) <= 0:
+                h.pop()
+            h.append(q)
+        return h
+    lower, upper = half(p), half(p[::-1])
+    hull = np.array(lower[:-1] + upper[:-1])
+    if len(hull) < 3:                                   # collinear: a segment
+        d = hull[-1] - hull[0]
+        L = float(np.hypot(*d))
+        c = (hull[0] + hull[-1]) / 2
+        theta = -np.arctan2(d[1], d[0])
+        theta = (theta + np.pi / 2) % np.pi - np.pi / 2
+        return float(c[0]), float(c[1]), L, 0.0, float(theta)
+    best = None
+    for i in range(len(hull)):
+        e = hull[(i + 1) % len(hull)] - hull[i]
+        n = np.hypot(*e)
+        if n == 0:
+            continue
+        u = e / n
+        v = np.array([-u[1], u[0]])
+        pu, pv = hull @ u, hull @ v
+        w, h = pu.max() - pu.min(), pv.max() - pv.min()
+        if best is None or w * h < best[0] - 1e-12:
+            c = u * (pu.max() + pu.min()) / 2 + v * (pv.max() + pv.min()) / 2
+            best = (w * h, c, w, h, np.arctan2(u[1], u[0]))
+    _, c, w, h, ang = best
+    if w < h:
+        w, h, ang = h, w, ang + np.pi / 2
+    theta = -ang                                          # image y points down: the obb angle is clockwise-positive
+    theta = (theta + np.pi / 2) % np.pi - np.pi / 2
+    return float(c[0]), float(c[1]), float(w), float(h), float(theta)
+
+
+def _poly2obb(polys):
+    """bbox_transforms.py:547-575 (host loop over ``cv2.minAreaRect``) with ``min_area_rect`` above."""
+    flat = polys.detach().cpu().double().numpy().reshape(-1, polys.shape[-1] // 2, 2)
+    out = np.array([min_area_rect(q) for q in flat], np.float64).reshape(*polys.shape[:-1], 5) if len(flat) else \
+        np.zeros((*polys.shape[:-1], 5))
+    return torch.from_numpy(out).to(polys.device, polys.dtype if polys.is_floating_point() else torch.float32)
+
+
+poly2obb = _poly2obb
 
 _type_func_map = {('poly', 'obb'): _poly2obb, ('poly', 'hbb'): poly2hbb, ('obb', 'poly'): obb2poly,
                   ('obb', 'hbb'): obb2hbb, ('hbb', 'poly'): hbb2poly, ('hbb', 'obb'): hbb2obb}

@@ -170,6 +170,37 @@ class Runner:
             return None
         return self.val_dataset.evaluate(results, self.work_dir, self.epoch, device=self.device)
 
+    def test(self, name=None):
+        """:210-249: predictions of ``test_dataset`` (plus the 'H' / 'V' / 'HV' flipped passes named by
+        ``cfg.flip_test``), pickled to ``<work_dir>/test/test_<epoch>.pkl`` like the reference, and -- for an
+        ImageDataset of tiles -- merged into whole-image detections and the submission archive
+        (data/devkits/data_merge.py; ``cfg.merge_nms_threshold_type`` selects the per-class NMS thresholds)."""
+        import os
+        import pickle
+        if self.test_dataset is None:
+            return None
+        flips = list(getattr(self.cfg, "flip_test", None) or [])
+        assert all(m in ("H", "V", "HV") for m in flips), flips
+        results = self._predict_dataset(self.test_dataset, flips)
+        if self.rank != 0:
+            return None
+        out = dict(results=results)
+        if self.work_dir:
+            os.makedirs(os.path.join(self.work_dir, "test"), exist_ok=True)
+            pkl = os.path.join(self.work_dir, "test", "test_%d.pkl" % self.epoch)
+            with open(pkl, "wb") as f:
+                pickle.dump(results, f)
+            out["pkl"] = pkl
+            ds_cfg = (self.cfg.dataset or {}).get("test", {}) if hasattr(self.cfg, "dataset") else {}
+            if ds_cfg.get("type") == "ImageDataset":
+                from rs_detection_amd.data.devkits.data_merge import data_merge_result
+                nm = name or ("%s_epoch%d" % (getattr(self.cfg, "name", None) or "run", self.epoch))
+                out["submission"] = data_merge_result(
+                    results, self.work_dir, self.epoch, nm, self.test_dataset.dataset_type,
+                    ds_cfg.get("images_dir", ""), device=self.device,
+                    nms_threshold_type=getattr(self.cfg, "merge_nms_threshold_type", None) or 0)
+        return out
+
     def run(self, checkpoint_interval=None, eval_interval=None, log_interval=50):
         """:91-103: train epochs until ``max_epoch``; checkpoint / evaluate at the config's intervals."""
         import os

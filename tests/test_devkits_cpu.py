@@ -135,3 +135,64 @@ def test_voc_eval_dota_and_driver_against_literal_restatement():
     cd = dets[dets[:, -1] == 1][:, :-1]
     g1 = {0: dict(box=np.zeros((0, 8)), det=[], difficult=np.zeros(0, bool))}
     assert voc_eval_dota(cd[:0], g1, iou_func=opoly.iou_poly) == (0., 0., 0.)
+
+
+# ---- test-time submission pipeline (data/devkits/data_merge.py) and poly2obb -------------------------------------
+def test_flip_box_prepare_data_and_fair_csv(tmp_path):
+    """data_merge.py:14-48 and dota_to_fair.py:6-36,102-118 restated: a flipped tile's polygon is mirrored back with the
+    tile's own size; one Task-1 line per detection with 4 decimals; the FAIR1M-1.5 csv carries `<id>.tif,class,...`."""
+    from rs_detection_amd.data.devkits import data_merge as DM
+    box = [10., 20., 30., 20., 30., 40., 10., 40.]
+    tgt = dict(ori_img_size=(100, 80), img_file="/x/P0007__1.0__0___0.png")
+    assert DM.flip_box(box, tgt) == box
+    assert DM.flip_box(box, dict(tgt, flip_mode="H")) == [90., 20., 70., 20., 70., 40., 90., 40.]
+    assert DM.flip_box(box, dict(tgt, flip_mode="V")) == [10., 60., 30., 60., 30., 40., 10., 40.]
+    assert DM.flip_box(box, dict(tgt, flip_mode="HV")) == [90., 60., 70., 60., 70., 40., 90., 40.]
+    res = [((np.array([box, box]), np.array([0.91234, 0.5]), np.array([0, 2])), tgt),
+           ((np.array([box]), np.array([0.7]), np.array([0])), dict(tgt, flip_mode="H"))]
+    classes = ["Airplane", "Ship", "Vehicle"]
+    DM.prepare_data(res, str(tmp_path / "before"), classes)
+    air = open(tmp_path / "before" / "Airplane.txt").read().splitlines()
+    assert air[0] == "P0007__1.0__0___0 0.9123 10.0000 20.0000 30.0000 20.0000 30.0000 40.0000 10.0000 40.0000"
+    assert air[1].startswith("P0007__1.0__0___0 0.7000 90.0000 20.0000") and len(air) == 2
+    assert len(open(tmp_path / "before" / "Vehicle.txt").read().splitlines()) == 1
+    # merged files -> csv
+    (tmp_path / "imgs").mkdir()
+    for n in ("P0007__1.0__0___0.png", "P0012__1.0__0___0.png", "notes.txt"):
+        (tmp_path / "imgs" / n).write_text("")
+    (tmp_path / "after").mkdir()
+    (tmp_path / "after" / "Tennis_Court.txt").write_text("P0007 0.9 1.0 2.0 3.0 4.0 5.0 6.0 7.0 8.0\n")
+    got = DM.pick_res(str(tmp_path / "after"), str(tmp_path / "imgs"), keep_underline=True)
+    assert set(got) == {"P0007", "P0012"} and got["P0012"] == [] and got["P0007"][0]["cls"] == "Tennis_Court"
+    assert DM.pick_res(str(tmp_path / "after"), str(tmp_path / "imgs"))["P0007"][0]["cls"] == "Tennis Court"
+    csv = DM.dota_to_fair1m_1_5(str(tmp_path / "after"), str(tmp_path / "fair"), str(tmp_path / "imgs"), "sub")
+    assert open(csv).read() == "7.tif,Tennis_Court,1.0000,2.0000,3.0000,4.0000,5.0000,6.0000,7.0000,8.0000,0.9000\n"
+
+
+def test_poly2obb_min_area_rect():
+    """The role of cv2.minAreaRect (absent here): exact on rectangles (any point order, duplicates), the enclosing
+    rectangle of a general quadrilateral has the smallest area over all hull-edge directions, w >= h and the angle in
+    [-pi/2, pi/2) -- the regular form `bbox2type(polys, 'obb')` promises (bbox_transforms.py:547-575)."""
+    import torch
+    from rs_detection_amd.ops import bbox_transforms as T
+    rng = np.random.default_rng(0)
+    obb = np.stack([rng.uniform(50, 200, 60), rng.uniform(50, 200, 60), rng.uniform(20, 80, 60), rng.uniform(5, 19, 60),
+                    rng.uniform(-np.pi / 2, np.pi / 2 - 1e-3, 60)], 1).astype(np.float32)
+    poly = T.obb2poly(torch.from_numpy(obb))
+    np.testing.assert_allclose(T.poly2obb(poly).numpy(), obb, atol=1e-3)
+    perm = poly.reshape(-1, 4, 2)[:, [2, 0, 3, 1]].reshape(-1, 8)                 # another vertex order
+    np.testing.assert_allclose(T.bbox2type(perm, 'obb').numpy(), obb, atol=1e-3)
+    quad = np.array([[0, 0, 10, 1, 12, 6, 1, 4]], np.float32)
+    x, y, w, h, t = T.poly2obb(torch.from_numpy(quad))[0].tolist()
+    assert w >= h and -np.pi / 2 <= t < np.pi / 2
+    pts = quad.reshape(4, 2)
+    for ang in np.linspace(0, np.pi, 721):                                          # no direction does better
+        u = np.array([np.cos(ang), np.sin(ang)])
+        v = np.array([-u[1], u[0]])
+        assert np.ptp(pts @ u) * np.ptp(pts @ v) >= w * h - 1e-3
+    rect = T.obb2poly(torch.tensor([[x, y, w, h, t]])).numpy().reshape(4, 2)        # ... and it contains the points
+    e = np.roll(rect, -1, 0) - rect
+    for q in pts:
+        s = np.sign(e[:, 0] * (q - rect)[:, 1] - e[:, 1] * (q - rect)[:, 0])
+        assert (s >= -1e-6).all() or (s <= 1e-6).all() or np.abs(e[:, 0] * (q - rect)[:, 1] - e[:, 1] * (q - rect)[:, 0]).min() < 1e-2
+    assert T.poly2obb(torch.zeros((0, 8))).shape == (0, 5)
