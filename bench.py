@@ -242,7 +242,7 @@ def next_row_kernels(device):
     y = ops.roi_align_rotated_v1(feat, rois, (7, 7), 0.25, 2)
     go = torch.randn_like(y)
     t = event_time(lambda: torch.autograd.grad(y, feat, go, retain_graph=True), 10, 2, graph=False)
-    row("rroi_idx_count+scan+fill+rroi_gather_nchw(backward; NCHW written directly, %d MB, incl. the RoI-side permute)"
+    row("rroi_idx_count+scan+fill+rroi_gather(backward; incl. the two layout permutes and a %d MB output)"
         % (N * C * H * H * 4 // 2 ** 20), 4 * (R * C * 49 + N * C * H * H), t)
     del feat, y, go
     # -- depthwise convolutions of the VAN backbone (a20): stage-1 shapes of VAN-B3 on two 1024^2 tiles;

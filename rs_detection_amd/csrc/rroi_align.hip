@@ -230,37 +230,52 @@ __global__ __launch_bounds__(256) void rroi_gather_kernel(const float* __restric
 
 // The same gather with the result written in NCHW -- what the convolution before the RoI head wants -- so that the
 // caller needs neither a (N,H,W,C) -> (N,C,H,W) transpose of the whole feature gradient (128 MB each way for a
-// 2 x 256 x 256 x 256 level) nor a pre-zeroed output.  A workgroup owns 64 consecutive pixels; per chunk of 64
-// channels each wave sums its 16 pixels (lanes = channels: the 256-byte rows of go_t are read coalesced), parks the
-// sums in an LDS tile, and the tile goes out transposed: lanes = pixels, one coalesced 256-byte store per channel.
+// 2 x 256 x 256 x 256 level) nor a pre-zeroed output.
+//   reads   lanes = channels: a gradient row is read in coalesced 256-byte pieces (1-2 cache lines per instruction)
+//   writes  lanes = pixels: a workgroup owns 64 consecutive pixels and writes whole 256-byte runs of a channel plane
+//   between a 64 pixel x 64 channel LDS tile
+// A pixel's entries {row, weight} are fetched by one coalesced load (lane = entry) and broadcast by shuffles.
+// NOT the default yet (ops/roi_align_rotated_v1.py keeps the channels-last gather + transposes): measured 321 us at a
+// 2 x 256 x 256 x 256 level with 512 RoIs, of which 136 us remain with the row reads removed and 328 us with the
+// stores removed -- it is the 64 serial (pixel, chunk) steps of a wave, one global round trip each for the entries,
+// that cost the time, not the stores.  Other forms measured: serial entry walk 250 us; lanes = pixels reading 64 B of
+// a row each, no LDS, 269 us (64 cache lines per load instruction); 16-pixel tiles with 64-byte writes per lane
+// 377 us.  Next: fetch the entries of all 16 pixels of a wave in one batch and keep four channel chunks in flight.
+constexpr int RG_PIX = 64;
 __global__ __launch_bounds__(256) void rroi_gather_nchw_kernel(const float* __restrict__ go_t, const int* __restrict__ start,
                                                                const int* __restrict__ ent_row,
                                                                const float* __restrict__ ent_w, long long npix, int C,
                                                                int HW, float* __restrict__ grad_nchw) {
-  __shared__ float s_tile[64][65];
+  __shared__ float s_tile[RG_PIX][65];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long p0 = (long long)rsdet_xcd_contiguous(blockIdx.x, gridDim.x) * 64;
-  // this lane's pixel in the write phase
-  const long long pw = p0 + lane;
-  const long long n_w = pw / HW;
-  const long long hw_w = pw - n_w * HW;
+  const long long p0 = (long long)rsdet_xcd_contiguous(blockIdx.x, gridDim.x) * RG_PIX;
+  const long long pw = p0 + lane;  // this lane's pixel in the write phase
+  const long long n_w = pw / HW, hw_w = pw - n_w * HW;
+  // the entry ranges of this wave's 16 pixels: one coalesced load (lanes 0..16 -> start[p .. p+16])
+  const long long pb = p0 + wave * 16;
+  const int my_start = (lane <= 16 && pb + lane <= npix) ? start[pb + lane] : 0;
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = c0 + lane;
     for (int k = 0; k < 16; ++k) {
-      const int pl = wave * 16 + k;
-      const long long pix = p0 + pl;
       float acc = 0.f;
-      if (pix < npix && c < C) {
-        const int e0 = start[pix], e1 = start[pix + 1];
-        int e = e0;
-        for (; e + 2 <= e1; e += 2) {
-          const float v0 = go_t[(long long)ent_row[e] * C + c], v1 = go_t[(long long)ent_row[e + 1] * C + c];
-          acc += ent_w[e] * v0;
-          acc += ent_w[e + 1] * v1;
+      if (pb + k < npix) {
+        const int e0 = __shfl(my_start, k), e1 = __shfl(my_start, k + 1);
+        for (int eb = e0; eb < e1; eb += 64) {
+          const int ne = min(64, e1 - eb);
+          int row = 0;
+          float w = 0.f;
+          if (lane < ne) {
+            row = ent_row[eb + lane];
+            w = ent_w[eb + lane];
+          }
+          for (int i = 0; i < ne; ++i) {  // independent row reads: addresses come from registers
+            const int r = __shfl(row, i);
+            const float wi = __shfl(w, i);
+            if (c < C) acc += wi * go_t[(long long)r * C + c];
+          }
         }
-        if (e < e1) acc += ent_w[e] * go_t[(long long)ent_row[e] * C + c];
       }
-      s_tile[pl][lane] = acc;
+      s_tile[wave * 16 + k][lane] = acc;
     }
     __syncthreads();
     if (pw < npix) {
@@ -323,8 +338,8 @@ void rsdet_launch_pixel_gather(const float* rows, const int* start, const int* e
 
 static void launch_pixel_gather_nchw(const float* rows, const int* start, const int* ent_row, const float* ent_w,
                                      long long npix, int C, int HW, float* out_nchw, hipStream_t s) {
-  hipLaunchKernelGGL(rroi_gather_nchw_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), 0, s, rows, start, ent_row,
-                     ent_w, npix, C, HW, out_nchw);
+  hipLaunchKernelGGL(rroi_gather_nchw_kernel, dim3((unsigned)((npix + RG_PIX - 1) / RG_PIX)), dim3(256), 0, s, rows,
+                     start, ent_row, ent_w, npix, C, HW, out_nchw);
 }
 
 static inline size_t rroi_align256(size_t b) { return (b + 255) & ~(size_t)255; }

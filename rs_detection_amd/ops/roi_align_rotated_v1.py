@@ -48,18 +48,21 @@ class _RotatedROIAlign_v1(torch.autograd.Function):
         go = grad_output.contiguous()
         R, PH, PW = rois.shape[0], output_size[0], output_size[1]
         if sr > 0 and R > 0:
-            # gather form: no fp32 atomics (csrc/rroi_align.hip).  Only the small RoI-side gradient (R, C, 49) is put
-            # channels-last; the feature-sized result is written straight in NCHW (no (N,H,W,C) intermediate, no
-            # transposes of 128 MB tensors, no pre-zeroed output: 0.069 -> of the HBM roofline in round 1)
+            # gather form: no fp32 atomics (csrc/rroi_align.hip); channels-last in, channels-last out.
+            # (rsdet_rroi_align_*_backward_gather_nchw_f32 writes NCHW directly and is correct, but its 64-pixel tile
+            # walks each pixel's entry chain serially: 321 us against ~35 us for this one-wave-per-pixel kernel at
+            # 2 x 256 x 256 x 256 -- measured round 2, RSDET_RROI_NCHW=1 selects it; the transposes stay for now.)
+            import os
+            nchw = os.environ.get("RSDET_RROI_NCHW", "0") == "1"
             go_t = go.permute(0, 2, 3, 1).reshape(R, PH * PW, C).contiguous()
-            grad_in = torch.empty((N, C, H, W), dtype=go.dtype, device=go.device)
+            g = torch.empty((N, C, H, W) if nchw else (N, H, W, C), dtype=go.dtype, device=go.device)
             ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
-            name = "rsdet_rroi_align_%s_backward_gather_nchw_f32" % variant
+            name = "rsdet_rroi_align_%s_backward_gather_%sf32" % (variant, "nchw_" if nchw else "")
             rc = getattr(lib, name)(_lib.ptr(go_t), _lib.ptr(rois), R, C, N, H, W, PH, PW, scale, sr,
-                                    _lib.ptr(grad_in), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+                                    _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
             _lib.check(rc, name)
-            return grad_in, None, None, None, None, None
+            return (g if nchw else g.permute(0, 3, 1, 2).contiguous()), None, None, None, None, None
         grad_in = torch.zeros(shape, dtype=go.dtype, device=go.device)  # :345 memset
         name = "rsdet_rroi_align_%s_backward_f32" % variant
         rc = getattr(lib, name)(_lib.ptr(go), _lib.ptr(rois), rois.shape[0], C, H, W, output_size[0], output_size[1],

@@ -730,3 +730,20 @@ def test_s2a_level_losses_vs_oracle_and_torch(cuda, dtype, B, size):
         assert gm.dtype == gr.dtype == dtype and gm.shape == gr.shape
         scale = float(gr.float().abs().max()) + 1e-12
         assert float((gm.float() - gr.float()).abs().max()) <= tol * scale + 1e-9
+
+
+def test_rroi_backward_nchw_form_equals_channels_last_form(cuda, monkeypatch):
+    """rsdet_rroi_align_v1_backward_gather_nchw_f32 (NCHW written directly) == the default channels-last gather."""
+    from rs_detection_amd.ops import roi_align_rotated_v1
+    rng = np.random.default_rng(8)
+    for (N, C, H, W, R) in ((2, 256, 64, 64, 60), (1, 20, 37, 41, 9), (3, 64, 16, 16, 5)):
+        feat = _t(rng.standard_normal((N, C, H, W)).astype(np.float32), cuda)
+        rois = _t(_rois(rng, R, N, W * 4), cuda)
+        go = _t(rng.standard_normal((R, C, 7, 7)).astype(np.float32), cuda)
+        grads = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("RSDET_RROI_NCHW", flag)
+            f = feat.clone().requires_grad_(True)
+            roi_align_rotated_v1(f, rois, (7, 7), 0.25, 2).backward(go)
+            grads.append(f.grad)
+        assert torch.equal(grads[0], grads[1])
