@@ -340,10 +340,14 @@ def main():
                     help="s2anet_r50 = BASELINE configs[1] (the metric, default); orcnn_van3 = the Oriented R-CNN + VAN-B3 "
                          "model of configs[3] (RROIAlign + rotated NMS in the train step), 2 tiles per GPU as in the "
                          "reference config; reported under its own workload name, no kernel table")
-    ap.add_argument("--memory-format", choices=["channels_last", "contiguous"], default="contiguous",
-                    help="activation layout of the torch/MIOpen part (measured r1 on MI355X, fp32: "
-                         "NCHW 68.7 ms/step, channels_last 494 ms/step)")
+    ap.add_argument("--memory-format", choices=["channels_last", "contiguous", "trunk_channels_last"], default=None,
+                    help="activation layout of the torch/MIOpen part.  Default: contiguous (NCHW) for f32 -- MIOpen's fp32 "
+                         "Winograd kernels are NCHW-native (channels_last measured 494 vs 68.7 ms/step in round 1) -- and "
+                         "channels_last for bf16, whose MIOpen kernels are NHWC-native (round 2, with the NHWC BatchNorm "
+                         "tails and tuned records: 26.8 vs 28.3 ms/step)")
     args = ap.parse_args()
+    if args.memory_format is None:
+        args.memory_format = "channels_last" if (args.dtype == "bf16" and args.model.startswith("s2anet")) else "contiguous"
 
     from rs_detection_amd.utils import dist as rdist
     from rs_detection_amd.utils import synthetic as syn
@@ -370,7 +374,7 @@ def main():
 
     from rs_detection_amd.runner.runner import Runner
     torch.manual_seed(0)  # same initial weights on every rank (DDP also broadcasts)
-    mf = torch.channels_last if args.memory_format == "channels_last" else None
+    mf = {"channels_last": torch.channels_last, "trunk_channels_last": "trunk_channels_last"}.get(args.memory_format)
     if args.model == "orcnn_van3":
         from rs_detection_amd.config import Config
         cfg, batch, ncls = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")), 2, 10
@@ -388,7 +392,7 @@ def main():
     # synthetic DOTA-shaped batch, resident in HBM before the timed region
     g = torch.Generator(device="cpu").manual_seed(0 + rank)
     images = torch.randn(batch, 3, TILE, TILE, generator=g).to(device)
-    if mf is not None:
+    if mf is torch.channels_last:
         images = images.contiguous(memory_format=mf)
     targets = []
     for t in syn.synthetic_targets(batch, rank=rank, it=0, num_classes=ncls, img=TILE):

@@ -424,6 +424,29 @@ int rsdet_bn_act_backward_bf16(const uint16_t* grad_y, const uint16_t* y, const 
                                int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
                                float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 
+/* Channels-last (NHWC) forms of the same four entries, for the bf16 trunk that runs channels_last (MIOpen's bf16
+ * convolutions are NHWC-native; on NCHW tensors every one of them is wrapped in layout transposes).  x / y / residual /
+ * gradients are (N, H, W, C) contiguous, i.e. torch tensors of shape (N, C, H, W) in channels_last memory format; same
+ * arithmetic, same deterministic two-stage parameter gradients.  C must satisfy rsdet_bn_act_nhwc_supported(C)
+ * (C % 4 == 0 and C / 4 a divisor or a multiple (<= 4x) of 256: every ResNet / FPN width). */
+int rsdet_bn_act_nhwc_supported(int C);
+size_t rsdet_bn_act_backward_nhwc_ws_size(int N, int C, int HW);
+int rsdet_bn_act_forward_nhwc_f32(const float* x, const float* residual, const float* running_mean,
+                                  const float* running_var, const float* weight, const float* bias, float eps,
+                                  int N, int C, int HW, int relu, float* y, void* stream);
+int rsdet_bn_act_backward_nhwc_f32(const float* grad_y, const float* y, const float* x, const float* running_mean,
+                                   const float* running_var, const float* weight, float eps, int N, int C, int HW,
+                                   int relu, float* grad_x, float* grad_residual, float* grad_weight,
+                                   float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+int rsdet_bn_act_forward_nhwc_bf16(const uint16_t* x, const uint16_t* residual, const float* running_mean,
+                                   const float* running_var, const float* weight, const float* bias, float eps,
+                                   int N, int C, int HW, int relu, uint16_t* y, void* stream);
+int rsdet_bn_act_backward_nhwc_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* x,
+                                    const float* running_mean, const float* running_var, const float* weight,
+                                    float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
+                                    uint16_t* grad_residual, float* grad_weight, float* grad_bias, void* ws,
+                                    size_t ws_bytes, void* stream);
+
 /* ---- 8(f) rank 1  polygon IoU + tile-merge polygon NMS (evaluation side) ------------------------------------
  * Replaces ops/nms_poly.py:247-252 (iou_poly: shapely intersection area, max(union, 0.01) in the denominator),
  * data/devkits/result_merge.py:66-126 (py_cpu_nms_poly_fast) and the overlap loop of

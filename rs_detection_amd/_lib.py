@@ -134,6 +134,18 @@ SIGNATURES = {
     "rsdet_bn_act_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                            c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_size_t, c_void_p]),
+    "rsdet_bn_act_nhwc_supported": (c_int, [c_int]),
+    "rsdet_bn_act_backward_nhwc_ws_size": (c_size_t, [c_int, c_int, c_int]),
+    "rsdet_bn_act_forward_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                              c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_bn_act_forward_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                               c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_bn_act_backward_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                                c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_size_t, c_void_p]),
+    "rsdet_bn_act_backward_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                               c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_size_t, c_void_p]),
     "rsdet_bn_act_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                           c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_size_t, c_void_p]),

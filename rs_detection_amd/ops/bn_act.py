@@ -19,8 +19,10 @@ class _BNAct(torch.autograd.Function):
     def forward(ctx, x, residual, weight, bias, mean, var, eps, relu):
         lib = _lib.load()
         N, C, H, W = x.shape
+        # channels_last tensors (the bf16 trunk) go to the NHWC kernels; the output keeps the input's layout
+        ctx.nhwc = not x.is_contiguous()
         y = torch.empty_like(x)
-        name = "rsdet_bn_act_forward_" + ("bf16" if x.dtype == torch.bfloat16 else "f32")
+        name = "rsdet_bn_act_forward_" + ("nhwc_" if ctx.nhwc else "") + ("bf16" if x.dtype == torch.bfloat16 else "f32")
         rc = getattr(lib, name)(_lib.ptr(x), _lib.ptr(residual), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(weight),
                                 _lib.ptr(bias), float(eps), N, C, H * W, int(relu), _lib.ptr(y), _lib.stream_ptr())
         _lib.check(rc, name)
@@ -36,7 +38,7 @@ class _BNAct(torch.autograd.Function):
         lib = _lib.load()
         x, y, weight, mean, var = ctx.saved_tensors
         N, C, H, W = ctx.shape
-        gy = gy.contiguous().to(y.dtype)
+        gy = gy.contiguous(memory_format=torch.channels_last if ctx.nhwc else torch.contiguous_format).to(y.dtype)
         need_x, need_res = ctx.needs_input_grad[0], ctx.has_res and ctx.needs_input_grad[1]
         need_w = weight is not None and ctx.needs_input_grad[2]
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
@@ -45,9 +47,10 @@ class _BNAct(torch.autograd.Function):
         gres = (torch.empty_like(y) if ctx.relu else gy) if need_res else None
         gw = torch.empty_like(weight) if need_w else None
         gb = torch.empty_like(mean) if need_b else None
-        ws_bytes = lib.rsdet_bn_act_backward_ws_size(N, C, H * W) if (need_w or need_b) else 0
+        ws_size = lib.rsdet_bn_act_backward_nhwc_ws_size if ctx.nhwc else lib.rsdet_bn_act_backward_ws_size
+        ws_bytes = ws_size(N, C, H * W) if (need_w or need_b) else 0
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=y.device) if ws_bytes else None
-        name = "rsdet_bn_act_backward_" + ("bf16" if y.dtype == torch.bfloat16 else "f32")
+        name = "rsdet_bn_act_backward_" + ("nhwc_" if ctx.nhwc else "") + ("bf16" if y.dtype == torch.bfloat16 else "f32")
         rc = getattr(lib, name)(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(var),
                                 _lib.ptr(weight), ctx.eps, N, C, H * W, int(ctx.relu), _lib.ptr(gx),
                                 _lib.ptr(gres) if (need_res and ctx.relu) else None, _lib.ptr(gw),
@@ -59,17 +62,29 @@ class _BNAct(torch.autograd.Function):
 _NO_FUSED_BN = os.environ.get("RSDET_NO_FUSED_BN", "0") == "1"  # A/B switch
 
 
+def _layout_ok(x, other=None):
+    """NCHW-contiguous, or channels_last-contiguous with a channel count the NHWC kernels take; ``other`` (residual)
+    must share the layout."""
+    if x.is_contiguous():
+        return other is None or other.is_contiguous()
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        if other is not None and not (other.is_contiguous(memory_format=torch.channels_last) and not other.is_contiguous()):
+            return False
+        return bool(_lib.load().rsdet_bn_act_nhwc_supported(int(x.shape[1])))
+    return False
+
+
 def _fusable(x, bn, residual):
     if _NO_FUSED_BN:
         return False
     # fp32 activations outside autocast, or bf16 activations (what the convolutions emit under bf16 autocast); the
     # BatchNorm parameters and running statistics are fp32 in both cases
     ok_dtype = (x.dtype == torch.float32 and not torch.is_autocast_enabled()) or x.dtype == torch.bfloat16
-    return (x.is_cuda and ok_dtype and x.dim() == 4 and x.is_contiguous() and not bn.training
+    return (x.is_cuda and ok_dtype and x.dim() == 4 and not bn.training
             and bn.running_mean is not None and bn.running_mean.dtype == torch.float32
             and (bn.weight is None or bn.weight.dtype == torch.float32)
-            and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
-                                      and residual.is_contiguous())))
+            and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape))
+            and _layout_ok(x, residual))
 
 
 def bn_act(x, bn, residual=None, relu=True):
@@ -105,7 +120,7 @@ def bias_act(x, bias, relu=True):
     """relu(x + bias[:, None, None]): the epilogue of a convolution launched without its bias (ConvModule of the
     detection heads).  One pass forward, one backward that also yields the bias gradient (deterministic two-stage
     sum) -- instead of MIOpen's bias kernel + clamp forward and threshold + reduction backward."""
-    if (x.is_cuda and x.dim() == 4 and x.is_contiguous() and bias is not None and bias.dtype == torch.float32
+    if (x.is_cuda and x.dim() == 4 and bias is not None and bias.dtype == torch.float32 and _layout_ok(x)
             and ((x.dtype == torch.float32 and not torch.is_autocast_enabled()) or x.dtype == torch.bfloat16)):
         key = (x.device, x.shape[1])
         if key not in _UNIT:

@@ -29,11 +29,15 @@ class Runner:
             device = torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu")
         self.device = device
         self.model = build_from_cfg(cfg.model, MODELS).to(device)
-        if memory_format is not None:
+        if memory_format is not None and memory_format != "trunk_channels_last":
             # only rank-4 parameters have a channels_last form (the ARF weight is rank 5)
             for p in self.model.parameters():
                 if p.dim() == 4:
                     p.data = p.data.contiguous(memory_format=memory_format)
+        if memory_format == "trunk_channels_last":       # only the backbone runs NHWC (ResNet.set_channels_last)
+            memory_format = None
+            if hasattr(self.model, "backbone") and hasattr(self.model.backbone, "set_channels_last"):
+                self.model.backbone.set_channels_last(True)
         self.memory_format = memory_format
         self.amp_dtype = amp_dtype
         params = [p for p in self.model.parameters() if p.requires_grad]

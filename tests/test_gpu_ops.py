@@ -747,3 +747,37 @@ def test_rroi_backward_nchw_form_equals_channels_last_form(cuda, monkeypatch):
             roi_align_rotated_v1(f, rois, (7, 7), 0.25, 2).backward(go)
             grads.append(f.grad)
         assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,relu,with_res", [((2, 64, 24, 20), True, False), ((3, 256, 9, 7), True, True),
+                                                 ((2, 2048, 5, 6), False, True), ((1, 1024, 8, 8), True, True)])
+def test_bn_act_channels_last_equals_nchw_form(cuda, dtype, shape, relu, with_res):
+    """The NHWC kernels (the bf16 trunk in channels_last) give the NCHW kernels' results: outputs bit for bit (same
+    per-element arithmetic), parameter gradients to summation-order round-off; layouts are preserved."""
+    from rs_detection_amd.ops.bn_act import bn_act
+    torch.manual_seed(shape[1])
+    bn = torch.nn.BatchNorm2d(shape[1]).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5), bn.running_var.uniform_(0.5, 2.0), bn.weight.normal_(1, 0.3), bn.bias.normal_(0, 0.3)
+    x = torch.randn(shape, device=cuda).to(dtype)
+    r = torch.randn(shape, device=cuda).to(dtype) if with_res else None
+    go = torch.randn(shape, device=cuda).to(dtype)
+    outs = []
+    for cl in (False, True):
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        xi = x.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        ri = r.clone().contiguous(memory_format=fmt).requires_grad_(True) if with_res else None
+        bn.zero_grad()
+        y = bn_act(xi, bn, ri, relu)
+        assert y.is_contiguous(memory_format=fmt)
+        y.backward(go.contiguous(memory_format=fmt))
+        outs.append((y.detach(), xi.grad, ri.grad if with_res else None, bn.weight.grad.clone(), bn.bias.grad.clone()))
+        assert xi.grad.is_contiguous(memory_format=fmt)
+    (y0, gx0, gr0, gw0, gb0), (y1, gx1, gr1, gw1, gb1) = outs
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    if with_res:
+        assert torch.equal(gr0, gr1)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert float((gw0 - gw1).abs().max()) <= tol * (float(gw0.abs().max()) + 1.0)
+    assert float((gb0 - gb1).abs().max()) <= tol * (float(gb0.abs().max()) + 1.0)

@@ -244,3 +244,23 @@ def test_runner_test_flip_and_submission(cuda, tmp_path):
     assert 0 < n_after < n_before                               # the three passes of a tile overlap: NMS removed some
     with zipfile.ZipFile(out["submission"]) as z:
         assert sorted(z.namelist()) == sorted(os.listdir(after))
+
+
+def test_s2anet_bf16_channels_last_step_tracks_the_nchw_step(cuda):
+    """The bf16 line runs channels_last (NHWC BatchNorm tails, ops/bn_act.py; MIOpen's bf16 kernels are NHWC-native):
+    same model, same batch -> the same losses as the NCHW bf16 step to bf16 round-off, and finite gradients."""
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.runner.runner import Runner
+    cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
+    images, targets = _batch(cuda)
+    out = {}
+    for name, mf in (("nchw", None), ("cl", torch.channels_last), ("trunk", "trunk_channels_last")):
+        torch.manual_seed(0)
+        r = Runner(cfg, device=cuda, distributed=False, amp_dtype=torch.bfloat16, memory_format=mf)
+        _, parsed = r.train_step(images, targets)
+        out[name] = {k: float(v) for k, v in parsed.items()}
+        assert all(np.isfinite(v) for v in out[name].values())
+        assert all(torch.isfinite(p.grad).all() for p in r.model.parameters() if p.grad is not None)
+    for name in ("cl", "trunk"):
+        for k, tol in (("loss_fam_cls", 0.05), ("loss_odm_cls", 0.05), ("loss_fam_bbox", 0.3), ("loss_odm_bbox", 0.3)):
+            assert abs(out[name][k] - out["nchw"][k]) / abs(out["nchw"][k]) < tol, (name, k, out[name][k], out["nchw"][k])
