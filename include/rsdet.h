@@ -91,6 +91,21 @@ int rsdet_box_iou_rotated_tiled_f32(const float* boxes1, int n1, int stride1, co
                                     int per_group, int heavy_from_col, int version, float* ious,
                                     void* stream);
 
+/* The same matrix in TWO launches -- the fastest dense form: (1) detection only (no clipper in the kernel: 12 KB of
+ * LDS, 8 workgroups per CU) leaves per tile a survivor bit mask and its surviving pairs in a sharded global queue;
+ * (2) every workgroup first zero-fills its share of the matrix SKIPPING the survivor bits, then clips its balanced share
+ * of the queue underneath the draining stores.  No element is written twice.  Arguments as rsdet_box_iou_rotated_tiled_f32
+ * plus: state = rsdet_box_iou_rotated_split_state_bytes() bytes that are zero on entry (left zero on exit), ws =
+ * rsdet_box_iou_rotated_split_ws_size(n1, n2, n_row_tiles) bytes of scratch (n_row_tiles: the tile table's length, or
+ * n_groups * ceil(max_rows_per_group / 16) without a table). */
+size_t rsdet_box_iou_rotated_split_state_bytes(void);
+size_t rsdet_box_iou_rotated_split_ws_size(int n1, int n2, int n_row_tiles);
+int rsdet_box_iou_rotated_split_f32(const float* boxes1, int n1, int stride1, const int* row_offsets, int n_groups,
+                                    int max_rows_per_group, const int* tile_table, int n_row_tiles,
+                                    const void* prepared1, const void* prepared2, int n2, int per_group,
+                                    int heavy_from_col, int version, float* ious, void* state, size_t state_bytes,
+                                    void* ws, size_t ws_bytes, void* stream);
+
 /* anchor_target for a whole batch WITHOUT the (K, A) matrix: rotated IoU of the surviving pairs only
  * (1.2 % at S2ANet shapes) -> MaxIoUAssigner (column max / first argmax, thresholds, low-quality
  * rule with gt_max_assign_all = True: the LAST gt whose IoU equals its row maximum; a gt that

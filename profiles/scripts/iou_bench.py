@@ -33,12 +33,17 @@ def main():
         r = {}
         r["r1 three launches (prepare+filter+clip)"] = event_time(
             lambda: ops.box_iou_rotated_grouped(gt, ro, max(ks), anchors, out=ov), 50) * 1e6
-        r["tiled, prepare every call (2 launches)"] = event_time(
-            lambda: ops.box_iou_rotated_tiled(gt, anchors, ro, ks=ks, out=ov), 50) * 1e6
-        r["tiled, prepared columns cached (1 launch)"] = event_time(
+        pgt = ops.prepare_boxes(gt)
+        r["split (detect | fill+clip), prepared anchors cached (2 launches)"] = event_time(
             lambda: ops.box_iou_rotated_tiled(gt, anchors, ro, ks=ks, out=ov, prepared=prep), 50) * 1e6
-        r["tiled, no tile table (early-exit grid)"] = event_time(
+        r["split, prepared anchors + gts cached"] = event_time(
+            lambda: ops.box_iou_rotated_tiled(gt, anchors, ro, ks=ks, out=ov, prepared=prep, prepared1=pgt), 50) * 1e6
+        r["split, prepare every call (3 launches)"] = event_time(
+            lambda: ops.box_iou_rotated_tiled(gt, anchors, ro, ks=ks, out=ov), 50) * 1e6
+        r["split, no tile table"] = event_time(
             lambda: ops.box_iou_rotated_tiled(gt, anchors, ro, max_rows=max(ks), out=ov, prepared=prep), 50) * 1e6
+        r["one launch (tile finished by its workgroup), prepared cached"] = event_time(
+            lambda: ops.box_iou_rotated_tiled(gt, anchors, ro, ks=ks, out=ov, prepared=prep, split=False), 50) * 1e6
         r["prepare only"] = event_time(lambda: ops.prepare_boxes(anchors), 50) * 1e6
         r["r1 assign (row+col)"] = event_time(
             lambda: ops.assign_wrt_overlaps(ov, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0), 50) * 1e6

@@ -26,7 +26,9 @@ for _ in range(n):
         ops.box_iou_rotated_grouped(gt, ro, max(ks), grid, out=ov)
         ops.assign_wrt_overlaps(ov, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0)
     if "tiled" in which:
-        ops.box_iou_rotated_tiled(gt, grid, ro, ks=ks, out=ov, prepared=prep, prepared1=pgt)
+        ops.box_iou_rotated_tiled(gt, grid, ro, ks=ks, out=ov, prepared=prep, prepared1=pgt, split=False)
+    if "split" in which:
+        ops.box_iou_rotated_tiled(gt, grid, ro, ks=ks, out=ov, prepared=prep)
     if "fused" in which:
         ops.anchor_target_rotated(grid, gt, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep, prepared_gt=pgt)
 torch.cuda.synchronize()

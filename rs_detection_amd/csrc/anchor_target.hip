@@ -72,6 +72,13 @@ struct AtEntry {
   float v;
 };
 
+struct WorkItem {  // one surviving pair of the split dense mode
+  int row, col;  // position in the IoU matrix
+  int p2;        // index of the column box in the prepared array (col + slab)
+  int pad;
+};
+constexpr int IOU2_SHARDS = 64;
+
 struct TileDesc {  // one per row tile (host-built when the gt counts are host-known)
   int group, row0, nrows, group_row0;
 };
@@ -120,6 +127,13 @@ struct TileArgs {
   int split_xt;  // column tiles >= split_xt are cut into T_SUB sub-tiles of T_TI / T_SUB rows (performance hint only)
   // dense mode
   float* out;
+  // split dense mode (detect kernel -> clip + fill kernel)
+  BoxPre* pre1_out;             // the prepared gts, written by the detect kernel for the clip kernel
+  unsigned long long* tilemask; // T_WORDS survivor words per directory slot
+  unsigned* tileflag;           // per slot: 0, or 1 + the number of survivors that did fit the queue (overflow)
+  struct WorkItem* queue;       // IOU2_SHARDS shards of `capacity` items
+  unsigned* counter;            // one fill counter per shard (128-byte lines), zero on entry
+  unsigned capacity;
   // sparse mode
   const unsigned char* valid;  // optional (n_groups, n2): columns outside it are never candidates
   unsigned* rowmax;            // (n1) float bits, zero on entry
@@ -184,6 +198,255 @@ __device__ __forceinline__ void scan_words(const unsigned long long* __restrict_
       if (tid >= off) c += o;
     }
     end[tid] = (unsigned short)c;
+  }
+}
+
+struct TileId {
+  int xt, rt, sub, g, row0, nrows, grow0;
+  size_t slot;
+  bool heavy;
+};
+// linear workgroup id -> tile (heavy column tiles first, each cut into T_SUB row sub-tiles)
+__device__ __forceinline__ TileId decode_tile(const TileArgs& a, int b) {
+  TileId t;
+  const int n_heavy = (a.nx - a.split_xt) * a.n_row_tiles * T_SUB;
+  t.sub = 0;
+  t.heavy = b < n_heavy;
+  if (t.heavy) {
+    const int per = a.n_row_tiles * T_SUB;
+    t.xt = a.nx - 1 - b / per;
+    const int rem = b % per;
+    t.rt = rem / T_SUB;
+    t.sub = rem - t.rt * T_SUB;
+  } else {
+    const int id = b - n_heavy;
+    t.xt = a.split_xt - 1 - id / a.n_row_tiles;
+    t.rt = id % a.n_row_tiles;
+  }
+  if (a.tiles) {
+    const TileDesc d = a.tiles[t.rt];
+    t.g = d.group, t.row0 = d.row0, t.nrows = d.nrows, t.grow0 = d.group_row0;
+  } else {
+    t.g = t.rt / a.ny;
+    const int y = t.rt - t.g * a.ny;
+    int rb = 0, re = a.n1;
+    if (a.row_offsets) {
+      rb = a.row_offsets[t.g];
+      re = a.row_offsets[t.g + 1];
+    }
+    t.grow0 = rb;
+    t.row0 = rb + y * T_TI;
+    t.nrows = min(T_TI, re - t.row0);
+  }
+  t.slot = ((size_t)t.xt * a.n_row_tiles + t.rt) * T_SUB + t.sub;
+  if (t.heavy) {
+    t.row0 += t.sub * (T_TI / T_SUB);
+    t.nrows = min(T_TI / T_SUB, t.nrows - t.sub * (T_TI / T_SUB));
+  }
+  return t;
+}
+
+// ---- split dense mode, launch 1: detection only ---------------------------------------------------------------------
+// The fused tile kernel above is bound by its LDS footprint (25 KB: 6 workgroups per CU) and by the ~800 VALU
+// instructions of a clip round stretching every latency-bound detection step of its neighbours (measured: 37 us, the
+// same as round 1's three launches).  Detection alone needs 12 KB and no clipper: 8 workgroups per CU, ~4 us per tile.
+// It leaves, per tile, the survivor bit mask (the fill of launch 2 skips exactly those positions) and the survivors as
+// work items in a sharded global queue (launch 2 clips them perfectly balanced), plus the prepared gts.
+template <int VERSION>
+__global__ __launch_bounds__(T_NT) void iou_detect_kernel(const TileArgs a) {
+  __shared__ BoxPre s_row[T_TI];
+  __shared__ __attribute__((aligned(16))) BoxPre s_col[T_NT];
+  __shared__ unsigned long long s_cm[T_WORDS], s_sm[T_WORDS];
+  __shared__ unsigned short s_cend[T_WORDS], s_send[T_WORDS];
+  __shared__ unsigned s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TileId t = decode_tile(a, blockIdx.x);
+  unsigned long long* mask_out = a.tilemask + t.slot * T_WORDS;
+  if (t.nrows <= 0) {
+    if (tid < T_WORDS) mask_out[tid] = 0ull;
+    if (tid == 0) a.tileflag[t.slot] = 0u;
+    return;
+  }
+  const long long slab = a.per_group ? (long long)t.g * ((a.n2 + 1) & ~1) : 0;
+  const int slab_word = a.per_group ? t.g * a.cw : 0;
+  const BoxPre* p2 = a.pre2 + slab;
+  const int col0 = t.xt * T_NT, col = col0 + tid;
+  const bool col_ok = col < a.n2;
+  const int ncols = min(T_NT, a.n2 - col0);
+  {
+    const float4* src = reinterpret_cast<const float4*>(p2 + col0);
+    float4* dst = reinterpret_cast<float4*>(s_col);
+    const int n16 = (ncols * (int)sizeof(BoxPre)) / 16;
+    for (int k = tid; k < n16; k += T_NT) dst[k] = src[k];
+    if ((ncols & 1) && tid == 0) {
+      const float2* s2 = reinterpret_cast<const float2*>(p2 + col0);
+      reinterpret_cast<float2*>(s_col)[n16 * 2] = s2[n16 * 2];
+    }
+  }
+  const int kw = (col0 >> 6) + wave;
+  float4 cb = a.colbox[slab_word + min(kw, a.cw - 1)];
+  if (kw >= a.cw) cb = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+  if (tid < t.nrows) {
+    const BoxPre r = a.pre1 ? a.pre1[t.row0 + tid] : prepare_box(a.boxes1 + (long long)(t.row0 + tid) * a.stride1);
+    s_row[tid] = r;
+    if (t.xt == 0) a.pre1_out[t.row0 + tid] = r;  // one column tile publishes the prepared gts for launch 2
+  }
+  if (tid < T_WORDS) {
+    s_cm[tid] = 0ull;
+    s_sm[tid] = 0ull;
+  }
+  __syncthreads();
+  const BoxPre mine = s_col[col_ok ? tid : 0];
+  bool lv = false;
+  if (lane < t.nrows) {
+    const float rx = s_row[lane].cx, ry = s_row[lane].cy;
+    const float dx = fmaxf(fmaxf(cb.x - rx, rx - cb.z), 0.f), dy = fmaxf(fmaxf(cb.y - ry, ry - cb.w), 0.f);
+    const float thr = 1.001f * s_row[lane].rad + 1e-5f * (fabsf(rx) + fabsf(ry));
+    lv = !(dx * dx + dy * dy > thr * thr);
+  }
+  unsigned live = (unsigned)__ballot(lv);
+  while (live) {
+    const int i = __builtin_ctz(live);
+    live &= live - 1u;
+    bool cand = false;
+    if (col_ok) {
+      const float dx = s_row[i].cx - mine.cx, dy = s_row[i].cy - mine.cy;
+      const float r = s_row[i].rad + mine.rad;
+      cand = !(dx * dx + dy * dy > r * r * 1.0001f);
+    }
+    const unsigned long long m = __ballot(cand);
+    if (m && lane == 0) s_cm[i * (T_NT / 64) + wave] = m;
+  }
+  __syncthreads();
+  scan_words(s_cm, s_cend, tid);
+  __syncthreads();
+  const int n_cand = s_cend[T_WORDS - 1];
+  for (int k = tid; k < n_cand; k += T_NT) {
+    int word, bit;
+    locate(s_cm, s_cend, k, word, bit);
+    if (!sat_disjoint<VERSION>(s_row[word >> 2], s_col[((word & 3) << 6) | bit])) atomicOr(&s_sm[word], 1ull << bit);
+  }
+  __syncthreads();
+  scan_words(s_sm, s_send, tid);
+  if (tid < T_WORDS) mask_out[tid] = s_sm[tid];
+  __syncthreads();
+  const int total = s_send[T_WORDS - 1];
+  if (total == 0) {
+    if (tid == 0) a.tileflag[t.slot] = 0u;
+    return;
+  }
+  const unsigned shard = (blockIdx.x * 7u + blockIdx.x / 64u) % IOU2_SHARDS;
+  if (tid == 0) s_base = atomicAdd(a.counter + shard * 32, (unsigned)total);
+  __syncthreads();
+  const unsigned base = s_base;
+  const int fit = base >= a.capacity ? 0 : (int)min((unsigned)total, a.capacity - base);
+  if (tid == 0) a.tileflag[t.slot] = fit == total ? 0u : 1u + (unsigned)fit;
+  WorkItem* qd = a.queue + (size_t)shard * a.capacity + base;
+  for (int q = tid; q < fit; q += T_NT) {
+    int word, bit;
+    locate(s_sm, s_send, q, word, bit);
+    WorkItem w;
+    w.row = t.row0 + (word >> 2);
+    w.col = col0 + (((word & 3) << 6) | bit);
+    w.p2 = (int)(slab + w.col);
+    w.pad = 0;
+    qd[q] = w;
+  }
+}
+
+// ---- split dense mode, launch 2: zero fill (every position that is NOT a survivor) + the balanced clip ----------------
+// No element of the matrix is written twice: the fill skips the survivor bits, the clip writes exactly those.  The
+// stores of the fill are issued first and drain underneath the VALU-bound clip.
+template <int VERSION>
+__global__ __launch_bounds__(T_NT) void iou_clip_fill_kernel(const TileArgs a, int n_detect_blocks, unsigned* done) {
+  __shared__ F2 s_pts[kQuadSlots * (T_NT / 4)];
+  __shared__ unsigned s_end[IOU2_SHARDS];
+  __shared__ unsigned long long s_sm[T_WORDS];
+  __shared__ unsigned short s_send[T_WORDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  F2* qscr = s_pts + (tid >> 2) * kQuadSlots;
+  // ---- fill
+  for (int b = blockIdx.x; b < n_detect_blocks; b += gridDim.x) {
+    const TileId t = decode_tile(a, b);
+    if (t.nrows <= 0) continue;
+    const int col0 = t.xt * T_NT, col = col0 + tid;
+    const unsigned long long* m = a.tilemask + t.slot * T_WORDS;
+    const unsigned flag = a.tileflag[t.slot];
+    {
+      // the 16 mask words of this wave's column strip first (independent loads), then the stores: a load per row
+      // inside the store loop made the fill a chain of 16 dependent global round trips per tile (40 us for the launch)
+      unsigned long long mw[T_TI];
+#pragma unroll
+      for (int i = 0; i < T_TI; ++i) mw[i] = i < t.nrows ? m[i * 4 + wave] : ~0ull;
+      if (col < a.n2) {
+        float* o = a.out + (long long)t.row0 * a.n2 + col;
+        const unsigned long long bitm = 1ull << lane;
+#pragma unroll
+        for (int i = 0; i < T_TI; ++i)
+          if (!(mw[i] & bitm)) o[(long long)i * a.n2] = 0.0f;
+      }
+    }
+    if (flag) {  // queue overflow (rare): the survivors past the ones that fit are clipped right here
+      if (tid < T_WORDS) s_sm[tid] = m[tid];
+      __syncthreads();
+      scan_words(s_sm, s_send, tid);
+      __syncthreads();
+      const int total = s_send[T_WORDS - 1];
+      const long long slab = a.per_group ? (long long)t.g * ((a.n2 + 1) & ~1) : 0;
+      for (int q0 = (int)flag - 1; q0 < total; q0 += T_NT / 4) {
+        const int q = q0 + (tid >> 2);
+        const bool on = q < total;
+        int word, bit;
+        locate(s_sm, s_send, on ? q : (int)flag - 1, word, bit);
+        const int i = word >> 2, j = ((word & 3) << 6) | bit;
+        const BoxPre ra = a.pre1_out[t.row0 + i], cbx = a.pre2[slab + col0 + j];
+        const float v = pair_iou_quad<VERSION>(ra, cbx, qscr, lane);
+        if (on && (tid & 3) == 0) a.out[(long long)(t.row0 + i) * a.n2 + col0 + j] = v;
+        lds_wave_order();
+      }
+      __syncthreads();
+    }
+  }
+  // ---- clip: the queue's pairs, a contiguous share per quad stride
+  if (tid < 64) {
+    static_assert(IOU2_SHARDS == 64, "one wave scans the shard counters");
+    unsigned c = min(a.counter[tid * 32], a.capacity);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(c, off);
+      if (tid >= off) c += o;
+    }
+    s_end[tid] = c;
+  }
+  __syncthreads();
+  const unsigned total = s_end[IOU2_SHARDS - 1];
+  const unsigned quads = gridDim.x * (T_NT / 4);
+  for (unsigned q = blockIdx.x * (T_NT / 4) + (tid >> 2); q < total; q += quads) {
+    int shard = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+      if (s_end[shard + step - 1] <= q) shard += step;
+    const unsigned first = shard ? s_end[shard - 1] : 0u;
+    const WorkItem w = a.queue[(size_t)shard * a.capacity + (q - first)];
+    const BoxPre ra = a.pre1_out[w.row], cbx = a.pre2[w.p2];
+    const float v = pair_iou_quad<VERSION>(ra, cbx, qscr, lane);
+    if ((tid & 3) == 0) a.out[(long long)w.row * a.n2 + w.col] = v;
+  }
+  // ---- the last workgroup to finish puts the shard counters back to zero for the next call.  Two levels: one
+  // returning atomic per workgroup on ONE word serialises at ~88 per us (2 048 workgroups: 23 us, measured as a 40 us
+  // launch); 64 first-level words take 32 arrivals each, their 64 last arrivers meet on the second-level word.
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned lvl1 = blockIdx.x % IOU2_SHARDS;
+    const unsigned members = (gridDim.x - lvl1 + IOU2_SHARDS - 1) / IOU2_SHARDS;
+    if (atomicAdd(done + lvl1 * 32, 1u) == members - 1u) {
+      atomicExch(done + lvl1 * 32, 0u);
+      const unsigned groups = min((unsigned)IOU2_SHARDS, gridDim.x);
+      if (atomicAdd(done + IOU2_SHARDS * 32, 1u) == groups - 1u) {
+        atomicExch(done + IOU2_SHARDS * 32, 0u);
+        for (int k = 0; k < IOU2_SHARDS; ++k) atomicExch(a.counter + k * 32, 0u);
+      }
+    }
   }
 }
 
@@ -709,6 +972,77 @@ extern "C" int rsdet_box_iou_rotated_tiled_f32(const float* boxes1, int n1, int 
     hipLaunchKernelGGL((iou_tile_kernel<0, 0>), grid, dim3(T_NT), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((iou_tile_kernel<1, 0>), grid, dim3(T_NT), 0, (hipStream_t)stream, a);
+  return rsdet_launch_status();
+}
+
+// ---- dense IoU in two launches (detect | fill + balanced clip) -------------------------------------------------------
+// state (zero on entry, zero again on exit): IOU2_SHARDS counters on 128-byte lines | done counter
+// ws: pre1 (n1 prepared gts) | tile masks (slots x 64 words) | tile flags (slots) | queue (IOU2_SHARDS x cap items)
+static inline long long split_queue_cap(long long n1, long long n2) {
+  const long long pairs = n1 * n2, total = pairs < (4LL << 20) ? pairs : (4LL << 20);
+  const long long per = (total + IOU2_SHARDS - 1) / IOU2_SHARDS, tile = (long long)T_TI * T_NT;
+  return per < tile ? (pairs < tile ? pairs : tile) : per;
+}
+
+extern "C" size_t rsdet_box_iou_rotated_split_state_bytes(void) { return 2 * IOU2_SHARDS * 128 + 256; }
+
+extern "C" size_t rsdet_box_iou_rotated_split_ws_size(int n1, int n2, int n_row_tiles) {
+  if (n1 <= 0 || n2 <= 0 || n_row_tiles <= 0) return 0;
+  const size_t slots = (size_t)((n2 + T_NT - 1) / T_NT) * n_row_tiles * T_SUB;
+  return up256((size_t)n1 * sizeof(BoxPre)) + up256(slots * T_WORDS * 8) + up256(slots * 4) +
+         (size_t)split_queue_cap(n1, n2) * IOU2_SHARDS * sizeof(WorkItem);
+}
+
+extern "C" int rsdet_box_iou_rotated_split_f32(const float* boxes1, int n1, int stride1, const int* row_offsets,
+                                               int n_groups, int max_rows_per_group, const int* tile_table,
+                                               int n_row_tiles, const void* prepared1, const void* prepared2, int n2,
+                                               int per_group, int heavy_from_col, int version, float* ious,
+                                               void* state, size_t state_bytes, void* ws, size_t ws_bytes,
+                                               void* stream) {
+  if (n1 < 0 || n2 < 0 || n_groups < 1 || stride1 < 5 || (version != 0 && version != 1)) return RSDET_EINVAL;
+  if (n1 == 0 || n2 == 0) return RSDET_OK;
+  if (!boxes1 || !prepared2 || !ious || !state || !ws || ((uintptr_t)ws & 15) || ((uintptr_t)state & 15))
+    return RSDET_EINVAL;
+  if (!row_offsets && n_groups != 1) return RSDET_EINVAL;
+  TileArgs a{};
+  a.boxes1 = boxes1, a.stride1 = stride1, a.n1 = n1;
+  a.pre1 = (const BoxPre*)prepared1;
+  split_prepared(prepared2, per_group ? n_groups : 1, n2, &a.pre2, &a.colbox);
+  a.n2 = n2, a.cw = (n2 + 63) / 64, a.per_group = per_group ? 1 : 0;
+  a.row_offsets = row_offsets;
+  a.tiles = (const TileDesc*)tile_table;
+  a.ny = (max_rows_per_group + T_TI - 1) / T_TI;
+  a.n_row_tiles = tile_table ? n_row_tiles : n_groups * a.ny;
+  a.nx = (n2 + T_NT - 1) / T_NT;
+  a.split_xt = split_tile(heavy_from_col, n2, a.nx);
+  a.out = ious;
+  if (a.n_row_tiles <= 0) return RSDET_OK;
+  if (state_bytes < rsdet_box_iou_rotated_split_state_bytes() ||
+      ws_bytes < rsdet_box_iou_rotated_split_ws_size(n1, n2, a.n_row_tiles))
+    return RSDET_EINVAL;
+  const size_t slots = (size_t)a.nx * a.n_row_tiles * T_SUB;
+  char* w = (char*)ws;
+  a.pre1_out = (BoxPre*)w;
+  w += up256((size_t)n1 * sizeof(BoxPre));
+  a.tilemask = (unsigned long long*)w;
+  w += up256(slots * T_WORDS * 8);
+  a.tileflag = (unsigned*)w;
+  w += up256(slots * 4);
+  a.queue = (WorkItem*)w;
+  a.counter = (unsigned*)state;
+  a.capacity = (unsigned)split_queue_cap(n1, n2);
+  unsigned* done = (unsigned*)((char*)state + IOU2_SHARDS * 128);
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = (int)tile_grid(a.nx, a.split_xt, a.n_row_tiles);
+  long long need = ((long long)a.capacity * IOU2_SHARDS + T_NT / 4 - 1) / (T_NT / 4);
+  const int clip_blocks = (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
+  if (version == 0) {
+    hipLaunchKernelGGL(iou_detect_kernel<0>, dim3(nblk), dim3(T_NT), 0, s, a);
+    hipLaunchKernelGGL(iou_clip_fill_kernel<0>, dim3(clip_blocks), dim3(T_NT), 0, s, a, nblk, done);
+  } else {
+    hipLaunchKernelGGL(iou_detect_kernel<1>, dim3(nblk), dim3(T_NT), 0, s, a);
+    hipLaunchKernelGGL(iou_clip_fill_kernel<1>, dim3(clip_blocks), dim3(T_NT), 0, s, a, nblk, done);
+  }
   return rsdet_launch_status();
 }
 

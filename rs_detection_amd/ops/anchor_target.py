@@ -107,9 +107,16 @@ def _zero_state(device, nbytes):
     return cur
 
 
+_split_state = {}
+
+
 def box_iou_rotated_tiled(boxes1, boxes2, row_offsets=None, ks=None, max_rows=None, version=0, out=None,
-                          prepared=None, cache_prepared=False, prepared1=None):
-    """Dense (n1, A) IoU in one launch.  ``boxes2`` (A,5) shared or (G,A,5) per group; ``row_offsets`` (G+1) int32
+                          prepared=None, cache_prepared=False, prepared1=None, split=False):
+    """Dense (n1, A) IoU out of the tile kernels of csrc/anchor_target.hip.  ``split=False``: ONE launch, every tile
+    detected, zero-filled and clipped by its own workgroup (38 us at the S2ANet step shape with cached anchors);
+    ``split=True``: two launches -- detection, then zero fill + balanced clip (rsdet_box_iou_rotated_split_f32, 43 us).
+    Both equal ``ops.box_iou_rotated_grouped`` (round 1's prepare + filter + clip, 36 us, still the fastest dense form
+    and the default of the IoU ops) bit for bit.  ``boxes2`` (A,5) shared or (G,A,5) per group; ``row_offsets`` (G+1) int32
     device tensor (None: a single group); ``ks``: host-known rows per group (enables the exact tile table)."""
     _lib.require_cuda_f32(boxes1, boxes2)
     lib = _lib.load()
@@ -129,6 +136,22 @@ def box_iou_rotated_tiled(boxes1, boxes2, row_offsets=None, ks=None, max_rows=No
         tptr, nt, mr = None, 0, int(max_rows if max_rows is not None else n1)
     if prepared1 is not None:
         assert prepared1.n_total == n1 and prepared1.groups == 1
+    if split:
+        dev = b1.device
+        st = _split_state.get(dev)
+        if st is None:
+            st = _split_state[dev] = torch.zeros((lib.rsdet_box_iou_rotated_split_state_bytes(),), dtype=torch.uint8,
+                                                 device=dev)
+        nrt = nt if ks is not None else G * ((mr + _TI - 1) // _TI)
+        ws_bytes = lib.rsdet_box_iou_rotated_split_ws_size(n1, A, max(nrt, 1))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        rc = lib.rsdet_box_iou_rotated_split_f32(_lib.ptr(b1), n1, b1.shape[1], _lib.ptr(row_offsets), G, mr, tptr, nt,
+                                                 _lib.ptr(prepared1.buf) if prepared1 is not None else None,
+                                                 _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,
+                                                 _lib.ptr(ious), _lib.ptr(st), st.numel(), _lib.ptr(ws), ws_bytes,
+                                                 _lib.stream_ptr())
+        _lib.check(rc, "rsdet_box_iou_rotated_split_f32")
+        return ious
     rc = lib.rsdet_box_iou_rotated_tiled_f32(_lib.ptr(b1), n1, b1.shape[1], _lib.ptr(row_offsets), G, mr, tptr, nt,
                                              _lib.ptr(prepared1.buf) if prepared1 is not None else None,
                                              _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,

@@ -40,11 +40,15 @@ def test_tiled_iou_equals_three_launch_form_and_oracle(cuda, oracle_c, version, 
     t1, t2, ro = torch.from_numpy(gts).to(cuda), torch.from_numpy(b2).to(cuda), _ro(ks, cuda)
     want = ops.box_iou_rotated_grouped(t1, ro, max(max(ks), 1), t2, version)
     got = ops.box_iou_rotated_tiled(t1, t2, ro, ks=ks if with_table else None, max_rows=max(ks), version=version)
-    assert torch.equal(got, want)                      # bit for bit, zeros included
+    assert torch.equal(got, want)                      # one launch: bit for bit, zeros included
+    two = ops.box_iou_rotated_tiled(t1, t2, ro, ks=ks if with_table else None, max_rows=max(ks), version=version,
+                                    split=True)        # detection | zero fill + balanced clip
+    assert torch.equal(two, want)
     # the same with the tiles of the large anchors (pyramid levels 2..4) cut into 4-row sub-tiles
-    hv = ops.box_iou_rotated_tiled(t1, t2, ro, ks=ks if with_table else None, max_rows=max(ks), version=version,
-                                   prepared=ops.prepare_boxes(t2, heavy_from=20480))
-    assert torch.equal(hv, want)
+    for split in (True, False):
+        hv = ops.box_iou_rotated_tiled(t1, t2, ro, ks=ks if with_table else None, max_rows=max(ks), version=version,
+                                       prepared=ops.prepare_boxes(t2, heavy_from=20480), split=split)
+        assert torch.equal(hv, want)
     # oracle on one image (restatement of the reference CPU loop)
     g = int(np.argmax(ks))
     r0 = int(np.sum(ks[:g]))
@@ -62,9 +66,10 @@ def test_tiled_iou_plain_form_degenerate_and_ragged(cuda, oracle_c):
     for n1, n2 in ((15, 15), (17, 321), (3, 1), (40, 1027)):
         b1 = np.concatenate([d, dota_boxes(rng, max(n1 - len(d), 0), 200)])[:n1]
         b2 = np.concatenate([d, dota_boxes(rng, max(n2 - len(d), 0), 200)])[:n2]
-        got = ops.box_iou_rotated_tiled(torch.from_numpy(b1).to(cuda), torch.from_numpy(b2).to(cuda))
         want = ops.box_iou_rotated(torch.from_numpy(b1).to(cuda), torch.from_numpy(b2).to(cuda))
-        assert torch.equal(got, want), (n1, n2)
+        for split in (True, False):
+            got = ops.box_iou_rotated_tiled(torch.from_numpy(b1).to(cuda), torch.from_numpy(b2).to(cuda), split=split)
+            assert torch.equal(got, want), (n1, n2, split)
         assert np.abs(got.cpu().numpy() - oracle_c.box_iou_rotated(b1, b2, 0)).max() <= 1e-4
     # per-group slabs with an odd number of columns (slab pitch is padded to keep 16-byte alignment)
     ks = [5, 9]
@@ -191,3 +196,20 @@ def test_prepared_cache_and_tile_table(cuda):
     t = table.cpu().numpy()
     assert (t[0] == [0, 0, 16, 0]).all() and (t[7] == [1, 16 + 96, 4, 16]).all() and (t[35] == [3, 516 + 32, 8, 516]).all()
     assert ops.row_tile_table([16, 100, 400, 40], cuda)[0] is table
+
+
+def test_split_dense_iou_queue_overflow(cuda):
+    """More surviving pairs than the global queue holds (4 Mi): the tiles whose survivors did not fit are clipped by the
+    fill phase of the second launch -- same values, nothing lost, and the shard counters come back to zero."""
+    from rs_detection_amd import ops
+    rng = np.random.default_rng(4)
+    n = 2112
+    base = np.array([100.0, 100.0, 60.0, 30.0, 0.3], np.float32)
+    b1 = (base + rng.normal(0, [4, 4, 3, 2, 0.2], (n, 5))).astype(np.float32)      # one pile: every pair overlaps
+    b2 = (base + rng.normal(0, [4, 4, 3, 2, 0.2], (n, 5))).astype(np.float32)
+    t1, t2 = torch.from_numpy(b1).to(cuda), torch.from_numpy(b2).to(cuda)
+    want = ops.box_iou_rotated(t1, t2)
+    assert int((want > 0).sum()) > (4 << 20)
+    for _ in range(2):                                                             # twice: the state is clean again
+        got = ops.box_iou_rotated_tiled(t1, t2, split=True)
+        assert torch.equal(got, want)
