@@ -24,7 +24,9 @@ __all__ = ["DeformConv", "deform_conv", "deformable_im2col", "deformable_col2im"
            "deformable_im2col_nhwc", "deformable_col2im_nhwc"]
 
 
-_LOWP_ALIGNCONV = os.environ.get("RSDET_ALIGNCONV_BF16", "0") == "1"
+# bf16 columns + bf16 products under bf16 autocast (what autocast does to every other convolution of the step);
+# RSDET_ALIGNCONV_BF16=0 keeps AlignConv in fp32 inside an autocast step
+_LOWP_ALIGNCONV = os.environ.get("RSDET_ALIGNCONV_BF16", "1") == "1"
 
 
 def _pair(x):
@@ -260,9 +262,8 @@ def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1
                 im2col_step=64):
     """dcn_v1.py:650 ``deform_conv = DeformConvFunction.apply`` (same positional signature)."""
     if groups == 1 and not offset.requires_grad and input is not None and input.dim() == 4 and input.is_cuda:
-        # bf16 columns + bf16 products under autocast save 2.9 ms of GPU time per S2ANet step (34.3 -> 31.4 ms of kernels),
-        # but the bf16 step is bound by the host's dispatch rate (31-34 ms/step either way, +-3 ms run to run): no
-        # wall-clock gain until the step runs from a captured graph, so it stays opt-in (RSDET_ALIGNCONV_BF16=1)
+        # bf16 columns + bf16 products under autocast: 26.8 -> 25.8 ms per channels_last S2ANet step (24.1 together with
+        # the fused bias + ReLU of the towers); in round 1 the step was host-bound and the same switch bought nothing
         lowp = (_LOWP_ALIGNCONV and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") == torch.bfloat16)
         return DeformConvFunctionNHWC.apply(input, offset, weight, stride, padding, dilation, deformable_groups, lowp)

@@ -618,12 +618,50 @@ def test_conv_module_fused_bias_relu_matches_unfused(cuda):
     assert torch.allclose(mc(xc), torch.relu(torch.nn.functional.conv2d(xc, mc.conv.weight, mc.conv.bias, 1, 1)))
 
 
+def test_conv_module_fused_bias_relu_under_bf16_autocast_channels_last(cuda):
+    """The bf16 line: a channels_last input under bf16 autocast takes the fused bias + ReLU pass too (an NCHW one keeps
+    the torch path).  The output tracks the fp32 module within bf16 accuracy; the gradients are compared with the
+    unfused module under the same autocast (against fp32 the weight gradient of torch's own bf16 path is 7 % off here)."""
+    from rs_detection_amd.models.utils import modules
+    from rs_detection_amd.models.utils.modules import ConvModule
+    from rs_detection_amd import _lib
+    torch.manual_seed(2)
+    m = ConvModule(32, 64, 3, stride=1, padding=1).to(cuda)
+    assert _lib.load().rsdet_bn_act_nhwc_supported(64)
+    with torch.no_grad():
+        m.conv.bias.normal_(0, 0.5)
+    x = torch.randn(2, 32, 20, 28, device=cuda)
+    xcl = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.conv2d(x, m.conv.weight, m.conv.bias, 1, 1))
+    go = torch.randn_like(ref).bfloat16()
+    res = {}
+    saved = modules._FUSE_BIAS_RELU_AMP
+    try:
+        for fused in (True, False):
+            modules._FUSE_BIAS_RELU_AMP = fused
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert m._fused_bias_relu(xcl, True) == fused and not m._fused_bias_relu(x, True)
+                y = m(xcl)
+            assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+            assert float((y.detach().float() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+            res[fused] = (y.detach().float(),) + torch.autograd.grad(y, (xcl, m.conv.weight, m.conv.bias), go)
+    finally:
+        modules._FUSE_BIAS_RELU_AMP = saved
+    # a handful of outputs within one bf16 step of zero change their ReLU mask, each moving single weight-gradient
+    # elements by |go * x|: compare in the mean, bound the maximum loosely
+    for a, b in zip(res[True], res[False]):
+        d = (a.float() - b.float()).abs()
+        assert float(d.mean()) <= 2e-2 * float(b.float().abs().mean())
+        assert float(d.max()) <= 0.2 * float(b.float().abs().max())
+    assert res[True][2].dtype == torch.float32 and res[True][3].dtype == torch.float32
+
+
 def test_deform_conv_bf16_autocast_path_tracks_fp32(cuda):
     """Under bf16 autocast AlignConv's columns are bf16 and its three products run on bf16 MFMA: output and both
     gradients stay within bf16 accuracy of the fp32 path (relative to the largest value), and the output is bf16."""
     from rs_detection_amd.ops import dcn_v1
     from rs_detection_amd.ops.dcn_v1 import DeformConv
-    dcn_v1._LOWP_ALIGNCONV = True        # opt-in path (RSDET_ALIGNCONV_BF16=1)
+    saved, dcn_v1._LOWP_ALIGNCONV = dcn_v1._LOWP_ALIGNCONV, True     # the default (RSDET_ALIGNCONV_BF16=0 turns it off)
     torch.manual_seed(5)
     B, C, O, H, W = 2, 32, 48, 24, 40
     m = DeformConv(C, O, 3, padding=1).to(cuda)
@@ -637,7 +675,7 @@ def test_deform_conv_bf16_autocast_path_tracks_fp32(cuda):
     assert y16.dtype == torch.bfloat16
     gx16, gw16 = torch.autograd.grad(y16, (x, m.weight), go.bfloat16())
     assert gx16.dtype == torch.float32 and gw16.dtype == torch.float32
-    dcn_v1._LOWP_ALIGNCONV = False
+    dcn_v1._LOWP_ALIGNCONV = saved
     for a, b in ((y16.float(), y32), (gx16, gx32), (gw16, gw32)):
         assert float((a - b).abs().max()) <= 3e-2 * float(b.abs().max())
 
