@@ -308,6 +308,19 @@ int rsdet_deform_im2col_bf16col_f32(const float* im, const float* offset, const 
 int rsdet_deform_col2im_gather_nhwc_bf16col_f32(const uint16_t* colT, const float* offset, const rsdet_dcn_geom* g,
                                                 float* grad_im, void* ws, size_t ws_bytes, void* stream);
 
+/* AlignConv as an implicit GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): replaces
+ * DeformConvFunction.forward, dcn_v1.py:412-454 (im2col :309-339 + the product :448-452), for the geometry AlignConv
+ * uses (3x3, stride 1, dilation 1, one deformable group; models/roi_heads/s2anet_head.py:603-660) in the arithmetic of
+ * a bf16 autocast step; the column matrix is not written unless asked for.
+ *   im_nhwc (B,H,W,C) bf16; offset (B,18,Ho,Wo) fp32; weight (O, 9*C) bf16 with k = tap*C + c;
+ *   out bf16: out_nhwc ? (B,Ho,Wo,O) : (B,O,Ho,Wo); colT: NULL, or (B*Ho*Wo, 9*C) bf16 = the sampled columns
+ *   (saved for the weight gradient).  _supported: 1 when the geometry is covered (C % 64 == 0, C <= 2048, O % 32 == 0,
+ *   B*H*W*C < 2^31), else 0 and the entry point returns RSDET_EINVAL. */
+int rsdet_alignconv_mfma_supported(const rsdet_dcn_geom* g, int O);
+int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, const uint16_t* weight,
+                                  const rsdet_dcn_geom* g, int O, int out_nhwc, uint16_t* out, uint16_t* colT,
+                                  void* stream);
+
 /* ---- a18  ROIAlignRotated_v1 -----------------------------------------------------------------
  * Replaces _RotatedROIAlign_v1.execute / .grad: ops/roi_align_rotated_v1.py:300-351
  * (kernels :71-147, :193-298).  feat (N,C,H,W); rois (R,6) = (batch, cx, cy, w, h, theta);

@@ -207,6 +207,76 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
         return grad_input, None, grad_weight, None, None, None, None, None
 
 
+# AlignConv on the bf16 matrix cores as an implicit GEMM (csrc/alignconv_mfma.hip); RSDET_ALIGNCONV_MFMA=0 keeps the
+# im2col + rocBLAS form of the bf16 step
+_MFMA_ALIGNCONV = os.environ.get("RSDET_ALIGNCONV_MFMA", "1") == "1"
+
+
+def _mfma_geom(input, weight, stride, padding, dilation, deformable_groups):
+    """The rsdet_dcn_geom of the call if the implicit-GEMM kernel covers it, else None."""
+    B, C, H, W = input.shape
+    O, _, kh, kw = weight.shape
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_groups)
+    return g if _lib.load().rsdet_alignconv_mfma_supported(g, O) else None
+
+
+class AlignConvMFMAFunction(torch.autograd.Function):
+    """bf16-autocast form of DeformConvFunction.forward / backward (dcn_v1.py:412-557) for the AlignConv geometry:
+    forward is ONE launch (samples interpolated in fp32 from the bf16 channels-last activations, rounded to bf16 in
+    LDS, products on v_mfma_f32_32x32x16_bf16; the sampled columns are written out once, channels-last, for the weight
+    gradient); backward = two bf16 GEMMs on views + the gather-form col2im.  No cast of the input: a channels_last
+    bf16 tensor is consumed as it is and the result is channels_last bf16."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, geom, padding):
+        lib = _lib.load()
+        B, C, H, W = input.shape
+        O = weight.shape[0]
+        Ho, Wo = H + 2 * padding[0] - 2, W + 2 * padding[1] - 2
+        x = input.permute(0, 2, 3, 1)                      # (B,H,W,C): a view of a channels_last tensor
+        if x.dtype != torch.bfloat16 or not x.is_contiguous():
+            x = x.to(torch.bfloat16).contiguous()
+        off = offset.float().contiguous()
+        w_flat = weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * C).to(torch.bfloat16)   # k = tap*C + c
+        need_w = ctx.needs_input_grad[2]
+        # channels_last storage == (B,Ho,Wo,O); returned as is (callers apply ReLU in place: not a view)
+        out = torch.empty((B, O, Ho, Wo), dtype=torch.bfloat16, device=input.device,
+                          memory_format=torch.channels_last)
+        colT = torch.empty((B * Ho * Wo, 9 * C), dtype=torch.bfloat16, device=input.device) if need_w else None
+        _lib.check(lib.rsdet_alignconv_fwd_mfma_bf16(_lib.ptr(x), _lib.ptr(off), _lib.ptr(w_flat), geom, O, 1,
+                                                     _lib.ptr(out), _lib.ptr(colT), _lib.stream_ptr()),
+                   "rsdet_alignconv_fwd_mfma_bf16")
+        ctx.save_for_backward(off, w_flat, colT)
+        ctx.shape = (B, C, H, W, O, Ho, Wo)
+        ctx.padding = padding
+        ctx.in_dtype = input.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        off, w_flat, colT = ctx.saved_tensors
+        B, C, H, W, O, Ho, Wo = ctx.shape
+        go = grad_output.permute(0, 2, 3, 1)               # (B,Ho,Wo,O): a view of a channels_last gradient
+        if go.dtype != torch.bfloat16 or not go.is_contiguous():
+            go = go.to(torch.bfloat16).contiguous()
+        go = go.reshape(B * Ho * Wo, O)
+        grad_input = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            gcolT = torch.mm(go, w_flat)                   # (P, 9*C): channels-last column gradient, bf16
+            gi = deformable_col2im_gather_nhwc(gcolT, off, (B, H, W, C), (3, 3), ctx.padding, (1, 1), (1, 1))
+            grad_input = gi.permute(0, 3, 1, 2).to(ctx.in_dtype)
+        if ctx.needs_input_grad[2]:
+            if colT is None:
+                raise RuntimeError("AlignConv: the weight gradient needs the columns of a forward run with grad enabled")
+            P = go.shape[0]
+            J = 16 if P % 16 == 0 and P >= 4096 else 1     # split K = P: 36 output tiles only otherwise
+            parts = torch.bmm(go.view(J, P // J, O).transpose(1, 2), colT.view(J, P // J, 9 * C))
+            gw = parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()
+            grad_weight = gw.view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+        return grad_input, None, grad_weight, None, None
+
+
 class DeformConvFunction(torch.autograd.Function):
     """dcn_v1.py:559-650 (reference column layout; used for groups > 1 or when the offset needs a gradient)."""
 
@@ -266,6 +336,10 @@ def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1
         # the fused bias + ReLU of the towers); in round 1 the step was host-bound and the same switch bought nothing
         lowp = (_LOWP_ALIGNCONV and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        if lowp and _MFMA_ALIGNCONV:
+            geom = _mfma_geom(input, weight, stride, padding, dilation, deformable_groups)
+            if geom is not None:
+                return AlignConvMFMAFunction.apply(input, offset, weight, geom, _pair(padding))
         return DeformConvFunctionNHWC.apply(input, offset, weight, stride, padding, dilation, deformable_groups, lowp)
     return DeformConvFunction.apply(input, offset, weight, stride, padding, dilation, groups, deformable_groups,
                                     im2col_step)

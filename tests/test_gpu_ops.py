@@ -680,6 +680,63 @@ def test_deform_conv_bf16_autocast_path_tracks_fp32(cuda):
         assert float((a - b).abs().max()) <= 3e-2 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96, 24, 40), (1, 128, 256, 9, 13), (3, 256, 64, 16, 16)])
+def test_alignconv_mfma_implicit_gemm_tracks_fp32(cuda, shape):
+    """Under bf16 autocast a covered AlignConv geometry runs as ONE implicit-GEMM launch on the bf16 matrix cores
+    (csrc/alignconv_mfma.hip), consuming channels_last bf16 activations as they are: output, input gradient and weight
+    gradient stay within bf16 accuracy of the fp32 path on the same bf16-valued operands; partial tiles (9x13), several
+    images, O != 256; the sampled columns equal the fp32 columns rounded to bf16."""
+    from rs_detection_amd.ops import dcn_v1
+    from rs_detection_amd.ops.dcn_v1 import DeformConv
+    from rs_detection_amd import _lib
+    B, C, O, H, W = shape
+    torch.manual_seed(11)
+    m = DeformConv(C, O, 3, padding=1).to(cuda)
+    with torch.no_grad():
+        m.weight.copy_(m.weight.bfloat16().float())
+    x = torch.randn(B, C, H, W, device=cuda).bfloat16().float().requires_grad_(True)
+    off = torch.randn(B, 18, H, W, device=cuda) * 2.0
+    off[0, :, 0, 0] = 50.0          # samples far outside the map: zeros
+    off[0, 0, 1, 1] = -1.5          # a sample straddling the upper border
+    y32 = m(x, off)
+    go = torch.randn_like(y32).bfloat16().float()
+    gx32, gw32 = torch.autograd.grad(y32, (x, m.weight), go)
+    assert dcn_v1._MFMA_ALIGNCONV and dcn_v1._LOWP_ALIGNCONV
+    xcl = x.detach().bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert dcn_v1._mfma_geom(xcl, m.weight, 1, 1, 1, 1) is not None
+        y16 = m(xcl, off)
+    assert y16.dtype == torch.bfloat16 and tuple(y16.shape) == tuple(y32.shape)
+    assert y16.is_contiguous(memory_format=torch.channels_last)
+    gx16, gw16 = torch.autograd.grad(y16, (xcl, m.weight), go.bfloat16().contiguous(memory_format=torch.channels_last))
+    assert gx16.dtype == torch.bfloat16 and gw16.dtype == torch.float32 and gw16.shape == m.weight.shape
+    for a, b in ((y16.float(), y32), (gx16.float(), gx32), (gw16, gw32)):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    # the columns the forward keeps == the fp32 columns, rounded
+    lib = _lib.load()
+    g = _lib.DcnGeom(C, H, W, 3, 3, 1, 1, 1, 1, 1, 1, B, 1)
+    out = torch.empty((B, H, W, O), dtype=torch.bfloat16, device=cuda)
+    colT = torch.empty((B * H * W, 9 * C), dtype=torch.bfloat16, device=cuda)
+    w_flat = m.weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * C).bfloat16()
+    x_nhwc = x.detach().permute(0, 2, 3, 1).contiguous().bfloat16()
+    assert lib.rsdet_alignconv_fwd_mfma_bf16(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_flat), g, O, 1, _lib.ptr(out),
+                                             _lib.ptr(colT), _lib.stream_ptr()) == 0
+    cref = dcn_v1.deformable_im2col(x.detach(), off, (3, 3), (1, 1), (1, 1), (1, 1), 1)
+    cref = cref.view(C, 9, -1).permute(2, 1, 0).reshape(-1, 9 * C)
+    assert float((colT.float() - cref).abs().max()) <= 2 ** -8 * float(cref.abs().max()) + 1e-6
+    # NCHW output form == NHWC output form
+    out2 = torch.empty((B, O, H, W), dtype=torch.bfloat16, device=cuda)
+    assert lib.rsdet_alignconv_fwd_mfma_bf16(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_flat), g, O, 0, _lib.ptr(out2),
+                                             None, _lib.stream_ptr()) == 0
+    assert torch.equal(out2, out.permute(0, 3, 1, 2))
+    # uncovered geometries are refused, not mis-run
+    assert not lib.rsdet_alignconv_mfma_supported(_lib.DcnGeom(32, H, W, 3, 3, 1, 1, 1, 1, 1, 1, B, 1), O)
+    assert not lib.rsdet_alignconv_mfma_supported(_lib.DcnGeom(C, H, W, 3, 3, 1, 1, 2, 2, 1, 1, B, 1), O)
+    assert lib.rsdet_alignconv_fwd_mfma_bf16(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_flat),
+                                             _lib.DcnGeom(C, H, W, 3, 3, 1, 1, 1, 1, 1, 1, B, 2), O, 1, _lib.ptr(out),
+                                             None, _lib.stream_ptr()) != 0
+
+
 def test_f4_ops_empty_and_degenerate_inputs(cuda):
     """Edge cases of the 8(f) rank-4 ops and the depthwise stencil: empty batches / no RoIs return empty results of
     the right shape (and zero gradients), nothing launches on zero elements, wrong geometry fails loudly."""
