@@ -315,8 +315,13 @@ int rsdet_deform_col2im_gather_nhwc_bf16col_f32(const uint16_t* colT, const floa
  *   im_nhwc (B,H,W,C) bf16; offset (B,18,Ho,Wo) fp32; weight (O, 9*C) bf16 with k = tap*C + c;
  *   out bf16: out_nhwc ? (B,Ho,Wo,O) : (B,O,Ho,Wo); colT: NULL, or (B*Ho*Wo, 9*C) bf16 = the sampled columns
  *   (saved for the weight gradient).  _supported: 1 when the geometry is covered (C % 64 == 0, C <= 2048, O % 32 == 0,
- *   B*H*W*C < 2^31), else 0 and the entry point returns RSDET_EINVAL. */
+ *   B*H*W*C < 2^31), else 0 and the entry point returns RSDET_EINVAL.
+ * _f32: the same kernel in exact fp32 (v_mfma_f32_32x32x2_f32; C % 32 == 0, C <= 1024): im_nhwc / weight / out / colT
+ * fp32, the sampled columns bit-identical to rsdet_deform_im2col_f32 (same operation order, no contraction). */
 int rsdet_alignconv_mfma_supported(const rsdet_dcn_geom* g, int O);
+int rsdet_alignconv_mfma_f32_supported(const rsdet_dcn_geom* g, int O);
+int rsdet_alignconv_fwd_mfma_f32(const float* im_nhwc, const float* offset, const float* weight,
+                                 const rsdet_dcn_geom* g, int O, int out_nhwc, float* out, float* colT, void* stream);
 int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, const uint16_t* weight,
                                   const rsdet_dcn_geom* g, int O, int out_nhwc, uint16_t* out, uint16_t* colT,
                                   void* stream);

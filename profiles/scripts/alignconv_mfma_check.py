@@ -20,6 +20,52 @@ def run(x_nhwc, off, w_flat, O, out_nhwc=True, want_col=False):
     return out, col
 
 
+def run32(x_nhwc, off, w_flat, O, out_nhwc=True, want_col=False):
+    B, H, W, C = x_nhwc.shape
+    g = _lib.DcnGeom(C, H, W, 3, 3, 1, 1, 1, 1, 1, 1, B, 1)
+    out = torch.empty((B, H, W, O) if out_nhwc else (B, O, H, W), dtype=torch.float32, device=dev)
+    col = torch.empty((B * H * W, 9 * C), dtype=torch.float32, device=dev) if want_col else None
+    rc = lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_flat), g, O, int(out_nhwc),
+                                          _lib.ptr(out), _lib.ptr(col), _lib.stream_ptr())
+    assert rc == 0, rc
+    return out, col
+
+
+def check32(B, C, O, H, W, scale):
+    torch.manual_seed(0)
+    x = torch.randn(B, C, H, W, device=dev)
+    wgt = torch.randn(O, C, 3, 3, device=dev) / (3 * C ** 0.5)
+    off = torch.randn(B, 18, H, W, device=dev) * scale
+    dcn_v1._LOWP_ALIGNCONV = False
+    ref = dcn_v1.deform_conv(x, off, wgt, 1, 1, 1, 1, 1)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    w_flat = wgt.permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
+    out, col = run32(x_nhwc, off, w_flat, O, False, True)
+    err = float((out - ref).abs().max()) / float(ref.abs().max())
+    cref = dcn_v1.deformable_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1), 1)
+    cref = cref.view(C, 9, -1).permute(2, 1, 0).reshape(-1, 9 * C)
+    print(f"f32 B{B} C{C} O{O} {H}x{W}: out rel err {err:.2e}  col equal {bool(torch.equal(col, cref))}")
+
+
+def bench32(B, C, O, H, W, want_col):
+    x_nhwc = torch.randn(B, H, W, C, device=dev)
+    w_flat = torch.randn(O, 9 * C, device=dev) / 48
+    off = anchor_offsets(B, H, W)
+    for _ in range(3):
+        run32(x_nhwc, off, w_flat, O, False, want_col)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()
+    for _ in range(n):
+        run32(x_nhwc, off, w_flat, O, False, want_col)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    fl = 2.0 * B * H * W * O * 9 * C
+    print(f"bench f32 B{B} C{C} O{O} {H}x{W} col={want_col}: {us:.1f} us  {fl / us / 1e6:.1f} TFLOP/s")
+
+
 def check(B, C, O, H, W, scale):
     torch.manual_seed(0)
     x = torch.randn(B, C, H, W, device=dev).bfloat16().float()
@@ -101,6 +147,13 @@ def bench(B, C, O, H, W, want_col):
 
 
 if __name__ == "__main__":
+    check32(2, 32, 32, 9, 13, 1.5)
+    check32(1, 96, 96, 20, 31, 3.0)
+    check32(2, 256, 256, 16, 16, 1.0)
+    bench32(4, 256, 256, 128, 128, False)
+    bench32(4, 256, 256, 128, 128, True)
+    bench32(4, 256, 256, 64, 64, True)
+    bench32(4, 256, 256, 8, 8, True)
     check(2, 64, 32, 9, 13, 1.5)
     check(1, 128, 96, 20, 31, 3.0)
     check(2, 256, 256, 16, 16, 1.0)

@@ -3,7 +3,7 @@
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-for dt in f32 bf16; do
+for dt in ${2:-f32 bf16}; do
   rm -rf $O/prof_step_$dt
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step_$dt -o p -- python3 $R/bench.py --dtype $dt --no-cpu-baseline --no-kernels --steps 10 --warmup 3 > $O/${TAG}_bench_under_rocprof_$dt.json 2>/dev/null
   python3 $R/profiles/scripts/step_breakdown.py $O/prof_step_$dt 13 > $O/${TAG}_step_breakdown_$dt.txt

@@ -18,6 +18,11 @@
 // the swizzle applied on the SOURCE address.  Two LDS stages: the loads of step s+1 are in flight under the 32 MFMAs
 // of step s.  Workgroup ids are banded per XCD so that neighbouring position tiles share an L2.
 //
+// The same kernel in exact fp32 (T = float): 32 channels per step (the same 128-B rows), samples interpolated in the
+// reference's operation order without contraction (columns bit-identical to rsdet_deform_im2col_f32), products on
+// v_mfma_f32_32x32x2_f32 -- 1/16 of the bf16 rate, so this form is bound by the matrix cores (77 GFLOP at level 0 of a
+// 4-tile batch = 0.49 ms at the 157 TFLOP/s peak) and the gather hides under them.
+//
 // LDS image (both tiles): row = position (A) / output channel (B), 128 B = 8 chunks of 8 bf16; chunk c of row r sits
 // in slot c ^ ((r >> 1) & 7): 16 consecutive rows of one chunk cover all 64 banks once (ds_read_b128 fragments), and a
 // producer / DMA piece of 8 rows x 8 slots is 1 KiB of consecutive LDS.
@@ -32,16 +37,17 @@ namespace rsdet {
 typedef __attribute__((ext_vector_type(8))) __bf16 acm_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float acm_f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned acm_u32x4;
+typedef __attribute__((ext_vector_type(4))) float acm_f32x4;
 
-constexpr int ACM_BM = 128, ACM_BN = 256, ACM_BK = 64, ACM_NT = 512;
+constexpr int ACM_BM = 128, ACM_BN = 256, ACM_NT = 512;  // K step: 128 B of channels = 64 bf16 / 32 fp32
 constexpr int ACM_TY = 8, ACM_TX = 16;            // the 128 positions of a workgroup: 8 x 16 output pixels
-constexpr int ACM_A_BYTES = ACM_BM * ACM_BK * 2;  // 16 KB
-constexpr int ACM_B_BYTES = ACM_BN * ACM_BK * 2;  // 32 KB
+constexpr int ACM_A_BYTES = ACM_BM * 128;          // 16 KB
+constexpr int ACM_B_BYTES = ACM_BN * 128;          // 32 KB
 constexpr int ACM_STAGE = ACM_A_BYTES + ACM_B_BYTES;
 constexpr int ACM_TASKS = ACM_BM * 8 / 256;       // (position, 8-channel chunk) tasks per producer thread and step: 4
 
-constexpr int ACM_MAX_C = 2048;
-__device__ const uint4 acm_zero_line[ACM_MAX_C / 8] = {};  // what the corners outside the map point at (zeros, C long)
+constexpr int ACM_ZERO_BYTES = 4096;  // C <= 2048 (bf16) / 1024 (fp32)
+__device__ const uint4 acm_zero_line[ACM_ZERO_BYTES / 16] = {};  // what the corners outside the map point at
 
 struct AcmGeom {
   int C, H, W, B, Ho, Wo, O;
@@ -109,16 +115,29 @@ __device__ __forceinline__ acm_u32x4 acm_blend(const acm_u32x4 (&v)[4], const fl
   return r;
 }
 
+// fp32 form: 4 samples, the reference's order w1*v1 + w2*v2 + w3*v3 + w4*v4 (this file is compiled without contraction)
+__device__ __forceinline__ acm_u32x4 acm_blend_f32(const acm_u32x4 (&v)[4], const float (&w)[4]) {
+  acm_u32x4 r;
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+    r[d] = __float_as_uint(w[0] * __uint_as_float(v[0][d]) + w[1] * __uint_as_float(v[1][d]) +
+                           w[2] * __uint_as_float(v[2][d]) + w[3] * __uint_as_float(v[3][d]));
+  return r;
+}
+
 // grid: rsdet_xcd_band_grid(position tiles, output-channel tiles); block 512; 96 KB of LDS (two stages).
 // Waves 0-3 CONSUME (each 64 positions x 128 output channels of MFMA tiles, and the LDS-DMA of the next B tile),
 // waves 4-7 PRODUCE the next A tile; one barrier per K step keeps the two halves in lockstep, so a step costs
 // max(gather + interpolation, MFMA) instead of their sum.  A producer thread holds the 18 offsets of its four
 // positions in registers from the start and keeps the corner loads of TWO steps in flight.
 // out: OUT_NHWC ? (B*Ho*Wo, O) : (B, O, Ho*Wo), bf16.  colT (optional): (B*Ho*Wo, 9*C) bf16, the A tiles as produced.
-template <bool OUT_NHWC>
+template <typename T, bool OUT_NHWC>
 __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
-    const bf16_t* __restrict__ im, const float* __restrict__ offset, const bf16_t* __restrict__ wt, AcmGeom g,
-    int m_tiles, int n_tiles, bf16_t* __restrict__ out, bf16_t* __restrict__ colT) {
+    const T* __restrict__ im, const float* __restrict__ offset, const T* __restrict__ wt, AcmGeom g,
+    int m_tiles, int n_tiles, T* __restrict__ out, T* __restrict__ colT) {
+  constexpr bool F32 = sizeof(T) == 4;
+  constexpr int BK = 128 / (int)sizeof(T);   // channels per K step
+  constexpr int EPT = 16 / (int)sizeof(T);   // channels per 16-byte piece
   __shared__ __attribute__((aligned(1024))) unsigned char acm_lds[2 * ACM_STAGE];
   const RsdetBandItem item = rsdet_xcd_band(blockIdx.x, m_tiles, n_tiles);
   if (!item.valid) return;
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
   // tile-local index p -> (ty0 + p / TX, tx0 + p % TX)
   const int n_base = item.inner * ACM_BN;
   const int K = 9 * g.C;
-  const int cchunks = g.C / ACM_BK;
+  const int cchunks = g.C / BK;
   const int steps = 9 * cchunks;
 
   if (wave >= 4) {
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
       ibase[i] = b * g.H * g.W * g.C;
       obase[i] = (int)((long long)b * 18 * plane + hw);
     }
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(acm_zero_line);
+    const T* zero = reinterpret_cast<const T*>(acm_zero_line);
     int foff[ACM_TASKS][4];          // corners of the tap whose loads are issued next (element offsets, -1 outside)
     float wa[ACM_TASKS][4], wb2[ACM_TASKS][4];  // bilinear weights of the even / odd taps
     float onext[ACM_TASKS][2];       // raw offsets of the following tap, fetched a tap ahead
@@ -192,16 +211,12 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     auto issue = [&](int step, acm_u32x4 (&dst)[ACM_TASKS][4]) {
       const int tap = step / cchunks, cc = step - tap * cchunks;
       if (cc == 0) feet(tap);
-      const int coff = cc * ACM_BK + q * 8;
+      const int coff = cc * BK + q * EPT;
 #pragma unroll
       for (int i = 0; i < ACM_TASKS; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#ifdef ACM_ABL_ZERO_A
-          const bf16_t* src = zero;
-#else
-          const bf16_t* src = foff[i][j] >= 0 ? im + foff[i][j] : zero;
-#endif
+          const T* src = foff[i][j] >= 0 ? im + foff[i][j] : zero;
           acm_gload(dst[i][j], src + coff);
         }
     };
@@ -214,17 +229,17 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     auto produce = [&](int step, const acm_u32x4 (&src)[ACM_TASKS][4]) {
       unsigned char* stage = acm_lds + (step & 1) * ACM_STAGE;
       const int tap = step / cchunks, cc = step - tap * cchunks;
-      const int k0 = tap * g.C + cc * ACM_BK;
+      const int k0 = tap * g.C + cc * BK;
 #pragma unroll
       for (int i = 0; i < ACM_TASKS; ++i) {
         float wt[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) wt[j] = (tap & 1) ? wb2[i][j] : wa[i][j];
-        const acm_u32x4 r = acm_blend(src[i], wt);
+        const acm_u32x4 r = F32 ? acm_blend_f32(src[i], wt) : acm_blend(src[i], wt);
         const int row = i * 32 + prow;
         *reinterpret_cast<acm_u32x4*>(stage + row * 128 + acm_slot(row, q) * 16) = r;
         if (colT != nullptr && ((vmask >> i) & 1u))
-          *reinterpret_cast<acm_u32x4*>(colT + cbase[i] + k0 + q * 8) = r;
+          *reinterpret_cast<acm_u32x4*>(colT + cbase[i] + k0 + q * EPT) = r;
       }
     };
     // step u travels in the register set u & 1; the weights of a tap live in the set tap & 1 (the steps in flight
@@ -268,10 +283,7 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
       const int row = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       const int o = min(n_base + row, g.O - 1);
-      const bf16_t* src = wt + (long long)o * K + k0 + chunk * 8;
-#ifdef ACM_ABL_NO_B
-      if (k0 > 0) continue;
-#endif
+      const T* src = wt + (long long)o * K + k0 + chunk * EPT;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + ACM_A_BYTES + piece * 1024),
                                        16, 0, 0);
@@ -286,32 +298,60 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     unsigned char* nxt = acm_lds + ((s + 1) & 1) * ACM_STAGE;
     if (s + 1 < steps) {
       const int t1 = (s + 1) / cchunks, c1 = (s + 1) - t1 * cchunks;
-      issue_b(t1 * g.C + c1 * ACM_BK, nxt);
+      issue_b(t1 * g.C + c1 * BK, nxt);
     }
-    // 4 k-steps of 16 on the current stage
+    if constexpr (!F32) {
+      // 4 k-steps of 16 on the current stage: lane half h holds k = 8h .. 8h+7 of a step, i.e. chunk 2*ks + h
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int chunk = ks * 2 + (lane >> 5);
-      acm_bf16x8 a[2], b[4];
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = ks * 2 + (lane >> 5);
+        acm_bf16x8 a[2], b[4];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int row = wm * 64 + mi * 32 + (lane & 31);
-        a[mi] = *reinterpret_cast<const acm_bf16x8*>(cur + row * 128 + acm_slot(row, chunk) * 16);
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = wm * 64 + mi * 32 + (lane & 31);
+          a[mi] = *reinterpret_cast<const acm_bf16x8*>(cur + row * 128 + acm_slot(row, chunk) * 16);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int row = wn * 128 + ni * 32 + (lane & 31);
+          b[ni] = *reinterpret_cast<const acm_bf16x8*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, chunk) * 16);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
       }
+    } else {
+      // 16 k-steps of 2: a 16-byte chunk holds k = 4c .. 4c+3 of a row; lane half h takes k = 4c + 2*kk + h
+      const int h = lane >> 5;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int row = wn * 128 + ni * 32 + (lane & 31);
-        b[ni] = *reinterpret_cast<const acm_bf16x8*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, chunk) * 16);
+      for (int c = 0; c < 8; ++c) {
+        acm_f32x4 a[2], b[4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = wm * 64 + mi * 32 + (lane & 31);
+          a[mi] = *reinterpret_cast<const acm_f32x4*>(cur + row * 128 + acm_slot(row, c) * 16);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int row = wn * 128 + ni * 32 + (lane & 31);
+          b[ni] = *reinterpret_cast<const acm_f32x4*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, c) * 16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float av[2], bv[4];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) av[mi] = h ? a[mi][2 * kk + 1] : a[mi][2 * kk];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) bv[ni] = h ? b[ni][2 * kk + 1] : b[ni][2 * kk];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#ifdef ACM_ABL_NO_MFMA
-          acc[mi][ni][0] += (float)a[mi][0] * (float)b[ni][0];
-#else
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -330,7 +370,8 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
         const int ho = ty0 + pl / ACM_TX, wo = tx0 + pl % ACM_TX;
         if (ho >= g.Ho || wo >= g.Wo) continue;
         const long long hw = (long long)ho * g.Wo + wo;
-        const bf16_t v = f2bf(acc[mi][ni][e]);
+        T v;
+        if constexpr (F32) v = acc[mi][ni][e]; else v = f2bf(acc[mi][ni][e]);
         if (OUT_NHWC) out[((long long)tb * plane + hw) * g.O + o] = v;
         else out[((long long)tb * g.O + o) * plane + hw] = v;
       }
@@ -341,19 +382,23 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
 
 using namespace rsdet;
 
-extern "C" int rsdet_alignconv_mfma_supported(const rsdet_dcn_geom* s, int O) {
+static int acm_supported(const rsdet_dcn_geom* s, int O, int elem_bytes) {
   if (!s) return 0;
   if (s->kh != 3 || s->kw != 3 || s->sh != 1 || s->sw != 1 || s->dh != 1 || s->dw != 1 || s->dg != 1) return 0;
-  if (s->C < ACM_BK || s->C % ACM_BK || s->C > ACM_MAX_C || O < 32 || O % 32) return 0;
+  const int bk = 128 / elem_bytes;
+  if (s->C < bk || s->C % bk || s->C * elem_bytes > ACM_ZERO_BYTES || O < 32 || O % 32) return 0;
   if (s->B < 1 || s->H < 1 || s->W < 1) return 0;
   if ((long long)s->B * s->H * s->W * s->C >= (1ll << 31)) return 0;
   return 1;
 }
 
-extern "C" int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, const uint16_t* weight,
-                                             const rsdet_dcn_geom* geom, int O, int out_nhwc, uint16_t* out,
-                                             uint16_t* colT, void* stream) {
-  if (!rsdet_alignconv_mfma_supported(geom, O)) return RSDET_EINVAL;
+extern "C" int rsdet_alignconv_mfma_supported(const rsdet_dcn_geom* s, int O) { return acm_supported(s, O, 2); }
+extern "C" int rsdet_alignconv_mfma_f32_supported(const rsdet_dcn_geom* s, int O) { return acm_supported(s, O, 4); }
+
+template <typename T>
+static int acm_launch(const T* im_nhwc, const float* offset, const T* weight, const rsdet_dcn_geom* geom, int O,
+                      int out_nhwc, T* out, T* colT, void* stream) {
+  if (!acm_supported(geom, O, (int)sizeof(T))) return RSDET_EINVAL;
   if (!im_nhwc || !offset || !weight || !out) return RSDET_EINVAL;
   AcmGeom g{geom->C, geom->H, geom->W, geom->B, 0, 0, O, geom->ph, geom->pw};
   g.Ho = geom->H + 2 * geom->ph - 2;
@@ -364,10 +409,22 @@ extern "C" int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const floa
   const dim3 grid((unsigned)rsdet_xcd_band_grid(m_tiles, n_tiles));
   hipStream_t st = (hipStream_t)stream;
   if (out_nhwc)
-    hipLaunchKernelGGL(alignconv_fwd_mfma_kernel<true>, grid, dim3(ACM_NT), 0, st, im_nhwc, offset, weight, g, m_tiles,
-                       n_tiles, out, colT);
+    hipLaunchKernelGGL((alignconv_fwd_mfma_kernel<T, true>), grid, dim3(ACM_NT), 0, st, im_nhwc, offset, weight, g,
+                       m_tiles, n_tiles, out, colT);
   else
-    hipLaunchKernelGGL(alignconv_fwd_mfma_kernel<false>, grid, dim3(ACM_NT), 0, st, im_nhwc, offset, weight, g, m_tiles,
-                       n_tiles, out, colT);
+    hipLaunchKernelGGL((alignconv_fwd_mfma_kernel<T, false>), grid, dim3(ACM_NT), 0, st, im_nhwc, offset, weight, g,
+                       m_tiles, n_tiles, out, colT);
   return rsdet_launch_status();
+}
+
+extern "C" int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, const uint16_t* weight,
+                                             const rsdet_dcn_geom* geom, int O, int out_nhwc, uint16_t* out,
+                                             uint16_t* colT, void* stream) {
+  return acm_launch<bf16_t>(im_nhwc, offset, weight, geom, O, out_nhwc, out, colT, stream);
+}
+
+extern "C" int rsdet_alignconv_fwd_mfma_f32(const float* im_nhwc, const float* offset, const float* weight,
+                                            const rsdet_dcn_geom* geom, int O, int out_nhwc, float* out, float* colT,
+                                            void* stream) {
+  return acm_launch<float>(im_nhwc, offset, weight, geom, O, out_nhwc, out, colT, stream);
 }

@@ -161,10 +161,31 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
         lowp = bool(lowp) and kh * kw == 9 and (C // deformable_groups) % 16 == 0 and W >= 2
         ctx.lowp = lowp
         cdt = torch.bfloat16 if lowp else input.dtype
+        hw = Ho * Wo
+        ctx.col_is_T = False
+        geom = None
+        if (not lowp) and _MFMA_ALIGNCONV and input.dtype == torch.float32:
+            geom = _mfma_geom_f32(input, weight, *ctx.cfg)
+        if geom is not None:
+            # exact-fp32 implicit GEMM (csrc/alignconv_mfma.hip, v_mfma_f32_32x32x2_f32): one launch, the sampled columns
+            # written once channels-last (bit-identical to the im2col kernel's) for the weight gradient
+            lib = _lib.load()
+            x_nhwc = input.permute(0, 2, 3, 1).contiguous()
+            w_t = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C).contiguous()
+            out = torch.empty((B, O, Ho, Wo), dtype=input.dtype, device=input.device)
+            colT = (torch.empty((B * hw, kh * kw * C), dtype=input.dtype, device=input.device)
+                    if ctx.needs_input_grad[2] else None)
+            off = offset.contiguous()
+            _lib.check(lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_t), geom, O, 0,
+                                                        _lib.ptr(out), _lib.ptr(colT), _lib.stream_ptr()),
+                       "rsdet_alignconv_fwd_mfma_f32")
+            ctx.col_is_T = True
+            ctx.save_for_backward(off, weight, colT)
+            ctx.in_shape = (B, C, H, W)
+            return out
         col = deformable_im2col(input, offset, (kh, kw), ctx.cfg[1], ctx.cfg[0], ctx.cfg[2], deformable_groups,
                                 col_dtype=cdt)
         w_flat = weight.reshape(O, C * kh * kw).to(cdt)
-        hw = Ho * Wo
         # one strided-batched product over the images, straight into the NCHW result: col (K, B*hw) is viewed as
         # (B, K, hw) with strides (hw, B*hw, 1) -- no copies, one launch (and one library call) per level
         out = torch.empty((B, O, Ho, Wo), dtype=cdt, device=input.device)  # returned as is (callers apply ReLU in place)
@@ -202,8 +223,15 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
             n = B * hw
             J = 16 if n % 16 == 0 and n >= 4096 else 1
             k = n // J
-            parts = torch.bmm(go2.view(O, J, k).permute(1, 0, 2), col.view(C * kh * kw, J, k).permute(1, 2, 0))
-            grad_weight = (parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()).view_as(weight)
+            if ctx.col_is_T:   # columns (positions, tap*C + c) from the implicit-GEMM forward
+                if col is None:
+                    raise RuntimeError("AlignConv: the weight gradient needs the columns of a forward run with grad enabled")
+                parts = torch.bmm(go2.view(O, J, k).permute(1, 0, 2), col.view(J, k, kh * kw * C))
+                gw = parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()
+                grad_weight = gw.view(O, kh, kw, C).permute(0, 3, 1, 2).contiguous()
+            else:
+                parts = torch.bmm(go2.view(O, J, k).permute(1, 0, 2), col.view(C * kh * kw, J, k).permute(1, 2, 0))
+                grad_weight = (parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()).view_as(weight)
         return grad_input, None, grad_weight, None, None, None, None, None
 
 
@@ -219,6 +247,21 @@ def _mfma_geom(input, weight, stride, padding, dilation, deformable_groups):
     (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
     g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_groups)
     return g if _lib.load().rsdet_alignconv_mfma_supported(g, O) else None
+
+
+def _mfma_geom_f32(input, weight, stride, padding, dilation, deformable_groups, min_tiles=384):
+    """Exact-fp32 implicit GEMM: 1/16 of the bf16 matrix rate, so it only pays where the launch fills the chip (one
+    workgroup per 128 positions runs 72 K steps of ~5 us; pyramid level 0 of a 4-tile batch has 512 of them)."""
+    B, C, H, W = input.shape
+    O, _, kh, kw = weight.shape
+    if kh != 3 or kw != 3:
+        return None
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    Ho, Wo = H + 2 * ph - 2, W + 2 * pw - 2
+    if B * ((Ho + 7) // 8) * ((Wo + 15) // 16) * ((O + 255) // 256) < min_tiles:
+        return None
+    g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, deformable_groups)
+    return g if _lib.load().rsdet_alignconv_mfma_f32_supported(g, O) else None
 
 
 class AlignConvMFMAFunction(torch.autograd.Function):

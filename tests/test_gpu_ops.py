@@ -737,6 +737,47 @@ def test_alignconv_mfma_implicit_gemm_tracks_fp32(cuda, shape):
                                              None, _lib.stream_ptr()) != 0
 
 
+def test_alignconv_mfma_fp32_implicit_gemm_equals_im2col_path(cuda):
+    """fp32: a level large enough to fill the chip runs as the exact-fp32 implicit GEMM (v_mfma_f32_32x32x2_f32); the
+    output and both gradients equal the im2col + rocBLAS path to fp32 summation-order noise, and the saved columns are
+    bit-identical to the im2col kernel's."""
+    from rs_detection_amd.ops import dcn_v1
+    from rs_detection_amd.ops.dcn_v1 import DeformConv
+    from rs_detection_amd import _lib
+    torch.manual_seed(3)
+    B, C, O, H, W = 2, 32, 64, 128, 192          # 2 x 16 x 12 = 384 position tiles
+    m = DeformConv(C, O, 3, padding=1).to(cuda)
+    x = torch.randn(B, C, H, W, device=cuda, requires_grad=True)
+    off = torch.randn(B, 18, H, W, device=cuda) * 2.0
+    go = torch.randn(B, O, H, W, device=cuda)
+    res = {}
+    saved = dcn_v1._MFMA_ALIGNCONV
+    try:
+        for on in (True, False):
+            dcn_v1._MFMA_ALIGNCONV = on
+            assert (dcn_v1._mfma_geom_f32(x, m.weight, (1, 1), (1, 1), (1, 1), 1) is not None)
+            y = m(x, off)
+            res[on] = (y.detach(),) + torch.autograd.grad(y, (x, m.weight), go)
+    finally:
+        dcn_v1._MFMA_ALIGNCONV = saved
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * float(res[False][0].abs().max())
+    # same kernels, but the gather sums its entries in the order an atomic counter handed them out
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-5 * float(res[False][1].abs().max())
+    assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-4 * float(res[False][2].abs().max())
+    # a small level keeps the im2col path
+    assert dcn_v1._mfma_geom_f32(x[:, :, :16, :16], m.weight, (1, 1), (1, 1), (1, 1), 1) is None
+    lib = _lib.load()
+    g = _lib.DcnGeom(C, 20, 31, 3, 3, 1, 1, 1, 1, 1, 1, B, 1)
+    xs, offs = x.detach()[:, :, :20, :31].contiguous(), off[:, :, :20, :31].contiguous()
+    out = torch.empty((B, O, 20, 31), device=cuda)
+    colT = torch.empty((B * 20 * 31, 9 * C), device=cuda)
+    w_t = m.weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
+    assert lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(xs.permute(0, 2, 3, 1).contiguous()), _lib.ptr(offs), _lib.ptr(w_t),
+                                            g, O, 0, _lib.ptr(out), _lib.ptr(colT), _lib.stream_ptr()) == 0
+    cref = dcn_v1.deformable_im2col(xs, offs, (3, 3), (1, 1), (1, 1), (1, 1), 1)
+    assert torch.equal(colT, cref.view(C, 9, -1).permute(2, 1, 0).reshape(-1, 9 * C))
+
+
 def test_f4_ops_empty_and_degenerate_inputs(cuda):
     """Edge cases of the 8(f) rank-4 ops and the depthwise stencil: empty batches / no RoIs return empty results of
     the right shape (and zero gradients), nothing launches on zero elements, wrong geometry fails loudly."""
