@@ -178,6 +178,25 @@ def kernel_rooflines(device, targets):
     out["deform_im2col_kernel"] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                        frac=by / t / 1e9 / HBM_PEAK_GBS, us=t * 1e6,
                                        traffic=pmc_traffic("deform_im2col", (B, C, H) == (4, 256, 128)))
+    # AlignConv as an implicit GEMM on the matrix cores (csrc/alignconv_mfma.hip): 2*B*HW*O*9*C flops; SURVEY 8(d)'s
+    # fused-variant bytes (no 9*C column term) for the HBM view.  bf16: gather-bound; fp32: bound by the fp32 MFMA rate
+    from rs_detection_amd import _lib as _L
+    lib_ = _L.load()
+    O_ = 256
+    geom = _L.DcnGeom(C, H, H, 3, 3, 1, 1, 1, 1, 1, 1, B, 1)
+    fl = 2.0 * B * H * H * O_ * 9 * C
+    for name, dt, entry, peak in (("bf16", torch.bfloat16, lib_.rsdet_alignconv_fwd_mfma_bf16, 2500.0),
+                                  ("f32", torch.float32, lib_.rsdet_alignconv_fwd_mfma_f32, 157.3)):
+        xq = x.permute(0, 2, 3, 1).contiguous().to(dt)
+        wq = (torch.randn(O_, 9 * C, device=device) / 48).to(dt)
+        oq = torch.empty((B, H, H, O_), dtype=dt, device=device)
+        t = event_time(lambda: entry(_L.ptr(xq), _L.ptr(off), _L.ptr(wq), geom, O_, 1, _L.ptr(oq), None,
+                                     _L.stream_ptr()), 10, 2)
+        es = xq.element_size()
+        by_f = es * (C * H * H * B + O_ * H * H * B + O_ * 9 * C) + 4 * 18 * H * H * B
+        out["alignconv_fwd_mfma_kernel<%s>(implicit GEMM, level 0, no columns in HBM)" % name] = dict(
+            bound="mfma", achieved=fl / t / 1e12, peak=peak, unit="TFLOP/s", frac=fl / t / 1e12 / peak, us=t * 1e6,
+            hbm_alg_bytes=by_f, traffic=pmc_traffic("alignconv_mfma_" + name, (B, C, H) == (4, 256, 128)))
     # (the reference-layout col2im -- one lane per column row, 13.2 ms here -- is kept for API parity only; the step
     #  uses the channels-last pair below, so it is not timed: it would dominate the rocprof summary of this command)
     xn = x.permute(0, 2, 3, 1).contiguous()

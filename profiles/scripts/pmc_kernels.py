@@ -42,6 +42,12 @@ ALG = {
 B, C, H = 4, 256, 128
 ALG["deform_im2col_taps_kernel"] = dict(call="deform_im2col", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
 ALG["deform_im2col_nhwc_kernel"] = dict(call="deform_im2col_nhwc", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
+# implicit-GEMM AlignConv: SURVEY 8(d)'s fused-variant bytes (input + output + weights + offsets; no 9*C column term)
+O_ = 256
+ALG["alignconv_fwd_mfma_kernel<unsigned short"] = dict(call="alignconv_mfma_bf16", bytes=2 * (C * H * H * B + O_ * H * H * B + O_ * 9 * C) + 4 * 18 * H * H * B,
+                                                       flops=2.0 * B * H * H * O_ * 9 * C)
+ALG["alignconv_fwd_mfma_kernel<float"] = dict(call="alignconv_mfma_f32", bytes=4 * (C * H * H * B + O_ * H * H * B + O_ * 9 * C) + 4 * 18 * H * H * B,
+                                              flops=2.0 * B * H * H * O_ * 9 * C)
 for k in ("dcn_idx_count_kernel", "dcn_idx_scan_kernel", "dcn_idx_chunk_sum_kernel", "dcn_idx_fill_kernel", "dcn_gather_kernel"):
     ALG[k] = dict(call="deform_col2im (gather form, 5 launches)", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
 M = 5344
@@ -63,6 +69,15 @@ for _ in range(3):
     ops.deformable_im2col(x, off, (3, 3), (1, 1), (1, 1), (1, 1))
     colT = ops.deformable_im2col_nhwc(xn, off, (3, 3), (1, 1), (1, 1), (1, 1))
     deformable_col2im_gather_nhwc(colT, off, xn.shape, (3, 3), (1, 1), (1, 1), (1, 1))
+from rs_detection_amd import _lib as _L
+_lib_ = _L.load()
+_geom = _L.DcnGeom(C, H, H, 3, 3, 1, 1, 1, 1, 1, 1, B, 1)
+for dt, entry in ((torch.bfloat16, _lib_.rsdet_alignconv_fwd_mfma_bf16), (torch.float32, _lib_.rsdet_alignconv_fwd_mfma_f32)):
+    xq, wq = xn.to(dt), (torch.randn(256, 9 * C, device=dev) / 48).to(dt)
+    oq = torch.empty((B, H, H, 256), dtype=dt, device=dev)
+    for _ in range(3):
+        entry(_L.ptr(xq), _L.ptr(off), _L.ptr(wq), _geom, 256, 1, _L.ptr(oq), None, _L.stream_ptr())
+    del xq, wq, oq
 del colT, x, xn
 d, s, l = syn.nms_cluster_boxes(5344)
 d6 = torch.from_numpy(np.concatenate([d, l[:, None].astype(np.float32)], 1)).to(dev)

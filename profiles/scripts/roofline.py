@@ -55,6 +55,8 @@ def main(d, out):
         if key:
             row["call"] = alg[key]["call"]
             c = calls.setdefault(alg[key]["call"], dict(alg_bytes=alg[key]["bytes"], kernels=[], us=0.0, traffic_bytes=0.0))
+            if "flops" in alg[key]:
+                c["alg_flops"] = alg[key]["flops"]
             c["kernels"].append(n)
             c["us"] += row["avg_us"]
             c["traffic_bytes"] += row.get("traffic_bytes") or 0.0
@@ -63,6 +65,8 @@ def main(d, out):
         c["achieved_GBps"] = c["alg_bytes"] / (c["us"] * 1e-6) / 1e9
         c["frac_of_hbm_peak"] = c["achieved_GBps"] / HBM_PEAK
         c["traffic_over_alg"] = c["traffic_bytes"] / c["alg_bytes"] if c["alg_bytes"] else None
+        if "alg_flops" in c:
+            c["achieved_TFLOPs"] = c["alg_flops"] / (c["us"] * 1e-6) / 1e12
     res = dict(hbm_peak_GBps=HBM_PEAK, source="rocprofv3 --kernel-trace + --pmc WRITE_SIZE / FETCH_SIZE over "
                "profiles/scripts/pmc_kernels.py; code-object notes via profiles/scripts/occupancy.py",
                calls=calls, kernels=kernels)
