@@ -1,6 +1,6 @@
 """AlignConv implicit GEMM (csrc/alignconv_mfma.hip): parity against the fp32 deform_conv on the same bf16-valued
 operands, and HIP-graph-free event timing at the S2ANet pyramid shapes."""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, ".")
 from rs_detection_amd import _lib
 from rs_detection_amd.ops import dcn_v1
@@ -131,6 +131,8 @@ def bench(B, C, O, H, W, want_col):
     x_nhwc = torch.randn(B, H, W, C, device=dev).bfloat16()
     w_flat = (torch.randn(O, 9 * C, device=dev) / 48).bfloat16()
     off = anchor_offsets(B, H, W) if REAL else torch.randn(B, 18, H, W, device=dev)
+    if os.environ.get("ACM_ZERO_OFF"):
+        off = off * 0
     for _ in range(3):
         run(x_nhwc, off, w_flat, O, True, want_col)
     torch.cuda.synchronize()

@@ -49,6 +49,17 @@ constexpr int ACM_TASKS = ACM_BM * 8 / 256;       // (position, 8-channel chunk)
 constexpr int ACM_ZERO_BYTES = 4096;  // C <= 2048 (bf16) / 1024 (fp32)
 __device__ const uint4 acm_zero_line[ACM_ZERO_BYTES / 16] = {};  // what the corners outside the map point at
 
+#ifdef ACM_TRACE  // debug builds only (profiles/scripts/trace_alignconv.py): per-step timestamps of the first tile
+__device__ unsigned long long* g_acm_trace;
+#define ACM_STAMP(slot, step, k)                                                                         \
+  do {                                                                                                   \
+    if (acm_trace_wg && (threadIdx.x & 63) == 0 && g_acm_trace && (step) < 80)                         \
+      g_acm_trace[((slot) * 80 + (step)) * 4 + (k)] = __builtin_amdgcn_s_memtime();                      \
+  } while (0)
+#else
+#define ACM_STAMP(slot, step, k)
+#endif
+
 struct AcmGeom {
   int C, H, W, B, Ho, Wo, O;
   int ph, pw;
@@ -141,6 +152,9 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
   __shared__ __attribute__((aligned(1024))) unsigned char acm_lds[2 * ACM_STAGE];
   const RsdetBandItem item = rsdet_xcd_band(blockIdx.x, m_tiles, n_tiles);
   if (!item.valid) return;
+#ifdef ACM_TRACE
+  const bool acm_trace_wg = item.outer == 0 && item.inner == 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long plane = (long long)g.Ho * g.Wo;
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     };
     auto produce = [&](int step, const acm_u32x4 (&src)[ACM_TASKS][4]) {
       unsigned char* stage = acm_lds + (step & 1) * ACM_STAGE;
+      if (wave == 4) ACM_STAMP(1, step, 0);
       const int tap = step / cchunks, cc = step - tap * cchunks;
       const int k0 = tap * g.C + cc * BK;
 #pragma unroll
@@ -241,6 +256,7 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
         if (colT != nullptr && ((vmask >> i) & 1u))
           *reinterpret_cast<acm_u32x4*>(colT + cbase[i] + k0 + q * EPT) = r;
       }
+      if (wave == 4) ACM_STAMP(1, step, 1);
     };
     // step u travels in the register set u & 1; the weights of a tap live in the set tap & 1 (the steps in flight
     // span at most two consecutive taps).  At the top of iteration s: stage s & 1 holds step s (its register set is
@@ -296,32 +312,37 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
   for (int s = 0; s < steps; ++s) {
     unsigned char* cur = acm_lds + (s & 1) * ACM_STAGE;
     unsigned char* nxt = acm_lds + ((s + 1) & 1) * ACM_STAGE;
+    if (wave == 0) ACM_STAMP(0, s, 0);
     if (s + 1 < steps) {
       const int t1 = (s + 1) / cchunks, c1 = (s + 1) - t1 * cchunks;
       issue_b(t1 * g.C + c1 * BK, nxt);
     }
     if constexpr (!F32) {
-      // 4 k-steps of 16 on the current stage: lane half h holds k = 8h .. 8h+7 of a step, i.e. chunk 2*ks + h
+      // 4 k-steps of 16 on the current stage: lane half h holds k = 8h .. 8h+7 of a step, i.e. chunk 2*ks + h.
+      // All 24 fragment reads first, then 32 MFMAs back to back (fragments of one k-step ahead of their MFMAs would do,
+      // but the registers are there: 96 + 128 accumulators)
+      acm_bf16x8 a[4][2], b[4][4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int chunk = ks * 2 + (lane >> 5);
-        acm_bf16x8 a[2], b[4];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row = wm * 64 + mi * 32 + (lane & 31);
-          a[mi] = *reinterpret_cast<const acm_bf16x8*>(cur + row * 128 + acm_slot(row, chunk) * 16);
+          a[ks][mi] = *reinterpret_cast<const acm_bf16x8*>(cur + row * 128 + acm_slot(row, chunk) * 16);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const int row = wn * 128 + ni * 32 + (lane & 31);
-          b[ni] = *reinterpret_cast<const acm_bf16x8*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, chunk) * 16);
+          b[ks][ni] = *reinterpret_cast<const acm_bf16x8*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, chunk) * 16);
         }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-      }
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][mi], b[ks][ni], acc[mi][ni], 0, 0, 0);
     } else {
       // 16 k-steps of 2: a 16-byte chunk holds k = 4c .. 4c+3 of a row; lane half h takes k = 4c + 2*kk + h
       const int h = lane >> 5;
@@ -353,8 +374,11 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
         }
       }
     }
+    if (wave == 0) ACM_STAMP(0, s, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 0) ACM_STAMP(0, s, 2);
     __syncthreads();
+    if (wave == 0) ACM_STAMP(0, s, 3);
   }
 
   // epilogue: D[row = position][col = output channel]; col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
@@ -381,6 +405,10 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
 }  // namespace rsdet
 
 using namespace rsdet;
+
+#ifdef ACM_TRACE
+extern "C" void rsdet_debug_set_acm_trace(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_acm_trace), &p, sizeof(p)); }
+#endif
 
 static int acm_supported(const rsdet_dcn_geom* s, int O, int elem_bytes) {
   if (!s) return 0;
