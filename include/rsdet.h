@@ -457,6 +457,13 @@ int rsdet_bn_act_backward_bf16(const uint16_t* grad_y, const uint16_t* y, const 
                                int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
                                float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 
+/* Column sums of a (rows, C) matrix, C <= 64: out[c] = sum_r x[r, c] in fp32 (two deterministic stages).  The bias
+ * gradient of a channels_last convolution with few output channels (the 5- / 15-channel prediction maps of
+ * models/roi_heads/s2anet_head.py:128-142): rows = N*H*W. */
+size_t rsdet_colsum_ws_size(long long rows, int C);
+int rsdet_colsum_f32(const float* x, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+int rsdet_colsum_bf16(const uint16_t* x, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* Channels-last (NHWC) forms of the same four entries, for the bf16 trunk that runs channels_last (MIOpen's bf16
  * convolutions are NHWC-native; on NCHW tensors every one of them is wrapped in layout transposes).  x / y / residual /
  * gradients are (N, H, W, C) contiguous, i.e. torch tensors of shape (N, C, H, W) in channels_last memory format; same

@@ -11,6 +11,7 @@
 // then max(., 0).  HBM-bound: forward reads x (+res), writes y; backward reads dy, y, x, writes dx
 // (the residual gradient is the masked dy itself and shares dx's mask: written once as `g`).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
@@ -393,6 +394,63 @@ extern "C" int rsdet_bn_act_backward_bf16(const uint16_t* grad_y, const uint16_t
 static inline bool bn_nhwc_ok(int C) {
   const int G = C / 4;
   return C > 0 && (C & 3) == 0 && ((G <= BN_NT && BN_NT % G == 0) || (G > BN_NT && G <= 4 * BN_NT));
+}
+
+// ---- column sums of a (rows, C) matrix with a small C (bias gradient of the 5- / 15-channel prediction maps of a
+// channels_last head: torch's reduction takes ~20 us per call there).  Thread (c, rl): column c, rows rl, rl + RL, ...
+// of the workgroup's slice; the row lanes fold in LDS in a fixed order; a second launch folds the slices.
+constexpr int CS_MAX_C = 64, CS_MAX_S = 512;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long long rows, int C, int cpad,
+                                                             int rows_per, float* __restrict__ partial) {
+  __shared__ float s_red[256];
+  const int t = threadIdx.x, c = t % cpad, rl = t / cpad, RL = 256 / cpad;
+  const long long r0 = (long long)blockIdx.x * rows_per, r1 = min(rows, r0 + rows_per);
+  float acc = 0.f;
+  if (c < C)
+    for (long long r = r0 + rl; r < r1; r += RL) acc += ld1(x + r * C + c);
+  s_red[t] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float a = 0.f;
+    for (int k = 0; k < RL; ++k) a += s_red[k * cpad + c];
+    partial[(long long)blockIdx.x * C + c] = a;
+  }
+}
+__global__ __launch_bounds__(64) void colsum_finish_kernel(const float* __restrict__ partial, int C, int S,
+                                                           float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += partial[(long long)s * C + c];
+  out[c] = a;
+}
+static int colsum_slices(long long rows) { return (int)std::min<long long>(CS_MAX_S, std::max<long long>(1, rows / 512)); }
+
+extern "C" size_t rsdet_colsum_ws_size(long long rows, int C) {
+  return rows > 0 && C > 0 ? (size_t)colsum_slices(rows) * C * sizeof(float) : 0;
+}
+template <typename T>
+static int colsum_launch(const T* x, long long rows, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (rows < 0 || C < 1 || C > CS_MAX_C || !out) return RSDET_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) return hipMemsetAsync(out, 0, C * sizeof(float), st) == hipSuccess ? RSDET_OK : RSDET_ELAUNCH;
+  if (!x || !ws || ws_bytes < rsdet_colsum_ws_size(rows, C)) return RSDET_EINVAL;
+  int cpad = 1;
+  while (cpad < C) cpad <<= 1;
+  const int S = colsum_slices(rows);
+  const int rows_per = (int)((rows + S - 1) / S);
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(S), dim3(256), 0, st, x, rows, C, cpad, rows_per, (float*)ws);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, C, S, out);
+  return rsdet_launch_status();
+}
+extern "C" int rsdet_colsum_f32(const float* x, long long rows, int C, float* out, void* ws, size_t ws_bytes,
+                                void* stream) {
+  return colsum_launch<float>(x, rows, C, out, ws, ws_bytes, stream);
+}
+extern "C" int rsdet_colsum_bf16(const uint16_t* x, long long rows, int C, float* out, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  return colsum_launch<bf16_t>(x, rows, C, out, ws, ws_bytes, stream);
 }
 
 extern "C" int rsdet_bn_act_nhwc_supported(int C) { return bn_nhwc_ok(C) ? 1 : 0; }

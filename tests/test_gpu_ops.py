@@ -656,6 +656,41 @@ def test_conv_module_fused_bias_relu_under_bf16_autocast_channels_last(cuda):
     assert res[True][2].dtype == torch.float32 and res[True][3].dtype == torch.float32
 
 
+def test_colsum_and_conv2d_bias_channels_last(cuda):
+    """rsdet_colsum_* == the fp32 column sum (to summation order), incl. ragged row counts and C = 1 / 5 / 15 / 64;
+    conv2d_bias under bf16 autocast on a channels_last input == the module itself (output, input / weight / bias
+    gradients) for a 5-channel and a 64-channel convolution, and is the module itself outside that case."""
+    from rs_detection_amd import _lib
+    from rs_detection_amd.ops.bn_act import conv2d_bias
+    lib = _lib.load()
+    torch.manual_seed(4)
+    for rows, C in ((1, 5), (777, 15), (70000, 5), (4096, 64), (333, 1)):
+        x = torch.randn(rows, C, device=cuda)
+        for xt, name in ((x, "rsdet_colsum_f32"), (x.bfloat16(), "rsdet_colsum_bf16")):
+            out = torch.empty(C, device=cuda)
+            wsb = lib.rsdet_colsum_ws_size(rows, C)
+            ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=cuda)
+            assert getattr(lib, name)(_lib.ptr(xt), rows, C, _lib.ptr(out), _lib.ptr(ws), wsb, _lib.stream_ptr()) == 0
+            ref = xt.double().sum(0)
+            assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())) * rows ** 0.5
+    out = torch.empty(65, device=cuda)
+    assert lib.rsdet_colsum_f32(_lib.ptr(x), 10, 65, _lib.ptr(out), None, 0, _lib.stream_ptr()) != 0
+    for cout in (5, 64):
+        conv = torch.nn.Conv2d(32, cout, 3, padding=1).to(cuda)
+        x = torch.randn(2, 32, 24, 40, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        go = torch.randn(2, cout, 24, 40, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+        res = []
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            for f in (lambda: conv2d_bias(conv, x), lambda: conv(x)):
+                y = f()
+                res.append((y.detach().float(),) + tuple(t.float() for t in
+                                                          torch.autograd.grad(y, (x, conv.weight, conv.bias), go)))
+        for a, b in zip(*res):
+            assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    xn = torch.randn(2, 32, 8, 8, device=cuda)
+    assert torch.equal(conv2d_bias(conv, xn), conv(xn))        # NCHW fp32: the module itself
+
+
 def test_deform_conv_bf16_autocast_path_tracks_fp32(cuda):
     """Under bf16 autocast AlignConv's columns are bf16 and its three products run on bf16 MFMA: output and both
     gradients stay within bf16 accuracy of the fp32 path (relative to the largest value), and the output is bf16."""
