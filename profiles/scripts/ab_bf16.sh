@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B of the bf16 line: AlignConv in bf16, bias+ReLU fused under autocast
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-run() { tag=$1; shift; env "$@" python3 $R/bench.py --dtype bf16 --no-cpu-baseline --no-kernels --steps 30 --warmup 5 2>/dev/null | grep '^{' | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', d['value'], d['ms_per_step'])"; }
-run base A=1
-run acbf16 RSDET_ALIGNCONV_BF16=1
-run biasact RSDET_FUSED_BIAS_RELU_AMP=1
-run both RSDET_ALIGNCONV_BF16=1 RSDET_FUSED_BIAS_RELU_AMP=1
-run base2 A=1
+# A/B of the bf16 line inside ONE box (boxes differ by 1-3 %): alternate the two settings
+# usage: ab_bf16.sh VAR   -> runs VAR=1 / VAR=0 alternately, 3 times each
+R=$GRAFT_REPO_ROOT
+V=${1:-RSDET_CONV2D_BIAS}
+for i in 1 2 3; do for v in 1 0; do
+  env $V=$v python3 $R/bench.py --dtype bf16 --no-cpu-baseline --no-kernels --steps 30 --warmup 5 2>/dev/null | grep '^{' | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$V=$v', round(d['ms_per_step'],3))"
+done; done
