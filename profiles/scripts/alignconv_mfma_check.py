@@ -1,7 +1,7 @@
 """AlignConv implicit GEMM (csrc/alignconv_mfma.hip): parity against the fp32 deform_conv on the same bf16-valued
 operands, and HIP-graph-free event timing at the S2ANet pyramid shapes."""
 import os, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from rs_detection_amd import _lib
 from rs_detection_amd.ops import dcn_v1
 

@@ -39,12 +39,15 @@ typedef __attribute__((ext_vector_type(16))) float acm_f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned acm_u32x4;
 typedef __attribute__((ext_vector_type(4))) float acm_f32x4;
 
-constexpr int ACM_BM = 128, ACM_BN = 256, ACM_NT = 512;  // K step: 128 B of channels = 64 bf16 / 32 fp32
+constexpr int ACM_BM = 128, ACM_BN = 256;          // K step: 128 B of channels = 64 bf16 / 32 fp32
 constexpr int ACM_TY = 8, ACM_TX = 16;            // the 128 positions of a workgroup: 8 x 16 output pixels
 constexpr int ACM_A_BYTES = ACM_BM * 128;          // 16 KB
 constexpr int ACM_B_BYTES = ACM_BN * 128;          // 32 KB
 constexpr int ACM_STAGE = ACM_A_BYTES + ACM_B_BYTES;
-constexpr int ACM_TASKS = ACM_BM * 8 / 256;       // (position, 8-channel chunk) tasks per producer thread and step: 4
+// wave split (template parameters of the kernel): ACM_CW consumer waves = 2 (rows) x ACM_CW/2 (columns) wave tiles of
+// 64 x (512 / ACM_CW), ACM_PW producer waves.  Measured in one box at level 0: bf16 4+4 waves 169 us, 8+8 waves 150 us
+// (a second wave of each kind per SIMD hides the LDS / global latencies of the first); fp32 848 vs 867 us (bound by the
+// matrix cores: the smaller wave tiles only add fragment reads)
 
 constexpr int ACM_ZERO_BYTES = 4096;  // C <= 2048 (bf16) / 1024 (fp32)
 __device__ const uint4 acm_zero_line[ACM_ZERO_BYTES / 16] = {};  // what the corners outside the map point at
@@ -70,20 +73,25 @@ __device__ __forceinline__ int acm_slot(int row, int chunk) { return chunk ^ ((r
 // corner element offsets (from the image's first pixel; -1 = outside the map) and weights of one (position, tap):
 // dcn_v1.py:25-56 and the window test of :170.  h, w: the sampling point (base + kernel + learned offset)
 __device__ __forceinline__ void acm_foot(const AcmGeom& g, float h, float w, bool valid, int ibase, int (&off)[4],
-                                         float (&wt)[4]) {
+                                         float (&frac)[2]) {
   const bool in = valid && (h > -1 && w > -1 && h < g.H && w < g.W);
   const float fh = floorf(h), fw = floorf(w);
   const int hl = (int)fh, wl = (int)fw;
   const int hh = hl + 1, wh = wl + 1;
-  const float lh = h - fh, lw = w - fw;
-  const float uh = 1 - lh, uw = 1 - lw;
   const bool t = in && hl >= 0, bt = in && hh <= g.H - 1, l = wl >= 0, r = wh <= g.W - 1;
   const int row0 = ibase + hl * g.W * g.C, row1 = row0 + g.W * g.C;
   off[0] = (t && l) ? row0 + wl * g.C : -1;
   off[1] = (t && r) ? row0 + wh * g.C : -1;
   off[2] = (bt && l) ? row1 + wl * g.C : -1;
   off[3] = (bt && r) ? row1 + wh * g.C : -1;
-  // a corner outside the map contributes 0: it is read from a line of zeros, so its weight does not matter
+  // (lh, lw): the four weights are formed where they are used; a corner outside the map contributes 0 because it is
+  // read from a line of zeros, whatever its weight
+  frac[0] = h - fh;
+  frac[1] = w - fw;
+}
+
+__device__ __forceinline__ void acm_weights(float lh, float lw, float (&wt)[4]) {  // dcn_v1.py:44-47
+  const float uh = 1 - lh, uw = 1 - lw;
   wt[0] = uh * uw; wt[1] = uh * lw; wt[2] = lh * uw; wt[3] = lh * lw;
 }
 
@@ -142,10 +150,15 @@ __device__ __forceinline__ acm_u32x4 acm_blend_f32(const acm_u32x4 (&v)[4], cons
 // max(gather + interpolation, MFMA) instead of their sum.  A producer thread holds the 18 offsets of its four
 // positions in registers from the start and keeps the corner loads of TWO steps in flight.
 // out: OUT_NHWC ? (B*Ho*Wo, O) : (B, O, Ho*Wo), bf16.  colT (optional): (B*Ho*Wo, 9*C) bf16, the A tiles as produced.
-template <typename T, bool OUT_NHWC>
-__global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
+template <typename T, bool OUT_NHWC, int ACM_CW, int ACM_PW>
+__global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_kernel(
     const T* __restrict__ im, const float* __restrict__ offset, const T* __restrict__ wt, AcmGeom g,
     int m_tiles, int n_tiles, T* __restrict__ out, T* __restrict__ colT) {
+  constexpr int ACM_WN = ACM_CW / 2;                 // consumer waves along N
+  constexpr int ACM_NI = ACM_BN / ACM_WN / 32;       // 32-wide MFMA tiles per wave along N (4 or 2)
+  constexpr int ACM_PT = 64 * ACM_PW;                // producer threads
+  constexpr int ACM_TASKS = ACM_BM * 8 / ACM_PT;     // (position, 16-byte chunk) tasks per producer thread and step
+  constexpr int ACM_LOADS = ACM_TASKS * 4;           // corner loads a producer thread issues per step
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int BK = 128 / (int)sizeof(T);   // channels per K step
   constexpr int EPT = 16 / (int)sizeof(T);   // channels per 16-byte piece
@@ -169,23 +182,23 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
   const int cchunks = g.C / BK;
   const int steps = 9 * cchunks;
 
-  if (wave >= 4) {
+  if (wave >= ACM_CW) {
     // ------------------------------------------------------------------ producers
-    const int ptid = tid - 256;
+    const int ptid = tid - 64 * ACM_CW;
     const int q = ptid & 7, prow = ptid >> 3;  // tile positions i*32 + prow, channel chunk q of the step's 64
-    long long cbase[ACM_TASKS];  // first column element of the position in colT
+    int cbase[ACM_TASKS];        // first column element of the position in colT (B*Ho*Wo*9*C < 2^31 is checked)
     float hb[ACM_TASKS], wb[ACM_TASKS];
     int ibase[ACM_TASKS], obase[ACM_TASKS];  // element offsets of the image / of the position inside the offset tensor
     unsigned vmask = 0;
 #pragma unroll
     for (int i = 0; i < ACM_TASKS; ++i) {
-      const int pl = i * 32 + prow;
+      const int pl = i * (ACM_PT / 8) + prow;
       const int ho = ty0 + pl / ACM_TX, wo = tx0 + pl % ACM_TX;
       const bool ok = ho < g.Ho && wo < g.Wo;
       vmask |= ok ? (1u << i) : 0u;
       const int b = tb;
       const int hw = ok ? ho * g.Wo + wo : 0;
-      cbase[i] = ((long long)b * plane + hw) * K;
+      cbase[i] = (int)(((long long)b * plane + hw) * K);
       hb[i] = (float)(ho - g.ph);
       wb[i] = (float)(wo - g.pw);
       ibase[i] = b * g.H * g.W * g.C;
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     }
     const T* zero = reinterpret_cast<const T*>(acm_zero_line);
     int foff[ACM_TASKS][4];          // corners of the tap whose loads are issued next (element offsets, -1 outside)
-    float wa[ACM_TASKS][4], wb2[ACM_TASKS][4];  // bilinear weights of the even / odd taps
+    float wa[ACM_TASKS][2], wb2[ACM_TASKS][2];  // (lh, lw) of the even / odd taps
     float onext[ACM_TASKS][2];       // raw offsets of the following tap, fetched a tap ahead
     acm_u32x4 pre0[ACM_TASKS][4], pre1[ACM_TASKS][4];  // corner loads of the even / odd steps in flight
 
@@ -206,16 +219,16 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     };
     auto feet = [&](int tap) {  // from onext (>= 16 loads were issued after them, except for tap 0); then start
       const int ki = tap / 3, kj = tap - ki * 3;  // fetching the following tap's offsets
-      if (tap == 0) acm_wait_vm<0>(); else acm_wait_vm<16>();
+      if (tap == 0) acm_wait_vm<0>(); else acm_wait_vm<ACM_LOADS>();
 #pragma unroll
       for (int i = 0; i < ACM_TASKS; ++i) { acm_landed(onext[i][0]); acm_landed(onext[i][1]); }
 #pragma unroll
       for (int i = 0; i < ACM_TASKS; ++i) {
         const float h = hb[i] + (float)ki + onext[i][0], w = wb[i] + (float)kj + onext[i][1];
-        float wt[4];
+        float wt[2];
         acm_foot(g, h, w, (vmask >> i) & 1u, ibase[i], foff[i], wt);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {  // value selects: a pointer select would put both sets in scratch
+        for (int j = 0; j < 2; ++j) {  // value selects: a pointer select would put both sets in scratch
           wa[i][j] = (tap & 1) ? wa[i][j] : wt[j];
           wb2[i][j] = (tap & 1) ? wt[j] : wb2[i][j];
         }
@@ -242,21 +255,20 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     };
     auto produce = [&](int step, const acm_u32x4 (&src)[ACM_TASKS][4]) {
       unsigned char* stage = acm_lds + (step & 1) * ACM_STAGE;
-      if (wave == 4) ACM_STAMP(1, step, 0);
+      if (wave == ACM_CW) ACM_STAMP(1, step, 0);
       const int tap = step / cchunks, cc = step - tap * cchunks;
       const int k0 = tap * g.C + cc * BK;
 #pragma unroll
       for (int i = 0; i < ACM_TASKS; ++i) {
         float wt[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wt[j] = (tap & 1) ? wb2[i][j] : wa[i][j];
+        acm_weights((tap & 1) ? wb2[i][0] : wa[i][0], (tap & 1) ? wb2[i][1] : wa[i][1], wt);
         const acm_u32x4 r = F32 ? acm_blend_f32(src[i], wt) : acm_blend(src[i], wt);
-        const int row = i * 32 + prow;
+        const int row = i * (ACM_PT / 8) + prow;
         *reinterpret_cast<acm_u32x4*>(stage + row * 128 + acm_slot(row, q) * 16) = r;
         if (colT != nullptr && ((vmask >> i) & 1u))
           *reinterpret_cast<acm_u32x4*>(colT + cbase[i] + k0 + q * EPT) = r;
       }
-      if (wave == 4) ACM_STAMP(1, step, 1);
+      if (wave == ACM_CW) ACM_STAMP(1, step, 1);
     };
     // step u travels in the register set u & 1; the weights of a tap live in the set tap & 1 (the steps in flight
     // span at most two consecutive taps).  At the top of iteration s: stage s & 1 holds step s (its register set is
@@ -264,16 +276,16 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
     // and produces step s+1.
     fetch_offsets(0);
     issue(0, pre0);
-    if (steps > 1) { issue(1, pre1); acm_wait_vm<16>(); } else { acm_wait_vm<0>(); }
+    if (steps > 1) { issue(1, pre1); acm_wait_vm<ACM_LOADS>(); } else { acm_wait_vm<0>(); }
     landed(pre0);
     produce(0, pre0);
     __syncthreads();
     for (int s = 0; s < steps; s += 2) {
-      if (s + 2 < steps) { issue(s + 2, pre0); acm_wait_vm<16>(); } else { acm_wait_vm<0>(); }
+      if (s + 2 < steps) { issue(s + 2, pre0); acm_wait_vm<ACM_LOADS>(); } else { acm_wait_vm<0>(); }
       if (s + 1 < steps) { landed(pre1); produce(s + 1, pre1); }
       __syncthreads();
       if (s + 1 < steps) {
-        if (s + 3 < steps) { issue(s + 3, pre1); acm_wait_vm<16>(); } else { acm_wait_vm<0>(); }
+        if (s + 3 < steps) { issue(s + 3, pre1); acm_wait_vm<ACM_LOADS>(); } else { acm_wait_vm<0>(); }
         if (s + 2 < steps) { landed(pre0); produce(s + 2, pre0); }
         __syncthreads();
       }
@@ -282,20 +294,20 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
   }
 
   // -------------------------------------------------------------------- consumers
-  const int wm = wave >> 1, wn = wave & 1;       // 2 x 2 waves: 64 positions x 128 output channels each
-  acm_f32x16 acc[2][4];
+  const int wm = wave / ACM_WN, wn = wave % ACM_WN;  // 2 x ACM_WN waves: 64 positions x 32*ACM_NI output channels each
+  acm_f32x16 acc[2][ACM_NI];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < ACM_NI; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   auto issue_b = [&](int k0, unsigned char* stage) {
     // 32 pieces of 8 rows x 128 B; wave w moves pieces w*8 .. w*8+7
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int piece = wave * 8 + it;
+    for (int it = 0; it < 32 / ACM_CW; ++it) {
+      const int piece = wave * (32 / ACM_CW) + it;
       const int row = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       const int o = min(n_base + row, g.O - 1);
@@ -321,55 +333,58 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
       // 4 k-steps of 16 on the current stage: lane half h holds k = 8h .. 8h+7 of a step, i.e. chunk 2*ks + h.
       // All 24 fragment reads first, then 32 MFMAs back to back (fragments of one k-step ahead of their MFMAs would do,
       // but the registers are there: 96 + 128 accumulators)
-      acm_bf16x8 a[4][2], b[4][4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      // (fragments of two k-steps in registers: the reads of step ks+1 are issued before the MFMAs of step ks)
+      acm_bf16x8 a[2][2], b[2][ACM_NI];
+      auto frags = [&](int ks, acm_bf16x8 (&fa)[2], acm_bf16x8 (&fb)[ACM_NI]) {
         const int chunk = ks * 2 + (lane >> 5);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row = wm * 64 + mi * 32 + (lane & 31);
-          a[ks][mi] = *reinterpret_cast<const acm_bf16x8*>(cur + row * 128 + acm_slot(row, chunk) * 16);
+          fa[mi] = *reinterpret_cast<const acm_bf16x8*>(cur + row * 128 + acm_slot(row, chunk) * 16);
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int row = wn * 128 + ni * 32 + (lane & 31);
-          b[ks][ni] = *reinterpret_cast<const acm_bf16x8*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, chunk) * 16);
+        for (int ni = 0; ni < ACM_NI; ++ni) {
+          const int row = wn * (32 * ACM_NI) + ni * 32 + (lane & 31);
+          fb[ni] = *reinterpret_cast<const acm_bf16x8*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, chunk) * 16);
         }
-      }
+      };
+      frags(0, a[0], b[0]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][mi], b[ks][ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < ACM_NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mi], b[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+      }
     } else {
       // 16 k-steps of 2: a 16-byte chunk holds k = 4c .. 4c+3 of a row; lane half h takes k = 4c + 2*kk + h
       const int h = lane >> 5;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        acm_f32x4 a[2], b[4];
+        acm_f32x4 a[2], b[ACM_NI];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row = wm * 64 + mi * 32 + (lane & 31);
           a[mi] = *reinterpret_cast<const acm_f32x4*>(cur + row * 128 + acm_slot(row, c) * 16);
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int row = wn * 128 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < ACM_NI; ++ni) {
+          const int row = wn * (32 * ACM_NI) + ni * 32 + (lane & 31);
           b[ni] = *reinterpret_cast<const acm_f32x4*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, c) * 16);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          float av[2], bv[4];
+          float av[2], bv[ACM_NI];
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) av[mi] = h ? a[mi][2 * kk + 1] : a[mi][2 * kk];
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) bv[ni] = h ? b[ni][2 * kk + 1] : b[ni][2 * kk];
+          for (int ni = 0; ni < ACM_NI; ++ni) bv[ni] = h ? b[ni][2 * kk + 1] : b[ni][2 * kk];
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < ACM_NI; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
         }
       }
@@ -385,8 +400,8 @@ __global__ __launch_bounds__(ACM_NT, 1) void alignconv_fwd_mfma_kernel(
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int o = n_base + wn * 128 + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < ACM_NI; ++ni) {
+      const int o = n_base + wn * (32 * ACM_NI) + ni * 32 + (lane & 31);
       if (o >= g.O) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -417,6 +432,7 @@ static int acm_supported(const rsdet_dcn_geom* s, int O, int elem_bytes) {
   if (s->C < bk || s->C % bk || s->C * elem_bytes > ACM_ZERO_BYTES || O < 32 || O % 32) return 0;
   if (s->B < 1 || s->H < 1 || s->W < 1) return 0;
   if ((long long)s->B * s->H * s->W * s->C >= (1ll << 31)) return 0;
+  if ((long long)s->B * (s->H + 2 * s->ph - 2) * (s->W + 2 * s->pw - 2) * 9 * s->C >= (1ll << 31)) return 0;
   return 1;
 }
 
@@ -436,12 +452,13 @@ static int acm_launch(const T* im_nhwc, const float* offset, const T* weight, co
   const int n_tiles = (O + ACM_BN - 1) / ACM_BN;
   const dim3 grid((unsigned)rsdet_xcd_band_grid(m_tiles, n_tiles));
   hipStream_t st = (hipStream_t)stream;
+  constexpr int CW = sizeof(T) == 4 ? 4 : 8, PW = CW;   // see the note on the wave split above
   if (out_nhwc)
-    hipLaunchKernelGGL((alignconv_fwd_mfma_kernel<T, true>), grid, dim3(ACM_NT), 0, st, im_nhwc, offset, weight, g,
-                       m_tiles, n_tiles, out, colT);
+    hipLaunchKernelGGL((alignconv_fwd_mfma_kernel<T, true, CW, PW>), grid, dim3(64 * (CW + PW)), 0, st, im_nhwc, offset,
+                       weight, g, m_tiles, n_tiles, out, colT);
   else
-    hipLaunchKernelGGL((alignconv_fwd_mfma_kernel<T, false>), grid, dim3(ACM_NT), 0, st, im_nhwc, offset, weight, g,
-                       m_tiles, n_tiles, out, colT);
+    hipLaunchKernelGGL((alignconv_fwd_mfma_kernel<T, false, CW, PW>), grid, dim3(64 * (CW + PW)), 0, st, im_nhwc, offset,
+                       weight, g, m_tiles, n_tiles, out, colT);
   return rsdet_launch_status();
 }
 
