@@ -43,7 +43,9 @@ constexpr int ACM_BM = 128, ACM_BN = 256;          // K step: 128 B of channels 
 constexpr int ACM_TY = 8, ACM_TX = 16;            // the 128 positions of a workgroup: 8 x 16 output pixels
 constexpr int ACM_A_BYTES = ACM_BM * 128;          // 16 KB
 constexpr int ACM_B_BYTES = ACM_BN * 128;          // 32 KB
-constexpr int ACM_STAGE = ACM_A_BYTES + ACM_B_BYTES;
+constexpr int ACM_B_STAGES = 3;                    // weight tiles travel two steps ahead of their use
+constexpr int ACM_B_OFF = 2 * ACM_A_BYTES;         // LDS: A0 A1 | B0 B1 B2  (128 KB)
+constexpr int ACM_LDS_BYTES = ACM_B_OFF + ACM_B_STAGES * ACM_B_BYTES;
 // wave split (template parameters of the kernel): ACM_CW consumer waves = 2 (rows) x ACM_CW/2 (columns) wave tiles of
 // 64 x (512 / ACM_CW), ACM_PW producer waves.  Measured in one box at level 0: bf16 4+4 waves 169 us, 8+8 waves 150 us
 // (a second wave of each kind per SIMD hides the LDS / global latencies of the first); fp32 848 vs 867 us (bound by the
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int BK = 128 / (int)sizeof(T);   // channels per K step
   constexpr int EPT = 16 / (int)sizeof(T);   // channels per 16-byte piece
-  __shared__ __attribute__((aligned(1024))) unsigned char acm_lds[2 * ACM_STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char acm_lds[ACM_LDS_BYTES];
   const RsdetBandItem item = rsdet_xcd_band(blockIdx.x, m_tiles, n_tiles);
   if (!item.valid) return;
 #ifdef ACM_TRACE
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
         for (int j = 0; j < 4; ++j) acm_landed(v[i][j]);
     };
     auto produce = [&](int step, const acm_u32x4 (&src)[ACM_TASKS][4]) {
-      unsigned char* stage = acm_lds + (step & 1) * ACM_STAGE;
+      unsigned char* stage = acm_lds + (step & 1) * ACM_A_BYTES;
       if (wave == ACM_CW) ACM_STAMP(1, step, 0);
       const int tap = step / cchunks, cc = step - tap * cchunks;
       const int k0 = tap * g.C + cc * BK;
@@ -303,7 +305,10 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  auto issue_b = [&](int k0, unsigned char* stage) {
+  auto issue_b = [&](int step) {
+    const int t1 = step / cchunks, c1 = step - t1 * cchunks;
+    const int k0 = t1 * g.C + c1 * BK;
+    unsigned char* stage = acm_lds + ACM_B_OFF + (step % ACM_B_STAGES) * ACM_B_BYTES;
     // 32 pieces of 8 rows x 128 B; wave w moves pieces w*8 .. w*8+7
 #pragma unroll
     for (int it = 0; it < 32 / ACM_CW; ++it) {
@@ -313,22 +318,22 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
       const int o = min(n_base + row, g.O - 1);
       const T* src = wt + (long long)o * K + k0 + chunk * EPT;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(stage + ACM_A_BYTES + piece * 1024),
+                                       (__attribute__((address_space(3))) void*)(stage + piece * 1024),
                                        16, 0, 0);
     }
   };
-  issue_b(0, acm_lds);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  constexpr int B_OPS = 32 / ACM_CW;            // LDS-DMA operations of one tile per consumer wave
+  issue_b(0);
+  if (steps > 1) issue_b(1);
+  if (steps > 1) acm_wait_vm<B_OPS>(); else acm_wait_vm<0>();   // tile 0 landed, tile 1 may still be in flight
   __syncthreads();
 
   for (int s = 0; s < steps; ++s) {
-    unsigned char* cur = acm_lds + (s & 1) * ACM_STAGE;
-    unsigned char* nxt = acm_lds + ((s + 1) & 1) * ACM_STAGE;
+    const unsigned char* cur = acm_lds + (s & 1) * ACM_A_BYTES;
+    const unsigned char* curb = acm_lds + ACM_B_OFF + (s % ACM_B_STAGES) * ACM_B_BYTES;
     if (wave == 0) ACM_STAMP(0, s, 0);
-    if (s + 1 < steps) {
-      const int t1 = (s + 1) / cchunks, c1 = (s + 1) - t1 * cchunks;
-      issue_b(t1 * g.C + c1 * BK, nxt);
-    }
+    // tile s+2 goes where tile s-1 was: every consumer wave finished reading that one before the last barrier
+    if (s + 2 < steps) issue_b(s + 2);
     if constexpr (!F32) {
       // 4 k-steps of 16 on the current stage: lane half h holds k = 8h .. 8h+7 of a step, i.e. chunk 2*ks + h.
       // All 24 fragment reads first, then 32 MFMAs back to back (fragments of one k-step ahead of their MFMAs would do,
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
 #pragma unroll
         for (int ni = 0; ni < ACM_NI; ++ni) {
           const int row = wn * (32 * ACM_NI) + ni * 32 + (lane & 31);
-          fb[ni] = *reinterpret_cast<const acm_bf16x8*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, chunk) * 16);
+          fb[ni] = *reinterpret_cast<const acm_bf16x8*>(curb + row * 128 + acm_slot(row, chunk) * 16);
         }
       };
       frags(0, a[0], b[0]);
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
 #pragma unroll
         for (int ni = 0; ni < ACM_NI; ++ni) {
           const int row = wn * (32 * ACM_NI) + ni * 32 + (lane & 31);
-          b[ni] = *reinterpret_cast<const acm_f32x4*>(cur + ACM_A_BYTES + row * 128 + acm_slot(row, c) * 16);
+          b[ni] = *reinterpret_cast<const acm_f32x4*>(curb + row * 128 + acm_slot(row, c) * 16);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -390,7 +395,8 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
       }
     }
     if (wave == 0) ACM_STAMP(0, s, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile s+1 must have landed before the barrier; tile s+2 (the B_OPS newest operations) stays in flight
+    if (s + 2 < steps) acm_wait_vm<B_OPS>(); else acm_wait_vm<0>();
     if (wave == 0) ACM_STAMP(0, s, 2);
     __syncthreads();
     if (wave == 0) ACM_STAMP(0, s, 3);
