@@ -9,14 +9,15 @@
 //
 //   out[p, o] = sum_{t < 9, c < C}  S(p, t, c) * W[o, t*C + c]        p = (b, ho, wo): GEMM  M = B*Ho*Wo, N = O, K = 9*C
 //
-// One workgroup (4 waves, one per SIMD) owns 128 consecutive positions x 256 output channels, so every sample is
+// One workgroup owns 128 positions (an 8 x 16 pixel tile of one image) x 256 output channels, so every sample is
 // interpolated exactly once.  K runs tap-major in steps of 64 channels of one tap; a step's A tile (128 x 64 samples)
-// is PRODUCED into LDS by the workgroup itself: a thread keeps the four corner pointers and weights of its four
-// positions for the current tap in registers, loads 4 x 16 B per corner (channels-last: the 64 channels of a corner
-// are one 128-B line, 8 lanes per line), interpolates, rounds, and writes 16 B into the swizzled tile.  The B tile
-// (256 x 64 weights, 32 KB, L2-resident: every workgroup re-reads the same 1.2 MB) goes global -> LDS by LDS-DMA with
-// the swizzle applied on the SOURCE address.  Two LDS stages: the loads of step s+1 are in flight under the 32 MFMAs
-// of step s.  Workgroup ids are banded per XCD so that neighbouring position tiles share an L2.
+// is PRODUCED into LDS by half of the workgroup's waves: a thread keeps the corner offsets and (lh, lw) of its
+// positions for the current tap in registers, loads 16 B per corner (channels-last: the 64 channels of a corner are
+// one 128-B line, 8 lanes per line), interpolates, rounds, and writes 16 B into the swizzled tile; the corner loads of
+// two steps are in flight.  The other half CONSUMES: 32 x 32 MFMA tiles, and the B tiles (256 x 64 weights, 32 KB,
+// L2-resident: every workgroup re-reads the same 1.2 MB) by LDS-DMA with the swizzle applied on the SOURCE address,
+// two steps ahead of their use in a 3-deep ring.  A tiles are double-buffered; one barrier per step.  Workgroup ids
+// are banded per XCD so that neighbouring position tiles share an L2.
 //
 // The same kernel in exact fp32 (T = float): 32 channels per step (the same 128-B rows), samples interpolated in the
 // reference's operation order without contraction (columns bit-identical to rsdet_deform_im2col_f32), products on
@@ -146,11 +147,11 @@ __device__ __forceinline__ acm_u32x4 acm_blend_f32(const acm_u32x4 (&v)[4], cons
   return r;
 }
 
-// grid: rsdet_xcd_band_grid(position tiles, output-channel tiles); block 512; 96 KB of LDS (two stages).
-// Waves 0-3 CONSUME (each 64 positions x 128 output channels of MFMA tiles, and the LDS-DMA of the next B tile),
-// waves 4-7 PRODUCE the next A tile; one barrier per K step keeps the two halves in lockstep, so a step costs
-// max(gather + interpolation, MFMA) instead of their sum.  A producer thread holds the 18 offsets of its four
-// positions in registers from the start and keeps the corner loads of TWO steps in flight.
+// grid: rsdet_xcd_band_grid(position tiles, output-channel tiles); block 64 * (ACM_CW + ACM_PW); 128 KB of LDS.
+// Waves [0, ACM_CW) CONSUME (MFMA tiles + the LDS-DMA of the weight tiles), waves [ACM_CW, ACM_CW + ACM_PW) PRODUCE the
+// next A tile; one barrier per K step keeps the two halves in lockstep, so a step costs max(gather + interpolation,
+// MFMA) instead of their sum.  A producer thread fetches the raw offsets of a tap one tap ahead and keeps the corner
+// loads of TWO steps in flight.
 // out: OUT_NHWC ? (B*Ho*Wo, O) : (B, O, Ho*Wo), bf16.  colT (optional): (B*Ho*Wo, 9*C) bf16, the A tiles as produced.
 template <typename T, bool OUT_NHWC, int ACM_CW, int ACM_PW>
 __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_kernel(
@@ -336,9 +337,7 @@ __global__ __launch_bounds__(64 * (ACM_CW + ACM_PW), 1) void alignconv_fwd_mfma_
     if (s + 2 < steps) issue_b(s + 2);
     if constexpr (!F32) {
       // 4 k-steps of 16 on the current stage: lane half h holds k = 8h .. 8h+7 of a step, i.e. chunk 2*ks + h.
-      // All 24 fragment reads first, then 32 MFMAs back to back (fragments of one k-step ahead of their MFMAs would do,
-      // but the registers are there: 96 + 128 accumulators)
-      // (fragments of two k-steps in registers: the reads of step ks+1 are issued before the MFMAs of step ks)
+      // Fragments of two k-steps in registers: the reads of step ks+1 are issued before the MFMAs of step ks
       acm_bf16x8 a[2][2], b[2][ACM_NI];
       auto frags = [&](int ks, acm_bf16x8 (&fa)[2], acm_bf16x8 (&fb)[ACM_NI]) {
         const int chunk = ks * 2 + (lane >> 5);
