@@ -772,6 +772,39 @@ def test_alignconv_mfma_implicit_gemm_tracks_fp32(cuda, shape):
                                              None, _lib.stream_ptr()) != 0
 
 
+def test_alignconv_mfma_matches_the_oracle(cuda):
+    """The implicit-GEMM AlignConv against the CPU oracle (oracle.deform_im2col, dcn_v1.py:132-184): fp32 columns bit
+    for bit, fp32 output == oracle columns x weights (float64 product) within 1e-4, bf16 output within bf16 accuracy;
+    offsets that leave the map, ragged tiles, several images."""
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    B, C, O, H, W = 2, 64, 96, 11, 21
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    off = (rng.standard_normal((B, 18, H, W)) * 2.5).astype(np.float32)
+    off[0, :, 0, :3] = 40.0
+    wgt = (rng.standard_normal((O, C, 3, 3)) / 24).astype(np.float32)
+    geom = dict(kh=3, kw=3, ph=1, pw=1, sh=1, sw=1, dh=1, dw=1)
+    col = oracle.c().deform_im2col(x, off, geom).reshape(C, 9, B * H * W)
+    want_colT = col.transpose(2, 1, 0).reshape(B * H * W, 9 * C)
+    want = (wgt.reshape(O, C * 9).astype(np.float64) @ col.reshape(C * 9, -1).astype(np.float64))
+    want = want.reshape(O, B, H, W).transpose(1, 0, 2, 3)
+    g = _lib.DcnGeom(C, H, W, 3, 3, 1, 1, 1, 1, 1, 1, B, 1)
+    xd = torch.from_numpy(x).to(cuda).permute(0, 2, 3, 1).contiguous()
+    wd = torch.from_numpy(wgt).to(cuda).permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
+    offd = torch.from_numpy(off).to(cuda)
+    out = torch.empty((B, O, H, W), device=cuda)
+    colT = torch.empty((B * H * W, 9 * C), device=cuda)
+    assert lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(xd), _lib.ptr(offd), _lib.ptr(wd), g, O, 0, _lib.ptr(out),
+                                            _lib.ptr(colT), _lib.stream_ptr()) == 0
+    assert (colT.cpu().numpy() == want_colT).all()
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-4
+    outb = torch.empty((B, O, H, W), dtype=torch.bfloat16, device=cuda)
+    assert lib.rsdet_alignconv_fwd_mfma_bf16(_lib.ptr(xd.bfloat16()), _lib.ptr(offd), _lib.ptr(wd.bfloat16()), g, O, 0,
+                                             _lib.ptr(outb), None, _lib.stream_ptr()) == 0
+    assert np.abs(outb.float().cpu().numpy() - want).max() <= 2e-2 * np.abs(want).max()
+
+
 def test_alignconv_mfma_fp32_implicit_gemm_equals_im2col_path(cuda):
     """fp32: a level large enough to fill the chip runs as the exact-fp32 implicit GEMM (v_mfma_f32_32x32x2_f32); the
     output and both gradients equal the im2col + rocBLAS path to fp32 summation-order noise, and the saved columns are
