@@ -805,6 +805,66 @@ def test_alignconv_mfma_matches_the_oracle(cuda):
     assert np.abs(outb.float().cpu().numpy() - want).max() <= 2e-2 * np.abs(want).max()
 
 
+def test_alignconv_mfma_full_size_properties(cuda):
+    """At the step's own size (pyramid level 0 of a 4-tile batch: 4 x 256 x 128 x 128, O = 256) through size-independent
+    properties: zero offsets == the plain 3 x 3 convolution (fp32 within 1e-4, bf16 within bf16 accuracy); integer
+    offsets == the convolution of the shifted image; linearity in the weights; a constant image with in-map samples ->
+    every interior column equals the constant."""
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(21)
+    B, C, O, H, W = 4, 256, 256, 128, 128
+    g = _lib.DcnGeom(C, H, W, 3, 3, 1, 1, 1, 1, 1, 1, B, 1)
+    x = torch.randn(B, C, H, W, device=cuda)
+    w = torch.randn(O, C, 3, 3, device=cuda) / 48
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wf = w.permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
+    zero = torch.zeros(B, 18, H, W, device=cuda)
+
+    def run32(xn_, off_, wf_):
+        out = torch.empty((B, O, H, W), device=cuda)
+        assert lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(xn_), _lib.ptr(off_), _lib.ptr(wf_), g, O, 0, _lib.ptr(out), None,
+                                                _lib.stream_ptr()) == 0
+        return out
+
+    ref = torch.nn.functional.conv2d(x, w, None, 1, 1)
+    scale = float(ref.abs().max())
+    y0 = run32(xn, zero, wf)
+    assert float((y0 - ref).abs().max()) <= 1e-4 * scale
+    # bf16 form on the same (bf16-valued) operands
+    xb, wb = xn.bfloat16(), wf.bfloat16()
+    outb = torch.empty((B, H, W, O), dtype=torch.bfloat16, device=cuda)
+    assert lib.rsdet_alignconv_fwd_mfma_bf16(_lib.ptr(xb), _lib.ptr(zero), _lib.ptr(wb), g, O, 1, _lib.ptr(outb), None,
+                                             _lib.stream_ptr()) == 0
+    refb = torch.nn.functional.conv2d(xb.float().permute(0, 3, 1, 2), wb.float().view(O, 3, 3, C).permute(0, 3, 1, 2),
+                                      None, 1, 1)
+    assert float((outb.float().permute(0, 3, 1, 2) - refb).abs().max()) <= 1.5e-2 * float(refb.abs().max())
+    # every tap moved by (+1 row, -2 columns): the convolution of the image shifted the same way -- away from the border
+    # (at the border the shifted image's zero padding and the samples that come into view differ by construction)
+    sh = zero.clone()
+    sh[:, 0::2] = 1.0
+    sh[:, 1::2] = -2.0
+    xs = torch.zeros_like(x)
+    xs[:, :, :H - 1, 2:] = x[:, :, 1:, :W - 2]
+    d = (run32(xn, sh, wf) - torch.nn.functional.conv2d(xs, w, None, 1, 1))[:, :, 3:H - 3, 4:W - 4]
+    assert float(d.abs().max()) <= 1e-4 * scale
+    # linearity in the weights (same samples): f(2 w1 - 3 w2) == 2 f(w1) - 3 f(w2)
+    off = torch.randn(B, 18, H, W, device=cuda) * 2
+    w2 = torch.randn_like(wf) / 48
+    lhs = run32(xn, off, (2 * wf - 3 * w2).contiguous())
+    rhs = 2 * run32(xn, off, wf) - 3 * run32(xn, off, w2)
+    assert float((lhs - rhs).abs().max()) <= 2e-4 * float(rhs.abs().max())
+    # a constant image: a sample whose four corners are inside the map reproduces the constant
+    colT = torch.empty((B * H * W, 9 * C), device=cuda)
+    out = torch.empty((B, O, H, W), device=cuda)
+    ones = torch.full_like(xn, 0.75)
+    small = (torch.rand(B, 18, H, W, device=cuda) - 0.5) * 0.9
+    assert lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(ones), _lib.ptr(small), _lib.ptr(wf), g, O, 0, _lib.ptr(out),
+                                            _lib.ptr(colT), _lib.stream_ptr()) == 0
+    inner = colT.view(B, H, W, 9 * C)[:, 2:H - 2, 2:W - 2]
+    assert float((inner - 0.75).abs().max()) <= 1e-6
+
+
 def test_alignconv_mfma_fp32_implicit_gemm_equals_im2col_path(cuda):
     """fp32: a level large enough to fill the chip runs as the exact-fp32 implicit GEMM (v_mfma_f32_32x32x2_f32); the
     output and both gradients equal the im2col + rocBLAS path to fp32 summation-order noise, and the saved columns are
