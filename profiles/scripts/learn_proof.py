@@ -24,7 +24,7 @@ def make_runner(model="s2anet", dtype="f32", tile=256, classes=4, lr=None, image
             if backbone in ("Resnet18", "Resnet34"):
                 cfg.model["neck"]["in_channels"] = [64, 128, 256, 512]
         cfg.model["bbox_head"]["num_classes"] = classes + 1
-        cfg.optimizer = dict(type='SGD', lr=lr or 0.01, momentum=0.9, weight_decay=0.0001, grad_clip=dict(max_norm=35, norm_type=2))
+        cfg.optimizer = dict(type='SGD', lr=lr or 0.0025, momentum=0.9, weight_decay=0.0001, grad_clip=dict(max_norm=35, norm_type=2))
         cfg.scheduler = dict(type='StepLR', warmup='linear', warmup_iters=50, warmup_ratio=1.0 / 3, milestones=[1000])
     else:
         cfg = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py"))
