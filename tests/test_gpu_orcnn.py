@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import oracle
 import pytest
 import torch
 
@@ -62,6 +63,21 @@ def test_roi_extractor_equals_per_level_gather(cuda):
             want[m] = ex.roi_layers[i](feats[i], r[m])
     torch.testing.assert_close(got, want, atol=1e-5, rtol=1e-5)
     assert len(set(lv.tolist())) >= 3
+    # independent known answer: NumPy restatement of the RoI extension (roi_extractors/oriented_single_level.py:85-88:
+    # (h_f, w_f) = extend_factor, w *= w_f, h *= h_f) and of the level map (:68-70: floor(log2(sqrt(w*h) / 56 + 1e-6)),
+    # clamped) + the ORACLE's RROIAlign on the mapped level
+    ext_r = rois.cpu().numpy().astype(np.float64)
+    ext_r[:, 3] *= 1.2
+    ext_r[:, 4] *= 1.4
+    lv_np = np.clip(np.floor(np.log2(np.sqrt(ext_r[:, 3] * ext_r[:, 4]) / 56 + 1e-6)), 0, 3).astype(np.int64)
+    assert (lv_np == lv.cpu().numpy()).all()
+    want_np = np.zeros(tuple(got.shape), np.float32)
+    for i, s_ in enumerate((4, 8, 16, 32)):
+        m = lv_np == i
+        if m.any():
+            want_np[m] = oracle.c().rroi_align_v1_forward(feats[i].cpu().numpy(), ext_r[m].astype(np.float32), (7, 7),
+                                                          1.0 / s_, 2)
+    assert np.abs(got.cpu().numpy() - want_np).max() <= 1e-4
 
 
 def test_oriented_rcnn_train_step_and_eval(cuda):
