@@ -258,12 +258,12 @@ def next_row_kernels(device):
     for tag, fn in (("v1", ops.roi_align_rotated_v1), ("v0", ops.roi_align_rotated.roi_align)):
         t = event_time(lambda: fn(feat.detach(), rois, (7, 7), 0.25, 2), 10, 2)
         row("rroi_forward_kernel(%s; 512 RoIs x 256 ch)" % tag, by, t)
-    y = ops.roi_align_rotated_v1(feat, rois, (7, 7), 0.25, 2)
-    go = torch.randn_like(y)
-    t = event_time(lambda: torch.autograd.grad(y, feat, go, retain_graph=True), 10, 2, graph=False)
+    from rs_detection_amd.ops.roi_align_rotated_v1 import rroi_align_backward
+    go = torch.randn(R, C, 7, 7, device=device)
+    t = event_time(lambda: rroi_align_backward(go, rois, (N, C, H, H), (7, 7), 0.25, 2, "v1"), 10, 2)
     row("rroi_idx_count+scan+fill+rroi_gather(backward; incl. the two layout permutes and a %d MB output)"
         % (N * C * H * H * 4 // 2 ** 20), 4 * (R * C * 49 + N * C * H * H), t)
-    del feat, y, go
+    del feat, go
     # -- depthwise convolutions of the VAN backbone (a20): stage-1 shapes of VAN-B3 on two 1024^2 tiles;
     #    bytes = one read + one write of the tensor (forward / backward-data), two reads (backward-weight)
     from rs_detection_amd.ops.dwconv import dwconv2d
@@ -290,11 +290,11 @@ def next_row_kernels(device):
     for pts in (1, 5):
         t = event_time(lambda: ops.feature_refine(f.detach(), bx, 0.125, pts), 10, 2)
         row("fr_forward_kernel<%d>" % pts, by, t)
-        y = ops.feature_refine(f, bx, 0.125, pts)
-        go = torch.randn_like(y)
-        t = event_time(lambda: torch.autograd.grad(y, f, go, retain_graph=True), 10, 2, graph=False)
+        from rs_detection_amd.ops.fr import feature_refine_backward
+        go = torch.randn(N, C, H, H, device=device)
+        t = event_time(lambda: feature_refine_backward(go, bx, 0.125, pts), 10, 2)
         row("fr_idx_count+scan+fill+gather<%d>(backward; incl. the two layout permutes)" % pts, by, t)
-    del f, y, go
+    del f, go
     # -- convex_sort (f4): the poly_iou_loss shape, 24 candidate points per pair, 20 000 pairs
     nbs, npts = 20000, 24
     p = torch.randn(nbs, npts, 2, device=device) * 20

@@ -457,6 +457,11 @@ int rsdet_bn_act_backward_bf16(const uint16_t* grad_y, const uint16_t* y, const 
                                int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
                                float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 
+/* in (B, R, C) -> out (B, C, R), fp32, through 64 x 64 LDS tiles: the NCHW <-> NHWC turns around the channels-last
+ * gather kernels (ops/roi_align_rotated_v1.py:329-351, ops/fr.py:235-260 and ops/dcn_v1.py:456-557 consume and produce
+ * NCHW).  NHWC -> NCHW: B = N, R = H*W, C = channels.  in != out; R <= 64*65535. */
+int rsdet_transpose_last2_f32(const float* in, float* out, int B, int R, int C, void* stream);
+
 /* Column sums of a (rows, C) matrix, C <= 64: out[c] = sum_r x[r, c] in fp32 (two deterministic stages).  The bias
  * gradient of a channels_last convolution with few output channels (the 5- / 15-channel prediction maps of
  * models/roi_heads/s2anet_head.py:128-142): rows = N*H*W. */

@@ -1,0 +1,64 @@
+// layout.hip -- (B, R, C) -> (B, C, R) transposes of fp32 tensors through an LDS tile: the NCHW <-> NHWC turns around
+// the channels-last gather kernels (RROIAlign / FeatureRefine / AlignConv backward, /root/reference/python/jdet/ops/
+// roi_align_rotated_v1.py:329-351, fr.py:235-260, dcn_v1.py:456-557 consume and produce NCHW).  torch's generic strided
+// copy moves such a turn at ~1.5 TB/s (a 134 MB level: ~180 us); 64 x 64 tiles with 16-byte accesses on both sides run at
+// the HBM rate.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsdet_api_internal.h"
+
+namespace rsdet {
+
+constexpr int TR_T = 64;  // tile edge
+
+// grid: (ceil(C / 64), ceil(R / 64), B); block 256.  in[b][r][c] -> out[b][c][r]
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int R, int C) {
+  __shared__ float tile[TR_T][TR_T + 1];
+  const int t = threadIdx.x;
+  const long long base_in = (long long)blockIdx.z * R * C, base_out = base_in;
+  const int c0 = blockIdx.x * TR_T, r0 = blockIdx.y * TR_T;
+  const bool full = c0 + TR_T <= C && r0 + TR_T <= R && (C & 3) == 0 && (R & 3) == 0;
+  if (full) {
+    const int q = (t & 15) * 4, p = t >> 4;   // 16 threads x float4 = one 256-byte tile row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = p + 16 * i;
+      const float4 v = *reinterpret_cast<const float4*>(in + base_in + (long long)(r0 + r) * C + c0 + q);
+      tile[q][r] = v.x; tile[q + 1][r] = v.y; tile[q + 2][r] = v.z; tile[q + 3][r] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = p + 16 * i;
+      const float4 v = make_float4(tile[c][q], tile[c][q + 1], tile[c][q + 2], tile[c][q + 3]);
+      *reinterpret_cast<float4*>(out + base_out + (long long)(c0 + c) * R + r0 + q) = v;
+    }
+  } else {   // ragged edge tiles: element by element
+    for (int e = t; e < TR_T * TR_T; e += 256) {
+      const int r = e / TR_T, c = e - r * TR_T;
+      if (r0 + r < R && c0 + c < C) tile[c][r] = in[base_in + (long long)(r0 + r) * C + c0 + c];
+    }
+    __syncthreads();
+    for (int e = t; e < TR_T * TR_T; e += 256) {
+      const int c = e / TR_T, r = e - c * TR_T;
+      if (r0 + r < R && c0 + c < C) out[base_out + (long long)(c0 + c) * R + r0 + r] = tile[c][r];
+    }
+  }
+}
+
+}  // namespace rsdet
+
+using namespace rsdet;
+
+extern "C" int rsdet_transpose_last2_f32(const float* in, float* out, int B, int R, int C, void* stream) {
+  if (B < 0 || R < 0 || C < 0) return RSDET_EINVAL;
+  if (B == 0 || R == 0 || C == 0) return RSDET_OK;
+  if (!in || !out || in == out) return RSDET_EINVAL;
+  const long long gx = (C + TR_T - 1) / TR_T, gy = (R + TR_T - 1) / TR_T;
+  if (gy > 65535 || B > 65535) return RSDET_EINVAL;
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, in, out, R, C);
+  return rsdet_launch_status();
+}

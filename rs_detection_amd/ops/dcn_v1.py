@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from .layout import nchw_to_nhwc, nhwc_to_nchw
 
 __all__ = ["DeformConv", "deform_conv", "deformable_im2col", "deformable_col2im", "deformable_col2im_coord",
            "deformable_im2col_nhwc", "deformable_col2im_nhwc"]
@@ -170,7 +171,7 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
             # exact-fp32 implicit GEMM (csrc/alignconv_mfma.hip, v_mfma_f32_32x32x2_f32): one launch, the sampled columns
             # written once channels-last (bit-identical to the im2col kernel's) for the weight gradient
             lib = _lib.load()
-            x_nhwc = input.permute(0, 2, 3, 1).contiguous()
+            x_nhwc = nchw_to_nhwc(input)
             w_t = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C).contiguous()
             out = torch.empty((B, O, Ho, Wo), dtype=input.dtype, device=input.device)
             colT = (torch.empty((B * hw, kh * kw * C), dtype=input.dtype, device=input.device)
@@ -216,7 +217,7 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
                 gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation)
             else:
                 gi = deformable_col2im_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation, dg)
-            grad_input = gi.permute(0, 3, 1, 2).contiguous()
+            grad_input = nhwc_to_nchw(gi)
         if ctx.needs_input_grad[2]:
             # gw (O, C*kh*kw) = go2 @ col^T has only 36 output tiles of 128 x 128 for K = B*hw up to 65 536: split K into
             # J slices as a strided-batched product (views, no copies) and add the J partial results

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from .layout import nchw_to_nhwc, nhwc_to_nchw
 
 __all__ = ["feature_refine", "FR", "FeatureRefineModule"]
 
@@ -36,18 +37,24 @@ class FeatureRefineFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         (boxes,) = ctx.saved_tensors
         scale, points = ctx.cfg
-        lib = _lib.load()
-        N, C, H, W = grad_output.shape
-        if N == 0 or C == 0:
-            return torch.zeros_like(grad_output), None, None, None
-        go = grad_output.permute(0, 2, 3, 1).contiguous()  # channels-last rows for the gather
-        gi = torch.empty_like(go)
-        ws_bytes = lib.rsdet_feature_refine_backward_ws_size(N, H, W, points)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
-        rc = lib.rsdet_feature_refine_backward_nhwc_f32(_lib.ptr(go), _lib.ptr(boxes), N, C, H, W, scale, points,
-                                                        _lib.ptr(gi), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
-        _lib.check(rc, "rsdet_feature_refine_backward_nhwc_f32")
-        return gi.permute(0, 3, 1, 2).contiguous(), None, None, None
+        return feature_refine_backward(grad_output, boxes, scale, points), None, None, None
+
+
+def feature_refine_backward(grad_output, boxes, scale, points):
+    """grad_features of FeatureRefineFunction (fr.py:235-260); a plain function so that the bench can replay it from a
+    hipGraph (device time, like the forward rows)."""
+    lib = _lib.load()
+    N, C, H, W = grad_output.shape
+    if N == 0 or C == 0:
+        return torch.zeros_like(grad_output)
+    go = nchw_to_nhwc(grad_output.contiguous())  # channels-last rows for the gather
+    gi = torch.empty_like(go)
+    ws_bytes = lib.rsdet_feature_refine_backward_ws_size(N, H, W, points)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
+    rc = lib.rsdet_feature_refine_backward_nhwc_f32(_lib.ptr(go), _lib.ptr(boxes), N, C, H, W, scale, points,
+                                                    _lib.ptr(gi), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+    _lib.check(rc, "rsdet_feature_refine_backward_nhwc_f32")
+    return nhwc_to_nchw(gi)
 
 
 def feature_refine(features, best_rbboxes, spatial_scale, points=1):

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from .layout import nhwc_to_nchw, transpose_last2
 
 __all__ = ["ROIAlignRotated_v1", "roi_align_rotated_v1", "rroi_align"]
 
@@ -43,32 +44,38 @@ class _RotatedROIAlign_v1(torch.autograd.Function):
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors
         shape, output_size, scale, sr, variant = ctx.cfg
-        lib = _lib.load()
-        N, C, H, W = shape
-        go = grad_output.contiguous()
-        R, PH, PW = rois.shape[0], output_size[0], output_size[1]
-        if sr > 0 and R > 0:
-            # gather form: no fp32 atomics (csrc/rroi_align.hip); channels-last in, channels-last out.
-            # (rsdet_rroi_align_*_backward_gather_nchw_f32 writes NCHW directly and is correct, but its 64-pixel tile
-            # walks each pixel's entry chain serially: 321 us against ~35 us for this one-wave-per-pixel kernel at
-            # 2 x 256 x 256 x 256 -- measured round 2, RSDET_RROI_NCHW=1 selects it; the transposes stay for now.)
-            import os
-            nchw = os.environ.get("RSDET_RROI_NCHW", "0") == "1"
-            go_t = go.permute(0, 2, 3, 1).reshape(R, PH * PW, C).contiguous()
-            g = torch.empty((N, C, H, W) if nchw else (N, H, W, C), dtype=go.dtype, device=go.device)
-            ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
-            name = "rsdet_rroi_align_%s_backward_gather_%sf32" % (variant, "nchw_" if nchw else "")
-            rc = getattr(lib, name)(_lib.ptr(go_t), _lib.ptr(rois), R, C, N, H, W, PH, PW, scale, sr,
-                                    _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
-            _lib.check(rc, name)
-            return (g if nchw else g.permute(0, 3, 1, 2).contiguous()), None, None, None, None, None
-        grad_in = torch.zeros(shape, dtype=go.dtype, device=go.device)  # :345 memset
-        name = "rsdet_rroi_align_%s_backward_f32" % variant
-        rc = getattr(lib, name)(_lib.ptr(go), _lib.ptr(rois), rois.shape[0], C, H, W, output_size[0], output_size[1],
-                                scale, sr, _lib.ptr(grad_in), _lib.stream_ptr())
+        return rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant), None, None, None, None, None
+
+
+def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant="v1"):
+    """grad_feat (N,C,H,W) of _RotatedROIAlign_v1 (roi_align_rotated_v1.py:329-351); a plain function so that the bench
+    can replay it from a hipGraph (device time, like the forward rows)."""
+    lib = _lib.load()
+    N, C, H, W = shape
+    go = grad_output.contiguous()
+    R, PH, PW = rois.shape[0], output_size[0], output_size[1]
+    if sr > 0 and R > 0:
+        # gather form: no fp32 atomics (csrc/rroi_align.hip); channels-last in, channels-last out.
+        # (rsdet_rroi_align_*_backward_gather_nchw_f32 writes NCHW directly and is correct, but its 64-pixel tile
+        # walks each pixel's entry chain serially: 321 us against ~35 us for this one-wave-per-pixel kernel at
+        # 2 x 256 x 256 x 256 -- measured round 2, RSDET_RROI_NCHW=1 selects it; the transposes stay for now.)
+        import os
+        nchw = os.environ.get("RSDET_RROI_NCHW", "0") == "1"
+        go_t = transpose_last2(go.view(R, C, PH * PW))            # (R, 49, C): channels-last rows for the gather
+        g = torch.empty((N, C, H, W) if nchw else (N, H, W, C), dtype=go.dtype, device=go.device)
+        ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
+        name = "rsdet_rroi_align_%s_backward_gather_%sf32" % (variant, "nchw_" if nchw else "")
+        rc = getattr(lib, name)(_lib.ptr(go_t), _lib.ptr(rois), R, C, N, H, W, PH, PW, scale, sr,
+                                _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
         _lib.check(rc, name)
-        return grad_in, None, None, None, None, None
+        return g if nchw else nhwc_to_nchw(g)
+    grad_in = torch.zeros(shape, dtype=go.dtype, device=go.device)  # :345 memset
+    name = "rsdet_rroi_align_%s_backward_f32" % variant
+    rc = getattr(lib, name)(_lib.ptr(go), _lib.ptr(rois), rois.shape[0], C, H, W, output_size[0], output_size[1],
+                            scale, sr, _lib.ptr(grad_in), _lib.stream_ptr())
+    _lib.check(rc, name)
+    return grad_in
 
 
 rroi_align = _RotatedROIAlign_v1.apply

@@ -656,6 +656,19 @@ def test_conv_module_fused_bias_relu_under_bf16_autocast_channels_last(cuda):
     assert res[True][2].dtype == torch.float32 and res[True][3].dtype == torch.float32
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 64), (1, 100, 49), (3, 7, 260), (512, 256, 49), (2, 4096, 256), (1, 1, 1)])
+def test_transpose_last2_equals_torch(cuda, shape):
+    """csrc/layout.hip: (B, R, C) -> (B, C, R) bit for bit, full and ragged tiles; the NCHW <-> NHWC helpers on top."""
+    from rs_detection_amd.ops.layout import transpose_last2, nchw_to_nhwc, nhwc_to_nchw
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=cuda)
+    assert torch.equal(transpose_last2(x), x.transpose(1, 2).contiguous())
+    y = torch.randn(2, 24, 9, 13, device=cuda)
+    n = nchw_to_nhwc(y)
+    assert n.is_contiguous() and torch.equal(n, y.permute(0, 2, 3, 1)) and torch.equal(nhwc_to_nchw(n), y)
+    assert torch.equal(nchw_to_nhwc(y.double()), y.double().permute(0, 2, 3, 1).contiguous())   # other dtypes: torch
+
+
 def test_colsum_and_conv2d_bias_channels_last(cuda):
     """rsdet_colsum_* == the fp32 column sum (to summation order), incl. ragged row counts and C = 1 / 5 / 15 / 64;
     conv2d_bias under bf16 autocast on a channels_last input == the module itself (output, input / weight / bias
