@@ -102,7 +102,11 @@ def event_time(fn, iters, warmup=3, graph=True):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r02_roofline.json")
+ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r03_roofline.json")
+if not os.path.exists(ROOFLINE_FILE):
+    ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r02_roofline.json")
+AT_ROW = "anchor_target_rotated(fused: IoU + assign + encode + weights; 2 launches)"
+BN_ROW = "bn_act_forward_kernel<f32>(bn + residual + relu; 4x256x256x256, layer1 of the step)"
 
 
 def pmc_traffic(call, shape_ok):
@@ -159,7 +163,7 @@ def kernel_rooflines(device, targets):
     t2 = event_time(lambda: ops.anchor_target_rotated(anchors, gt, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep,
                                                       prepared_gt=pgt), 50)
     by2 = 20 * (n1 + A) + 56 * len(ks) * A
-    out["anchor_target_rotated(fused: IoU + assign + encode + weights; 2 launches)"] = dict(
+    out[AT_ROW] = dict(
         bound="latency/alu", achieved=by2 / t2 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by2 / t2 / 1e9 / HBM_PEAK_GBS,
         traffic=pmc_traffic("anchor_target_rotated (2 launches)", (n1, A) == (556, 21824)), us=t2 * 1e6,
         replaces="box_iou_rotated_grouped + assign_wrt_overlaps + ~15 torch kernels of anchor_target_batched")
@@ -233,7 +237,40 @@ def kernel_rooflines(device, targets):
         t = event_time(fn, 10, 2)
         out[name] = dict(bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6, mboxes_per_s=M / t / 1e6)
+    out.update(bn_act_rows(device, len(ks)))
     out.update(next_row_kernels(device))
+    return out
+
+
+def bn_act_rows(device, B):
+    """The fused eval-mode BatchNorm tails of the trunk (csrc/bn_act.hip), the hand-written kernels with the most time
+    in the step.  Shapes: the layer1 block output of the step (B x 256 x 256 x 256 with the identity added) in fp32 NCHW
+    and in bf16 channels_last.  bytes: forward = x + residual in, y out; backward = gy + y in, gx + gres out (the
+    per-channel parameter sums ride on the same pass)."""
+    from rs_detection_amd.ops.bn_act import bn_act
+    out = {}
+    C, H = 256, TILE // 4
+    bn = torch.nn.BatchNorm2d(C).to(device).eval()
+    for tag, dt, cl in (("f32", torch.float32, False), ("bf16 nhwc", torch.bfloat16, True)):
+        x = torch.randn(B, C, H, H, device=device, dtype=dt)
+        r = torch.randn(B, C, H, H, device=device, dtype=dt)
+        if cl:
+            x, r = x.contiguous(memory_format=torch.channels_last), r.contiguous(memory_format=torch.channels_last)
+        es = x.element_size()
+        t = event_time(lambda: bn_act(x, bn, r, True), 10, 2)
+        name = BN_ROW if tag == "f32" else "bn_act_forward_nhwc_kernel<bf16>(bn + residual + relu; %dx256x%dx%d)" % (B, H, H)
+        by = 3 * es * x.numel()
+        out[name] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+                         traffic=pmc_traffic("bn_act_forward_" + tag.split()[0], (B, H) == (4, 256)), us=t * 1e6)
+        xg, rg = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        y = bn_act(xg, bn, rg, True)
+        gy = torch.randn_like(y)
+        t = event_time(lambda: torch.autograd.grad(y, (xg, rg, bn.weight, bn.bias), gy, retain_graph=True), 10, 2, graph=False)
+        by = 4 * es * x.numel()
+        out["bn_act_backward%s<%s>(gx + gres + parameter sums; same shape; eager launches)" % ("_nhwc" if cl else "", tag.split()[0])] = dict(
+            bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+            traffic=pmc_traffic("bn_act_backward_" + tag.split()[0], (B, H) == (4, 256)), us=t * 1e6)
+        del x, r, xg, rg, y, gy
     return out
 
 
@@ -345,6 +382,45 @@ def cpu_baseline(budget_s=12.0):
                                sample="K=%d gt split over %d threads, %.0f s" % (big.shape[0], ncores, dt2)))
 
 
+N_BATCHES = 4  # resident batches rotated through the timed loop
+
+
+def make_batches(n, batch, rank, ncls, device, mf, orcnn):
+    from rs_detection_amd.utils import synthetic as syn
+    out = []
+    for it in range(n):
+        g = torch.Generator(device="cpu").manual_seed(1000 * it + rank)
+        images = torch.randn(batch, 3, TILE, TILE, generator=g).to(device)
+        if mf is torch.channels_last:
+            images = images.contiguous(memory_format=mf)
+        targets = []
+        for t in syn.synthetic_targets(batch, rank=rank, it=it, num_classes=ncls, img=TILE, k_shift=it):
+            t = dict(t)
+            t["rboxes"] = torch.from_numpy(t["rboxes"]).to(device)
+            t["labels"] = torch.from_numpy(t["labels"]).to(device)
+            if orcnn:
+                t["hboxes"] = None
+            targets.append(t)
+        out.append((images, targets))
+    return out
+
+
+def timed_region(runner, batches, steps, rdist, device):
+    """EXACTLY `steps` train steps between barrier + synchronize on both sides; max over ranks."""
+    rdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, _ = runner.train_step(*batches[i % len(batches)])
+    torch.cuda.synchronize()
+    rdist.barrier()
+    dt = time.perf_counter() - t0
+    dt = rdist.all_reduce_max(dt, device)
+    loss_v = float(loss.detach())
+    assert np.isfinite(loss_v), "non-finite loss"
+    return dt, loss_v
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +428,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the second (bf16) timed leg of the default line")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE config[1] (the metric); bf16 = torch.autocast over the MIOpen/rocBLAS part "
                          "(configs[2]/[4]); the oriented-box kernels always compute in fp32")
@@ -406,24 +483,16 @@ def main():
         args.no_kernels = True
     else:
         cfg, batch, ncls = s2anet_cfg(), BATCH_PER_GPU, 15
-    runner = Runner(cfg, device=device, memory_format=mf,
-                    amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
-    # synthetic DOTA-shaped batch, resident in HBM before the timed region
-    g = torch.Generator(device="cpu").manual_seed(0 + rank)
-    images = torch.randn(batch, 3, TILE, TILE, generator=g).to(device)
-    if mf is torch.channels_last:
-        images = images.contiguous(memory_format=mf)
-    targets = []
-    for t in syn.synthetic_targets(batch, rank=rank, it=0, num_classes=ncls, img=TILE):
-        t = dict(t)
-        t["rboxes"] = torch.from_numpy(t["rboxes"]).to(device)
-        t["labels"] = torch.from_numpy(t["labels"]).to(device)
-        if args.model == "orcnn_van3":
-            t["hboxes"] = None
-        targets.append(t)
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+    runner = Runner(cfg, device=device, memory_format=mf, amp_dtype=amp)
+    # synthetic DOTA-shaped batches, resident in HBM before the timed region.  N_BATCHES different batches
+    # rotate through the timed loop (step i runs batch i % N_BATCHES, the K cycle shifted by one slot per batch), so the
+    # per-K-tuple tile tables and the prepared-box caches of the anchor-target path see new gts every step.
+    batches = make_batches(N_BATCHES, batch, rank, ncls, device, mf, args.model == "orcnn_van3")
+    images, targets = batches[0]
 
-    for _ in range(args.warmup):
-        runner.train_step(images, targets)
+    for i in range(args.warmup):
+        runner.train_step(*batches[i % N_BATCHES])
     step_flops = None
     if not args.no_kernels:
         # one extra UNTIMED step under torch's flop counter (convs + GEMMs, fwd + bwd).  On EVERY rank: the step
@@ -432,25 +501,39 @@ def main():
         with FlopCounterMode(display=False) as fc:
             runner.train_step(images, targets)
         step_flops = float(fc.get_total_flops())
-    rdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = runner.train_step(images, targets)
-    torch.cuda.synchronize()
-    rdist.barrier()
-    dt = time.perf_counter() - t0
-    dt = rdist.all_reduce_max(dt, device)
-    loss_v = float(loss.detach())
-    assert np.isfinite(loss_v), "non-finite loss"
+    dt, loss_v = timed_region(runner, batches, args.steps, rdist, device)
+
+    # second, separately timed leg: the SAME model and batches in bf16 autocast + channels_last (BASELINE configs[2]'s
+    # arithmetic), its own Runner, its own warm-up; reported as a nested object, never as `value`
+    bf16_leg = None
+    if args.dtype == "f32" and args.model == "s2anet_r50" and not args.no_bf16_leg:
+        del runner
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        r16 = Runner(cfg, device=device, memory_format=torch.channels_last, amp_dtype=torch.bfloat16)
+        b16 = [(im.contiguous(memory_format=torch.channels_last), tg) for im, tg in batches]
+        for i in range(max(args.warmup, 3)):
+            r16.train_step(*b16[i % N_BATCHES])
+        steps16 = max(args.steps, 20)
+        dt16, loss16 = timed_region(r16, b16, steps16, rdist, device)
+        bf16_leg = {"value": batch * world * steps16 / dt16, "unit": "tiles/s", "ms_per_step": dt16 / steps16 * 1e3,
+                    "steps": steps16, "warmup": max(args.warmup, 3), "dtype": "bf16", "memory_format": "channels_last",
+                    "final_loss": loss16,
+                    "flop_roofline": None if step_flops is None else {
+                        "bound": "mfma", "achieved": step_flops / (dt16 / steps16) / 1e12, "unit": "TFLOP/s",
+                        "peak": 2500.0, "frac": step_flops / (dt16 / steps16) / 1e12 / 2500.0}}
+        del r16, b16
+        torch.cuda.empty_cache()
 
     if rank != 0:
         rdist.barrier()          # rank 0 is still timing its kernel table: leave the group together
         rdist.shutdown()
         return
     kernels = {} if args.no_kernels else kernel_rooflines(device, targets)
-    roof = kernels.get("box_iou_rotated(prepare+filter+clip)")
+    dense = kernels.get("box_iou_rotated(prepare+filter+clip)")
+    roof = kernels.get(AT_ROW)
     tiles = batch * world * args.steps
+    keys = ("bound", "achieved", "peak", "unit", "frac", "traffic")
     line = {
         "metric": METRICS[args.model],
         "value": tiles / dt,
@@ -466,18 +549,35 @@ def main():
         "data": "synthetic",
         "config": {"workload": (WORKLOADS[args.model] % (batch, TILE, TILE, "fp32" if args.dtype == "f32" else
                                                              "bf16 autocast (fp32 box kernels)")
-                                + "; one cached batch per rank, resident in HBM, replayed every step"),
+                                + "; %d different batches per rank resident in HBM, step i runs batch i %% %d (K cycle "
+                                  "shifted by one slot per batch)" % (N_BATCHES, N_BATCHES)
+                                ),
                    "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "memory_format": args.memory_format,
                    "miopen_records": "packaged (rs_detection_amd/miopen_db)" if MIOPEN_DB_DIR else "none / user-provided"},
         "final_loss": loss_v,
-        "rotated_iou_mpairs_per_s": roof["mpairs_per_s"] if roof else None,
-        "roofline": ({k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {
-            "kernel": "rsdet_box_iou_rotated_grouped_f32 = iou_prepare + iou_filter + iou_clip kernels",
-            "traffic_source": "profiles/r02_roofline.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
-                              "profiles/scripts/roofline.sh); occupancy of every kernel: profiles/r02_occupancy.json",
-            "us_per_launch": roof["us"], "shape": roof["shape"], "valu_frac": roof["valu_frac"],
-            "alg_gflop": roof["alg_gflop"], "overlapping_pairs": roof["overlapping_pairs"]}) if roof else None,
+        "rotated_iou_mpairs_per_s": dense["mpairs_per_s"] if dense else None,
+        # the oriented-box kernel the timed step itself runs: the fused sparse anchor-target call (twice per step: FAM
+        # and ODM).  Priced against HBM as the contract asks; its algorithmic bytes are tiny (no K x A matrix is ever
+        # written), so the fraction says "latency / VALU bound", which is what `bound_note` states.
+        "roofline": ({k: roof[k] for k in keys} | {
+            "bound": "hbm",
+            "bound_note": "latency / VALU-issue bound: 5.3 MB of algorithmic bytes per launch pair; see kernels[] and "
+                          "profiles/%s for the instruction counters" % os.path.basename(ROOFLINE_FILE),
+            "kernel": "rsdet_anchor_target_rotated_f32 = iou_tile_kernel<SPARSE> + at_finish_kernel (the call the "
+                      "timed step makes for FAM and ODM targets)",
+            "traffic_source": "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
+                              "profiles/scripts/roofline.sh)" % os.path.basename(ROOFLINE_FILE),
+            "us_per_launch": roof["us"], "shape": dense["shape"] if dense else None}) if roof else None,
+        # the standalone north-star kernel (dense K x A rotated IoU, the matrix written to HBM), not on the step's path
+        "roofline_dense_iou": ({k: dense[k] for k in keys} | {
+            "kernel": "rsdet_box_iou_rotated_grouped_f32 (dense K x A matrix; standalone metric, not in the timed step)",
+            "us_per_launch": dense["us"], "shape": dense["shape"], "valu_frac": dense["valu_frac"],
+            "alg_gflop": dense["alg_gflop"], "overlapping_pairs": dense["overlapping_pairs"]}) if dense else None,
+        # the hand-written kernel with the most time in the timed step (4.3 of 6.3 ms of hand-written kernels)
+        "roofline_dominant_handwritten": ({k: kernels[BN_ROW][k] for k in keys} | {
+            "kernel": BN_ROW, "us_per_launch": kernels[BN_ROW]["us"]}) if BN_ROW in kernels else None,
+        "bf16": bf16_leg,
         # the conv / GEMM side of the step against the MFMA roofline: flops of one rank's step as counted
         # by torch.utils.flop_counter, over the measured step time, over the dense peak of the compute dtype
         "flop_roofline": None if step_flops is None else {

@@ -306,3 +306,258 @@ def np_oriented_rpn_get_bboxes_single(cls_scores, bbox_preds, mlvl_anchors, mean
     hp = hp + (ids.astype(F) * (hp.max() - hp.min() + 1))[:, None]                 # levels never suppress each other
     keep = np_hbb_nms(np.concatenate([hp, sc[:, None]], 1).astype(F), nms_thresh)
     return np.concatenate([props, sc[:, None]], 1)[keep][:nms_post].astype(F)
+
+
+# ---- Oriented R-CNN: shared pieces -------------------------------------------------------------------------------
+def np_bbox_overlaps_hbb(b1, b2, version=0, eps=1e-6):
+    """models/boxes/iou_calculator.py:164-270, mode 'iou', not aligned: (m,4) x (n,4) -> (m,n) fp32."""
+    b1, b2 = b1[:, :4].astype(F), b2[:, :4].astype(F)
+    a1 = (b1[:, 2] - b1[:, 0] + F(version)) * (b1[:, 3] - b1[:, 1] + F(version))
+    a2 = (b2[:, 2] - b2[:, 0] + F(version)) * (b2[:, 3] - b2[:, 1] + F(version))
+    lt = np.maximum(b1[:, None, :2], b2[None, :, :2])
+    rb = np.minimum(b1[:, None, 2:], b2[None, :, 2:])
+    wh = np.clip(rb - lt + F(version), 0, None).astype(F)
+    ov = wh[..., 0] * wh[..., 1]
+    union = np.maximum(a1[:, None] + a2[None, :] - ov, F(eps))
+    return (ov / union).astype(F)
+
+
+def np_hbb2obb(h):
+    """ops/bbox_transforms.py:640-652."""
+    x, y = (h[..., 0] + h[..., 2]) * F(0.5), (h[..., 1] + h[..., 3]) * F(0.5)
+    w, hh = h[..., 2] - h[..., 0], h[..., 3] - h[..., 1]
+    z = np.zeros_like(x)
+    o1 = np.stack([x, y, w, hh, z], -1)
+    o2 = np.stack([x, y, hh, w, z - F(PI / 2)], -1)
+    flag = (w >= hh)[..., None].astype(F)
+    return (flag * o1 + (1 - flag) * o2).astype(F)
+
+
+def np_anchor_generator_grid(strides, ratios, scales, featmap_sizes):
+    """AnchorGenerator (models/boxes/anchor_generator.py:94-407): base anchors (:232-272: scale_major, centre offset 0,
+    base size = stride) + grid (:386-407: x fastest, the A base anchors of a cell adjacent) -> list of (H*W*A, 4)."""
+    out = []
+    r, s = np.asarray(ratios, F), np.asarray(scales, F)
+    for st, (fh, fw) in zip(strides, featmap_sizes):
+        hr = np.sqrt(r).astype(F)
+        wr = (F(1) / hr).astype(F)
+        ws = (F(st) * wr[:, None] * s[None, :]).reshape(-1)
+        hs = (F(st) * hr[:, None] * s[None, :]).reshape(-1)
+        base = np.stack([-F(0.5) * ws, -F(0.5) * hs, F(0.5) * ws, F(0.5) * hs], -1).astype(F)
+        sx, sy = np.arange(fw, dtype=F) * st, np.arange(fh, dtype=F) * st
+        xx, yy = np.tile(sx, fh), np.repeat(sy, fw)
+        shifts = np.stack([xx, yy, xx, yy], -1)
+        out.append((base[None] + shifts[:, None]).reshape(-1, 4).astype(F))
+    return out
+
+
+def np_anchor_valid_flags(strides, featmap_sizes, pad_shape, num_base):
+    """:425-470: cells whose origin lies inside the padded image, repeated for the A base anchors."""
+    out = []
+    for st, (fh, fw) in zip(strides, featmap_sizes):
+        vh, vw = min(int(np.ceil(pad_shape[0] / st)), fh), min(int(np.ceil(pad_shape[1] / st)), fw)
+        vx, vy = np.arange(fw) < vw, np.arange(fh) < vh
+        out.append(np.repeat(np.tile(vx, fh) & np.repeat(vy, fw), num_base))
+    return out
+
+
+def np_anchor_inside_flags(flat_anchors, valid, img_shape, allowed_border=0):
+    """models/boxes/anchor_target.py:184-195 (img_shape[:2] read as (h, w))."""
+    h, w = img_shape[:2]
+    if allowed_border < 0:
+        return valid
+    a = flat_anchors
+    return valid & (a[:, 0] >= -allowed_border) & (a[:, 1] >= -allowed_border) & \
+        (a[:, 2] < w + allowed_border) & (a[:, 3] < h + allowed_border)
+
+
+def np_random_sample(gt_inds, num, pos_fraction, neg_pos_ub, choice):
+    """BaseSampler.sample + RandomSampler._sample_pos/_neg (models/boxes/sampler.py:57-111,156-176) on the (already
+    gt-extended) gt_inds.  ``choice(gallery, n)`` stands in for ``gallery[jt.randperm(len)[:n]]`` (:139-149): the test
+    feeds the SAME fixed choice to both sides.  `.unique()` (:94,107) sorts."""
+    pos = np.nonzero(gt_inds > 0)[0]
+    n_pos = int(num * pos_fraction)
+    if len(pos) > n_pos:
+        pos = choice(pos, n_pos)
+    pos = np.unique(pos)
+    n_neg = num - len(pos)
+    if neg_pos_ub >= 0:
+        n_neg = min(n_neg, int(neg_pos_ub * max(1, len(pos))))
+    neg = np.nonzero(gt_inds == 0)[0]
+    if len(neg) > n_neg:
+        neg = choice(neg, n_neg)
+    return pos, np.unique(neg)
+
+
+def np_bce_with_logits_sum(pred, target, weight):
+    """jt.nn.binary_cross_entropy_with_logits(size_average=False) as used by losses/cross_entropy_loss.py:24-32."""
+    x, t = pred.astype(np.float64), target.astype(np.float64)
+    return float(((np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))) * weight).sum())
+
+
+def np_cross_entropy_rows(pred, target):
+    """losses/cross_entropy_loss.py:57-66: logsumexp(pred - max) - (pred - max)[target] per row."""
+    x = pred.astype(np.float64)
+    x = x - x.max(1, keepdims=True)
+    return np.log(np.exp(x).sum(1)) - x[np.arange(len(x)), target]
+
+
+def np_smooth_l1_sum(pred, target, weight, beta):
+    """losses/smooth_l1_loss.py:5-16 before the reduction."""
+    d = np.abs(pred.astype(np.float64) - target.astype(np.float64))
+    loss = np.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta) if beta != 0 else d
+    return float((loss * weight).sum())
+
+
+# ---- OrientedRPNHead.loss ----------------------------------------------------------------------------------------
+def np_oriented_rpn_targets_single(flat_anchors, valid, gt_obb, img_size, cfg, choice):
+    """_get_targets_single (roi_heads/oriented_rpn_head.py:274-366) for one image.  ``gt_obb``: the target's rboxes
+    BEFORE the sign flip of :281-282 (done here).  -> labels, label_weights, bbox_targets, bbox_weights (all anchors),
+    pos_inds, neg_inds (indices into the INSIDE subset, as the reference returns them)."""
+    gt = gt_obb.astype(F).copy()
+    gt[:, -1] *= -1
+    inside = np_anchor_inside_flags(flat_anchors, valid, img_size, 0)              # :295
+    anchors = flat_anchors[inside]
+    tgt = np_obb2hbb(gt)                                                           # bbox2type(gt, 'hbb') :302
+    ov = np_bbox_overlaps_hbb(tgt, anchors)                                        # assigner.py:94, BboxOverlaps2D
+    a = cfg["assigner"]
+    gi, _, _ = oracle.c().assign_wrt_overlaps(ov, a["pos_iou_thr"], a["neg_iou_thr"], a["min_pos_iou"],
+                                              a.get("match_low_quality", True), True, None,
+                                              a.get("assigned_labels_filled", -1))
+    s = cfg["sampler"]
+    assert not s.get("add_gt_as_proposals", False)
+    pos, neg = np_random_sample(gi, s["num"], s["pos_fraction"], s.get("neg_pos_ub", -1), choice)   # :307
+    n = anchors.shape[0]
+    bt, bw = np.zeros((n, 6), F), np.zeros((n, 6), F)
+    lab, lw = np.full(n, cfg.get("background_label", 0), np.int64), np.zeros(n, F)
+    if len(pos):
+        pos_gt = gt[gi[pos] - 1]                                                   # :310-314: the OBB gts
+        c = cfg["bbox_coder"]
+        bt[pos] = np_midpoint_offset_encode(anchors[pos], pos_gt, c["target_means"], c["target_stds"])   # :327-329
+        bw[pos] = 1.0
+        lab[pos] = 1                                                               # :334-336
+        lw[pos] = 1.0 if cfg.get("pos_weight", -1) <= 0 else cfg["pos_weight"]
+    lw[neg] = 1.0
+
+    def unmap(d, fill=0):                                                          # :349-361
+        out = np.full((flat_anchors.shape[0],) + d.shape[1:], fill, d.dtype)
+        out[inside] = d
+        return out
+    return unmap(lab, cfg.get("background_label", 0)), unmap(lw), unmap(bt), unmap(bw), pos, neg
+
+
+def np_oriented_rpn_loss(cls_scores, bbox_preds, targets, cfg, choice):
+    """OrientedRPNHead.loss (:432-480) + get_targets (:368-398) + loss_single (:400-430) ->
+    dict(loss_rpn_cls=[per level], loss_rpn_bbox=[per level]).  cls_scores / bbox_preds: lists (levels) of
+    (B, A*1, H, W) / (B, A*6, H, W); targets: list of dict(rboxes, img_size, pad_shape)."""
+    ag = cfg["anchor_generator"]
+    sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+    mla = np_anchor_generator_grid(ag["strides"], ag["ratios"], ag["scales"], sizes)
+    nA = len(ag["ratios"]) * len(ag["scales"])
+    flat = np.concatenate(mla)
+    per = []
+    for t in targets:
+        valid = np.concatenate(np_anchor_valid_flags(ag["strides"], sizes, t["pad_shape"], nA))
+        per.append(np_oriented_rpn_targets_single(flat, valid, t["rboxes"], t["img_size"], cfg, choice))
+    num_total = sum(max(len(p[4]), 1) for p in per) + sum(max(len(p[5]), 1) for p in per)      # :386-387, :466
+    labels, lw = np.stack([p[0] for p in per]), np.stack([p[1] for p in per])
+    bt, bw = np.stack([p[2] for p in per]), np.stack([p[3] for p in per])
+    beta = cfg["loss_bbox"].get("beta", 1.0)
+    l_cls, l_box, s = [], [], 0
+    for lvl, a in enumerate(mla):
+        n = a.shape[0]
+        cs = np.transpose(cls_scores[lvl], (0, 2, 3, 1)).reshape(-1, 1)             # :424: cls_out_channels = 1
+        bp = np.transpose(bbox_preds[lvl], (0, 2, 3, 1)).reshape(-1, 6)
+        lb, w = labels[:, s:s + n].reshape(-1), lw[:, s:s + n].reshape(-1)
+        # _expand_binary_labels (cross_entropy_loss.py:15-23): column label-1 set where label >= 1
+        l_cls.append(cfg["loss_cls"].get("loss_weight", 1.0) *
+                     np_bce_with_logits_sum(cs, (lb >= 1).astype(F)[:, None], w[:, None]) / num_total)
+        l_box.append(cfg["loss_bbox"].get("loss_weight", 1.0) *
+                     np_smooth_l1_sum(bp, bt[:, s:s + n].reshape(-1, 6), bw[:, s:s + n].reshape(-1, 6), beta) / num_total)
+        s += n
+    return dict(loss_rpn_cls=l_cls, loss_rpn_bbox=l_box), per
+
+
+# ---- OrientedHead ------------------------------------------------------------------------------------------------
+def np_oriented_head_sample(proposals, gt_obb, gt_labels_1based, cfg, choice):
+    """OrientedHead.execute (roi_heads/oriented_head.py:539-588) for one image: sign flip of theta + 0-based labels
+    (:551-552,:564), MaxIoUAssigner over rotated IoU v1 (K x P), RandomSamplerRotated with the gts prepended
+    (sampler.py:204-232).  -> dict(pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, pos_inds, neg_inds)."""
+    gt = gt_obb.astype(F).copy()
+    gt[:, -1] *= -1
+    labels = gt_labels_1based.astype(np.int32) - 1
+    props = proposals.astype(F)
+    a = cfg["assigner"]
+    ov = oracle.c().box_iou_rotated(gt, np.ascontiguousarray(props[:, :5]), 1)
+    gi, _, lb = oracle.c().assign_wrt_overlaps(ov, a["pos_iou_thr"], a["neg_iou_thr"], a["min_pos_iou"],
+                                               a.get("match_low_quality", True), True, labels,
+                                               a.get("assigned_labels_filled", -1))
+    s = cfg["sampler"]
+    boxes = props[:, :5]
+    if s.get("add_gt_as_proposals", True):                                         # sampler.py:214-218 + add_gt_
+        boxes = np.concatenate([gt, boxes])
+        gi = np.concatenate([np.arange(1, len(gt) + 1, dtype=gi.dtype), gi])
+        lb = np.concatenate([labels, lb])
+    pos, neg = np_random_sample(gi, s["num"], s["pos_fraction"], s.get("neg_pos_ub", -1), choice)
+    return dict(pos_bboxes=boxes[pos], neg_bboxes=boxes[neg], pos_gt_bboxes=gt[gi[pos] - 1], pos_gt_labels=lb[pos],
+                pos_inds=pos, neg_inds=neg)
+
+
+def np_oriented_head_targets(samples, cfg, num_classes):
+    """get_bboxes_targets / get_bboxes_target_single (:426-496), reg_decoded_bbox False, concat=True."""
+    c = cfg["bbox_coder"]
+    labs, lws, bts, bws = [], [], [], []
+    for s in samples:
+        npos, nneg = len(s["pos_bboxes"]), len(s["neg_bboxes"])
+        n = npos + nneg
+        lab, lw = np.full(n, num_classes, np.int64), np.zeros(n, F)
+        bt, bw = np.zeros((n, 5), F), np.zeros((n, 5), F)
+        if npos:
+            lab[:npos] = s["pos_gt_labels"]
+            lw[:npos] = 1.0 if cfg.get("pos_weight", -1) <= 0 else cfg["pos_weight"]
+            bt[:npos] = np_oriented_delta_encode(s["pos_bboxes"], s["pos_gt_bboxes"], c["target_means"], c["target_stds"])
+            bw[:npos] = 1
+        if nneg:
+            lw[-nneg:] = 1.0
+        labs.append(lab), lws.append(lw), bts.append(bt), bws.append(bw)
+    return np.concatenate(labs), np.concatenate(lws), np.concatenate(bts), np.concatenate(bws)
+
+
+def np_oriented_head_rois(samples):
+    """arb2roi (:259-277) over [pos_bboxes ; neg_bboxes] of each image: (n, 6) = (batch index, obb)."""
+    return np.concatenate([np.concatenate([np.full((len(s["pos_bboxes"]) + len(s["neg_bboxes"]), 1), i, F),
+                                           np.concatenate([s["pos_bboxes"], s["neg_bboxes"]])], 1)
+                           for i, s in enumerate(samples)]).astype(F)
+
+
+def np_oriented_head_loss(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, cfg, num_classes):
+    """OrientedHead.loss (:354-424), class-agnostic regression, CrossEntropyLoss 'mean' with
+    avg_factor = #(label_weights > 0) (:358-365) and SmoothL1 over the positives / avg_factor = #samples (:412-417)."""
+    avg = max(float((label_weights > 0).sum()), 1.0)
+    lc = cfg["loss_cls"].get("loss_weight", 1.0) * float((np_cross_entropy_rows(cls_score, labels) * label_weights).sum()) / avg
+    pos = (labels >= 0) & (labels < num_classes)
+    if pos.any():
+        lb = cfg["loss_bbox"].get("loss_weight", 1.0) * np_smooth_l1_sum(
+            bbox_pred.reshape(len(bbox_pred), 5)[pos], bbox_targets[pos], bbox_weights[pos],
+            cfg["loss_bbox"].get("beta", 1.0)) / bbox_targets.shape[0]
+    else:
+        lb = 0.0
+    return dict(loss_cls=lc, orcnn_bbox_loss=lb)
+
+
+def np_oriented_head_get_bboxes(rois, cls_score, bbox_pred, scale_factor, cfg, num_classes):
+    """get_bboxes (:498-536) + get_results (:279-305): softmax, OrientedDeltaXYWHT decode (max_shape is accepted and
+    unused by the coder, coder.py:484-513), rescale of (x, y, w, h), score threshold over the foreground columns ->
+    (n, 9) polys + score in (roi, class) row-major order of the mask, labels (n,)."""
+    x = cls_score.astype(np.float64)
+    e = np.exp(x - x.max(1, keepdims=True))
+    scores = (e / e.sum(1, keepdims=True)).astype(F)
+    c = cfg["bbox_coder"]
+    boxes = np_oriented_delta_decode(rois[:, 1:], bbox_pred, c["target_means"], c["target_stds"])
+    sf = np.asarray([scale_factor] * 4 if isinstance(scale_factor, float) else scale_factor, F)
+    boxes = boxes.reshape(len(boxes), -1, 5)
+    boxes = np.concatenate([boxes[..., :4] / sf, boxes[..., 4:]], -1).reshape(len(boxes), -1)
+    b = np.broadcast_to(boxes[:, None], (len(boxes), num_classes, 5))
+    s = scores[:, :-1]
+    valid = s > cfg["score_thresh"]
+    return np.concatenate([np_obb2poly(b[valid]), s[valid][:, None]], 1).astype(F), np.nonzero(valid)[1]

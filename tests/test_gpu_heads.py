@@ -119,3 +119,133 @@ def test_oriented_rpn_get_bboxes_single_known_answer(cuda):
     assert got.shape == want.shape and got.shape[0] > 50 and got.shape[1] == 6
     np.testing.assert_allclose(got[:, 5], want[:, 5], rtol=1e-5, atol=1e-6)        # same proposals, same order
     np.testing.assert_allclose(got[:, :5], want[:, :5], rtol=1e-4, atol=5e-3)
+
+
+# ---- Oriented R-CNN heads: known answers with a FIXED sampling choice --------------------------------
+def _fixed_choice_np(gallery, num):
+    """stands in for gallery[randperm(len)[:num]] on both sides (jt.randperm is not reproducible across frameworks)"""
+    return gallery[np.random.default_rng(len(gallery) * 7919 + num).permutation(len(gallery))[:num]]
+
+
+@pytest.fixture
+def fixed_choice(monkeypatch):
+    from rs_detection_amd.models.boxes.sampler import RandomSampler
+
+    def choice(gallery, num):
+        idx = np.random.default_rng(gallery.numel() * 7919 + num).permutation(gallery.numel())[:num]
+        return gallery[torch.from_numpy(idx).to(gallery.device)]
+    monkeypatch.setattr(RandomSampler, "random_choice", staticmethod(choice))
+    return _fixed_choice_np
+
+
+def _orcnn_cfg():
+    from rs_detection_amd.config import Config
+    return Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")).dump()["model"]
+
+
+def test_oriented_rpn_loss_known_answer(cuda, fixed_choice):
+    """OrientedRPNHead.loss (oriented_rpn_head.py:274-480): 2 x 5 per-level scalars + the per-image target maps
+    against oracle/heads.np_oriented_rpn_loss on seeded maps, the reference's own config for the head."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.utils.registry import HEADS, build_from_cfg
+    cfg = _orcnn_cfg()["rpn"]
+    torch.manual_seed(0)
+    rpn = build_from_cfg(cfg, HEADS).to(cuda).train()
+    rng = np.random.default_rng(21)
+    size, strides, B = 256, [4, 8, 16, 32, 64], 2
+    sizes = [(size // s, size // s) for s in strides]
+    cls = [rng.normal(-1, 1.5, (B, 7, h, w)).astype(np.float32) for h, w in sizes]
+    reg = [rng.normal(0, 0.3, (B, 42, h, w)).astype(np.float32) for h, w in sizes]
+    targets = []
+    for k in (9, 25):
+        rb = dota_boxes(rng, k, float(size), 12, 120, 60)
+        rb[:, :2] = np.clip(rb[:, :2], 40, size - 40)
+        targets.append(dict(rboxes=rb, rboxes_ignore=None, img_size=(size, size), pad_shape=(size, size)))
+    t = lambda xs: [torch.from_numpy(x).to(cuda) for x in xs]
+    tt = [dict(x, rboxes=torch.from_numpy(x["rboxes"]).to(cuda)) for x in targets]
+    got = rpn.loss(t(cls), t(reg), tt)
+    want, per = H.np_oriented_rpn_loss(cls, reg, targets, cfg, fixed_choice)
+    assert sum(len(p[4]) for p in per) > 20 and all(len(p[5]) > 100 for p in per)       # the sampler had to choose
+    for k in ("loss_rpn_cls", "loss_rpn_bbox"):
+        assert len(got[k]) == len(want[k]) == 5
+        for lvl in range(5):
+            g, w = float(got[k][lvl]), float(want[k][lvl])
+            assert abs(g - w) <= 2e-4 * max(abs(w), 1e-3) + 1e-6, (k, lvl, g, w)
+    assert sum(want["loss_rpn_bbox"]) > 0
+    # the target maps themselves, image by image (labels, weights, encoded targets)
+    mla = rpn.anchor_generator.grid_anchors(sizes, device=cuda)
+    for i, tg in enumerate(tt):
+        vf = rpn.anchor_generator.valid_flags(sizes, tg["pad_shape"], device=cuda)
+        lab, lw, bt, bw, pos, neg, _ = rpn._get_targets_single(mla, vf, tg)
+        assert (lab.cpu().numpy() == per[i][0]).all() and (lw.cpu().numpy() == per[i][1]).all()
+        assert (bw.cpu().numpy() == per[i][3]).all()
+        np.testing.assert_allclose(bt.cpu().numpy(), per[i][2], rtol=1e-4, atol=1e-4)
+        assert (pos.cpu().numpy() == per[i][4]).all() and (neg.cpu().numpy() == per[i][5]).all()
+
+
+def test_oriented_head_known_answers(cuda, fixed_choice):
+    """OrientedHead: assign + sample (oriented_head.py:566-588), get_bboxes_targets (:426-496), loss (:354-424) and
+    get_bboxes (:498-536, :279-305) against oracle/heads.py on seeded proposals / predictions."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.utils.registry import HEADS, build_from_cfg
+    cfg = _orcnn_cfg()["bbox_head"]
+    torch.manual_seed(0)
+    head = build_from_cfg(cfg, HEADS).to(cuda).train()
+    rng = np.random.default_rng(33)
+    size, ks, P = 512, (6, 40), 900
+    gts, labs, props = [], [], []
+    for k in ks:
+        g = dota_boxes(rng, k, float(size), 16, 140, 60)
+        g[:, 4] = rng.uniform(-np.pi / 2, np.pi / 2, k)
+        near = g[rng.integers(0, k, P // 2)].copy()                    # jittered copies of the gts (theta sign as the
+        near[:, 4] *= -1                                               # head sees them) + background boxes
+        near[:, :2] += rng.normal(0, 4, (P // 2, 2))
+        near[:, 2:4] *= np.exp(rng.normal(0, 0.15, (P // 2, 2)))
+        near[:, 4] += rng.normal(0, 0.08, P // 2)
+        far = dota_boxes(rng, P - P // 2, float(size), 16, 140, 60)
+        p = np.concatenate([near, far]).astype(np.float32)
+        p = np.concatenate([p, rng.uniform(0, 1, (P, 1)).astype(np.float32)], 1)[rng.permutation(P)]
+        gts.append(g.astype(np.float32)), labs.append(rng.integers(1, 11, k).astype(np.int64)), props.append(p)
+    samples, results = [], []
+    for i in range(len(ks)):
+        obb = torch.from_numpy(gts[i]).to(cuda).clone()
+        obb[:, -1] *= -1
+        lab0 = torch.from_numpy(labs[i]).to(cuda) - 1
+        pr = torch.from_numpy(props[i]).to(cuda)
+        ar = head.assigner.assign(pr, obb, None, lab0)
+        res = head.sampler.sample(ar, pr, obb, lab0)
+        want = H.np_oriented_head_sample(props[i], gts[i], labs[i], cfg, fixed_choice)
+        assert (res.pos_inds.cpu().numpy() == want["pos_inds"]).all() and len(want["pos_inds"]) >= min(ks[i], 128)
+        assert (res.neg_inds.cpu().numpy() == want["neg_inds"]).all()
+        assert len(want["pos_inds"]) + len(want["neg_inds"]) == 512
+        np.testing.assert_array_equal(res.pos_bboxes.cpu().numpy(), want["pos_bboxes"])
+        np.testing.assert_array_equal(res.pos_gt_bboxes.cpu().numpy(), want["pos_gt_bboxes"])
+        assert (res.pos_gt_labels.cpu().numpy() == want["pos_gt_labels"]).all()
+        samples.append(want), results.append(res)
+    assert len(samples[1]["pos_inds"]) == 128                          # the positive cap was hit: the choice mattered
+    labels, lw, bt, _, bw = head.get_bboxes_targets(results)
+    wl, wlw, wbt, wbw = H.np_oriented_head_targets(samples, cfg, 10)
+    assert (labels.cpu().numpy() == wl).all() and (lw.cpu().numpy() == wlw).all() and (bw.cpu().numpy() == wbw).all()
+    np.testing.assert_allclose(bt.cpu().numpy(), wbt, rtol=1e-4, atol=2e-4)
+    rois = head.arb2roi([r.bboxes for r in results], bbox_type='obb')
+    wr = H.np_oriented_head_rois(samples)
+    np.testing.assert_array_equal(rois.cpu().numpy(), wr)
+    n = len(wr)
+    cls = rng.normal(0, 1.5, (n, 11)).astype(np.float32)
+    reg = rng.normal(0, 0.5, (n, 5)).astype(np.float32)
+    got = head.loss(torch.from_numpy(cls).to(cuda), torch.from_numpy(reg).to(cuda), rois, labels, lw, bt, None, bw)
+    want = H.np_oriented_head_loss(cls, reg, wl, wlw, wbt, wbw, cfg, 10)
+    for k in ("loss_cls", "orcnn_bbox_loss"):
+        g, w = float(got[k]), want[k]
+        assert w > 0 and abs(g - w) <= 2e-4 * abs(w) + 1e-6, (k, g, w)
+    # test-time branch
+    head.eval()
+    r1 = wr[wr[:, 0] == 1]
+    r1[:, 0] = 0
+    sl = slice(len(wr) - len(r1), len(wr))
+    det, dl = head.get_bboxes(torch.from_numpy(r1).to(cuda), torch.from_numpy(cls[sl]).to(cuda),
+                              torch.from_numpy(reg[sl]).to(cuda), (size, size), 2.0, rescale=True)
+    wd, wdl = H.np_oriented_head_get_bboxes(r1, cls[sl], reg[sl], 2.0, cfg, 10)
+    assert det.shape == wd.shape and det.shape[0] > 500 and (dl.cpu().numpy() == wdl).all()
+    np.testing.assert_allclose(det[:, 8].cpu().numpy(), wd[:, 8], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(det[:, :8].cpu().numpy(), wd[:, :8], rtol=1e-4, atol=5e-3)

@@ -103,3 +103,59 @@ def test_multiclass_nms_glue_known_answer():
     assert list(l) == [0, 2, 1] and np.allclose(d[:, 5], [0.9, 0.8, 0.7])
     d, l = H.np_multiclass_nms_rotated(boxes, scores, 0.95, 0.1, 100)
     assert d.shape == (0, 6) and l.shape == (0,)
+
+
+def test_anchor_generator_and_hbb_overlaps_match_the_transcriptions():
+    """AnchorGenerator grid / valid flags / inside flags and BboxOverlaps2D (pure torch in the product) against the
+    NumPy restatements of models/boxes/anchor_generator.py:94-470, anchor_target.py:184-195, iou_calculator.py:164-270."""
+    from rs_detection_amd.models.boxes.anchor_generator import AnchorGenerator
+    from rs_detection_amd.models.boxes.anchor_target import anchor_inside_flags
+    from rs_detection_amd.models.boxes.iou_calculator import bbox_overlaps
+    from rs_detection_amd.ops.bbox_transforms import hbb2obb
+    strides, ratios, scales = [4, 8, 16, 32, 64], [0.125, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0], [8]
+    sizes = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+    ag = AnchorGenerator(strides=strides, ratios=ratios, scales=scales)
+    got = ag.grid_anchors(sizes)
+    want = H.np_anchor_generator_grid(strides, ratios, scales, sizes)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g.numpy(), w, rtol=1e-6, atol=1e-4)
+    # the doc example of the reference (anchor_generator.py:122-128): stride 16, ratio 1, scale 1, base size 9 is not
+    # reachable through np_anchor_generator_grid (base = stride); check the stride-16 / scale-1 analogue by hand
+    a = H.np_anchor_generator_grid([16], [1.0], [1.0], [(2, 2)])[0]
+    np.testing.assert_allclose(a, [[-8, -8, 8, 8], [8, -8, 24, 8], [-8, 8, 8, 24], [8, 8, 24, 24]])
+    pad = (90, 100)
+    vf = ag.valid_flags(sizes, pad)
+    wf = H.np_anchor_valid_flags(strides, sizes, pad, 7)
+    for g, w in zip(vf, wf):
+        assert (g.numpy() == w).all()
+    assert 0 < wf[0].sum() < wf[0].size
+    flat, valid = torch.cat(got), torch.cat(vf)
+    ins = anchor_inside_flags(flat, valid, (96, 128), allowed_border=0).numpy()
+    assert (ins == H.np_anchor_inside_flags(flat.numpy(), valid.numpy(), (96, 128), 0)).all() and 0 < ins.sum() < ins.size
+    rng = np.random.default_rng(3)
+    c, wh = rng.uniform(0, 100, (40, 2)), rng.uniform(2, 40, (40, 2))
+    b1 = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    b2 = flat.numpy()[::37]
+    np.testing.assert_allclose(bbox_overlaps(torch.from_numpy(b1), torch.from_numpy(b2)).numpy(),
+                               H.np_bbox_overlaps_hbb(b1, b2), rtol=1e-6, atol=1e-7)
+    # known answers of the reference's docstring (iou_calculator.py:188-199)
+    d1 = np.array([[0, 0, 10, 10], [10, 10, 20, 20], [32, 32, 38, 42]], np.float32)
+    d2 = np.array([[0, 0, 10, 20], [0, 10, 10, 19], [10, 10, 20, 20]], np.float32)
+    np.testing.assert_allclose(H.np_bbox_overlaps_hbb(d1, d2), [[0.5, 0, 0], [0, 0, 1], [0, 0, 0]], atol=1e-6)
+    np.testing.assert_allclose(hbb2obb(torch.from_numpy(b1)).numpy(), H.np_hbb2obb(b1), atol=1e-5)
+
+
+def test_random_sample_restatement_on_a_fixed_choice():
+    """sampler.py:57-111 with a fixed choice: counts, disjointness, the neg_pos_ub bound, sortedness (`unique`)."""
+    rng = np.random.default_rng(4)
+    gi = rng.choice([-1, 0, 0, 0, 1, 2, 3], 5000).astype(np.int32)
+    first = lambda g, n: g[:n]
+    pos, neg = H.np_random_sample(gi, 256, 0.5, -1, first)
+    assert len(pos) == 128 and len(neg) == 128 and (gi[pos] > 0).all() and (gi[neg] == 0).all()
+    assert (np.diff(pos) > 0).all() and (np.diff(neg) > 0).all()
+    few = np.zeros(1000, np.int32)
+    few[[5, 50]] = 1
+    pos, neg = H.np_random_sample(few, 256, 0.5, -1, first)
+    assert list(pos) == [5, 50] and len(neg) == 254
+    pos, neg = H.np_random_sample(few, 256, 0.5, 3, first)
+    assert len(neg) == 6
