@@ -105,6 +105,7 @@ def event_time(fn, iters, warmup=3, graph=True):
 ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r03_roofline.json")
 if not os.path.exists(ROOFLINE_FILE):
     ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r02_roofline.json")
+FAST_ROW = "box_iou_rotated_fast(two-tier clipper, 1 launch; prepared anchors cached, gts prepared in the tile)"
 AT_ROW = "anchor_target_rotated(fused: IoU + assign + encode + weights; 2 launches)"
 BN_ROW = "bn_act_forward_kernel<f32>(bn + residual + relu; 4x256x256x256, layer1 of the step)"
 
@@ -158,6 +159,13 @@ def kernel_rooflines(device, targets):
     out["box_iou_rotated_tiled(1 launch; prepared anchors cached)"] = dict(
         bound="hbm", achieved=by / t1 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t1 / 1e9 / HBM_PEAK_GBS,
         traffic=pmc_traffic("box_iou_rotated_tiled (1 launch)", (n1, A) == (556, 21824)), us=t1 * 1e6)
+    # -- the same matrix with the two-tier clipper (csrc/iou_fast.hip): Green integral on every overlapping pair, the
+    #    reference-order clipper only where the reference itself is fragile / for exact zeros; |value - exact| < 3e-6
+    t3 = event_time(lambda: ops.box_iou_rotated_fast(gt, anchors, ro, ks=ks, out=ov, prepared=prep), 50)
+    out[FAST_ROW] = dict(
+        bound="hbm", achieved=by / t3 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t3 / 1e9 / HBM_PEAK_GBS,
+        traffic=pmc_traffic("box_iou_rotated_fast (1 launch)", (n1, A) == (556, 21824)), us=t3 * 1e6,
+        mpairs_per_s=n1 * A / t3 / 1e6)
     # -- what the train step runs since round 2: fused sparse anchor targets (IoU of the overlapping pairs only ->
     #    assignment -> encode -> weights / counts, no matrix): bytes = boxes in + 56 B of targets per anchor out
     t2 = event_time(lambda: ops.anchor_target_rotated(anchors, gt, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep,
@@ -571,9 +579,15 @@ def main():
             "us_per_launch": roof["us"], "shape": dense["shape"] if dense else None}) if roof else None,
         # the standalone north-star kernel (dense K x A rotated IoU, the matrix written to HBM), not on the step's path
         "roofline_dense_iou": ({k: dense[k] for k in keys} | {
-            "kernel": "rsdet_box_iou_rotated_grouped_f32 (dense K x A matrix; standalone metric, not in the timed step)",
+            "kernel": "rsdet_box_iou_rotated_grouped_f32 (dense K x A matrix, bit-exact reference-order clipper on "
+                      "every overlapping pair; standalone metric, not in the timed step)",
             "us_per_launch": dense["us"], "shape": dense["shape"], "valu_frac": dense["valu_frac"],
             "alg_gflop": dense["alg_gflop"], "overlapping_pairs": dense["overlapping_pairs"]}) if dense else None,
+        "roofline_dense_iou_two_tier": ({k: kernels[FAST_ROW][k] for k in keys} | {
+            "kernel": "rsdet_box_iou_rotated_fast_f32 (the same matrix to |d| < 3e-6 of the reference: Green integral + "
+                      "reference-order clipper where the reference is fragile; standalone metric)",
+            "us_per_launch": kernels[FAST_ROW]["us"], "mpairs_per_s": kernels[FAST_ROW]["mpairs_per_s"]})
+        if FAST_ROW in kernels else None,
         # the hand-written kernel with the most time in the timed step (4.3 of 6.3 ms of hand-written kernels)
         "roofline_dominant_handwritten": ({k: kernels[BN_ROW][k] for k in keys} | {
             "kernel": BN_ROW, "us_per_launch": kernels[BN_ROW]["us"]}) if BN_ROW in kernels else None,

@@ -106,6 +106,22 @@ int rsdet_box_iou_rotated_split_f32(const float* boxes1, int n1, int stride1, co
                                     int heavy_from_col, int version, float* ious, void* state, size_t state_bytes,
                                     void* ws, size_t ws_bytes, void* stream);
 
+/* Dense IoU matrix in ONE launch with a TWO-TIER clipper (csrc/iou_fast.hip): values within the north star's
+ * tolerance of the reference (|IoU - reference| <= 1e-4 asked, < 3e-6 measured), not bit-identical to it.
+ * Tier 1 (every overlapping pair): intersection area by Green's theorem, one lane per pair, registers only.
+ * Tier 2 (the reference-order clipper of rsdet_box_iou_rotated_f32): pairs in which a corner of one box lies within
+ * 0.01 px of an edge of the other -- where the REFERENCE itself leaves the true area (its hull scan reads dist[] with
+ * pre-sort indices, box_iou_rotated.py:199-212) -- pairs with IoU < 3e-5 (exact zeros are kept) and NaN boxes.
+ * Replaces ops/box_iou_rotated.py:502-509 / box_iou_rotated_v1.py:507-524 for callers that need the VALUES only;
+ * callers that derive indices from thresholds or ties (MaxIoUAssigner) keep the bit-exact entries above or use
+ * rsdet_anchor_target_rotated_f32.  Arguments as rsdet_box_iou_rotated_tiled_f32, except that row tiles hold
+ * rsdet_box_iou_rotated_fast_rows_per_tile() (= 32) rows (heavy column tiles: four 8-row sub-tiles). */
+int rsdet_box_iou_rotated_fast_rows_per_tile(void);
+int rsdet_box_iou_rotated_fast_f32(const float* boxes1, int n1, int stride1, const int* row_offsets, int n_groups,
+                                   int max_rows_per_group, const int* tile_table, int n_row_tiles,
+                                   const void* prepared1, const void* prepared2, int n2, int per_group,
+                                   int heavy_from_col, int version, float* ious, void* stream);
+
 /* anchor_target for a whole batch WITHOUT the (K, A) matrix: rotated IoU of the surviving pairs only
  * (1.2 % at S2ANet shapes) -> MaxIoUAssigner (column max / first argmax, thresholds, low-quality
  * rule with gt_max_assign_all = True: the LAST gt whose IoU equals its row maximum; a gt that

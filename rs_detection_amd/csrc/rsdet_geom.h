@@ -28,7 +28,7 @@ struct BoxPre {
   float lu, lv;      // |half-width vector|, |half-height vector| (early-out only)
 };                   // 40 B
 
-__device__ __forceinline__ BoxPre prepare_box(const float* __restrict__ b) {
+__host__ __device__ __forceinline__ BoxPre prepare_box(const float* __restrict__ b) {
   BoxPre p;
   float w = b[2], h = b[3];
   double theta = (double)b[4];
@@ -53,7 +53,7 @@ __device__ __forceinline__ BoxPre prepare_box(const float* __restrict__ b) {
 
 // true  => the exact algorithm is guaranteed to find no intersection point and no
 //          contained corner, i.e. the reference returns exactly 0.0f.
-__device__ __forceinline__ bool surely_disjoint(const BoxPre& a, const BoxPre& b) {
+__host__ __device__ __forceinline__ bool surely_disjoint(const BoxPre& a, const BoxPre& b) {
   float dx = a.cx - b.cx, dy = a.cy - b.cy;
   float r = a.rad + b.rad;
   // NaN/Inf inputs fail this test and take the exact path, like the reference.
@@ -67,7 +67,7 @@ __device__ __forceinline__ bool surely_disjoint(const BoxPre& a, const BoxPre& b
 // margin, so the reference's clipper finds nothing and returns exactly 0.0f (barring
 // its own collinear-edge round-off artefacts of order 1e-10).
 template <int VERSION>
-__device__ __forceinline__ bool sat_disjoint(const BoxPre& a, const BoxPre& b) {
+__host__ __device__ __forceinline__ bool sat_disjoint(const BoxPre& a, const BoxPre& b) {
   const float sg = VERSION == 0 ? 1.f : -1.f;
   const float dx = b.cx - a.cx, dy = b.cy - a.cy;
   const float aux = a.cw, auy = sg * a.sw, avx = -sg * a.sh, avy = a.ch;
@@ -130,10 +130,10 @@ struct Scratch {
 //   (double)x <  1e-14  <=>  x <= 0x283424dc (9.99999982e-15)
 //   (double)x >  1e-14  <=>  x >= 0x283424dd (1.00000007e-14)
 // (NaN fails both forms alike.)
-__device__ __forceinline__ bool lt_1e6(float x) { return x <= __uint_as_float(0x358637bdu); }
-__device__ __forceinline__ bool gt_1e8(float x) { return x >= __uint_as_float(0x322bcc78u); }
-__device__ __forceinline__ bool lt_1e14(float x) { return x <= __uint_as_float(0x283424dcu); }
-__device__ __forceinline__ bool gt_1e14(float x) { return x >= __uint_as_float(0x283424ddu); }
+__host__ __device__ __forceinline__ bool lt_1e6(float x) { return x <= __builtin_bit_cast(float, 0x358637bdu); }
+__host__ __device__ __forceinline__ bool gt_1e8(float x) { return x >= __builtin_bit_cast(float, 0x322bcc78u); }
+__host__ __device__ __forceinline__ bool lt_1e14(float x) { return x <= __builtin_bit_cast(float, 0x283424dcu); }
+__host__ __device__ __forceinline__ bool gt_1e14(float x) { return x >= __builtin_bit_cast(float, 0x283424ddu); }
 
 // hull-sort predicate of the reference CPU path (box_iou_rotated.py:317-325)
 __device__ __forceinline__ bool hull_less(F2 A, F2 B) {

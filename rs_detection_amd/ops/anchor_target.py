@@ -15,7 +15,7 @@ import torch
 
 from .. import _lib
 
-__all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "anchor_target_rotated"]
+__all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "box_iou_rotated_fast", "anchor_target_rotated"]
 
 _TI = 16  # rows per tile (csrc/anchor_target.hip T_TI)
 _prepared_cache = {}
@@ -78,16 +78,16 @@ def prepare_boxes(boxes, cache=False, heavy_from=None):
     return prep
 
 
-def row_tile_table(ks, device):
+def row_tile_table(ks, device, rows_per_tile=_TI):
     """Host-known gt counts per image -> (tile table (T,4) int32 on ``device``, group_tile0 (G+1) int32, T)."""
-    key = (tuple(int(k) for k in ks), str(device))
+    key = (tuple(int(k) for k in ks), str(device), int(rows_per_tile))
     hit = _tile_cache.get(key)
     if hit is not None:
         return hit
     rows, tile0, r0 = [], [0], 0
     for g, k in enumerate(key[0]):
-        for y in range(0, k, _TI):
-            rows.append((g, r0 + y, min(_TI, k - y), r0))
+        for y in range(0, k, rows_per_tile):
+            rows.append((g, r0 + y, min(rows_per_tile, k - y), r0))
         tile0.append(len(rows))
         r0 += k
     n = len(rows)
@@ -105,6 +105,40 @@ def _zero_state(device, nbytes):
         cur = torch.zeros((max(nbytes, 4096) * 2,), dtype=torch.uint8, device=device)   # grow-only, zeroed once
         _state[device] = cur
     return cur
+
+
+def box_iou_rotated_fast(boxes1, boxes2, row_offsets=None, ks=None, max_rows=None, version=0, out=None,
+                         prepared=None, cache_prepared=False, prepared1=None):
+    """Dense (n1, A) IoU in ONE launch with the two-tier clipper of csrc/iou_fast.hip: every overlapping pair by the
+    Green integral (one lane per pair), the reference-order clipper only where the reference itself is fragile (a corner
+    within 0.01 px of an edge of the other box), for IoU < 3e-5 and for NaN boxes.  |value - reference| < 3e-6 measured
+    (1e-4 is the contract); NOT bit-identical to ``box_iou_rotated`` -- use it where the values are the result, keep
+    the exact ops (or ``anchor_target_rotated``) where indices are derived from thresholds or ties.  Arguments as
+    ``box_iou_rotated_tiled``."""
+    _lib.require_cuda_f32(boxes1, boxes2)
+    lib = _lib.load()
+    b1, b2 = boxes1.contiguous(), boxes2.contiguous()
+    n1, A = b1.shape[0], b2.shape[-2]
+    per_group = 1 if b2.dim() == 3 else 0
+    G = (row_offsets.numel() - 1) if row_offsets is not None else 1
+    ious = out if out is not None else torch.empty((n1, A), dtype=torch.float32, device=b1.device)
+    if n1 == 0 or A == 0:
+        return ious
+    prep = prepared if prepared is not None else prepare_boxes(b2, cache=cache_prepared)
+    assert prep.n_per_group == A and prep.groups == (G if per_group else 1)
+    if ks is not None:
+        table, _, nt = row_tile_table(ks, b1.device, lib.rsdet_box_iou_rotated_fast_rows_per_tile())
+        tptr, mr = _lib.ptr(table), max(ks)
+    else:
+        tptr, nt, mr = None, 0, int(max_rows if max_rows is not None else n1)
+    if prepared1 is not None:
+        assert prepared1.n_total == n1 and prepared1.groups == 1
+    rc = lib.rsdet_box_iou_rotated_fast_f32(_lib.ptr(b1), n1, b1.shape[-1], _lib.ptr(row_offsets), G, mr, tptr, nt,
+                                            _lib.ptr(prepared1.buf) if prepared1 is not None else None,
+                                            _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,
+                                            _lib.ptr(ious), _lib.stream_ptr())
+    _lib.check(rc, "rsdet_box_iou_rotated_fast_f32")
+    return ious
 
 
 _split_state = {}

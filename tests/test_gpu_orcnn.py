@@ -190,7 +190,9 @@ def test_config3_van_b3_1024_train_step_and_eval(cuda):
         seen["n_feats"] = len(args[0])
     h = model.bbox_head.bbox_roi_extractor.register_forward_pre_hook(grab)
     props = {}
-    hp = model.rpn.register_forward_hook(lambda m, a, out: props.setdefault("n", [len(p) for p in out[0]]))
+    def count(mod, args, out):
+        props["n"] = [len(p) for p in out[0]]        # (a hook that returns a value would replace the output)
+    hp = model.rpn.register_forward_hook(count)
     model.train()
     losses = model(images, [t])
     h.remove(), hp.remove()
