@@ -144,6 +144,14 @@ int rsdet_box_iou_rotated_fast_f32(const float* boxes1, int n1, int stride1, con
  * Outputs, each optional (NULL): gt_inds / max_overlaps / labels / label_weights (n_groups, n2),
  * bbox_targets / bbox_weights (n_groups, n2, 5), totals[2] = { sum_g max(#pos_g, 1),
  * sum_g max(#neg_g, 1) } (anchor_target.py:79-80).
+ *   two_tier != 0 (round 3; opt-in, the Python op's default is 0): every overlapping pair gets the Green-integral IoU of
+ *          rsdet_geom_fast.h (one lane per pair; |error| < 3e-6 against the reference, budget 2e-5) and the
+ *          reference-order clipper runs only where a DECISION could depend on the difference: pairs in the
+ *          reference's fragile zone / IoU < 1e-6 / NaN, per gt the pairs within 4e-5 of its best value in a tile
+ *          (-> exact row maxima and exact `== row maximum` matches of the low-quality rule), per anchor the gts
+ *          within 4e-5 of its best value when there are several or when a threshold lies within 2e-5 of it.
+ *          gt_inds, labels, weights, targets and totals are those of two_tier == 0 bit for bit; max_overlaps is
+ *          the fast value (within the budget) wherever no decision needed the exact one.
  *   state: rsdet_anchor_target_rotated_state_bytes(n1, n2, n_groups) bytes that MUST be zero on entry;
  *          the call leaves them zero again (counters reset by its last workgroups), so one zeroed
  *          buffer serves every later call on the same stream.
@@ -155,7 +163,8 @@ int rsdet_anchor_target_rotated_f32(
     const float* gt_boxes, int n1, int stride1, const int* gt_labels, const int* row_offsets, int n_groups,
     int max_rows_per_group, const int* tile_table, int n_row_tiles, const int* group_tile0, const float* anchors,
     int n2, int stride2, int per_group, const void* prepared2, const void* prepared_gt, int heavy_from_col,
-    const unsigned char* valid, int version, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int match_low_quality,
+    const unsigned char* valid, int version, int two_tier, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi,
+    float min_pos_iou, int match_low_quality,
     int labels_filled, float pos_weight, int reg_decoded_bbox, const float* means_host, const float* stds_host,
     int* gt_inds, float* max_overlaps, int* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
     float* totals, void* state, size_t state_bytes, void* ws, size_t ws_bytes, void* stream);

@@ -41,6 +41,14 @@ def main():
             lambda: ops.box_iou_rotated_fast(gt, anchors, ro, ks=ks, out=ov), 50) * 1e6
         r["two-tier, no tile table, prepare every call"] = event_time(
             lambda: ops.box_iou_rotated_fast(gt, anchors, ro, max_rows=max(ks), out=ov), 50) * 1e6
+        lab = torch.cat([torch.from_numpy(t["labels"]) for t in tg]).to(dev).int()
+        for tt in (False, True):
+            tag = "two-tier" if tt else "exact"
+            r["fused anchor targets, %s (cached prepare; 2 launches)" % tag] = event_time(
+                lambda: ops.anchor_target_rotated(anchors, gt, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep, prepared_gt=pgt,
+                                                  two_tier=tt), 50) * 1e6
+            r["fused anchor targets, %s (anchors cached, gts prepared in the tiles)" % tag] = event_time(
+                lambda: ops.anchor_target_rotated(anchors, gt, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep, two_tier=tt), 50) * 1e6
         r["max |two-tier - exact|"] = float((ov - exact).abs().max())
         r["zeros agree"] = bool(((ov == 0) == (exact == 0)).all())
         r["memset of the matrix (torch.zero_)"] = event_time(lambda: ov.zero_(), 50) * 1e6

@@ -46,7 +46,7 @@ SIGNATURES = {
     "rsdet_anchor_target_rotated_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "rsdet_anchor_target_rotated_f32": (c_int, [
         c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
-        c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+        c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
         c_float, c_float, c_float, c_float, c_int, c_int, c_float, c_int,
         ctypes.POINTER(c_float), ctypes.POINTER(c_float),
         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

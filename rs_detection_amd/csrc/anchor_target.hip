@@ -34,7 +34,8 @@
 
 #include "rsdet_api_internal.h"
 #include "rsdet_coder.h"
-#include "rsdet_geom.h"
+#include "rsdet_geom_fast.h"
+#include "rsdet_tile.h"
 
 namespace rsdet {
 
@@ -698,6 +699,255 @@ __global__ __launch_bounds__(T_NT) void iou_tile_kernel(const TileArgs a) {
   }
 }
 
+// ---- sparse mode with the TWO-TIER clipper (round 3) -------------------------------------------------------------------
+// What the anchor targets need from the IoU values is decisions, not digits: per anchor the maximum over the gts against
+// two thresholds and its FIRST argmax, per gt the anchors whose IoU EQUALS its maximum.  So every surviving pair gets the
+// Green-integral IoU of rsdet_geom_fast.h (one lane per pair, ~350 instructions, |error| < 3e-6 against the reference,
+// budgeted kFastBudget = 2e-5), and the reference-order clipper (~3 200 lane-instructions per pair) runs only where a
+// decision could depend on the difference:
+//   here      (a) pairs the fast path flags itself: the reference's fragile zone, IoU < 1e-6, NaN;
+//             (b) per gt, the pairs within 2 x budget of the gt's best value inside this tile -- a superset of the pairs
+//                 that can equal the gt's exact maximum; their exact values give the exact row maximum (global atomic
+//                 max) and the `v == row maximum` entries of the low-quality rule (assigner.py:151-160);
+//   at_finish (c) per anchor, when more than one gt comes within 2 x budget of the anchor's best value, or that value is
+//                 within the budget of a threshold: those pairs only (kernel below).
+// EVERY surviving pair leaves an entry {row, column, value, exact?} for (c); the column accumulators take the best value
+// known here (exact where computed, fast otherwise).
+constexpr unsigned AT_EXACT = 0x80000000u;   // entry key flag: the value is the reference-order clipper's
+constexpr int T2_XCAP = 768;                 // pairs queued for the clipper per tile and phase (more: chunked)
+constexpr int T2_QUADS = 32;                 // quads that clip: waves 0 and 1
+#ifndef RSDET_T2_KEEP
+#define RSDET_T2_KEEP 4
+#endif
+constexpr int T2_KEEP = RSDET_T2_KEEP;                   // rounds of 256 survivors whose fast values wait in registers
+constexpr unsigned T2_NONE = 0xFFFFFFFFu, T2_PEND = 0x40000000u;
+
+#ifndef RSDET_T2_WAVES
+#define RSDET_T2_WAVES 8
+#endif
+template <int VERSION>
+__global__ __launch_bounds__(T_NT) void at_tile2_kernel(const TileArgs a) {
+  __shared__ BoxPre s_row[T_TI];
+  __shared__ __attribute__((aligned(16))) BoxPre s_col[T_NT];
+  __shared__ unsigned long long s_sm[T_WORDS];
+  __shared__ unsigned short s_send[T_WORDS];
+  __shared__ F2 s_pts[kQuadSlots * T2_QUADS];
+  __shared__ unsigned short s_x[T2_XCAP];
+  __shared__ float s_xv[T2_XCAP];          // the clipper's value of queue slot q
+  __shared__ unsigned char s_xk[T2_XCAP];  // ... and what to keep of it
+  __shared__ unsigned s_rapx[T_TI];   // best FAST value of the row inside the tile (float bits)
+  __shared__ unsigned s_rex[T_TI];    // best EXACT value of the row inside the tile
+  __shared__ unsigned s_nx, s_nent;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TTRACE(0);
+  const TileId t = decode_tile(a, blockIdx.x);
+  if (!t.heavy && tid >= 1 && tid < T_SUB) a.dir[t.slot + tid] = 0u;  // a whole tile uses sub-slice 0 only
+  if (t.nrows <= 0) {
+    if (tid == 0) a.dir[t.slot] = 0u;
+    return;
+  }
+  const int row0 = t.row0, nrows = t.nrows, g = t.g;
+  const long long slab = a.per_group ? (long long)g * ((a.n2 + 1) & ~1) : 0;
+  const int slab_word = a.per_group ? g * a.cw : 0;
+  const int col0 = t.xt * T_NT, col = col0 + tid;
+  bool col_ok = col < a.n2;
+  const int ncols = min(T_NT, a.n2 - col0);
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.pre2 + slab + col0);
+    float4* dst = reinterpret_cast<float4*>(s_col);
+    const int n16 = (ncols * (int)sizeof(BoxPre)) / 16;
+    for (int k = tid; k < n16; k += T_NT) dst[k] = src[k];
+    if ((ncols & 1) && tid == 0) {
+      const float2* s2 = reinterpret_cast<const float2*>(a.pre2 + slab + col0);
+      reinterpret_cast<float2*>(s_col)[n16 * 2] = s2[n16 * 2];
+    }
+  }
+  const int kw = (col0 >> 6) + wave;
+  float4 cb = a.colbox[slab_word + min(kw, a.cw - 1)];
+  if (kw >= a.cw) cb = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+  if (tid < nrows) {
+    const BoxPre r = a.pre1 ? a.pre1[row0 + tid] : prepare_box(a.boxes1 + (long long)(row0 + tid) * a.stride1);
+    s_row[tid] = r;
+    if (t.xt == 0) a.pre1_out[row0 + tid] = r;   // one column tile publishes the prepared gts for at_finish
+  }
+  if (tid < T_WORDS) s_sm[tid] = 0ull;
+  if (tid < T_TI) {
+    s_rapx[tid] = 0u;
+    s_rex[tid] = 0u;
+  }
+  if (tid == 0) {
+    s_nx = 0u;
+    s_nent = 0u;
+  }
+  if (a.valid && col_ok) col_ok = a.valid[(long long)g * a.n2 + col] != 0;
+  __syncthreads();
+  TTRACE(1);
+  const BoxPre mine = s_col[col_ok ? tid : 0];
+
+  // ---- detection in one pass: strip cull, then circles + separating axes for the live (row, strip) words
+  bool lv = false;
+  if (lane < nrows) {
+    const float rx = s_row[lane].cx, ry = s_row[lane].cy;
+    const float dx = fmaxf(fmaxf(cb.x - rx, rx - cb.z), 0.f), dy = fmaxf(fmaxf(cb.y - ry, ry - cb.w), 0.f);
+    const float thr = 1.001f * s_row[lane].rad + 1e-5f * (fabsf(rx) + fabsf(ry));
+    lv = !(dx * dx + dy * dy > thr * thr);
+  }
+  unsigned live = (unsigned)__ballot(lv);
+  while (live) {
+    const int i = __builtin_ctz(live);
+    live &= live - 1u;
+    bool surv = false;
+    if (col_ok) {
+      const BoxPre r = s_row[i];
+      const float dx = r.cx - mine.cx, dy = r.cy - mine.cy;
+      const float rr = r.rad + mine.rad;
+      if (!(dx * dx + dy * dy > rr * rr * 1.0001f)) surv = !sat_disjoint<VERSION>(r, mine);
+    }
+    const unsigned long long m = __ballot(surv);
+    if (m && lane == 0) s_sm[i * (T_NT / 64) + wave] = m;
+  }
+  __syncthreads();
+  scan_mask_words<T_WORDS>(s_sm, s_send, tid);
+  __syncthreads();
+  TTRACE(2);
+  const int total = s_send[T_WORDS - 1];
+  if (total == 0) {
+    if (tid == 0) a.dir[t.slot] = 0u;
+    return;
+  }
+  AtEntry* slice = a.list + t.slot * (T_TI / T_SUB * T_NT);
+  const long long gcol0 = (long long)g * a.n2 + col0;
+  const int growb = row0 - t.grow0;   // row inside its group of tile row 0
+
+  // Column accumulator update with the value known here; true when the pair is (so far) within 2 x budget of the
+  // column's best value -- only such pairs can be candidates for the column maximum in at_finish, the others leave no
+  // entry (the returned old value is a lower bound of the final maximum).
+  auto to_column = [&](int i, int j, float v) -> bool {
+    const unsigned long long old = atomicMax(a.colkey + gcol0 + j, at_pack(v, growb + i));
+    return old == ~0ull || v >= __uint_as_float((unsigned)(old >> 32)) - 2.f * kFastBudget;
+  };
+  auto put_entry = [&](int i, int j, float v, bool exact) {
+    AtEntry en;
+    en.key = ((unsigned)(growb + i) << 8) | (unsigned)j | (exact ? AT_EXACT : 0u);
+    en.v = v;
+    slice[atomicAdd(&s_nent, 1u)] = en;
+  };
+
+  // ---- T2_KEEP rounds of 256 survivors per trip (one trip unless the tile has > T2_KEEP * 256 of them)
+  float hv[T2_KEEP];
+  unsigned hk[T2_KEEP];   // (i << 8) | j; T2_NONE = nothing held; T2_PEND: waits for room in the clipper's queue
+  const int nround = (total + T_NT - 1) / T_NT;
+  for (int base = 0; base < nround; base += T2_KEEP) {
+    // -- A: tier 1 on every survivor.  Fast values stay in registers; what the fast path flags is queued
+#pragma unroll
+    for (int r = 0; r < T2_KEEP; ++r) {
+      hk[r] = T2_NONE;
+      hv[r] = 0.f;
+      const int k = (base + r) * T_NT + tid;
+      if (k < total) {
+        int word, bit;
+        locate_bit<T_WORDS>(s_sm, s_send, k, word, bit);
+        const int i = word >> 2, j = ((word & 3) << 6) | bit;
+        bool danger, apart;
+        const float v = pair_iou_fast<VERSION>(s_row[i], s_col[j], danger, apart);
+        if (!apart) {
+          const unsigned ij = (unsigned)((i << 8) | j);
+          if (danger || !(v >= kFastSliver)) {
+            const unsigned at = atomicAdd(&s_nx, 1u);
+            if (at < (unsigned)T2_XCAP) s_x[at] = (unsigned short)ij;
+            else hk[r] = T2_PEND | ij;
+          } else {
+            hv[r] = v;
+            hk[r] = ij;
+            atomicMax(&s_rapx[i], __float_as_uint(v));   // best FAST value of the row in this tile
+          }
+        }
+      }
+    }
+    __syncthreads();
+    TTRACE(3);
+    // -- B: a held fast value within 2 x budget of the row's best fast value may be the row's exact maximum: queued
+    // too (the flagged pairs are clipped anyway; every other pair that could equal the exact maximum is within the
+    // budget of its fast value, hence inside this window).  The rest is final: column accumulator, maybe an entry.
+#pragma unroll
+    for (int r = 0; r < T2_KEEP; ++r)
+      if (hk[r] != T2_NONE && !(hk[r] & T2_PEND)) {
+        const int i = (int)(hk[r] >> 8), j = (int)(hk[r] & 255u);
+        if (hv[r] >= __uint_as_float(s_rapx[i]) - 2.f * kFastBudget) {
+          const unsigned at = atomicAdd(&s_nx, 1u);
+          if (at < (unsigned)T2_XCAP) {
+            s_x[at] = (unsigned short)hk[r];
+            hk[r] = T2_NONE;
+          } else {
+            hk[r] |= T2_PEND;
+          }
+        } else {
+          if (to_column(i, j, hv[r])) put_entry(i, j, hv[r], false);
+          hk[r] = T2_NONE;
+        }
+      }
+    // -- C / D: the queue through the reference-order clipper, in chunks of T2_XCAP while something waits for room
+    for (;;) {
+      __syncthreads();
+      const int nq = min((int)s_nx, T2_XCAP);
+      const bool over = (int)s_nx > T2_XCAP;
+      if (wave < T2_QUADS / 16) {
+        F2* qscr = s_pts + (tid >> 2) * kQuadSlots;
+        for (int q0 = 0; q0 < nq; q0 += T2_QUADS) {
+          if (q0 + wave * 16 >= nq) break;               // wave-uniform: the clipper uses wave ballots only
+          const int q = q0 + (tid >> 2);
+          const bool on = q < nq;
+          const unsigned e = s_x[on ? q : q0];
+          const int i = (int)(e >> 8), j = (int)(e & 255u);
+          const float v = pair_iou_quad<VERSION>(s_row[i], s_col[j], qscr, lane);
+          if (on && (tid & 3) == 0) {
+            unsigned keep = 0u;   // bit 0: positive value, bit 1: candidate for its column's maximum
+            if (v > 0.f) {
+              atomicMax(&s_rex[i], __float_as_uint(v));
+              keep = 1u | (to_column(i, j, v) ? 2u : 0u);
+            } else if (v != v && growb + i == 0) {
+              atomicMax(a.colkey + gcol0 + j, ~0ull);   // a NaN in the image's first row sticks (assigner.py:133)
+            }
+            s_xv[q] = v;
+            s_xk[q] = (unsigned char)keep;
+          }
+          lds_wave_order();
+        }
+      }
+      __syncthreads();
+      // entries of the clipped pairs: column candidates, and the pairs that equal the row's exact maximum so far
+      // (low-quality rule, assigner.py:151-160; at_finish repeats the comparison against the global maximum)
+      for (int q = tid; q < nq; q += T_NT) {
+        const unsigned e = s_x[q];
+        const int i = (int)(e >> 8), j = (int)(e & 255u);
+        const float v = s_xv[q];
+        const unsigned keep = s_xk[q];
+        if ((keep & 1u) && ((keep & 2u) || __float_as_uint(v) == s_rex[i])) put_entry(i, j, v, true);
+      }
+      __syncthreads();
+      if (tid == 0) s_nx = 0u;
+      if (!over) break;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < T2_KEEP; ++r)
+        if (hk[r] != T2_NONE) {      // only T2_PEND items are still held here
+          const unsigned at = atomicAdd(&s_nx, 1u);
+          if (at < (unsigned)T2_XCAP) {
+            s_x[at] = (unsigned short)(hk[r] & 0xFFFFu);
+            hk[r] = T2_NONE;
+          }
+        }
+    }
+    __syncthreads();
+  }
+  TTRACE(4);
+  // ---- the exact row maxima of this tile, the entry count
+  if (tid < nrows && s_rex[tid] != 0u) atomicMax(a.rowmax + row0 + tid, s_rex[tid]);
+  if (tid == 0) a.dir[t.slot] = s_nent;
+  TTRACE(5);
+}
+
 // ---- at_finish: one workgroup per (column tile, image): low-quality rule + the targets ---------------------------
 struct FinishArgs {
   const float* boxes1;  // raw gts
@@ -726,10 +976,25 @@ struct FinishArgs {
   float* totals;        // [0] = sum_g max(#pos_g, 1), [1] = sum_g max(#neg_g, 1)
   unsigned* state;      // 64-bit words: [0] batch, [1 + g] image g = packed {pos, neg, arrivals}: zero on entry / exit
   unsigned* rowmax_rw;  // same array as rowmax: cleared by the last workgroup
+  // two-tier mode: the prepared boxes for the clipper on the undecided columns
+  const BoxPre* pre1;   // prepared gts (n1), written by at_tile2_kernel
+  const BoxPre* pre2;   // prepared anchors, slab g at g * pitch when per_group
 };
 
+// MODE 0: every entry is an exact value that equals its tile's row maximum (iou_tile_kernel<.., SPARSE>).
+// MODE 1 / 2 (two-tier, box convention 0 / 1): every surviving pair is an entry, exact or fast (AT_EXACT); the columns
+// whose decision could depend on the difference are settled here with the reference-order clipper.
+template <int MODE>
 __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
   constexpr int RM_CAP = 2048;  // row maxima of the image staged in LDS (larger images gather them from global)
+  constexpr int FX_CAP = MODE ? 1024 : 1;   // undecided pairs queued for the clipper (drained when nearly full)
+  __shared__ unsigned s_cmax[MODE ? T_NT : 1];              // the column's best value so far (float bits)
+  __shared__ unsigned s_ncont[MODE ? T_NT : 1];             // entries within 2 x budget of it | 0x10000 if a fast one is among them
+  __shared__ unsigned long long s_exkey[MODE ? T_NT : 1];   // exact accumulator of an undecided column
+  __shared__ unsigned char s_unc[MODE ? T_NT : 1];
+  __shared__ unsigned s_fx[FX_CAP];                         // (row in group << 8) | column in tile
+  __shared__ unsigned s_nfx;
+  __shared__ F2 s_pts[MODE ? kQuadSlots * 16 : 1];
   __shared__ int s_lowq[T_NT];
   __shared__ unsigned s_end[T_NT], s_wsum[T_NT / 64];
   __shared__ unsigned s_rm[RM_CAP];
@@ -762,25 +1027,26 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
   }
   __syncthreads();
   FTRACE(1);
-  if (K > 0 && a.match_low_quality) {
-    // gts that overlap nothing: their row maximum is 0 and every anchor "equals" it (assigner.py:155)
-    const bool zero_rows = 0.0f >= a.min_pos_iou;
-    for (int r = tid; r < K; r += T_NT) {
-      const unsigned rm = a.rowmax[r0 + r];
-      if (r < RM_CAP) s_rm[r] = rm;
-      if (zero_rows && rm == 0u) atomicMax(&s_zmax, r);
-    }
-    // The sub-slices {count} this column tile received from the image's row tiles: all counts are fetched at once
-    // (one per thread), scanned in LDS, and the entries walked as ONE flat range of independent loads.
-    const size_t slot0 = ((size_t)xt * a.n_row_tiles + t0) * T_SUB;
-    const int n_slots = (t1 - t0) * T_SUB;
+  if (MODE) {
+    s_cmax[tid] = (key_in != 0ull && key_in != ~0ull) ? (unsigned)(key_in >> 32) : 0u;
+    s_ncont[tid] = 0u;
+    s_exkey[tid] = 0ull;
+    s_unc[tid] = 0;
+    if (tid == 0) s_nfx = 0u;
+  }
+  // The sub-slices {count} this column tile received from the image's row tiles: all counts are fetched at once (one
+  // per thread), scanned in LDS, and the entries walked as ONE flat range of independent loads.  `visit(row, j, v,
+  // exact)` per entry; `after()` once per 256 entries, by every thread (it may hold barriers).
+  const size_t slot0 = ((size_t)xt * a.n_row_tiles + t0) * T_SUB;
+  const int n_slots = (t1 - t0) * T_SUB;
+  auto scan_entries = [&](auto visit, auto after) {
     for (int sb = 0; sb < n_slots; sb += T_NT) {
       const int ns = min(T_NT, n_slots - sb);
       unsigned inc = tid < ns ? a.dir[slot0 + sb + tid] : 0u;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
-        const unsigned o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
+        const unsigned o2 = __shfl_up(inc, off);
+        if (lane >= off) inc += o2;
       }
       if (lane == 63) s_wsum[tid >> 6] = inc;
       __syncthreads();
@@ -789,18 +1055,91 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
       s_end[tid] = inc + add;
       __syncthreads();
       const unsigned total = s_end[T_NT - 1];
-      for (unsigned e = tid; e < total; e += T_NT) {
-        int lo = 0;  // first sub-slice whose inclusive end exceeds e
+      for (unsigned e0 = 0; e0 < total; e0 += T_NT) {
+        const unsigned e = e0 + tid;
+        if (e < total) {
+          int lo = 0;  // first sub-slice whose inclusive end exceeds e
 #pragma unroll
-        for (int step = T_NT / 2; step > 0; step >>= 1)
-          if (s_end[lo + step - 1] <= e) lo += step;
-        const unsigned before = lo ? s_end[lo - 1] : 0u;
-        const AtEntry en = a.list[(slot0 + sb + lo) * (T_TI / T_SUB * T_NT) + (e - before)];
-        const int row = (int)(en.key >> 8), j = (int)(en.key & 255u);
-        const float rm = __uint_as_float(row < RM_CAP ? s_rm[row] : a.rowmax[r0 + row]);
-        if (rm >= a.min_pos_iou && en.v == rm) atomicMax(&s_lowq[j], row);
+          for (int step = T_NT / 2; step > 0; step >>= 1)
+            if (s_end[lo + step - 1] <= e) lo += step;
+          const unsigned before = lo ? s_end[lo - 1] : 0u;
+          const AtEntry en = a.list[(slot0 + sb + lo) * (T_TI / T_SUB * T_NT) + (e - before)];
+          visit((int)((en.key & ~AT_EXACT) >> 8), (int)(en.key & 255u), en.v, MODE == 0 || (en.key & AT_EXACT) != 0u);
+        }
+        after();
       }
       __syncthreads();
+    }
+  };
+  if (K > 0 && (a.match_low_quality || MODE)) {
+    // gts that overlap nothing: their row maximum is 0 and every anchor "equals" it (assigner.py:155)
+    const bool zero_rows = a.match_low_quality && 0.0f >= a.min_pos_iou;
+    for (int r = tid; r < K; r += T_NT) {
+      const unsigned rm = a.rowmax[r0 + r];
+      if (r < RM_CAP) s_rm[r] = rm;
+      if (zero_rows && rm == 0u) atomicMax(&s_zmax, r);
+    }
+    if (MODE) __syncthreads();   // s_cmax is read by other lanes below
+    scan_entries(
+        [&](int row, int j, float v, bool exact) {
+          if (a.match_low_quality && exact) {
+            const float rm = __uint_as_float(row < RM_CAP ? s_rm[row] : a.rowmax[r0 + row]);
+            if (rm >= a.min_pos_iou && v == rm) atomicMax(&s_lowq[j], row);
+          }
+          if (MODE && v >= __uint_as_float(s_cmax[j]) - 2.f * kFastBudget) atomicAdd(&s_ncont[j], exact ? 1u : 0x10001u);
+        },
+        [] {});
+  }
+  __syncthreads();
+  unsigned long long key_final = key_in;
+  if (MODE && K > 0) {
+    // ---- undecided columns: a fast value among the candidates for the column maximum and either a second candidate
+    // (maximum / first argmax open) or a threshold within the budget of the best value (side of the threshold open)
+    const unsigned nc = s_ncont[tid];
+    const float m = __uint_as_float(s_cmax[tid]);
+    const bool near_thr = fabsf(m - a.pos_thr) <= kFastBudget || fabsf(m - a.neg_hi) <= kFastBudget ||
+                          (a.neg_lo > 0.f && fabsf(m - a.neg_lo) <= kFastBudget);
+    const bool unc = col < a.n2 && valid_in && key_in != 0ull && key_in != ~0ull && (nc & 0xFFFF0000u) != 0u &&
+                     ((nc & 0xFFFFu) >= 2u || near_thr);
+    s_unc[tid] = unc ? 1 : 0;
+    if (__syncthreads_or(unc ? 1 : 0)) {
+      const BoxPre* p2 = a.pre2 + (a.per_group ? (long long)g * ((a.n2 + 1) & ~1) : 0) + (long long)xt * T_NT;
+      auto drain = [&]() {   // the queued pairs through the reference-order clipper (first wave, 16 quads)
+        const int n = (int)s_nfx;
+        if (tid < 64) {
+          F2* qscr = s_pts + (tid >> 2) * kQuadSlots;
+          for (int q0 = 0; q0 < n; q0 += 16) {
+            const int q = q0 + (tid >> 2);
+            const bool on = q < n;
+            const unsigned e = s_fx[on ? q : q0];
+            const int row = (int)(e >> 8), j = (int)(e & 255u);
+            const BoxPre ra = a.pre1[r0 + row], cbx = p2[j];
+            const float v = MODE == 1 ? pair_iou_quad<0>(ra, cbx, qscr, lane) : pair_iou_quad<1>(ra, cbx, qscr, lane);
+            if (on && (tid & 3) == 0) {
+              if (v > 0.f) atomicMax(&s_exkey[j], at_pack(v, row));
+              else if (v != v && row == 0) atomicMax(&s_exkey[j], ~0ull);
+            }
+            lds_wave_order();
+          }
+        }
+        __syncthreads();
+        if (tid == 0) s_nfx = 0u;
+        __syncthreads();
+      };
+      scan_entries(
+          [&](int row, int j, float v, bool exact) {
+            if (s_unc[j] && v >= __uint_as_float(s_cmax[j]) - 2.f * kFastBudget) {
+              if (exact) atomicMax(&s_exkey[j], at_pack(v, row));
+              else s_fx[atomicAdd(&s_nfx, 1u)] = ((unsigned)row << 8) | (unsigned)j;
+            }
+          },
+          [&] {
+            __syncthreads();
+            if ((int)s_nfx > FX_CAP - T_NT) drain();   // uniform: read after the barrier
+          });
+      __syncthreads();
+      if (s_nfx != 0u) drain();
+      if (unc) key_final = s_exkey[tid];
     }
   }
   __syncthreads();
@@ -816,8 +1155,8 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
       gi = -1;
       best = -1.f;
     } else {
-      const unsigned long long key = key_in;
-      if (key != 0ull) a.colkey[o] = 0ull;  // empty again for the next call
+      const unsigned long long key = key_final;
+      if (key_in != 0ull) a.colkey[o] = 0ull;  // empty again for the next call
       int arg = 0;
       best = 0.f;  // key 0: no positive entry -> the column holds zeros only: maximum 0 at the first row
       if (key != 0ull) {
@@ -1061,14 +1400,16 @@ extern "C" size_t rsdet_anchor_target_rotated_state_bytes(int n1, int n2, int n_
 extern "C" size_t rsdet_anchor_target_rotated_ws_size(int n2, int n_groups, int n_row_tiles) {
   if (n2 <= 0 || n_row_tiles <= 0 || n_groups <= 0) return 0;
   const size_t nx = (size_t)(n2 + T_NT - 1) / T_NT;
-  return up256(nx * (size_t)n_row_tiles * T_SUB * 4) + nx * (size_t)n_row_tiles * (T_TI * T_NT) * sizeof(AtEntry);
+  // directory | entry slices | prepared gts of the two-tier mode (at most T_TI rows per row tile)
+  return up256(nx * (size_t)n_row_tiles * T_SUB * 4) + up256(nx * (size_t)n_row_tiles * (T_TI * T_NT) * sizeof(AtEntry)) +
+         up256((size_t)n_row_tiles * T_TI * sizeof(BoxPre));
 }
 
 extern "C" int rsdet_anchor_target_rotated_f32(
     const float* gt_boxes, int n1, int stride1, const int* gt_labels, const int* row_offsets, int n_groups,
     int max_rows_per_group, const int* tile_table, int n_row_tiles, const int* group_tile0, const float* anchors,
     int n2, int stride2, int per_group, const void* prepared2, const void* prepared_gt, int heavy_from_col,
-    const unsigned char* valid, int version, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi,
+    const unsigned char* valid, int version, int two_tier, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi,
     float min_pos_iou, int match_low_quality, int labels_filled, float pos_weight, int reg_decoded_bbox,
     const float* means_host, const float* stds_host, int* gt_inds, float* max_overlaps, int* labels,
     float* label_weights, float* bbox_targets, float* bbox_weights, float* totals, void* state, size_t state_bytes,
@@ -1094,6 +1435,8 @@ extern "C" int rsdet_anchor_target_rotated_f32(
   unsigned long long* colkey = (unsigned long long*)((char*)rowmax + up256((size_t)(n1 > 0 ? n1 : 1) * 4));
   unsigned* dir = (unsigned*)ws;
   AtEntry* list = (AtEntry*)((char*)ws + up256((size_t)nx * nrt1 * T_SUB * 4));
+  BoxPre* pre1_out = (BoxPre*)((char*)list + up256((size_t)nx * nrt1 * (T_TI * T_NT) * sizeof(AtEntry)));
+  if (n1 > (long long)nrt1 * T_TI) return RSDET_EINVAL;   // the row tiles cover every gt
 
   if (n1 > 0 && nrt > 0) {
     TileArgs a{};
@@ -1106,13 +1449,21 @@ extern "C" int rsdet_anchor_target_rotated_f32(
     a.ny = ny, a.n_row_tiles = nrt, a.nx = nx;
     a.split_xt = split_tile(heavy_from_col, n2, nx);
     a.valid = valid, a.rowmax = rowmax, a.list = list, a.dir = dir, a.colkey = colkey;
+    a.pre1_out = pre1_out;
     const dim3 grid((unsigned)tile_grid(nx, a.split_xt, nrt));
-    if (version == 0)
+    if (two_tier) {
+      if (version == 0)
+        hipLaunchKernelGGL(at_tile2_kernel<0>, grid, dim3(T_NT), 0, s, a);
+      else
+        hipLaunchKernelGGL(at_tile2_kernel<1>, grid, dim3(T_NT), 0, s, a);
+    } else if (version == 0) {
       hipLaunchKernelGGL((iou_tile_kernel<0, 1>), grid, dim3(T_NT), 0, s, a);
-    else
+    } else {
       hipLaunchKernelGGL((iou_tile_kernel<1, 1>), grid, dim3(T_NT), 0, s, a);
+    }
   }
   FinishArgs f{};
+  const float4* f_colbox_unused = nullptr;
   f.boxes1 = gt_boxes, f.stride1 = stride1, f.boxes2 = anchors, f.stride2 = stride2, f.n2 = n2;
   f.per_group = per_group ? 1 : 0, f.row_offsets = row_offsets, f.group_tile0 = group_tile0;
   f.n_row_tiles = nrt1, f.ny = ny, f.nx = nx, f.n_groups = n_groups, f.n1 = n1;
@@ -1124,6 +1475,13 @@ extern "C" int rsdet_anchor_target_rotated_f32(
   f.gt_inds = gt_inds, f.max_ov = max_overlaps, f.labels = labels, f.label_weights = label_weights;
   f.bbox_targets = bbox_targets, f.bbox_weights = bbox_weights, f.totals = totals;
   f.state = st, f.rowmax_rw = rowmax;
-  hipLaunchKernelGGL(at_finish_kernel, dim3(nx, n_groups), dim3(T_NT), 0, s, f);
+  f.pre1 = pre1_out;
+  split_prepared(prepared2, per_group ? n_groups : 1, n2, &f.pre2, &f_colbox_unused);
+  if (!two_tier)
+    hipLaunchKernelGGL(at_finish_kernel<0>, dim3(nx, n_groups), dim3(T_NT), 0, s, f);
+  else if (version == 0)
+    hipLaunchKernelGGL(at_finish_kernel<1>, dim3(nx, n_groups), dim3(T_NT), 0, s, f);
+  else
+    hipLaunchKernelGGL(at_finish_kernel<2>, dim3(nx, n_groups), dim3(T_NT), 0, s, f);
   return rsdet_launch_status();
 }

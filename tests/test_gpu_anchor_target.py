@@ -103,21 +103,28 @@ def _dense_chain(ops, anchors_t, gt_t, lab_t, ro, ks, valid=None, version=0, mea
     return gi, mo, lab, lw, bt, bw, pos.sum(1).clamp(min=1).sum().float(), neg.sum(1).clamp(min=1).sum().float()
 
 
-def _check_equal(out, want):
+def _check_equal(out, want, two_tier=False):
+    """Every DECISION (gt_inds, labels, weights, encoded targets, counts) bit for bit; max_overlaps bit for bit in the
+    exact mode and within the two-tier budget (rsdet_geom_fast.h kFastBudget = 2e-5; the contract is 1e-4) otherwise."""
     gi, mo, lab, lw, bt, bw, npos, nneg = want
-    assert torch.equal(out["gt_inds"], gi)
+    assert torch.equal(out["gt_inds"], gi), int((out["gt_inds"] != gi).sum())
     assert torch.equal(out["labels"], lab)
     assert torch.equal(out["label_weights"], lw)
     assert torch.equal(out["bbox_weights"], bw.contiguous())
     assert torch.equal(out["bbox_targets"], bt), float((out["bbox_targets"] - bt).abs().max())
     mo_ok = torch.where(gi >= 0, mo, out["max_overlaps"])      # ignored (invalid) anchors: -1 either way
-    assert torch.equal(out["max_overlaps"], mo_ok)
+    if two_tier:
+        d = (out["max_overlaps"] - mo_ok).abs()
+        assert float(d.max()) <= 2e-5 and ((out["max_overlaps"] == 0) == (mo_ok == 0)).all()
+    else:
+        assert torch.equal(out["max_overlaps"], mo_ok)
     assert float(out["totals"][0]) == float(npos) and float(out["totals"][1]) == float(nneg)
 
 
+@pytest.mark.parametrize("two_tier", [False, True])
 @pytest.mark.parametrize("ks,per_image", [([16, 100, 400, 40], False), ([16, 100, 400, 40], True), ([1], False),
                                           ([3, 0, 250], True), ([0, 0], False)])
-def test_fused_anchor_target_equals_dense_chain(cuda, oracle_c, ks, per_image):
+def test_fused_anchor_target_equals_dense_chain(cuda, oracle_c, ks, per_image, two_tier):
     from rs_detection_amd import ops
     rng = np.random.default_rng(sum(ks) * 3 + per_image)
     anchors = s2anet_anchors()
@@ -130,9 +137,9 @@ def test_fused_anchor_target_equals_dense_chain(cuda, oracle_c, ks, per_image):
     for rep in range(4):          # the state buffer must come back zeroed: repeated calls give the same answer
         prep = ops.prepare_boxes(at, heavy_from=(None, 20480, 16384, 0)[rep])   # whole tiles / 4-row sub-tiles
         out = ops.anchor_target_rotated(at, gt, lt, ro, ks, 0.5, 0.4, 0.0, target_means=means, target_stds=stds,
-                                        want_gt_inds=True, prepared=prep,
+                                        want_gt_inds=True, prepared=prep, two_tier=two_tier,
                                         prepared_gt=ops.prepare_boxes(gt) if rep % 2 else None)
-        _check_equal(out, _dense_chain(ops, at, gt, lt, ro, ks, means=means, stds=stds))
+        _check_equal(out, _dense_chain(ops, at, gt, lt, ro, ks, means=means, stds=stds), two_tier)
     # ... and the assignment equals the oracle's (restatement of assigner.py:111-170 over the reference-pinned IoU)
     g = int(np.argmax(ks))
     if ks[g]:
@@ -142,7 +149,8 @@ def test_fused_anchor_target_equals_dense_chain(cuda, oracle_c, ks, per_image):
         assert (out["gt_inds"][g].cpu().numpy() == wgi).all() and (out["labels"][g].cpu().numpy() == wl).all()
 
 
-def test_fused_anchor_target_special_rows_ties_and_valid_mask(cuda, oracle_c):
+@pytest.mark.parametrize("two_tier", [False, True])
+def test_fused_anchor_target_special_rows_ties_and_valid_mask(cuda, oracle_c, two_tier):
     """(i) a gt that overlaps NO anchor has row maximum 0 and, with min_pos_iou = 0, claims every anchor whose IoU with
     it is 0 -- i.e. all of them, unless a later gt overrides (assigner.py:151-160); (ii) exact IoU ties between
     anchors of a regular grid (gt centred between two cells): every tied anchor is assigned; (iii) a valid mask."""
@@ -160,8 +168,8 @@ def test_fused_anchor_target_special_rows_ties_and_valid_mask(cuda, oracle_c):
         labs = rng.integers(1, 16, len(gts)).astype(np.int32)
         at, gt, lt, ro = (torch.from_numpy(anchors).to(cuda), torch.from_numpy(gts).to(cuda),
                           torch.from_numpy(labs).to(cuda), _ro(ks, cuda))
-        out = ops.anchor_target_rotated(at, gt, lt, ro, ks, 0.5, 0.4, 0.0, want_gt_inds=True)
-        _check_equal(out, _dense_chain(ops, at, gt, lt, ro, ks))
+        out = ops.anchor_target_rotated(at, gt, lt, ro, ks, 0.5, 0.4, 0.0, want_gt_inds=True, two_tier=two_tier)
+        _check_equal(out, _dense_chain(ops, at, gt, lt, ro, ks), two_tier)
         r0 = 0
         for g, k in enumerate(ks):
             ov = oracle_c.box_iou_rotated(gts[r0:r0 + k], anchors, 0)
@@ -176,8 +184,8 @@ def test_fused_anchor_target_special_rows_ties_and_valid_mask(cuda, oracle_c):
     valid = torch.from_numpy(np.stack([anchors[:, 0] < 700, anchors[:, 1] < 650])).to(cuda)
     at, gt, lt, ro = (torch.from_numpy(anchors).to(cuda), torch.from_numpy(gts).to(cuda),
                       torch.from_numpy(labs).to(cuda), _ro(ks, cuda))
-    out = ops.anchor_target_rotated(at, gt, lt, ro, ks, 0.5, 0.4, 0.0, valid=valid, want_gt_inds=True)
-    _check_equal(out, _dense_chain(ops, at, gt, lt, ro, ks, valid=valid))
+    out = ops.anchor_target_rotated(at, gt, lt, ro, ks, 0.5, 0.4, 0.0, valid=valid, want_gt_inds=True, two_tier=two_tier)
+    _check_equal(out, _dense_chain(ops, at, gt, lt, ro, ks, valid=valid), two_tier)
     assert (out["gt_inds"][~valid] == -1).all() and (out["label_weights"][~valid] == 0).all()
 
 
@@ -213,3 +221,66 @@ def test_split_dense_iou_queue_overflow(cuda):
     for _ in range(2):                                                             # twice: the state is clean again
         got = ops.box_iou_rotated_tiled(t1, t2, split=True)
         assert torch.equal(got, want)
+
+
+def test_two_tier_anchor_target_decisions_under_pressure(cuda, oracle_c):
+    """The two-tier path where its second tier matters: (i) duplicated gts (every column they top has two candidates
+    with EQUAL values: first-argmax must win), (ii) gts shifted by 1e-4 px copies (candidates within the budget but not
+    equal), (iii) IoUs pinned next to the thresholds: anchors' own boxes scaled so that IoU = 0.5 / 0.4 +- 1e-6 ...,
+    (iv) integer axis-aligned gts (the reference's fragile zone), (v) a pile: > 2 048 survivors in one tile.
+    gt_inds / labels / targets must equal the dense chain (bit-exact reference-order values) AND the oracle."""
+    from rs_detection_amd import ops
+    rng = np.random.default_rng(11)
+    anchors = s2anet_anchors()
+    A = anchors.shape[0]
+    base = dota_boxes(rng, 40)
+    cases = []
+    cases.append((np.concatenate([base, base[::-1].copy()]), [80]))                                   # (i)
+    sh = base.copy()
+    sh[:, :2] += rng.normal(0, 1e-4, (40, 2)).astype(np.float32)
+    cases.append((np.concatenate([base, sh]), [40, 40]))                                              # (ii) two images
+    cases.append((np.concatenate([base, sh, base]), [120]))                                           # (ii) one image
+    # (iii) a gt concentric with an anchor, same angle, scaled: IoU = (s^2 if s < 1) -> s = sqrt(thr +- d)
+    pick = anchors[rng.integers(0, A, 60)]
+    g3 = pick.copy()
+    sc = np.sqrt(np.concatenate([0.5 + rng.uniform(-3e-6, 3e-6, 30), 0.4 + rng.uniform(-3e-6, 3e-6, 30)])).astype(np.float32)
+    g3[:, 2:4] *= sc[:, None]
+    cases.append((g3, [60]))
+    ib = dota_boxes(rng, 50)
+    ib[:, :4] = np.round(ib[:, :4])
+    ib[:, 4] = rng.choice([0, np.pi / 2, -np.pi / 2], 50)
+    cases.append((ib.astype(np.float32), [50]))                                                       # (iv)
+    pile = (np.array([512, 512, 300, 200, 0.3], np.float32) + rng.normal(0, [3, 3, 2, 2, 0.1], (300, 5))).astype(np.float32)
+    cases.append((pile, [300]))                                                                       # (v)
+    for gts, ks in cases:
+        labs = rng.integers(1, 16, len(gts)).astype(np.int32)
+        at, gt, lt, ro = (torch.from_numpy(anchors).to(cuda), torch.from_numpy(gts).to(cuda),
+                          torch.from_numpy(labs).to(cuda), _ro(ks, cuda))
+        for hf in (None, 20480):
+            out = ops.anchor_target_rotated(at, gt, lt, ro, ks, 0.5, 0.4, 0.0, want_gt_inds=True, two_tier=True,
+                                            prepared=ops.prepare_boxes(at, heavy_from=hf))
+            _check_equal(out, _dense_chain(ops, at, gt, lt, ro, ks), True)
+        r0 = 0
+        for g, k in enumerate(ks):
+            ov = oracle_c.box_iou_rotated(gts[r0:r0 + k], anchors, 0)
+            wgi, _, _ = oracle_c.assign_wrt_overlaps(ov, 0.5, 0.4, 0.0, True, True, labs[r0:r0 + k], 0)
+            assert (out["gt_inds"][g].cpu().numpy() == wgi).all()
+            r0 += k
+
+
+def test_two_tier_anchor_target_uses_the_fast_tier(cuda):
+    """Guard against a silent all-exact path: at the step shape most max_overlaps must DIFFER in the last bits from the
+    exact mode (they are Green-integral values), while every decision is identical."""
+    from rs_detection_amd import ops
+    rng = np.random.default_rng(3)
+    ks = [16, 100, 400, 40]
+    anchors = s2anet_anchors()
+    gts = np.concatenate([dota_boxes(rng, k) for k in ks])
+    at, gt, ro = torch.from_numpy(anchors).to(cuda), torch.from_numpy(gts).to(cuda), _ro(ks, cuda)
+    a = ops.anchor_target_rotated(at, gt, None, ro, ks, 0.5, 0.4, 0.0, want_gt_inds=True, two_tier=True)
+    b = ops.anchor_target_rotated(at, gt, None, ro, ks, 0.5, 0.4, 0.0, want_gt_inds=True, two_tier=False)
+    assert torch.equal(a["gt_inds"], b["gt_inds"]) and torch.equal(a["bbox_targets"], b["bbox_targets"])
+    nz = b["max_overlaps"] > 0
+    frac_same = float((a["max_overlaps"][nz] == b["max_overlaps"][nz]).float().mean())
+    assert frac_same < 0.6, frac_same
+    assert float((a["max_overlaps"] - b["max_overlaps"]).abs().max()) <= 2e-5
