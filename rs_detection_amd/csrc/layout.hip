@@ -14,12 +14,13 @@ constexpr int TR_T = 64;  // tile edge
 
 // grid: (ceil(C / 64), ceil(R / 64), B); block 256.  in[b][r][c] -> out[b][c][r]
 __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                              int R, int C) {
+                                                              int R, int C, int aligned16) {
   __shared__ float tile[TR_T][TR_T + 1];
   const int t = threadIdx.x;
   const long long base_in = (long long)blockIdx.z * R * C, base_out = base_in;
   const int c0 = blockIdx.x * TR_T, r0 = blockIdx.y * TR_T;
-  const bool full = c0 + TR_T <= C && r0 + TR_T <= R && (C & 3) == 0 && (R & 3) == 0;
+  // 16-byte accesses need 16-byte aligned bases (a view with a storage offset need not be) and row pitches
+  const bool full = aligned16 && c0 + TR_T <= C && r0 + TR_T <= R && (C & 3) == 0 && (R & 3) == 0;
   if (full) {
     const int q = (t & 15) * 4, p = t >> 4;   // 16 threads x float4 = one 256-byte tile row
 #pragma unroll
@@ -59,6 +60,7 @@ extern "C" int rsdet_transpose_last2_f32(const float* in, float* out, int B, int
   const long long gx = (C + TR_T - 1) / TR_T, gy = (R + TR_T - 1) / TR_T;
   if (gy > 65535 || B > 65535) return RSDET_EINVAL;
   hipLaunchKernelGGL(transpose_last2_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)B), dim3(256), 0,
-                     (hipStream_t)stream, in, out, R, C);
+                     (hipStream_t)stream, in, out, R, C,
+                     (((uintptr_t)in | (uintptr_t)out) & 15) == 0 ? 1 : 0);
   return rsdet_launch_status();
 }

@@ -138,11 +138,12 @@ __global__ __launch_bounds__(LOSS_NT) void s2a_loss_fwd_kernel(
   const float sc = block_sum(cls, s_part);
   const float sb = block_sum(box, s_part);
   if (threadIdx.x == 0) {
-    // partials go out as device-scope atomic stores and are complete (value returned) before the arrival counts
-    const unsigned o1 = atomicExch(reinterpret_cast<unsigned*>(partial) + 2 * blockIdx.x, __float_as_uint(sc));
-    const unsigned o2 = atomicExch(reinterpret_cast<unsigned*>(partial) + 2 * blockIdx.x + 1, __float_as_uint(sb));
-    asm volatile("" ::"v"(o1), "v"(o2));
-    s_last = atomicAdd(counter, 1u) == gridDim.x - 1u;
+    // partials go out as device-scope atomic stores; the arrival is an agent-scope RELEASE (orders them before the
+    // count for every observer) and ACQUIRE (the last arriver's reads below come after every other arrival's
+    // release): one fence pair per workgroup, 341 workgroups -- by the memory model, not by in-order issue
+    atomicExch(reinterpret_cast<unsigned*>(partial) + 2 * blockIdx.x, __float_as_uint(sc));
+    atomicExch(reinterpret_cast<unsigned*>(partial) + 2 * blockIdx.x + 1, __float_as_uint(sb));
+    s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
   }
   __syncthreads();
   if (!s_last) return;

@@ -84,11 +84,49 @@ def dota_to_fair1m_1_5(src_path, tar_path, images_dir, name):
     return out
 
 
+SUPPORTED_MERGE_TYPES = ("FAIR", "DOTA", "DOTA1", "DOTA1_5", "DOTA2", "FAIR1M_1_5")
+
+
+def check_dataset_type(dataset_type):
+    """Raised BEFORE any inference is run (ImageDataset.__init__, Runner.test): a whole predicted test set must not be
+    lost to a type the submission writer does not know (the reference asserts only after the run, data_merge.py:57)."""
+    if dataset_type not in SUPPORTED_MERGE_TYPES:
+        raise ValueError("dataset.test.dataset_type = %r: set it to one of %s" % (dataset_type, ", ".join(SUPPORTED_MERGE_TYPES)))
+
+
+def dota_to_fair(src_path, tar_path, images_dir):
+    """dota_to_fair.py:37-100: one FAIR1M (v1) submission XML per image, ``<int(id)>.xml``: source / research / size
+    blocks with the fixed values of the challenge template (1000 x 1000 x 3, GF2/GF3, version 4.0) and one <object> per
+    detection: class, probability, the four corners + the first one again (closed rectangle)."""
+    data = pick_res(src_path, images_dir)
+    os.makedirs(tar_path, exist_ok=True)
+    for i in data:
+        img = str(int(i[1:]))
+        parts = ['<?xml version="1.0" encoding="utf-8"?>', "<annotation>",
+                 "  <source>", "    <filename>%s.tif</filename>" % img, "    <origin>GF2/GF3</origin>", "  </source>",
+                 "  <research>", "    <version>4.0</version>", "    <provider>placeholder_affiliation</provider>",
+                 "    <author>placeholder_authorname</author>", "    <pluginname>placeholder_direction</pluginname>",
+                 "    <pluginclass>placeholder_suject</pluginclass>", "    <time>2020-07-2020-11</time>", "  </research>",
+                 "  <size>", "    <width>1000</width>", "    <height>1000</height>", "    <depth>3</depth>", "  </size>",
+                 "  <objects>"]
+        for obj in data[i]:
+            b = obj["box"]
+            pts = ["%s, %s" % (b[2 * k], b[2 * k + 1]) for k in (0, 1, 2, 3, 0)]
+            parts += ["    <object>", "      <coordinate>pixel</coordinate>", "      <type>rectangle</type>",
+                      "      <description>None</description>", "      <possibleresult>",
+                      "        <name>%s</name>" % obj["cls"], "        <probability>%s</probability>" % obj["p"],
+                      "      </possibleresult>", "      <points>"]
+            parts += ["        <point>%s</point>" % q for q in pts]
+            parts += ["      </points>", "    </object>"]
+        parts += ["  </objects>", "</annotation>", ""]
+        with open(os.path.join(tar_path, img + ".xml"), "w") as f:
+            f.write("\n".join(parts))
+
+
 def data_merge_result(results, work_dir, epoch, name, dataset_type, images_dir="", device="cuda",
                       nms_threshold_type=0):
-    """:56-104 -> path of the submission file (zip, or csv for FAIR1M_1_5)."""
-    assert dataset_type in ["DOTA", "DOTA1", "DOTA1_5", "DOTA2", "FAIR1M_1_5"], \
-        "set dataset.test.dataset_type in the config file (DOTA, DOTA1_5, DOTA2 and FAIR1M_1_5 are supported)"
+    """:56-104 -> path of the submission file (zip; csv for FAIR1M_1_5; a zip of test/*.xml for FAIR)."""
+    check_dataset_type(dataset_type)
     save_path = os.path.join(work_dir, "test", "submit_%s" % epoch, "before_nms")
     final_path = os.path.join(work_dir, "test", "submit_%s" % epoch, "after_nms")
     for p in (save_path, final_path):
@@ -106,6 +144,15 @@ def data_merge_result(results, work_dir, epoch, name, dataset_type, images_dir="
     out = os.path.join(zips, name + ".zip")
     if os.path.exists(out):
         os.remove(out)
+    if dataset_type == 'FAIR':
+        fair = os.path.join(work_dir, "test", "submit_%s" % epoch, "final_fair", "test")
+        if os.path.exists(fair):
+            shutil.rmtree(fair)
+        dota_to_fair(final_path, fair, images_dir)
+        with zipfile.ZipFile(out, 'w', zipfile.ZIP_DEFLATED) as z:
+            for f in sorted(os.listdir(fair)):
+                z.write(os.path.join(fair, f), os.path.join("test", f))    # `zip -r name.zip test`
+        return out
     with zipfile.ZipFile(out, 'w', zipfile.ZIP_DEFLATED) as z:
         for f in sorted(os.listdir(final_path)):
             z.write(os.path.join(final_path, f), f)          # `zip -rj`: junk the paths

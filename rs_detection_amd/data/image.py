@@ -19,6 +19,8 @@ _DEFAULT_TF = (dict(type="Resize", min_size=[800], max_size=1333), dict(type="Pa
 class ImageDataset:
     def __init__(self, images_file=None, images_dir="", dataset_type="DOTA", transforms=_DEFAULT_TF, batch_size=1,
                  num_workers=0, shuffle=False):
+        from rs_detection_amd.data.devkits.data_merge import check_dataset_type
+        check_dataset_type(dataset_type)          # before any inference is spent on a type the merge cannot write
         self.images_file = self._load_images(images_file, images_dir)
         self.total_len, self.dataset_type = len(self.images_file), dataset_type
         self.batch_size, self.num_workers, self.shuffle = batch_size, num_workers, shuffle

@@ -112,7 +112,7 @@ def _fused_ok(assigner, coder, cfg):
 
 
 def anchor_target_batched(anchors, gt_cat, gt_labels_cat, row_offsets, max_k, cfg, assigner=None, coder=None,
-                          valid=None, ks=None, cache_anchors=False, heavy_from=None):
+                          valid=None, ks=None, cache_anchors=False, heavy_from=None, prepared_gt=None):
     """anchors (A,5) shared or (B,A,5); gt_cat (sumK,5); gt_labels_cat (sumK,) int; row_offsets (B+1) i32.
     -> labels (B,A) i32, label_weights (B,A), bbox_targets (B,A,5), bbox_weights (B,A,5),
        num_total_pos (device scalar, float), num_total_neg (device scalar, float).
@@ -120,7 +120,9 @@ def anchor_target_batched(anchors, gt_cat, gt_labels_cat, row_offsets, max_k, cf
     ``ks`` (the gt counts as Python ints, which every caller has: they are tensor shapes) selects the fused sparse
     path: rotated IoU of the overlapping pairs only -> assignment -> encode -> weights / counts in TWO launches
     (ops/anchor_target.py), no (K, A) matrix.  ``cache_anchors``: the anchors are the same tensor every step (the FAM
-    grid) -- their prepared form is kept; ``heavy_from``: first anchor index of the large pyramid levels (hint)."""
+    grid) -- their prepared form is kept; ``heavy_from``: first anchor index of the large pyramid levels (hint);
+    ``prepared_gt``: ``ops.prepare_boxes(gt_cat)`` made once by a caller that assigns the same gts twice (FAM + ODM) --
+    never cached: the gts of a step are never seen again."""
     assigner = assigner or build_from_cfg(cfg.get('assigner', ''), BOXES)
     coder = coder or _coder(cfg)
     B = row_offsets.numel() - 1
@@ -132,7 +134,8 @@ def anchor_target_batched(anchors, gt_cat, gt_labels_cat, row_offsets, max_k, cf
             assigner._neg(), assigner.min_pos_iou, assigner.match_low_quality, assigner.assigned_labels_filled,
             float(cfg.get('pos_weight', -1)), bool(cfg.get('reg_decoded_bbox', False)), coder.means, coder.stds,
             valid, assigner.iou_calculator.version, prepared=prep,
-            prepared_gt=_at.prepare_boxes(gt_cat, cache=True, heavy_from=gt_cat.shape[0]) if gt_cat.shape[0] else None)
+            prepared_gt=prepared_gt if prepared_gt is not None else (
+                _at.prepare_boxes(gt_cat, heavy_from=gt_cat.shape[0]) if gt_cat.shape[0] else None))
         return (out["labels"], out["label_weights"], out["bbox_targets"], out["bbox_weights"], out["totals"][0],
                 out["totals"][1])
     gt_inds, _, labels = assigner.assign_batch(anchors, gt_cat, row_offsets, max_k, gt_labels_cat, valid)

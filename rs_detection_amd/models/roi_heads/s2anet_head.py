@@ -286,9 +286,12 @@ class S2ANetHead(nn.Module):
                                                      for i in range(len(featmap_sizes))])
         init_anchors = self._init_anchor_cat[akey]
         assigner, coder = self._cfg_objs('fam_cfg')
+        from rs_detection_amd.ops.anchor_target import prepare_boxes
+        # the gts' prepared form (fp64 sincos) once for both modules; not cached (these gts never come back)
+        pgt = prepare_boxes(gt_cat, heavy_from=gt_cat.shape[0]) if gt_cat.is_cuda else None
         labels, lw, bt, bw, npos, nneg = anchor_target_batched(init_anchors, gt_cat, lab_cat, row_offsets, max(ks),
                                                                self.train_cfg['fam_cfg'], assigner, coder, valid,
-                                                               ks=ks, cache_anchors=True)
+                                                               ks=ks, cache_anchors=True, prepared_gt=pgt)
         avg = npos + nneg if self.sampling else npos
         fused = self._fused_losses(self.loss_fam_cls, self.loss_fam_bbox, fam_cls_scores, fam_bbox_preds, labels, lw, bt,
                                    bw, avg, self.train_cfg['fam_cfg'])
@@ -299,11 +302,10 @@ class S2ANetHead(nn.Module):
         # Oriented Detection Module: per-image refined anchors
         refined = torch.cat([r.reshape(r.shape[0], -1, 5) for r in refine_anchors], dim=1)
         assigner, coder = self._cfg_objs('odm_cfg')
-        from rs_detection_amd.ops.anchor_target import prepare_boxes
         heavy = prepare_boxes(init_anchors, cache=True).heavy_from     # the refinements keep the grid's level layout
         labels, lw, bt, bw, npos, nneg = anchor_target_batched(refined, gt_cat, lab_cat, row_offsets, max(ks),
                                                                self.train_cfg['odm_cfg'], assigner, coder, valid,
-                                                               ks=ks, heavy_from=heavy)
+                                                               ks=ks, heavy_from=heavy, prepared_gt=pgt)
         avg = npos + nneg if self.sampling else npos
         fused = self._fused_losses(self.loss_odm_cls, self.loss_odm_bbox, odm_cls_scores, odm_bbox_preds, labels, lw, bt,
                                    bw, avg, self.train_cfg['odm_cfg'])

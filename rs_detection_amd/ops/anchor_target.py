@@ -63,6 +63,7 @@ def prepare_boxes(boxes, cache=False, heavy_from=None):
     if key is not None:
         hit = _prepared_cache.get(key)
         if hit is not None and hit[0]() is b:
+            _prepared_cache[key] = _prepared_cache.pop(key)   # most recently used: last in insertion order
             return hit[1]
     nbytes = lib.rsdet_iou_prepared_bytes(total, per) if total else 0
     buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=b.device)
@@ -75,7 +76,12 @@ def prepare_boxes(boxes, cache=False, heavy_from=None):
     if key is not None:
         import weakref
         if len(_prepared_cache) > 64:
-            _prepared_cache.clear()
+            # dead tensors first, then the oldest entries (dicts keep insertion order): a long-lived entry such as the
+            # FAM anchor grid is re-inserted on every hit below and so never the oldest
+            for k in [k for k, (ref, _) in _prepared_cache.items() if ref() is None]:
+                del _prepared_cache[k]
+            while len(_prepared_cache) > 48:
+                del _prepared_cache[next(iter(_prepared_cache))]
         _prepared_cache[key] = (weakref.ref(b), prep)
     return prep
 
@@ -101,12 +107,24 @@ def row_tile_table(ks, device, rows_per_tile=_TI):
     return _tile_cache[key]
 
 
-def _zero_state(device, nbytes):
-    cur = _state.get(device)
+def _zero_state(device, nbytes, table=None):
+    """The zero-on-entry / zero-on-exit scratch of the self-cleaning kernels, one buffer per (device, STREAM): two
+    streams that used one buffer concurrently would corrupt each other's counters.  ``_dirty_state`` re-zeroes it after
+    a failed launch (an aborted kernel leaves counters behind)."""
+    table = _state if table is None else table
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    cur = table.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.zeros((max(nbytes, 4096) * 2,), dtype=torch.uint8, device=device)   # grow-only, zeroed once
-        _state[device] = cur
+        table[key] = cur
     return cur
+
+
+def _dirty_state(device, table=None):
+    table = _state if table is None else table
+    cur = table.get((device, torch.cuda.current_stream(device).cuda_stream))
+    if cur is not None:
+        cur.zero_()
 
 
 def box_iou_rotated_fast(boxes1, boxes2, row_offsets=None, ks=None, max_rows=None, version=0, out=None,
@@ -174,10 +192,7 @@ def box_iou_rotated_tiled(boxes1, boxes2, row_offsets=None, ks=None, max_rows=No
         assert prepared1.n_total == n1 and prepared1.groups == 1
     if split:
         dev = b1.device
-        st = _split_state.get(dev)
-        if st is None:
-            st = _split_state[dev] = torch.zeros((lib.rsdet_box_iou_rotated_split_state_bytes(),), dtype=torch.uint8,
-                                                 device=dev)
+        st = _zero_state(dev, lib.rsdet_box_iou_rotated_split_state_bytes(), _split_state)
         nrt = nt if ks is not None else G * ((mr + _TI - 1) // _TI)
         ws_bytes = lib.rsdet_box_iou_rotated_split_ws_size(n1, A, max(nrt, 1))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
@@ -186,6 +201,8 @@ def box_iou_rotated_tiled(boxes1, boxes2, row_offsets=None, ks=None, max_rows=No
                                                  _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,
                                                  _lib.ptr(ious), _lib.ptr(st), st.numel(), _lib.ptr(ws), ws_bytes,
                                                  _lib.stream_ptr())
+        if rc != _lib.RSDET_OK:
+            _dirty_state(dev, _split_state)
         _lib.check(rc, "rsdet_box_iou_rotated_split_f32")
         return ious
     rc = lib.rsdet_box_iou_rotated_tiled_f32(_lib.ptr(b1), n1, b1.shape[1], _lib.ptr(row_offsets), G, mr, tptr, nt,
@@ -263,5 +280,7 @@ def anchor_target_rotated(anchors, gt_cat, gt_labels_cat, row_offsets, ks, pos_i
         _lib.ptr(out.get("gt_inds")), _lib.ptr(out.get("max_overlaps")), _lib.ptr(out["labels"]),
         _lib.ptr(out["label_weights"]), _lib.ptr(out.get("bbox_targets")), _lib.ptr(out.get("bbox_weights")),
         _lib.ptr(out["totals"]), _lib.ptr(state), state.numel(), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+    if rc != _lib.RSDET_OK:
+        _dirty_state(dev)          # an aborted launch may leave counters behind: zero the buffer before the next call
     _lib.check(rc, "rsdet_anchor_target_rotated_f32")
     return out

@@ -20,10 +20,13 @@ def _ptr_array(tensors):
 
 
 def _workspace(dev, nbytes):
-    cur = _ws.get(dev)
+    """Zero-on-entry / zero-on-exit counter + partials, one buffer per (device, stream): concurrent use from two
+    streams must not share the arrival counter."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    cur = _ws.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.zeros((max(nbytes, 4096) * 2,), dtype=torch.uint8, device=dev)   # counter word zeroed once
-        _ws[dev] = cur
+        _ws[key] = cur
     return cur
 
 
@@ -51,6 +54,8 @@ class _S2ALoss(torch.autograd.Function):
                                         _lib.ptr(lab), _lib.ptr(lw), _lib.ptr(bt), _lib.ptr(bw), _lib.ptr(avg),
                                         alpha, gamma, beta, w_cls, w_box, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                         _lib.stream_ptr())
+        if rc != _lib.RSDET_OK:
+            ws.zero_()          # an aborted launch may leave the arrival counter behind
         _lib.check(rc, "rsdet_s2a_loss_forward")
         ctx.save_for_backward(lab, lw, bt, bw, avg, *cls, *box)
         ctx.params, ctx.L, ctx.hw = params, L, hw

@@ -167,6 +167,24 @@ def test_flip_box_prepare_data_and_fair_csv(tmp_path):
     assert DM.pick_res(str(tmp_path / "after"), str(tmp_path / "imgs"))["P0007"][0]["cls"] == "Tennis Court"
     csv = DM.dota_to_fair1m_1_5(str(tmp_path / "after"), str(tmp_path / "fair"), str(tmp_path / "imgs"), "sub")
     assert open(csv).read() == "7.tif,Tennis_Court,1.0000,2.0000,3.0000,4.0000,5.0000,6.0000,7.0000,8.0000,0.9000\n"
+    # dataset_type 'FAIR' (dota_to_fair.py:37-100): one XML per image of images_dir, class names with spaces, the first
+    # corner repeated to close the rectangle; an unknown type is refused BEFORE any inference (ImageDataset.__init__)
+    import xml.etree.ElementTree as ET
+    DM.dota_to_fair(str(tmp_path / "after"), str(tmp_path / "fairxml"), str(tmp_path / "imgs"))
+    assert sorted(os.listdir(tmp_path / "fairxml")) == ["12.xml", "7.xml"]
+    root = ET.parse(tmp_path / "fairxml" / "7.xml").getroot()
+    assert root.find("source/filename").text == "7.tif" and root.find("size/width").text == "1000"
+    obj = root.findall("objects/object")
+    assert len(obj) == 1 and obj[0].find("possibleresult/name").text == "Tennis Court"
+    assert obj[0].find("possibleresult/probability").text == "0.9"
+    assert [p.text for p in obj[0].findall("points/point")] == ["1.0, 2.0", "3.0, 4.0", "5.0, 6.0", "7.0, 8.0", "1.0, 2.0"]
+    assert ET.parse(tmp_path / "fairxml" / "12.xml").getroot().findall("objects/object") == []
+    with pytest.raises(ValueError):
+        DM.check_dataset_type("COCO")
+    from rs_detection_amd.data.image import ImageDataset
+    with pytest.raises(ValueError):
+        ImageDataset(images_dir=str(tmp_path / "imgs"), dataset_type="FAIR2")
+    assert ImageDataset(images_dir=str(tmp_path / "imgs"), dataset_type="FAIR").dataset_type == "FAIR"
 
 
 def test_poly2obb_min_area_rect():
