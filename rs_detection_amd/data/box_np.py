@@ -52,7 +52,27 @@ def get_best_begin_point_single(coordinate):
 
 
 def get_best_begin_point(coordinates):
-    return np.array([get_best_begin_point_single(c) for c in np.asarray(coordinates).tolist()])
+    """Vectorised form of ``[get_best_begin_point_single(c) for c in coordinates]`` (the per-box Python loop was 2/3
+    of a 400-gt DOTA tile's transform time): the same double-precision arithmetic in the same order -- four distances
+    summed left to right, the FIRST strictly smaller sum wins, sums >= 1e8 or NaN never win."""
+    c = np.asarray(coordinates, dtype=np.float64)
+    if c.ndim != 2 or c.shape[0] == 0:
+        return np.array([get_best_begin_point_single(x) for x in np.asarray(coordinates).tolist()])
+    pts = c[:, :8].reshape(-1, 4, 2)
+    xmin, ymin = pts[:, :, 0].min(1), pts[:, :, 1].min(1)
+    xmax, ymax = pts[:, :, 0].max(1), pts[:, :, 1].max(1)
+    dst = np.stack([np.stack([xmin, ymin], 1), np.stack([xmax, ymin], 1), np.stack([xmax, ymax], 1),
+                    np.stack([xmin, ymax], 1)], 1)                                   # (n, 4, 2)
+    force = np.empty((len(c), 4))
+    for i in range(4):
+        comb = np.roll(pts, -i, axis=1)                                              # pts[i:] + pts[:i]
+        d = comb - dst
+        ln = np.sqrt(d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1])
+        force[:, i] = ((ln[:, 0] + ln[:, 1]) + ln[:, 2]) + ln[:, 3]
+    f = np.where(np.isnan(force), np.inf, force)
+    flag = np.where(f.min(1) < 100000000.0, f.argmin(1), 0)
+    idx = (flag[:, None] + np.arange(4)[None, :]) % 4
+    return np.take_along_axis(pts, idx[:, :, None], axis=1).reshape(-1, 8)
 
 
 def rotated_box_to_poly_single(rrect):
@@ -60,10 +80,8 @@ def rotated_box_to_poly_single(rrect):
     return rotated_box_to_poly_np_le135(np.asarray(rrect, dtype=np.float64).reshape(1, -1))[0]
 
 
-def rotated_box_to_poly_np_le135(rrects):
-    """:580-602."""
-    if rrects.shape[0] == 0:
-        return np.zeros([0, 8], dtype=np.float32)
+def _le135_corners_loop(rrects):
+    """:580-600, box by box (the reference's own form: a 2x2 @ 2x4 ``dot`` per box)."""
     polys = []
     for rrect in rrects:
         x_ctr, y_ctr, width, height, angle = rrect[:5]
@@ -74,7 +92,55 @@ def rotated_box_to_poly_np_le135(rrects):
         x0, x1, x2, x3 = poly[0, :4] + x_ctr
         y0, y1, y2, y3 = poly[1, :4] + y_ctr
         polys.append(np.array([x0, y0, x1, y1, x2, y2, x3, y3], dtype=np.float32))
-    return get_best_begin_point(np.array(polys)).astype(np.float32)
+    return np.array(polys)
+
+
+def _le135_corners_vec(r):
+    """The same corners for all boxes at once.  ``R.dot(rect)`` in float32 is an sgemm: acc = R[i,0] * rect[0,j], then
+    one fused multiply-add with R[i,1] * rect[1,j] -- reproduced through float64 (the product of two float32 is exact
+    there); in float64 the plain expression is the dot product bit for bit.  Verified against the loop form at first
+    use (_le135_vec_ok): another BLAS that rounds differently switches this path off, never the results."""
+    x, y, w, h, a = (r[:, k] for k in range(5))
+    tlx, tly, brx, bry = -w / 2, -h / 2, w / 2, h / 2
+    c, s = np.cos(a), np.sin(a)
+    rx, ry = np.stack([tlx, brx, brx, tlx], 1), np.stack([tly, tly, bry, bry], 1)
+    if r.dtype == np.float32:
+        D = np.float64
+        px = ((-s)[:, None].astype(D) * ry.astype(D) + (c[:, None] * rx).astype(D)).astype(np.float32)
+        py = (c[:, None].astype(D) * ry.astype(D) + (s[:, None] * rx).astype(D)).astype(np.float32)
+    else:
+        px = c[:, None] * rx + (-s)[:, None] * ry
+        py = s[:, None] * rx + c[:, None] * ry
+    out = np.empty((len(r), 8), np.float32)
+    out[:, 0::2] = px + x[:, None]
+    out[:, 1::2] = py + y[:, None]
+    return out
+
+
+_le135_vec_state = {}
+
+
+def _le135_vec_ok(dtype):
+    ok = _le135_vec_state.get(dtype)
+    if ok is None:
+        rng = np.random.default_rng(20240917)
+        t = np.stack([rng.uniform(0, 1024, 256), rng.uniform(0, 1024, 256), rng.uniform(5, 300, 256),
+                      rng.uniform(2, 100, 256), rng.uniform(-2, 3, 256)], 1).astype(dtype)
+        ok = _le135_vec_state[dtype] = bool(np.array_equal(_le135_corners_loop(t), _le135_corners_vec(t)))
+    return ok
+
+
+def rotated_box_to_poly_np_le135(rrects):
+    """:580-602.  Vectorised over the boxes (the per-box loop + per-box begin-point search were ~110 ms of a 400-gt
+    tile's 170 ms in the loader); bit-identical to the loop form, checked at first use per dtype."""
+    if rrects.shape[0] == 0:
+        return np.zeros([0, 8], dtype=np.float32)
+    r = np.asarray(rrects)
+    if r.ndim == 2 and r.dtype in (np.float32, np.float64) and _le135_vec_ok(r.dtype.type):
+        polys = _le135_corners_vec(r[:, :5])
+    else:
+        polys = _le135_corners_loop(rrects)
+    return get_best_begin_point(polys).astype(np.float32)
 
 
 def rotated_box_to_poly_np_le90(obboxes):

@@ -80,10 +80,18 @@ class CustomDataset:
         return image, anno
 
     def collate_batch(self, batch):
-        """:92-108: zero-pad to the largest height / width of the batch."""
+        """:92-108: zero-pad to the largest height / width of the batch.  With ``self.reuse_batch_buffers`` (switched on
+        by data/loader.prefetch_to_device for the duration of its loop) the batch array is one of a ring of long-lived
+        -- pinned, where a GPU is present -- buffers: valid until five further batches have been collated."""
         imgs, anns = [b[0] for b in batch], [b[1] for b in batch]
         max_h, max_w = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
-        batch_imgs = np.zeros((len(imgs), 3, max_h, max_w), dtype=np.float32)
+        if getattr(self, "reuse_batch_buffers", False):
+            from .loader import reusable_batch_buffer
+            batch_imgs = reusable_batch_buffer(self, (len(imgs), 3, max_h, max_w), np.float32)
+            if any(i.shape[-2] != max_h or i.shape[-1] != max_w for i in imgs):
+                batch_imgs.fill(0)
+        else:
+            batch_imgs = np.zeros((len(imgs), 3, max_h, max_w), dtype=np.float32)
         for i, image in enumerate(imgs):
             batch_imgs[i, :, :image.shape[-2], :image.shape[-1]] = image
         return batch_imgs, anns
@@ -105,12 +113,25 @@ class CustomDataset:
         return idx[self.rank::self.world_size] if self.world_size > 1 else idx
 
     def __iter__(self):
+        """Batches of this rank's share of the epoch.  ``num_workers > 0``: decode + transforms in worker processes
+        (data/loader.py), a few batches ahead; the batches are the same either way (per-sample random state)."""
+        from .loader import iterate_samples
         idx = self._indices()
-        for s in range(0, len(idx), self.batch_size):
-            chunk = idx[s:s + self.batch_size]
-            if len(chunk) < self.batch_size and self.drop_last:
-                break
-            yield self.collate_batch([self[int(i)] for i in chunk])
+        n_full = (len(idx) // self.batch_size) * self.batch_size
+        if self.drop_last:
+            idx = idx[:n_full]
+        batch = []
+        for sample in iterate_samples(self, idx):
+            batch.append(sample)
+            if len(batch) == self.batch_size:
+                yield self.collate_batch(batch)
+                batch = []
+        if batch:
+            yield self.collate_batch(batch)
+
+    def __getstate__(self):
+        from .loader import state_without_pool
+        return state_without_pool(self)
 
     def evaluate(self, results, work_dir, epoch, logger=None):
         raise NotImplementedError

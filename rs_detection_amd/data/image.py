@@ -72,6 +72,17 @@ class ImageDataset:
         return out, anns
 
     def __iter__(self):
+        from .loader import iterate_samples
         idx = np.arange(self.total_len)[self.rank::self.world_size]
-        for s in range(0, len(idx), self.batch_size):
-            yield self.collate_batch([self[int(i)] for i in idx[s:s + self.batch_size]])
+        batch = []
+        for sample in iterate_samples(self, idx):          # worker processes when num_workers > 0 (data/loader.py)
+            batch.append(sample)
+            if len(batch) == self.batch_size:
+                yield self.collate_batch(batch)
+                batch = []
+        if batch:
+            yield self.collate_batch(batch)
+
+    def __getstate__(self):
+        from .loader import state_without_pool
+        return state_without_pool(self)

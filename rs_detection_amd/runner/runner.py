@@ -114,15 +114,16 @@ class Runner:
 
     def train(self, log_interval=50):
         """One epoch over ``train_dataset`` (:131-179)."""
-        from rs_detection_amd.data import batch_to_device
+        from rs_detection_amd.data.loader import prefetch_to_device
         self.train_dataset.set_epoch(self.epoch)
         self.model.train()                                        # once per epoch, as :133
         self._train_mode_applied = True
         start, last = time.time(), None
         swa = self.swa_start_epoch is not None and self.epoch >= self.swa_start_epoch and self.optimizer_swa is not None
         n_batches = max(len(self.train_dataset._indices()) // max(self.train_dataset.batch_size, 1), 1)
-        for batch_idx, (images, targets) in enumerate(self.train_dataset):
-            images, targets = batch_to_device(images, targets, self.device)
+        # decode / transforms in the dataset's worker processes, collate + pinned H2D copy on a side stream, two
+        # batches ahead of the step (data/loader.py)
+        for batch_idx, (images, targets) in enumerate(prefetch_to_device(self.train_dataset, self.device)):
             # train_step advances self.iter
             total, losses = self.train_step(images, targets, swa_factor=batch_idx / n_batches if swa else None)
             last = total
