@@ -31,6 +31,39 @@ def free_port():
     return p
 
 
+def pin_rank_to_cores(local_rank=None, local_world=None):
+    """Give this rank its own contiguous share of the host cores: ``os.sched_setaffinity`` over the cores this process
+    is allowed to use, split evenly by LOCAL_RANK.  The bf16 step is bound by the host (one Python thread enqueues
+    ~1 700 launches per step): eight ranks that migrate over -- and share -- the same cores lose to each other and to
+    their own loader workers; pinned, every rank keeps its L2 / NUMA locality and its workers (children of this process)
+    inherit the same share.  Must run before the first GPU call of the process (HIP's helper threads inherit the mask
+    they are created under).  No-op for a single rank, when ``RSDET_NO_AFFINITY=1``, or where the OS has no affinity API.
+    Returns the list of cores set (or None)."""
+    if os.environ.get("RSDET_NO_AFFINITY", "0") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    rank, lr, world = env_world()
+    local_rank = lr if local_rank is None else int(local_rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world)) if local_world is None else int(local_world)
+    if local_world <= 1:
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:                         # more ranks than cores: leave the scheduler alone
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    # intra-op thread pools sized for the share (the default is the machine's core count, per rank)
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(per, 8)))
+    try:
+        torch.set_num_threads(min(per, 8))
+    except RuntimeError:
+        pass
+    return mine
+
+
 def pick_backend():
     """RCCL when every rank has a GPU of its own; gloo when ranks have to share a device (RCCL refuses two ranks on
     one GPU) or there is none.  ``RSDET_DIST_BACKEND`` overrides.  ``device_count`` does not initialise HIP."""
@@ -46,6 +79,7 @@ def init_distributed(backend=None, timeout_s=1800):
     """Initialise the default process group from torchrun env vars (no-op for world size 1)."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
+        pin_rank_to_cores()             # before this process's first GPU call (set_device / NCCL init below)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -63,7 +97,7 @@ def shutdown():
         dist.destroy_process_group()
 
 
-def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_parameters=False):
+def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_parameters=False, static_graph=None):
     """DDP with gradient-as-bucket-view; 64 MB buckets: the 145 MB fp32 gradient set of
     S2ANet-R50 goes out as ~3 large all-reduces (per-link-bound ring over xGMI favours few,
     large messages) that overlap with the backbone backward.
@@ -73,13 +107,19 @@ def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_param
     xGMI link (72 MB instead of 145 MB per step); the master gradients and the SGD update stay fp32.
 
     The model's only graph-less parameters (RotationInvariantPooling's unused conv/BN) are frozen
-    (``requires_grad=False``), so DDP never waits for them and ``find_unused_parameters`` can stay off."""
+    (``requires_grad=False``), so DDP never waits for them and ``find_unused_parameters`` can stay off.
+
+    ``static_graph`` (default: env ``RSDET_DDP_STATIC_GRAPH``, off): the S2ANet / Oriented R-CNN steps use the same
+    parameters in the same order every iteration, so DDP may skip its per-iteration bookkeeping of the autograd graph
+    (tests/test_gpu_dist.py runs both settings: identical parameters after two steps)."""
+    if static_graph is None:
+        static_graph = os.environ.get("RSDET_DDP_STATIC_GRAPH", "0") == "1"
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if device.type == "cuda" else None
     ddp = DDP(model, device_ids=ids, gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb,
-              broadcast_buffers=False, find_unused_parameters=find_unused_parameters)
+              broadcast_buffers=False, find_unused_parameters=find_unused_parameters, static_graph=bool(static_graph))
     if grad_dtype == torch.bfloat16:
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)

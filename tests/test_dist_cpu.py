@@ -151,3 +151,105 @@ def test_bf16_gradient_buckets():
     for rank, is_f32, rel, on_grid in out:
         assert is_f32 and rel < 2e-2          # bf16 has 8 significant bits
         assert on_grid                        # every value is a bf16 number: the hook really compressed the bucket
+
+
+# ---- 8 ranks without the hardware: affinity, the shared MIOpen record directory, an 8-rank smoke -----
+def test_pin_rank_to_cores_splits_the_allowed_cores():
+    import subprocess
+    code = ("import os, sys, json\nsys.path.insert(0, %r)\nfrom rs_detection_amd.utils import dist as d\n"
+            "before = sorted(os.sched_getaffinity(0))\nmine = d.pin_rank_to_cores()\n"
+            "print(json.dumps([before, mine, sorted(os.sched_getaffinity(0))]))" % ROOT)
+    import json
+    allowed = sorted(os.sched_getaffinity(0))
+    n = 4 if len(allowed) >= 4 else len(allowed)
+    if n < 2:
+        pytest.skip("one core")
+    shares = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        before, mine, after = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True,
+                                                        text=True, check=True).stdout.strip().splitlines()[-1])
+        assert mine == after and len(mine) == len(allowed) // n and set(mine) <= set(before)
+        shares.append(set(mine))
+    assert all(shares[i].isdisjoint(shares[j]) for i in range(n) for j in range(i))       # no two ranks share a core
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), RSDET_NO_AFFINITY="1")
+    before, mine, after = json.loads(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True,
+                                                    text=True, check=True).stdout.strip().splitlines()[-1])
+    assert mine is None and after == before
+
+
+def _db_racer(tmp, q):
+    os.environ["XDG_CACHE_HOME"] = tmp
+    os.environ.pop("MIOPEN_USER_DB_PATH", None)
+    os.environ.pop("RSDET_NO_MIOPEN_DB", None)
+    sys.path.insert(0, ROOT)
+    from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db
+    d = use_packaged_miopen_db()
+    q.put((d, sorted((f, os.path.getsize(os.path.join(d, f))) for f in os.listdir(d)) if d else None))
+
+
+@pytest.mark.timeout(180)
+def test_eight_processes_race_on_one_miopen_db_directory(tmp_path):
+    """The 8 ranks of a node start together and copy the packaged MIOpen records into ONE per-user directory: every
+    rank must end up with complete files (atomic replace), no temporaries left behind."""
+    import glob
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_db_racer, args=(str(tmp_path), q)) for _ in range(8)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    pkg = os.path.join(ROOT, "rs_detection_amd", "miopen_db")
+    want = sorted((os.path.basename(f), os.path.getsize(f)) for f in glob.glob(os.path.join(pkg, "*db.txt")))
+    assert want, "packaged records missing"
+    for d, files in outs:
+        assert d == outs[0][0] and files == want, (d, files)                    # same directory, whole files, no *.tmp
+
+
+def _rank8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    import torch.distributed as dist
+    from rs_detection_amd.utils import dist as rdist
+    from rs_detection_amd.data import SyntheticDOTADataset
+    r, _, w = rdist.init_distributed(backend="gloo")
+    ds = SyntheticDOTADataset(tile=32, batch_size=2, num_images=37, shuffle=True)
+    ds.set_shard(r, w)                                   # training split: whole global batches, equal steps per rank
+    train = [t["filename"] for _, tg in ds for t in tg]
+    ds.set_shard(r, w, keep_all=True)                    # evaluation split: every image exactly once
+    val = [t["filename"] for _, tg in ds for t in tg]
+    allval = [n for part in rdist.gather_objects(val) for n in part]
+    synced = rdist.sync_mean({"loss": torch.tensor(float(r))}, torch.device("cpu"))
+    tmax = rdist.all_reduce_max(float(r), torch.device("cpu"))
+    q.put((r, len(train), sorted(train), len(set(allval)), len(allval), synced["loss"], tmax,
+           sorted(os.sched_getaffinity(0))))
+    rdist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_gloo_smoke_shards_sync_and_gather():
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o[0] for o in out] == list(range(8))
+    assert len({o[1] for o in out}) == 1 and out[0][1] == 4                     # 37 images, 8 ranks x batch 2: 2 steps each
+    seen = [n for o in out for n in o[2]]
+    assert len(seen) == len(set(seen)) == 32                                     # disjoint training shards
+    assert all(o[3] == 37 and o[4] == 37 for o in out)                           # sharded validation covers every image once
+    assert all(abs(o[5] - 3.5) < 1e-6 and o[6] == 7.0 for o in out)              # mean / max over 8 ranks
+    cores = [set(o[7]) for o in out]
+    if len(os.sched_getaffinity(0)) >= 8:                                        # init_distributed pinned every rank
+        assert all(cores[i].isdisjoint(cores[j]) for i in range(8) for j in range(i))

@@ -21,9 +21,9 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def _run(model, dtype, tmp_path, size=256, world=2):
+def _run(model, dtype, tmp_path, size=256, world=2, extra_env=None):
     from rs_detection_amd.utils import dist as rdist
-    env = dict(os.environ)
+    env = dict(os.environ, **(extra_env or {}))
     if torch.cuda.device_count() < world:
         env["RSDET_DIST_BACKEND"] = "gloo"
     out = str(tmp_path / "res")
@@ -49,6 +49,16 @@ def test_two_rank_ddp_real_model(model, dtype, tol, tmp_path):
         assert r["param_spread"] == 0.0, r           # bit-identical parameters on both ranks after two steps
         assert r["grad_norm"] > 0 and r["n_grad"] > 1e6
     assert res[0]["loss"] != res[1]["loss"]          # the ranks really worked on different shards
+
+
+@pytest.mark.timeout(1000)
+def test_two_rank_ddp_static_graph(tmp_path):
+    """DDP(static_graph=True) (RSDET_DDP_STATIC_GRAPH=1): the S2ANet step touches the same parameters in the same order
+    every iteration -- same reduced gradients, bit-identical parameters on both ranks after two steps."""
+    _need_gpu()
+    for r in _run("s2anet", "f32", tmp_path, extra_env={"RSDET_DDP_STATIC_GRAPH": "1"}):
+        assert r["world"] == 2 and r["finite"] and r["param_spread"] == 0.0, r
+        assert r["grad_rel_err"] < max(1e-3, 3 * r["noise"]), r
 
 
 @pytest.mark.timeout(1000)
