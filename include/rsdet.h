@@ -528,6 +528,23 @@ int rsdet_poly_iou_f64(const double* polys1, int n1, const double* polys2, int n
 int rsdet_nms_poly_sorted_f64(const double* polys_sorted, int n, double thr, uint8_t* keep_sorted, void* ws,
                               size_t ws_bytes, void* stream);
 
+/* ---- optimizer step over all parameters in two launches (csrc/optim.hip) ---------------------------------------------
+ * Replaces optims/optimizer.py:24-43 (grad_clip max_norm / norm_type 2, then SGD with weight decay and momentum) and,
+ * for bf16 model weights, the per-parameter master <-> bf16 casts of the autocast route.
+ *   tensors: n_tensors 64-byte device records { const void* grad; void* param; float* master; float* mom;
+ *            long long n; int flags; pad } -- flags bit 0: grad is bf16, bit 1: param is bf16 (then master != NULL holds
+ *            the fp32 parameter; otherwise param is the fp32 parameter itself);
+ *   chunks:  n_chunks device int pairs { tensor index, chunk index } covering every tensor in pieces of
+ *            rsdet_mt_chunk_elems() elements;
+ *   max_norm <= 0: no clipping (launch 1 is skipped unless sqnorm_out is given); sqnorm_out: optional device float that
+ *            receives the squared global gradient norm;
+ *   state:   rsdet_mt_sgd_state_bytes(n_chunks) bytes, zero on entry, left zero.
+ * m = momentum * m + (grad * clip_coef + weight_decay * p);  p -= lr * m   (torch.optim.SGD, dampening 0). */
+int rsdet_mt_chunk_elems(void);
+size_t rsdet_mt_sgd_state_bytes(int n_chunks);
+int rsdet_mt_sgd_step(const void* tensors, const int* chunks, int n_chunks, float max_norm, float lr, float momentum,
+                      float weight_decay, float* sqnorm_out, void* state, size_t state_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

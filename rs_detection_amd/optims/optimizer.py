@@ -49,3 +49,135 @@ class AdamW(torch.optim.AdamW, _Mixin):
     def step(self, closure=None):
         self._clip()
         return super().step(closure)
+
+
+@OPTIMS.register_module()
+class FusedSGD(torch.optim.Optimizer, _Mixin):
+    """SGD + global grad-norm clip as TWO launches over all parameters (csrc/optim.hip), with fp32 MASTER copies for
+    parameters the model holds in bf16 (``Runner(bf16_params=True)``): the kernel reads bf16 / fp32 gradients, updates
+    the fp32 master and momentum and writes the model's copy in its own dtype -- no autocast weight cast, no gradient
+    widening, no foreach passes.  Same arithmetic as ``SGD`` above (torch.optim.SGD with dampening 0, no nesterov;
+    clip_grad_norm_ with norm_type 2), which the reference configures in optims/optimizer.py:24-43.
+
+    One hyper-parameter set for all parameters (the reference's configs have a single group).  ``state_dict`` carries
+    ``momentum_buffer`` and, for bf16 parameters, ``master``."""
+
+    def __init__(self, params, lr, momentum=0, weight_decay=0, dampening=0, nesterov=False, grad_clip=None):
+        assert dampening == 0 and not nesterov, "FusedSGD: dampening / nesterov are not on the reference's path"
+        params = [p for p in params if p.requires_grad] if not isinstance(params, (list, tuple)) or \
+            (params and not isinstance(params[0], dict)) else params
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        assert len(self.param_groups) == 1, "FusedSGD: one parameter group"
+        self.grad_clip = grad_clip
+        self.lr = lr
+        self._params_key = None
+
+    def _ensure_state(self, p):
+        st = self.state[p]
+        if "momentum_buffer" not in st:
+            st["momentum_buffer"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+        if p.dtype == torch.bfloat16 and "master" not in st:
+            st["master"] = p.detach().float().clone()
+        return st
+
+    def master_state_dict(self, model):
+        """name -> fp32 tensor for every parameter of ``model`` (the master where the model holds bf16): what a
+        checkpoint stores, so that a saved run continues from the unrounded weights."""
+        out = {}
+        for name, p in model.named_parameters():
+            st = self.state.get(p, {})
+            out[name] = st["master"] if "master" in st else p.detach()
+        return out
+
+    def set_masters(self, model, params):
+        """After a checkpoint went into a model with bf16 weights: the fp32 values of ``params`` (name -> ndarray /
+        tensor) become the masters, so that the run continues from the unrounded weights."""
+        import numpy as np
+        named = dict(model.named_parameters())
+        with torch.no_grad():
+            for k, v in params.items():
+                p = named.get(k)
+                if p is None or p.dtype != torch.bfloat16 or not p.requires_grad:
+                    continue
+                t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else torch.as_tensor(v)
+                if tuple(t.shape) != tuple(p.shape):
+                    continue
+                st = self._ensure_state(p)
+                st["master"].copy_(t.to(device=p.device, dtype=torch.float32))
+
+    @staticmethod
+    def _same_order(a, b):
+        """Same element order in memory: strides equal on every dimension of size > 1."""
+        return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+    def _build(self, params, lib):
+        """Static part of the device table (once per parameter set): records without the gradient pointers + chunks."""
+        import numpy as np
+        dev = params[0].device
+        chunk = lib.rsdet_mt_chunk_elems()
+        rec = np.zeros((len(params), 8), np.int64)              # 64-byte records of csrc/optim.hip (MtTensor)
+        chunks = []
+        for i, p in enumerate(params):
+            assert p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last), "dense parameters only"
+            st = self._ensure_state(p)
+            for k in ("momentum_buffer", "master"):             # companions in the parameter's memory order
+                t = st.get(k)
+                if t is not None and not self._same_order(t, p):
+                    st[k] = torch.empty_strided(p.shape, p.stride(), dtype=torch.float32, device=dev).copy_(t)
+            master = st.get("master")
+            rec[i, 1:5] = (p.data_ptr(), master.data_ptr() if master is not None else 0,
+                           st["momentum_buffer"].data_ptr(), p.numel())
+            rec[i, 5] = 2 if p.dtype == torch.bfloat16 else 0    # low 32 bits = flags (little endian); grad bit per step
+            chunks += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
+        self._rec = rec
+        self._gflag = np.array([1 if p.dtype == torch.bfloat16 else 0 for p in params], np.int64)
+        n_rec32 = rec.size * 2
+        host = np.concatenate([rec.reshape(-1).view(np.int32), np.asarray(chunks, np.int32).reshape(-1)])
+        self._pinned = torch.empty((host.size,), dtype=torch.int32, pin_memory=True)
+        self._pinned.numpy()[...] = host
+        self._pin_rec = self._pinned.numpy()[:n_rec32].view(np.int64).reshape(len(params), 8)
+        self._table = torch.empty((host.size,), dtype=torch.int32, device=dev)
+        self._n_rec32, self._n_chunks = n_rec32, len(chunks)
+        self._state_buf = torch.zeros((lib.rsdet_mt_sgd_state_bytes(self._n_chunks),), dtype=torch.uint8, device=dev)
+        self._params_key = tuple(id(p) for p in params)
+        self._grad_ptrs = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from rs_detection_amd import _lib
+        lib = _lib.load()
+        g = self.param_groups[0]
+        params = [p for p in g["params"] if p.grad is not None]
+        if not params:
+            return None
+        if getattr(self, "_params_key", None) != tuple(id(p) for p in params):
+            self._build(params, lib)
+        # per step: the gradient pointers (autograd hands out fresh gradient tensors after zero_grad(set_to_none=True);
+        # DDP's bucket views stay put and skip the upload)
+        ptrs = []
+        for p in params:
+            gr = p.grad
+            if gr.dtype != p.dtype or not self._same_order(gr, p):   # rare: a gradient in another layout / dtype
+                gr = p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(gr)
+            ptrs.append(gr.data_ptr())
+        if ptrs != self._grad_ptrs:
+            self._pin_rec[:, 0] = ptrs
+            self._pin_rec[:, 5] = self._rec[:, 5] | self._gflag
+            self._table.copy_(self._pinned, non_blocking=True)
+            self._grad_ptrs = ptrs
+        clip = float(self.grad_clip.get("max_norm", 35)) if getattr(self, "grad_clip", None) else 0.0
+        if clip > 0:
+            assert float(self.grad_clip.get("norm_type", 2)) == 2.0, "FusedSGD clips the L2 norm"
+        tab = self._table
+        rc = lib.rsdet_mt_sgd_step(_lib.ptr(tab), ctypes_ptr_offset(tab, self._n_rec32 * 4), self._n_chunks, clip,
+                                   float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), None,
+                                   _lib.ptr(self._state_buf), self._state_buf.numel(), _lib.stream_ptr())
+        if rc != _lib.RSDET_OK:
+            self._state_buf.zero_()
+        _lib.check(rc, "rsdet_mt_sgd_step")
+        return None
+
+
+def ctypes_ptr_offset(t, nbytes):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + nbytes)

@@ -16,7 +16,8 @@ import torch
 
 def _to_numpy(obj):
     if isinstance(obj, torch.Tensor):
-        return obj.detach().cpu().numpy()
+        t = obj.detach().cpu()
+        return (t.float() if t.dtype == torch.bfloat16 else t).numpy()   # NumPy has no bf16: widen (exact)
     if isinstance(obj, dict):
         return {k: _to_numpy(v) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
@@ -25,9 +26,14 @@ def _to_numpy(obj):
 
 
 def save_checkpoint(path, model, optimizer=None, scheduler=None, meta=None):
-    """``Runner.save`` (:251-269): same top-level keys, arrays as NumPy, plain pickle."""
+    """``Runner.save`` (:251-269): same top-level keys, arrays as NumPy, plain pickle.  Where the optimizer keeps fp32
+    masters of bf16 model weights (FusedSGD) the checkpoint stores the MASTERS under the model's names: a JDet-layout
+    fp32 file either way."""
+    state = dict(model.state_dict())
+    if optimizer is not None and hasattr(optimizer, "master_state_dict"):
+        state.update(optimizer.master_state_dict(model))
     data = {"meta": dict(meta or {}, save_time=time.strftime("%Y%m%d_%H%M%S")),
-            "model": _to_numpy(model.state_dict()),
+            "model": _to_numpy(state),
             "scheduler": _to_numpy(scheduler.parameters()) if scheduler is not None else {},
             "optimizer": _to_numpy(optimizer.state_dict()) if optimizer is not None else {}}
     with open(path, "wb") as f:

@@ -8,6 +8,7 @@ layout (:251-290, runner/checkpoint.py), and the epoch loop ``run`` / ``train`` 
 ``dataset.train`` / ``dataset.val`` sections of the config (data/).  Loggers are a print line; flip-test and the
 tile-merge submission of ``test`` live in data/devkits.
 """
+import os
 import time
 
 import torch
@@ -20,7 +21,8 @@ from rs_detection_amd.utils.registry import MODELS, OPTIMS, SCHEDULERS, build_fr
 
 
 class Runner:
-    def __init__(self, cfg, device=None, distributed=None, memory_format=None, amp_dtype=None, grad_dtype="auto"):
+    def __init__(self, cfg, device=None, distributed=None, memory_format=None, amp_dtype=None, grad_dtype="auto",
+                 bf16_params=None):
         self.cfg = cfg
         from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db
         use_packaged_miopen_db()  # tuned MIOpen solver records of the shipped configs (before the first convolution)
@@ -40,8 +42,26 @@ class Runner:
                 self.model.backbone.set_channels_last(True)
         self.memory_format = memory_format
         self.amp_dtype = amp_dtype
+        # bf16 PARAMETERS (launch diet of the bf16 step): the weights / biases of the plain convolutions and
+        # linear layers live in bf16 in the model, their fp32 masters and momenta in FusedSGD (csrc/optim.hip: clip +
+        # SGD + both copies in two launches).  Removes, per step, one fp32->bf16 cast per weight (autocast), one
+        # bf16->fp32 cast per weight gradient and the foreach passes of clip_grad_norm_ / SGD (~250 launches of ~1 700).
+        # BatchNorm parameters, the ARF weight of ORConv2d (fp32 kernels) and every other parameter stay fp32.
+        if bf16_params is None:
+            bf16_params = os.environ.get("RSDET_BF16_PARAMS", "0") == "1"
+        self.bf16_params = bool(bf16_params) and amp_dtype == torch.bfloat16 and device.type == "cuda" and \
+            bool(cfg.optimizer) and cfg.optimizer.get("type") == "SGD"
+        if self.bf16_params:
+            for m in self.model.modules():
+                if type(m) in (torch.nn.Conv2d, torch.nn.Linear):
+                    for p in (m.weight, m.bias):
+                        if p is not None and p.requires_grad:
+                            p.data = p.data.to(torch.bfloat16)
         params = [p for p in self.model.parameters() if p.requires_grad]
-        self.optimizer = build_from_cfg(cfg.optimizer, OPTIMS, params=params) if cfg.optimizer else None
+        opt_cfg = cfg.optimizer
+        if self.bf16_params:
+            opt_cfg = dict(cfg.optimizer, type="FusedSGD")
+        self.optimizer = build_from_cfg(opt_cfg, OPTIMS, params=params) if cfg.optimizer else None
         self.scheduler = build_from_cfg(cfg.scheduler, SCHEDULERS, optimizer=self.optimizer) \
             if (cfg.scheduler and self.optimizer) else None
         # the SWA phase (runner.py:51-53): its own optimizer + per-epoch cosine schedule over the same parameters
@@ -249,7 +269,11 @@ class Runner:
                         return [back(v) for v in o]
                     return o
                 self.optimizer.load_state_dict(back(opt))
-        return load_parameters(self.model, model_parameters(data))
+                self.optimizer._params_key = None if hasattr(self.optimizer, "_params_key") else None
+        out = load_parameters(self.model, model_parameters(data))
+        if hasattr(self.optimizer, "set_masters"):        # bf16 model weights: the file's fp32 values are the masters
+            self.optimizer.set_masters(self.model, model_parameters(data))
+        return out
 
     resume = load
 

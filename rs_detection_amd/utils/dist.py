@@ -109,9 +109,11 @@ def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_param
     The model's only graph-less parameters (RotationInvariantPooling's unused conv/BN) are frozen
     (``requires_grad=False``), so DDP never waits for them and ``find_unused_parameters`` can stay off.
 
-    ``static_graph`` (default: env ``RSDET_DDP_STATIC_GRAPH``, off): the S2ANet / Oriented R-CNN steps use the same
-    parameters in the same order every iteration, so DDP may skip its per-iteration bookkeeping of the autograd graph
-    (tests/test_gpu_dist.py runs both settings: identical parameters after two steps)."""
+    ``static_graph`` (default: env ``RSDET_DDP_STATIC_GRAPH``, off).  Evaluated in round 3 and left off: the steps use
+    the same parameters in the same order every iteration, so it is legal, but with torch 2.10 + ROCm the 2-rank
+    harness (tests/dist_worker.py: a second backward through an un-wrapped copy sharing the parameters) trips the
+    reducer's internal assert `expect_autograd_hooks_` (reducer.cpp:1703) under static_graph=True; plain DDP passes the
+    same harness, and the bookkeeping it would save is ~0.1 ms of a 23-57 ms step."""
     if static_graph is None:
         static_graph = os.environ.get("RSDET_DDP_STATIC_GRAPH", "0") == "1"
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

