@@ -437,6 +437,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the second (bf16) timed leg of the default line")
+    ap.add_argument("--bf16-params", choices=["0", "1"], default=os.environ.get("RSDET_BF16_PARAMS", "1"),
+                    help="bf16 legs: conv / linear weights held in bf16 with fp32 masters in the fused optimizer "
+                         "(csrc/optim.hip; 1, default) or fp32 parameters under autocast + foreach SGD (0)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE config[1] (the metric); bf16 = torch.autocast over the MIOpen/rocBLAS part "
                          "(configs[2]/[4]); the oriented-box kernels always compute in fp32")
@@ -492,7 +495,7 @@ def main():
     else:
         cfg, batch, ncls = s2anet_cfg(), BATCH_PER_GPU, 15
     amp = torch.bfloat16 if args.dtype == "bf16" else None
-    runner = Runner(cfg, device=device, memory_format=mf, amp_dtype=amp)
+    runner = Runner(cfg, device=device, memory_format=mf, amp_dtype=amp, bf16_params=args.bf16_params == "1")
     # synthetic DOTA-shaped batches, resident in HBM before the timed region.  N_BATCHES different batches
     # rotate through the timed loop (step i runs batch i % N_BATCHES, the K cycle shifted by one slot per batch), so the
     # per-K-tuple tile tables and the prepared-box caches of the anchor-target path see new gts every step.
@@ -518,7 +521,8 @@ def main():
         del runner
         torch.cuda.empty_cache()
         torch.manual_seed(0)
-        r16 = Runner(cfg, device=device, memory_format=torch.channels_last, amp_dtype=torch.bfloat16)
+        r16 = Runner(cfg, device=device, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
+                     bf16_params=args.bf16_params == "1")
         b16 = [(im.contiguous(memory_format=torch.channels_last), tg) for im, tg in batches]
         for i in range(max(args.warmup, 3)):
             r16.train_step(*b16[i % N_BATCHES])
@@ -526,6 +530,7 @@ def main():
         dt16, loss16 = timed_region(r16, b16, steps16, rdist, device)
         bf16_leg = {"value": batch * world * steps16 / dt16, "unit": "tiles/s", "ms_per_step": dt16 / steps16 * 1e3,
                     "steps": steps16, "warmup": max(args.warmup, 3), "dtype": "bf16", "memory_format": "channels_last",
+                    "bf16_params": bool(r16.bf16_params),
                     "final_loss": loss16,
                     "flop_roofline": None if step_flops is None else {
                         "bound": "mfma", "achieved": step_flops / (dt16 / steps16) / 1e12, "unit": "TFLOP/s",

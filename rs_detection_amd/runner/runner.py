@@ -54,8 +54,8 @@ class Runner:
         if self.bf16_params:
             for m in self.model.modules():
                 if type(m) in (torch.nn.Conv2d, torch.nn.Linear):
-                    for p in (m.weight, m.bias):
-                        if p is not None and p.requires_grad:
+                    for p in (m.weight, m.bias):          # frozen stages too: their weights are cast every step as well
+                        if p is not None:
                             p.data = p.data.to(torch.bfloat16)
         params = [p for p in self.model.parameters() if p.requires_grad]
         opt_cfg = cfg.optimizer
