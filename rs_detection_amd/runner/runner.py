@@ -42,8 +42,8 @@ class Runner:
                 self.model.backbone.set_channels_last(True)
         self.memory_format = memory_format
         self.amp_dtype = amp_dtype
-        # bf16 PARAMETERS (launch diet of the bf16 step): the weights / biases of the plain convolutions and
-        # linear layers live in bf16 in the model, their fp32 masters and momenta in FusedSGD (csrc/optim.hip: clip +
+        # bf16 PARAMETERS (launch diet of the bf16 step): the weights of the plain convolutions and linear
+        # layers live in bf16 in the model, their fp32 masters and momenta in FusedSGD (csrc/optim.hip: clip +
         # SGD + both copies in two launches).  Removes, per step, one fp32->bf16 cast per weight (autocast), one
         # bf16->fp32 cast per weight gradient and the foreach passes of clip_grad_norm_ / SGD (~250 launches of ~1 700).
         # BatchNorm parameters, the ARF weight of ORConv2d (fp32 kernels) and every other parameter stay fp32.
@@ -54,9 +54,9 @@ class Runner:
         if self.bf16_params:
             for m in self.model.modules():
                 if type(m) in (torch.nn.Conv2d, torch.nn.Linear):
-                    for p in (m.weight, m.bias):          # frozen stages too: their weights are cast every step as well
-                        if p is not None:
-                            p.data = p.data.to(torch.bfloat16)
+                    # weights only (frozen stages too: autocast casts those every step as well); the biases stay fp32
+                    # -- the fused bias + ReLU tails (ops/bn_act.bias_act) take fp32 per-channel parameters
+                    m.weight.data = m.weight.data.to(torch.bfloat16)
         params = [p for p in self.model.parameters() if p.requires_grad]
         opt_cfg = cfg.optimizer
         if self.bf16_params:
