@@ -21,7 +21,9 @@ for _ in range(4):
     ops.box_iou_rotated_grouped(g, ro, max(ks), a, out=out)
     ops.assign_wrt_overlaps(out, ro, max(ks), 0.5, 0.4, 0.0, True, True, lab, 0)
     ops.box_iou_rotated_tiled(g, a, ro, ks=ks, out=out, prepared=prep, prepared1=pgt)
-    ops.anchor_target_rotated(a, g, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep, prepared_gt=pgt)
+    ops.anchor_target_rotated(a, g, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep, prepared_gt=pgt, two_tier=False)
+    ops.anchor_target_rotated(a, g, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep, prepared_gt=pgt, two_tier=True)
+    ops.box_iou_rotated_fast(g, a, ro, ks=ks, out=out, prepared=prep)
     ops.prepare_boxes(a)
 # algorithmic bytes per launch of the kernels this driver runs, keyed by a substring of the kernel name;
 # kernels that share one figure (the launches of one C-ABI call) carry the same "call" tag and are summed by roofline.py
@@ -38,7 +40,12 @@ ALG = {
     "iou_tile_kernel<0, 1>": dict(call="anchor_target_rotated (2 launches)", bytes=20 * (n1 + A) + 56 * len(ks) * A),
     "at_finish_kernel": dict(call="anchor_target_rotated (2 launches)", bytes=20 * (n1 + A) + 56 * len(ks) * A),
     "at_prepare_kernel": dict(call="iou_prepare", bytes=(20 + 40) * A),
+    # round 3: two-tier forms
+    "iou_fast_tile_kernel": dict(call="box_iou_rotated_fast (1 launch)", bytes=iou_b),
+    "at_tile2_kernel": dict(call="anchor_target_rotated two-tier (2 launches)", bytes=20 * (n1 + A) + 56 * len(ks) * A),
+    "at_finish_kernel<1>": dict(call="anchor_target_rotated two-tier (2 launches)", bytes=20 * (n1 + A) + 56 * len(ks) * A),
 }
+ALG["at_finish_kernel<0>"] = ALG.pop("at_finish_kernel")
 B, C, H = 4, 256, 128
 ALG["deform_im2col_taps_kernel"] = dict(call="deform_im2col", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
 ALG["deform_im2col_nhwc_kernel"] = dict(call="deform_im2col_nhwc", bytes=4 * (C * H * H * B + 18 * H * H * B + 9 * C * H * H * B))
@@ -116,3 +123,34 @@ dets = torch.cat([rotated_box_to_poly(torch.from_numpy(dd).to(dev)), torch.from_
 for _ in range(2):
     ops.poly_nms(dets, 0.1)
 torch.cuda.synchronize(); print("done")
+
+# ---- round 3: the fused BatchNorm tails at the layer1 shape of the step, and the fused optimizer step
+from rs_detection_amd.ops.bn_act import bn_act
+Cb, Hb = 256, 256
+bn = torch.nn.BatchNorm2d(Cb).to(dev).eval()
+for tag, dt, cl in (("f32", torch.float32, False), ("bf16", torch.bfloat16, True)):
+    xb = torch.randn(4, Cb, Hb, Hb, device=dev, dtype=dt)
+    rb = torch.randn(4, Cb, Hb, Hb, device=dev, dtype=dt)
+    if cl:
+        xb, rb = xb.contiguous(memory_format=torch.channels_last), rb.contiguous(memory_format=torch.channels_last)
+    xb.requires_grad_(True), rb.requires_grad_(True)
+    for _ in range(3):
+        yb = bn_act(xb, bn, rb, True)
+        torch.autograd.grad(yb, (xb, rb, bn.weight, bn.bias), torch.randn_like(yb))
+    del xb, rb, yb
+es = {"f32": 4, "bf16": 2}
+nb = 4 * Cb * Hb * Hb
+ALG2 = {"bn_act_fwd_kernel<true, true, float>": dict(call="bn_act_forward_f32", bytes=3 * 4 * nb),
+        "bn_act_bwd_kernel<true, float>": dict(call="bn_act_backward_f32", bytes=4 * 4 * nb),
+        "bn_act_fwd_nhwc_kernel<true, true, unsigned short>": dict(call="bn_act_forward_bf16", bytes=3 * 2 * nb),
+        "bn_act_bwd_nhwc_kernel<true, unsigned short": dict(call="bn_act_backward_bf16", bytes=4 * 2 * nb)}
+from rs_detection_amd.optims.optimizer import FusedSGD
+ps = [torch.nn.Parameter(torch.randn(36_000_000, device=dev))]
+opt = FusedSGD(ps, lr=0.01, momentum=0.9, weight_decay=1e-4, grad_clip=dict(max_norm=35, norm_type=2))
+for _ in range(3):
+    ps[0].grad = torch.randn_like(ps[0])
+    opt.step()
+ALG2["mt_sqnorm_kernel"] = dict(call="fused SGD step (2 launches, 36 M fp32 parameters)", bytes=4 * 36_000_000 * (1 + 1 + 2 + 2))
+ALG2["mt_sgd_kernel"] = dict(call="fused SGD step (2 launches, 36 M fp32 parameters)", bytes=4 * 36_000_000 * (1 + 1 + 2 + 2))
+ALG.update(ALG2)
+json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)

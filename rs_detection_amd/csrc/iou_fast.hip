@@ -20,6 +20,7 @@
 // CU, same L2 channel), so no element depends on the order of two stores in flight.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rsdet_api_internal.h"
 #include "rsdet_geom_fast.h"

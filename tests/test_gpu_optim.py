@@ -103,9 +103,9 @@ def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
     path = str(tmp_path / "ckpt.pkl")
     rb.save(path)
     raw = read_checkpoint(path)
-    assert raw["model"]["backbone.layer1.0.conv1.weight"].dtype == np.float32
-    m = rb.optimizer.state[rb.model.backbone.layer1[0].conv1.weight]["master"]
-    assert np.array_equal(raw["model"]["backbone.layer1.0.conv1.weight"], m.cpu().numpy())
+    assert raw["model"]["backbone.layer1.0.conv1.weight"].dtype == np.float32      # frozen stage: widened bf16 copy
+    m = rb.optimizer.state[rb.model.backbone.layer2[0].conv1.weight]["master"]
+    assert np.array_equal(raw["model"]["backbone.layer2.0.conv1.weight"], m.cpu().numpy())
     ra = runs[False][0]
     loaded, missing, unexpected, mismatched = ra.load(path, model_only=True)
     assert not missing and not unexpected and not mismatched
@@ -115,7 +115,7 @@ def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
         rc = Runner(cfg, device=cuda, distributed=False, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
                     bf16_params=True)
     rc.load(path)
-    w = rc.model.backbone.layer1[0].conv1.weight
+    w = rc.model.backbone.layer2[0].conv1.weight
     assert torch.equal(rc.optimizer.state[w]["master"], m) and torch.equal(w.detach(), m.to(torch.bfloat16))
     t3, _ = rc.train_step(images, targets)
     assert np.isfinite(float(t3))
