@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the default bench (fp32) and the bf16 line; summaries -> gpurun_out/prof_<tag>_{f32,bf16}.txt
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 for dt in ${2:-f32 bf16}; do
