@@ -133,10 +133,13 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         self._gflag = np.array([1 if p.dtype == torch.bfloat16 else 0 for p in params], np.int64)
         n_rec32 = rec.size * 2
         host = np.concatenate([rec.reshape(-1).view(np.int32), np.asarray(chunks, np.int32).reshape(-1)])
-        self._pinned = torch.empty((host.size,), dtype=torch.int32, pin_memory=True)
-        self._pinned.numpy()[...] = host
-        self._pin_rec = self._pinned.numpy()[:n_rec32].view(np.int64).reshape(len(params), 8)
+        # PAGEABLE host copy on purpose: an async copy out of a pinned buffer that the next step rewrites races with a
+        # GPU that is a step or more behind the host (the fp32 step is); a copy from pageable memory is staged by the
+        # runtime before the call returns.  2.5 KB per step.
+        self._host = torch.from_numpy(host.copy())
+        self._pin_rec = self._host.numpy()[:n_rec32].view(np.int64).reshape(len(params), 8)
         self._table = torch.empty((host.size,), dtype=torch.int32, device=dev)
+        self._table.copy_(self._host)
         self._n_rec32, self._n_chunks = n_rec32, len(chunks)
         self._state_buf = torch.zeros((lib.rsdet_mt_sgd_state_bytes(self._n_chunks),), dtype=torch.uint8, device=dev)
         self._params_key = tuple(id(p) for p in params)
@@ -163,7 +166,7 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         if ptrs != self._grad_ptrs:
             self._pin_rec[:, 0] = ptrs
             self._pin_rec[:, 5] = self._rec[:, 5] | self._gflag
-            self._table.copy_(self._pinned, non_blocking=True)
+            self._table[:self._n_rec32].copy_(self._host[:self._n_rec32])    # staged synchronously (pageable source)
             self._grad_ptrs = ptrs
         clip = float(self.grad_clip.get("max_norm", 35)) if getattr(self, "grad_clip", None) else 0.0
         if clip > 0:
