@@ -1209,17 +1209,19 @@ __global__ __launch_bounds__(T_NT) void at_finish_kernel(const FinishArgs a) {
     unsigned long long* words = reinterpret_cast<unsigned long long*>(a.state);
     const unsigned long long mine = ((unsigned long long)(unsigned)s_cnt[0] << 40) |
                                     ((unsigned long long)(unsigned)s_cnt[1] << 16) | 1ull;
-    // agent-scope acq_rel: the arrival is ordered after this workgroup's reads of rowmax / colkey (release) and the
-    // last arriver's clears below after every other arrival (acquire) by the memory model, not only by the data
-    // dependency of `mine` on those reads (one fence pair per workgroup, 344 workgroups: measured +<1 us)
-    const unsigned long long now =
-        __hip_atomic_fetch_add(words + 1 + g, mine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + mine;
+    // Arrival.  What the LAST arriver does afterwards (clearing rowmax) only has to come after every other workgroup's
+    // READS of rowmax; those reads feed `mine` (the counts depend on the low-quality matches, which depend on the row
+    // maxima), so each workgroup's arrival atomic cannot issue before its reads have returned -- a data dependency, not a
+    // fence.  The compiler barrier keeps the atomic below the output stores in program order.  (An agent-scope acq_rel
+    // arrival -- one buffer_wbl2 + buffer_inv per workgroup -- was measured in round 3: at_finish 11.8 -> 20.7 us.)
+    asm volatile("" ::: "memory");
+    const unsigned long long now = atomicAdd(words + 1 + g, mine) + mine;
     int last = 0;
     if ((now & 0xFFFFull) == (unsigned long long)gridDim.x) {  // this image is complete
       atomicExch(words + 1 + g, 0ull);
       const unsigned long long p = now >> 40, n = (now >> 16) & 0xFFFFFFull;
       const unsigned long long img = ((p ? p : 1ull) << 38) | ((n ? n : 1ull) << 12) | 1ull;
-      const unsigned long long all = __hip_atomic_fetch_add(words, img, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + img;
+      const unsigned long long all = atomicAdd(words, img) + img;
       if ((all & 0xFFFull) == (unsigned long long)gridDim.y) {  // ... and so is the batch
         atomicExch(words, 0ull);
         if (a.totals) {

@@ -138,12 +138,15 @@ __global__ __launch_bounds__(LOSS_NT) void s2a_loss_fwd_kernel(
   const float sc = block_sum(cls, s_part);
   const float sb = block_sum(box, s_part);
   if (threadIdx.x == 0) {
-    // partials go out as device-scope atomic stores; the arrival is an agent-scope RELEASE (orders them before the
-    // count for every observer) and ACQUIRE (the last arriver's reads below come after every other arrival's
-    // release): one fence pair per workgroup, 341 workgroups -- by the memory model, not by in-order issue
+    // Hand-off in the form MI355X_MICROARCH.md lists as valid for cross-CU data ("agent atomics both sides"): the
+    // partials go out as device-scope atomic stores, this wave WAITS for them (s_waitcnt vmcnt(0); the "memory" clobber
+    // also pins the compiler's order), only then the arrival is counted; the last arriver reads the partials with
+    // returning atomics.  (An acq_rel arrival costs a buffer_wbl2 + buffer_inv per workgroup: at_finish, which uses the
+    // same pattern, went from 11.8 to 20.7 us with it.)
     atomicExch(reinterpret_cast<unsigned*>(partial) + 2 * blockIdx.x, __float_as_uint(sc));
     atomicExch(reinterpret_cast<unsigned*>(partial) + 2 * blockIdx.x + 1, __float_as_uint(sb));
-    s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(counter, 1u) == gridDim.x - 1u;
   }
   __syncthreads();
   if (!s_last) return;

@@ -7,7 +7,7 @@
 // optimizer keeps the fp32 masters and momenta and writes both copies in the same pass.
 //
 //   launch 1  mt_sqnorm   one workgroup per 16 Ki-element chunk of a gradient: sum of squares in fp32 -> partial;
-//                         the last workgroup to arrive (agent-scope acq_rel counter) folds the partials in a fixed
+//                         the last workgroup to arrive (device-scope atomics both sides) folds the partials in a fixed
 //                         order (deterministic) into the squared global norm
 //   launch 2  mt_sgd      same chunks: g = grad * min(1, max_norm / (norm + 1e-6)) [+ wd * p];
 //                         m = momentum * m + g;  p32 -= lr * m;  p_model = (bf16 | f32) p32
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(MT_NT) void mt_sqnorm_kernel(const MtTensor* __rest
     float v = 0.f;
     for (int w = 0; w < MT_NT / 64; ++w) v += s_red[w];
     atomicExch(reinterpret_cast<unsigned*>(partial) + blockIdx.x, __float_as_uint(v));
-    s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)n_chunks - 1u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partial is performed before the arrival is counted
+    s_last = atomicAdd(counter, 1u) == (unsigned)n_chunks - 1u;
   }
   __syncthreads();
   if (!s_last) return;

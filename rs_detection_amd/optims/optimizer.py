@@ -133,13 +133,16 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         self._gflag = np.array([1 if p.dtype == torch.bfloat16 else 0 for p in params], np.int64)
         n_rec32 = rec.size * 2
         host = np.concatenate([rec.reshape(-1).view(np.int32), np.asarray(chunks, np.int32).reshape(-1)])
-        # PAGEABLE host copy on purpose: an async copy out of a pinned buffer that the next step rewrites races with a
-        # GPU that is a step or more behind the host (the fp32 step is); a copy from pageable memory is staged by the
-        # runtime before the call returns.  2.5 KB per step.
-        self._host = torch.from_numpy(host.copy())
-        self._pin_rec = self._host.numpy()[:n_rec32].view(np.int64).reshape(len(params), 8)
+        # The records go up once; per step only the gradient pointers change.  Staging for that upload: a RING of pinned
+        # copies of the record block, each guarded by an event -- an async copy out of ONE pinned buffer that the next
+        # step rewrites races with a GPU that is a step or more behind the host (the fp32 step is: found as a
+        # non-finite loss in the bench), and a pageable source makes the copy synchronise the stream (24.9 vs 22.4 ms).
         self._table = torch.empty((host.size,), dtype=torch.int32, device=dev)
-        self._table.copy_(self._host)
+        self._table.copy_(torch.from_numpy(host.copy()))
+        self._ring = [torch.empty((n_rec32,), dtype=torch.int32, pin_memory=True) for _ in range(8)]
+        for r in self._ring:
+            r.numpy()[...] = host[:n_rec32]
+        self._ring_ev, self._ring_at = [None] * len(self._ring), 0
         self._n_rec32, self._n_chunks = n_rec32, len(chunks)
         self._state_buf = torch.zeros((lib.rsdet_mt_sgd_state_bytes(self._n_chunks),), dtype=torch.uint8, device=dev)
         self._params_key = tuple(id(p) for p in params)
@@ -164,9 +167,18 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
                 gr = p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(gr)
             ptrs.append(gr.data_ptr())
         if ptrs != self._grad_ptrs:
-            self._pin_rec[:, 0] = ptrs
-            self._pin_rec[:, 5] = self._rec[:, 5] | self._gflag
-            self._table[:self._n_rec32].copy_(self._host[:self._n_rec32])    # staged synchronously (pageable source)
+            import numpy as np
+            k = self._ring_at
+            self._ring_at = (k + 1) % len(self._ring)
+            if self._ring_ev[k] is not None:
+                self._ring_ev[k].synchronize()        # the copy issued 8 steps ago out of this buffer: long done
+            rec = self._ring[k].numpy().view(np.int64).reshape(len(params), 8)
+            rec[:, 0] = ptrs
+            rec[:, 5] = self._rec[:, 5] | self._gflag
+            self._table[:self._n_rec32].copy_(self._ring[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ring_ev[k] = ev
             self._grad_ptrs = ptrs
         clip = float(self.grad_clip.get("max_norm", 35)) if getattr(self, "grad_clip", None) else 0.0
         if clip > 0:
