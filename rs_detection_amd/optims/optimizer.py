@@ -72,6 +72,22 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         self.lr = lr
         self._params_key = None
 
+    def load_state_dict(self, state_dict):
+        """torch's ``load_state_dict`` casts floating-point state to the PARAMETER's dtype: for a bf16 parameter that
+        would round the fp32 master and momentum (and hand the kernel 2-byte buffers).  The state of this optimizer is
+        fp32 whatever the parameter holds: put the saved tensors back unrounded."""
+        super().load_state_dict(state_dict)
+        saved_ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        params = [p for g in self.param_groups for p in g["params"]]
+        for sid, p in zip(saved_ids, params):
+            st = state_dict["state"].get(sid)
+            if st is None:
+                continue
+            for k, v in st.items():
+                if isinstance(v, torch.Tensor) and v.is_floating_point():
+                    self.state[p][k] = v.detach().to(device=p.device, dtype=torch.float32).clone()
+        self._params_key = None          # the device table points at the old state tensors
+
     def _ensure_state(self, p):
         st = self.state[p]
         if "momentum_buffer" not in st:
