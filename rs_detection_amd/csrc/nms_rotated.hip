@@ -24,8 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "rsdet_api_internal.h"
-#include "rsdet_geom.h"
+#include "rsdet_geom_fast.h"
 
 namespace rsdet {
 
@@ -101,7 +103,12 @@ __device__ __forceinline__ void nms_emit_entries(unsigned long long word, int la
   }
 }
 
-template <bool GE>
+// TWO_TIER (round 3, the default): the suppression bit of a pair is a DECISION (IoU against one threshold), so the
+// Green-integral IoU of rsdet_geom_fast.h (one lane per pair) settles every pair whose value is more than the budget away
+// from the threshold; the reference-order clipper only sees the pairs inside the budget, the pairs in the reference's
+// fragile zone (where its own value may be anything) and NaN boxes -- ~0.3 % of the pairs that reach this stage.  The bits,
+// hence `keep`, are those of the all-exact form.
+template <bool GE, bool TWO_TIER>
 __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restrict__ sorted, int n,
                                                           float thr, int col_blocks,
                                                           NmsEntry* __restrict__ entries,
@@ -173,7 +180,38 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
   }
   __syncthreads();
 
-  const int total = s_count2;
+  int total = s_count2;
+  if (TWO_TIER) {
+    // tier 1 on dense lanes; what it cannot decide is compacted in place for the clipper below (by the barrier every
+    // entry below q0 + NMS_NT has been read, and at most that many were kept)
+    __shared__ int s_count3;
+    if (tid == 0) s_count3 = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < total; q0 += NMS_NT) {
+      const int q = q0 + tid;
+      unsigned e = 0;
+      if (q < total) e = s_queue[q];
+      __syncthreads();
+      bool undecided = false;
+      if (q < total) {
+        const int i = e >> 6, j = e & 63;
+        bool danger, apart;
+        const float v = pair_iou_fast<0>(s_row[i].p, s_col[j].p, danger, apart);
+        // `apart`: the reference returns exactly 0 (a hit only for thr <= 0 with >=, which the budget test catches)
+        undecided = danger || !(fabsf(v - thr) > kFastBudget);          // NaN lands here too
+        if (!undecided && (GE ? (v >= thr) : (v > thr))) atomicOr(&s_mask[i], 1ull << j);
+      }
+      unsigned long long m = __ballot(undecided);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_count3, __popcll(m));
+        base = __shfl(base, 0);
+        if (undecided) s_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)e;
+      }
+    }
+    __syncthreads();
+    total = s_count3;
+  }
   const int quad = tid >> 2;
   F2* qscr = s_pts + quad * kQuadSlots;
   for (int q = quad; q < total; q += NMS_NT / 4) {  // four lanes per pair (rsdet_geom.h)
@@ -389,12 +427,19 @@ extern "C" int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, cons
   if (hipMemsetAsync(segs, 0, sizeof(int), s) != hipSuccess) return RSDET_ELAUNCH;
   hipLaunchKernelGGL(nms_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dets, n, box_len,
                      order, sorted, blk_cnt, blk_label, label_major, segs);
-  if (ge)
-    hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr, cb,
-                       entries, blk_cnt, diag_t, blk_label);
-  else
-    hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr,
-                       cb, entries, blk_cnt, diag_t, blk_label);
+  static const bool exact_all = [] {   // A/B switch: RSDET_NMS_EXACT=1 runs the reference-order clipper on every pair
+    const char* e = getenv("RSDET_NMS_EXACT");
+    return e && e[0] == '1';
+  }();
+#define RSDET_NMS_MASK(G, T)                                                                                       \
+  hipLaunchKernelGGL((nms_mask_kernel<G, T>), dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr, cb, entries, blk_cnt, \
+                     diag_t, blk_label)
+  if (ge) {
+    if (exact_all) RSDET_NMS_MASK(true, false); else RSDET_NMS_MASK(true, true);
+  } else {
+    if (exact_all) RSDET_NMS_MASK(false, false); else RSDET_NMS_MASK(false, true);
+  }
+#undef RSDET_NMS_MASK
   // one workgroup per label run (at most 64 in flight; more runs are walked in turn); idle workgroups exit at once
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(label_major ? 64 : 1), dim3(SWEEP_NT),
                      (size_t)(cb + 1) * 8 + (size_t)cb * 4, s, entries, blk_cnt, diag_t, n, cb, order, keep, segs);

@@ -279,7 +279,14 @@ class Runner:
 
     @torch.no_grad()
     def predict(self, images, targets):
+        """Inference in the dtype the model trains in: fp32, or bf16 autocast (with bf16 parameters the convolutions
+        need it: their weights ARE bf16)."""
         self.model.eval()
+        if self.memory_format is not None:
+            images = images.contiguous(memory_format=self.memory_format)
+        if self.amp_dtype is not None:
+            with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype):
+                return self.model(images, targets)
         return self.model(images, targets)
 
     def test_time(self, images, targets, warmup=10, iters=100):
