@@ -238,13 +238,18 @@ def kernel_rooflines(device, targets):
     order = torch.argsort(sc, descending=True, stable=True).int()
     M = 5344
     by = 4 * 6 * M + 2 * 8 * M * ((M + 63) // 64) + M
+    cnt = np.bincount(l.astype(np.int64))
+    same_cls = int((cnt * (cnt - 1) // 2).sum())
     for name, fn in (("nms_rotated(3 kernels; label-major order, as ml_nms_rotated calls it)",
                       lambda: ops.nms_rotated_keep_mask(d6, lorder, 0.1, 6, label_major=True)),
                      ("nms_rotated(3 kernels; plain score order, one sweep)",
                       lambda: ops.nms_rotated_keep_mask(d6, order, 0.1, 6))):
         t = event_time(fn, 10, 2)
+        # the ALU-side figure: candidate pairs the greedy rule is defined over (ordered pairs i < j of the same class:
+        # nms_rotated.py:73-120 tests exactly those) per second; the mask kernel culls most of them on centre distance
         out[name] = dict(bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6, mboxes_per_s=M / t / 1e6)
+                         frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6, mboxes_per_s=M / t / 1e6,
+                         same_class_pairs=same_cls, mpairs_per_s=same_cls / t / 1e6)
     out.update(bn_act_rows(device, len(ks)))
     out.update(next_row_kernels(device))
     return out

@@ -545,6 +545,23 @@ size_t rsdet_mt_sgd_state_bytes(int n_chunks);
 int rsdet_mt_sgd_step(const void* tensors, const int* chunks, int n_chunks, float max_norm, float lr, float momentum,
                       float weight_decay, float* sqnorm_out, void* state, size_t state_bytes, void* stream);
 
+/* ---- the pyramid canvas of the S2ANet head (csrc/canvas.hip) ----------------------------------------------------------
+ * The reference applies the head's shared-weight convolutions level by level
+ * (/root/reference/python/jdet/models/roi_heads/s2anet_head.py:207-255).  These entry points lay the L <= 8 level maps of
+ * a batch side by side in one (B, C, Hc, Wc) canvas with zero gaps, so that each convolution runs once:
+ *   pixmap:  canvas_pixels device ints, -1 for a gap pixel, else (level << 27) | pixel index inside that level;
+ *   rsdet_pyramid_copy: to_canvas != 0: canvas <- levels, gap pixels <- 0; to_canvas == 0: levels <- canvas.  Either side
+ *            NCHW (flag 0) or channels-last (flag 1); elem_bytes 2 or 4 (bits are copied, no conversion);
+ *   rsdet_canvas_bias_act_*: y = act(x + bias[c]) at live pixels (live[p] != 0), 0 at gap pixels; act = ReLU (relu != 0)
+ *            or identity.  nhwc: C % 4 == 0.  Backward of the ReLU form = rsdet_bn_act_backward_* gated on y > 0. */
+int rsdet_pyramid_copy(void* const* levels, const int* level_pixels, int n_levels, void* canvas, const int* pixmap, int B,
+                       int C, int canvas_pixels, int elem_bytes, int canvas_nhwc, int levels_nhwc, int to_canvas,
+                       void* stream);
+int rsdet_canvas_bias_act_f32(const float* x, const float* bias, const uint8_t* live, int N, int C, int HW, int relu,
+                              int nhwc, float* y, void* stream);
+int rsdet_canvas_bias_act_bf16(const uint16_t* x, const float* bias, const uint8_t* live, int N, int C, int HW, int relu,
+                               int nhwc, uint16_t* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

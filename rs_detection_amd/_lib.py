@@ -95,6 +95,12 @@ SIGNATURES = {
     "rsdet_transpose_last2_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rsdet_mt_chunk_elems": (c_int, []),
     "rsdet_mt_sgd_state_bytes": (c_size_t, [c_int]),
+    "rsdet_pyramid_copy": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsdet_canvas_bias_act_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_void_p]),
+    "rsdet_canvas_bias_act_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                           c_void_p]),
     "rsdet_mt_sgd_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
     "rsdet_colsum_ws_size": (c_size_t, [c_ll, c_int]),

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
                                                           NmsEntry* __restrict__ entries,
                                                           unsigned* __restrict__ blk_cnt,
                                                           unsigned long long* __restrict__ diag_t,
-                                                          const float2* __restrict__ blk_label) {
+                                                          const float2* __restrict__ blk_label, int no_cull) {
+  // no_cull: ">= thr" with thr <= 0 -- the reference's CPU loop (nms_rotated.py:443-444) then suppresses on an IoU of
+  // exactly 0 too, i.e. disjoint pairs count: the disjointness filters below must not drop them.
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;  // lower triangle never read by the sweep
   if (cbk != rb) {       // label ranges apart: no pair of this tile passes the label gate (diagonal tiles always run:
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
     bool cand = false;
     if (lane < cols) {
       bool later = (cbk > rb) || (lane > i);
-      cand = later && s_row[i].label == s_col[lane].label && !surely_disjoint(s_row[i].p, s_col[lane].p);
+      cand = later && s_row[i].label == s_col[lane].label && (no_cull || !surely_disjoint(s_row[i].p, s_col[lane].p));
     }
     unsigned long long m = __ballot(cand);
     if (m) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_mask_kernel(const NmsBox* __restri
     unsigned e = 0;
     if (q < n_cand) e = s_queue[q];
     __syncthreads();
-    const bool keep = q < n_cand && !sat_disjoint<0>(s_row[e >> 6].p, s_col[e & 63].p);
+    const bool keep = q < n_cand && (no_cull || !sat_disjoint<0>(s_row[e >> 6].p, s_col[e & 63].p));
     unsigned long long m = __ballot(keep);
     if (m) {
       int base = 0;
@@ -433,7 +435,7 @@ extern "C" int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, cons
   }();
 #define RSDET_NMS_MASK(G, T)                                                                                       \
   hipLaunchKernelGGL((nms_mask_kernel<G, T>), dim3(cb, cb), dim3(NMS_NT), 0, s, sorted, n, thr, cb, entries, blk_cnt, \
-                     diag_t, blk_label)
+                     diag_t, blk_label, (ge && !(thr > 0.f)) ? 1 : 0)
   if (ge) {
     if (exact_all) RSDET_NMS_MASK(true, false); else RSDET_NMS_MASK(true, true);
   } else {

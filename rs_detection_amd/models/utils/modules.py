@@ -103,11 +103,19 @@ class ConvModule(nn.Module):
                      or (_FUSE_BIAS_RELU_AMP and torch.is_autocast_enabled() and x.dim() == 4 and not x.is_contiguous()
                          and x.is_contiguous(memory_format=torch.channels_last))))
 
-    def forward(self, x, activate=True, norm=True):
+    def forward(self, x, activate=True, norm=True, canvas=None):
+        """``canvas``: x is a pyramid canvas (ops/pyramid.CanvasLayout) -- the output's gap pixels are put back to zero
+        so that the next convolution of the tower sees each level's zero padding."""
         if self._fused_bias_relu(x, activate):
             conv = self.conv
             y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if canvas is not None:
+                from rs_detection_amd.ops.pyramid import canvas_bias_act
+                return canvas_bias_act(y, conv.bias, canvas, relu=True)
             return bias_act(y, conv.bias, relu=True)
+        if canvas is not None:
+            out = self.forward(x, activate, norm)
+            return out * canvas.live_f.to(out.dtype)
         for layer in self.order:
             if layer == 'conv':
                 x = self.conv(x)

@@ -198,6 +198,36 @@ def test_nms_suppression_chains_and_dense_blocks(cuda, oracle_c):
     assert (got == want).all(), int((got != want).sum())
 
 
+def test_nms_two_tier_decisions_at_the_threshold(cuda, oracle_c):
+    """The mask kernel settles a pair from the Green-integral IoU only when that sits further than the tier budget from
+    the threshold and no corner lies on an edge (csrc/nms_rotated.hip, rsdet_geom_fast.h); everything else goes through
+    the reference-order clipper.  Families built to sit ON the threshold: integer boxes (IoU exactly 1/4, 1/3, 1/2 for
+    thousands of pairs, and the reference's hull scan dropping a vertex on shared edges), 3-4-5 rotations, and
+    near-copies of the same box (IoU ~ 1, corners within 1e-5 .. 1e-2 px of the other box's edges)."""
+    from rs_detection_amd.ops import nms_rotated_keep_mask
+    rng = np.random.default_rng(77)
+    n = 1500
+    ib = np.stack([rng.integers(0, 60, n), rng.integers(0, 60, n), rng.integers(1, 12, n) * 2,
+                   rng.integers(1, 12, n) * 2, rng.choice([0, np.pi / 2, np.pi, -np.pi / 2], n)], 1).astype(np.float32)
+    ib345 = ib.copy()
+    ang = np.arctan2(3, 4)
+    ib345[:, 4] = rng.choice([ang, -ang, ang + np.pi / 2, 0], n)
+    base = dota_boxes(rng, 300, 400)
+    near = np.concatenate([base] + [(base + rng.normal(0, e, base.shape)).astype(np.float32)
+                                    for e in (1e-5, 1e-3, 1e-2, 0.3)])
+    n_dec = 0
+    for name, d, thrs in (("integer", ib, (0.25, 1 / 3, 0.5, 0.2, 0.1, 0.0)),
+                          ("3-4-5", ib345, (0.25, 1 / 3, 0.5, 0.1)),
+                          ("near copies", near, (0.5, 0.9, 0.99, 0.999, 1.0))):
+        order = rng.permutation(d.shape[0]).astype(np.int32)
+        for thr in thrs:
+            want = oracle_c.nms_rotated(d, order, np.float32(thr))
+            got = nms_rotated_keep_mask(_t(d, cuda), _t(order, cuda), float(np.float32(thr)), 5).cpu().numpy()
+            assert (got == want).all(), (name, thr, int((got != want).sum()))
+            n_dec += int(want.sum())
+    assert n_dec > 1000
+
+
 @pytest.mark.parametrize("n,n_labels", [(700, 3), (3000, 15), (3000, 200), (500, 1), (130, 130)])
 def test_nms_label_major_order_and_segmented_sweep(cuda, oracle_c, n, n_labels):
     """Class-aware NMS with the label-major order (tiles of disjoint label ranges skipped, one concurrent sweep per

@@ -1,0 +1,241 @@
+"""GPU: the pyramid canvas (csrc/canvas.hip, ops/pyramid.py) and the S2ANet head's canvas path against the reference's
+per-level loop (/root/reference/python/jdet/models/roi_heads/s2anet_head.py:207-255 -- forward_single under
+multi_apply, kept in the product as S2ANetHead.forward_single).
+
+pack / unpack are copies: bit-exact against torch slicing, both directions, both memory formats, 2- and 4-byte elements,
+ragged (non-square, odd) level sizes.  The head: same weights through forward_packed and through the level loop ->
+the same 25 maps and the same gradients (every parameter + every FPN input), to convolution round-off in fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SIZES = [[(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)],
+         [(25, 38), (13, 19), (7, 10), (4, 5), (2, 3)],           # a 200 x 300 image: odd, non-square, ragged
+         [(16, 16), (8, 8)],
+         [(5, 40), (3, 20), (2, 10), (1, 5), (1, 3), (1, 2), (1, 1), (1, 1)]]
+
+
+def _slice_pack(levels, lay):
+    B, C = levels[0].shape[:2]
+    c = torch.zeros((B, C, lay.Hc, lay.Wc), dtype=levels[0].dtype, device=levels[0].device)
+    for t, (y0, x0, h, w) in zip(levels, lay.rects):
+        c[:, :, y0:y0 + h, x0:x0 + w] = t
+    return c
+
+
+@pytest.mark.parametrize("sizes", SIZES)
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 16), (torch.bfloat16, 8), (torch.float32, 5), (torch.bfloat16, 15)])
+def test_pack_unpack_are_exact_copies(cuda, sizes, dtype, C):
+    from rs_detection_amd.ops.pyramid import canvas_layout, pyramid_pack, pyramid_unpack
+    lay = canvas_layout(sizes, cuda)
+    assert (lay.Hc * lay.Wc) % 4 == 0 and 0.25 < lay.fill <= 1.0
+    # levels never touch or overlap: every pair of rects is separated by at least one gap pixel
+    pm = lay.pixmap.view(lay.Hc, lay.Wc).cpu().numpy()
+    lvl = np.where(pm >= 0, pm >> 27, -1)
+    for dy, dx in ((0, 1), (1, 0), (1, 1), (1, -1)):
+        a = lvl[max(dy, 0):, max(dx, 0):lvl.shape[1] + min(dx, 0)]
+        b = lvl[:lvl.shape[0] - dy, max(-dx, 0):lvl.shape[1] - max(dx, 0)]
+        assert not ((a >= 0) & (b >= 0) & (a != b)).any()
+    g = torch.Generator(device="cpu").manual_seed(len(sizes) * 100 + C)
+    B = 3
+    levels = [torch.randn((B, C, h, w), generator=g).to(cuda).to(dtype) for h, w in sizes]
+    want = _slice_pack(levels, lay)
+    for cl_in in (False, True):
+        lv = [t.contiguous(memory_format=torch.channels_last) for t in levels] if cl_in else levels
+        for cl_canvas in (False, True):
+            canvas = pyramid_pack(lv, lay, channels_last=cl_canvas)
+            assert canvas.is_contiguous(memory_format=torch.channels_last if cl_canvas else torch.contiguous_format)
+            assert torch.equal(canvas, want), (cl_in, cl_canvas)
+            for cl_out in (False, True):
+                back = pyramid_unpack(canvas, lay, channels_last=cl_out)
+                assert all(torch.equal(a, b) for a, b in zip(back, levels)), (cl_in, cl_canvas, cl_out)
+
+
+def test_pack_unpack_gradients(cuda):
+    from rs_detection_amd.ops.pyramid import canvas_layout, pyramid_pack, pyramid_unpack
+    sizes = SIZES[1]
+    lay = canvas_layout(sizes, cuda)
+    torch.manual_seed(3)
+    levels = [torch.randn((2, 8, h, w), device=cuda, requires_grad=True) for h, w in sizes]
+    wc = torch.randn((2, 8, lay.Hc, lay.Wc), device=cuda)
+    (pyramid_pack(levels, lay) * wc).sum().backward()
+    for t, (y0, x0, h, w) in zip(levels, lay.rects):
+        assert torch.equal(t.grad, wc[:, :, y0:y0 + h, x0:x0 + w])
+    canvas = torch.randn((2, 8, lay.Hc, lay.Wc), device=cuda, requires_grad=True)
+    out = pyramid_unpack(canvas, lay)
+    ws = [torch.randn_like(o) for o in out]
+    sum((o * w).sum() for o, w in list(zip(out, ws))[:-1]).backward()      # the last level unused: its gradient is zero
+    want = _slice_pack(ws[:-1] + [torch.zeros_like(ws[-1])], lay)
+    assert torch.equal(canvas.grad, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
+@pytest.mark.parametrize("relu", [True, False])
+def test_canvas_bias_act_matches_torch(cuda, dtype, cl, relu):
+    from rs_detection_amd.ops.pyramid import canvas_layout, canvas_bias_act
+    lay = canvas_layout(SIZES[1], cuda)
+    torch.manual_seed(11)
+    C = 32
+    x = torch.randn((2, C, lay.Hc, lay.Wc), device=cuda).to(dtype)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    bias = torch.randn(C, device=cuda, requires_grad=True)
+    y = canvas_bias_act(x, bias, lay, relu)
+    ref = x.detach().float() + bias.detach()[None, :, None, None]
+    ref = (torch.relu(ref) if relu else ref) * lay.live_f
+    assert torch.equal(y.float(), ref.to(dtype).float())
+    assert (y[:, :, lay.live_f[0, 0] == 0] == 0).all()
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    gate = (ref > 0).float() if relu else lay.live_f.expand_as(ref)
+    gx = gy.float() * gate
+    assert torch.equal(x.grad.float(), gx.to(dtype).float())
+    np.testing.assert_allclose(bias.grad.cpu().numpy(), gx.sum((0, 2, 3)).cpu().numpy(), rtol=2e-3 if dtype == torch.bfloat16 else 1e-5,
+                               atol=1e-4)
+
+
+def _head(cuda, all_positive=False):
+    """``all_positive``: tower biases of +3 under the shipped small weights keep every pre-activation positive, so no
+    ReLU gate can flip between the two paths on a 1e-6 difference -- gradients then agree to round-off everywhere, and
+    the gap pixels (also positive before masking) exercise the canvas epilogue's zeroing.  Otherwise: weights x 4 so the
+    ReLUs bite; a handful of gates flip, so gradients are compared in the L2 norm."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.utils.registry import HEADS, build_from_cfg
+    cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
+    torch.manual_seed(0)
+    head = build_from_cfg(cfg.model["bbox_head"], HEADS).to(cuda)
+    with torch.no_grad():
+        if all_positive:
+            for m in list(head.fam_reg_convs) + list(head.fam_cls_convs) + list(head.odm_reg_convs) + list(head.odm_cls_convs):
+                m.conv.bias.fill_(3.0)
+                m.conv.weight.mul_(0.1)
+            head.align_conv.deform_conv.weight.abs_().mul_(0.1)      # positive inputs (the test's) -> positive outputs
+            head.or_conv.bias.fill_(1.0)
+        else:
+            for p in head.parameters():
+                if p.requires_grad and p.dim() > 1:
+                    p.mul_(4.0)
+    return head
+
+
+def _run(head, feats, packed, train):
+    head.train(train)
+    for p in head.parameters():
+        p.grad = None
+    xs = [f.clone().requires_grad_(True) for f in feats]
+    if packed:
+        os.environ["RSDET_S2A_GROUPS"] = packed
+        try:
+            outs = head.forward_levels(xs)
+        finally:
+            del os.environ["RSDET_S2A_GROUPS"]
+    else:
+        outs = tuple(map(list, zip(*[head.forward_single(x, s) for x, s in zip(xs, head.anchor_strides)])))
+    maps = [m for group in outs for m in group if m is not None]
+    if train:
+        torch.manual_seed(5)
+        loss = sum((m.float() * torch.randn_like(m.float())).sum() for m in maps if m.requires_grad)
+        loss.backward()
+    grads = {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
+    return maps, [x.grad for x in xs], grads
+
+
+def _rel_l2(a, b):
+    return float((a.detach() - b.detach()).norm()) / (float(a.detach().norm()) + 1e-12)
+
+
+@pytest.mark.parametrize("sizes", [SIZES[0], SIZES[1]])
+@pytest.mark.parametrize("train,all_positive", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("groups", ["all", "split"])
+def test_head_canvas_path_equals_the_level_loop_fp32(cuda, sizes, train, all_positive, groups):
+    head = _head(cuda, all_positive)
+    torch.manual_seed(1)
+    B = 2
+    feats = [torch.randn((B, 256, h, w), device=cuda) for h, w in sizes]
+    if all_positive:
+        feats = [f.abs() * 0.5 for f in feats]
+    assert head._packed_ok(feats)
+    with torch.set_grad_enabled(train):
+        m_loop, gx_loop, gp_loop = _run(head, feats, False, train)
+        m_can, gx_can, gp_can = _run(head, feats, groups, train)
+    assert len(m_loop) == len(m_can) == (25 if train else 20)
+    for a, b in zip(m_loop, m_can):
+        assert a.shape == b.shape
+        scale = float(a.detach().abs().max()) + 1e-6
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-4 * scale, (a.shape, scale)
+    if train:
+        assert set(gp_loop) == set(gp_can) and len(gp_loop) >= 26
+        # all_positive: no ReLU gate can flip -> agreement to round-off at every element.  Otherwise some gates flip on
+        # 1e-7 differences of their pre-activations and each moves the gradients of its (six layers deep) receptive
+        # field: the L2 distance stays small, single elements do not
+        for a, b in zip(gx_loop, gx_can):
+            scale = float(a.abs().max())
+            assert scale > 0
+            if all_positive:
+                assert float((a - b).abs().max()) <= 3e-3 * scale      # sums of positive terms: cancellation
+            else:
+                assert _rel_l2(a, b) <= 5e-2
+        for n in gp_loop:
+            assert _rel_l2(gp_loop[n], gp_can[n]) <= (3e-3 if all_positive else 5e-2), n
+
+
+def test_head_canvas_path_bf16_channels_last(cuda):
+    """The bf16 step's form: channels_last bf16 maps under autocast.  One canvas convolution and five level
+    convolutions go to different MIOpen solvers (some round their bf16 outputs to nearest, the assembly implicit-GEMM
+    ones truncate), so the two bf16 results differ by bf16 round-off -- the yardstick is the fp32 result of the same
+    weights: the canvas path's distance from it stays within 2.5 x the level loop's, map by map."""
+    head = _head(cuda, False)
+    with torch.no_grad():
+        for p in head.parameters():
+            if p.requires_grad and p.dim() > 1:
+                p.mul_(0.5)                       # x 2 over the shipped init
+    torch.manual_seed(2)
+    feats = [torch.randn((2, 256, h, w), device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+             for h, w in SIZES[0]]
+    truth, _, gt = _run(head, [f.float().contiguous() for f in feats], False, True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        m_loop, _, gp_loop = _run(head, feats, False, True)
+        m_all, _, gp_all = _run(head, feats, "all", True)
+        m_split, _, gp_split = _run(head, feats, "split", True)
+    for m_can, gp_can in ((m_all, gp_all), (m_split, gp_split)):
+        for t, a, b in zip(truth, m_loop, m_can):
+            t, a, b = t.detach().float(), a.detach().float(), b.detach().float()
+            e_loop, e_can = float((a - t).abs().mean()), float((b - t).abs().mean())
+            assert e_can <= 2.5 * e_loop + 1e-6 * float(t.abs().mean()), (tuple(t.shape), e_loop, e_can)
+        for n in gp_loop:
+            e_loop, e_can = _rel_l2(gt[n], gp_loop[n].float()), _rel_l2(gt[n], gp_can[n].float())
+            assert e_can <= 2.5 * e_loop + 1e-3, (n, e_loop, e_can)
+
+
+def test_model_train_step_uses_the_canvas(cuda, monkeypatch):
+    """The whole S2ANet model: the step goes through forward_packed by default and through the loop with
+    RSDET_S2A_PACKED=0, same losses."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.utils.registry import MODELS, build_from_cfg
+    from rs_detection_amd.utils.synthetic import synthetic_targets
+    cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
+    torch.manual_seed(0)
+    model = build_from_cfg(cfg.model, MODELS).to(cuda).train()
+    imgs = torch.randn((2, 3, 256, 256), device=cuda)
+    targets = synthetic_targets(2, img=256)
+    calls = []
+    orig = type(model.bbox_head).forward_packed
+    monkeypatch.setattr(type(model.bbox_head), "forward_packed", lambda self, f, **kw: calls.append(1) or orig(self, f, **kw))
+    out_c = model(imgs, targets)
+    assert calls == [1]
+    monkeypatch.setenv("RSDET_S2A_PACKED", "0")
+    out_l = model(imgs, targets)
+    assert calls == [1]
+    for k in out_l:
+        a = torch.stack(list(out_l[k])) if isinstance(out_l[k], (list, tuple)) else out_l[k]
+        b = torch.stack(list(out_c[k])) if isinstance(out_c[k], (list, tuple)) else out_c[k]
+        assert torch.allclose(a, b, rtol=2e-3, atol=1e-5), (k, a, b)
