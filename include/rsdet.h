@@ -276,6 +276,14 @@ int rsdet_arf_forward_f32(const float* weight, const uint8_t* indices, int O, in
 int rsdet_arf_backward_f32(const uint8_t* indices, const float* grad_out, int O, int I, int nOri,
                            int kH, int kW, int nRot, float* grad_weight, void* stream);
 
+/* RotationInvariantPooling (ops/orn.py:595-617 of the reference): y[n,f,p] = max_k x[n, f*nOri + k, p] over the nOri
+ * orientation channels; x (N, F*nOri, H, W), y (N, F, H, W), both NCHW (nhwc = 0) or both channels-last (nhwc = 1);
+ * bf16 != 0: 2-byte bfloat16 elements, else float.  Backward: the gradient is shared equally by tied maxima (the rule of
+ * the torch.amax this replaces). */
+int rsdet_ori_maxpool_forward(const void* x, int bf16, int N, int F, int nOri, int HW, int nhwc, void* y, void* stream);
+int rsdet_ori_maxpool_backward(const void* x, const void* grad_y, int bf16, int N, int F, int nOri, int HW, int nhwc,
+                               void* grad_x, void* stream);
+
 /* ---- 8(f)4  rotation-invariant encoding ------------------------------------------------------
  * Replaces rie_forward / rie_backward: ops/orn.py:516-540 (CPU kernels :290-363).  feature / aligned /
  * grad (nBatch, nFeature*nOri) fp32 [H = W = 1]; direction (nBatch, nFeature) uint8 = first arg-max over

@@ -76,6 +76,9 @@ SIGNATURES = {
     "rsdet_s2a_refine_and_offset_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                                 ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float,
                                                 c_void_p, c_void_p, c_void_p]),
+    "rsdet_ori_maxpool_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_ori_maxpool_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                           c_void_p]),
     "rsdet_arf_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p]),
     "rsdet_arf_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -394,6 +394,7 @@ class S2ANetHead(nn.Module):
         neighbour on the canvas), so it stays per level and reads the FPN maps themselves.  Same outputs as the loop:
         five lists of per-level maps.  ``feats`` are the maps of levels first_level, first_level + 1, ..."""
         from rs_detection_amd.ops.pyramid import canvas_layout, pyramid_pack, pyramid_unpack, canvas_bias_act
+        from rs_detection_amd.ops.bn_act import conv2d_bias
         import torch.nn.functional as F
         sizes = [tuple(f.shape[-2:]) for f in feats]
         strides = self.anchor_strides[first_level:first_level + len(feats)]
@@ -402,12 +403,12 @@ class S2ANetHead(nn.Module):
         reg = xc
         for conv in self.fam_reg_convs:
             reg = conv(reg, canvas=lay)
-        fam_bbox_preds = pyramid_unpack(self.fam_reg(reg), lay)
+        fam_bbox_preds = pyramid_unpack(conv2d_bias(self.fam_reg, reg), lay)
         if self.training:
             cls = xc
             for conv in self.fam_cls_convs:
                 cls = conv(cls, canvas=lay)
-            fam_cls_scores = pyramid_unpack(self.fam_cls(cls), lay)
+            fam_cls_scores = pyramid_unpack(conv2d_bias(self.fam_cls, cls), lay)
         else:
             fam_cls_scores = [None] * len(feats)
         refine_anchors, align = [], []
@@ -431,8 +432,8 @@ class S2ANetHead(nn.Module):
             odm_reg_feat = conv(odm_reg_feat, canvas=lay)
         for conv in self.odm_cls_convs:
             odm_cls_feat = conv(odm_cls_feat, canvas=lay)
-        odm_cls_scores = pyramid_unpack(self.odm_cls(odm_cls_feat), lay)
-        odm_bbox_preds = pyramid_unpack(self.odm_reg(odm_reg_feat), lay)
+        odm_cls_scores = pyramid_unpack(conv2d_bias(self.odm_cls, odm_cls_feat), lay)
+        odm_bbox_preds = pyramid_unpack(conv2d_bias(self.odm_reg, odm_reg_feat), lay)
         return fam_cls_scores, fam_bbox_preds, refine_anchors, odm_cls_scores, odm_bbox_preds
 
     def _level_groups(self, n, dtype=torch.float32):

@@ -144,7 +144,40 @@ class RotationInvariantPooling(nn.Module):
 
     def forward(self, x):
         N, c, h, w = x.size()
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and c % self.nOrientation == 0 and \
+                (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+            return _OriMaxPool.apply(x, self.nOrientation)
         return x.view(N, -1, self.nOrientation, h, w).amax(dim=2)
+
+
+class _OriMaxPool(torch.autograd.Function):
+    """max over the orientation channels as one pass each way (csrc/arf.hip: ori_maxpool_*), NCHW or channels_last,
+    fp32 or bf16; gradients shared equally by tied maxima like the torch.amax it replaces."""
+
+    @staticmethod
+    def forward(ctx, x, nori):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        nhwc = not x.is_contiguous()
+        y = torch.empty((N, C // nori, H, W), dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+        _lib.check(lib.rsdet_ori_maxpool_forward(_lib.ptr(x), int(x.dtype == torch.bfloat16), N, C // nori, nori, H * W,
+                                                 int(nhwc), _lib.ptr(y), _lib.stream_ptr()), "rsdet_ori_maxpool_forward")
+        ctx.save_for_backward(x)
+        ctx.nori, ctx.nhwc = nori, nhwc
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last if ctx.nhwc else torch.contiguous_format).to(x.dtype)
+        gx = torch.empty_like(x)
+        _lib.check(lib.rsdet_ori_maxpool_backward(_lib.ptr(x), _lib.ptr(gy), int(x.dtype == torch.bfloat16), N,
+                                                  C // ctx.nori, ctx.nori, H * W, int(ctx.nhwc), _lib.ptr(gx),
+                                                  _lib.stream_ptr()), "rsdet_ori_maxpool_backward")
+        return gx, None
 
 
 _KERNEL_INDICES = {

@@ -239,3 +239,27 @@ def test_model_train_step_uses_the_canvas(cuda, monkeypatch):
         a = torch.stack(list(out_l[k])) if isinstance(out_l[k], (list, tuple)) else out_l[k]
         b = torch.stack(list(out_c[k])) if isinstance(out_c[k], (list, tuple)) else out_c[k]
         assert torch.allclose(a, b, rtol=2e-3, atol=1e-5), (k, a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cl", [False, True])
+def test_orientation_maxpool_matches_amax(cuda, dtype, cl):
+    """RotationInvariantPooling (orn.py:595-617) through csrc/arf.hip == torch.amax over the orientation axis, values
+    and gradients, with ties (bf16 makes them common; zeros at canvas gaps make them certain)."""
+    from rs_detection_amd.ops.orn import RotationInvariantPooling
+    torch.manual_seed(4)
+    x = torch.randn((3, 64, 9, 13), device=cuda).to(dtype)
+    x[:, :, 2:4] = 0                                     # all-equal groups
+    x[:, 8:16, 5] = x[:, 8:9, 5]                         # one tied group per pixel of row 5
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    pool = RotationInvariantPooling(64, 8).to(cuda)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = pool(xa)
+    ref = xb.view(3, 8, 8, 9, 13).amax(dim=2)
+    assert y.shape == ref.shape and torch.equal(y, ref)
+    g = torch.randn_like(ref)
+    y.backward(g)
+    ref.backward(g)
+    assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-6)
+    assert ((xa.grad != 0) == (xb.grad != 0)).all()
