@@ -453,13 +453,16 @@ def main():
                          "model of configs[3] (RROIAlign + rotated NMS in the train step), 2 tiles per GPU as in the "
                          "reference config; reported under its own workload name, no kernel table")
     ap.add_argument("--memory-format", choices=["channels_last", "contiguous", "trunk_channels_last"], default=None,
-                    help="activation layout of the torch/MIOpen part.  Default: contiguous (NCHW) for f32 -- MIOpen's fp32 "
-                         "Winograd kernels are NCHW-native (channels_last measured 494 vs 68.7 ms/step in round 1) -- and "
-                         "channels_last for bf16, whose MIOpen kernels are NHWC-native (round 2, with the NHWC BatchNorm "
-                         "tails and tuned records: 26.8 vs 28.3 ms/step)")
+                    help="activation layout of the torch/MIOpen part.  Default: channels_last for the S2ANet models in "
+                         "both dtypes.  bf16: MIOpen's bf16 kernels are NHWC-native (round 2: 26.8 vs 28.3 ms/step).  f32: "
+                         "with find records for the NHWC shapes MIOpen runs its fp32 MFMA implicit-GEMM kernels without "
+                         "layout transposes, 52.5 vs 55.3 ms/step (round 3; on heuristics the same layout was 494 ms in "
+                         "round 1 -- the packaged records are what makes it the faster one).  contiguous for the others")
     args = ap.parse_args()
     if args.memory_format is None:
-        args.memory_format = "channels_last" if (args.dtype == "bf16" and args.model.startswith("s2anet")) else "contiguous"
+        # (the R101 trunk has fp32 NHWC records for none of its layer3 shapes: it stays NCHW in f32)
+        args.memory_format = "channels_last" if (args.model == "s2anet_r50" or (
+            args.dtype == "bf16" and args.model.startswith("s2anet"))) else "contiguous"
 
     from rs_detection_amd.utils import dist as rdist
     from rs_detection_amd.utils import synthetic as syn
