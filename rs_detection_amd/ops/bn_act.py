@@ -151,8 +151,10 @@ def conv2d_bias(conv, x):
     the convolution without its bias and the bias as a separate pass whose backward is OUR reduction: the fused
     NHWC bias pass (``bias_act(relu=False)``) for the wide maps, torch's add + rsdet_colsum for maps with few channels.
     Everything else: the module itself."""
+    fp32_few = (not torch.is_autocast_enabled() and x.dtype == torch.float32 and conv.out_channels <= 64
+                and conv.bias is not None and conv.bias.dtype == torch.float32)   # the fp32 step in channels_last
     if (type(conv) is torch.nn.Conv2d and conv.bias is not None and conv.padding_mode == 'zeros' and x.is_cuda
-            and x.dim() == 4 and torch.is_autocast_enabled() and not x.is_contiguous()
+            and x.dim() == 4 and (torch.is_autocast_enabled() or fp32_few) and not x.is_contiguous()
             and x.is_contiguous(memory_format=torch.channels_last) and not _NO_FUSED_BN):
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if y.is_contiguous(memory_format=torch.channels_last) or y.shape[1] == 1:

@@ -171,14 +171,18 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
             # exact-fp32 implicit GEMM (csrc/alignconv_mfma.hip, v_mfma_f32_32x32x2_f32): one launch, the sampled columns
             # written once channels-last (bit-identical to the im2col kernel's) for the weight gradient
             lib = _lib.load()
+            # a channels_last input (the fp32 step in channels_last) is consumed as it is and answered in kind: no
+            # layout copies either way, and the backward below works on (positions, channels) views
+            ctx.cl = not input.is_contiguous() and input.is_contiguous(memory_format=torch.channels_last)
             x_nhwc = nchw_to_nhwc(input)
             w_t = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C).contiguous()
-            out = torch.empty((B, O, Ho, Wo), dtype=input.dtype, device=input.device)
+            out = torch.empty((B, O, Ho, Wo), dtype=input.dtype, device=input.device,
+                              memory_format=torch.channels_last if ctx.cl else torch.contiguous_format)
             colT = (torch.empty((B * hw, kh * kw * C), dtype=input.dtype, device=input.device)
                     if ctx.needs_input_grad[2] else None)
             off = offset.contiguous()
-            _lib.check(lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_t), geom, O, 0,
-                                                        _lib.ptr(out), _lib.ptr(colT), _lib.stream_ptr()),
+            _lib.check(lib.rsdet_alignconv_fwd_mfma_f32(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_t), geom, O,
+                                                        int(ctx.cl), _lib.ptr(out), _lib.ptr(colT), _lib.stream_ptr()),
                        "rsdet_alignconv_fwd_mfma_f32")
             ctx.col_is_T = True
             ctx.save_for_backward(off, weight, colT)
@@ -204,6 +208,8 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
         B, C, H, W = ctx.in_shape
         O, _, kh, kw = weight.shape
         cdt = torch.bfloat16 if ctx.lowp else weight.dtype
+        if getattr(ctx, "cl", False):
+            return DeformConvFunctionNHWC._backward_channels_last(ctx, grad_output)
         go = grad_output.contiguous().to(cdt).view(B, O, -1)  # (B, O, Ho*Wo)
         hw = go.shape[2]
         grad_input = grad_weight = None
@@ -234,6 +240,40 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
                 parts = torch.bmm(go2.view(O, J, k).permute(1, 0, 2), col.view(C * kh * kw, J, k).permute(1, 2, 0))
                 grad_weight = (parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()).view_as(weight)
         return grad_input, None, grad_weight, None, None, None, None, None
+
+
+def _dcn_backward_channels_last(ctx, grad_output):
+    """Backward of the channels_last fp32 implicit-GEMM forward: the same three products as the NCHW form on
+    (positions, channels) views of the channels_last gradient -- no transposed copies -- and a channels_last result."""
+    offset, weight, colT = ctx.saved_tensors
+    stride, padding, dilation, dg = ctx.cfg
+    B, C, H, W = ctx.in_shape
+    O, _, kh, kw = weight.shape
+    go = grad_output.permute(0, 2, 3, 1)
+    if not go.is_contiguous():
+        go = go.contiguous()
+    go = go.reshape(-1, O).to(weight.dtype)                       # (P, O)
+    grad_input = grad_weight = None
+    if ctx.needs_input_grad[0]:
+        w_ok = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C)
+        gcolT = torch.mm(go, w_ok)                                 # (P, kh*kw*C)
+        if dg == 1:
+            gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation)
+        else:
+            gi = deformable_col2im_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation, dg)
+        grad_input = gi.permute(0, 3, 1, 2)                        # channels_last storage, NCHW shape
+    if ctx.needs_input_grad[2]:
+        if colT is None:
+            raise RuntimeError("AlignConv: the weight gradient needs the columns of a forward run with grad enabled")
+        P = go.shape[0]
+        J = 16 if P % 16 == 0 and P >= 4096 else 1
+        parts = torch.bmm(go.view(J, P // J, O).transpose(1, 2), colT.view(J, P // J, kh * kw * C))
+        gw = parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()
+        grad_weight = gw.view(O, kh, kw, C).permute(0, 3, 1, 2).contiguous()
+    return grad_input, None, grad_weight, None, None, None, None, None
+
+
+DeformConvFunctionNHWC._backward_channels_last = staticmethod(_dcn_backward_channels_last)
 
 
 # AlignConv on the bf16 matrix cores as an implicit GEMM (csrc/alignconv_mfma.hip); RSDET_ALIGNCONV_MFMA=0 keeps the

@@ -85,7 +85,7 @@ def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
             warnings.simplefilter("ignore")
             r = Runner(cfg, device=cuda, distributed=False, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
                        bf16_params=mode)
-        assert r.bf16_params == mode and (type(r.optimizer).__name__ == ("FusedSGD" if mode else "SGD"))
+        assert r.bf16_params == mode and type(r.optimizer).__name__ == "FusedSGD"
         runs[mode] = (r, [r.train_step(images, targets) for _ in range(3)])
     rb = runs[True][0]
     assert rb.model.backbone.conv1.weight.dtype == torch.bfloat16 and rb.model.backbone.bn1.weight.dtype == torch.float32
@@ -123,3 +123,40 @@ def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
     assert torch.equal(rc.optimizer.state[w]["master"], m) and torch.equal(w.detach(), m.to(torch.bfloat16))
     t3, _ = rc.train_step(images, targets)
     assert np.isfinite(float(t3))
+
+
+def test_runner_fp32_fused_sgd_tracks_torch_sgd(cuda, monkeypatch):
+    """The fp32 Runner takes FusedSGD by default; RSDET_FUSED_SGD=0 restores torch.optim.SGD + clip_grad_norm_.  Same
+    arithmetic: after three steps from the same seed the parameters agree to fp32 round-off of the (atomic, hence not
+    bit-reproducible) weight-gradient kernels."""
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.runner.runner import Runner
+    from rs_detection_amd.utils import synthetic as syn
+    import warnings
+    cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
+    images = torch.randn(2, 3, 256, 256, device=cuda)
+    targets = []
+    for t in syn.synthetic_targets(2, img=256):
+        t = dict(t)
+        t["rboxes"], t["labels"] = torch.from_numpy(t["rboxes"][:20]).to(cuda), torch.from_numpy(t["labels"][:20]).to(cuda)
+        targets.append(t)
+    out = {}
+    for tag, fused in (("fused", "1"), ("torch", "0"), ("torch again", "0")):
+        monkeypatch.setenv("RSDET_FUSED_SGD", fused)
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = Runner(cfg, device=cuda, distributed=False)
+        assert type(r.optimizer).__name__ == ("FusedSGD" if fused == "1" else "SGD")
+        losses = [float(r.train_step(images, targets)[0]) for _ in range(3)]
+        out[tag] = (losses, {n: p.detach().clone() for n, p in r.model.named_parameters() if p.requires_grad})
+    for a, b in zip(out["fused"][0], out["torch"][0]):
+        assert abs(a - b) <= 2e-3 * abs(b), (out["fused"][0], out["torch"][0])
+
+    def worst(x, y):
+        return max(float((p - y[1][n]).norm() / (p.norm() + 1e-12)) for n, p in x[1].items())
+
+    # the yardstick is the step's own run-to-run noise (atomic weight-gradient kernels; zero-initialised biases make the
+    # relative distance of a single parameter large): two torch runs against each other
+    noise = worst(out["torch"], out["torch again"])
+    assert worst(out["torch"], out["fused"]) <= 3 * noise + 1e-4, (worst(out["torch"], out["fused"]), noise)
