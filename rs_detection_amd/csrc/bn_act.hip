@@ -12,6 +12,7 @@
 // (the residual gradient is the masked dy itself and shares dx's mask: written once as `g`).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
@@ -283,8 +284,15 @@ static inline void bn_nhwc_split(long long rows, int C, int* rows_per, int* S) {
   const int RL = G < BN_NT ? BN_NT / G : 1;
   long long per = (long long)RL * 8;                       // ~8 rows per thread
   long long s = (rows + per - 1) / per;
-  if (s > 4096) {
-    s = 4096;
+  // slices the finish kernel folds.  2 048: bf16 step 18.7 -> 18.3 ms against 4 096 (the finish reads half the
+  // partials), 512 starves the main pass (19.1); fp32 step flat (profiles/r03_canvas_ab.txt).  RSDET_BN_SCAP: A/B.
+  static const long long cap = [] {
+    const char* e = getenv("RSDET_BN_SCAP");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 64 ? v : 2048LL;
+  }();
+  if (s > cap) {
+    s = cap;
     per = (rows + s - 1) / s;
     per = (per + RL - 1) / RL * RL;
     s = (rows + per - 1) / per;
