@@ -516,9 +516,19 @@ def main():
     if not args.no_kernels:
         # one extra UNTIMED step under torch's flop counter (convs + GEMMs, fwd + bwd).  On EVERY rank: the step
         # contains DDP's gradient all-reduce, a rank that skipped it would leave the others hanging.
+        # Counted on the reference's level-by-level head (RSDET_S2A_PACKED=0 for this one step): the canvas of the timed
+        # step convolves 13-15 % gap pixels too, and those are not algorithmic flops.
         from torch.utils.flop_counter import FlopCounterMode
-        with FlopCounterMode(display=False) as fc:
-            runner.train_step(images, targets)
+        prev = os.environ.get("RSDET_S2A_PACKED")
+        os.environ["RSDET_S2A_PACKED"] = "0"
+        try:
+            with FlopCounterMode(display=False) as fc:
+                runner.train_step(images, targets)
+        finally:
+            if prev is None:
+                del os.environ["RSDET_S2A_PACKED"]
+            else:
+                os.environ["RSDET_S2A_PACKED"] = prev
         step_flops = float(fc.get_total_flops())
     dt, loss_v = timed_region(runner, batches, args.steps, rdist, device)
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round measurements: the bench lines of every configuration + rocprofv3 kernel stats of the fp32 and bf16 steps
-TAG=${1:-r03_e}
+TAG=${1:-r03_k}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
