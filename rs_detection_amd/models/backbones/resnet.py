@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from rs_detection_amd.ops.bn_act import bn_act
+from rs_detection_amd.ops.conv1x1 import conv1x1
 from rs_detection_amd.utils.registry import BACKBONES
 
 __all__ = ['ResNet', 'Resnet18', 'Resnet34', 'Resnet50', 'Resnet101', 'Resnet152']
@@ -58,10 +59,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         # bn -> (+ identity) -> relu as one pass each way when the BatchNorm is in eval mode (ops/bn_act.py)
-        idt = x if self.downsample is None else bn_act(self.downsample[0](x), self.downsample[1], relu=False)
-        out = bn_act(self.conv1(x), self.bn1)
+        # conv1 / conv3 / a stride-1 downsample are 1x1: GEMMs on views when the step runs channels_last (ops/conv1x1.py)
+        idt = x if self.downsample is None else bn_act(conv1x1(self.downsample[0], x), self.downsample[1], relu=False)
+        out = bn_act(conv1x1(self.conv1, x), self.bn1)
         out = bn_act(self.conv2(out), self.bn2)
-        return bn_act(self.conv3(out), self.bn3, residual=idt)
+        return bn_act(conv1x1(self.conv3, out), self.bn3, residual=idt)
 
 
 @BACKBONES.register_module()

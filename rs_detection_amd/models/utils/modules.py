@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from rs_detection_amd.ops.bn_act import bias_act
+from rs_detection_amd.ops.conv1x1 import conv1x1
 from rs_detection_amd.utils.registry import BRICKS, build_from_cfg
 from .weight_init import kaiming_init, constant_init
 
@@ -118,7 +119,7 @@ class ConvModule(nn.Module):
             return out * canvas.live_f.to(out.dtype)
         for layer in self.order:
             if layer == 'conv':
-                x = self.conv(x)
+                x = conv1x1(self.conv, x)       # the module itself unless it is a 1x1 of a channels_last map
             elif layer == 'norm' and norm and self.with_norm:
                 x = getattr(self, self.norm)(x)
             elif layer == 'act' and activate and self.with_activation and hasattr(self, 'activate'):

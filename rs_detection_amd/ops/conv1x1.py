@@ -1,0 +1,79 @@
+"""1x1 / stride-1 convolutions of a channels_last step as what they are: GEMMs on (pixels, channels) views.
+
+A channels_last (B, C, H, W) tensor IS the row-major (B*H*W, C) matrix, so ``conv1x1(x, w) = x2d @ w2d^T`` and its
+backward-data ``gy2d @ w2d`` need no copies.  MIOpen runs these through its implicit-GEMM convolution kernels; measured on
+the ResNet-50 / FPN shapes of the 4 x 1024^2 step (profiles/r03_conv1x1.txt, bf16): backward-data is 1.3-1.9 x faster as a
+library GEMM everywhere, the forward is faster for maps of <= 128^2 (the FPN laterals: 33-84 us -> < 19 us) and slower at
+256^2, and the weight gradient (K = B*H*W, a split-K reduction) is 5-10 x SLOWER as a GEMM.  Hence the split:
+
+    forward        GEMM for B*H*W <= 65 536 pixels, MIOpen above
+    backward-data  GEMM (torch.mm -> hipBLASLt / rocBLAS)
+    backward-w     MIOpen (aten.convolution_backward with only the weight mask set)
+
+The arithmetic is the convolution's own (products accumulated in fp32, one rounding of the result); which library
+computes it is not part of the reference's semantics (the reference calls cuDNN here:
+/root/reference/python/jdet/models/backbones/resnet.py:101-126, necks/fpn.py lateral convolutions)."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+_ON = os.environ.get("RSDET_CONV1X1_GEMM", "1") == "1"   # A/B switch
+_FWD_MAX_PIXELS = 65536
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.bfloat16)
+    def forward(ctx, x, w, bias):
+        B, C, H, W = x.shape
+        O = w.shape[0]
+        if not (x.dtype == w.dtype):
+            w = w.to(x.dtype)
+        x = x.contiguous(memory_format=torch.channels_last)
+        P = B * H * W
+        if P <= _FWD_MAX_PIXELS:
+            x2, w2 = x.permute(0, 2, 3, 1).reshape(P, C), w.reshape(O, C)
+            y2 = torch.mm(x2, w2.t()) if bias is None else torch.addmm(bias.to(x.dtype), x2, w2.t())
+            y = y2.view(B, H, W, O).permute(0, 3, 1, 2)
+        else:
+            y = F.conv2d(x, w, None if bias is None else bias.to(x.dtype))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, C, H, W = x.shape
+        O = w.shape[0]
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gy2 = gy.permute(0, 2, 3, 1).reshape(-1, O)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(gy2, w.reshape(O, C)).view(B, H, W, C).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+        return gx, gw, gb
+
+
+def conv1x1_applies(conv, x):
+    return (_ON and type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv1x1(conv, x):
+    """``conv(x)`` for an ``nn.Conv2d``; the GEMM split above when it is a 1x1 / stride-1 convolution of a channels_last
+    CUDA tensor, the module itself otherwise."""
+    if conv1x1_applies(conv, x):
+        return _Conv1x1.apply(x, conv.weight, conv.bias)
+    return conv(x)

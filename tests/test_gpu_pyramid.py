@@ -297,3 +297,34 @@ def test_model_eval_detections_canvas_equals_loop(cuda, monkeypatch):
         assert float(same.any(1).float().mean()) >= 0.99 and float(same.any(0).float().mean()) >= 0.99
         n += pc.shape[0]
     assert n > 20
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,O,H,W,bias", [(2, 64, 256, 40, 24, False), (1, 256, 64, 300, 260, True), (2, 512, 256, 16, 16, True)])
+def test_conv1x1_gemm_split_matches_conv2d(cuda, dtype, B, C, O, H, W, bias):
+    """ops/conv1x1.py: a 1x1 / stride-1 convolution of a channels_last map as GEMMs on views (forward for small maps,
+    backward-data always) + MIOpen's weight gradient == nn.Conv2d, values and all three gradients; both sides of the
+    forward's pixel-count switch (300 x 260 > 65 536 pixels)."""
+    from rs_detection_amd.ops.conv1x1 import conv1x1, conv1x1_applies
+    torch.manual_seed(B * C + O)
+    conv = torch.nn.Conv2d(C, O, 1, bias=bias).to(cuda).to(memory_format=torch.channels_last)
+    x = torch.randn((B, C, H, W), device=cuda).contiguous(memory_format=torch.channels_last)
+    g = torch.randn((B, O, H, W), device=cuda).contiguous(memory_format=torch.channels_last)
+    assert conv1x1_applies(conv, x) and not conv1x1_applies(conv, x.contiguous())
+    assert not conv1x1_applies(torch.nn.Conv2d(C, O, 1, stride=2).to(cuda), x)
+    outs = []
+    for fn in (lambda t: conv1x1(conv, t), lambda t: conv(t)):
+        xa = x.clone().requires_grad_(True)
+        conv.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = fn(xa)
+        assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+        y.backward(g.to(dtype))
+        outs.append((y.detach().float(), xa.grad.float(), conv.weight.grad.float().clone(),
+                     conv.bias.grad.float().clone() if bias else None))
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    for a, b in zip(*outs):
+        if a is None:
+            continue
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6
