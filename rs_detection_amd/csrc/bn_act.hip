@@ -278,9 +278,152 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
   }
 }
 
+// ---- bf16 channels-last forms with EIGHT channels (16 bytes) per lane -------------------------------------------------------
+// The four-channel forms above move 8 bytes per lane per access in bf16: half of what a wave instruction can carry.  With
+// C % 8 == 0 and C <= 2 048 (every trunk / head map of the step) a lane owns eight consecutive channels: 16-byte loads and
+// stores, and the backward needs no multi-group (J > 1) variant.  Same arithmetic, same partial layout.
+struct F8 {
+  float v[8];
+};
+__device__ __forceinline__ F8 ld8(const bf16_t* p) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  F8 o;
+  o.v[0] = __uint_as_float(r.x << 16), o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+  o.v[2] = __uint_as_float(r.y << 16), o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+  o.v[4] = __uint_as_float(r.z << 16), o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+  o.v[6] = __uint_as_float(r.w << 16), o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+  return o;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
+  uint4 r;
+  r.x = (uint32_t)f2bf(a.v[0]) | ((uint32_t)f2bf(a.v[1]) << 16);
+  r.y = (uint32_t)f2bf(a.v[2]) | ((uint32_t)f2bf(a.v[3]) << 16);
+  r.z = (uint32_t)f2bf(a.v[4]) | ((uint32_t)f2bf(a.v[5]) << 16);
+  r.w = (uint32_t)f2bf(a.v[6]) | ((uint32_t)f2bf(a.v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = r;
+}
+__device__ __forceinline__ F8 ldp8(const float* p) {   // eight consecutive fp32 parameters
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  F8 o;
+  o.v[0] = a.x, o.v[1] = a.y, o.v[2] = a.z, o.v[3] = a.w, o.v[4] = b.x, o.v[5] = b.y, o.v[6] = b.z, o.v[7] = b.w;
+  return o;
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc8_kernel(const bf16_t* __restrict__ x,
+                                                                const bf16_t* __restrict__ res,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ var,
+                                                                const float* __restrict__ weight,
+                                                                const float* __restrict__ bias, float eps, int C,
+                                                                long long total_q, bf16_t* __restrict__ y) {
+  const long long q = (long long)blockIdx.x * BN_NT + threadIdx.x;
+  if (q >= total_q) return;
+  const int c0 = (int)((q * 8) % C);
+  const F8 m = ldp8(mean + c0), vr = ldp8(var + c0);
+  F8 g, b;
+  if (weight) g = ldp8(weight + c0);
+  if (bias) b = ldp8(bias + c0);
+  const F8 v = ld8(x + q * 8);
+  F8 r;
+  if (RES) r = ld8(res + q * 8);
+  F8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float t = ((v.v[k] - m.v[k]) * (1.0f / sqrtf(vr.v[k] + eps))) * (weight ? g.v[k] : 1.0f) + (bias ? b.v[k] : 0.0f);
+    if (RES) t += r.v[k];
+    if (RELU) t = fmaxf(t, 0.f);
+    o.v[k] = t;
+  }
+  st8(y + q * 8, o);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ weight, float eps,
+    long long rows, int C, int rows_per, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
+    float* __restrict__ partial) {
+  __shared__ float s_red[BN_NT][17];   // 17: the fold below reads a column of 16 across rows
+  const int G = C >> 3, S = gridDim.x, s = blockIdx.x;
+  const int RL = BN_NT / G;            // G is a divisor of 256 (host-checked)
+  const int t = threadIdx.x, rl = t / G, c0 = (t % G) * 8;
+  const long long r0 = (long long)s * rows_per, r1 = min(rows, r0 + rows_per);
+  const F8 m = ldp8(mean + c0), vr = ldp8(var + c0);
+  F8 is, sc;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) is.v[k] = 1.0f / sqrtf(vr.v[k] + eps);
+  if (weight) {
+    const F8 w = ldp8(weight + c0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sc.v[k] = is.v[k] * w.v[k];
+  } else {
+    sc = is;
+  }
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll 2
+  for (long long r = r0 + rl; r < r1; r += RL) {
+    const long long base = r * C + c0;
+    F8 g = ld8(dy + base);
+    if (RELU) {
+      const F8 o = ld8(y + base);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g.v[k] = o.v[k] > 0.f ? g.v[k] : 0.f;
+    }
+    if (partial) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += g.v[k];
+      if (x) {
+        const F8 v = ld8(x + base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[8 + k] += g.v[k] * ((v.v[k] - m.v[k]) * is.v[k]);
+      }
+    }
+    if (dres) st8(dres + base, g);
+    if (dx) {
+      F8 d;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d.v[k] = g.v[k] * sc.v[k];
+      st8(dx + base, d);
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s_red[t][k] = acc[k];
+  __syncthreads();
+  if (t < G) {
+    float tot[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot[k] = 0.f;
+    for (int l = 0; l < RL; ++l)  // fixed order
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot[k] += s_red[l * G + t][k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      partial[((long long)(t * 8 + k) * S + s) * 2 + 0] = tot[k];
+      partial[((long long)(t * 8 + k) * S + s) * 2 + 1] = tot[8 + k];
+    }
+  }
+}
+
+static inline bool bn_nhwc8_ok(int C) {   // eight channels per lane: C / 8 a divisor of 256
+  const int G = C / 8;
+  return C > 0 && (C & 7) == 0 && G <= BN_NT && BN_NT % G == 0;
+}
+
+static inline bool bn_vec8() {   // A/B switch: RSDET_BN_VEC8=0 keeps the four-channel bf16 kernels
+  static const bool on = [] {
+    const char* e = getenv("RSDET_BN_VEC8");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // rows per workgroup / number of workgroups of the NHWC backward
-static inline void bn_nhwc_split(long long rows, int C, int* rows_per, int* S) {
-  const int G = C / 4;
+static inline void bn_nhwc_split(long long rows, int C, int* rows_per, int* S, int vec = 4) {
+  const int G = C / vec;
   const int RL = G < BN_NT ? BN_NT / G : 1;
   long long per = (long long)RL * 8;                       // ~8 rows per thread
   long long s = (rows + per - 1) / per;
@@ -477,9 +620,25 @@ static int bn_act_forward_nhwc(const T* x, const T* residual, const float* runni
   if (N < 0 || HW < 0 || !bn_nhwc_ok(C)) return RSDET_EINVAL;
   if (N == 0 || HW == 0) return RSDET_OK;
   if (!x || !running_mean || !running_var || !y) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if constexpr (sizeof(T) == 2) {
+    if (bn_nhwc8_ok(C) && bn_vec8()) {
+      const long long tq = (long long)N * HW * (C / 8);
+      const dim3 g8((unsigned)((tq + BN_NT - 1) / BN_NT));
+#define RSDET_BN_FWD8(R, A)                                                                                         \
+  hipLaunchKernelGGL((bn_act_fwd_nhwc8_kernel<R, A>), g8, dim3(BN_NT), 0, s, x, residual, running_mean, running_var, \
+                     weight, bias, eps, C, tq, y)
+      if (relu) {
+        if (residual) RSDET_BN_FWD8(true, true); else RSDET_BN_FWD8(true, false);
+      } else {
+        if (residual) RSDET_BN_FWD8(false, true); else RSDET_BN_FWD8(false, false);
+      }
+#undef RSDET_BN_FWD8
+      return rsdet_launch_status();
+    }
+  }
   const long long total_q = (long long)N * HW * (C / 4);
   const dim3 grid((unsigned)((total_q + BN_NT - 1) / BN_NT));
-  hipStream_t s = (hipStream_t)stream;
 #define RSDET_BN_FWD(R, A)                                                                                      \
   hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<R, A, T>), grid, dim3(BN_NT), 0, s, x, residual, running_mean,     \
                      running_var, weight, bias, eps, C, total_q, y)
@@ -509,6 +668,21 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const T* x, const f
   int per, S;
   bn_nhwc_split(rows, C, &per, &S);
   float* partial = need_param ? (float*)ws : nullptr;
+  if constexpr (sizeof(T) == 2) {
+    if (bn_nhwc8_ok(C) && bn_vec8()) {
+      bn_nhwc_split(rows, C, &per, &S, 8);   // never more slices than the four-channel split the workspace is sized for
+      if (relu)
+        hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<true>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
+                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial);
+      else
+        hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<false>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
+                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial);
+      if (need_param)
+        hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
+                           grad_bias);
+      return rsdet_launch_status();
+    }
+  }
   const int G = C / 4;
   const int J = G <= BN_NT ? 1 : (G + BN_NT - 1) / BN_NT;
 #define RSDET_BN_BWD(R, JJ)                                                                                        \

@@ -1059,3 +1059,46 @@ def test_bn_act_channels_last_equals_nchw_form(cuda, dtype, shape, relu, with_re
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     assert float((gw0 - gw1).abs().max()) <= tol * (float(gw0.abs().max()) + 1.0)
     assert float((gb0 - gb1).abs().max()) <= tol * (float(gb0.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 20, 36), (4, 20, 36), (256, 9, 7), (2048, 3, 5), (1024, 4, 4)])
+@pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, True), (False, False)])
+def test_bn_act_bf16_channels_last_forms(cuda, C, H, W, relu, res):
+    """The channels_last bf16 kernels of the autocast step -- eight channels (16 bytes) per lane where C / 8 divides 256
+    (64, 256, 1024, 2048 here), four per lane otherwise (4) -- against the fp32 formula on the same bf16 inputs:
+    outputs within one bf16 ulp, input / residual gradients likewise, parameter gradients as fp32 sums."""
+    from rs_detection_amd.ops.bn_act import bn_act, _fusable
+    torch.manual_seed(C + H)
+    N = 3
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_(1, 0.2)
+        bn.bias.normal_(0, 0.2)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    x = cl(torch.randn(N, C, H, W, device=cuda).bfloat16()).requires_grad_(True)
+    r = cl(torch.randn(N, C, H, W, device=cuda).bfloat16()).requires_grad_(True) if res else None
+    assert _fusable(x, bn, r)
+    y = bn_act(x, bn, r, relu)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    xf = x.detach().float().requires_grad_(True)
+    rf = r.detach().float().requires_grad_(True) if res else None
+    w, b = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    yf = ((xf - bn.running_mean[None, :, None, None]) / torch.sqrt(bn.running_var + bn.eps)[None, :, None, None]) \
+        * w[None, :, None, None] + b[None, :, None, None]
+    if res:
+        yf = yf + rf
+    if relu:
+        yf = torch.relu(yf)
+    assert float((y.float() - yf).abs().max()) <= 2 ** -7 * max(1.0, float(yf.abs().max()))
+    go = cl(torch.randn_like(yf).bfloat16())
+    y.backward(go)
+    yf2 = yf if not relu else yf * (y.float() > 0)
+    yf2.backward(go.float())
+    assert float((x.grad.float() - xf.grad).abs().max()) <= 2 ** -7 * max(1.0, float(xf.grad.abs().max()))
+    if res:
+        assert float((r.grad.float() - rf.grad).abs().max()) <= 2 ** -7 * max(1.0, float(rf.grad.abs().max()))
+    assert bn.weight.grad.dtype == torch.float32
+    assert float((bn.weight.grad - w.grad).abs().max()) <= 2e-2 * max(1.0, float(w.grad.abs().max()))
+    assert float((bn.bias.grad - b.grad).abs().max()) <= 2e-2 * max(1.0, float(b.grad.abs().max()))
