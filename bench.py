@@ -461,7 +461,9 @@ def main():
     args = ap.parse_args()
     if args.memory_format is None:
         # (the R101 trunk has fp32 NHWC records for none of its layer3 shapes: it stays NCHW in f32)
-        args.memory_format = "channels_last" if (args.model == "s2anet_r50" or (
+        from rs_detection_amd.utils.miopen_db import packaged_records_match
+        f32_cl = args.model == "s2anet_r50" and packaged_records_match()     # without the records: 7 x slower, NCHW then
+        args.memory_format = "channels_last" if (f32_cl or (
             args.dtype == "bf16" and args.model.startswith("s2anet"))) else "contiguous"
 
     from rs_detection_amd.utils import dist as rdist

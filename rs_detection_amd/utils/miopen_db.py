@@ -65,3 +65,25 @@ def use_packaged_miopen_db():
         return None
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     return dst
+
+
+def packaged_records_match():
+    """True when the packaged record files were made by the MIOpen this process runs (same major.minor.patch -- the
+    version is part of the file name MIOpen looks for) and will be used.  The fp32 channels_last step depends on them:
+    on heuristics MIOpen picks a 7 x slower solver set for that layout (DESIGN R3.6), so callers that default to
+    channels_last for fp32 fall back to NCHW when this is False."""
+    import re
+    if os.environ.get("RSDET_NO_MIOPEN_DB", "0") == "1":
+        return False
+    files = glob.glob(os.path.join(_PKG_DB, "*.ufdb.txt"))
+    if not files:
+        return False
+    try:
+        import torch
+        v = int(torch.backends.cudnn.version() or 0)
+    except Exception:
+        return False
+    want = "%d_%d_%d_" % (v // 1000000, (v // 1000) % 1000, v % 1000)
+    user = os.environ.get("MIOPEN_USER_DB_PATH")
+    ours = user is None or os.path.realpath(user) == os.path.realpath(_private_dir() or "")
+    return ours and any(re.search(r"\.HIP\." + re.escape(want), os.path.basename(f)) for f in files)

@@ -150,3 +150,22 @@ def test_xcd_workgroup_renumbering_is_a_bijection():
         for xcd in range(8):
             outers = sorted({x[0] for i, x in enumerate(items) if x is not None and i % 8 == xcd})
             assert outers == list(range(outers[0], outers[0] + len(outers))) if outers else True
+
+
+def test_packaged_miopen_records_match_rule(monkeypatch, tmp_path):
+    """bench.py runs the fp32 step in channels_last only when the packaged find records belong to the MIOpen in use and
+    are the ones MIOpen will read (utils/miopen_db.packaged_records_match): version taken from the record file names."""
+    import torch
+    from rs_detection_amd.utils import miopen_db as m
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("RSDET_NO_MIOPEN_DB", raising=False)
+    monkeypatch.setattr(torch.backends.cudnn, "version", lambda: 3005000)
+    assert m.packaged_records_match()
+    monkeypatch.setattr(torch.backends.cudnn, "version", lambda: 3006001)      # another MIOpen: its own file names
+    assert not m.packaged_records_match()
+    monkeypatch.setattr(torch.backends.cudnn, "version", lambda: 3005000)
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path))                   # the user's own database wins
+    assert not m.packaged_records_match()
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("RSDET_NO_MIOPEN_DB", "1")
+    assert not m.packaged_records_match()
