@@ -300,7 +300,14 @@ __device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
   r.y = (uint32_t)f2bf(a.v[2]) | ((uint32_t)f2bf(a.v[3]) << 16);
   r.z = (uint32_t)f2bf(a.v[4]) | ((uint32_t)f2bf(a.v[5]) << 16);
   r.w = (uint32_t)f2bf(a.v[6]) | ((uint32_t)f2bf(a.v[7]) << 16);
+#ifdef RSDET_BN8_NT
+  __builtin_nontemporal_store(r.x, reinterpret_cast<uint32_t*>(p));
+  __builtin_nontemporal_store(r.y, reinterpret_cast<uint32_t*>(p) + 1);
+  __builtin_nontemporal_store(r.z, reinterpret_cast<uint32_t*>(p) + 2);
+  __builtin_nontemporal_store(r.w, reinterpret_cast<uint32_t*>(p) + 3);
+#else
   *reinterpret_cast<uint4*>(p) = r;
+#endif
 }
 __device__ __forceinline__ F8 ldp8(const float* p) {   // eight consecutive fp32 parameters
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -363,7 +370,10 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
   float acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-#pragma unroll 2
+#ifndef RSDET_BN8_UNROLL
+#define RSDET_BN8_UNROLL 4
+#endif
+#pragma unroll RSDET_BN8_UNROLL
   for (long long r = r0 + rl; r < r1; r += RL) {
     const long long base = r * C + c0;
     F8 g = ld8(dy + base);
