@@ -227,6 +227,10 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
     const float4 w = weight ? *reinterpret_cast<const float4*>(weight + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float is0 = 1.0f / sqrtf(vr.x + eps), is1 = 1.0f / sqrtf(vr.y + eps), is2 = 1.0f / sqrtf(vr.z + eps),
                 is3 = 1.0f / sqrtf(vr.w + eps);
+#ifndef RSDET_BN4_UNROLL
+#define RSDET_BN4_UNROLL 1
+#endif
+#pragma unroll RSDET_BN4_UNROLL
     for (long long r = r0 + rl; r < r1; r += RL) {
       const long long base = r * C + c0;
       float4 g = ld4(dy + base);
