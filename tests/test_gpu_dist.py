@@ -33,7 +33,7 @@ def _run(model, dtype, tmp_path, size=256, world=2, extra_env=None):
 
 
 @pytest.mark.timeout(1000)
-@pytest.mark.parametrize("model,dtype,tol", [("s2anet", "f32", 1e-3), ("s2anet", "bf16", 0.1),
+@pytest.mark.parametrize("model,dtype,tol", [("s2anet", "f32", 1e-3), ("s2anet", "f32cl", 1e-3), ("s2anet", "bf16", 0.1),
                                              ("orcnn", "f32", 5e-3), ("orcnn", "bf16", 0.1)])
 def test_two_rank_ddp_real_model(model, dtype, tol, tmp_path):
     _need_gpu()
