@@ -154,3 +154,42 @@ ALG2["mt_sqnorm_kernel"] = dict(call="fused SGD step (2 launches, 36 M fp32 para
 ALG2["mt_sgd_kernel"] = dict(call="fused SGD step (2 launches, 36 M fp32 parameters)", bytes=4 * 36_000_000 * (1 + 1 + 2 + 2))
 ALG.update(ALG2)
 json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
+
+# ---- round 3, second half: the channels_last fp32 tails, the 16-byte-lane bf16 tails, the pyramid canvas kernels and
+# the orientation max-pool, at the shapes of the 4 x 1024^2 step
+xb = torch.randn(4, Cb, Hb, Hb, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+rb = torch.randn(4, Cb, Hb, Hb, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+for _ in range(3):
+    yb = bn_act(xb, bn, rb, True)
+    torch.autograd.grad(yb, (xb, rb, bn.weight, bn.bias), torch.randn_like(yb))
+del xb, rb, yb
+ALG3 = {"bn_act_fwd_nhwc_kernel<true, true, float>": dict(call="bn_act_forward_nhwc_f32", bytes=3 * 4 * nb),
+        "bn_act_bwd_nhwc_kernel<true, float": dict(call="bn_act_backward_nhwc_f32", bytes=4 * 4 * nb),
+        "bn_act_fwd_nhwc8_kernel<true, true>": dict(call="bn_act_forward_bf16", bytes=3 * 2 * nb),
+        "bn_act_bwd_nhwc8_kernel<true>": dict(call="bn_act_backward_bf16", bytes=4 * 2 * nb)}
+from rs_detection_amd.ops.pyramid import canvas_layout, pyramid_pack, pyramid_unpack, canvas_bias_act
+from rs_detection_amd.ops.orn import RotationInvariantPooling
+sizes = [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)]
+lay = canvas_layout(sizes, dev)
+npx, ncv = sum(h * w for h, w in sizes), lay.Hc * lay.Wc
+pool = RotationInvariantPooling(256, 8).to(dev)
+for dt, es_ in ((torch.bfloat16, 2), (torch.float32, 4)):
+    lv = [torch.randn(4, 256, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+    bias = torch.randn(256, device=dev)
+    for _ in range(3):
+        cv = pyramid_pack(lv, lay)
+        pyramid_unpack(cv, lay, channels_last=True)
+        yb = canvas_bias_act(cv, bias, lay, True)
+        pb = pool(cv)
+    small = pyramid_unpack(cv[:, :16].contiguous(memory_format=torch.channels_last), lay)     # 16-channel maps -> NCHW levels
+    del lv, cv, yb, pb, small
+tag = {2: "unsigned short", 4: "float"}
+ALG3["pyramid_copy_nhwc16_kernel<true>"] = dict(call="pyramid_pack (256 ch, channels_last)", bytes=(2 + 4) * 4 * 256 * (npx + ncv) // 2)
+ALG3["pyramid_copy_nhwc16_kernel<false>"] = dict(call="pyramid_unpack (256 ch, channels_last)", bytes=(2 + 4) * 4 * 256 * 2 * npx // 2)
+ALG3["canvas_bias_act_nhwc_kernel<true, unsigned short>"] = dict(call="canvas_bias_act bf16", bytes=2 * 2 * 4 * 256 * ncv)
+ALG3["canvas_bias_act_nhwc_kernel<true, float>"] = dict(call="canvas_bias_act f32", bytes=2 * 4 * 4 * 256 * ncv)
+ALG3["ori_maxpool8x4_kernel<unsigned short, false>"] = dict(call="ori_maxpool bf16", bytes=2 * 4 * ncv * (256 + 32))
+ALG3["ori_maxpool8x4_kernel<float, false>"] = dict(call="ori_maxpool f32", bytes=4 * 4 * ncv * (256 + 32))
+ALG.update(ALG3)
+json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
+torch.cuda.synchronize(); print("done (round 3 additions)")

@@ -142,12 +142,61 @@ __global__ __launch_bounds__(256) void ori_maxpool_bwd_kernel(const T* __restric
   for (int k = 0; k < nOri; ++k) st1(gx + base + k * step, (ld1(x + base + k * step) == m) ? g : 0.f);
 }
 
+// channels-last, nOri == 8, F % 4 == 0 (the S2ANet head: F = 32): a thread owns FOUR features = 32 consecutive channels of
+// one pixel -- 64 B (bf16) / 128 B (fp32) of loads in flight per lane instead of 16 / 32 B, and an 8- / 16-byte store
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void ori_maxpool8x4_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                             long long total4, T* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;   // index of a group of 4 outputs
+  if (e >= total4) return;
+  const T* xp = x + e * 32;
+  float v[32];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 a = ld4(xp + 4 * j);
+    v[4 * j] = a.x, v[4 * j + 1] = a.y, v[4 * j + 2] = a.z, v[4 * j + 3] = a.w;
+  }
+  float m[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    m[f] = v[8 * f];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) m[f] = (v[8 * f + k] > m[f] || v[8 * f + k] != v[8 * f + k]) ? v[8 * f + k] : m[f];
+  }
+  if (!BWD) {
+    st4(out + e * 4, make_float4(m[0], m[1], m[2], m[3]));
+    return;
+  }
+  const float4 g4 = ld4(gy + e * 4);
+  const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt += (v[8 * f + k] == m[f]) ? 1 : 0;
+    const float gg = cnt > 0 ? g[f] / (float)cnt : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[8 * f + k] = (v[8 * f + k] == m[f]) ? gg : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) st4(out + e * 32 + 4 * j, make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
+}
+
 template <typename T>
 static int ori_maxpool(const T* x, const T* gy, int N, int F, int nOri, int HW, int nhwc, T* out, hipStream_t s) {
   if (N < 0 || F < 0 || HW < 0 || nOri < 1) return RSDET_EINVAL;
   const long long total = (long long)N * F * HW;
   if (total == 0) return RSDET_OK;
   if (!x || !out) return RSDET_EINVAL;
+  if (nhwc && nOri == 8 && (F & 3) == 0) {
+    const long long t4 = total / 4;
+    const dim3 g4((unsigned)((t4 + 255) / 256));
+    if (gy)
+      hipLaunchKernelGGL((ori_maxpool8x4_kernel<T, true>), g4, dim3(256), 0, s, x, gy, t4, out);
+    else
+      hipLaunchKernelGGL((ori_maxpool8x4_kernel<T, false>), g4, dim3(256), 0, s, x, gy, t4, out);
+    return rsdet_launch_status();
+  }
   const dim3 grid((unsigned)((total + 255) / 256));
   if (gy)
     hipLaunchKernelGGL(ori_maxpool_bwd_kernel<T>, grid, dim3(256), 0, s, x, gy, total, F, nOri, HW, nhwc, out);
