@@ -186,7 +186,7 @@ for dt, es_ in ((torch.bfloat16, 2), (torch.float32, 4)):
 tag = {2: "unsigned short", 4: "float"}
 ALG3["pyramid_copy_nhwc16_kernel<true>"] = dict(call="pyramid_pack (256 ch, channels_last)", bytes=(2 + 4) * 4 * 256 * (npx + ncv) // 2)
 ALG3["pyramid_copy_nhwc16_kernel<false>"] = dict(call="pyramid_unpack (256 ch, channels_last)", bytes=(2 + 4) * 4 * 256 * 2 * npx // 2)
-ALG3["canvas_bias_act_nhwc_kernel<true, unsigned short>"] = dict(call="canvas_bias_act bf16", bytes=2 * 2 * 4 * 256 * ncv)
+ALG3["canvas_bias_act_nhwc8_kernel<true>"] = dict(call="canvas_bias_act bf16", bytes=2 * 2 * 4 * 256 * ncv)
 ALG3["canvas_bias_act_nhwc_kernel<true, float>"] = dict(call="canvas_bias_act f32", bytes=2 * 4 * 4 * 256 * ncv)
 ALG3["ori_maxpool8x4_kernel<unsigned short, false>"] = dict(call="ori_maxpool bf16", bytes=2 * 4 * ncv * (256 + 32))
 ALG3["ori_maxpool8x4_kernel<float, false>"] = dict(call="ori_maxpool f32", bytes=4 * 4 * ncv * (256 + 32))

@@ -286,40 +286,6 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
 // The four-channel forms above move 8 bytes per lane per access in bf16: half of what a wave instruction can carry.  With
 // C % 8 == 0 and C <= 2 048 (every trunk / head map of the step) a lane owns eight consecutive channels: 16-byte loads and
 // stores, and the backward needs no multi-group (J > 1) variant.  Same arithmetic, same partial layout.
-struct F8 {
-  float v[8];
-};
-__device__ __forceinline__ F8 ld8(const bf16_t* p) {
-  const uint4 r = *reinterpret_cast<const uint4*>(p);
-  F8 o;
-  o.v[0] = __uint_as_float(r.x << 16), o.v[1] = __uint_as_float(r.x & 0xffff0000u);
-  o.v[2] = __uint_as_float(r.y << 16), o.v[3] = __uint_as_float(r.y & 0xffff0000u);
-  o.v[4] = __uint_as_float(r.z << 16), o.v[5] = __uint_as_float(r.z & 0xffff0000u);
-  o.v[6] = __uint_as_float(r.w << 16), o.v[7] = __uint_as_float(r.w & 0xffff0000u);
-  return o;
-}
-__device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
-  uint4 r;
-  r.x = (uint32_t)f2bf(a.v[0]) | ((uint32_t)f2bf(a.v[1]) << 16);
-  r.y = (uint32_t)f2bf(a.v[2]) | ((uint32_t)f2bf(a.v[3]) << 16);
-  r.z = (uint32_t)f2bf(a.v[4]) | ((uint32_t)f2bf(a.v[5]) << 16);
-  r.w = (uint32_t)f2bf(a.v[6]) | ((uint32_t)f2bf(a.v[7]) << 16);
-#ifdef RSDET_BN8_NT
-  __builtin_nontemporal_store(r.x, reinterpret_cast<uint32_t*>(p));
-  __builtin_nontemporal_store(r.y, reinterpret_cast<uint32_t*>(p) + 1);
-  __builtin_nontemporal_store(r.z, reinterpret_cast<uint32_t*>(p) + 2);
-  __builtin_nontemporal_store(r.w, reinterpret_cast<uint32_t*>(p) + 3);
-#else
-  *reinterpret_cast<uint4*>(p) = r;
-#endif
-}
-__device__ __forceinline__ F8 ldp8(const float* p) {   // eight consecutive fp32 parameters
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  F8 o;
-  o.v[0] = a.x, o.v[1] = a.y, o.v[2] = a.z, o.v[3] = a.w, o.v[4] = b.x, o.v[5] = b.y, o.v[6] = b.z, o.v[7] = b.w;
-  return o;
-}
-
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc8_kernel(const bf16_t* __restrict__ x,
                                                                 const bf16_t* __restrict__ res,
@@ -328,25 +294,32 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc8_kernel(const bf16_t* _
                                                                 const float* __restrict__ weight,
                                                                 const float* __restrict__ bias, float eps, int C,
                                                                 long long total_q, bf16_t* __restrict__ y) {
+  // a lane owns granule q and the granule half the tensor away (same channels: total_q / 2 is a multiple of C / 8 --
+  // the host launches this form only then): two independent 16-byte load streams per lane, one set of parameters
+  const long long half = total_q >> 1;
   const long long q = (long long)blockIdx.x * BN_NT + threadIdx.x;
-  if (q >= total_q) return;
+  if (q >= half) return;
   const int c0 = (int)((q * 8) % C);
   const F8 m = ldp8(mean + c0), vr = ldp8(var + c0);
-  F8 g, b;
+  F8 g, b, is;
   if (weight) g = ldp8(weight + c0);
   if (bias) b = ldp8(bias + c0);
-  const F8 v = ld8(x + q * 8);
-  F8 r;
-  if (RES) r = ld8(res + q * 8);
-  F8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) is.v[k] = 1.0f / sqrtf(vr.v[k] + eps);
+  const F8 v0 = ld8(x + q * 8), v1 = ld8(x + (q + half) * 8);
+  F8 r0, r1;
+  if (RES) r0 = ld8(res + q * 8), r1 = ld8(res + (q + half) * 8);
+  F8 o0, o1;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float t = ((v.v[k] - m.v[k]) * (1.0f / sqrtf(vr.v[k] + eps))) * (weight ? g.v[k] : 1.0f) + (bias ? b.v[k] : 0.0f);
-    if (RES) t += r.v[k];
-    if (RELU) t = fmaxf(t, 0.f);
-    o.v[k] = t;
+    float t0 = ((v0.v[k] - m.v[k]) * is.v[k]) * (weight ? g.v[k] : 1.0f) + (bias ? b.v[k] : 0.0f);
+    float t1 = ((v1.v[k] - m.v[k]) * is.v[k]) * (weight ? g.v[k] : 1.0f) + (bias ? b.v[k] : 0.0f);
+    if (RES) t0 += r0.v[k], t1 += r1.v[k];
+    if (RELU) t0 = fmaxf(t0, 0.f), t1 = fmaxf(t1, 0.f);
+    o0.v[k] = t0, o1.v[k] = t1;
   }
-  st8(y + q * 8, o);
+  st8(y + q * 8, o0);
+  st8(y + (q + half) * 8, o1);
 }
 
 template <bool RELU>
@@ -636,9 +609,9 @@ static int bn_act_forward_nhwc(const T* x, const T* residual, const float* runni
   if (!x || !running_mean || !running_var || !y) return RSDET_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if constexpr (sizeof(T) == 2) {
-    if (bn_nhwc8_ok(C) && bn_vec8()) {
+    if (bn_nhwc8_ok(C) && bn_vec8() && (((long long)N * HW) & 1) == 0) {
       const long long tq = (long long)N * HW * (C / 8);
-      const dim3 g8((unsigned)((tq + BN_NT - 1) / BN_NT));
+      const dim3 g8((unsigned)((tq / 2 + BN_NT - 1) / BN_NT));
 #define RSDET_BN_FWD8(R, A)                                                                                         \
   hipLaunchKernelGGL((bn_act_fwd_nhwc8_kernel<R, A>), g8, dim3(BN_NT), 0, s, x, residual, running_mean, running_var, \
                      weight, bias, eps, C, tq, y)

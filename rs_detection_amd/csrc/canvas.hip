@@ -141,12 +141,48 @@ __global__ __launch_bounds__(CV_NT) void canvas_bias_act_nhwc_kernel(const T* __
   st4(y + e, o);
 }
 
+// bf16, C % 8 == 0: eight channels (16 bytes) per lane
+template <bool RELU>
+__global__ __launch_bounds__(CV_NT) void canvas_bias_act_nhwc8_kernel(const bf16_t* __restrict__ x,
+                                                                      const float* __restrict__ bias,
+                                                                      const uint8_t* __restrict__ live, int C, int HW,
+                                                                      long long total_q, bf16_t* __restrict__ y) {
+  const long long q = (long long)blockIdx.x * CV_NT + threadIdx.x;
+  if (q >= total_q) return;
+  const long long e = q * 8;
+  const int c0 = (int)(e % C);
+  const int p = (int)((e / C) % HW);
+  F8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o.v[k] = 0.f;
+  if (live[p]) {
+    const F8 b = ldp8(bias + c0), v = ld8(x + e);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float t = v.v[k] + b.v[k];
+      o.v[k] = RELU ? fmaxf(t, 0.f) : t;
+    }
+  }
+  st8(y + e, o);
+}
+
 template <typename T>
 static int canvas_bias_act(const T* x, const float* bias, const uint8_t* live, int N, int C, int HW, int relu, int nhwc,
                            T* y, hipStream_t s) {
   if (!x || !bias || !live || !y || N <= 0 || C <= 0 || HW <= 0) return RSDET_EINVAL;
   if (nhwc) {
     if (C & 3) return RSDET_EINVAL;
+    if constexpr (sizeof(T) == 2) {
+      if ((C & 7) == 0) {
+        const long long tq = (long long)N * HW * (C / 8);
+        const dim3 g8((unsigned)((tq + CV_NT - 1) / CV_NT));
+        if (relu)
+          hipLaunchKernelGGL((canvas_bias_act_nhwc8_kernel<true>), g8, dim3(CV_NT), 0, s, x, bias, live, C, HW, tq, y);
+        else
+          hipLaunchKernelGGL((canvas_bias_act_nhwc8_kernel<false>), g8, dim3(CV_NT), 0, s, x, bias, live, C, HW, tq, y);
+        return rsdet_launch_status();
+      }
+    }
     const long long total_q = (long long)N * HW * (C / 4);
     const dim3 grid((unsigned)((total_q + CV_NT - 1) / CV_NT));
     if (relu)

@@ -33,4 +33,39 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
 __device__ __forceinline__ float ld1(const bf16_t* p) { return bf2f(*p); }
 __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = f2bf(v); }
 
+// eight consecutive bf16 activations (16 bytes) <-> eight floats; eight consecutive fp32 parameters
+struct F8 {
+  float v[8];
+};
+__device__ __forceinline__ F8 ld8(const bf16_t* p) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  F8 o;
+  o.v[0] = __uint_as_float(r.x << 16), o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+  o.v[2] = __uint_as_float(r.y << 16), o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+  o.v[4] = __uint_as_float(r.z << 16), o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+  o.v[6] = __uint_as_float(r.w << 16), o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+  return o;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
+  uint4 r;
+  r.x = (uint32_t)f2bf(a.v[0]) | ((uint32_t)f2bf(a.v[1]) << 16);
+  r.y = (uint32_t)f2bf(a.v[2]) | ((uint32_t)f2bf(a.v[3]) << 16);
+  r.z = (uint32_t)f2bf(a.v[4]) | ((uint32_t)f2bf(a.v[5]) << 16);
+  r.w = (uint32_t)f2bf(a.v[6]) | ((uint32_t)f2bf(a.v[7]) << 16);
+#ifdef RSDET_BN8_NT
+  __builtin_nontemporal_store(r.x, reinterpret_cast<uint32_t*>(p));
+  __builtin_nontemporal_store(r.y, reinterpret_cast<uint32_t*>(p) + 1);
+  __builtin_nontemporal_store(r.z, reinterpret_cast<uint32_t*>(p) + 2);
+  __builtin_nontemporal_store(r.w, reinterpret_cast<uint32_t*>(p) + 3);
+#else
+  *reinterpret_cast<uint4*>(p) = r;
+#endif
+}
+__device__ __forceinline__ F8 ldp8(const float* p) {   // eight consecutive fp32 parameters
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  F8 o;
+  o.v[0] = a.x, o.v[1] = a.y, o.v[2] = a.z, o.v[3] = a.w, o.v[4] = b.x, o.v[5] = b.y, o.v[6] = b.z, o.v[7] = b.w;
+  return o;
+}
+
 }  // namespace rsdet
