@@ -507,6 +507,12 @@ int rsdet_colsum_bf16(const uint16_t* x, long long rows, int C, float* out, void
  * gradients are (N, H, W, C) contiguous, i.e. torch tensors of shape (N, C, H, W) in channels_last memory format; same
  * arithmetic, same deterministic two-stage parameter gradients.  C must satisfy rsdet_bn_act_nhwc_supported(C)
  * (C % 4 == 0 and C / 4 a divisor or a multiple (<= 4x) of 256: every ResNet / FPN width). */
+/* Stem tail (models/backbones/resnet.py:186-189 of the reference: bn1 -> relu -> maxpool 3x3 / stride 2 / padding 1) as one
+ * forward pass over a channels-last map: y (N, (H+1)/2, (W+1)/2, C) <- maxpool(relu(bn(x))), x (N, H, W, C).  bf16 != 0:
+ * bfloat16 elements and C % 8 == 0, else float and C % 4 == 0.  Forward only (the shipped configs freeze the stem). */
+int rsdet_bn_relu_maxpool_nhwc(const void* x, int bf16, const float* running_mean, const float* running_var,
+                               const float* weight, const float* bias, float eps, int N, int C, int H, int W, void* y,
+                               void* stream);
 int rsdet_bn_act_nhwc_supported(int C);
 size_t rsdet_bn_act_backward_nhwc_ws_size(int N, int C, int HW);
 int rsdet_bn_act_forward_nhwc_f32(const float* x, const float* residual, const float* running_mean,

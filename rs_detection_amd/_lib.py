@@ -165,6 +165,8 @@ SIGNATURES = {
     "rsdet_bn_act_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                            c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_size_t, c_void_p]),
+    "rsdet_bn_relu_maxpool_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
+                                           c_int, c_int, c_void_p, c_void_p]),
     "rsdet_bn_act_nhwc_supported": (c_int, [c_int]),
     "rsdet_bn_act_backward_nhwc_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "rsdet_bn_act_forward_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
@@ -400,6 +401,89 @@ static inline bool bn_nhwc8_ok(int C) {   // eight channels per lane: C / 8 a di
   return C > 0 && (C & 7) == 0 && G <= BN_NT && BN_NT % G == 0;
 }
 
+// ---- stem tail: eval-mode BatchNorm + ReLU + 3x3 / stride 2 / padding 1 max-pool in ONE pass (channels-last, forward) ----
+// resnet.py:186-189 of the reference: conv1 -> bn1 -> relu -> maxpool.  With the stem frozen (every shipped config) no
+// gradient flows here, so the full-resolution activation (4 x 64 x 512 x 512: 134 MB in bf16) need not exist: a lane owns
+// VEC consecutive channels of one pooled pixel, reads its <= 9 inputs (neighbouring windows overlap: those re-reads hit
+// L2), applies the affine + ReLU to each and keeps the maximum (max and a monotone map do not commute with a negative
+// scale, so the affine is applied per input, exactly as the unfused sequence does).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ var,
+                                                                   const float* __restrict__ weight,
+                                                                   const float* __restrict__ bias, float eps, int C, int H,
+                                                                   int W, int Ho, int Wo, long long total,
+                                                                   T* __restrict__ y) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;   // (n, ho, wo, channel group)
+  if (q >= total) return;
+  const int G = C / VEC;
+  const int g = (int)(q % G);
+  long long r = q / G;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const long long n = r / Ho;
+  const int c0 = g * VEC;
+  float m[VEC], is[VEC], gw[VEC], sh[VEC], best[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; j += 4) {   // parameters by 16-byte loads
+    const float4 a = *reinterpret_cast<const float4*>(mean + c0 + j), b = *reinterpret_cast<const float4*>(var + c0 + j);
+    const float4 w4 = weight ? *reinterpret_cast<const float4*>(weight + c0 + j) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    m[j] = a.x, m[j + 1] = a.y, m[j + 2] = a.z, m[j + 3] = a.w;
+    is[j] = 1.0f / sqrtf(b.x + eps), is[j + 1] = 1.0f / sqrtf(b.y + eps), is[j + 2] = 1.0f / sqrtf(b.z + eps),
+    is[j + 3] = 1.0f / sqrtf(b.w + eps);
+    gw[j] = w4.x, gw[j + 1] = w4.y, gw[j + 2] = w4.z, gw[j + 3] = w4.w;
+    sh[j] = b4.x, sh[j + 1] = b4.y, sh[j + 2] = b4.z, sh[j + 3] = b4.w;
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) best[k] = -INFINITY;
+  const T* xn = x + n * (long long)H * W * C + c0;
+  // all nine loads first (addresses clamped into the map, validity kept aside), then the arithmetic: the loop with
+  // early `continue`s serialised the loads behind the border tests
+  typedef typename std::conditional<VEC == 8, uint4, float4>::type Raw;
+  Raw raw[9];
+  bool ok[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int h = 2 * ho - 1 + t / 3, w = 2 * wo - 1 + t % 3;
+    ok[t] = h >= 0 && h < H && w >= 0 && w < W;
+    const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+    raw[t] = *reinterpret_cast<const Raw*>(xn + ((long long)hc * W + wc) * C);
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v[VEC];
+    if constexpr (VEC == 8) {
+      const uint4 r4 = raw[t];
+      v[0] = __uint_as_float(r4.x << 16), v[1] = __uint_as_float(r4.x & 0xffff0000u);
+      v[2] = __uint_as_float(r4.y << 16), v[3] = __uint_as_float(r4.y & 0xffff0000u);
+      v[4] = __uint_as_float(r4.z << 16), v[5] = __uint_as_float(r4.z & 0xffff0000u);
+      v[6] = __uint_as_float(r4.w << 16), v[7] = __uint_as_float(r4.w & 0xffff0000u);
+    } else {
+      v[0] = raw[t].x, v[1] = raw[t].y, v[2] = raw[t].z, v[3] = raw[t].w;
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      // bn_act's own operation order for the affine (it does not commute with max: scales may be negative); ReLU and the
+      // rounding to the storage type the unfused sequence applies before the pool are monotone, so they follow the max
+      const float r = ((v[k] - m[k]) * is[k]) * gw[k] + sh[k];
+      best[k] = ok[t] ? fmaxf(best[k], r) : best[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) best[k] = fmaxf(best[k], 0.f);
+  T* o = y + q * VEC;
+  if (VEC == 8) {
+    F8 b;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) b.v[k] = best[k];
+    st8(reinterpret_cast<bf16_t*>(o), b);
+  } else {
+    st4(o, make_float4(best[0], best[1], best[2], best[3]));
+  }
+}
+
 static inline bool bn_vec8() {   // A/B switch: RSDET_BN_VEC8=0 keeps the four-channel bf16 kernels
   static const bool on = [] {
     const char* e = getenv("RSDET_BN_VEC8");
@@ -709,3 +793,25 @@ typedef float rsdet_bn_f32_t;
 typedef bf16_t rsdet_bn_bf16_t;
 RSDET_BN_NHWC_ENTRIES(f32, float)
 RSDET_BN_NHWC_ENTRIES(bf16, uint16_t)
+
+// y (N, Ho, Wo, C) <- maxpool3x3/s2/p1(relu(bn(x))), x (N, H, W, C) channels-last; Ho = (H + 1) / 2, Wo = (W + 1) / 2.
+// bf16: C % 8 == 0; f32: C % 4 == 0.
+extern "C" int rsdet_bn_relu_maxpool_nhwc(const void* x, int bf16, const float* running_mean, const float* running_var,
+                                          const float* weight, const float* bias, float eps, int N, int C, int H, int W,
+                                          void* y, void* stream) {
+  if (N < 0 || C <= 0 || H < 0 || W < 0 || (C & (bf16 ? 7 : 3))) return RSDET_EINVAL;
+  if (N == 0 || H == 0 || W == 0) return RSDET_OK;
+  if (!x || !running_mean || !running_var || !y) return RSDET_EINVAL;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  hipStream_t s = (hipStream_t)stream;
+  if (bf16) {
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL((bn_relu_maxpool_nhwc_kernel<bf16_t, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const bf16_t*)x, running_mean, running_var, weight, bias, eps, C, H, W, Ho, Wo, total, (bf16_t*)y);
+  } else {
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL((bn_relu_maxpool_nhwc_kernel<float, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const float*)x, running_mean, running_var, weight, bias, eps, C, H, W, Ho, Wo, total, (float*)y);
+  }
+  return rsdet_launch_status();
+}

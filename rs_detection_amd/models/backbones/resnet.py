@@ -11,7 +11,7 @@ here, so weights stay random-initialised (relu-invariant gaussian, fan_out).
 import torch
 import torch.nn as nn
 
-from rs_detection_amd.ops.bn_act import bn_act
+from rs_detection_amd.ops.bn_act import bn_act, bn_relu_maxpool
 from rs_detection_amd.ops.conv1x1 import conv1x1
 from rs_detection_amd.utils.registry import BACKBONES
 
@@ -138,7 +138,7 @@ class ResNet(nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
         frozen_stem = self.frozen_stages >= 0
         with torch.set_grad_enabled(torch.is_grad_enabled() and not frozen_stem):
-            x = self.maxpool(bn_act(self.conv1(x), self.bn1))
+            x = bn_relu_maxpool(self.conv1(x), self.bn1, self.maxpool)   # one pass when no gradient is recorded
         for i in range(1, 5):
             name = f"layer{i}"
             with torch.set_grad_enabled(torch.is_grad_enabled() and i > self.frozen_stages):

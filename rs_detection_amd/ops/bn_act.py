@@ -180,3 +180,34 @@ def bias_act(x, bias, relu=True):
         return _BNAct.apply(x, None, None, bias, mean, var, 0.0, relu)
     out = x + bias.to(x.dtype)[None, :, None, None]
     return F.relu(out) if relu else out
+
+
+def bn_relu_maxpool(x, bn, pool):
+    """``pool(relu(bn(x)))`` -- the ResNet stem tail (models/backbones/resnet.py:186-189 of the reference).  One fused
+    forward pass (csrc/bn_act.hip: bn_relu_maxpool_nhwc_kernel) when no gradient is recorded (the stem is frozen in every
+    shipped config, or inference), the map is channels_last on the GPU, ``bn`` is in eval mode and ``pool`` is the
+    3x3 / stride 2 / padding 1 max-pool: the full-resolution activation is never written.  The unfused sequence otherwise."""
+    C = x.shape[1] if x.dim() == 4 else 0
+    if (not torch.is_grad_enabled() and not _NO_FUSED_BN and x.is_cuda and x.dim() == 4 and not bn.training
+            and x.dtype in (torch.float32, torch.bfloat16) and C % (8 if x.dtype == torch.bfloat16 else 4) == 0
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+            and bn.running_mean is not None and bn.running_mean.dtype == torch.float32
+            and (bn.weight is None or bn.weight.dtype == torch.float32)
+            and isinstance(pool, torch.nn.MaxPool2d) and _pair2(pool.kernel_size) == (3, 3) and _pair2(pool.stride) == (2, 2)
+            and _pair2(pool.padding) == (1, 1) and _pair2(pool.dilation) == (1, 1) and not pool.ceil_mode
+            and not pool.return_indices
+            and (x.dtype == torch.bfloat16 or not torch.is_autocast_enabled())):
+        lib = _lib.load()
+        N, _, H, W = x.shape
+        y = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device,
+                        memory_format=torch.channels_last)
+        rc = lib.rsdet_bn_relu_maxpool_nhwc(_lib.ptr(x), int(x.dtype == torch.bfloat16), _lib.ptr(bn.running_mean),
+                                            _lib.ptr(bn.running_var), _lib.ptr(bn.weight), _lib.ptr(bn.bias), float(bn.eps),
+                                            N, C, H, W, _lib.ptr(y), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_bn_relu_maxpool_nhwc")
+        return y
+    return pool(bn_act(x, bn))
+
+
+def _pair2(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)

@@ -1102,3 +1102,29 @@ def test_bn_act_bf16_channels_last_forms(cuda, C, H, W, relu, res):
     assert bn.weight.grad.dtype == torch.float32
     assert float((bn.weight.grad - w.grad).abs().max()) <= 2e-2 * max(1.0, float(w.grad.abs().max()))
     assert float((bn.bias.grad - b.grad).abs().max()) <= 2e-2 * max(1.0, float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 40, 56), (1, 64, 33, 47), (3, 16, 7, 9), (1, 8, 1, 1)])
+def test_bn_relu_maxpool_stem_tail_is_bit_identical(cuda, dtype, N, C, H, W):
+    """The fused stem tail (bn1 -> relu -> maxpool 3x3/s2/p1 in one pass, csrc/bn_act.hip) == maxpool(bn_act(x)) bit for
+    bit, odd sizes and borders included; with a gradient recorded it falls back to the unfused sequence."""
+    from rs_detection_amd.ops.bn_act import bn_relu_maxpool, bn_act
+    torch.manual_seed(N * 100 + H)
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_(0, 1.0)          # negative scales too: max and the affine do not commute
+        bn.bias.normal_(0, 0.5)
+    pool = torch.nn.MaxPool2d(3, 2, 1)
+    x = torch.randn(N, C, H, W, device=cuda).to(dtype).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        got = bn_relu_maxpool(x, bn, pool)
+        want = pool(bn_act(x, bn))
+    assert got.shape == want.shape == (N, C, (H + 1) // 2, (W + 1) // 2)
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    xg = x.clone().requires_grad_(True)
+    y = bn_relu_maxpool(xg, bn, pool)           # gradient recorded: the unfused path, differentiable
+    y.float().sum().backward()
+    assert xg.grad is not None and torch.equal(y.detach(), want)
