@@ -64,6 +64,7 @@ def use_packaged_miopen_db():
     except OSError:
         return None
     os.environ["MIOPEN_USER_DB_PATH"] = dst
+    os.environ["RSDET_MIOPEN_DB_IN_USE"] = dst     # child processes (bench.py --gpus N, loader workers) inherit both
     return dst
 
 
@@ -85,5 +86,6 @@ def packaged_records_match():
         return False
     want = "%d_%d_%d_" % (v // 1000000, (v // 1000) % 1000, v % 1000)
     user = os.environ.get("MIOPEN_USER_DB_PATH")
-    ours = user is None or os.path.realpath(user) == os.path.realpath(_private_dir() or "")
+    mine = os.environ.get("RSDET_MIOPEN_DB_IN_USE")      # set by use_packaged_miopen_db(), here or in a parent process
+    ours = user is None or (mine is not None and os.path.realpath(user) == os.path.realpath(mine))
     return ours and any(re.search(r"\.HIP\." + re.escape(want), os.path.basename(f)) for f in files)
