@@ -495,6 +495,12 @@ int rsdet_bn_act_backward_bf16(const uint16_t* grad_y, const uint16_t* y, const 
  * NCHW).  NHWC -> NCHW: B = N, R = H*W, C = channels.  in != out; R <= 64*65535. */
 int rsdet_transpose_last2_f32(const float* in, float* out, int B, int R, int C, void* stream);
 
+/* Channels-last convolution weights for "backward-data as a forward convolution" (a stride-1 / same-padding convolution's
+ * input gradient is the forward convolution of the output gradient with the taps reversed and the channel axes
+ * exchanged; the reference's convolutions: models/utils/modules.py ConvModule, models/backbones/resnet.py:101-126):
+ * in (O, T, C) -> out (C, T, O) with tap t -> T - 1 - t; elem_bytes 2 or 4, bits copied. */
+int rsdet_weight_flip_transpose(const void* in, void* out, int O, int C, int T, int elem_bytes, void* stream);
+
 /* Column sums of a (rows, C) matrix, C <= 64: out[c] = sum_r x[r, c] in fp32 (two deterministic stages).  The bias
  * gradient of a channels_last convolution with few output channels (the 5- / 15-channel prediction maps of
  * models/roi_heads/s2anet_head.py:128-142): rows = N*H*W. */

@@ -95,6 +95,7 @@ SIGNATURES = {
     "rsdet_deform_im2col_bf16col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),
     "rsdet_deform_col2im_gather_nhwc_bf16col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
                                                             c_void_p, c_size_t, c_void_p]),
+    "rsdet_weight_flip_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rsdet_transpose_last2_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rsdet_mt_chunk_elems": (c_int, []),
     "rsdet_mt_sgd_state_bytes": (c_size_t, [c_int]),

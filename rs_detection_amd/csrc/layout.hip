@@ -49,6 +49,29 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
   }
 }
 
+
+// Channels-last convolution weights (O, T, C) -> (C, T', O) with the T taps reversed (t' = T - 1 - t): the weights of the
+// convolution that computes a stride-1 "same" convolution's INPUT gradient as a forward convolution of the output
+// gradient (ops/conv3x3.py).  One 32 x 32 (o, c) tile per workgroup and tap through LDS; elements are copied as bits.
+template <typename E>
+__global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const E* __restrict__ in, E* __restrict__ out, int O,
+                                                                    int C, int T) {
+  __shared__ E tile[32][33];
+  const int t = blockIdx.z, o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = o0 + ty + 8 * i, c = c0 + tx;
+    if (o < O && c < C) tile[ty + 8 * i][tx] = in[((long long)o * T + t) * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, o = o0 + tx;
+    if (o < O && c < C) out[((long long)c * T + (T - 1 - t)) * O + o] = tile[tx][ty + 8 * i];
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -62,5 +85,23 @@ extern "C" int rsdet_transpose_last2_f32(const float* in, float* out, int B, int
   hipLaunchKernelGGL(transpose_last2_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)B), dim3(256), 0,
                      (hipStream_t)stream, in, out, R, C,
                      (((uintptr_t)in | (uintptr_t)out) & 15) == 0 ? 1 : 0);
+  return rsdet_launch_status();
+}
+
+// in: (O, T, C) elements of elem_bytes (2 or 4) -- a channels_last (O, C, kh, kw) weight with T = kh * kw;
+// out: (C, T, O) with the taps reversed -- the channels_last (C, O, kh, kw) weight flipped in both spatial directions.
+extern "C" int rsdet_weight_flip_transpose(const void* in, void* out, int O, int C, int T, int elem_bytes, void* stream) {
+  if (O < 0 || C < 0 || T < 0 || (elem_bytes != 2 && elem_bytes != 4)) return RSDET_EINVAL;
+  if (O == 0 || C == 0 || T == 0) return RSDET_OK;
+  if (!in || !out || in == out || T > 65535) return RSDET_EINVAL;
+  const dim3 grid((C + 31) / 32, (O + 31) / 32, T);
+  if (grid.y > 65535u) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(weight_flip_transpose_kernel<uint32_t>, grid, dim3(256), 0, s, (const uint32_t*)in, (uint32_t*)out,
+                       O, C, T);
+  else
+    hipLaunchKernelGGL(weight_flip_transpose_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)in, (uint16_t*)out,
+                       O, C, T);
   return rsdet_launch_status();
 }

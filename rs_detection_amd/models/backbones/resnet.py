@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from rs_detection_amd.ops.bn_act import bn_act, bn_relu_maxpool
 from rs_detection_amd.ops.conv1x1 import conv1x1
+from rs_detection_amd.ops.conv3x3 import fast_conv
 from rs_detection_amd.utils.registry import BACKBONES
 
 __all__ = ['ResNet', 'Resnet18', 'Resnet34', 'Resnet50', 'Resnet101', 'Resnet152']
@@ -62,7 +63,7 @@ class Bottleneck(nn.Module):
         # conv1 / conv3 / a stride-1 downsample are 1x1: GEMMs on views when the step runs channels_last (ops/conv1x1.py)
         idt = x if self.downsample is None else bn_act(conv1x1(self.downsample[0], x), self.downsample[1], relu=False)
         out = bn_act(conv1x1(self.conv1, x), self.bn1)
-        out = bn_act(self.conv2(out), self.bn2)
+        out = bn_act(fast_conv(self.conv2, out), self.bn2)      # stride-1 3x3: backward-data via the forward solver
         return bn_act(conv1x1(self.conv3, out), self.bn3, residual=idt)
 
 

@@ -421,7 +421,11 @@ class S2ANetHead(nn.Module):
         ac = pyramid_pack(align, lay, channels_last=not xc.is_contiguous())
         oc = self.or_conv
         w = oc.rotate_arf() if isinstance(oc, ORConv2d) else oc.weight
-        or_feat = F.conv2d(ac, w, None, oc.stride, oc.padding, oc.dilation, oc.groups)
+        from rs_detection_amd.ops.conv3x3 import conv3x3_applies, conv3x3_same
+        if conv3x3_applies(ac, w, oc.stride, oc.padding, oc.dilation, oc.groups):
+            or_feat = conv3x3_same(ac, w)
+        else:
+            or_feat = F.conv2d(ac, w, None, oc.stride, oc.padding, oc.dilation, oc.groups)
         if oc.bias is not None:
             or_feat = canvas_bias_act(or_feat, oc.bias, lay, relu=False)
         else:

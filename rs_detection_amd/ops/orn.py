@@ -242,4 +242,8 @@ class ORConv2d(nn.Conv2d):
         return active_rotating_filter(self.weight, self.indices)
 
     def forward(self, input):
-        return F.conv2d(input, self.rotate_arf(), self.bias, self.stride, self.padding, self.dilation, self.groups)
+        w = self.rotate_arf()
+        from .conv3x3 import conv3x3_applies, _Conv3x3Same
+        if conv3x3_applies(input, w, self.stride, self.padding, self.dilation, self.groups):
+            return _Conv3x3Same.apply(input, w, self.bias)     # backward-data through the forward solver
+        return F.conv2d(input, w, self.bias, self.stride, self.padding, self.dilation, self.groups)

@@ -328,3 +328,59 @@ def test_conv1x1_gemm_split_matches_conv2d(cuda, dtype, B, C, O, H, W, bias):
             continue
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W,bias", [(2, 64, 40, 24, False), (1, 32, 37, 51, True), (2, 256, 16, 20, True)])
+def test_conv3x3_backward_data_through_the_forward_solver(cuda, monkeypatch, dtype, B, C, H, W, bias):
+    """ops/conv3x3.py: a square 3x3 / stride-1 / padding-1 convolution whose input gradient is computed as a FORWARD
+    convolution of the output gradient with the flipped, channel-transposed weights == nn.Conv2d: values and all three
+    gradients (odd sizes: the borders are where a wrong flip or padding would show)."""
+    from rs_detection_amd.ops import conv3x3 as c3
+    from rs_detection_amd.ops.conv3x3 import fast_conv, conv3x3_applies
+    monkeypatch.setattr(c3, "_F32", True)         # the fp32 route is off by default (neutral on the step): test it too
+    torch.manual_seed(C + H)
+    conv = torch.nn.Conv2d(C, C, 3, padding=1, bias=bias).to(cuda).to(memory_format=torch.channels_last)
+    x = torch.randn((B, C, H, W), device=cuda).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = torch.randn((B, C, H, W), device=cuda).contiguous(memory_format=torch.channels_last)
+    xr = x.clone().requires_grad_(True)
+    assert conv3x3_applies(xr, conv.weight) and not conv3x3_applies(x, conv.weight)          # no gradient wanted: plain
+    assert not conv3x3_applies(xr, torch.nn.Conv2d(C, 2 * C, 3, padding=1).to(cuda).weight)   # not square
+    assert not conv3x3_applies(xr.detach().contiguous().requires_grad_(True), conv.weight)    # NCHW
+    outs = []
+    for fn in (lambda t: fast_conv(conv, t), lambda t: conv(t)):
+        xa = x.clone().requires_grad_(True)
+        conv.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = fn(xa)
+        assert y.dtype == dtype
+        y.backward(g.to(dtype))
+        outs.append((y.detach().float(), xa.grad.float(), conv.weight.grad.float().clone(),
+                     conv.bias.grad.float().clone() if bias else None))
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-5
+    for a, b in zip(*outs):
+        if a is None:
+            continue
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6
+
+
+def test_orconv_backward_data_through_the_forward_solver(cuda, monkeypatch):
+    """ORConv2d (8 rotated copies of the filters: 256 -> 256 as a plain 3x3 convolution of the rotated weight) takes the
+    same route; gradients reach the ARF weight through rotate_arf as before."""
+    from rs_detection_amd.ops.orn import ORConv2d
+    from rs_detection_amd.ops import conv3x3 as c3
+    monkeypatch.setattr(c3, "_F32", True)
+    torch.manual_seed(7)
+    m = ORConv2d(64, 8, kernel_size=3, padding=1, arf_config=(1, 8)).to(cuda)
+    x = torch.randn((2, 64, 20, 24), device=cuda).contiguous(memory_format=torch.channels_last)
+    g = torch.randn((2, 64, 20, 24), device=cuda)
+    res = []
+    for cl in (True, False):
+        xa = (x if cl else x.contiguous()).clone().requires_grad_(True)
+        m.zero_grad()
+        y = m(xa)
+        y.backward(g)
+        res.append((y.detach(), xa.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone()))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-6
