@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc_kernel(const T* __re
       // bn_act's own operation order for the affine (it does not commute with max: scales may be negative); ReLU and the
       // rounding to the storage type the unfused sequence applies before the pool are monotone, so they follow the max
       const float r = ((v[k] - m[k]) * is[k]) * gw[k] + sh[k];
-      best[k] = ok[t] ? fmaxf(best[k], r) : best[k];
+      best[k] = ok[t] ? fmaxf(best[k], r) : best[k];     // a NaN input loses, as it does after bn_act's fmaxf ReLU
     }
   }
 #pragma unroll

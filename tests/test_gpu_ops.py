@@ -1118,12 +1118,16 @@ def test_bn_relu_maxpool_stem_tail_is_bit_identical(cuda, dtype, N, C, H, W):
         bn.weight.normal_(0, 1.0)          # negative scales too: max and the affine do not commute
         bn.bias.normal_(0, 0.5)
     pool = torch.nn.MaxPool2d(3, 2, 1)
-    x = torch.randn(N, C, H, W, device=cuda).to(dtype).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device=cuda).to(dtype)
+    x[0, 0, 0, 0] = float("nan")                 # non-finite inputs: as through bn_act (its ReLU maps NaN to 0) + max_pool2d
+    x[-1, -1, -1, -1] = float("inf")
+    x = x.contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         got = bn_relu_maxpool(x, bn, pool)
         want = pool(bn_act(x, bn))
     assert got.shape == want.shape == (N, C, (H + 1) // 2, (W + 1) // 2)
-    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert not torch.isnan(want).any() and torch.equal(got, want)
     xg = x.clone().requires_grad_(True)
     y = bn_relu_maxpool(xg, bn, pool)           # gradient recorded: the unfused path, differentiable
     y.float().sum().backward()
