@@ -1,4 +1,4 @@
-import sys, os, cProfile, pstats, io; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, cProfile, pstats, io; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 import torch
 from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db; use_packaged_miopen_db()
@@ -8,7 +8,7 @@ from rs_detection_amd.utils import synthetic as syn
 dev = torch.device("cuda", 0)
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 runner = Runner(bench.s2anet_cfg(), device=dev, amp_dtype=torch.bfloat16 if dt == "bf16" else None,
-                memory_format=torch.channels_last if dt == "bf16" else None)
+                memory_format=torch.channels_last if dt == "bf16" else None, bf16_params=(dt == "bf16"))
 images = torch.randn(4, 3, 1024, 1024, device=dev)
 if dt == "bf16":
     images = images.contiguous(memory_format=torch.channels_last)
