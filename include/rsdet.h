@@ -111,16 +111,20 @@ int rsdet_box_iou_rotated_split_f32(const float* boxes1, int n1, int stride1, co
  * Tier 1 (every overlapping pair): intersection area by Green's theorem, one lane per pair, registers only.
  * Tier 2 (the reference-order clipper of rsdet_box_iou_rotated_f32): pairs in which a corner of one box lies within
  * 0.01 px of an edge of the other -- where the REFERENCE itself leaves the true area (its hull scan reads dist[] with
- * pre-sort indices, box_iou_rotated.py:199-212) -- pairs with IoU < 3e-5 (exact zeros are kept) and NaN boxes.
+ * pre-sort indices, box_iou_rotated.py:199-212) -- pairs with IoU < 1e-6 (exact zeros are kept) and NaN boxes.
+ * Every element of the matrix is stored exactly once: zeros of the (row, 64-column) cells whose bounding shapes are
+ * apart by dedicated store workgroups, the other cells by the workgroups that compute them.
  * Replaces ops/box_iou_rotated.py:502-509 / box_iou_rotated_v1.py:507-524 for callers that need the VALUES only;
  * callers that derive indices from thresholds or ties (MaxIoUAssigner) keep the bit-exact entries above or use
  * rsdet_anchor_target_rotated_f32.  Arguments as rsdet_box_iou_rotated_tiled_f32, except that row tiles hold
- * rsdet_box_iou_rotated_fast_rows_per_tile() (= 32) rows (heavy column tiles: four 8-row sub-tiles). */
+ * rsdet_box_iou_rotated_fast_rows_per_tile() (= 64) rows and that there are two performance hints (any value is
+ * correct; -1 = none): column tiles from heavy_from_col on (large boxes: most rows overlap them) are worked on in
+ * 8-row sub-tiles, those from medium_from_col (<= heavy_from_col) on in 32-row sub-tiles. */
 int rsdet_box_iou_rotated_fast_rows_per_tile(void);
 int rsdet_box_iou_rotated_fast_f32(const float* boxes1, int n1, int stride1, const int* row_offsets, int n_groups,
                                    int max_rows_per_group, const int* tile_table, int n_row_tiles,
                                    const void* prepared1, const void* prepared2, int n2, int per_group,
-                                   int heavy_from_col, int version, float* ious, void* stream);
+                                   int medium_from_col, int heavy_from_col, int version, float* ious, void* stream);
 
 /* anchor_target for a whole batch WITHOUT the (K, A) matrix: rotated IoU of the surviving pairs only
  * (1.2 % at S2ANet shapes) -> MaxIoUAssigner (column max / first argmax, thresholds, low-quality

@@ -36,7 +36,7 @@ SIGNATURES = {
                                                 c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rsdet_box_iou_rotated_fast_rows_per_tile": (c_int, []),
     "rsdet_box_iou_rotated_fast_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                                               c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                               c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rsdet_box_iou_rotated_split_state_bytes": (c_size_t, []),
     "rsdet_box_iou_rotated_split_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "rsdet_box_iou_rotated_split_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
