@@ -12,6 +12,7 @@ hands ``num_workers`` to Jittor's multi-process ``Dataset``).
   side stream; the training stream only waits for the copy's event, so decode, collate and PCIe overlap the step."""
 import multiprocessing as mp
 import os
+import collections
 import queue
 import random
 import threading
@@ -227,7 +228,17 @@ def prefetch_to_device(dataset, device, depth=2):
         try:
             torch.cuda.set_device(dev)
             slot = 0
-            for images, targets in dataset:
+            copied = collections.deque()   # events of the batches whose pinned source may still be read by the side stream
+            it = iter(dataset)
+            while True:
+                # A pinned source buffer (the dataset's collate ring of 6, the staging ring of depth + 2 below) is
+                # rewritten a few batches later: the copy that read it three batches ago must be over first.
+                while len(copied) >= 3:
+                    copied.popleft().synchronize()
+                try:
+                    images, targets = next(it)
+                except StopIteration:
+                    break
                 if stop.is_set():
                     return
                 arr = np.ascontiguousarray(images)
@@ -250,6 +261,7 @@ def prefetch_to_device(dataset, device, depth=2):
                         tg_d.append(t)
                     ev = torch.cuda.Event()
                     ev.record(side)
+                copied.append(ev)
                 q.put((img_d, tg_d, ev))
                 slot += 1
             q.put(None)
@@ -266,8 +278,17 @@ def prefetch_to_device(dataset, device, depth=2):
             if isinstance(item, BaseException):
                 raise item
             img_d, tg_d, ev = item
-            torch.cuda.current_stream(dev).wait_event(ev)
-            img_d.record_stream(torch.cuda.current_stream(dev))
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)
+            # Every tensor allocated on the side stream is used on the consumer's stream: without record_stream the
+            # caching allocator hands a dropped block back to the side-stream pool at once, and the feeder -- two or
+            # three batches ahead of a GPU that itself runs behind the host -- would overwrite targets that queued
+            # kernels have not read yet.
+            img_d.record_stream(cur)
+            for t in tg_d:
+                for v in t.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
             yield img_d, tg_d
     finally:
         stop.set()

@@ -100,9 +100,12 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         """name -> fp32 tensor for every parameter of ``model`` (the master where the model holds bf16): what a
         checkpoint stores, so that a saved run continues from the unrounded weights."""
         out = {}
+        frozen = getattr(self, "frozen_masters", None) or {}
         for name, p in model.named_parameters():
             st = self.state.get(p, {})
-            out[name] = st["master"] if "master" in st else p.detach()
+            # a frozen weight the Runner cast to bf16 has no optimizer state: its fp32 original is kept in
+            # ``frozen_masters`` (set by the Runner), so a save / load cycle does not round the pretrained values
+            out[name] = st["master"] if "master" in st else frozen.get(name, p.detach())
         return out
 
     def set_masters(self, model, params):
@@ -111,12 +114,17 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         import numpy as np
         named = dict(model.named_parameters())
         with torch.no_grad():
+            frozen = getattr(self, "frozen_masters", None)
             for k, v in params.items():
                 p = named.get(k)
-                if p is None or p.dtype != torch.bfloat16 or not p.requires_grad:
+                if p is None or p.dtype != torch.bfloat16:
                     continue
                 t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else torch.as_tensor(v)
                 if tuple(t.shape) != tuple(p.shape):
+                    continue
+                if not p.requires_grad:
+                    if frozen is not None and k in frozen:
+                        frozen[k].copy_(t.to(device=p.device, dtype=torch.float32))
                     continue
                 st = self._ensure_state(p)
                 st["master"].copy_(t.to(device=p.device, dtype=torch.float32))

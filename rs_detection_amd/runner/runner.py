@@ -5,7 +5,7 @@ hot path needs: ``train_step`` (forward, parse_losses, backward, grad all-reduce
 clip 35, SGD update, LR schedule -- :131-179) and ``test_time`` (:105-129: warm-up then timed
 iterations on one cached batch, prints FPS), ``save`` / ``load`` / ``resume`` in the reference's checkpoint
 layout (:251-290, runner/checkpoint.py), and the epoch loop ``run`` / ``train`` / ``val`` (:91-103, :131-208) over the
-``dataset.train`` / ``dataset.val`` sections of the config (data/).  Loggers are a print line; flip-test and the
+``dataset.train`` / ``dataset.val`` sections of the config (data/).  ``cfg.logger`` (RunLogger) writes the reference's text log; flip-test and the
 tile-merge submission of ``test`` live in data/devkits.
 """
 import os
@@ -16,6 +16,7 @@ import torch
 import rs_detection_amd.models  # noqa: F401  (registers everything)
 from rs_detection_amd.optims import optimizer as _o, lr_scheduler as _s  # noqa: F401
 from rs_detection_amd.utils import dist as rdist
+from rs_detection_amd.utils import logger as _l  # (registers RunLogger / TextLogger / TensorboardLogger)
 from rs_detection_amd.utils.general import parse_losses
 from rs_detection_amd.utils.registry import MODELS, OPTIMS, SCHEDULERS, build_from_cfg
 
@@ -49,13 +50,19 @@ class Runner:
         # BatchNorm parameters, the ARF weight of ORConv2d (fp32 kernels) and every other parameter stay fp32.
         if bf16_params is None:
             bf16_params = os.environ.get("RSDET_BF16_PARAMS", "0") == "1"
+        # Not with an SWA phase: ``optimizer_swa`` is a plain optimizer over the same parameters and would update the bf16
+        # copies while FusedSGD's fp32 masters went stale (and the checkpoint, which stores the masters, lost the phase).
         self.bf16_params = bool(bf16_params) and amp_dtype == torch.bfloat16 and device.type == "cuda" and \
-            bool(cfg.optimizer) and cfg.optimizer.get("type") == "SGD"
+            bool(cfg.optimizer) and cfg.optimizer.get("type") == "SGD" and not getattr(cfg, "optimizer_swa", None)
+        frozen_masters = {}
         if self.bf16_params:
-            for m in self.model.modules():
+            for mname, m in self.model.named_modules():
                 if type(m) in (torch.nn.Conv2d, torch.nn.Linear):
                     # weights only (frozen stages too: autocast casts those every step as well); the biases stay fp32
-                    # -- the fused bias + ReLU tails (ops/bn_act.bias_act) take fp32 per-channel parameters
+                    # -- the fused bias + ReLU tails (ops/bn_act.bias_act) take fp32 per-channel parameters.  A frozen
+                    # weight has no optimizer state to hold its fp32 original, so the Runner keeps it for checkpoints.
+                    if not m.weight.requires_grad:
+                        frozen_masters[(mname + "." if mname else "") + "weight"] = m.weight.detach().float().clone()
                     m.weight.data = m.weight.data.to(torch.bfloat16)
         params = [p for p in self.model.parameters() if p.requires_grad]
         opt_cfg = cfg.optimizer
@@ -68,6 +75,8 @@ class Runner:
         if self.bf16_params or fused_ok:
             opt_cfg = dict(cfg.optimizer, type="FusedSGD")
         self.optimizer = build_from_cfg(opt_cfg, OPTIMS, params=params) if cfg.optimizer else None
+        if frozen_masters and self.optimizer is not None:
+            self.optimizer.frozen_masters = frozen_masters
         self.scheduler = build_from_cfg(cfg.scheduler, SCHEDULERS, optimizer=self.optimizer) \
             if (cfg.scheduler and self.optimizer) else None
         # the SWA phase (runner.py:51-53): its own optimizer + per-epoch cosine schedule over the same parameters
@@ -86,6 +95,7 @@ class Runner:
         self.max_iter = cfg.max_iter if hasattr(cfg, "max_iter") else None
         self.train_dataset = self.val_dataset = self.test_dataset = None
         self.work_dir = None
+        self.logger = None          # built from cfg.logger on the first record, once work_dir is known (rank 0)
 
     def train_step(self, images, targets, swa_factor=None):
         """One iteration (:138-150).  ``swa_factor`` = batch_idx / batches_per_epoch switches to the SWA optimizer and
@@ -153,15 +163,42 @@ class Runner:
             # train_step advances self.iter
             total, losses = self.train_step(images, targets, swa_factor=batch_idx / n_batches if swa else None)
             last = total
-            if log_interval and self.iter % log_interval == 0 and self.rank == 0:
-                fps = len(targets) * self.world * (batch_idx + 1) / (time.time() - start)
-                print("epoch %d iter %d lr %.5f loss %.4f fps %.1f " % (self.epoch, self.iter, (self.optimizer_swa if swa else self.optimizer).cur_lr(),
-                                                                      float(total.detach()), fps) +
-                      " ".join("%s %.4f" % (k, float(v.detach())) for k, v in losses.items()))
+            if log_interval and self.iter % log_interval == 0:
+                self._log_step(batch_idx, len(targets), total, losses, time.time() - start, n_batches, swa)
             if self.finish:
                 break
         self.epoch += 1
         return last
+
+    def _log_step(self, batch_idx, n_images, total, losses, elapsed, n_batches, swa=False):
+        """The reference's log record (runner.py:151-171): name, lr, iter, epoch, batch_idx, batch_size, total_loss, fps,
+        eta and the loss terms, averaged over the ranks (``sync``), handed on rank 0 to the logger the config names
+        (``logger=dict(type="RunLogger")`` -> ``<work_dir>/textlog``, ``<work_dir>/tensorboard``, a console line).
+        Without a ``work_dir`` there are no files: the console line alone."""
+        import datetime
+        scal = dict(losses)
+        scal["total_loss"] = total
+        scal = rdist.sync_mean(scal, self.device)          # every rank takes part in the mean; one host read per record
+        if self.rank != 0:
+            return
+        batch_size = n_images * self.world
+        if self.max_epoch:
+            total_iter = self.max_epoch * n_batches
+        else:
+            total_iter = self.max_iter or self.iter
+        eta = max(total_iter - self.iter, 0) * elapsed / (batch_idx + 1)
+        data = dict(name=getattr(self.cfg, "name", None), lr=(self.optimizer_swa if swa else self.optimizer).cur_lr(),
+                    iter=self.iter, epoch=self.epoch, batch_idx=batch_idx, batch_size=batch_size,
+                    total_loss=scal.pop("total_loss"), fps=batch_size * (batch_idx + 1) / max(elapsed, 1e-9),
+                    eta=str(datetime.timedelta(seconds=int(eta))))
+        data.update(scal)
+        if self.logger is None and self.work_dir and getattr(self.cfg, "logger", None):
+            from rs_detection_amd.utils.registry import HOOKS
+            self.logger = build_from_cfg(self.cfg.logger, HOOKS, work_dir=self.work_dir)
+        if self.logger is not None:
+            self.logger.log(data)
+        else:
+            _l.print_record(data)
 
     @torch.no_grad()
     def _predict_dataset(self, dataset, flip_test=()):
@@ -275,7 +312,6 @@ class Runner:
                         return [back(v) for v in o]
                     return o
                 self.optimizer.load_state_dict(back(opt))
-                self.optimizer._params_key = None if hasattr(self.optimizer, "_params_key") else None
         out = load_parameters(self.model, model_parameters(data))
         if hasattr(self.optimizer, "set_masters"):        # bf16 model weights: the file's fp32 values are the masters
             self.optimizer.set_masters(self.model, model_parameters(data))

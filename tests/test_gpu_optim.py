@@ -107,7 +107,11 @@ def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
     path = str(tmp_path / "ckpt.pkl")
     rb.save(path)
     raw = read_checkpoint(path)
-    assert raw["model"]["backbone.layer1.0.conv1.weight"].dtype == np.float32      # frozen stage: widened bf16 copy
+    # frozen stage: the fp32 ORIGINAL (the Runner keeps it beside the bf16 copy), not the widened bf16 rounding of it
+    frozen_ref = runs[False][0].model.backbone.layer1[0].conv1.weight.detach().float().cpu().numpy()   # same seed, fp32, never updated
+    assert raw["model"]["backbone.layer1.0.conv1.weight"].dtype == np.float32
+    assert np.array_equal(raw["model"]["backbone.layer1.0.conv1.weight"], frozen_ref)
+    assert not np.array_equal(frozen_ref, rb.model.backbone.layer1[0].conv1.weight.detach().float().cpu().numpy())
     m = rb.optimizer.state[rb.model.backbone.layer2[0].conv1.weight]["master"]
     assert np.array_equal(raw["model"]["backbone.layer2.0.conv1.weight"], m.cpu().numpy())
     ra = runs[False][0]
@@ -119,6 +123,9 @@ def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
         rc = Runner(cfg, device=cuda, distributed=False, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
                     bf16_params=True)
     rc.load(path)
+    path2 = str(tmp_path / "ckpt2.pkl")
+    rc.save(path2)                       # a save / load / save cycle keeps the frozen fp32 values bit for bit
+    assert np.array_equal(read_checkpoint(path2)["model"]["backbone.layer1.0.conv1.weight"], frozen_ref)
     w = rc.model.backbone.layer2[0].conv1.weight
     assert torch.equal(rc.optimizer.state[w]["master"], m) and torch.equal(w.detach(), m.to(torch.bfloat16))
     t3, _ = rc.train_step(images, targets)
