@@ -12,10 +12,14 @@ IoU + MaxIoU assignment), focal/smooth-L1 losses, backward, RCCL gradient all-re
 grad-clip 35, SGD update.  Inputs (tiles and targets) are resident in HBM before the timed
 region.  Weak scaling: 4 tiles per GPU at every N.
 
-Extra objects on the same JSON line:
-  roofline      dominant hand-written kernel of the north-star metric (batched rotated IoU at
-                the step's own shape), HIP-event timed in this process
-  kernels       the same measurement for every other hand-written kernel on the path
+Extra objects on the same JSON line (kept under 8 KB: the driver's record truncates longer lines):
+  roofline      the oriented-box call the timed step makes (fused anchor targets), HIP-event timed in
+                this process; roofline_dense_iou / roofline_dense_iou_two_tier / roofline_nms beside it
+  kernels_top12 {us, frac, bound} of the 12 hand-written kernels with the most time; the full table
+                goes to kernels_file (gpurun_out/bench_kernels.json or ./bench_kernels.json) and stderr
+  bf16, bf16_*  the second timed leg (bf16 autocast, channels_last) and its flat scalars
+  fresh_k*      a short leg on never-seen gt-count tuples (what --fresh-k times in full)
+  host_enqueue_ms_per_step   host time to enqueue a step (== ms_per_step: the host paces the GPU)
   cpu_baseline  the reference's own CPU rotated-IoU source (oracle/_ref, kind "reference";
                 falls back to the oracle restatement, kind "port") on this box's host cores
 """
@@ -102,13 +106,23 @@ def event_time(fn, iters, warmup=3, graph=True):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r03_roofline.json")
-if not os.path.exists(ROOFLINE_FILE):
-    ROOFLINE_FILE = os.path.join(ROOT, "profiles", "r02_roofline.json")
+ROOFLINE_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_roofline.json" % r) for r in (4, 3, 2))
+                      if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04_roofline.json"))
 FAST_ROW = "box_iou_rotated_fast(two-tier clipper, 1 launch; prepared anchors cached, gts prepared in the tile)"
 AT_ROW = "anchor_target_rotated(fused: IoU + assign + encode + weights; 2 launches)"
 BN_ROW = "bn_act_forward_kernel<f32>(bn + residual + relu; 4x256x256x256, NCHW)"
 BN_ROW_CL = "bn_act_forward_nhwc_kernel<f32>(bn + residual + relu; 4x256x256x256, layer1 of the channels_last step)"
+NMS_ROW = "nms_rotated(3 kernels; label-major order, as ml_nms_rotated calls it)"
+
+
+def issue_side():
+    """VALU / latency side of the calls whose HBM fraction says nothing (anchor targets, NMS, the dense two-tier IoU):
+    VALU instructions issued / issue slots of the launch, waiting share, from the SQ-counter passes committed in
+    profiles/ (`issue` object of the roofline file, written by profiles/scripts/roofline.py) -- never a literal here."""
+    if not os.path.exists(ROOFLINE_FILE):
+        return {}
+    with open(ROOFLINE_FILE) as f:
+        return json.load(f).get("issue", {})
 
 
 def pmc_traffic(call, shape_ok):
@@ -423,19 +437,44 @@ def make_batches(n, batch, rank, ncls, device, mf, orcnn):
 
 
 def timed_region(runner, batches, steps, rdist, device):
-    """EXACTLY `steps` train steps between barrier + synchronize on both sides; max over ranks."""
+    """EXACTLY `steps` train steps between barrier + synchronize on both sides; max over ranks.  Also returns the host
+    time the loop took to ENQUEUE the steps (before the closing synchronize): enqueue ~ total means the host, not the
+    GPU, paces the step -- the number that explains a flat multi-GPU curve with one Python process per GPU."""
     rdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         loss, _ = runner.train_step(*batches[i % len(batches)])
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     rdist.barrier()
     dt = time.perf_counter() - t0
     dt = rdist.all_reduce_max(dt, device)
     loss_v = float(loss.detach())
     assert np.isfinite(loss_v), "non-finite loss"
-    return dt, loss_v
+    return dt, loss_v, t_enq
+
+
+def fresh_k_batches(batches, n, rank, ncls, device, orcnn):
+    """`n` target sets with a K tuple never seen before (a real DOTA stream brings new gt counts every step),
+    on the images of the resident batches: every step then misses the per-K-tuple tile table of the anchor-target path
+    (ops/anchor_target.row_tile_table: built on the host, one pinned upload) and meets new allocation sizes."""
+    from rs_detection_amd.utils import synthetic as syn
+    rng = np.random.default_rng(99 + rank)
+    out = []
+    for it in range(n):
+        images, tg0 = batches[it % len(batches)]
+        ks = [int(k) for k in rng.integers(8, 420, len(tg0))]
+        targets = []
+        for j, k in enumerate(ks):
+            t = dict(syn.synthetic_targets(1, rank=rank, it=1000 + it * 16 + j, num_classes=ncls, img=TILE, ks=[k])[0])
+            t["rboxes"] = torch.from_numpy(t["rboxes"]).to(device)
+            t["labels"] = torch.from_numpy(t["labels"]).to(device)
+            if orcnn:
+                t["hboxes"] = None
+            targets.append(t)
+        out.append((images, targets))
+    return out
 
 
 def main():
@@ -446,6 +485,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the second (bf16) timed leg of the default line")
+    ap.add_argument("--fresh-k", action="store_true",
+                    help="the timed steps see a NEW gt-count tuple every step (the per-iteration stream of real DOTA "
+                         "batches) instead of the four rotating resident batches; without the flag the default line "
+                         "reports that mode as a short extra leg (fresh_k_ms_per_step)")
+    ap.add_argument("--kernels-out", default=None, help="where the full per-kernel table goes (default: "
+                    "gpurun_out/bench_kernels.json when that directory exists, else ./bench_kernels.json); the JSON "
+                    "line itself carries the 12 rows with the most time")
     ap.add_argument("--bf16-params", choices=["0", "1"], default=os.environ.get("RSDET_BF16_PARAMS", "1"),
                     help="bf16 legs: conv / linear weights held in bf16 with fp32 masters in the fused optimizer "
                          "(csrc/optim.hip; 1, default) or fp32 parameters under autocast + foreach SGD (0)")
@@ -539,9 +585,25 @@ def main():
             else:
                 os.environ["RSDET_S2A_PACKED"] = prev
         step_flops = float(fc.get_total_flops())
+    orcnn = args.model == "orcnn_van3"
+    timed_batches = batches
+    if args.fresh_k:
+        timed_batches = fresh_k_batches(batches, args.warmup + args.steps, rank, ncls, device, orcnn)
     for i in range(args.warmup):
-        runner.train_step(*batches[i % N_BATCHES])
-    dt, loss_v = timed_region(runner, batches, args.steps, rdist, device)
+        runner.train_step(*timed_batches[i % len(timed_batches)])
+    if args.fresh_k:
+        timed_batches = timed_batches[args.warmup:]
+    dt, loss_v, t_enq = timed_region(runner, timed_batches, args.steps, rdist, device)
+    # short extra leg of the default line: the same runner on never-seen K tuples (what --fresh-k times in full)
+    fresh = None
+    if not args.fresh_k and args.model == "s2anet_r50":
+        nf = min(max(args.steps, 8), 16)
+        fb = fresh_k_batches(batches, nf + 2, rank, ncls, device, orcnn)
+        for b_ in fb[:2]:
+            runner.train_step(*b_)
+        dtf, _, enqf = timed_region(runner, fb[2:], nf, rdist, device)
+        fresh = dict(ms_per_step=dtf / nf * 1e3, steps=nf, host_enqueue_ms_per_step=enqf / nf * 1e3)
+        del fb
     BN_DOM = BN_ROW_CL if args.memory_format == "channels_last" else BN_ROW     # the form the timed fp32 step ran
 
     # second, separately timed leg: the SAME model and batches in bf16 autocast + channels_last (BASELINE configs[2]'s
@@ -560,10 +622,10 @@ def main():
         for i in range(warm16):
             r16.train_step(*b16[i % N_BATCHES])
         steps16 = max(args.steps, 20)
-        dt16, loss16 = timed_region(r16, b16, steps16, rdist, device)
+        dt16, loss16, enq16 = timed_region(r16, b16, steps16, rdist, device)
         bf16_leg = {"value": batch * world * steps16 / dt16, "unit": "tiles/s", "ms_per_step": dt16 / steps16 * 1e3,
                     "steps": steps16, "warmup": warm16, "dtype": "bf16", "memory_format": "channels_last",
-                    "bf16_params": bool(r16.bf16_params),
+                    "bf16_params": bool(r16.bf16_params), "host_enqueue_ms_per_step": enq16 / steps16 * 1e3,
                     "final_loss": loss16,
                     "flop_roofline": None if step_flops is None else {
                         "bound": "mfma", "achieved": step_flops / (dt16 / steps16) / 1e12, "unit": "TFLOP/s",
@@ -580,6 +642,21 @@ def main():
     roof = kernels.get(AT_ROW)
     tiles = batch * world * args.steps
     keys = ("bound", "achieved", "peak", "unit", "frac", "traffic")
+    issue = issue_side()     # VALU / latency side of the latency-bound calls, from the committed SQ-counter table
+    # The full per-kernel table goes to a file (and stderr); the line keeps the 12 rows with the most time, as
+    # {us, frac of the bound's peak, bound} -- the driver's record holds ~8 KB of this line, the table alone was 12.
+    kfile = None
+    if kernels:
+        kfile = args.kernels_out or os.path.join("gpurun_out" if os.path.isdir("gpurun_out") else ".", "bench_kernels.json")
+        try:
+            with open(kfile, "w") as fh:
+                json.dump(kernels, fh, indent=1)
+        except OSError:
+            kfile = None
+        print("bench.py kernels " + json.dumps(kernels), file=sys.stderr, flush=True)
+    top = sorted(kernels.items(), key=lambda kv: -kv[1].get("us", 0.0))[:12]
+    r3 = lambda x: None if x is None else float("%.4g" % x)
+    peak_f = FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0
     line = {
         "metric": METRICS[args.model],
         "value": tiles / dt,
@@ -595,49 +672,56 @@ def main():
         "data": "synthetic",
         "config": {"workload": (WORKLOADS[args.model] % (batch, TILE, TILE, "fp32" if args.dtype == "f32" else
                                                              "bf16 autocast (fp32 box kernels)")
-                                + "; %d different batches per rank resident in HBM, step i runs batch i %% %d (K cycle "
-                                  "shifted by one slot per batch)" % (N_BATCHES, N_BATCHES)
-                                ),
+                                + ("; a NEW K tuple every step (--fresh-k)" if args.fresh_k else
+                                   "; %d resident batches per rank, step i runs batch i %% %d" % (N_BATCHES, N_BATCHES))),
                    "global_batch": batch * world, "parallelism": "dp%d" % world,
                    "memory_format": args.memory_format,
-                   "miopen_records": "packaged (rs_detection_amd/miopen_db)" if MIOPEN_DB_DIR else "none / user-provided"},
+                   "miopen_records": "packaged" if MIOPEN_DB_DIR else "none / user-provided"},
         "final_loss": loss_v,
+        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+        "fresh_k_ms_per_step": fresh["ms_per_step"] if fresh else None,
+        "fresh_k_delta_ms": (fresh["ms_per_step"] - dt / args.steps * 1e3) if fresh else None,
+        "bf16_tiles_per_s": bf16_leg["value"] if bf16_leg else None,
+        "bf16_ms_per_step": bf16_leg["ms_per_step"] if bf16_leg else None,
+        "bf16_flop_frac": bf16_leg["flop_roofline"]["frac"] if bf16_leg and bf16_leg["flop_roofline"] else None,
+        "bf16_host_enqueue_ms_per_step": bf16_leg["host_enqueue_ms_per_step"] if bf16_leg else None,
         "rotated_iou_mpairs_per_s": dense["mpairs_per_s"] if dense else None,
-        # the oriented-box kernel the timed step itself runs: the fused sparse anchor-target call (twice per step: FAM
-        # and ODM).  Priced against HBM as the contract asks; its algorithmic bytes are tiny (no K x A matrix is ever
-        # written), so the fraction says "latency / VALU bound", which is what `bound_note` states.
+        # the oriented-box call the timed step itself makes (twice per step: FAM and ODM targets).  Priced against HBM as
+        # the contract asks; its algorithmic bytes are tiny (no K x A matrix is written), so the HBM fraction only says
+        # "not bandwidth-bound": `issue` is the side that binds (VALU instructions issued / issue slots, SQ counters)
         "roofline": ({k: roof[k] for k in keys} | {
-            "bound": "hbm",
-            "bound_note": "latency / VALU-issue bound: 5.3 MB of algorithmic bytes per launch pair; see kernels[] and "
-                          "profiles/%s for the instruction counters" % os.path.basename(ROOFLINE_FILE),
-            "kernel": "rsdet_anchor_target_rotated_f32 = iou_tile_kernel<SPARSE> + at_finish_kernel (the call the "
-                      "timed step makes for FAM and ODM targets)",
-            "traffic_source": "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
-                              "profiles/scripts/roofline.sh)" % os.path.basename(ROOFLINE_FILE),
-            "us_per_launch": roof["us"], "shape": dense["shape"] if dense else None}) if roof else None,
+            "bound": "hbm", "bound_note": "latency / VALU-issue bound (5.3 MB algorithmic per call)",
+            "kernel": "rsdet_anchor_target_rotated_f32 (tile + finish launches)",
+            "traffic_source": "profiles/%s" % os.path.basename(ROOFLINE_FILE),
+            "us_per_launch": roof["us"], "shape": dense["shape"] if dense else None,
+            "issue": issue.get("anchor_target")}) if roof else None,
         # the standalone north-star kernel (dense K x A rotated IoU, the matrix written to HBM), not on the step's path
         "roofline_dense_iou": ({k: dense[k] for k in keys} | {
-            "kernel": "rsdet_box_iou_rotated_grouped_f32 (dense K x A matrix, bit-exact reference-order clipper on "
-                      "every overlapping pair; standalone metric, not in the timed step)",
+            "kernel": "rsdet_box_iou_rotated_grouped_f32 (bit-exact, 3 launches)",
             "us_per_launch": dense["us"], "shape": dense["shape"], "valu_frac": dense["valu_frac"],
-            "alg_gflop": dense["alg_gflop"], "overlapping_pairs": dense["overlapping_pairs"]}) if dense else None,
+            "overlapping_pairs": dense["overlapping_pairs"]}) if dense else None,
         "roofline_dense_iou_two_tier": ({k: kernels[FAST_ROW][k] for k in keys} | {
-            "kernel": "rsdet_box_iou_rotated_fast_f32 (the same matrix to |d| < 3e-6 of the reference: Green integral + "
-                      "reference-order clipper where the reference is fragile; standalone metric)",
-            "us_per_launch": kernels[FAST_ROW]["us"], "mpairs_per_s": kernels[FAST_ROW]["mpairs_per_s"]})
+            "kernel": "rsdet_box_iou_rotated_fast_f32 (1 launch, every element stored once; |d| < 3e-6 of the reference)",
+            "us_per_launch": kernels[FAST_ROW]["us"], "mpairs_per_s": kernels[FAST_ROW]["mpairs_per_s"],
+            "issue": issue.get("dense_iou_two_tier")})
         if FAST_ROW in kernels else None,
-        # the hand-written kernel with the most time in the timed step (4.3 of 6.3 ms of hand-written kernels)
+        "roofline_nms": ({k: kernels[NMS_ROW][k] for k in keys} | {
+            "kernel": "rsdet_nms_rotated (prepare + mask + sweep), M=5344, 15 classes, label-major",
+            "us_per_launch": kernels[NMS_ROW]["us"], "mpairs_per_s": kernels[NMS_ROW]["mpairs_per_s"],
+            "issue": issue.get("nms_rotated")}) if NMS_ROW in kernels else None,
+        # the hand-written kernel with the most time in the timed step
         "roofline_dominant_handwritten": ({k: kernels[BN_DOM][k] for k in keys} | {
             "kernel": BN_DOM, "us_per_launch": kernels[BN_DOM]["us"]}) if BN_DOM in kernels else None,
         "bf16": bf16_leg,
+        "fresh_k": fresh,
         # the conv / GEMM side of the step against the MFMA roofline: flops of one rank's step as counted
         # by torch.utils.flop_counter, over the measured step time, over the dense peak of the compute dtype
         "flop_roofline": None if step_flops is None else {
             "bound": "mfma", "tflop_per_step_per_gpu": step_flops / 1e12,
-            "achieved": step_flops / (dt / args.steps) / 1e12, "unit": "TFLOP/s",
-            "peak": FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0,
-            "frac": step_flops / (dt / args.steps) / 1e12 / (FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0)},
-        "kernels": kernels,
+            "achieved": step_flops / (dt / args.steps) / 1e12, "unit": "TFLOP/s", "peak": peak_f,
+            "frac": step_flops / (dt / args.steps) / 1e12 / peak_f},
+        "kernels_top12": {k: {"us": r3(v.get("us")), "frac": r3(v.get("frac")), "bound": v.get("bound")} for k, v in top},
+        "kernels_file": kfile,
         # the CPU baseline is timed on rank 0 of a single-GPU run only (SURVEY 8d / bench contract)
         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),
     }

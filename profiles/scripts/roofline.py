@@ -67,13 +67,52 @@ def main(d, out):
         c["traffic_over_alg"] = c["traffic_bytes"] / c["alg_bytes"] if c["alg_bytes"] else None
         if "alg_flops" in c:
             c["achieved_TFLOPs"] = c["alg_flops"] / (c["us"] * 1e-6) / 1e12
-    res = dict(hbm_peak_GBps=HBM_PEAK, source="rocprofv3 --kernel-trace + --pmc WRITE_SIZE / FETCH_SIZE over "
-               "profiles/scripts/pmc_kernels.py; code-object notes via profiles/scripts/occupancy.py",
-               calls=calls, kernels=kernels)
+    issue = issue_side(d, calls, kernels)
+    res = dict(hbm_peak_GBps=HBM_PEAK, source="rocprofv3 --kernel-trace + --pmc WRITE_SIZE / FETCH_SIZE (+ two SQ counter "
+               "passes) over profiles/scripts/pmc_kernels.py; code-object notes via profiles/scripts/occupancy.py",
+               calls=calls, kernels=kernels, issue=issue)
     json.dump(res, open(out, "w"), indent=1)
     for name, c in calls.items():
         print("%-44s %8.1f us  alg %8.2f MB  %7.0f GB/s  frac %.3f  traffic/alg %.2f" % (
             name, c["us"], c["alg_bytes"] / 1e6, c["achieved_GBps"], c["frac_of_hbm_peak"], c["traffic_over_alg"] or 0))
+
+
+N_SIMD, CLK_GHZ = 1024, 2.4      # 256 CUs x 4 SIMDs; nominal shader clock (MI355X_MICROARCH.md)
+ISSUE_CALLS = {"anchor_target": "anchor_target_rotated (2 launches)", "nms_rotated": "nms_rotated (3 launches)",
+               "dense_iou_two_tier": "box_iou_rotated_fast (1 launch)", "dense_iou_exact": "box_iou_rotated (3 launches)"}
+
+
+def issue_side(d, calls, kernels):
+    """The VALU / latency side of the calls whose HBM fraction says nothing: per call, summed over its kernels,
+    VALU instructions issued (SQ_INSTS_VALU), the share of the launch's VALU issue slots they fill -- one slot = one
+    quad-cycle of one SIMD (a wave's VALU instruction holds its SIMD's issue port for 4 clocks: SQ_ACTIVE_INST_VALU ~
+    SQ_INSTS_VALU quad-cycles), slots = 1024 SIMDs x duration x 2.4 GHz / 4 -- and the share of wave-cycles spent
+    waiting (s_waitcnt / barrier) or stalled at issue."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "sq*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not acc:
+        return {}
+    out = {}
+    for tag, call in ISSUE_CALLS.items():
+        c = calls.get(call)
+        if not c:
+            continue
+        tot = collections.defaultdict(float)
+        for k in c["kernels"]:
+            for name, v in acc.get(k, {}).items():
+                tot[name] += sum(v) / len(v)
+        if not tot.get("SQ_INSTS_VALU"):
+            continue
+        slots = N_SIMD * c["us"] * 1e-6 * CLK_GHZ * 1e9 / 4.0
+        wc = tot.get("SQ_WAVE_CYCLES") or 1.0
+        out[tag] = dict(call=call, us=c["us"], waves=tot.get("SQ_WAVES"), valu_insts=tot["SQ_INSTS_VALU"],
+                        valu_issue_frac=tot["SQ_INSTS_VALU"] / slots, salu_insts=tot.get("SQ_INSTS_SALU"),
+                        lds_insts=tot.get("SQ_INSTS_LDS"), wait_frac=tot.get("SQ_WAIT_ANY", 0.0) / wc,
+                        issue_stall_frac=tot.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                        note="valu_issue_frac = VALU instructions / (1024 SIMDs x duration x 2.4 GHz / 4)")
+    return out
 
 
 if __name__ == "__main__":

@@ -13,6 +13,8 @@ Host-side helpers kept here:
 """
 import os
 
+import collections
+
 import torch
 
 from .. import _lib
@@ -21,7 +23,7 @@ __all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "box_iou_
 
 _TI = 16  # rows per tile (csrc/anchor_target.hip T_TI)
 _prepared_cache = {}
-_tile_cache = {}
+_tile_cache = collections.OrderedDict()
 _state = {}
 
 
@@ -94,23 +96,83 @@ def prepare_boxes(boxes, cache=False, heavy_from=None, medium_from=None):
     return prep
 
 
+_TILE_CACHE_MAX = 512
+_tile_ring = {}     # device -> [pinned int32 staging buffers, their copy events, next slot]
+
+
+def _tile_stage(device, n_ints):
+    """A pinned int32 staging buffer for the table upload: a ring of 16, each guarded by the event of the copy that last
+    read it (an async copy out of ONE pinned buffer that the next miss rewrites would race with a GPU that runs behind
+    the host; a pageable source would make the copy synchronous)."""
+    ent = _tile_ring.get(device)
+    if ent is None or ent[0][0].numel() < n_ints:
+        size = max(4096, 1 << int(n_ints - 1).bit_length())
+        ent = _tile_ring[device] = [[torch.empty((size,), dtype=torch.int32, pin_memory=True) for _ in range(16)],
+                                    [None] * 16, 0]
+    k = ent[2]
+    ent[2] = (k + 1) % 16
+    if ent[1][k] is not None:
+        ent[1][k].synchronize()      # the copy issued 16 misses ago: long done
+    return ent, k
+
+
 def row_tile_table(ks, device, rows_per_tile=_TI):
-    """Host-known gt counts per image -> (tile table (T,4) int32 on ``device``, group_tile0 (G+1) int32, T)."""
+    """Host-known gt counts per image -> (tile table (T,4) int32 on ``device``, group_tile0 (G+1) int32, T).
+    Real DOTA batches bring a new K tuple nearly every step, so a miss must be cheap: the table is built with a handful
+    of NumPy array operations straight into a pinned staging buffer and uploaded with ONE non-blocking copy (the table
+    and the group offsets share it); hits are remembered for the 512 most recently used tuples."""
+    import numpy as np
     key = (tuple(int(k) for k in ks), str(device), int(rows_per_tile))
     hit = _tile_cache.get(key)
     if hit is not None:
+        _tile_cache.move_to_end(key)                     # most recently used: last
         return hit
-    rows, tile0, r0 = [], [0], 0
-    for g, k in enumerate(key[0]):
-        for y in range(0, k, rows_per_tile):
-            rows.append((g, r0 + y, min(rows_per_tile, k - y), r0))
-        tile0.append(len(rows))
-        r0 += k
-    n = len(rows)
-    table = torch.tensor(rows if rows else [(0, 0, 0, 0)], dtype=torch.int32).to(device, non_blocking=True)
-    t0 = torch.tensor(tile0, dtype=torch.int32).to(device, non_blocking=True)
-    if len(_tile_cache) > 256:
-        _tile_cache.clear()
+    R = int(rows_per_tile)
+    kt = key[0]
+    G = len(kt)
+    per = [(k + R - 1) // R for k in kt]                   # tiles of each group
+    n = sum(per)
+    T = max(n, 1)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        ent, slot = _tile_stage(dev, 4 * T + G + 1)
+        host = ent[0][slot].numpy()
+    else:
+        host = np.empty(4 * T + G + 1, dtype=np.int32)
+    if n <= 512:
+        # a step's worth of tiles (tens): plain Python ints and ONE assignment into the staging buffer beat a dozen
+        # NumPy calls (their fixed cost is ~1 us each)
+        flat, tile0, r0 = [], [0], 0
+        for g, k in enumerate(kt):
+            for y in range(0, k, R):
+                flat += (g, r0 + y, R if k - y > R else k - y, r0)
+            tile0.append(len(flat) >> 2)
+            r0 += k
+        if not flat:
+            flat = [0, 0, 0, 0]
+        host[:4 * T + G + 1] = flat + tile0
+    else:
+        k = np.asarray(kt, dtype=np.int64)
+        pern = np.asarray(per, dtype=np.int64)
+        tile0 = np.zeros(G + 1, dtype=np.int64)
+        np.cumsum(pern, out=tile0[1:])
+        rows = host[:4 * T].reshape(T, 4)
+        g = np.repeat(np.arange(G), pern)                  # group of every tile
+        y = (np.arange(n) - tile0[g]) * R                  # its first row inside the group
+        r0 = np.concatenate([[0], np.cumsum(k)[:-1]])      # first row of every group
+        rows[:n, 0], rows[:n, 1], rows[:n, 2], rows[:n, 3] = g, r0[g] + y, np.minimum(R, k[g] - y), r0[g]
+        host[4 * T:4 * T + G + 1] = tile0
+    if dev.type == "cuda":
+        both = torch.empty((4 * T + G + 1,), dtype=torch.int32, device=dev)
+        both.copy_(ent[0][slot][:4 * T + G + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        ent[1][slot] = ev
+    else:
+        both = torch.from_numpy(host.copy())
+    table, t0 = both[:4 * T].view(T, 4), both[4 * T:]
+    while len(_tile_cache) >= _TILE_CACHE_MAX:
+        _tile_cache.popitem(last=False)                    # the least recently used tuple
     _tile_cache[key] = (table, t0, n)
     return _tile_cache[key]
 

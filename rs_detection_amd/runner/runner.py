@@ -48,8 +48,8 @@ class Runner:
         # SGD + both copies in two launches).  Removes, per step, one fp32->bf16 cast per weight (autocast), one
         # bf16->fp32 cast per weight gradient and the foreach passes of clip_grad_norm_ / SGD (~250 launches of ~1 700).
         # BatchNorm parameters, the ARF weight of ORConv2d (fp32 kernels) and every other parameter stay fp32.
-        if bf16_params is None:
-            bf16_params = os.environ.get("RSDET_BF16_PARAMS", "0") == "1"
+        if bf16_params is None:      # on by default wherever it applies (bf16 autocast + SGD, no SWA phase): what bench.py times
+            bf16_params = os.environ.get("RSDET_BF16_PARAMS", "1") == "1"
         # Not with an SWA phase: ``optimizer_swa`` is a plain optimizer over the same parameters and would update the bf16
         # copies while FusedSGD's fp32 masters went stale (and the checkpoint, which stores the masters, lost the phase).
         self.bf16_params = bool(bf16_params) and amp_dtype == torch.bfloat16 and device.type == "cuda" and \

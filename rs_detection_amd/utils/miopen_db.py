@@ -43,11 +43,21 @@ def _private_dir():
             return None
 
 
+def _source_stamp(path):
+    import hashlib
+    with open(path, "rb") as fh:
+        data = fh.read()
+    return "%d:%s" % (len(data), hashlib.sha1(data).hexdigest())
+
+
 def use_packaged_miopen_db():
     """Call before the first convolution of the process (MIOpen reads the variable when its handle is created).
     Returns the directory in use, or None when nothing was changed."""
-    if os.environ.get("RSDET_NO_MIOPEN_DB", "0") == "1" or "MIOPEN_USER_DB_PATH" in os.environ:
+    if os.environ.get("RSDET_NO_MIOPEN_DB", "0") == "1":
         return None
+    user = os.environ.get("MIOPEN_USER_DB_PATH")
+    if user is not None and user != os.environ.get("RSDET_MIOPEN_DB_IN_USE"):
+        return None          # the user's own directory wins (a second call of ours just refreshes our copy)
     files = sorted(glob.glob(os.path.join(_PKG_DB, "*db.txt")))
     if not files:
         return None
@@ -57,10 +67,21 @@ def use_packaged_miopen_db():
     try:
         for f in files:  # MIOpen appends to its user database: never hand it the packaged originals
             t = os.path.join(dst, os.path.basename(f))
-            if not os.path.exists(t) or os.path.getsize(t) < os.path.getsize(f):
+            # the working copy grows (MIOpen appends), so its size says nothing about WHICH packaged file it started
+            # from: a stamp beside it names the source (size + digest); another stamp = a stale copy, replaced
+            stamp = _source_stamp(f)
+            try:
+                with open(t + ".src") as fh:
+                    have = fh.read().strip()
+            except OSError:
+                have = None
+            if not os.path.exists(t) or have != stamp:
                 tmp = "%s.%d.tmp" % (t, os.getpid())
                 shutil.copyfile(f, tmp)
                 os.replace(tmp, t)  # atomic: ranks of one node start together
+                with open(tmp, "w") as fh:
+                    fh.write(stamp + "\n")
+                os.replace(tmp, t + ".src")
     except OSError:
         return None
     os.environ["MIOPEN_USER_DB_PATH"] = dst
@@ -87,5 +108,11 @@ def packaged_records_match():
     want = "%d_%d_%d_" % (v // 1000000, (v // 1000) % 1000, v % 1000)
     user = os.environ.get("MIOPEN_USER_DB_PATH")
     mine = os.environ.get("RSDET_MIOPEN_DB_IN_USE")      # set by use_packaged_miopen_db(), here or in a parent process
-    ours = user is None or (mine is not None and os.path.realpath(user) == os.path.realpath(mine))
-    return ours and any(re.search(r"\.HIP\." + re.escape(want), os.path.basename(f)) for f in files)
+    if user is None and mine is None:
+        mine = use_packaged_miopen_db()                  # not called yet in this process: do it now (idempotent)
+        user = os.environ.get("MIOPEN_USER_DB_PATH")
+    if user is None or mine is None or os.path.realpath(user) != os.path.realpath(mine):
+        return False                                     # the copy failed, or the user points MIOpen elsewhere
+    match = [f for f in files if re.search(r"\.HIP\." + re.escape(want), os.path.basename(f))]
+    # ... and the directory MIOpen will read really holds them
+    return bool(match) and all(os.path.exists(os.path.join(mine, os.path.basename(f))) for f in match)

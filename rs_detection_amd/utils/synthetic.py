@@ -52,13 +52,14 @@ def nms_cluster_boxes(m, seed=11, n_centres=200):
     return d, scores, labels
 
 
-def synthetic_targets(batch, rank=0, it=0, num_classes=15, img=1024, k_shift=0):
+def synthetic_targets(batch, rank=0, it=0, num_classes=15, img=1024, k_shift=0, ks=None):
     """Per-tile target dicts with the reference schema (data/custom.py:75-88).  ``k_shift`` rotates the K cycle (with a
-    batch of len(K_CYCLE) tiles every ``it`` would otherwise put the same K in the same slot)."""
+    batch of len(K_CYCLE) tiles every ``it`` would otherwise put the same K in the same slot); ``ks`` gives the gt
+    counts explicitly (the fresh-K leg of bench.py)."""
     rng = np.random.default_rng(1234 + 1000 * rank + it)
     out = []
     for b in range(batch):
-        k = K_CYCLE[(it * batch + b + k_shift) % len(K_CYCLE)]
+        k = K_CYCLE[(it * batch + b + k_shift) % len(K_CYCLE)] if ks is None else int(ks[b])
         out.append(dict(rboxes=dota_gt_boxes(rng, k, img),
                         labels=rng.integers(1, num_classes + 1, k).astype(np.int32),
                         rboxes_ignore=np.zeros((0, 5), np.float32),

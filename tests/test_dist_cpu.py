@@ -181,11 +181,13 @@ def test_pin_rank_to_cores_splits_the_allowed_cores():
 def _db_racer(tmp, q):
     os.environ["XDG_CACHE_HOME"] = tmp
     os.environ.pop("MIOPEN_USER_DB_PATH", None)
+    os.environ.pop("RSDET_MIOPEN_DB_IN_USE", None)
     os.environ.pop("RSDET_NO_MIOPEN_DB", None)
     sys.path.insert(0, ROOT)
     from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db
     d = use_packaged_miopen_db()
-    q.put((d, sorted((f, os.path.getsize(os.path.join(d, f))) for f in os.listdir(d)) if d else None))
+    # (the "<file>.src" stamps name the packaged file a working copy came from: not record files)
+    q.put((d, sorted((f, os.path.getsize(os.path.join(d, f))) for f in os.listdir(d) if not f.endswith(".src")) if d else None))
 
 
 @pytest.mark.timeout(180)
