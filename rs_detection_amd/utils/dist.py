@@ -10,6 +10,7 @@ draws its own tiles; the only collective is the bucketed gradient all-reduce DDP
 the GPU (a process that has initialised HIP must never be replaced or forked into ranks) and relays rank 0's output.
 """
 import datetime
+import glob
 import os
 import socket
 import subprocess
@@ -31,13 +32,83 @@ def free_port():
     return p
 
 
-def pin_rank_to_cores(local_rank=None, local_world=None):
-    """Give this rank its own contiguous share of the host cores: ``os.sched_setaffinity`` over the cores this process
-    is allowed to use, split evenly by LOCAL_RANK.  The bf16 step is bound by the host (one Python thread enqueues
-    ~1 700 launches per step): eight ranks that migrate over -- and share -- the same cores lose to each other and to
-    their own loader workers; pinned, every rank keeps its L2 / NUMA locality and its workers (children of this process)
-    inherit the same share.  Must run before the first GPU call of the process (HIP's helper threads inherit the mask
-    they are created under).  No-op for a single rank, when ``RSDET_NO_AFFINITY=1``, or where the OS has no affinity API.
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _cpulist(text):
+    """'0-3,8-11' -> [0, 1, 2, 3, 8, 9, 10, 11]"""
+    out = []
+    for part in (text or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every AMD GPU of the machine in PCI-address order (the order HIP enumerates them in), read from
+    ``/sys/class/drm/card*/device/numa_node`` -- no HIP call.  None for a GPU whose node the kernel does not know (-1)."""
+    found = {}
+    for dev in glob.glob(os.path.join(sysfs, "class", "drm", "card[0-9]*", "device")):
+        if "-" in os.path.basename(os.path.dirname(dev)):          # card0-DP-1 ...: connectors, not devices
+            continue
+        if (_read(os.path.join(dev, "vendor")) or "").lower() != "0x1002":
+            continue
+        slot = None
+        for ln in (_read(os.path.join(dev, "uevent")) or "").splitlines():
+            if ln.startswith("PCI_SLOT_NAME="):
+                slot = ln.split("=", 1)[1]
+        slot = slot or os.path.basename(os.path.realpath(dev))
+        node = _read(os.path.join(dev, "numa_node"))
+        found[slot] = int(node) if node not in (None, "", "-1") else None
+    return [found[k] for k in sorted(found)]
+
+
+def _visible_gpu(local_rank):
+    """Physical index of the GPU this rank will open: the local rank through the *_VISIBLE_DEVICES remapping."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            ids = [x.strip() for x in v.split(",") if x.strip()]
+            if all(x.isdigit() for x in ids) and local_rank < len(ids):
+                return int(ids[local_rank])
+            return None                 # UUIDs or fewer devices than ranks: do not guess
+    return local_rank
+
+
+def _sibling_groups(cores, sysfs="/sys"):
+    """``cores`` grouped by physical core (SMT siblings together), groups in ascending order of their first CPU."""
+    seen, groups = set(), []
+    allowed = set(cores)
+    for c in sorted(cores):
+        if c in seen:
+            continue
+        sib = _cpulist(_read(os.path.join(sysfs, "devices", "system", "cpu", "cpu%d" % c, "topology",
+                                          "thread_siblings_list")))
+        grp = sorted(x for x in (sib or [c]) if x in allowed) or [c]
+        seen.update(grp)
+        groups.append(grp)
+    return groups
+
+
+def pin_rank_to_cores(local_rank=None, local_world=None, sysfs=None):
+    """Give this rank its own share of the host cores ON THE SOCKET ITS GPU HANGS OFF: ``os.sched_setaffinity`` over
+    the cores this process is allowed to use.  The GPU's NUMA node comes from sysfs (``gpu_numa_nodes``); the ranks whose
+    GPUs share a node split that node's cores evenly, whole physical cores at a time (SMT siblings stay together).
+    Where the topology is unknown (no sysfs entry, a container that hides it, more ranks than cores on a node) the
+    allowed cores are split evenly by LOCAL_RANK instead.  The bf16 step is bound by the host (one Python thread
+    enqueues ~800 launches per step): eight ranks that migrate over -- and share -- the same cores lose to each other
+    and to their own loader workers, and a rank on the far socket pays the inter-socket hop on every doorbell; pinned,
+    every rank keeps its L2 / NUMA locality and its workers (children of this process) inherit the same share.  Must
+    run before the first GPU call of the process (HIP's helper threads inherit the mask they are created under).
+    No-op for a single rank, when ``RSDET_NO_AFFINITY=1``, or where the OS has no affinity API.
     Returns the list of cores set (or None)."""
     if os.environ.get("RSDET_NO_AFFINITY", "0") == "1" or not hasattr(os, "sched_setaffinity"):
         return None
@@ -46,19 +117,43 @@ def pin_rank_to_cores(local_rank=None, local_world=None):
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world)) if local_world is None else int(local_world)
     if local_world <= 1:
         return None
+    sysfs = sysfs or os.environ.get("RSDET_SYSFS_ROOT", "/sys")
     cores = sorted(os.sched_getaffinity(0))
-    per = len(cores) // local_world
-    if per < 1:                         # more ranks than cores: leave the scheduler alone
-        return None
-    mine = cores[local_rank * per:(local_rank + 1) * per]
+    mine = None
+    # ---- NUMA-aware share
+    nodes = gpu_numa_nodes(sysfs)
+    phys = [_visible_gpu(r) for r in range(local_world)]
+    if nodes and all(p is not None and p < len(nodes) and nodes[p] is not None for p in phys):
+        # the decision must be the same on every rank (each one computes it alone): NUMA shares only if EVERY node that
+        # hosts a rank has at least one allowed physical core per rank, else all ranks take the even split below
+        shares = {}
+        for node in sorted(set(nodes[p] for p in phys)):
+            peers = [r for r in range(local_world) if nodes[phys[r]] == node]
+            node_cpus = set(_cpulist(_read(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist"))))
+            groups = _sibling_groups([c for c in cores if c in node_cpus], sysfs)
+            per = len(groups) // len(peers)
+            if per < 1:
+                shares = None
+                break
+            for k, r in enumerate(peers):
+                shares[r] = sorted(c for g in groups[k * per:(k + 1) * per] for c in g)
+        if shares:
+            mine = shares[local_rank]
+    # ---- topology unknown: even split of the allowed cores (whole physical cores where sysfs names the siblings)
+    if mine is None:
+        groups = _sibling_groups(cores, sysfs)
+        per = len(groups) // local_world
+        if per < 1:                         # more ranks than cores: leave the scheduler alone
+            return None
+        mine = sorted(c for g in groups[local_rank * per:(local_rank + 1) * per] for c in g)
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
     # intra-op thread pools sized for the share (the default is the machine's core count, per rank)
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(per, 8)))
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(len(mine), 8)))
     try:
-        torch.set_num_threads(min(per, 8))
+        torch.set_num_threads(min(len(mine), 8))
     except RuntimeError:
         pass
     return mine

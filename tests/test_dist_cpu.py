@@ -178,6 +178,65 @@ def test_pin_rank_to_cores_splits_the_allowed_cores():
     assert mine is None and after == before
 
 
+def _fake_sysfs(root, gpu_nodes, node_cpus, siblings):
+    """A minimal /sys: drm cards (AMD, PCI slot names in order) with their NUMA node, node cpulists, SMT siblings."""
+    for i, node in enumerate(gpu_nodes):
+        d = os.path.join(root, "class", "drm", "card%d" % (7 - i), "device")        # card numbers need not follow PCI order
+        os.makedirs(d)
+        for name, text in (("vendor", "0x1002"), ("numa_node", str(node)), ("uevent", "DRIVER=amdgpu\nPCI_SLOT_NAME=0000:%02x:00.0" % (0x10 + i))):
+            with open(os.path.join(d, name), "w") as f:
+                f.write(text + "\n")
+    os.makedirs(os.path.join(root, "class", "drm", "card0-DP-1", "device"))      # a connector: not a device
+    for n, cpus in node_cpus.items():
+        os.makedirs(os.path.join(root, "devices", "system", "node", "node%d" % n))
+        with open(os.path.join(root, "devices", "system", "node", "node%d" % n, "cpulist"), "w") as f:
+            f.write(cpus + "\n")
+    for c, sib in siblings.items():
+        d = os.path.join(root, "devices", "system", "cpu", "cpu%d" % c, "topology")
+        os.makedirs(d)
+        with open(os.path.join(d, "thread_siblings_list"), "w") as f:
+            f.write(sib + "\n")
+
+
+def test_pin_rank_to_cores_follows_the_gpu_numa_node(tmp_path, monkeypatch):
+    """8 GPUs on 2 sockets (4 + 4), 16 physical cores with SMT (cpu c and c + 16 are siblings), socket 0 = physical
+    cores 0-7, socket 1 = 8-15: a rank gets whole physical cores of ITS GPU's socket; ranks of one socket split it."""
+    from rs_detection_amd.utils import dist as d
+    root = str(tmp_path / "sys")
+    _fake_sysfs(root, gpu_nodes=[0, 0, 1, 1, 0, 0, 1, 1], node_cpus={0: "0-7,16-23", 1: "8-15,24-31"},
+                siblings={c: "%d,%d" % (c % 16, c % 16 + 16) for c in range(32)})
+    assert d.gpu_numa_nodes(root) == [0, 0, 1, 1, 0, 0, 1, 1]
+    applied = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(32)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: applied.__setitem__("cores", sorted(cores)))
+    monkeypatch.setattr(d.torch, "set_num_threads", lambda n: None)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "RSDET_NO_AFFINITY"):
+        monkeypatch.delenv(var, raising=False)
+    shares = []
+    for r in range(8):
+        mine = d.pin_rank_to_cores(local_rank=r, local_world=8, sysfs=root)
+        assert mine == applied["cores"] and len(mine) == 4                      # 2 physical cores x 2 threads
+        node_cpus = set(range(0, 8)) | set(range(16, 24)) if r in (0, 1, 4, 5) else set(range(8, 16)) | set(range(24, 32))
+        assert set(mine) <= node_cpus, (r, mine)                                # on the socket of its own GPU
+        assert all((c + 16) % 32 in mine for c in mine)                         # SMT siblings stay together
+        shares.append(set(mine))
+    assert all(shares[i].isdisjoint(shares[j]) for i in range(8) for j in range(i))
+    # HIP_VISIBLE_DEVICES remaps local ranks to physical GPUs: rank 0 -> GPU 2 (socket 1), rank 1 -> GPU 0 (socket 0)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert set(d.pin_rank_to_cores(local_rank=0, local_world=2, sysfs=root)) <= set(range(8, 16)) | set(range(24, 32))
+    assert set(d.pin_rank_to_cores(local_rank=1, local_world=2, sysfs=root)) <= set(range(0, 8)) | set(range(16, 24))
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # a restricted process (cgroup of 8 CPUs, all on socket 0) with GPUs on both sockets: the socket-1 ranks find none
+    # of their socket's cores allowed, so the allowed cores are split evenly instead of leaving ranks without a share
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(0, 4)) | set(range(16, 20)))
+    got = [d.pin_rank_to_cores(local_rank=r, local_world=4, sysfs=root) for r in range(4)]
+    assert all(g and len(g) == 2 for g in got) and len(set(map(tuple, got))) == 4
+    # no sysfs at all (a container that hides it): even split by local rank
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)))
+    got = [d.pin_rank_to_cores(local_rank=r, local_world=4, sysfs=str(tmp_path / "nothing")) for r in range(4)]
+    assert got == [[0, 1], [2, 3], [4, 5], [6, 7]]
+
+
 def _db_racer(tmp, q):
     os.environ["XDG_CACHE_HOME"] = tmp
     os.environ.pop("MIOPEN_USER_DB_PATH", None)

@@ -37,8 +37,8 @@ def test_retinanet_hbb_config_builds_and_trains_on_cpu():
     opt = build_from_cfg(cfg.optimizer, OPTIMS, params=[p for p in model.parameters() if p.requires_grad])
     model.train()
     rng = np.random.default_rng(0)
-    images = torch.randn(2, 3, 320, 320)
-    targets = _targets(rng, 2, 320)
+    images = torch.randn(2, 3, 600, 600)          # BASELINE.json configs[0]: 2 x 600 x 600 synthetic tiles, CPU
+    targets = _targets(rng, 2, 600)
     first = None
     for _ in range(2):
         losses = model(images, targets)
