@@ -121,7 +121,9 @@ def main():
     spread = float((hi - lo).abs().max())
     res = dict(rank=rank, world=world, backend=dist.get_backend(), loss=loss, grad_rel_err=rel, grad_max_abs=maxabs,
                grad_norm=float(want.norm()), noise=noise, local_rel_err=local_rel, param_spread=spread, final_loss=float(total.detach()),
-               n_grad=int(got.numel()), finite=bool(torch.isfinite(flat).all()))
+               n_grad=int(got.numel()), finite=bool(torch.isfinite(flat).all()),
+               bf16_params=bool(runner.bf16_params), optimizer=type(runner.optimizer).__name__,
+               bucket_view=bool(getattr(runner.ddp, "gradient_as_bucket_view", False)))
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(res, f)
     rdist.barrier()

@@ -48,22 +48,30 @@ def test_two_rank_ddp_real_model(model, dtype, tol, tmp_path):
         assert r["grad_rel_err"] < max(tol, 3 * r["noise"]), r
         assert r["param_spread"] == 0.0, r           # bit-identical parameters on both ranks after two steps
         assert r["grad_norm"] > 0 and r["n_grad"] > 1e6
+        if model == "s2anet":
+            # the two train steps above ran FusedSGD (its per-step gradient-pointer ring) on gradients that are VIEWS
+            # into DDP's buckets; in bf16 additionally with bf16 parameters and the bf16 compress hook on the buckets
+            assert r["optimizer"] == "FusedSGD" and r["bucket_view"], r
+            assert r["bf16_params"] == (dtype == "bf16"), r
     assert res[0]["loss"] != res[1]["loss"]          # the ranks really worked on different shards
 
 
-@pytest.mark.timeout(1000)
-def test_bench_self_launches_its_ranks(tmp_path):
-    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE): the parent starts two child ranks and relays rank 0's
-    single JSON line (the driver's N>1 contract); exit code 0."""
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_self_launches_its_ranks(tmp_path, n):
+    """`python bench.py --gpus N` (no launcher, no WORLD_SIZE): the parent starts N child ranks and relays rank 0's
+    single JSON line (the driver's N>1 contract); exit code 0.  N = 8 is the driver's largest run: eight ranks on this
+    box's one GPU over gloo prove the launcher / relay / barrier path at that width (not a scaling number)."""
     _need_gpu()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env["RSDET_BENCH_TILE"] = "256"                  # two S2ANet replicas on one GPU: keep the tiles small
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--no-kernels"], env=env, capture_output=True, text=True, timeout=900)
+    env["RSDET_BENCH_TILE"] = "256"                  # N S2ANet replicas on one GPU: keep the tiles small
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--no-kernels", "--no-bf16-leg"], env=env, capture_output=True, text=True, timeout=1400)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
-    assert line["config"]["global_batch"] == 2 * line["config"]["global_batch"] // 2
+    assert line["n_gpus"] == n and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["global_batch"] == 4 * n and line["config"]["parallelism"] == "dp%d" % n
+    assert len(lines[0]) < 8192                      # the driver's record keeps ~8 KB of the line
     assert line["cpu_baseline"] is None              # timed at N=1 only
