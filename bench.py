@@ -701,7 +701,7 @@ def main():
             "us_per_launch": dense["us"], "shape": dense["shape"], "valu_frac": dense["valu_frac"],
             "overlapping_pairs": dense["overlapping_pairs"]}) if dense else None,
         "roofline_dense_iou_two_tier": ({k: kernels[FAST_ROW][k] for k in keys} | {
-            "kernel": "rsdet_box_iou_rotated_fast_f32 (1 launch, every element stored once; |d| < 3e-6 of the reference)",
+            "kernel": "rsdet_box_iou_rotated_fast_f32 (1 launch, two-tier clipper; |d| < 3e-6 of the reference)",
             "us_per_launch": kernels[FAST_ROW]["us"], "mpairs_per_s": kernels[FAST_ROW]["mpairs_per_s"],
             "issue": issue.get("dense_iou_two_tier")})
         if FAST_ROW in kernels else None,

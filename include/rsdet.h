@@ -111,20 +111,16 @@ int rsdet_box_iou_rotated_split_f32(const float* boxes1, int n1, int stride1, co
  * Tier 1 (every overlapping pair): intersection area by Green's theorem, one lane per pair, registers only.
  * Tier 2 (the reference-order clipper of rsdet_box_iou_rotated_f32): pairs in which a corner of one box lies within
  * 0.01 px of an edge of the other -- where the REFERENCE itself leaves the true area (its hull scan reads dist[] with
- * pre-sort indices, box_iou_rotated.py:199-212) -- pairs with IoU < 1e-6 (exact zeros are kept) and NaN boxes.
- * Every element of the matrix is stored exactly once: zeros of the (row, 64-column) cells whose bounding shapes are
- * apart by dedicated store workgroups, the other cells by the workgroups that compute them.
+ * pre-sort indices, box_iou_rotated.py:199-212) -- pairs with IoU < 3e-5 (exact zeros are kept) and NaN boxes.
  * Replaces ops/box_iou_rotated.py:502-509 / box_iou_rotated_v1.py:507-524 for callers that need the VALUES only;
  * callers that derive indices from thresholds or ties (MaxIoUAssigner) keep the bit-exact entries above or use
  * rsdet_anchor_target_rotated_f32.  Arguments as rsdet_box_iou_rotated_tiled_f32, except that row tiles hold
- * rsdet_box_iou_rotated_fast_rows_per_tile() (= 64) rows and that there are two performance hints (any value is
- * correct; -1 = none): column tiles from heavy_from_col on (large boxes: most rows overlap them) are worked on in
- * 8-row sub-tiles, those from medium_from_col (<= heavy_from_col) on in 32-row sub-tiles. */
+ * rsdet_box_iou_rotated_fast_rows_per_tile() (= 32) rows (heavy column tiles: four 8-row sub-tiles). */
 int rsdet_box_iou_rotated_fast_rows_per_tile(void);
 int rsdet_box_iou_rotated_fast_f32(const float* boxes1, int n1, int stride1, const int* row_offsets, int n_groups,
                                    int max_rows_per_group, const int* tile_table, int n_row_tiles,
                                    const void* prepared1, const void* prepared2, int n2, int per_group,
-                                   int medium_from_col, int heavy_from_col, int version, float* ious, void* stream);
+                                   int heavy_from_col, int version, float* ious, void* stream);
 
 /* anchor_target for a whole batch WITHOUT the (K, A) matrix: rotated IoU of the surviving pairs only
  * (1.2 % at S2ANet shapes) -> MaxIoUAssigner (column max / first argmax, thresholds, low-quality
@@ -540,6 +536,26 @@ int rsdet_bn_act_backward_nhwc_bf16(const uint16_t* grad_y, const uint16_t* y, c
                                     float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
                                     uint16_t* grad_residual, float* grad_weight, float* grad_bias, void* ws,
                                     size_t ws_bytes, void* stream);
+
+/* The same pair with the ReLU gate carried as ONE BIT per element instead of re-read from y: the forward writes
+ * rsdet_bn_act_relu_mask_bytes(N, C, HW, bf16) bytes (0 = this shape has no mask form: use the entries above), the
+ * backward reads them in place of y -- 19 % less HBM traffic for the backward (resnet.py:101-126 is the fused sequence;
+ * nothing in the reference corresponds to the mask, its autograd keeps y).  relu is implied (= 1). */
+size_t rsdet_bn_act_relu_mask_bytes(int N, int C, int HW, int bf16);
+int rsdet_bn_act_forward_nhwc_mask_f32(const float* x, const float* residual, const float* running_mean,
+                                       const float* running_var, const float* weight, const float* bias, float eps,
+                                       int N, int C, int HW, int relu, float* y, uint8_t* relu_mask, void* stream);
+int rsdet_bn_act_forward_nhwc_mask_bf16(const uint16_t* x, const uint16_t* residual, const float* running_mean,
+                                        const float* running_var, const float* weight, const float* bias, float eps,
+                                        int N, int C, int HW, int relu, uint16_t* y, uint8_t* relu_mask, void* stream);
+int rsdet_bn_act_backward_nhwc_mask_f32(const float* grad_y, const uint8_t* relu_mask, const float* x,
+                                        const float* running_mean, const float* running_var, const float* weight,
+                                        float eps, int N, int C, int HW, float* grad_x, float* grad_residual,
+                                        float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+int rsdet_bn_act_backward_nhwc_mask_bf16(const uint16_t* grad_y, const uint8_t* relu_mask, const uint16_t* x,
+                                         const float* running_mean, const float* running_var, const float* weight,
+                                         float eps, int N, int C, int HW, uint16_t* grad_x, uint16_t* grad_residual,
+                                         float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- 8(f) rank 1  polygon IoU + tile-merge polygon NMS (evaluation side) ------------------------------------
  * Replaces ops/nms_poly.py:247-252 (iou_poly: shapely intersection area, max(union, 0.01) in the denominator),

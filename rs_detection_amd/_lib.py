@@ -36,7 +36,7 @@ SIGNATURES = {
                                                 c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rsdet_box_iou_rotated_fast_rows_per_tile": (c_int, []),
     "rsdet_box_iou_rotated_fast_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                                               c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                               c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rsdet_box_iou_rotated_split_state_bytes": (c_size_t, []),
     "rsdet_box_iou_rotated_split_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "rsdet_box_iou_rotated_split_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
@@ -177,6 +177,17 @@ SIGNATURES = {
     "rsdet_bn_act_backward_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                                 c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_size_t, c_void_p]),
+    "rsdet_bn_act_relu_mask_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rsdet_bn_act_forward_nhwc_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rsdet_bn_act_forward_nhwc_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rsdet_bn_act_backward_nhwc_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                    c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    c_size_t, c_void_p]),
+    "rsdet_bn_act_backward_nhwc_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_size_t, c_void_p]),
     "rsdet_bn_act_backward_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                                c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_size_t, c_void_p]),

@@ -171,13 +171,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_finish_kernel(const float* __r
 // convolution in layout transposes, 6.6 ms of a 28 ms step).  Same arithmetic, different indexing: a thread owns FOUR
 // CONSECUTIVE CHANNELS (one 16-byte / 8-byte access), so the per-channel parameters are four values in registers and
 // consecutive lanes walk a pixel's channel vector.  C % 4 == 0.
+template <typename T>
+__device__ __forceinline__ bool stored_pos(float v) {   // is the value positive once stored as T?
+  if constexpr (sizeof(T) == 2) return bf2f(f2bf(v)) > 0.f;
+  return v > 0.f;
+}
+
 template <bool RELU, bool RES, typename T>
 __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ var,
                                                                const float* __restrict__ weight,
                                                                const float* __restrict__ bias, float eps, int C,
-                                                               long long total_q, T* __restrict__ y) {
+                                                               long long total_q, T* __restrict__ y,
+                                                               unsigned char* __restrict__ mask) {
   const long long q = (long long)blockIdx.x * BN_NT + threadIdx.x;
   if (q >= total_q) return;
   const int c0 = (int)((q * 4) % C);
@@ -194,7 +201,13 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc_kernel(const T* __restr
     const float4 r = ld4(res + q * 4);
     o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
   }
-  if (RELU) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+  if (RELU) {
+    // the backward's ReLU gate as ONE BIT per element (a byte per lane granule): it then reads these instead of y
+    o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+    if (mask)   // "the STORED y > 0" (bf16: of the rounded value)
+      mask[q] = (unsigned char)((int)stored_pos<T>(o.x) | ((int)stored_pos<T>(o.y) << 1) | ((int)stored_pos<T>(o.z) << 2) |
+                                ((int)stored_pos<T>(o.w) << 3));
+  }
   st4(y + q * 4, o);
 }
 
@@ -206,7 +219,7 @@ template <bool RELU, typename T, int J>
 __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ weight, float eps, long long rows, int C, int rows_per,
-    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial) {
+    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial, const unsigned char* __restrict__ mask) {
   __shared__ float s_red[BN_NT][8];
   const int G = C >> 2, S = gridDim.x, s = blockIdx.x;
   const int RL = J == 1 ? max(BN_NT / G, 1) : 1;
@@ -236,8 +249,13 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
       const long long base = r * C + c0;
       float4 g = ld4(dy + base);
       if (RELU) {
-        const float4 o = ld4(y + base);
-        g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
+        if (mask) {       // one byte instead of the 16 / 8 bytes of y
+          const unsigned b = mask[base >> 2];
+          g.x = (b & 1u) ? g.x : 0.f, g.y = (b & 2u) ? g.y : 0.f, g.z = (b & 4u) ? g.z : 0.f, g.w = (b & 8u) ? g.w : 0.f;
+        } else {
+          const float4 o = ld4(y + base);
+          g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
+        }
       }
       if (partial) {
         acc[j][0] += g.x, acc[j][1] += g.y, acc[j][2] += g.z, acc[j][3] += g.w;
@@ -294,7 +312,8 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc8_kernel(const bf16_t* _
                                                                 const float* __restrict__ var,
                                                                 const float* __restrict__ weight,
                                                                 const float* __restrict__ bias, float eps, int C,
-                                                                long long total_q, bf16_t* __restrict__ y) {
+                                                                long long total_q, bf16_t* __restrict__ y,
+                                                                unsigned char* __restrict__ mask) {
   // a lane owns granule q and the granule half the tensor away (same channels: total_q / 2 is a multiple of C / 8 --
   // the host launches this form only then): two independent 16-byte load streams per lane, one set of parameters
   const long long half = total_q >> 1;
@@ -311,16 +330,23 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc8_kernel(const bf16_t* _
   F8 r0, r1;
   if (RES) r0 = ld8(res + q * 8), r1 = ld8(res + (q + half) * 8);
   F8 o0, o1;
+  unsigned b0 = 0u, b1 = 0u;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float t0 = ((v0.v[k] - m.v[k]) * is.v[k]) * (weight ? g.v[k] : 1.0f) + (bias ? b.v[k] : 0.0f);
     float t1 = ((v1.v[k] - m.v[k]) * is.v[k]) * (weight ? g.v[k] : 1.0f) + (bias ? b.v[k] : 0.0f);
     if (RES) t0 += r0.v[k], t1 += r1.v[k];
-    if (RELU) t0 = fmaxf(t0, 0.f), t1 = fmaxf(t1, 0.f);
+    if (RELU) {
+      t0 = fmaxf(t0, 0.f), t1 = fmaxf(t1, 0.f);
+      // the gate the backward needs is "the STORED y > 0": compare the bf16-rounded value (the same conversion the
+      // store below makes; a positive below the smallest bf16 rounds to +0)
+      b0 |= (unsigned)(bf2f(f2bf(t0)) > 0.f) << k, b1 |= (unsigned)(bf2f(f2bf(t1)) > 0.f) << k;
+    }
     o0.v[k] = t0, o1.v[k] = t1;
   }
   st8(y + q * 8, o0);
   st8(y + (q + half) * 8, o1);
+  if (RELU && mask) mask[q] = (unsigned char)b0, mask[q + half] = (unsigned char)b1;
 }
 
 template <bool RELU>
@@ -328,7 +354,7 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ weight, float eps,
     long long rows, int C, int rows_per, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, const unsigned char* __restrict__ mask) {
   __shared__ float s_red[BN_NT][17];   // 17: the fold below reads a column of 16 across rows
   const int G = C >> 3, S = gridDim.x, s = blockIdx.x;
   const int RL = BN_NT / G;            // G is a divisor of 256 (host-checked)
@@ -356,9 +382,15 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     const long long base = r * C + c0;
     F8 g = ld8(dy + base);
     if (RELU) {
-      const F8 o = ld8(y + base);
+      if (mask) {         // one byte instead of the 16 bytes of y
+        const unsigned b = mask[base >> 3];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) g.v[k] = o.v[k] > 0.f ? g.v[k] : 0.f;
+        for (int k = 0; k < 8; ++k) g.v[k] = ((b >> k) & 1u) ? g.v[k] : 0.f;
+      } else {
+        const F8 o = ld8(y + base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g.v[k] = o.v[k] > 0.f ? g.v[k] : 0.f;
+      }
     }
     if (partial) {
 #pragma unroll
@@ -684,13 +716,24 @@ extern "C" size_t rsdet_bn_act_backward_nhwc_ws_size(int N, int C, int HW) {
   return (size_t)C * S * 2 * sizeof(float);
 }
 
+// Bytes of the ReLU bit mask of an (N, HW, C) channels-last map: one byte per lane granule (8 channels where the bf16
+// eight-channel kernels run -- forward AND backward must take them, so the forward's extra condition, an even pixel
+// count, is part of it -- else 4 channels, the low nibble used).  0 = no mask form for this shape (callers keep y).
+extern "C" size_t rsdet_bn_act_relu_mask_bytes(int N, int C, int HW, int bf16) {
+  if (N <= 0 || HW <= 0 || !bn_nhwc_ok(C)) return 0;
+  const long long rows = (long long)N * HW;
+  if (bf16 && bn_nhwc8_ok(C) && bn_vec8()) return (rows & 1) ? 0 : (size_t)(rows * (C / 8));
+  return (size_t)(rows * (C / 4));
+}
+
 template <typename T>
 static int bn_act_forward_nhwc(const T* x, const T* residual, const float* running_mean, const float* running_var,
                                const float* weight, const float* bias, float eps, int N, int C, int HW, int relu, T* y,
-                               void* stream) {
+                               unsigned char* mask, void* stream) {
   if (N < 0 || HW < 0 || !bn_nhwc_ok(C)) return RSDET_EINVAL;
   if (N == 0 || HW == 0) return RSDET_OK;
   if (!x || !running_mean || !running_var || !y) return RSDET_EINVAL;
+  if (mask && (!relu || rsdet_bn_act_relu_mask_bytes(N, C, HW, sizeof(T) == 2) == 0)) return RSDET_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if constexpr (sizeof(T) == 2) {
     if (bn_nhwc8_ok(C) && bn_vec8() && (((long long)N * HW) & 1) == 0) {
@@ -698,7 +741,7 @@ static int bn_act_forward_nhwc(const T* x, const T* residual, const float* runni
       const dim3 g8((unsigned)((tq / 2 + BN_NT - 1) / BN_NT));
 #define RSDET_BN_FWD8(R, A)                                                                                         \
   hipLaunchKernelGGL((bn_act_fwd_nhwc8_kernel<R, A>), g8, dim3(BN_NT), 0, s, x, residual, running_mean, running_var, \
-                     weight, bias, eps, C, tq, y)
+                     weight, bias, eps, C, tq, y, mask)
       if (relu) {
         if (residual) RSDET_BN_FWD8(true, true); else RSDET_BN_FWD8(true, false);
       } else {
@@ -712,7 +755,7 @@ static int bn_act_forward_nhwc(const T* x, const T* residual, const float* runni
   const dim3 grid((unsigned)((total_q + BN_NT - 1) / BN_NT));
 #define RSDET_BN_FWD(R, A)                                                                                      \
   hipLaunchKernelGGL((bn_act_fwd_nhwc_kernel<R, A, T>), grid, dim3(BN_NT), 0, s, x, residual, running_mean,     \
-                     running_var, weight, bias, eps, C, total_q, y)
+                     running_var, weight, bias, eps, C, total_q, y, mask)
   if (relu) {
     if (residual) RSDET_BN_FWD(true, true); else RSDET_BN_FWD(true, false);
   } else {
@@ -723,13 +766,14 @@ static int bn_act_forward_nhwc(const T* x, const T* residual, const float* runni
 }
 
 template <typename T>
-static int bn_act_backward_nhwc(const T* grad_y, const T* y, const T* x, const float* running_mean,
-                                const float* running_var, const float* weight, float eps, int N, int C, int HW,
-                                int relu, T* grad_x, T* grad_residual, float* grad_weight, float* grad_bias, void* ws,
-                                size_t ws_bytes, void* stream) {
+static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char* mask, const T* x,
+                                const float* running_mean, const float* running_var, const float* weight, float eps,
+                                int N, int C, int HW, int relu, T* grad_x, T* grad_residual, float* grad_weight,
+                                float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
   if (N < 0 || HW < 0 || !bn_nhwc_ok(C)) return RSDET_EINVAL;
   if (N == 0 || HW == 0) return RSDET_OK;
-  if (!grad_y || !running_mean || !running_var || (relu && !y)) return RSDET_EINVAL;
+  if (!grad_y || !running_mean || !running_var || (relu && !y && !mask)) return RSDET_EINVAL;
+  if (mask && rsdet_bn_act_relu_mask_bytes(N, C, HW, sizeof(T) == 2) == 0) return RSDET_EINVAL;
   const bool need_param = grad_weight || grad_bias;
   if (need_param && ((grad_weight && !x) || !ws || ws_bytes < rsdet_bn_act_backward_nhwc_ws_size(N, C, HW)))
     return RSDET_EINVAL;
@@ -744,10 +788,10 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const T* x, const f
       bn_nhwc_split(rows, C, &per, &S, 8);   // never more slices than the four-channel split the workspace is sized for
       if (relu)
         hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<true>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
-                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial);
+                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask);
       else
         hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<false>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
-                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial);
+                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask);
       if (need_param)
         hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
                            grad_bias);
@@ -758,7 +802,7 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const T* x, const f
   const int J = G <= BN_NT ? 1 : (G + BN_NT - 1) / BN_NT;
 #define RSDET_BN_BWD(R, JJ)                                                                                        \
   hipLaunchKernelGGL((bn_act_bwd_nhwc_kernel<R, T, JJ>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,   \
-                     running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial)
+                     running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask)
   if (relu) {
     if (J == 1) RSDET_BN_BWD(true, 1); else if (J == 2) RSDET_BN_BWD(true, 2); else RSDET_BN_BWD(true, 4);
   } else {
@@ -777,14 +821,35 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const T* x, const f
                                                  float eps, int N, int C, int HW, int relu, T* y, void* stream) {     \
     return bn_act_forward_nhwc(reinterpret_cast<const rsdet_bn_##tag##_t*>(x),                                        \
                                reinterpret_cast<const rsdet_bn_##tag##_t*>(residual), running_mean, running_var,      \
-                               weight, bias, eps, N, C, HW, relu, reinterpret_cast<rsdet_bn_##tag##_t*>(y), stream);  \
+                               weight, bias, eps, N, C, HW, relu, reinterpret_cast<rsdet_bn_##tag##_t*>(y), nullptr,  \
+                               stream);                                                                               \
+  }                                                                                                                   \
+  extern "C" int rsdet_bn_act_forward_nhwc_mask_##tag(const T* x, const T* residual, const float* running_mean,       \
+                                                      const float* running_var, const float* weight,                  \
+                                                      const float* bias, float eps, int N, int C, int HW, int relu,   \
+                                                      T* y, uint8_t* relu_mask, void* stream) {                       \
+    return bn_act_forward_nhwc(reinterpret_cast<const rsdet_bn_##tag##_t*>(x),                                        \
+                               reinterpret_cast<const rsdet_bn_##tag##_t*>(residual), running_mean, running_var,      \
+                               weight, bias, eps, N, C, HW, relu, reinterpret_cast<rsdet_bn_##tag##_t*>(y),           \
+                               relu_mask, stream);                                                                    \
+  }                                                                                                                   \
+  extern "C" int rsdet_bn_act_backward_nhwc_mask_##tag(                                                               \
+      const T* grad_y, const uint8_t* relu_mask, const T* x, const float* running_mean, const float* running_var,     \
+      const float* weight, float eps, int N, int C, int HW, T* grad_x, T* grad_residual, float* grad_weight,          \
+      float* grad_bias, void* ws, size_t ws_bytes, void* stream) {                                                    \
+    typedef rsdet_bn_##tag##_t E;                                                                                     \
+    if (!relu_mask) return RSDET_EINVAL;                                                                              \
+    return bn_act_backward_nhwc<E>(reinterpret_cast<const E*>(grad_y), nullptr, relu_mask,                            \
+                                   reinterpret_cast<const E*>(x), running_mean, running_var, weight, eps, N, C, HW,   \
+                                   1, reinterpret_cast<E*>(grad_x), reinterpret_cast<E*>(grad_residual),              \
+                                   grad_weight, grad_bias, ws, ws_bytes, stream);                                     \
   }                                                                                                                   \
   extern "C" int rsdet_bn_act_backward_nhwc_##tag(                                                                    \
       const T* grad_y, const T* y, const T* x, const float* running_mean, const float* running_var,                   \
       const float* weight, float eps, int N, int C, int HW, int relu, T* grad_x, T* grad_residual,                    \
       float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream) {                                \
     typedef rsdet_bn_##tag##_t E;                                                                                     \
-    return bn_act_backward_nhwc(reinterpret_cast<const E*>(grad_y), reinterpret_cast<const E*>(y),                    \
+    return bn_act_backward_nhwc(reinterpret_cast<const E*>(grad_y), reinterpret_cast<const E*>(y), nullptr,           \
                                 reinterpret_cast<const E*>(x), running_mean, running_var, weight, eps, N, C, HW,      \
                                 relu, reinterpret_cast<E*>(grad_x), reinterpret_cast<E*>(grad_residual), grad_weight, \
                                 grad_bias, ws, ws_bytes, stream);                                                     \

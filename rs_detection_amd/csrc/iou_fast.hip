@@ -3,32 +3,21 @@
 // Replaces, to the north star's tolerance (|IoU - reference| <= 1e-4; measured < 3e-6), the pair loop of
 //   /root/reference/python/jdet/ops/box_iou_rotated.py:487-500 (box_iou_rotated) and box_iou_rotated_v1.py:507-524.
 // The bit-exact form of the same op stays in box_iou_rotated.hip (three launches, reference-order clipper on every
-// overlapping pair, 37 us at the S2ANet step shape); this one is for callers that need the VALUES only.
+// overlapping pair, 37 us at the S2ANet step shape); this one is for callers that need the VALUES only:
 //
-// Round 4 form: EVERY ELEMENT OF THE MATRIX IS STORED EXACTLY ONCE, by one of two kinds of workgroup that
-// never talk to each other.  The unit both agree on is the CELL = (row, 64-column strip): `strip_live()` (the row's
-// bounding circle against the bounding box of the strip's 64 column circles) is evaluated by both kinds with the same
-// inlined arithmetic on the same inputs (-ffp-contract=off), so they hold the same live set (~12 % of the cells at
-// S2ANet shapes) without exchanging a byte.
-//
-//   store workgroups    (lowest block ids: dispatched first) own the CULLED cells: a wave loads 32 rows' circles and
-//                       four strip boxes, culls, and streams the zeros of its 32 x 256 block as 16-byte-per-lane
-//                       row-contiguous stores (1 KB of one matrix row per wave instruction) with the live cells
-//                       masked out.  They do nothing else, so that a wave blocked at store issue (the CU's memory
-//                       queue stays full for the whole launch: 48 MB leave at the HBM rate) delays no arithmetic.
-//   compute workgroups  own the LIVE cells of a 64-row x 256-column tile (heavy column tiles -- the top pyramid
-//                       levels, where most cells are live -- as eight 8-row sub-tiles):
-//     detect   bounding circles -> separating axes, the ballot word is the survivor set of the cell (rsdet_tile.h)
-//     zeros    of the live cells' non-survivors, 16 lanes per cell: a granule without survivors as one 16-byte store,
-//              a mixed granule element by element
-//     tier 1   every survivor: intersection area by Green's theorem, one lane per pair, registers only, ~350 VALU
-//              instructions (rsdet_geom_fast.h); the lane stores its own element
-//     tier 2   the survivors tier 1 flags (and does not store) -- a corner of one box within 0.01 px of an edge of the
-//              other (where the REFERENCE leaves the true area, see rsdet_geom_fast.h), IoU < 1e-6 (exact zeros), NaN --
-//              through the reference-order clipper (rsdet_geom.h, 4 lanes per pair) on the first wave
-// so every ELEMENT has exactly one store in the launch and nothing ever waits for a store.  Round 3 stored the tile's
-// zeros first and the values after `s_waitcnt vmcnt(0)` (every value waited behind 48 MB of everyone's zeros: 21 us
-// at the step shape).
+//   tile       32 gts x 256 anchors per workgroup, row tiles from a host-built table (no empty workgroups)
+//   fill       first thing in the kernel: the tile's zeros as 16-byte-per-lane row-contiguous stores (a wave writes
+//              1 KB of one matrix row per instruction, 8 instructions per lane), never waited for while detecting
+//   detect     strip cull against the 64-column boxes -> bounding circles -> separating axes on dense lanes; the
+//              candidate / survivor sets are bit masks (rsdet_tile.h)
+//   tier 1     every survivor: intersection area by Green's theorem, one lane per pair, registers only, ~350 VALU
+//              instructions (rsdet_geom_fast.h) -- against ~3 200 lane-instructions of the reference-order clipper
+//   tier 2     the survivors tier 1 flags -- a corner of one box within 0.01 px of an edge of the other (where the
+//              REFERENCE leaves the true area, see rsdet_geom_fast.h), IoU < 3e-5 (exact zeros), NaN -- go through
+//              the reference-order clipper (rsdet_geom.h, 4 lanes per pair) on the first wave: ~1.2 % of the survivors
+//              of random boxes
+// Values are stored after the workgroup's own zero stores have been acknowledged (s_waitcnt vmcnt(0) + barrier: same
+// CU, same L2 channel), so no element depends on the order of two stores in flight.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -49,36 +38,14 @@ __device__ unsigned long long* g_fast_trace;
 #define FTR(k)
 #endif
 
-constexpr int F_NT = 256;     // columns per compute tile = threads per workgroup
-#ifndef RSDET_FAST_ROWS
-#define RSDET_FAST_ROWS 64
-#endif
-constexpr int F_R = RSDET_FAST_ROWS;   // rows per compute tile (= lanes of the strip cull)
+constexpr int F_NT = 256;     // columns per tile = threads per workgroup
+constexpr int F_R = 32;       // rows per tile
 #ifndef RSDET_FAST_SUB
-#define RSDET_FAST_SUB 8
+#define RSDET_FAST_SUB 4
 #endif
-constexpr int F_SUB = RSDET_FAST_SUB;  // heavy column tiles (large boxes: most cells live) are cut into F_SUB row sub-tiles,
-#ifndef RSDET_FAST_MSUB
-#define RSDET_FAST_MSUB 2
-#endif
-constexpr int F_MSUB = RSDET_FAST_MSUB;  // medium ones (the level below them) into F_MSUB
-constexpr int F_NW = F_R * (F_NT / 64);   // survivor words of a tile
-constexpr int F_QSLOTS = 24;  // LDS slots per quad of the clipper (kQuadSlots = 25 is bank-conflict free; 24 makes the
-                              // workgroup exactly 20 480 B = 8 per CU, and tier 2 is 0.4 % of the survivors)
-#ifndef RSDET_FAST_STORE_LAST
-#define RSDET_FAST_STORE_LAST 1
-#endif
-#ifndef RSDET_FAST_LIGHT_FIRST
-#define RSDET_FAST_LIGHT_FIRST 0
-#endif
-#ifndef RSDET_FAST_PRIO
-#define RSDET_FAST_PRIO 0
-#endif
-#ifndef RSDET_FAST_STORE_SLEEP
-#define RSDET_FAST_STORE_SLEEP 0
-#endif
-
-static_assert(F_R <= 64 && F_R % F_SUB == 0 && F_R % F_MSUB == 0, "row mask is one 64-bit ballot");
+constexpr int F_SUB = RSDET_FAST_SUB;  // heavy column tiles (large boxes: most rows overlap them) are cut into F_SUB row sub-tiles
+constexpr int F_NW = F_R * (F_NT / 64);
+constexpr int F_XCAP = 1024;  // flagged pairs kept per tile (more: the whole tile goes through tier 2)
 
 struct FastArgs {
   const float* boxes1;   // raw rows (n1, stride1)
@@ -90,25 +57,62 @@ struct FastArgs {
   const int* row_offsets;  // n_groups + 1 (device); nullptr: one group = all rows
   const RowTile* tiles;    // n_row_tiles descriptors, or nullptr (then row tiles = n_groups x ny)
   int n_row_tiles, ny, nx;
-  int split_xt, split_mt;  // column tiles >= split_xt are cut into F_SUB sub-tiles, [split_mt, split_xt) into F_MSUB (hints)
+  int split_xt;            // column tiles >= split_xt are cut into F_SUB sub-tiles (performance hint only)
   int vec4;                // matrix rows are 16-byte aligned (n2 % 4 == 0 and an aligned base)
-  int n_store, n_compute, nxs;   // workgroups of each kind; column super-blocks of 4 * F_NT per row tile (store)
   float* out;
 };
 
-// THE cell predicate (both kinds of workgroup): may row circle (rx, ry, rad) touch one of the 64 column circles
-// bounded by cb?  NaN / infinite inputs answer yes.
-__device__ __forceinline__ bool strip_live(float rx, float ry, float rad, float4 cb) {
-  const float dx = fmaxf(fmaxf(cb.x - rx, rx - cb.z), 0.f), dy = fmaxf(fmaxf(cb.y - ry, ry - cb.w), 0.f);
-  const float thr = 1.001f * rad + 1e-5f * (fabsf(rx) + fabsf(ry));
-  return !(dx * dx + dy * dy > thr * thr);
-}
+template <int VERSION>
+__global__ __launch_bounds__(F_NT) void iou_fast_tile_kernel(const FastArgs a) {
+  __shared__ BoxPre s_row[F_R];
+  __shared__ __attribute__((aligned(16))) BoxPre s_col[F_NT];
+  __shared__ unsigned long long s_sm[F_NW];
+  __shared__ unsigned short s_send[F_NW];
+  __shared__ F2 s_pts[kQuadSlots * 16];
+  __shared__ unsigned short s_xlist[F_XCAP];
+  __shared__ unsigned s_nx;
 
-// bounding radius exactly as prepare_box() computes it (rsdet_geom.h)
-__device__ __forceinline__ float box_rad(float w, float h) { return 0.5f * (fabsf(w) + fabsf(h)) * 1.0001f + 1e-3f; }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  FTR(0);
+  // heavy column tiles (the top pyramid levels: the last columns) first, each cut into F_SUB row sub-tiles
+  const int n_heavy = (a.nx - a.split_xt) * a.n_row_tiles * F_SUB;
+  const bool heavy = (int)blockIdx.x < n_heavy;
+  int xt, rt, sub = 0;
+  if (heavy) {
+    const int per = a.n_row_tiles * F_SUB;
+    xt = a.nx - 1 - (int)blockIdx.x / per;
+    const int rem = (int)blockIdx.x % per;
+    rt = rem / F_SUB;
+    sub = rem - rt * F_SUB;
+  } else {
+    const int id = (int)blockIdx.x - n_heavy;
+    xt = a.split_xt - 1 - id / a.n_row_tiles;
+    rt = id % a.n_row_tiles;
+  }
+  const int col0 = xt * F_NT, col = col0 + tid;
+  const int ncols = min(F_NT, a.n2 - col0);
+  const bool col_ok = col < a.n2;
 
-template <class A>
-__device__ __forceinline__ void row_tile(A& a, int rt, int& g, int& row0, int& nrows) {
+  // ---- LOADS FIRST: a CU serves its vector-memory queue in order, and the chip is about to be saturated by 48 MB of
+  // zero stores -- loads queued behind this workgroup's own stores came back after 5 us (measured); queued ahead
+  // of them they take ~1.5.  The tile's columns (40-byte prepared boxes: 2.5 float4 per column), its strip box, its rows.
+  // With one column set for all groups the column loads do not depend on the tile table: they go out before it is read.
+  const int n16 = (ncols * (int)sizeof(BoxPre)) / 16;
+  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, cb = c0;
+  float2 ctail = make_float2(0.f, 0.f);
+  const bool has_tail = (ncols & 1) && tid == 0;   // odd column count: 8 bytes beyond the last whole float4
+  const int kw = (col0 >> 6) + wave;
+  auto load_cols = [&](long long slab, int slab_word) {
+    const float4* src = reinterpret_cast<const float4*>(a.pre2 + slab + col0);  // 40 * 256 * xt bytes: 16-byte aligned
+    if (tid < n16) c0 = src[tid];
+    if (tid + F_NT < n16) c1 = src[tid + F_NT];
+    if (tid + 2 * F_NT < n16) c2 = src[tid + 2 * F_NT];
+    if (has_tail) ctail = reinterpret_cast<const float2*>(src)[n16 * 2];
+    cb = a.colbox[slab_word + min(kw, a.cw - 1)];
+  };
+  if (!a.per_group) load_cols(0, 0);
+
+  int g, row0, nrows;
   if (a.tiles) {
     const RowTile t = a.tiles[rt];
     g = t.group, row0 = t.row0, nrows = t.nrows;
@@ -123,147 +127,10 @@ __device__ __forceinline__ void row_tile(A& a, int rt, int& g, int& row0, int& n
     row0 = rb + y * F_R;
     nrows = min(F_R, re - row0);
   }
-}
-
-// ---- store workgroup: zeros of the culled cells of (F_R rows) x (4 * 256 columns); wave = one 256-column block
-template <class A>
-__device__ __forceinline__ void store_role(A& a, int sb) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rt = sb / a.nxs, xs = sb - rt * a.nxs;
-  const int xt = xs * (F_NT / 64) + wave;
-  if (xt >= a.nx) return;
-  int g, row0, nrows;
-  row_tile(a, rt, g, row0, nrows);
-  if (nrows <= 0) return;
-  const int col0 = xt * F_NT, kw0 = col0 >> 6;
-  const int slab_word = a.per_group ? g * a.cw : 0;
-  // lane = row: its circle against the four strip boxes of the block
-  float rx = 0.f, ry = 0.f, rad = 0.f;
-  if (lane < nrows) {
-    if (a.pre1) {
-      const BoxPre* p = a.pre1 + row0 + lane;
-      rx = p->cx, ry = p->cy, rad = p->rad;
-    } else {
-      const float* p = a.boxes1 + (long long)(row0 + lane) * a.stride1;
-      rx = p[0], ry = p[1], rad = box_rad(p[2], p[3]);
-    }
+  if (heavy) {
+    row0 += sub * (F_R / F_SUB);
+    nrows = min(F_R / F_SUB, nrows - sub * (F_R / F_SUB));
   }
-  unsigned long long lv[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const float4 cb = a.colbox[slab_word + min(kw0 + s, a.cw - 1)];
-    lv[s] = __ballot(lane < nrows && kw0 + s < a.cw && strip_live(rx, ry, rad, cb));
-  }
-  FTR(1);
-  if (a.vec4) {
-    // lane = 16-byte granule of the 1 KB row segment; its strip is lane >> 4
-    const int s = lane >> 4;
-    unsigned long long mylive = (s & 1) ? ((s & 2) ? lv[3] : lv[1]) : ((s & 2) ? lv[2] : lv[0]);
-    const int c = col0 + 4 * lane;
-    if (c < a.n2) {
-      float* o = a.out + (long long)row0 * a.n2 + c;     // a per-lane running pointer (scalar row offsets would cost 2 SGPRs each)
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-      for (int k = 0; k < nrows; ++k, o += a.n2, mylive >>= 1) {
-        if (!(mylive & 1ull)) *reinterpret_cast<float4*>(o) = z;
-#if RSDET_FAST_STORE_SLEEP > 0
-        __builtin_amdgcn_s_sleep(RSDET_FAST_STORE_SLEEP);
-#endif
-      }
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int c = col0 + 64 * s + lane;
-      if (c < a.n2) {
-        float* o = a.out + (long long)row0 * a.n2 + c;
-        for (int k = 0; k < nrows; ++k)
-          if (!((lv[s] >> k) & 1ull)) o[(long long)k * a.n2] = 0.0f;
-      }
-    }
-  }
-  FTR(2);
-}
-
-// The kernel arguments are read through a pointer the compiler cannot see through, once per phase: otherwise all 26
-// argument dwords are loaded at the entry and stay in SGPRs for the whole kernel (98 SGPRs: 6 workgroups per CU).
-typedef const __attribute__((address_space(4))) FastArgs KFastArgs;
-__device__ __forceinline__ KFastArgs& args_again() {
-  KFastArgs* p = (KFastArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // the struct is the kernel's only parameter
-  asm volatile("" : "+s"(p));
-  return *p;
-}
-
-template <int VERSION>
-__global__ __launch_bounds__(F_NT) void iou_fast_tile_kernel(const FastArgs a0) {
-  __shared__ BoxPre s_row[F_R];
-  __shared__ __attribute__((aligned(16))) BoxPre s_col[F_NT];
-  __shared__ unsigned long long s_sm[F_NW];
-  __shared__ unsigned short s_send[F_NW];
-  __shared__ unsigned long long s_fm[F_NW];   // survivors tier 1 hands to tier 2
-  __shared__ F2 s_pts[F_QSLOTS * 16];
-
-  FTR(0);
-  // Compute workgroups take the LOW block ids: they are dispatched first and their loads return before the store
-  // workgroups saturate the memory system (with the store workgroups first the staging took 3.5 us instead of ~2).
-  int cbid = RSDET_FAST_STORE_LAST ? (int)blockIdx.x : (int)blockIdx.x - a0.n_store;
-  if (RSDET_FAST_STORE_LAST ? cbid >= a0.n_compute : cbid < 0) {
-    store_role(args_again(), RSDET_FAST_STORE_LAST ? cbid - a0.n_compute : (int)blockIdx.x);
-    return;
-  }
-  KFastArgs& a = args_again();
-  if (RSDET_FAST_LIGHT_FIRST) cbid = a.n_compute - 1 - cbid;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // heavy column tiles (the top pyramid levels: the last columns) first, each cut into F_SUB row sub-tiles, then the
-  // medium ones in F_MSUB sub-tiles, then the light ones whole: the longest chains start first
-  const int n_heavy = (a.nx - a.split_xt) * a.n_row_tiles * F_SUB;
-  const int n_medium = (a.split_xt - a.split_mt) * a.n_row_tiles * F_MSUB;
-  int xt, rt, sub = 0, sub_rows = F_R;
-  if (cbid < n_heavy) {
-    const int per = a.n_row_tiles * F_SUB;
-    xt = a.nx - 1 - cbid / per;
-    const int rem = cbid % per;
-    rt = rem / F_SUB;
-    sub = rem - rt * F_SUB;
-    sub_rows = F_R / F_SUB;
-  } else if (cbid < n_heavy + n_medium) {
-    const int id = cbid - n_heavy, per = a.n_row_tiles * F_MSUB;
-    xt = a.split_xt - 1 - id / per;
-    const int rem = id % per;
-    rt = rem / F_MSUB;
-    sub = rem - rt * F_MSUB;
-    sub_rows = F_R / F_MSUB;
-  } else {
-    const int id = cbid - n_heavy - n_medium;
-    xt = a.split_mt - 1 - id / a.n_row_tiles;
-    rt = id % a.n_row_tiles;
-  }
-  const int col0 = xt * F_NT, col = col0 + tid;
-  const int ncols = min(F_NT, a.n2 - col0);
-  const bool col_ok = col < a.n2;
-
-  // ---- loads: the tile's columns (40-byte prepared boxes: 2.5 float4 per column), its strip box, its rows.  With one
-  // column set for all groups the column loads do not depend on the tile table: they go out before it is read.
-  const int n16 = (ncols * (int)sizeof(BoxPre)) / 16;
-  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0, c2 = c0, cb = c0, cb0 = c0;
-  float2 ctail = make_float2(0.f, 0.f);
-  const bool has_tail = (ncols & 1) && tid == 0;   // odd column count: 8 bytes beyond the last whole float4
-  const int kw = (col0 >> 6) + wave;
-  auto load_cols = [&](long long slab, int slab_word) {
-    const float4* src = reinterpret_cast<const float4*>(a.pre2 + slab + col0);  // 40 * 256 * xt bytes: 16-byte aligned
-    if (tid < n16) c0 = src[tid];
-    if (tid + F_NT < n16) c1 = src[tid + F_NT];
-    if (tid + 2 * F_NT < n16) c2 = src[tid + 2 * F_NT];
-    if (has_tail) ctail = reinterpret_cast<const float2*>(src)[n16 * 2];
-    cb = a.colbox[slab_word + min(kw, a.cw - 1)];
-    cb0 = a.colbox[slab_word + (col0 >> 6)];
-  };
-  if (!a.per_group) load_cols(0, 0);
-
-  int g, row0, nrows;
-  row_tile(a, rt, g, row0, nrows);
-  row0 += sub * sub_rows;
-  nrows = min(sub_rows, nrows - sub * sub_rows);
   if (nrows <= 0) return;
   if (a.per_group) load_cols((long long)g * ((a.n2 + 1) & ~1), g * a.cw);
   float rraw[10];
@@ -280,7 +147,11 @@ __global__ __launch_bounds__(F_NT) void iou_fast_tile_kernel(const FastArgs a0) 
       for (int k = 0; k < 5; ++k) rraw[k] = rp[k];
     }
   }
-  {
+
+  // ---- the tile's zeros (16-byte-per-lane, a wave writes 1 KB of one matrix row per instruction), then the staging
+  // of what was loaded above.  NST is a compile-time count so that the compiler waits for the loads with
+  // s_waitcnt vmcnt(NST) and leaves the stores in flight (rows past the tile's end repeat its last row).
+  auto stage = [&]() {
     float4* dst = reinterpret_cast<float4*>(s_col);
     if (tid < n16) dst[tid] = c0;
     if (tid + F_NT < n16) dst[tid + F_NT] = c1;
@@ -295,137 +166,114 @@ __global__ __launch_bounds__(F_NT) void iou_fast_tile_kernel(const FastArgs a0) 
         s_row[tid] = prepare_box(rraw);
       }
     }
-    for (int k = tid; k < F_NW; k += F_NT) s_sm[k] = 0ull, s_fm[k] = 0ull;
+    for (int k = tid; k < F_NW; k += F_NT) s_sm[k] = 0ull;
+    if (tid == 0) s_nx = 0u;
+  };
+  if (a.vec4) {
+    const int c4 = min(col0 + 4 * lane, a.n2 - 4);      // lanes past a ragged tile's end repeat its last 16 bytes
+    float* o = a.out + (long long)row0 * a.n2 + c4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (heavy) {
+#pragma unroll
+      for (int k = 0; k < F_R / F_SUB / 4; ++k)
+        *reinterpret_cast<float4*>(o + (long long)min(wave + 4 * k, nrows - 1) * a.n2) = z;
+      stage();
+    } else {
+#pragma unroll
+      for (int k = 0; k < F_R / 4; ++k)
+        *reinterpret_cast<float4*>(o + (long long)min(wave + 4 * k, nrows - 1) * a.n2) = z;
+      stage();
+    }
+  } else {
+    if (col_ok) {
+      float* o = a.out + (long long)row0 * a.n2 + col;
+      for (int r = 0; r < nrows; ++r) o[(long long)r * a.n2] = 0.0f;
+    }
+    stage();
   }
-  lds_barrier();
+  if (kw >= a.cw) cb = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);  // empty strip
+  lds_barrier();   // (LDS-only barrier: the zero stores stay in flight)
   FTR(1);
   const BoxPre mine = s_col[col_ok ? tid : 0];
 
-  // ---- detection, no compaction: lane i < nrows tests cell (i, this wave's strip) with the predicate the store
-  // workgroups use; for every live cell the lanes whose circles touch run the separating-axis test at once and the
-  // ballot word IS the survivor set of the cell.  (Culling the strip's four 16-column quarters again and letting each
-  // 16-lane group walk its own list of live rows halves the iterations and doubles their cost: measured slower,
-  // profiles/experiments/iou_fast_r04_quarter_cull.hip.txt.)
+  // ---- detection in one pass, no compaction: lane i < nrows tests row i's circle against the bounding box of this
+  // wave's 64 column circles (strip cull); for every live (row, strip) the lanes whose circles touch run the
+  // separating-axis test at once -- ~70 instructions per live strip, 2-3 live strips per wave in a sparse tile -- and
+  // the ballot word IS the survivor set of (row, wave).
+  static_assert(F_R <= 32, "row mask is 32 bits wide");
   bool lv = false;
-  if (lane < nrows && kw < a.cw) lv = strip_live(s_row[lane].cx, s_row[lane].cy, s_row[lane].rad, cb);
-  const unsigned long long live = __ballot(lv);
-  // (the last wave stores the zeros of the first wave's strip as well, see the end: it derives that live set itself)
-  const unsigned long long live0 =
-      wave == F_NT / 64 - 1 ? __ballot(lane < nrows && strip_live(s_row[lane].cx, s_row[lane].cy, s_row[lane].rad, cb0)) : 0ull;
-  if (live) {
-    unsigned long long todo = live;
-    int i = __builtin_ctzll(todo);
-    BoxPre r = s_row[i];
-    while (true) {
-      todo &= todo - 1ull;
-      const int inext = todo ? __builtin_ctzll(todo) : i;
-      const BoxPre rnext = s_row[inext];                     // the next live row's box is in flight under this one's tests
-      bool surv = false;
-      if (col_ok) {
-        const float dx = r.cx - mine.cx, dy = r.cy - mine.cy;
-        const float rr = r.rad + mine.rad;
-        if (!(dx * dx + dy * dy > rr * rr * 1.0001f))          // == !surely_disjoint(r, mine)
-          surv = !sat_disjoint<VERSION>(r, mine);
-      }
-      const unsigned long long m = __ballot(surv);
-      if (m && lane == 0) s_sm[i * (F_NT / 64) + wave] = m;
-      if (!todo) break;
-      r = rnext;
-      i = inext;
+  if (lane < nrows) {
+    const float rx = s_row[lane].cx, ry = s_row[lane].cy;
+    const float dx = fmaxf(fmaxf(cb.x - rx, rx - cb.z), 0.f), dy = fmaxf(fmaxf(cb.y - ry, ry - cb.w), 0.f);
+    const float thr = 1.001f * s_row[lane].rad + 1e-5f * (fabsf(rx) + fabsf(ry));
+    lv = !(dx * dx + dy * dy > thr * thr);
+  }
+  unsigned live = (unsigned)__ballot(lv);
+  while (live) {
+    const int i = __builtin_ctz(live);
+    live &= live - 1u;
+    bool surv = false;
+    if (col_ok) {
+      const BoxPre r = s_row[i];
+      const float dx = r.cx - mine.cx, dy = r.cy - mine.cy;
+      const float rr = r.rad + mine.rad;
+      if (!(dx * dx + dy * dy > rr * rr * 1.0001f))          // == !surely_disjoint(r, mine)
+        surv = !sat_disjoint<VERSION>(r, mine);
     }
+    const unsigned long long m = __ballot(surv);
+    if (m && lane == 0) s_sm[i * (F_NT / 64) + wave] = m;
   }
   lds_barrier();
   FTR(2);
   scan_mask_words<F_NW>(s_sm, s_send, tid);
   lds_barrier();
-  const int total = __builtin_amdgcn_readfirstlane((int)s_send[F_NW - 1]);
+  const int total = s_send[F_NW - 1];
   FTR(3);
-#ifdef RSDET_FAST_TRACE   // slot 4: survivors | live cells of wave 0's strip << 16 | tile column << 32
-  if (tid == 0 && g_fast_trace)
-    g_fast_trace[(size_t)blockIdx.x * 8 + 4] = (unsigned long long)total | ((unsigned long long)__popcll(live) << 16) | ((unsigned long long)xt << 32);
-#endif
-  KFastArgs& b = args_again();   // (out, n2, vec4 only from here on)
+  if (total == 0) return;
 
-  if (total) {
-#if RSDET_FAST_PRIO
-    __builtin_amdgcn_s_setprio(RSDET_FAST_PRIO);   // the latency chain of this workgroup from here on: ahead of other workgroups' detection
-#endif
-    // ---- tier 1: Green integral, one lane per survivor; the value goes straight to its element
-    for (int k = tid; k < total; k += F_NT) {
-      int word, bit;
-      locate_bit<F_NW>(s_sm, s_send, k, word, bit);
-      const int i = word >> 2, j = ((word & 3) << 6) | bit;
-      bool danger, apart;
-      const float v = pair_iou_fast<VERSION>(s_row[i], s_col[j], danger, apart);
-      if (!apart && (danger || !(v >= kFastSliver))) {
-        atomicOr(&s_fm[word], 1ull << bit);                     // tier 2's: not stored here
-      } else {
-        b.out[(long long)(row0 + i) * b.n2 + col0 + j] = v;     // (apart: v == 0)
-      }
-    }
-    lds_barrier();
-    FTR(5);
-    // ---- tier 2: the flagged survivors (a bit mask like the survivors': it cannot overflow) through the
-    // reference-order clipper, 16 quads of the first wave
-    if (wave == 0) {
-      scan_mask_words<F_NW>(s_fm, s_send, tid);      // (tier 1 is over: the survivors' prefix counts are free)
-      lds_wave_order();
-      const int nflag = s_send[F_NW - 1];
-      F2* qscr = s_pts + (lane >> 2) * F_QSLOTS;
-      for (int q0 = 0; q0 < nflag; q0 += 16) {
-        const int q = q0 + (lane >> 2);
-        const bool on = q < nflag;
-        int word, bit;
-        locate_bit<F_NW>(s_fm, s_send, on ? q : 0, word, bit);
-        const int i = word >> 2, j = ((word & 3) << 6) | bit;
-        const float v = pair_iou_quad<VERSION>(s_row[i], s_col[j], qscr, lane);
-        if (on && (lane & 3) == 0) b.out[(long long)(row0 + i) * b.n2 + col0 + j] = v;
-        lds_wave_order();
-      }
+  // every zero of this workgroup is in L2 before the first value is stored
+  __syncthreads();   // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
+  FTR(4);
+
+  // ---- tier 1: Green integral, one lane per survivor
+  for (int k = tid; k < total; k += F_NT) {
+    int word, bit;
+    locate_bit<F_NW>(s_sm, s_send, k, word, bit);
+    const int i = word >> 2, j = ((word & 3) << 6) | bit;
+    bool danger, apart;
+    const float v = pair_iou_fast<VERSION>(s_row[i], s_col[j], danger, apart);
+    if (!apart && (danger || !(v >= kFastSliver))) {
+      const unsigned at = atomicAdd(&s_nx, 1u);
+      if (at < (unsigned)F_XCAP) s_xlist[at] = (unsigned short)((i << 8) | j);
+    } else if (!apart) {
+      a.out[(long long)(row0 + i) * a.n2 + col0 + j] = v;
     }
   }
-  FTR(6);
-  // ---- LAST (off the tier 1 -> tier 2 chain): zeros of the live cells' non-survivors, 16 lanes per cell: a granule without
-  // survivors as one 16-byte store, a mixed granule element by element; the survivors' own elements were stored by the
-  // lanes that computed them above.  The first wave (tier 2) leaves its strip to the last one.
-  auto zero_strip = [&](int sw, unsigned long long L) {
-    if (b.vec4) {
-      const int q = lane >> 4, gq = lane & 15;
-      const int c = col0 + sw * 64 + 4 * gq;
-      while (L) {
-        int i = -1;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (L) {
-            if (q == t) i = __builtin_ctzll(L);
-            L &= L - 1ull;
-          }
-        }
-        if (i >= 0 && c < b.n2) {
-          const unsigned nib = (unsigned)(s_sm[i * (F_NT / 64) + sw] >> (4 * gq)) & 15u;
-          float* o = b.out + (long long)(row0 + i) * b.n2 + c;
-          if (nib == 0u) {
-            *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
-          } else {
-            if (!(nib & 1u)) o[0] = 0.f;
-            if (!(nib & 2u)) o[1] = 0.f;
-            if (!(nib & 4u)) o[2] = 0.f;
-            if (!(nib & 8u)) o[3] = 0.f;
-          }
-        }
-      }
+  __syncthreads();
+  FTR(5);
+  // ---- tier 2: the flagged pairs through the reference-order clipper, 16 quads of the first wave
+  const unsigned nflag = s_nx;
+  if (nflag == 0u || wave != 0) return;
+  F2* qscr = s_pts + (lane >> 2) * kQuadSlots;
+  const bool overflow = nflag > (unsigned)F_XCAP;   // more than the list holds: every survivor of the tile
+  const int n2nd = overflow ? total : (int)nflag;
+  for (int q0 = 0; q0 < n2nd; q0 += 16) {
+    const int q = q0 + (lane >> 2);
+    const bool on = q < n2nd;
+    int i, j;
+    if (overflow) {
+      int word, bit;
+      locate_bit<F_NW>(s_sm, s_send, on ? q : 0, word, bit);
+      i = word >> 2, j = ((word & 3) << 6) | bit;
     } else {
-      const int c = col0 + sw * 64 + lane;
-      while (L) {
-        const int i = __builtin_ctzll(L);
-        L &= L - 1ull;
-        if (c < b.n2 && !((s_sm[i * (F_NT / 64) + sw] >> lane) & 1ull)) b.out[(long long)(row0 + i) * b.n2 + c] = 0.f;
-      }
+      const unsigned e = s_xlist[on ? q : 0];
+      i = (int)(e >> 8), j = (int)(e & 255u);
     }
-  };
-  if (wave != 0) zero_strip(wave, live);
-  if (wave == F_NT / 64 - 1) zero_strip(0, live0);
-  FTR(7);
+    const float v = pair_iou_quad<VERSION>(s_row[i], s_col[j], qscr, lane);
+    if (on && (lane & 3) == 0) a.out[(long long)(row0 + i) * a.n2 + col0 + j] = v;
+    lds_wave_order();
+  }
+  FTR(6);
 }
 
 }  // namespace rsdet
@@ -437,8 +285,8 @@ static inline size_t fast_up256(size_t b) { return (b + 255) & ~(size_t)255; }
 extern "C" int rsdet_box_iou_rotated_fast_f32(const float* boxes1, int n1, int stride1, const int* row_offsets,
                                               int n_groups, int max_rows_per_group, const int* tile_table,
                                               int n_row_tiles, const void* prepared1, const void* prepared2, int n2,
-                                              int per_group, int medium_from_col, int heavy_from_col, int version,
-                                              float* ious, void* stream) {
+                                              int per_group, int heavy_from_col, int version, float* ious,
+                                              void* stream) {
   if (n1 < 0 || n2 < 0 || n_groups < 1 || stride1 < 5 || (version != 0 && version != 1)) return RSDET_EINVAL;
   if (n1 == 0 || n2 == 0) return RSDET_OK;
   if (!boxes1 || !prepared2 || !ious) return RSDET_EINVAL;
@@ -457,19 +305,10 @@ extern "C" int rsdet_box_iou_rotated_fast_f32(const float* boxes1, int n1, int s
   a.n_row_tiles = tile_table ? n_row_tiles : n_groups * a.ny;
   a.nx = (n2 + F_NT - 1) / F_NT;
   a.split_xt = (heavy_from_col < 0 || heavy_from_col >= n2) ? a.nx : heavy_from_col / F_NT;
-  a.split_mt = (medium_from_col < 0 || medium_from_col >= n2) ? a.split_xt : medium_from_col / F_NT;
-  if (a.split_mt > a.split_xt) a.split_mt = a.split_xt;
   a.vec4 = ((n2 & 3) == 0 && n2 >= 4 && ((uintptr_t)ious & 15) == 0) ? 1 : 0;
   a.out = ious;
   if (a.n_row_tiles <= 0) return RSDET_OK;
-  a.nxs = (a.nx + F_NT / 64 - 1) / (F_NT / 64);
-  const long long n_store = (long long)a.n_row_tiles * a.nxs;
-  const long long n_compute = (long long)a.n_row_tiles * ((long long)a.split_mt + (long long)(a.split_xt - a.split_mt) * F_MSUB +
-                                                        (long long)(a.nx - a.split_xt) * F_SUB);
-  if (n_store + n_compute > 0x7fffffffLL) return RSDET_EINVAL;
-  a.n_store = (int)n_store;
-  a.n_compute = (int)n_compute;
-  const dim3 grid((unsigned)(n_store + n_compute));
+  const dim3 grid((unsigned)((long long)a.split_xt * a.n_row_tiles + (long long)(a.nx - a.split_xt) * a.n_row_tiles * F_SUB));
   if (version == 0)
     hipLaunchKernelGGL(iou_fast_tile_kernel<0>, grid, dim3(F_NT), 0, (hipStream_t)stream, a);
   else

@@ -29,25 +29,19 @@ _state = {}
 
 class PreparedBoxes:
     """Device buffer of rsdet_iou_prepare_f32 + the geometry it was made for."""
-    __slots__ = ("buf", "n_total", "n_per_group", "groups", "heavy_from", "medium_from")
+    __slots__ = ("buf", "n_total", "n_per_group", "groups", "heavy_from")
 
-    def __init__(self, buf, n_total, n_per_group, heavy_from=None, medium_from=None):
+    def __init__(self, buf, n_total, n_per_group, heavy_from=None):
         self.buf, self.n_total, self.n_per_group = buf, n_total, n_per_group
         self.groups = n_total // n_per_group if n_per_group else 1
         self.heavy_from = n_per_group if heavy_from is None else int(heavy_from)
-        # the class below "heavy" (boxes half as large): by default the stretch in front of the heavy columns that is
-        # three times as long -- exact for a pyramid whose every level has four times the boxes of the next one
-        if medium_from is None:
-            medium_from = max(0, self.heavy_from - 3 * (n_per_group - self.heavy_from)) if self.heavy_from < n_per_group else n_per_group
-        self.medium_from = min(int(medium_from), self.heavy_from)
 
 
 def heavy_from_boxes(boxes, frac=0.1):
     """First column from which the boxes are LARGE (bounding radius > ``frac`` of the extent of the set) -- the hint
-    ``heavy_from_col`` of the tile kernels (their tiles are cut into row sub-tiles); ``frac=0.05`` gives the
-    ``medium_from_col`` hint of the two-tier dense kernel.  Reads the device once: call it for anchor sets that are
-    cached (the FAM grid), and pass the value on for sets that share their layout (the ODM refinements of that grid).
-    Only meaningful when box size grows with the index (pyramid levels, small to large)."""
+    ``heavy_from_col`` of the tile kernels (their tiles are cut into row sub-tiles).  Reads the device once: call it
+    for anchor sets that are cached (the FAM grid), and pass the value on for sets that share their layout (the ODM
+    refinements of that grid).  Only meaningful when box size grows with the index (pyramid levels, small to large)."""
     b = boxes.reshape(-1, boxes.shape[-1])[:boxes.shape[-2]]
     if b.shape[0] == 0:
         return 0
@@ -58,7 +52,7 @@ def heavy_from_boxes(boxes, frac=0.1):
     return int((suffix_small > 0).sum().item())
 
 
-def prepare_boxes(boxes, cache=False, heavy_from=None, medium_from=None):
+def prepare_boxes(boxes, cache=False, heavy_from=None):
     """boxes (A, s>=5) or (G, A, s): -> PreparedBoxes.  ``cache=True`` keeps the result for this very tensor (same
     storage, same version counter) -- for anchors that do not change between steps -- and measures ``heavy_from``
     (one device read, once)."""
@@ -80,9 +74,7 @@ def prepare_boxes(boxes, cache=False, heavy_from=None, medium_from=None):
         _lib.check(rc, "rsdet_iou_prepare_f32")
     if heavy_from is None and cache and total:
         heavy_from = heavy_from_boxes(b)
-        if medium_from is None:
-            medium_from = heavy_from_boxes(b, 0.05)
-    prep = PreparedBoxes(buf, total, per, heavy_from, medium_from)
+    prep = PreparedBoxes(buf, total, per, heavy_from)
     if key is not None:
         import weakref
         if len(_prepared_cache) > 64:
@@ -225,7 +217,7 @@ def box_iou_rotated_fast(boxes1, boxes2, row_offsets=None, ks=None, max_rows=Non
         assert prepared1.n_total == n1 and prepared1.groups == 1
     rc = lib.rsdet_box_iou_rotated_fast_f32(_lib.ptr(b1), n1, b1.shape[-1], _lib.ptr(row_offsets), G, mr, tptr, nt,
                                             _lib.ptr(prepared1.buf) if prepared1 is not None else None,
-                                            _lib.ptr(prep.buf), A, per_group, prep.medium_from, prep.heavy_from, version,
+                                            _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,
                                             _lib.ptr(ious), _lib.stream_ptr())
     _lib.check(rc, "rsdet_box_iou_rotated_fast_f32")
     return ious

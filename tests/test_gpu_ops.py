@@ -1061,6 +1061,47 @@ def test_bn_act_channels_last_equals_nchw_form(cuda, dtype, shape, relu, with_re
     assert float((gb0 - gb1).abs().max()) <= tol * (float(gb0.abs().max()) + 1.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,with_res", [((2, 64, 24, 20), False), ((3, 256, 9, 7), True), ((2, 12, 5, 6), True),
+                                            ((1, 2048, 4, 4), True)])
+def test_bn_act_relu_bit_mask_equals_the_y_gate(cuda, monkeypatch, dtype, shape, with_res):
+    """Channels-last bn_act with a ReLU: the backward that reads the forward's one-bit-per-element gate gives the very
+    gradients of the backward that re-reads y (outputs of exactly 0 and of -0 included: both gate the gradient off);
+    shapes with no mask form (bf16, eight-channel kernels, odd pixel count: (3, 256, 9, 7)) quietly keep y."""
+    from rs_detection_amd.ops import bn_act as mod
+    from rs_detection_amd import _lib
+    torch.manual_seed(shape[1] + shape[2])
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C).to(cuda).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5), bn.running_var.uniform_(0.5, 2.0), bn.weight.normal_(1, 0.3), bn.bias.normal_(0, 0.3)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(shape, device=cuda).to(dtype)
+    r = torch.randn(shape, device=cuda).to(dtype) if with_res else None
+    if with_res:                       # some outputs exactly 0: bn(x) + r == 0 where r = -bn(x) (as stored)
+        with torch.no_grad():
+            r[:, :, 0, :] = -mod.bn_act(cl(x), bn, None, False)[:, :, 0, :]
+    go = cl(torch.randn(shape, device=cuda).to(dtype))
+    outs = []
+    for use_mask in (True, False):
+        monkeypatch.setattr(mod, "_RELU_MASK", use_mask)
+        xi = cl(x.clone()).requires_grad_(True)
+        ri = cl(r.clone()).requires_grad_(True) if with_res else None
+        bn.zero_grad()
+        y = mod.bn_act(xi, bn, ri, True)
+        saved = y.grad_fn.saved_tensors[1]
+        nb = _lib.load().rsdet_bn_act_relu_mask_bytes(shape[0], C, shape[2] * shape[3], int(dtype == torch.bfloat16))
+        assert (saved.dtype == torch.uint8 and saved.numel() == nb) if (use_mask and nb) else saved.dtype == dtype
+        y.backward(go)
+        outs.append((y.detach().clone(), xi.grad.clone(), ri.grad.clone() if with_res else None, bn.weight.grad.clone(),
+                     bn.bias.grad.clone()))
+    for a, b in zip(*outs):
+        if a is not None:
+            assert torch.equal(a, b)
+    if with_res:
+        assert bool((outs[0][0][:, :, 0, :] == 0).all()) and bool((outs[0][2][:, :, 0, :] == 0).all())
+
+
 @pytest.mark.parametrize("C,H,W", [(64, 20, 36), (4, 20, 36), (256, 9, 7), (2048, 3, 5), (1024, 4, 4)])
 @pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, True), (False, False)])
 def test_bn_act_bf16_channels_last_forms(cuda, C, H, W, relu, res):
