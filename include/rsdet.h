@@ -355,6 +355,18 @@ int rsdet_alignconv_mfma_supported(const rsdet_dcn_geom* g, int O);
 int rsdet_alignconv_mfma_f32_supported(const rsdet_dcn_geom* g, int O);
 int rsdet_alignconv_fwd_mfma_f32(const float* im_nhwc, const float* offset, const float* weight,
                                  const rsdet_dcn_geom* g, int O, int out_nhwc, float* out, float* colT, void* stream);
+
+/* 3x3 / stride 1 / padding 1 convolution of a channels-last bf16 map as an implicit GEMM on the matrix cores
+ * (csrc/conv3x3_mfma.hip): one workgroup per image row x 256 output channels, both operands by LDS-DMA, bf16 products,
+ * fp32 accumulation.  The library kernel behind the shared-weight tower convolutions of the S2ANet head
+ * (models/roi_heads/s2anet_head.py:127-186 of the reference builds them as ConvModule(256, 256, 3)); their
+ * backward-data is the same call on the flipped, transposed weights.
+ * x (B, H, W, C); weight (O, 3, 3, C) = the storage of a channels_last (O, C, 3, 3) tensor; out (B, H, W, O).
+ * Optional fused epilogue: bias (O fp32, NULL = none), relu, live (B*H*W bytes, NULL = all live): positions whose byte
+ * is 0 -- the gap pixels of the pyramid canvas -- are written as zeros.  C % 64 == 0, O % 32 == 0. */
+int rsdet_conv3x3_mfma_supported(int B, int H, int W, int C, int O);
+int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* weight, const float* bias, const uint8_t* live, int B,
+                                int H, int W, int C, int O, int relu, uint16_t* out, void* stream);
 int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, const uint16_t* weight,
                                   const rsdet_dcn_geom* g, int O, int out_nhwc, uint16_t* out, uint16_t* colT,
                                   void* stream);

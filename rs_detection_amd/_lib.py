@@ -177,6 +177,9 @@ SIGNATURES = {
     "rsdet_bn_act_backward_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                                 c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_size_t, c_void_p]),
+    "rsdet_conv3x3_mfma_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "rsdet_conv3x3_fwd_mfma_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                            c_int, c_void_p, c_void_p]),
     "rsdet_bn_act_relu_mask_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rsdet_bn_act_forward_nhwc_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
