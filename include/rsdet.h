@@ -362,7 +362,7 @@ int rsdet_alignconv_fwd_mfma_f32(const float* im_nhwc, const float* offset, cons
  * (models/roi_heads/s2anet_head.py:127-186 of the reference builds them as ConvModule(256, 256, 3)); their
  * backward-data is the same call on the flipped, transposed weights.
  * x (B, H, W, C); weight (O, 3, 3, C) = the storage of a channels_last (O, C, 3, 3) tensor; out (B, H, W, O).
- * Optional fused epilogue: bias (O fp32, NULL = none), relu, live (B*H*W bytes, NULL = all live): positions whose byte
+ * Optional fused epilogue: bias (O fp32, NULL = none), relu, live (H*W bytes shared by all images, NULL = all live): positions whose byte
  * is 0 -- the gap pixels of the pyramid canvas -- are written as zeros.  C % 64 == 0, O % 32 == 0. */
 int rsdet_conv3x3_mfma_supported(int B, int H, int W, int C, int O);
 int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* weight, const float* bias, const uint8_t* live, int B,

@@ -10,7 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from rs_detection_amd.ops.bn_act import bias_act
-from rs_detection_amd.ops.conv3x3 import conv3x3_applies, conv3x3_same, fast_conv
+from rs_detection_amd.ops.conv3x3 import (conv3x3_applies, conv3x3_same, fast_conv, conv3x3_mfma_applies,
+                                          conv3x3_bias_relu)
 from rs_detection_amd.utils.registry import BRICKS, build_from_cfg
 from .weight_init import kaiming_init, constant_init
 
@@ -109,6 +110,8 @@ class ConvModule(nn.Module):
         so that the next convolution of the tower sees each level's zero padding."""
         if self._fused_bias_relu(x, activate):
             conv = self.conv
+            if conv3x3_mfma_applies(x, conv):         # conv + bias + ReLU (+ gap mask) in one launch of our own kernel
+                return conv3x3_bias_relu(x, conv, None if canvas is None else canvas.live)
             if conv3x3_applies(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups):
                 y = conv3x3_same(x, conv.weight)      # backward-data through the forward solver (ops/conv3x3.py)
             else:

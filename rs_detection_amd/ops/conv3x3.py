@@ -64,6 +64,129 @@ class _Conv3x3Same(torch.autograd.Function):
         return gx, gw, gb
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# The head canvas in bf16: conv + bias + ReLU + gap mask as ONE launch of our own implicit-GEMM kernel
+# (csrc/conv3x3_mfma.hip), backward-data through the same kernel on the flipped weights.
+_MFMA = os.environ.get("RSDET_CONV3X3_MFMA", "1") == "1"      # A/B switch
+_MFMA_TM = 224                                                  # positions of one row a workgroup covers (C3_TM)
+
+
+def _mfma_conv(x, w_cl, bias, live, relu):
+    """x (B,C,H,W) bf16 channels_last, w_cl (O,C,3,3) bf16 channels_last -> (B,O,H,W) bf16 channels_last."""
+    from .. import _lib
+    B, C, H, W = x.shape
+    O = w_cl.shape[0]
+    y = torch.empty((B, O, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    rc = _lib.load().rsdet_conv3x3_fwd_mfma_bf16(_lib.ptr(x), _lib.ptr(w_cl), _lib.ptr(bias), _lib.ptr(live), B, H, W, C,
+                                                 O, int(relu), _lib.ptr(y), _lib.stream_ptr())
+    _lib.check(rc, "rsdet_conv3x3_fwd_mfma_bf16")
+    return y
+
+
+def _lib_supported(B, H, W, C, O):
+    from .. import _lib
+    return bool(_lib.load().rsdet_conv3x3_mfma_supported(B, H, W, C, O))
+
+
+def _bias_relu_backward(gy, y, need_b):
+    """gy * (y > 0) and its per-channel fp32 sum in one launch (csrc/bn_act.hip with mean 0 / variance 1)."""
+    from .. import _lib
+    from .bn_act import _UNIT
+    lib = _lib.load()
+    N, C, H, W = gy.shape
+    if not lib.rsdet_bn_act_nhwc_supported(C):        # a channel count the fused pass does not tile: two torch passes
+        gx = gy * (y > 0)
+        return gx, (gx.sum((0, 2, 3), dtype=torch.float32) if need_b else None)
+    gx = torch.empty_like(gy)
+    gb = torch.empty((C,), dtype=torch.float32, device=gy.device) if need_b else None
+    ws_bytes = lib.rsdet_bn_act_backward_nhwc_ws_size(N, C, H * W) if need_b else 0
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gy.device) if ws_bytes else None
+    key = (gy.device, C)
+    if key not in _UNIT:
+        _UNIT[key] = (torch.zeros(C, device=gy.device), torch.ones(C, device=gy.device))
+    mean, var = _UNIT[key]
+    rc = lib.rsdet_bn_act_backward_nhwc_bf16(_lib.ptr(gy), _lib.ptr(y), None, _lib.ptr(mean), _lib.ptr(var), None, 0.0, N,
+                                             C, H * W, 1, _lib.ptr(gx), None, None, _lib.ptr(gb), _lib.ptr(ws), ws_bytes,
+                                             _lib.stream_ptr())
+    _lib.check(rc, "rsdet_bn_act_backward_nhwc_bf16")
+    return gx, gb
+
+
+class _Conv3x3BiasReLU(torch.autograd.Function):
+    """relu(conv3x3(x, w) + bias) with the canvas gap pixels written as zeros -- one launch forward.  Backward: the ReLU
+    gate + bias gradient (one launch; the gate y > 0 also excludes the gap pixels), backward-data as the same kernel
+    on the flipped weights, the weight gradient from MIOpen.  Accumulation in fp32, bf16 products and one rounding of
+    the result, like MIOpen's bf16 solvers (identical values on the shapes of tests/test_gpu_ops.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, live):
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        xb = xb.contiguous(memory_format=torch.channels_last)
+        wb = (w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)).contiguous(memory_format=torch.channels_last)
+        bf = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        y = _mfma_conv(xb, wb, bf, live, True)
+        ctx.save_for_backward(xb, wb, y)
+        ctx.in_dtype, ctx.w_dtype = x.dtype, w.dtype
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb, y = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        need_b = ctx.bias_dtype is not None and ctx.needs_input_grad[2]
+        g, gb = _bias_relu_backward(gy, y, need_b)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wf = _flipped(wb)
+            B, O, H, W = g.shape
+            if _lib_supported(B, H, W, O, wf.shape[0]):
+                gx = _mfma_conv(g, wf, None, None, False)
+            else:                     # the transposed problem's channel counts do not tile (C_out % 64): MIOpen's solver
+                gx = F.conv2d(g, wf, None, 1, 1)
+            if gx.dtype != ctx.in_dtype:
+                gx = gx.to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(g, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+            if gw.dtype != ctx.w_dtype:
+                gw = gw.to(ctx.w_dtype)
+        if gb is not None and gb.dtype != ctx.bias_dtype:
+            gb = gb.to(ctx.bias_dtype)
+        return gx, gw, gb, None
+
+
+def conv3x3_mfma_applies(x, conv):
+    """Our kernel takes the layer: bf16 (or bf16 autocast) channels_last CUDA map, 3x3 / stride 1 / padding 1 / no groups,
+    channel counts its tiles divide, and a row length its 224-position tile wastes at most 15 % of (the 196-wide head
+    canvas of 1024^2 tiles: 12.5 %; a 128-wide level alone would idle 43 % of the MFMAs -- MIOpen keeps those)."""
+    if not (_MFMA and type(conv) is torch.nn.Conv2d and conv.padding_mode == 'zeros' and x.is_cuda and x.dim() == 4):
+        return False
+    w = conv.weight
+    if not (tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and x.shape[1] == w.shape[1]):
+        return False
+    if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and x.dtype == torch.float32
+                                          and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
+        return False
+    if x.is_contiguous() or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    tiles = (W + _MFMA_TM - 1) // _MFMA_TM
+    if tiles * _MFMA_TM > 1.15 * W:
+        return False
+    return _lib_supported(B, H, W, C, O)
+
+
+def conv3x3_bias_relu(x, conv, live=None):
+    """``relu(conv(x))`` for an ``nn.Conv2d`` that conv3x3_mfma_applies() accepted; ``live`` (uint8 per pixel of ONE
+    image, ops/pyramid.CanvasLayout.live) zeroes the canvas gap pixels of the output."""
+    return _Conv3x3BiasReLU.apply(x, conv.weight, conv.bias, live)
+
+
 def conv3x3_applies(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1):
     return (_ON and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] == weight.shape[1]
             and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1

@@ -384,3 +384,105 @@ def test_orconv_backward_data_through_the_forward_solver(cuda, monkeypatch):
         res.append((y.detach(), xa.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone()))
     for a, b in zip(*res):
         assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-6
+
+
+def _conv_truth(x, w, bias, live, relu=True):
+    """fp32 convolution of the bf16-valued operands (exact products, fp32 sums) + bias, ReLU, gap mask."""
+    y = torch.nn.functional.conv2d(x.float().contiguous(), w.float().contiguous(), bias, 1, 1)
+    if relu:
+        y = torch.relu(y)
+    if live is not None:
+        y = y * live.view(1, 1, *y.shape[2:]).float()
+    return y
+
+
+@pytest.mark.parametrize("B,C,O,H,W,masked", [(2, 256, 256, 9, 196, True), (1, 64, 32, 3, 224, False),
+                                              (1, 128, 256, 4, 230, True), (2, 64, 64, 1, 5, False),
+                                              (1, 192, 96, 5, 33, True)])
+def test_conv3x3_mfma_bias_relu_mask_forward_backward(cuda, B, C, O, H, W, masked):
+    """csrc/conv3x3_mfma.hip behind ops/conv3x3._Conv3x3BiasReLU: relu(conv + bias) with the gap pixels zeroed, in one
+    launch -- against the fp32 convolution of the same bf16 operands.  One bf16 rounding of an fp32 sum: within one bf16
+    step (2^-8 relative) of the rounded truth up to the summation order; the masked positions are exact zeros.  Ragged
+    rows (W not a multiple of the 224-position tile, a second tile of 6 positions, H = 1) exercise the halo and tail
+    logic; the gradients: the same three a Conv2d + ReLU pair gives, gate taken from the kernel's own output."""
+    from rs_detection_amd.ops import conv3x3 as c3
+    torch.manual_seed(B * 1000 + W)
+    x = torch.randn((B, C, H, W), device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((O, C, 3, 3), device=cuda) / (3 * C ** 0.5)).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    bias = torch.randn((O,), device=cuda) * 0.2
+    live = None
+    if masked:
+        live = (torch.rand((H * W,), device=cuda) > 0.2).to(torch.uint8)
+        x = (x * live.view(1, 1, H, W).to(x.dtype)).contiguous(memory_format=torch.channels_last)
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    y = c3._Conv3x3BiasReLU.apply(xa, wa, ba, live)
+    assert y.dtype == torch.bfloat16 and y.shape == (B, O, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    truth = _conv_truth(x, w, bias, live)
+    err = (y.detach().float() - truth).abs()
+    assert float((err - truth.abs() * 2.0 ** -7).max()) <= 1e-3 * float(truth.abs().max()), float(err.max())
+    if masked:
+        dead = (live == 0).view(1, 1, H, W).expand_as(y)
+        assert float(y.detach()[dead].abs().max()) == 0.0
+    g = torch.randn((B, O, H, W), device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    # reference gradients: fp32 autograd through conv2d with the ReLU gate of the kernel's own y (no gate flips at y~0)
+    xr, wr, br = x.float().contiguous().requires_grad_(True), w.float().contiguous().requires_grad_(True), \
+        bias.clone().requires_grad_(True)
+    pre = torch.nn.functional.conv2d(xr, wr, br, 1, 1)
+    pre.backward(g.float() * (y.float() > 0))
+    for name, a, b, tol in (("gx", xa.grad, xr.grad, 1e-2), ("gw", wa.grad, wr.grad, 1e-2), ("gb", ba.grad, br.grad, 2e-3)):
+        assert a.shape == b.shape, name
+        rel = float((a.float() - b).norm() / b.norm().clamp_min(1e-12))
+        assert rel <= tol, (name, rel)
+
+
+def test_convmodule_takes_the_mfma_kernel_on_the_head_canvas(cuda, monkeypatch):
+    """ConvModule(256, 256, 3) + ReLU on a 196-wide bf16 channels_last canvas (the 1024^2 tile's): the one-launch kernel
+    runs, and the tower it builds equals the MIOpen + canvas_bias_act sequence it replaces within bf16 round-off --
+    yardstick: both against the fp32 tower."""
+    from rs_detection_amd.models.utils.modules import ConvModule
+    from rs_detection_amd.ops import conv3x3 as c3
+    from rs_detection_amd.ops.pyramid import canvas_layout
+    lay = canvas_layout([(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], cuda)
+    assert lay.Wc == 196
+    torch.manual_seed(5)
+    tower = [ConvModule(256, 256, 3, stride=1, padding=1).to(cuda).to(memory_format=torch.channels_last)
+             for _ in range(2)]
+    x = (torch.randn((1, 256, lay.Hc, lay.Wc), device=cuda) * lay.live_f).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    calls = []
+    real = c3._mfma_conv
+    monkeypatch.setattr(c3, "_mfma_conv", lambda *a: (calls.append(1), real(*a))[1])
+
+    def run(on):
+        monkeypatch.setattr(c3, "_MFMA", on)
+        xa = x.clone().requires_grad_(True)
+        for m in tower:
+            m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            t = xa
+            for m in tower:
+                t = m(t, canvas=lay)
+        t.float().square().sum().backward()
+        return [t.detach().float(), xa.grad.float()] + [m.conv.weight.grad.float().clone() for m in tower] + \
+            [m.conv.bias.grad.float().clone() for m in tower]
+
+    ours = run(True)
+    assert len(calls) == 4                                   # 2 forward + 2 backward-data launches
+    theirs = run(False)
+    assert len(calls) == 4
+    xf = x.float().contiguous().requires_grad_(True)
+    t = xf
+    for m in tower:
+        m.zero_grad()
+        t = torch.relu(torch.nn.functional.conv2d(t, m.conv.weight.float().contiguous(), m.conv.bias, 1, 1)) * lay.live_f
+    t.square().sum().backward()
+    truth = [t.detach(), xf.grad] + [m.conv.weight.grad.float().clone() for m in tower] + \
+        [m.conv.bias.grad.float().clone() for m in tower]
+    gaps = (lay.live == 0).view(1, 1, lay.Hc, lay.Wc).expand_as(ours[0])
+    assert float(ours[0][gaps].abs().max()) == 0.0
+    for a, b, c in zip(ours, theirs, truth):
+        e_ours = float((a - c).norm() / c.norm())
+        e_theirs = float((b - c).norm() / c.norm())
+        assert e_ours <= 1.5 * e_theirs + 2e-3, (tuple(c.shape), e_ours, e_theirs)
