@@ -32,13 +32,13 @@ for (B, C, O, H, W) in [(4, 256, 256, 128, 196), (1, 64, 32, 5, 37), (2, 128, 96
     x = torch.randn(B, C, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(O, C, 3, 3, device=dev) * 0.05).bfloat16().contiguous(memory_format=torch.channels_last)
     bias = torch.randn(O, device=dev)
-    live = (torch.rand(B, H, W, device=dev) > 0.2).to(torch.uint8).contiguous()
+    live = (torch.rand(H, W, device=dev) > 0.2).to(torch.uint8).contiguous()       # one mask for all images
     ref = F.conv2d(x.float(), w.float(), None, 1, 1)
     got = ours(x, w)
     e0 = float((got.float() - ref).abs().max() / ref.abs().max())
     lib_y = F.conv2d(x, w, None, 1, 1)
     e_lib = float((lib_y.float() - ref).abs().max() / ref.abs().max())
-    ref2 = torch.relu(ref + bias[None, :, None, None]) * live[:, None].float()
+    ref2 = torch.relu(ref + bias[None, :, None, None]) * live[None, None].float()
     got2 = ours(x, w, bias, live, True)
     e1 = float((got2.float() - ref2).abs().max() / ref2.abs().max())
     assert got.is_contiguous(memory_format=torch.channels_last)
