@@ -584,7 +584,7 @@ int rsdet_nms_poly_sorted_f64(const double* polys_sorted, int n, double thr, uin
  * Replaces optims/optimizer.py:24-43 (grad_clip max_norm / norm_type 2, then SGD with weight decay and momentum) and,
  * for bf16 model weights, the per-parameter master <-> bf16 casts of the autocast route.
  *   tensors: n_tensors 64-byte device records { const void* grad; void* param; float* master; float* mom;
- *            long long n; int flags; pad } -- flags bit 0: grad is bf16, bit 1: param is bf16 (then master != NULL holds
+ *            long long n; int flags; pad; float* mom2; pad } -- flags bit 0: grad is bf16, bit 1: param is bf16 (then master != NULL holds
  *            the fp32 parameter; otherwise param is the fp32 parameter itself);
  *   chunks:  n_chunks device int pairs { tensor index, chunk index } covering every tensor in pieces of
  *            rsdet_mt_chunk_elems() elements;
@@ -596,6 +596,13 @@ int rsdet_mt_chunk_elems(void);
 size_t rsdet_mt_sgd_state_bytes(int n_chunks);
 int rsdet_mt_sgd_step(const void* tensors, const int* chunks, int n_chunks, float max_norm, float lr, float momentum,
                       float weight_decay, float* sqnorm_out, void* state, size_t state_bytes, void* stream);
+/* AdamW over the same records and chunks (optims/optimizer.py:24-43 with jittor.optim.AdamW, the optimizer of
+ * configs/orcnn/orcnn_van3_7_anchor.py): the record's 8 bytes after `flags; pad` hold `float* mom2` (exp_avg_sq), `mom`
+ * is exp_avg.  step = 1-based count of this update.  p *= 1 - lr * wd;  m += (g - m)(1 - beta1);
+ * v = v * beta2 + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps). */
+int rsdet_mt_adamw_step(const void* tensors, const int* chunks, int n_chunks, float max_norm, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, long long step, float* sqnorm_out, void* state,
+                        size_t state_bytes, void* stream);
 
 /* ---- the pyramid canvas of the S2ANet head (csrc/canvas.hip) ----------------------------------------------------------
  * The reference applies the head's shared-weight convolutions level by level

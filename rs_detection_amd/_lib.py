@@ -16,6 +16,7 @@ RSDET_ELAUNCH = -5
 c_void_p, c_int, c_float, c_size_t, c_ll = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                             ctypes.c_size_t, ctypes.c_longlong)
 
+c_double = ctypes.c_double
 
 class DcnGeom(ctypes.Structure):
     """struct rsdet_dcn_geom (include/rsdet.h)."""
@@ -107,6 +108,8 @@ SIGNATURES = {
                                            c_void_p]),
     "rsdet_mt_sgd_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
+    "rsdet_mt_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_double, c_double, c_double, c_double, c_double, c_ll,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_colsum_ws_size": (c_size_t, [c_ll, c_int]),
     "rsdet_colsum_f32": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_colsum_bf16": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

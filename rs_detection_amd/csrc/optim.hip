@@ -13,6 +13,7 @@
 //                         m = momentum * m + g;  p32 -= lr * m;  p_model = (bf16 | f32) p32
 // HBM-bound by construction: every gradient read twice, parameter / momentum read + written once.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
@@ -30,7 +31,8 @@ struct MtTensor {       // one per parameter, in device memory (64 bytes)
   float* mom;           // fp32 momentum buffer
   long long n;
   int flags, pad;
-  long long pad2[2];
+  float* mom2;          // AdamW: fp32 second-moment buffer (exp_avg_sq); unused by SGD
+  long long pad2;
 };
 static_assert(sizeof(MtTensor) == 64, "host packs 64-byte records");
 
@@ -134,6 +136,55 @@ __global__ __launch_bounds__(MT_NT) void mt_sgd_kernel(const MtTensor* __restric
   }
 }
 
+// AdamW (torch.optim.AdamW, amsgrad off), same chunks and records; `mom` = exp_avg, `mom2` = exp_avg_sq:
+//   p *= 1 - lr * wd;  m += (g - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g * g;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)          bc1 = 1 - beta1^t, bc2 = 1 - beta2^t (host, double)
+__global__ __launch_bounds__(MT_NT) void mt_adamw_kernel(const MtTensor* __restrict__ tensors,
+                                                         const int2* __restrict__ chunks, const float* __restrict__ sqnorm,
+                                                         float max_norm, float decay, float w1, float beta2, float w2,
+                                                         float eps, float step_size, float rsqrt_bc2) {
+  const int2 c = chunks[blockIdx.x];
+  const MtTensor t = tensors[c.x];
+  const long long i0 = (long long)c.y * MT_CHUNK, i1 = min(i0 + MT_CHUNK, t.n);
+  const bool gb = (t.flags & 1) != 0, pb = (t.flags & 2) != 0;
+  float coef = 1.0f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (sqrtf(sqnorm[0]) + 1e-6f), 1.0f);
+  float* p32 = t.master ? t.master : reinterpret_cast<float*>(t.param);
+  auto upd = [&](float p, float g, float& m, float& v) {
+    g *= coef;
+    p *= decay;
+    m = m + (g - m) * w1;
+    v = v * beta2 + (w2 * g) * g;
+    return p - step_size * (m / (sqrtf(v) * rsqrt_bc2 + eps));
+  };
+  const bool vec = ((uintptr_t)t.grad & (gb ? 7 : 15)) == 0 && ((uintptr_t)p32 & 15) == 0 && ((uintptr_t)t.mom & 15) == 0 &&
+                   ((uintptr_t)t.mom2 & 15) == 0 && (!pb || ((uintptr_t)t.param & 7) == 0);
+  long long iv = i0;
+  if (vec) {
+    const long long nv = (i1 - i0) & ~3LL;
+    for (long long i = i0 + 4 * threadIdx.x; i < i0 + nv; i += 4 * MT_NT) {
+      const float4 p = ld4(p32 + i);
+      float4 m = ld4(t.mom + i), v = ld4(t.mom2 + i);
+      const float4 g = gb ? ld4(reinterpret_cast<const bf16_t*>(t.grad) + i) : ld4(reinterpret_cast<const float*>(t.grad) + i);
+      const float4 pn = make_float4(upd(p.x, g.x, m.x, v.x), upd(p.y, g.y, m.y, v.y), upd(p.z, g.z, m.z, v.z),
+                                    upd(p.w, g.w, m.w, v.w));
+      st4(t.mom + i, m);
+      st4(t.mom2 + i, v);
+      st4(p32 + i, pn);
+      if (pb) st4(reinterpret_cast<bf16_t*>(t.param) + i, pn);
+    }
+    iv = i0 + nv;
+  }
+  for (long long i = iv + threadIdx.x; i < i1; i += MT_NT) {
+    float m = t.mom[i], v = t.mom2[i];
+    const float pn = upd(p32[i], mt_load(t.grad, i, gb), m, v);
+    t.mom[i] = m;
+    t.mom2[i] = v;
+    p32[i] = pn;
+    if (pb) reinterpret_cast<uint16_t*>(t.param)[i] = f2bf(pn);
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -161,5 +212,29 @@ extern "C" int rsdet_mt_sgd_step(const void* tensors, const int* chunks, int n_c
   }
   hipLaunchKernelGGL(mt_sgd_kernel, dim3(n_chunks), dim3(MT_NT), 0, s, (const MtTensor*)tensors, (const int2*)chunks,
                      sqnorm_out ? sqnorm_out : sqnorm, max_norm, lr, momentum, weight_decay);
+  return rsdet_launch_status();
+}
+
+// AdamW over the same records (`mom2` set) and chunks; `step` = this update's 1-based count (bias corrections).
+// (hyper-parameters as doubles: torch forms 1 - beta, 1 - lr * wd and the bias corrections in double before rounding)
+extern "C" int rsdet_mt_adamw_step(const void* tensors, const int* chunks, int n_chunks, float max_norm, double lr,
+                                   double beta1, double beta2, double eps, double weight_decay, long long step,
+                                   float* sqnorm_out, void* state, size_t state_bytes, void* stream) {
+  if (n_chunks < 0 || step < 1) return RSDET_EINVAL;
+  if (n_chunks == 0) return RSDET_OK;
+  if (!tensors || !chunks || !state || ((uintptr_t)state & 15) || state_bytes < rsdet_mt_sgd_state_bytes(n_chunks))
+    return RSDET_EINVAL;
+  unsigned* counter = (unsigned*)state;
+  float* sqnorm = (float*)((char*)state + 128);
+  float* partial = (float*)((char*)state + 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (max_norm > 0.f || sqnorm_out) {
+    hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(n_chunks), dim3(MT_NT), 0, s, (const MtTensor*)tensors,
+                       (const int2*)chunks, n_chunks, partial, counter, sqnorm_out ? sqnorm_out : sqnorm);
+  }
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(mt_adamw_kernel, dim3(n_chunks), dim3(MT_NT), 0, s, (const MtTensor*)tensors, (const int2*)chunks,
+                     sqnorm_out ? sqnorm_out : sqnorm, max_norm, (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
   return rsdet_launch_status();
 }

@@ -88,10 +88,13 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
                     self.state[p][k] = v.detach().to(device=p.device, dtype=torch.float32).clone()
         self._params_key = None          # the device table points at the old state tensors
 
+    _STATE_KEYS = ("momentum_buffer",)       # fp32 companions of a parameter, in record order (mom, mom2)
+
     def _ensure_state(self, p):
         st = self.state[p]
-        if "momentum_buffer" not in st:
-            st["momentum_buffer"] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+        for k in self._STATE_KEYS:
+            if k not in st:
+                st[k] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
         if p.dtype == torch.bfloat16 and "master" not in st:
             st["master"] = p.detach().float().clone()
         return st
@@ -144,13 +147,15 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         for i, p in enumerate(params):
             assert p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last), "dense parameters only"
             st = self._ensure_state(p)
-            for k in ("momentum_buffer", "master"):             # companions in the parameter's memory order
+            for k in self._STATE_KEYS + ("master",):            # companions in the parameter's memory order
                 t = st.get(k)
                 if t is not None and not self._same_order(t, p):
                     st[k] = torch.empty_strided(p.shape, p.stride(), dtype=torch.float32, device=dev).copy_(t)
             master = st.get("master")
             rec[i, 1:5] = (p.data_ptr(), master.data_ptr() if master is not None else 0,
-                           st["momentum_buffer"].data_ptr(), p.numel())
+                           st[self._STATE_KEYS[0]].data_ptr(), p.numel())
+            if len(self._STATE_KEYS) > 1:
+                rec[i, 6] = st[self._STATE_KEYS[1]].data_ptr()
             rec[i, 5] = 2 if p.dtype == torch.bfloat16 else 0    # low 32 bits = flags (little endian); grad bit per step
             chunks += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
         self._rec = rec
@@ -207,14 +212,49 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         clip = float(self.grad_clip.get("max_norm", 35)) if getattr(self, "grad_clip", None) else 0.0
         if clip > 0:
             assert float(self.grad_clip.get("norm_type", 2)) == 2.0, "FusedSGD clips the L2 norm"
-        tab = self._table
-        rc = lib.rsdet_mt_sgd_step(_lib.ptr(tab), ctypes_ptr_offset(tab, self._n_rec32 * 4), self._n_chunks, clip,
-                                   float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), None,
-                                   _lib.ptr(self._state_buf), self._state_buf.numel(), _lib.stream_ptr())
+        rc = self._launch(lib, _lib, g, clip)
         if rc != _lib.RSDET_OK:
             self._state_buf.zero_()
-        _lib.check(rc, "rsdet_mt_sgd_step")
+        _lib.check(rc, self._ENTRY)
         return None
+
+    _ENTRY = "rsdet_mt_sgd_step"
+
+    def _launch(self, lib, _lib, g, clip):
+        tab = self._table
+        return lib.rsdet_mt_sgd_step(_lib.ptr(tab), ctypes_ptr_offset(tab, self._n_rec32 * 4), self._n_chunks, clip,
+                                     float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), None,
+                                     _lib.ptr(self._state_buf), self._state_buf.numel(), _lib.stream_ptr())
+
+
+@OPTIMS.register_module()
+class FusedAdamW(FusedSGD):
+    """AdamW + global grad-norm clip as two launches over all parameters (csrc/optim.hip: mt_adamw_kernel) -- the
+    optimizer of configs/orcnn/orcnn_van3_7_anchor.py.  torch.optim.AdamW's arithmetic (amsgrad off): decoupled weight
+    decay, exp_avg / exp_avg_sq in fp32, bias corrections from the step count (kept in the parameter group: one count
+    for all parameters, as they are all updated every step).  Replaces ~130 foreach launches per step (2.9 ms on
+    VAN-B3) with 1-2; bf16 parameters get fp32 masters exactly as in FusedSGD."""
+
+    _STATE_KEYS = ("exp_avg", "exp_avg_sq")
+    _ENTRY = "rsdet_mt_adamw_step"
+
+    def __init__(self, params, lr, eps=1e-8, betas=(0.9, 0.999), weight_decay=0, grad_clip=None):
+        params = [p for p in params if p.requires_grad] if not isinstance(params, (list, tuple)) or \
+            (params and not isinstance(params[0], dict)) else params
+        torch.optim.Optimizer.__init__(self, params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
+                                                          step=0))
+        assert len(self.param_groups) == 1, "FusedAdamW: one parameter group"
+        self.grad_clip = grad_clip
+        self.lr = lr
+        self._params_key = None
+
+    def _launch(self, lib, _lib, g, clip):
+        g["step"] = int(g.get("step", 0)) + 1
+        tab = self._table
+        return lib.rsdet_mt_adamw_step(_lib.ptr(tab), ctypes_ptr_offset(tab, self._n_rec32 * 4), self._n_chunks, clip,
+                                       float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                       float(g["weight_decay"]), g["step"], None, _lib.ptr(self._state_buf),
+                                       self._state_buf.numel(), _lib.stream_ptr())
 
 
 def ctypes_ptr_offset(t, nbytes):

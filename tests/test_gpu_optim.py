@@ -167,3 +167,52 @@ def test_runner_fp32_fused_sgd_tracks_torch_sgd(cuda, monkeypatch):
     # relative distance of a single parameter large): two torch runs against each other
     noise = worst(out["torch"], out["torch again"])
     assert worst(out["torch"], out["fused"]) <= 3 * noise + 1e-4, (worst(out["torch"], out["fused"]), noise)
+
+
+@pytest.mark.parametrize("clip", [None, dict(max_norm=35, norm_type=2), dict(max_norm=0.5, norm_type=2)])
+def test_fused_adamw_equals_torch_adamw(cuda, clip):
+    """optims.FusedAdamW (csrc/optim.hip: mt_adamw_kernel) == clip_grad_norm_ + torch.optim.AdamW step for step: weights,
+    exp_avg, exp_avg_sq; a learning-rate change through param_groups; state survives state_dict / load_state_dict."""
+    from rs_detection_amd.optims.optimizer import AdamW, FusedAdamW
+    a, b = _params(cuda, 0, [torch.float32]), _params(cuda, 0, [torch.float32])
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, grad_clip=clip)
+    oa, ob = AdamW(a, **kw), FusedAdamW(b, **kw)
+    g = torch.Generator().manual_seed(1)
+
+    def one_step(step):
+        for pa, pb in zip(a, b):
+            gr = (torch.randn(pa.shape, generator=g) * (3.0 if step == 1 else 0.3)).to(cuda)
+            pa.grad = gr.clone().contiguous(memory_format=torch.channels_last) if pa.dim() == 4 and not pa.is_contiguous() else gr.clone()
+            pb.grad = pa.grad.clone()
+        oa.step(), ob.step()
+
+    for step in range(5):
+        if step == 2:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 2e-4
+        one_step(step)
+        for pa, pb in zip(a, b):
+            torch.testing.assert_close(pb, pa, rtol=3e-6, atol=3e-7)
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(ob.state[pb]["exp_avg"], oa.state[pa]["exp_avg"], rtol=3e-6, atol=1e-7)
+        torch.testing.assert_close(ob.state[pb]["exp_avg_sq"], oa.state[pa]["exp_avg_sq"], rtol=3e-6, atol=1e-9)
+    sd = ob.state_dict()
+    assert sd["param_groups"][0]["step"] == 5 and "exp_avg_sq" in sd["state"][0]
+    oc = FusedAdamW(b, **kw)
+    oc.load_state_dict(sd)
+    ob = oc                                     # continue with the reloaded optimizer: same trajectory as torch's
+    for step in range(5, 7):
+        one_step(step)
+    for pa, pb in zip(a, b):
+        torch.testing.assert_close(pb, pa, rtol=5e-6, atol=5e-7)
+
+
+def test_runner_builds_fused_adamw_for_the_orcnn_config(cuda):
+    import warnings
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.optims.optimizer import FusedAdamW
+    from rs_detection_amd.runner.runner import Runner
+    cfg = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = Runner(cfg, device=cuda)
+    assert isinstance(r.optimizer, FusedAdamW) and r.optimizer.param_groups[0]["weight_decay"] == 0.05
