@@ -108,8 +108,8 @@ def packaged_records_match():
     want = "%d_%d_%d_" % (v // 1000000, (v // 1000) % 1000, v % 1000)
     user = os.environ.get("MIOPEN_USER_DB_PATH")
     mine = os.environ.get("RSDET_MIOPEN_DB_IN_USE")      # set by use_packaged_miopen_db(), here or in a parent process
-    if user is None and mine is None:
-        mine = use_packaged_miopen_db()                  # not called yet in this process: do it now (idempotent)
+    if user is None:                                     # not called yet in this process (or the variable was dropped
+        mine = use_packaged_miopen_db()                  # since): do it now (idempotent)
         user = os.environ.get("MIOPEN_USER_DB_PATH")
     if user is None or mine is None or os.path.realpath(user) != os.path.realpath(mine):
         return False                                     # the copy failed, or the user points MIOpen elsewhere
