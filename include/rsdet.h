@@ -604,6 +604,31 @@ int rsdet_mt_adamw_step(const void* tensors, const int* chunks, int n_chunks, fl
                         double beta2, double eps, double weight_decay, long long step, float* sqnorm_out, void* state,
                         size_t state_bytes, void* stream);
 
+/* ---- the elementwise tails of a VAN block, fused (csrc/van_ops.hip; NCHW fp32) ------------------------------------------
+ * Replace, with the 1x1 convolutions run without their bias, the bias adds, GELU, gate product, shortcut and layer-scale
+ * passes of /root/reference/python/jdet/models/backbones/van.py:46-122 (Mlp, LKA / Attention, Block.execute) and their
+ * backward passes incl. the per-channel bias / scale reductions (deterministic two-stage sums).  Maps are (N, C, HW)
+ * contiguous; bias / shortcut may be NULL; gbias / gscale NULL = not wanted; ws: rsdet_van_ws_size(N, C, HW) bytes.
+ *   bias_gelu  y = GELU(x + b[c]) (erf form)         bwd: gx = gy * GELU'(x + b), gbias = sum gx
+ *   gate       y = u * (a + b[c])                    bwd: gu = g * (a + b), ga = g * u, gbias = sum ga
+ *   residual   y = x + scale[c] * (p + b[c] + shortcut)
+ *              bwd: gp = scale * g (= the shortcut's gradient), gbias = scale * sum g, gscale = sum g * (p + b + shortcut);
+ *              the gradient of x is g itself. */
+int rsdet_van_supported(int N, int C, int HW);
+size_t rsdet_van_ws_size(int N, int C, int HW);
+int rsdet_van_bias_gelu_fwd_f32(const float* x, const float* bias, int N, int C, int HW, float* y, void* stream);
+int rsdet_van_bias_gelu_bwd_f32(const float* gy, const float* x, const float* bias, int N, int C, int HW, float* gx,
+                                float* gbias, void* ws, size_t ws_bytes, void* stream);
+int rsdet_van_gate_fwd_f32(const float* u, const float* a, const float* bias, int N, int C, int HW, float* y,
+                           void* stream);
+int rsdet_van_gate_bwd_f32(const float* g, const float* u, const float* a, const float* bias, int N, int C, int HW,
+                           float* gu, float* ga, float* gbias, void* ws, size_t ws_bytes, void* stream);
+int rsdet_van_residual_fwd_f32(const float* x, const float* p, const float* bias, const float* shortcut,
+                               const float* scale, int N, int C, int HW, float* y, void* stream);
+int rsdet_van_residual_bwd_f32(const float* g, const float* p, const float* bias, const float* shortcut,
+                               const float* scale, int N, int C, int HW, float* gp, float* gbias, float* gscale, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* ---- the pyramid canvas of the S2ANet head (csrc/canvas.hip) ----------------------------------------------------------
  * The reference applies the head's shared-weight convolutions level by level
  * (/root/reference/python/jdet/models/roi_heads/s2anet_head.py:207-255).  These entry points lay the L <= 8 level maps of

@@ -110,6 +110,18 @@ SIGNATURES = {
                                   c_size_t, c_void_p]),
     "rsdet_mt_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_double, c_double, c_double, c_double, c_double, c_ll,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_van_supported": (c_int, [c_int, c_int, c_int]),
+    "rsdet_van_ws_size": (c_size_t, [c_int, c_int, c_int]),
+    "rsdet_van_bias_gelu_fwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_van_bias_gelu_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
+    "rsdet_van_gate_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_van_gate_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_van_residual_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_void_p, c_void_p]),
+    "rsdet_van_residual_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_colsum_ws_size": (c_size_t, [c_ll, c_int]),
     "rsdet_colsum_f32": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_colsum_bf16": (c_int, [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -7,6 +7,7 @@ grouped rotated IoU + assignment, two launches + two passes for all images."""
 import torch
 
 from rs_detection_amd import ops
+from rs_detection_amd.utils.consts import const_tensor
 from rs_detection_amd.utils.registry import BOXES, build_from_cfg
 
 
@@ -56,7 +57,7 @@ class MaxIoUAssigner:
         if overlaps.numel() == 0:
             raise ValueError('No gt or proposals')
         K = overlaps.size(0)
-        ro = torch.tensor([0, K], dtype=torch.int32, device=overlaps.device)
+        ro = const_tensor([0, K], dtype=torch.int32, device=overlaps.device)
         gi, mo, lb = ops.assign_wrt_overlaps(overlaps, ro, K, self.pos_iou_thr, self._neg(), self.min_pos_iou,
                                              self.match_low_quality, self.gt_max_assign_all, gt_labels,
                                              self.assigned_labels_filled)
@@ -75,7 +76,7 @@ class MaxIoUAssigner:
             B = row_offsets.numel() - 1
             rows = torch.arange(ov.shape[0], device=ov.device)
             grp = torch.bucketize(rows, row_offsets[1:].long(), right=True).clamp(max=B - 1)
-            ov = torch.where(valid[grp], ov, ov.new_tensor(-1.0))
+            ov = torch.where(valid[grp], ov, -1.0)
         return ops.assign_wrt_overlaps(ov, row_offsets, max_k, self.pos_iou_thr, self._neg(), self.min_pos_iou,
                                        self.match_low_quality, self.gt_max_assign_all, gt_labels_cat,
                                        self.assigned_labels_filled)

@@ -3,6 +3,7 @@ The arithmetic lives in csrc/box_coder.hip; these are the reference-named entry 
 import numpy as np
 import torch
 
+from rs_detection_amd.utils.consts import const_tensor
 from rs_detection_amd.ops.box_coder import (bbox2delta_rotated, delta2bbox_rotated, rotated_box_to_poly)  # noqa: F401
 
 
@@ -22,7 +23,7 @@ def loc2bbox(src_bbox, loc, mean=(0., 0., 0., 0.), std=(1., 1., 1., 1.)):
     """box_ops.py:5-34: (x0,y0,x1,y1) anchors + (dx,dy,dw,dh) -> (x0,y0,x1,y1)."""
     if src_bbox.shape[0] == 0:
         return loc.new_zeros((0, 4))
-    loc = loc * loc.new_tensor(std) + loc.new_tensor(mean)
+    loc = loc * const_tensor(std, loc) + const_tensor(mean, loc)
     sw = src_bbox[:, 2:3] - src_bbox[:, 0:1]
     sh = src_bbox[:, 3:4] - src_bbox[:, 1:2]
     cx = loc[:, 0:1] * sw + src_bbox[:, 0:1] + 0.5 * sw
@@ -35,7 +36,7 @@ def loc2bbox_r(src_bbox, loc, mean=(0., 0., 0., 0., 0.), std=(1., 1., 1., 1., 1.
     """box_ops.py:36-64: (cx,cy,w,h,a) + (dx,dy,dw,dh,da) -> (cx,cy,w,h,a)."""
     if src_bbox.shape[0] == 0:
         return loc.new_zeros((0, 4))  # (sic) the reference returns 4 columns here
-    loc = loc * loc.new_tensor(std) + loc.new_tensor(mean)
+    loc = loc * const_tensor(std, loc) + const_tensor(mean, loc)
     sw, sh = src_bbox[:, 2:3], src_bbox[:, 3:4]
     cx = loc[:, 0:1] * sw + src_bbox[:, 0:1]
     cy = loc[:, 1:2] * sh + src_bbox[:, 1:2]
@@ -53,7 +54,7 @@ def bbox2loc_r(src_bbox, dst_bbox, mean=(0., 0., 0., 0., 0.), std=(1., 1., 1., 1
     dh = torch.log(dst_bbox[:, 3:4] / (h + 1) + 1e-5)
     da = dst_bbox[:, 4:5] - src_bbox[:, 4:5]
     loc = torch.cat([dx, dy, dw, dh, da], dim=1)
-    return (loc - loc.new_tensor(mean)) / loc.new_tensor(std)
+    return (loc - const_tensor(mean, loc)) / const_tensor(std, loc)
 
 
 def bbox2loc(src_bbox, dst_bbox, mean=(0., 0., 0., 0.), std=(1., 1., 1., 1.)):
@@ -66,7 +67,7 @@ def bbox2loc(src_bbox, dst_bbox, mean=(0., 0., 0., 0.), std=(1., 1., 1., 1.)):
     bcx, bcy = dst_bbox[:, 0:1] + 0.5 * bw, dst_bbox[:, 1:2] + 0.5 * bh
     h, w = torch.clamp(h, min=1e-5), torch.clamp(w, min=1e-5)
     loc = torch.cat([(bcx - cx) / w, (bcy - cy) / h, _safe_log(bw / w), _safe_log(bh / h)], dim=1)
-    return (loc - loc.new_tensor(mean)) / loc.new_tensor(std)
+    return (loc - const_tensor(mean, loc)) / const_tensor(std, loc)
 
 
 def bbox_iou(bbox_a, bbox_b):

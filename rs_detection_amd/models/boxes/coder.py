@@ -1,5 +1,6 @@
 """DeltaXYWHABBoxCoder (/root/reference/python/jdet/models/boxes/coder.py:76-141)."""
 from rs_detection_amd.ops.box_coder import bbox2delta_rotated, delta2bbox_rotated
+from rs_detection_amd.utils.consts import const_tensor
 from rs_detection_amd.utils.registry import BOXES
 
 
@@ -44,18 +45,18 @@ class MidpointOffsetCoder:
         x_coor, y_coor = poly[:, 0::2], poly[:, 1::2]
         y_min = y_coor.min(dim=1, keepdim=True)[0]
         x_max = x_coor.max(dim=1, keepdim=True)[0]
-        ga = torch.where((y_coor - y_min).abs() > 0.1, x_coor.new_tensor(-1000.), x_coor).max(1)[0]
-        gb = torch.where((x_coor - x_max).abs() > 0.1, y_coor.new_tensor(-1000.), y_coor).max(1)[0]
+        ga = torch.where((y_coor - y_min).abs() > 0.1, -1000., x_coor).max(1)[0]
+        gb = torch.where((x_coor - x_max).abs() > 0.1, -1000., y_coor).max(1)[0]
         deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph),
                               (ga - gx) / gw, (gb - gy) / gh], dim=-1)
-        means = deltas.new_tensor(self.means).unsqueeze(0)
-        stds = deltas.new_tensor(self.stds).unsqueeze(0)
+        means = const_tensor(self.means, deltas).unsqueeze(0)
+        stds = const_tensor(self.stds, deltas).unsqueeze(0)
         return (deltas - means) / stds
 
     def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
         assert pred_bboxes.size(0) == bboxes.size(0)
         rep = pred_bboxes.size(1) // 6
-        d = pred_bboxes * pred_bboxes.new_tensor(self.stds).repeat(rep) + pred_bboxes.new_tensor(self.means).repeat(rep)
+        d = pred_bboxes * const_tensor(self.stds, pred_bboxes).repeat(rep) + const_tensor(self.means, pred_bboxes).repeat(rep)
         dx, dy, dw, dh, da, db = (d[:, k::6] for k in range(6))
         max_ratio = float(np.abs(np.log(wh_ratio_clip)))
         dw, dh = dw.clamp(-max_ratio, max_ratio), dh.clamp(-max_ratio, max_ratio)
@@ -95,12 +96,12 @@ class OrientedDeltaXYWHTCoder:
         dx = (c * (gx - px) + s * (gy - py)) / pw
         dy = (-s * (gx - px) + c * (gy - py)) / ph
         deltas = torch.stack([dx, dy, torch.log(gw_r / pw), torch.log(gh_r / ph), dtheta], dim=-1)
-        return (deltas - deltas.new_tensor(self.means).unsqueeze(0)) / deltas.new_tensor(self.stds).unsqueeze(0)
+        return (deltas - const_tensor(self.means, deltas).unsqueeze(0)) / const_tensor(self.stds, deltas).unsqueeze(0)
 
     def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
         assert pred_bboxes.size(0) == bboxes.size(0)
         rep = pred_bboxes.size(1) // 5
-        d = pred_bboxes * pred_bboxes.new_tensor(self.stds).repeat(rep) + pred_bboxes.new_tensor(self.means).repeat(rep)
+        d = pred_bboxes * const_tensor(self.stds, pred_bboxes).repeat(rep) + const_tensor(self.means, pred_bboxes).repeat(rep)
         dx, dy, dw, dh, dt = (d[:, k::5] for k in range(5))
         max_ratio = float(np.abs(np.log(wh_ratio_clip)))
         dw, dh = dw.clamp(-max_ratio, max_ratio), dh.clamp(-max_ratio, max_ratio)

@@ -54,7 +54,7 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
         wh = (rb - lt).clamp(min=0)
         ov = wh[..., 0] * wh[..., 1]
         union = a1[:, None] + a2[None, :] - ov if mode == 'iou' else a1[:, None].expand_as(ov)
-    return ov / torch.max(union, union.new_tensor(eps))
+    return ov / union.clamp_min(eps)
 
 
 @BOXES.register_module()

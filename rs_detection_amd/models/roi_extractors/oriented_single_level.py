@@ -67,7 +67,7 @@ class OrientedSingleRoIExtractor(nn.Module):
         for i in range(num_levels):
             on = (target_lvls == i)
             r = rois.clone()
-            r[:, 1:3] = torch.where(on[:, None], rois[:, 1:3], rois.new_tensor(-1e8))
-            r[:, 3:5] = torch.where(on[:, None], rois[:, 3:5], rois.new_tensor(1.0))
+            r[:, 1:3] = torch.where(on[:, None], rois[:, 1:3], -1e8)
+            r[:, 3:5] = torch.where(on[:, None], rois[:, 3:5], 1.0)
             roi_feats = roi_feats + self.roi_layers[i](feats[i], r)
         return roi_feats

@@ -1089,9 +1089,10 @@ def test_bn_act_relu_bit_mask_equals_the_y_gate(cuda, monkeypatch, dtype, shape,
         ri = cl(r.clone()).requires_grad_(True) if with_res else None
         bn.zero_grad()
         y = mod.bn_act(xi, bn, ri, True)
-        saved = y.grad_fn.saved_tensors[1]
-        nb = _lib.load().rsdet_bn_act_relu_mask_bytes(shape[0], C, shape[2] * shape[3], int(dtype == torch.bfloat16))
-        assert (saved.dtype == torch.uint8 and saved.numel() == nb) if (use_mask and nb) else saved.dtype == dtype
+        if "BNAct" in type(y.grad_fn).__name__:        # (a channel count the NHWC kernels do not tile -- 12 -- runs torch)
+            saved = y.grad_fn.saved_tensors[1]
+            nb = _lib.load().rsdet_bn_act_relu_mask_bytes(shape[0], C, shape[2] * shape[3], int(dtype == torch.bfloat16))
+            assert (saved.dtype == torch.uint8 and saved.numel() == nb) if (use_mask and nb) else saved.dtype == dtype
         y.backward(go)
         outs.append((y.detach().clone(), xi.grad.clone(), ri.grad.clone() if with_res else None, bn.weight.grad.clone(),
                      bn.bias.grad.clone()))

@@ -1,0 +1,113 @@
+"""GPU: the fused elementwise tails of the VAN block (csrc/van_ops.hip, ops/van_fused.py) against the torch expressions
+they replace (the reference's Mlp / LKA / Attention / Block, /root/reference/python/jdet/models/backbones/van.py:46-122)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 64, 32, 48), (1, 320, 8, 8), (3, 10, 5, 7), (2, 512, 3, 2), (1, 4, 129, 130)]
+
+
+def _close(a, b, tol=2e-6):
+    scale = float(b.abs().max()) + 1e-12
+    assert a.shape == b.shape and float((a - b).abs().max()) <= tol * scale + 1e-7, float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_bias_gelu(cuda, shape, with_bias):
+    from rs_detection_amd.ops import van_fused
+    torch.manual_seed(shape[1])
+    x = (torch.randn(shape, device=cuda) * 2).requires_grad_(True)
+    b = torch.randn(shape[1], device=cuda).requires_grad_(True) if with_bias else None
+    g = torch.randn(shape, device=cuda)
+    assert van_fused.applies(x)
+    y = van_fused.bias_gelu(x, b)
+    y.backward(g)
+    x2 = x.detach().clone().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True) if with_bias else None
+    y2 = F.gelu(x2 + b2[None, :, None, None] if with_bias else x2)
+    y2.backward(g)
+    _close(y.detach(), y2.detach()), _close(x.grad, x2.grad)
+    if with_bias:
+        _close(b.grad, b2.grad, 2e-5)            # a sum of N*H*W terms in another order
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gate(cuda, shape):
+    from rs_detection_amd.ops import van_fused
+    torch.manual_seed(shape[2])
+    u, a = torch.randn(shape, device=cuda).requires_grad_(True), torch.randn(shape, device=cuda).requires_grad_(True)
+    b = torch.randn(shape[1], device=cuda).requires_grad_(True)
+    g = torch.randn(shape, device=cuda)
+    y = van_fused.gate(u, a, b)
+    y.backward(g)
+    u2, a2, b2 = (t.detach().clone().requires_grad_(True) for t in (u, a, b))
+    y2 = u2 * (a2 + b2[None, :, None, None])
+    y2.backward(g)
+    _close(y.detach(), y2.detach()), _close(u.grad, u2.grad), _close(a.grad, a2.grad), _close(b.grad, b2.grad, 2e-5)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("with_shortcut,with_bias", [(True, True), (False, True), (False, False)])
+def test_residual(cuda, shape, with_shortcut, with_bias):
+    """x + ls * (p + b + shortcut): values, and the five gradients -- x's is the incoming gradient itself, the shortcut's
+    and p's are the same ls * g, the bias' and the layer scale's are per-channel sums."""
+    from rs_detection_amd.ops import van_fused
+    torch.manual_seed(shape[3])
+    C = shape[1]
+    x, p = torch.randn(shape, device=cuda).requires_grad_(True), torch.randn(shape, device=cuda).requires_grad_(True)
+    sc = torch.randn(shape, device=cuda).requires_grad_(True) if with_shortcut else None
+    b = torch.randn(C, device=cuda).requires_grad_(True) if with_bias else None
+    ls = (0.01 + torch.rand(C, device=cuda)).requires_grad_(True)
+    g = torch.randn(shape, device=cuda)
+    y = van_fused.residual(x, p, b, sc, ls)
+    y.backward(g)
+    x2, p2, ls2 = (t.detach().clone().requires_grad_(True) for t in (x, p, ls))
+    sc2 = sc.detach().clone().requires_grad_(True) if with_shortcut else None
+    b2 = b.detach().clone().requires_grad_(True) if with_bias else None
+    f = p2
+    if with_bias:
+        f = f + b2[None, :, None, None]
+    if with_shortcut:
+        f = f + sc2
+    y2 = x2 + ls2[None, :, None, None] * f
+    y2.backward(g)
+    _close(y.detach(), y2.detach()), _close(x.grad, x2.grad, 0.0), _close(p.grad, p2.grad), _close(ls.grad, ls2.grad, 2e-5)
+    if with_shortcut:
+        _close(sc.grad, sc2.grad)
+    if with_bias:
+        _close(b.grad, b2.grad, 2e-5)
+
+
+def test_van_block_fused_equals_unfused(cuda, monkeypatch):
+    """A whole Block (and a two-block stage, so that gradients shared between the fused passes accumulate): the fused
+    tails against RSDET_VAN_FUSED=0 -- outputs, input gradient, every parameter gradient."""
+    from rs_detection_amd.models.backbones.van import Block
+    from rs_detection_amd.ops import van_fused
+    torch.manual_seed(3)
+    blocks = torch.nn.Sequential(Block(64, mlp_ratio=8), Block(64, mlp_ratio=8)).to(cuda).train()
+    with torch.no_grad():
+        for blk in blocks:
+            blk.layer_scale_1.uniform_(0.2, 1.0), blk.layer_scale_2.uniform_(0.2, 1.0)
+            for m in blk.modules():
+                if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
+                    m.bias.normal_(0, 0.2)
+    x = torch.randn((2, 64, 24, 40), device=cuda)
+    g = torch.randn_like(x)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(van_fused, "_ON", on)
+        xi = x.clone().requires_grad_(True)
+        blocks.zero_grad()
+        for blk in blocks:                      # same batch statistics both times: BatchNorm in training mode is stateful
+            blk.norm1.momentum = blk.norm2.momentum = 0.0
+        y = blocks(xi)
+        if on:
+            assert "_Residual" in type(y.grad_fn).__name__
+        y.backward(g)
+        outs.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in blocks.parameters()])
+    names = ["y", "gx"] + [n for n, _ in blocks.named_parameters()]
+    for n, a, b in zip(names, *outs):
+        assert float((a - b).abs().max()) <= 2e-4 * (float(b.abs().max()) + 1e-6), n
