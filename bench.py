@@ -224,6 +224,25 @@ def kernel_rooflines(device, targets):
         out["alignconv_fwd_mfma_kernel<%s>(implicit GEMM, level 0, no columns in HBM)" % name] = dict(
             bound="mfma", achieved=fl / t / 1e12, peak=peak, unit="TFLOP/s", frac=fl / t / 1e12 / peak, us=t * 1e6,
             hbm_alg_bytes=by_f, traffic=pmc_traffic("alignconv_mfma_" + name, (B, C, H) == (4, 256, 128)))
+    # the bf16 3x3 implicit GEMM of the head's tower convolutions on the pyramid canvas of this tile size
+    # (csrc/conv3x3_mfma.hip): plain, and with bias + ReLU + gap mask in the epilogue (what the step launches)
+    from rs_detection_amd.ops.pyramid import canvas_layout
+    lay = canvas_layout([(TILE // s_, TILE // s_) for s_ in (8, 16, 32, 64, 128)], device)
+    xc = torch.randn(B, C, lay.Hc, lay.Wc, device=device).bfloat16().contiguous(memory_format=torch.channels_last)
+    wc = (torch.randn(O_, C, 3, 3, device=device) * 0.05).bfloat16().contiguous(memory_format=torch.channels_last)
+    bc = torch.randn(O_, device=device)
+    oc = torch.empty((B, O_, lay.Hc, lay.Wc), dtype=torch.bfloat16, device=device, memory_format=torch.channels_last)
+    if lib_.rsdet_conv3x3_mfma_supported(B, lay.Hc, lay.Wc, C, O_):
+        flc = 2.0 * B * lay.Hc * lay.Wc * O_ * 9 * C
+        byc = 2 * (B * lay.Hc * lay.Wc * (C + O_) + 9 * C * O_)
+        for tag, args in (("plain", (None, None, 0)), ("bias+ReLU+gap mask fused", (_L.ptr(bc), _L.ptr(lay.live), 1))):
+            t = event_time(lambda: lib_.rsdet_conv3x3_fwd_mfma_bf16(_L.ptr(xc), _L.ptr(wc), args[0], args[1], B, lay.Hc,
+                                                                    lay.Wc, C, O_, args[2], _L.ptr(oc), _L.stream_ptr()),
+                           10, 2)
+            out["conv3x3_fwd_mfma_bf16_kernel(head canvas %dx%dx%dx%d, %s)" % (B, lay.Hc, lay.Wc, C, tag)] = dict(
+                bound="mfma", achieved=flc / t / 1e12, peak=2500.0, unit="TFLOP/s", frac=flc / t / 1e12 / 2500.0,
+                us=t * 1e6, hbm_alg_bytes=byc, traffic=pmc_traffic("conv3x3_mfma bf16 (head canvas 4x128x196x256)", (B, C, lay.Wc) == (4, 256, 196)))
+    del xc, wc, oc
     # (the reference-layout col2im -- one lane per column row, 13.2 ms here -- is kept for API parity only; the step
     #  uses the channels-last pair below, so it is not timed: it would dominate the rocprof summary of this command)
     xn = x.permute(0, 2, 3, 1).contiguous()

@@ -193,3 +193,46 @@ ALG3["ori_maxpool8x4_kernel<float, false>"] = dict(call="ori_maxpool f32", bytes
 ALG.update(ALG3)
 json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
 torch.cuda.synchronize(); print("done (round 3 additions)")
+
+# ---- round 4: the bf16 3x3 implicit GEMM of the head canvas (csrc/conv3x3_mfma.hip), plain and with the fused epilogue;
+# the VAN elementwise tails (csrc/van_ops.hip) at a stage-1 and a stage-3 map; the AdamW step over 60 M parameters
+Bc, Cc, Hc_, Wc_ = 4, 256, 128, 196
+xq = torch.randn(Bc, Cc, Hc_, Wc_, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+wq = (torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05).bfloat16().contiguous(memory_format=torch.channels_last)
+bq = torch.randn(Cc, device=dev)
+lq = (torch.rand(Hc_ * Wc_, device=dev) > 0.14).to(torch.uint8)
+oq = torch.empty((Bc, Cc, Hc_, Wc_), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+for _ in range(4):
+    _lib_.rsdet_conv3x3_fwd_mfma_bf16(_L.ptr(xq), _L.ptr(wq), None, None, Bc, Hc_, Wc_, Cc, Cc, 0, _L.ptr(oq), _L.stream_ptr())
+    _lib_.rsdet_conv3x3_fwd_mfma_bf16(_L.ptr(xq), _L.ptr(wq), _L.ptr(bq), _L.ptr(lq), Bc, Hc_, Wc_, Cc, Cc, 1, _L.ptr(oq), _L.stream_ptr())
+    torch.nn.functional.conv2d(xq, wq, None, 1, 1)          # the MIOpen / CK kernel beside it in the same trace
+ALG4 = {"conv3x3_fwd_mfma_bf16_kernel": dict(call="conv3x3_mfma bf16 (head canvas 4x128x196x256)",
+                                             bytes=2 * (2 * Bc * Hc_ * Wc_ * Cc + 9 * Cc * Cc),
+                                             flops=2.0 * Bc * Hc_ * Wc_ * Cc * 9 * Cc)}
+del xq, oq
+from rs_detection_amd.ops import van_fused
+for shp in ((2, 64, 256, 256), (2, 320, 64, 64)):
+    t1, t2, t3 = (torch.randn(shp, device=dev, requires_grad=True) for _ in range(3))
+    cb, cs = torch.randn(shp[1], device=dev, requires_grad=True), torch.rand(shp[1], device=dev, requires_grad=True)
+    for _ in range(3):
+        van_fused.bias_gelu(t1, cb).sum().backward()
+        van_fused.gate(t1, t2, cb).sum().backward()
+        van_fused.residual(t1, t2, cb, t3, cs).sum().backward()
+n_el = 2 * 64 * 256 * 256 + 2 * 320 * 64 * 64
+ALG4["van_bias_gelu_fwd_kernel"] = dict(call="van bias_gelu fwd", bytes=4 * 2 * n_el // 2)
+ALG4["van_bias_gelu_bwd_kernel"] = dict(call="van bias_gelu bwd", bytes=4 * 3 * n_el // 2)
+ALG4["van_gate_fwd_kernel"] = dict(call="van gate fwd", bytes=4 * 3 * n_el // 2)
+ALG4["van_gate_bwd_kernel"] = dict(call="van gate bwd", bytes=4 * 5 * n_el // 2)
+ALG4["van_residual_fwd_kernel"] = dict(call="van residual fwd", bytes=4 * 4 * n_el // 2)
+ALG4["van_residual_bwd_kernel"] = dict(call="van residual bwd", bytes=4 * 4 * n_el // 2)
+from rs_detection_amd.optims.optimizer import FusedAdamW
+pp = [torch.nn.Parameter(torch.randn(15_000_000, device=dev)) for _ in range(4)]
+opt = FusedAdamW(pp, lr=1e-4, weight_decay=0.05, grad_clip=dict(max_norm=35, norm_type=2))
+for _ in range(3):
+    for p_ in pp:
+        p_.grad = torch.randn_like(p_)
+    opt.step()
+ALG4["mt_adamw_kernel"] = dict(call="FusedAdamW update, 60 M parameters (the norm launch is the SGD row's)", bytes=4 * 60_000_000 * (4 + 3))
+ALG.update(ALG4)
+json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
+torch.cuda.synchronize(); print("done (round 4 additions)")
