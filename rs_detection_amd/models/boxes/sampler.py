@@ -1,5 +1,20 @@
-"""PseudoSampler / SamplingResult (/root/reference/python/jdet/models/boxes/sampler.py:6-36,114-130)."""
+"""PseudoSampler / SamplingResult (/root/reference/python/jdet/models/boxes/sampler.py:6-36,114-130).
+
+Index sets are data-dependent in size, so their SIZES have to come to the host -- once per ``sample`` call: the two
+counts travel together (one synchronisation), the index lists themselves are then built with ``nonzero_static`` (size
+known, no synchronisation).  The reference's ``nonzero`` + ``unique`` pairs are four synchronisations per call; with two
+images and two samplers per Oriented R-CNN step that is what kept the Python thread waiting on the device."""
 import torch
+
+
+def _pos_neg_indices(gt_inds):
+    """Ascending int64 indices of ``gt_inds > 0`` and of ``gt_inds == 0`` -- what ``nonzero(...).squeeze(-1).unique()``
+    gives for each (nonzero's output is already sorted and duplicate-free) -- with ONE device synchronisation."""
+    pos, neg = gt_inds > 0, gt_inds == 0
+    if not gt_inds.is_cuda:
+        return torch.nonzero(pos).squeeze(-1), torch.nonzero(neg).squeeze(-1)
+    npos, nneg = torch.stack([pos.sum(), neg.sum()]).tolist()
+    return (torch.nonzero_static(pos, size=int(npos)).squeeze(-1), torch.nonzero_static(neg, size=int(nneg)).squeeze(-1))
 
 from rs_detection_amd.utils.registry import BOXES
 
@@ -31,16 +46,15 @@ class PseudoSampler:
         pass
 
     def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
-        pos_inds = torch.nonzero(assign_result.gt_inds > 0).squeeze(-1).unique()
-        neg_inds = torch.nonzero(assign_result.gt_inds == 0).squeeze(-1).unique()
+        pos_inds, neg_inds = _pos_neg_indices(assign_result.gt_inds)
         gt_flags = torch.zeros(bboxes.shape[0], dtype=torch.bool, device=bboxes.device)
         return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
 
 
 class BaseSampler:
     """sampler.py:39-112: positive/negative sampling with optional gt-as-proposal injection.
-    Index sets are data-dependent in size, so ``nonzero`` synchronises with the device here just
-    as ``jt.nonzero(...).numel()`` does in the reference."""
+    Index sets are data-dependent in size: their two counts come to the host in one synchronisation (module docstring;
+    ``jt.nonzero(...).numel()`` in the reference synchronises per list)."""
     box_dim = 4
 
     def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
@@ -59,12 +73,23 @@ class BaseSampler:
             assign_result.add_gt_(gt_labels)
             gt_flags = torch.cat([torch.ones(gt_bboxes.shape[0], dtype=torch.bool, device=bboxes.device), gt_flags])
         num_expected_pos = int(self.num * self.pos_fraction)
-        pos_inds = self._sample_pos(assign_result, num_expected_pos, bboxes=bboxes, **kwargs).unique()
-        num_expected_neg = self.num - pos_inds.numel()
-        if self.neg_pos_ub >= 0:
-            num_expected_neg = min(num_expected_neg, int(self.neg_pos_ub * max(1, pos_inds.numel())))
-        neg_inds = self._sample_neg(assign_result, num_expected_neg, bboxes=bboxes, **kwargs).unique()
+        # both candidate lists with one synchronisation (module docstring); the draws below are the reference's
+        self._candidates = _pos_neg_indices(assign_result.gt_inds)
+        try:
+            pos_inds = self._sorted(self._sample_pos(assign_result, num_expected_pos, bboxes=bboxes, **kwargs))
+            num_expected_neg = self.num - pos_inds.numel()
+            if self.neg_pos_ub >= 0:
+                num_expected_neg = min(num_expected_neg, int(self.neg_pos_ub * max(1, pos_inds.numel())))
+            neg_inds = self._sorted(self._sample_neg(assign_result, num_expected_neg, bboxes=bboxes, **kwargs))
+        finally:
+            self._candidates = None
         return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+
+    @staticmethod
+    def _sorted(inds):
+        """``inds.unique()`` of the reference (sampler.py:95,100) for index lists that hold no duplicates (a subset of
+        nonzero's output): the ascending order, without unique's size synchronisation."""
+        return torch.sort(inds)[0] if inds.numel() > 1 else inds
 
 
 @BOXES.register_module()
@@ -79,11 +104,13 @@ class RandomSampler(BaseSampler):
         return gallery[perm]
 
     def _sample_pos(self, assign_result, num_expected, **kwargs):
-        pos_inds = torch.nonzero(assign_result.gt_inds > 0).squeeze(1)
+        cand = getattr(self, "_candidates", None)
+        pos_inds = cand[0] if cand is not None else torch.nonzero(assign_result.gt_inds > 0).squeeze(1)
         return pos_inds if pos_inds.numel() <= num_expected else self.random_choice(pos_inds, num_expected)
 
     def _sample_neg(self, assign_result, num_expected, **kwargs):
-        neg_inds = torch.nonzero(assign_result.gt_inds == 0).squeeze(1)
+        cand = getattr(self, "_candidates", None)
+        neg_inds = cand[1] if cand is not None else torch.nonzero(assign_result.gt_inds == 0).squeeze(1)
         return neg_inds if len(neg_inds) <= num_expected else self.random_choice(neg_inds, num_expected)
 
 

@@ -55,13 +55,37 @@ class OrientedRPNHead(nn.Module):
 
     @staticmethod
     def unmap(data, count, inds, fill=0):
-        if data.dim() == 1:
-            ret = data.new_full((count,), fill)
-            ret[inds.bool()] = data
+        """``inds``: the bool flags of the reference (anchor_target.py `unmap`) or, from the cached geometry below, the
+        int64 indices they select -- the index form needs no device synchronisation (a bool mask does: nonzero)."""
+        ret = data.new_full((count,) + tuple(data.shape[1:]), fill)
+        if inds.dtype == torch.bool:
+            ret[inds] = data
         else:
-            ret = data.new_full((count,) + tuple(data.shape[1:]), fill)
-            ret[inds.bool(), :] = data
+            ret.index_copy_(0, inds, data)
         return ret
+
+    def _inside_geometry(self, anchors_list, valid_flag_list, img_size):
+        """flat anchors, inside flags, their indices and the anchors they select, per (anchor set, valid flags, image
+        size): the anchor grid is the same tensor list every step (AnchorGenerator caches it) and the flags depend on
+        the tile shape only, so the two synchronising selections `bool(inside.any())` / `flat_anchors[inside]` run once
+        instead of every image of every step."""
+        key = (tuple(id(a) for a in anchors_list), tuple(id(f) for f in valid_flag_list),
+               tuple(int(v) for v in img_size[:2]))
+        hit = self._geom_cache.get(key) if hasattr(self, "_geom_cache") else None
+        if hit is not None and all(a is b for a, b in zip(hit["anchors_list"], anchors_list)) and \
+                all(a is b for a, b in zip(hit["flags"], valid_flag_list)):      # (the ids belong to live tensors)
+            return hit
+        flat_anchors, valid_flags = torch.cat(anchors_list), torch.cat(valid_flag_list)
+        inside = anchor_inside_flags(flat_anchors, valid_flags, img_size[:2], allowed_border=0)
+        idx = torch.nonzero(inside).squeeze(1)
+        geom = dict(anchors_list=list(anchors_list), flags=list(valid_flag_list), flat=flat_anchors,
+                    inside=inside, idx=idx, anchors=flat_anchors[idx, :], any=idx.numel() > 0)
+        if not hasattr(self, "_geom_cache"):
+            self._geom_cache = {}
+        if len(self._geom_cache) > 8:
+            self._geom_cache.clear()
+        self._geom_cache[key] = geom
+        return geom
 
     def forward_single(self, x):
         x = F.relu(self.rpn_conv(x))
@@ -120,11 +144,10 @@ class OrientedRPNHead(nn.Module):
             gt_ignore = torch.as_tensor(ign).to(dev).float().clone()
             gt_ignore[:, -1] *= -1
         gt_labels = None
-        flat_anchors, valid_flags = torch.cat(anchors_list), torch.cat(valid_flag_list)
-        inside = anchor_inside_flags(flat_anchors, valid_flags, target["img_size"][:2], allowed_border=0)
-        if not bool(inside.any()):
+        geom = self._inside_geometry(anchors_list, valid_flag_list, target["img_size"])
+        if not geom["any"]:
             return (None,) * 7
-        anchors = flat_anchors[inside, :]
+        flat_anchors, inside, anchors = geom["flat"], geom["idx"], geom["anchors"]
         a_type, g_type = get_bbox_type(anchors), get_bbox_type(gt_bboxes)
         tgt = bbox2type(gt_bboxes, a_type)
         tgt_ign = None if gt_ignore is None else bbox2type(gt_ignore, a_type)
@@ -180,13 +203,24 @@ class OrientedRPNHead(nn.Module):
         loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
         return loss_cls, loss_bbox
 
+    def _valid_flags(self, featmap_sizes, pad_shape, dev):
+        """AnchorGenerator.valid_flags per (pyramid shape, padded tile shape): the same tensors every step (they are the
+        key of the cached inside-anchor geometry above, and ~30 small launches per image otherwise)."""
+        key = (tuple(featmap_sizes), tuple(int(v) for v in pad_shape[:2]), str(dev))
+        cache = self.__dict__.setdefault("_vf_cache", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = self.anchor_generator.valid_flags(featmap_sizes, pad_shape, device=dev)
+        return cache[key]
+
     def loss(self, cls_scores, bbox_preds, targets):
         featmap_sizes = [tuple(f.shape[-2:]) for f in cls_scores]
         assert len(featmap_sizes) == self.anchor_generator.num_levels
         dev = cls_scores[0].device
         mla = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
         anchor_list = [mla for _ in range(len(targets))]
-        valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, t['pad_shape'], device=dev) for t in targets]
+        valid_flag_list = [self._valid_flags(featmap_sizes, t['pad_shape'], dev) for t in targets]
         (labels_list, lw_list, bt_list, bw_list, npos, nneg) = self.get_targets(anchor_list, valid_flag_list, targets)
         num_level_anchors = [a.size(0) for a in anchor_list[0]]
         all_anchor_list = images_to_levels([torch.cat(a) for a in anchor_list], num_level_anchors)
