@@ -367,6 +367,14 @@ int rsdet_alignconv_fwd_mfma_f32(const float* im_nhwc, const float* offset, cons
 int rsdet_conv3x3_mfma_supported(int B, int H, int W, int C, int O);
 int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* weight, const float* bias, const uint8_t* live, int B,
                                 int H, int W, int C, int O, int relu, uint16_t* out, void* stream);
+/* Weight gradient of the same convolution (csrc/conv3x3_wrw_mfma.hip): split-K implicit GEMM over groups of image rows,
+ * fragments by transposing LDS reads (both operands are position-major), fp32 partial tiles folded in a fixed order by a
+ * second launch.  grad_out (B, H, W, O), x (B, H, W, C) channels-last bf16; grad_weight (O, 3, 3, C) bf16 (out_bf16 != 0)
+ * or fp32; ws: rsdet_conv3x3_wrw_mfma_ws_size bytes, 16-byte aligned.  C % 64 == 0, O % 8 == 0. */
+int rsdet_conv3x3_wrw_mfma_supported(int B, int H, int W, int C, int O);
+size_t rsdet_conv3x3_wrw_mfma_ws_size(int B, int H, int W, int C, int O);
+int rsdet_conv3x3_wrw_mfma_bf16(const uint16_t* grad_out, const uint16_t* x, int B, int H, int W, int C, int O,
+                                void* grad_weight, int out_bf16, void* ws, size_t ws_bytes, void* stream);
 int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, const uint16_t* weight,
                                   const rsdet_dcn_geom* g, int O, int out_nhwc, uint16_t* out, uint16_t* colT,
                                   void* stream);

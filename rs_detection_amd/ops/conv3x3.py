@@ -83,6 +83,30 @@ def _mfma_conv(x, w_cl, bias, live, relu):
     return y
 
 
+_MFMA_WRW = os.environ.get("RSDET_CONV3X3_MFMA_WRW", "1") == "1"      # A/B switch
+
+
+def _mfma_wrw(g, x, out_dtype):
+    """Weight gradient (O, C, 3, 3) channels_last of the 3x3 convolution from g (B,O,H,W) and x (B,C,H,W), both bf16
+    channels_last (csrc/conv3x3_wrw_mfma.hip: split-K implicit GEMM + fold, two launches); None when the kernel does not
+    take the shape or the weight's dtype."""
+    from .. import _lib
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        return None
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    O = g.shape[1]
+    if not lib.rsdet_conv3x3_wrw_mfma_supported(B, H, W, C, O):
+        return None
+    gw = torch.empty((O, C, 3, 3), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
+    nb = lib.rsdet_conv3x3_wrw_mfma_ws_size(B, H, W, C, O)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=x.device)
+    rc = lib.rsdet_conv3x3_wrw_mfma_bf16(_lib.ptr(g), _lib.ptr(x), B, H, W, C, O, _lib.ptr(gw),
+                                         int(out_dtype == torch.bfloat16), _lib.ptr(ws), nb, _lib.stream_ptr())
+    _lib.check(rc, "rsdet_conv3x3_wrw_mfma_bf16")
+    return gw
+
+
 def _lib_supported(B, H, W, C, O):
     from .. import _lib
     return bool(_lib.load().rsdet_conv3x3_mfma_supported(B, H, W, C, O))
@@ -149,10 +173,12 @@ class _Conv3x3BiasReLU(torch.autograd.Function):
             if gx.dtype != ctx.in_dtype:
                 gx = gx.to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(g, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1]
-            if gw.dtype != ctx.w_dtype:
-                gw = gw.to(ctx.w_dtype)
+            gw = _mfma_wrw(g, xb, ctx.w_dtype) if _MFMA_WRW else None
+            if gw is None:           # MIOpen's solver (+ its zero-fill and cast launches)
+                gw = torch.ops.aten.convolution_backward(g, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1]
+                if gw.dtype != ctx.w_dtype:
+                    gw = gw.to(ctx.w_dtype)
         if gb is not None and gb.dtype != ctx.bias_dtype:
             gb = gb.to(ctx.bias_dtype)
         return gx, gw, gb, None
