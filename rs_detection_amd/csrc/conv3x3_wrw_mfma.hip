@@ -4,7 +4,7 @@
 // Replaces (as the library kernel behind it: bf16 products, fp32 accumulation, one rounding of the result) the
 // backward-weight pass of the `ConvModule(256, 256, 3)` tower convolutions of
 // /root/reference/python/jdet/models/roi_heads/s2anet_head.py:127-186 on the pyramid canvas (MIOpen: an NHWC
-// implicit-GEMM kernel + a zero-fill and a cast launch around it, 183 + ~10 us per call, 8 calls per bf16 step).
+// implicit-GEMM kernel + a zero-fill and a cast launch around it, 186 + ~10 us per call, 8 calls per bf16 step; this kernel: 155 us + a 9 us fold).
 //
 //   dW[o, (ki, kj), c] = sum_{b, y, x} g[b, y, x, o] * X[b, y + ki - 1, x + kj - 1, c]        GEMM: M = (kj, c), N = o,
 //   K = all positions.  BOTH operands are position-major in memory (channels contiguous), i.e. K is the slow index of
@@ -60,14 +60,18 @@ __device__ __forceinline__ void w3_wait_vm() {
 __device__ __forceinline__ void w3_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <int OFF>
 __device__ __forceinline__ void w3_tr_read(w3_u32x2& dst, unsigned addr) {
+#ifndef W3_AB_NO_LDS
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+#else
+  asm volatile("v_mov_b32 %0, %1" : "=v"(dst[0]) : "v"(addr) : "memory");   // timing-only ablation: no LDS traffic
+#endif
 }
 __device__ __forceinline__ void w3_landed(w3_u32x2& v) { asm volatile("" : "+v"(v)); }
 
 __device__ __forceinline__ int w3_fg(int row) { return (2 * (row & 3)) | (8 * ((row >> 3) & 1)); }
 __device__ __forceinline__ int w3_fx(int row) { return (2 * ((row >> 1) & 1)) | (4 * ((row >> 3) & 1)); }
 
-// grid: n_groups x (3 * C / 64) x ceil(O / 256) workgroups (x fastest: the row groups of one result tile), block 512.
+// grid: n_groups x (3 * C / 64) x ceil(O / 256) workgroups (logical order: result tile fastest), block 512.
 // partial: [group][tile = (ki, cc, ob)][o_local 256][192] fp32.
 __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
     const bf16_t* __restrict__ gmap, const bf16_t* __restrict__ xmap, W3Geom g, int n_groups, float* __restrict__ partial) {
@@ -75,7 +79,11 @@ __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cchunks = g.C >> 6;
-  const int grp = blockIdx.x % n_groups, tile = blockIdx.x / n_groups;
+  // the workgroups that stream the same rows of g (one row group, all result tiles) are neighbours in the logical order,
+  // and every XCD takes one contiguous range of it: they meet in one L2 (blockIdx.x, blockIdx.x + 8, ... share an XCD)
+  const int n_tiles_all = (int)gridDim.x / n_groups;
+  const unsigned lid = rsdet_xcd_contiguous(blockIdx.x, gridDim.x);
+  const int grp = (int)lid / n_tiles_all, tile = (int)lid - grp * n_tiles_all;
   const int ob = tile / (3 * cchunks), rem = tile - ob * 3 * cchunks;
   const int ki = rem / cchunks, cc = rem - ki * cchunks;
   const int o_base = ob * W3_TN;
@@ -136,18 +144,21 @@ __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
     if (++i_slot == W3_SLOTS) i_slot = 0;
   };
 
-  // ---- fragment addresses (without the slot base).  Transposing read: lane 4q + p of 16-lane group gq supplies the
+  // ---- fragment addresses.  Transposing read: lane 4q + p of 16-lane group gq supplies the
   // address of block row q, columns 4p .. 4p + 3; read h (0 / 1) of a fragment covers positions 8 gq + 4 h + q.
   const int wm = wave >> 2, wn = wave & 3;                 // wm: half of the 192 (kj, c) rows; wn: 64 output channels
   const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  unsigned pre_g[4];                                       // g fragments: ni = 0..3 (16 output channels each); + 2048 for h = 1
+  // running LDS addresses of the current STEP's first slot (the second chunk of a step is an immediate W3_SLOT away);
+  // they advance by two slots per step and wrap after three steps
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  unsigned ga[4];                                          // g fragments: ni = 0..3 (16 output channels each); + 2048 for h = 1
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int row = 8 * gq + q;                            // (h = 1: row + 4 -- the swizzle does not see bit 2)
     const int chunk = (wn * 64 + ni * 16) / 8 + (p >> 1);
-    pre_g[ni] = row * 512 + ((chunk ^ w3_fg(row)) << 4) + 8 * (p & 1);
+    ga[ni] = lds_base + row * 512 + ((chunk ^ w3_fg(row)) << 4) + 8 * (p & 1);
   }
-  unsigned pre_x[6][2];                                    // X fragments: mi = 0..5 -> n-tile wm * 6 + mi = (kj, c16)
+  unsigned xa[6][2];                                       // X fragments: mi = 0..5 -> n-tile wm * 6 + mi = (kj, c16)
 #pragma unroll
   for (int mi = 0; mi < 6; ++mi) {
     const int nt = wm * 6 + mi, kj = nt >> 2, c16 = nt & 3;
@@ -155,10 +166,9 @@ __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
     for (int h = 0; h < 2; ++h) {
       const int row = kj + 8 * gq + 4 * h + q;
       const int chunk = c16 * 2 + (p >> 1);
-      pre_x[mi][h] = W3_G_BYTES + row * 128 + ((chunk ^ w3_fx(row)) << 4) + 8 * (p & 1);
+      xa[mi][h] = lds_base + W3_G_BYTES + row * 128 + ((chunk ^ w3_fx(row)) << 4) + 8 * (p & 1);
     }
   }
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
   w3_f32x4 acc[6][4];
 #pragma unroll
@@ -173,48 +183,56 @@ __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
   // the second chunk's g fragments are read during the first chunk's MFMAs (two register sets), so only the first
   // chunk after the barrier waits for LDS.  LDS reads return in issue order: lgkmcnt(N) = "all but the N newest".
   w3_u32x2 fg[2][4][2], fx[2][2];
-  auto read_g = [&](int buf, int ni, unsigned sb) {
-    switch (ni) {          // (register arrays want constant indices)
-      case 0: w3_tr_read<0>(fg[buf][0][0], sb + pre_g[0]); w3_tr_read<2048>(fg[buf][0][1], sb + pre_g[0]); break;
-      case 1: w3_tr_read<0>(fg[buf][1][0], sb + pre_g[1]); w3_tr_read<2048>(fg[buf][1][1], sb + pre_g[1]); break;
-      case 2: w3_tr_read<0>(fg[buf][2][0], sb + pre_g[2]); w3_tr_read<2048>(fg[buf][2][1], sb + pre_g[2]); break;
-      default: w3_tr_read<0>(fg[buf][3][0], sb + pre_g[3]); w3_tr_read<2048>(fg[buf][3][1], sb + pre_g[3]); break;
-    }
-  };
-  auto read_x = [&](int xb, int mi, unsigned sb) {
-    w3_tr_read<0>(fx[xb][0], sb + pre_x[mi][0]);
-    w3_tr_read<0>(fx[xb][1], sb + pre_x[mi][1]);
-  };
-  // the 24 MFMAs of the chunk in slot base `sb` with the g fragments of set `buf` (already issued, as is X tile 0 into
-  // fx[0]); `sb_next` != 0: the next chunk of the same step -- its g fragments (set 1 - buf) and its X tile 0 are
-  // issued on the way.  Reads issued after X tile mi's, when tile mi is needed: X tile mi + 1 (2), and the g pairs of
-  // the next chunk issued in iterations mi - 1 and mi (2 each, iterations 1..4).
-  auto mfma_chunk = [&](int buf, unsigned sb, unsigned sb_next) {
-#pragma unroll
-    for (int mi = 0; mi < 6; ++mi) {
-      const int xb = mi & 1;
-      if (mi < 5) read_x(xb ^ 1, mi + 1, sb);
-      else if (sb_next) read_x(xb ^ 1, 0, sb_next);
-      const bool gnow = sb_next && mi >= 1 && mi <= 4, gprev = sb_next && mi >= 2 && mi <= 5;
-      if (gnow) read_g(buf ^ 1, mi - 1, sb_next);
-      const int newer = ((mi < 5 || sb_next) ? 2 : 0) + (gnow ? 2 : 0) + (gprev ? 2 : 0);
-      if (newer == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-      else if (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-      else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      w3_landed(fx[xb][0]), w3_landed(fx[xb][1]);
-      w3_u32x4 a;
-      a[0] = fx[xb][0][0], a[1] = fx[xb][0][1], a[2] = fx[xb][1][0], a[3] = fx[xb][1][1];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        if (mi == 0) w3_landed(fg[buf][ni][0]), w3_landed(fg[buf][ni][1]);
-        w3_u32x4 b;
-        b[0] = fg[buf][ni][0][0], b[1] = fg[buf][ni][0][1], b[2] = fg[buf][ni][1][0], b[3] = fg[buf][ni][1][1];
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w3_bf16x8, a),
-                                                              __builtin_bit_cast(w3_bf16x8, b), acc[mi][ni], 0, 0, 0);
-      }
-    }
-  };
+#define W3_RG(buf, ni, OFF)                                        \
+  w3_tr_read<(OFF)>(fg[buf][ni][0], ga[ni]);                       \
+  w3_tr_read<(OFF) + 2048>(fg[buf][ni][1], ga[ni])
+#define W3_RX(xb, mi, OFF)                                         \
+  w3_tr_read<(OFF)>(fx[xb][0], xa[mi][0]);                         \
+  w3_tr_read<(OFF)>(fx[xb][1], xa[mi][1])
+  // The 24 MFMAs of one chunk (PAR = 0 / 1: first / second chunk of the step, i.e. immediate 0 / W3_SLOT) with the g
+  // fragments of register set PAR, already issued, as is X tile 0 into fx[0].  NEXT: the second chunk of the step
+  // follows -- its g fragments (set 1) and its X tile 0 are issued on the way.  LDS reads return in issue order: when X
+  // tile mi is needed, the reads issued after it are X tile mi + 1 (2) and the g pairs of the next chunk issued in
+  // iterations mi - 1 and mi (2 each, iterations 1..4).
+#define W3_CHUNK(PAR, NEXT)                                                                                            \
+  _Pragma("unroll") for (int mi = 0; mi < 6; ++mi) {                                                                   \
+    const int xb = mi & 1;                                                                                             \
+    if (mi < 5) {                                                                                                      \
+      switch (mi) {                                                                                                    \
+        case 0: W3_RX(1, 1, (PAR) * W3_SLOT); break;                                                                   \
+        case 1: W3_RX(0, 2, (PAR) * W3_SLOT); break;                                                                   \
+        case 2: W3_RX(1, 3, (PAR) * W3_SLOT); break;                                                                   \
+        case 3: W3_RX(0, 4, (PAR) * W3_SLOT); break;                                                                   \
+        default: W3_RX(1, 5, (PAR) * W3_SLOT); break;                                                                  \
+      }                                                                                                                \
+    } else if (NEXT) {                                                                                                 \
+      W3_RX(0, 0, W3_SLOT);                                                                                            \
+    }                                                                                                                  \
+    const bool gnow = (NEXT) && mi >= 1 && mi <= 4, gprev = (NEXT) && mi >= 2 && mi <= 5;                              \
+    if (gnow) {                                                                                                        \
+      switch (mi) {                                                                                                    \
+        case 1: W3_RG(1, 0, W3_SLOT); break;                                                                           \
+        case 2: W3_RG(1, 1, W3_SLOT); break;                                                                           \
+        case 3: W3_RG(1, 2, W3_SLOT); break;                                                                           \
+        default: W3_RG(1, 3, W3_SLOT); break;                                                                          \
+      }                                                                                                                \
+    }                                                                                                                  \
+    const int newer = ((mi < 5 || (NEXT)) ? 2 : 0) + (gnow ? 2 : 0) + (gprev ? 2 : 0);                                 \
+    if (newer == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                                                 \
+    else if (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                            \
+    else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                            \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+    w3_landed(fx[xb][0]), w3_landed(fx[xb][1]);                                                                        \
+    w3_u32x4 a;                                                                                                        \
+    a[0] = fx[xb][0][0], a[1] = fx[xb][0][1], a[2] = fx[xb][1][0], a[3] = fx[xb][1][1];                                \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {                                                                 \
+      if (mi == 0) w3_landed(fg[PAR][ni][0]), w3_landed(fg[PAR][ni][1]);                                               \
+      w3_u32x4 b;                                                                                                      \
+      b[0] = fg[PAR][ni][0][0], b[1] = fg[PAR][ni][0][1], b[2] = fg[PAR][ni][1][0], b[3] = fg[PAR][ni][1][1];          \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w3_bf16x8, a),                          \
+                                                            __builtin_bit_cast(w3_bf16x8, b), acc[mi][ni], 0, 0, 0);   \
+    }                                                                                                                  \
+  }
 
   // ---- schedule: steps of two chunks; chunks 2s + 4, 2s + 5 are issued at the start of step s (into the slots step
   // s - 1 used), so at that point only the operations of chunks 2s + 2, 2s + 3 may still be in flight
@@ -233,16 +251,25 @@ __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
 #ifndef W3_AB_NO_BARRIER
     __syncthreads();
 #endif
+    // (the two chunks of a step sit in consecutive slots: 2s mod 6 is even)
+    W3_RG(0, 0, 0); W3_RG(0, 1, 0); W3_RG(0, 2, 0); W3_RG(0, 3, 0);
+    W3_RX(0, 0, 0);
+    // the refill of the slots step s - 1 used goes out while those ten reads are in flight
 #ifndef W3_AB_NO_DMA
     if (c0 + 4 < NC) issue_next();
     if (c0 + 5 < NC) issue_next();
 #endif
-    const unsigned sb0 = lds_base + (c0 % W3_SLOTS) * W3_SLOT;
-    const unsigned sb1 = c0 + 1 < NC ? lds_base + ((c0 + 1) % W3_SLOTS) * W3_SLOT : 0u;
-    read_g(0, 0, sb0), read_g(0, 1, sb0), read_g(0, 2, sb0), read_g(0, 3, sb0);
-    read_x(0, 0, sb0);
-    mfma_chunk(0, sb0, sb1);       // (its first wait, lgkmcnt(2), covers the ten reads above)
-    if (sb1) mfma_chunk(1, sb1, 0u);
+    if (c0 + 1 < NC) {
+      W3_CHUNK(0, true)            // (its first wait, lgkmcnt(2), covers the ten reads above)
+      W3_CHUNK(1, false)
+    } else {
+      W3_CHUNK(0, false)
+    }
+    const int adv = (c0 % W3_SLOTS) == W3_SLOTS - 2 ? -(W3_SLOTS - 2) * W3_SLOT : 2 * W3_SLOT;   // next step's first slot
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) ga[ni] += adv;
+#pragma unroll
+    for (int mi = 0; mi < 6; ++mi) xa[mi][0] += adv, xa[mi][1] += adv;
   }
 
   // ---- epilogue: D[row = (kj, c) local][col = o local]: lane holds rows 4 (lane >> 4) + 0..3 of n-tile mi and column
@@ -254,6 +281,9 @@ __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
 #pragma unroll
     for (int mi = 0; mi < 6; ++mi) {
       const int n = (wm * 6 + mi) * 16 + 4 * (lane >> 4);
+#ifdef W3_AB_NO_EPI
+      if (acc[mi][ni][0] == 12345.678f)
+#endif
       *reinterpret_cast<float4*>(pt + (long long)o * W3_TM + n) =
           make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
     }
