@@ -242,6 +242,19 @@ def kernel_rooflines(device, targets):
             out["conv3x3_fwd_mfma_bf16_kernel(head canvas %dx%dx%dx%d, %s)" % (B, lay.Hc, lay.Wc, C, tag)] = dict(
                 bound="mfma", achieved=flc / t / 1e12, peak=2500.0, unit="TFLOP/s", frac=flc / t / 1e12 / 2500.0,
                 us=t * 1e6, hbm_alg_bytes=byc, traffic=pmc_traffic("conv3x3_mfma bf16 (head canvas 4x128x196x256)", (B, C, lay.Wc) == (4, 256, 196)))
+    # ... and its weight gradient (csrc/conv3x3_wrw_mfma.hip: split-K main launch + fold), same canvas
+    if lib_.rsdet_conv3x3_wrw_mfma_supported(B, lay.Hc, lay.Wc, C, O_):
+        gc = torch.randn(B, O_, lay.Hc, lay.Wc, device=device).bfloat16().contiguous(memory_format=torch.channels_last)
+        gwc = torch.empty((O_, C, 3, 3), dtype=torch.bfloat16, device=device, memory_format=torch.channels_last)
+        nbw = lib_.rsdet_conv3x3_wrw_mfma_ws_size(B, lay.Hc, lay.Wc, C, O_)
+        wsw = torch.empty((nbw,), dtype=torch.uint8, device=device)
+        t = event_time(lambda: lib_.rsdet_conv3x3_wrw_mfma_bf16(_L.ptr(gc), _L.ptr(xc), B, lay.Hc, lay.Wc, C, O_, _L.ptr(gwc), 1,
+                                                                _L.ptr(wsw), nbw, _L.stream_ptr()), 10, 2)
+        out["conv3x3_wrw_mfma_bf16_kernel+fold(head canvas %dx%dx%dx%d, 2 launches)" % (B, lay.Hc, lay.Wc, C)] = dict(
+            bound="mfma", achieved=flc / t / 1e12, peak=2500.0, unit="TFLOP/s", frac=flc / t / 1e12 / 2500.0, us=t * 1e6,
+            hbm_alg_bytes=2 * (B * lay.Hc * lay.Wc * (C + O_) + 9 * C * O_),
+            traffic=pmc_traffic("conv3x3_wrw_mfma bf16 (head canvas 4x128x196x256, 2 launches)", (B, C, lay.Wc) == (4, 256, 196)))
+        del gc, gwc, wsw
     del xc, wc, oc
     # (the reference-layout col2im -- one lane per column row, 13.2 ms here -- is kept for API parity only; the step
     #  uses the channels-last pair below, so it is not timed: it would dominate the rocprof summary of this command)

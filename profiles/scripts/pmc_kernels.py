@@ -209,7 +209,17 @@ for _ in range(4):
 ALG4 = {"conv3x3_fwd_mfma_bf16_kernel": dict(call="conv3x3_mfma bf16 (head canvas 4x128x196x256)",
                                              bytes=2 * (2 * Bc * Hc_ * Wc_ * Cc + 9 * Cc * Cc),
                                              flops=2.0 * Bc * Hc_ * Wc_ * Cc * 9 * Cc)}
-del xq, oq
+gq_ = torch.randn(Bc, Cc, Hc_, Wc_, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+gwq = torch.empty((Cc, Cc, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+nbw = _lib_.rsdet_conv3x3_wrw_mfma_ws_size(Bc, Hc_, Wc_, Cc, Cc)
+wsw = torch.empty((nbw,), dtype=torch.uint8, device=dev)
+for _ in range(4):
+    _lib_.rsdet_conv3x3_wrw_mfma_bf16(_L.ptr(gq_), _L.ptr(xq), Bc, Hc_, Wc_, Cc, Cc, _L.ptr(gwq), 1, _L.ptr(wsw), nbw, _L.stream_ptr())
+    torch.ops.aten.convolution_backward(gq_, xq, wq, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))
+for kname in ("conv3x3_wrw_mfma_bf16_kernel", "conv3x3_wrw_fold_kernel"):
+    ALG4[kname] = dict(call="conv3x3_wrw_mfma bf16 (head canvas 4x128x196x256, 2 launches)",
+                       bytes=2 * (2 * Bc * Hc_ * Wc_ * Cc + 9 * Cc * Cc), flops=2.0 * Bc * Hc_ * Wc_ * Cc * 9 * Cc)
+del xq, oq, gq_, wsw
 from rs_detection_amd.ops import van_fused
 for shp in ((2, 64, 256, 256), (2, 320, 64, 64)):
     t1, t2, t3 = (torch.randn(shp, device=dev, requires_grad=True) for _ in range(3))

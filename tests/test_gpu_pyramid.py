@@ -486,3 +486,31 @@ def test_convmodule_takes_the_mfma_kernel_on_the_head_canvas(cuda, monkeypatch):
         e_ours = float((a - c).norm() / c.norm())
         e_theirs = float((b - c).norm() / c.norm())
         assert e_ours <= 1.5 * e_theirs + 2e-3, (tuple(c.shape), e_ours, e_theirs)
+
+
+@pytest.mark.parametrize("B,C,O,H,W", [(2, 256, 256, 9, 196), (1, 64, 32, 5, 37), (2, 128, 96, 9, 300), (1, 256, 256, 3, 224),
+                                       (2, 64, 256, 17, 1), (3, 64, 8, 2, 33), (1, 64, 264, 4, 40)])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_conv3x3_wrw_mfma_equals_the_fp32_weight_gradient(cuda, B, C, O, H, W, out_bf16):
+    """csrc/conv3x3_wrw_mfma.hip through its C ABI: dW of a 3x3 / stride 1 / padding 1 convolution from bf16 channels-last
+    g and x -- against the fp32 weight gradient of the same operands.  bf16 products are exact in fp32 and the sums are
+    fp32: the fp32 output agrees to summation order (1e-5 of the largest entry), the bf16 output to one rounding.  Rows
+    shorter / longer than the 32-position chunk, a single column, O below / above one 256-channel block, row groups
+    of unequal size."""
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(B * 100 + W)
+    x = torch.randn(B, C, H, W, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, O, H, W, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert lib.rsdet_conv3x3_wrw_mfma_supported(B, H, W, C, O)
+    gw = torch.empty((O, C, 3, 3), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=cuda,
+                     memory_format=torch.channels_last)
+    nb = lib.rsdet_conv3x3_wrw_mfma_ws_size(B, H, W, C, O)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=cuda)
+    _lib.check(lib.rsdet_conv3x3_wrw_mfma_bf16(_lib.ptr(g), _lib.ptr(x), B, H, W, C, O, _lib.ptr(gw), int(out_bf16),
+                                               _lib.ptr(ws), nb, _lib.stream_ptr()), "rsdet_conv3x3_wrw_mfma_bf16")
+    w0 = torch.zeros(O, C, 3, 3, device=cuda)
+    ref = torch.ops.aten.convolution_backward(g.float().contiguous(), x.float().contiguous(), w0, None, (1, 1), (1, 1), (1, 1),
+                                              False, (0, 0), 1, (False, True, False))[1]
+    err = float((gw.float() - ref).abs().max() / ref.abs().max())
+    assert err <= (4e-3 if out_bf16 else 1e-5), err
