@@ -14,13 +14,13 @@
 //   residual    y = x + ls[c] * (p + b[c] + sc)       backward: gp = ls * g (also sc's gradient), gb = ls * sum g,
 //                                                               gls = sum g * (p + b + sc); x's gradient is g itself
 // One workgroup = one slice of one (n, c) plane (the per-channel parameters are scalars), float4 accesses; the
-// per-channel sums are two-stage and deterministic: slice partials, folded per channel in a fixed order by the last
-// workgroup of the launch to arrive (no second launch).
+// per-channel sums are two-stage and deterministic: slice partials, then one wave per channel folds them (a second,
+// ~4 us launch; folding in the last workgroup to arrive through device-scope atomics was measured: it doubles the
+// 15 us backward passes -- every workgroup's arrival serialises on one counter).
 // GELU is the erf form of torch.nn.GELU() (what jittor.nn.GELU computes), in fp32 like torch's kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <atomic>
 #include <initializer_list>
 
 #include "rsdet_api_internal.h"
@@ -52,26 +52,9 @@ __device__ __forceinline__ VeSlice ve_slice(int C, int HW) {
   return v;
 }
 
-// Arrival counters of the "last workgroup folds the partials" tails below: zero between launches (the last workgroup puts
-// its counter back), one slot per launch in rotation so that launches on different streams do not share one.
-constexpr int VE_SLOTS = 64;
-__device__ unsigned g_ve_arrivals[VE_SLOTS];
-
-struct VeFold {
-  float* partial;      // (C, N * S) pairs
-  const float* mul0;   // optional per-channel factor of the first sum (the layer scale for the bias gradient)
-  float* out0;         // sum of the first components per channel (or nullptr)
-  float* out1;         // sum of the second components per channel (or nullptr)
-  int slot;
-};
-
-// (a, b) summed over the workgroup -> partial[c][n * S + s]; the LAST workgroup of the launch to arrive then folds all
-// partials per channel in a fixed order (deterministic) -- the separate finish launch this replaces cost ~5 us of GPU
-// time and a host launch per call, 304 times per Oriented R-CNN step.  Partials travel through device-scope atomics on
-// both sides (a workgroup on another XCD has another L2): 64-bit exchange to store a pair, atomic OR 0 to read it.
-__device__ __forceinline__ void ve_reduce_fold(float a, float b, int C, const VeFold& f) {
+// (a, b) summed over the workgroup -> partial[(c * (N * S) + n * S + s) * 2 + {0, 1}]
+__device__ __forceinline__ void ve_reduce_store(float a, float b, int C, float* __restrict__ partial) {
   __shared__ float s_red[VE_NT / 64][2];
-  __shared__ int s_last;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     a += __shfl_down(a, off);
@@ -79,30 +62,14 @@ __device__ __forceinline__ void ve_reduce_fold(float a, float b, int C, const Ve
   }
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][0] = a, s_red[threadIdx.x >> 6][1] = b;
   __syncthreads();
-  const int pc = blockIdx.y, S = gridDim.x, n = pc / C, c0 = pc - n * C, N = gridDim.y / C, NS = N * S;
-  unsigned long long* part = reinterpret_cast<unsigned long long*>(f.partial);
   if (threadIdx.x == 0) {
     float ta = 0.f, tb = 0.f;
 #pragma unroll
     for (int w = 0; w < VE_NT / 64; ++w) ta += s_red[w][0], tb += s_red[w][1];
-    const unsigned long long pair = (unsigned long long)__float_as_uint(ta) | ((unsigned long long)__float_as_uint(tb) << 32);
-    atomicExch(part + (long long)c0 * NS + n * S + blockIdx.x, pair);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair is performed before the arrival is counted
-    s_last = atomicAdd(&g_ve_arrivals[f.slot], 1u) == gridDim.x * gridDim.y - 1u;
+    const int pc = blockIdx.y, S = gridDim.x, n = pc / C, c = pc - n * C, N = gridDim.y / C;
+    float* dst = partial + ((long long)c * (N * S) + n * S + blockIdx.x) * 2;
+    dst[0] = ta, dst[1] = tb;
   }
-  __syncthreads();
-  if (!s_last) return;
-  for (int c = threadIdx.x; c < C; c += VE_NT) {
-    float ta = 0.f, tb = 0.f;
-    for (int k = 0; k < NS; ++k) {
-      const unsigned long long pair = atomicOr(part + (long long)c * NS + k, 0ull);
-      ta += __uint_as_float((unsigned)(pair & 0xffffffffull));
-      tb += __uint_as_float((unsigned)(pair >> 32));
-    }
-    if (f.out0) f.out0[c] = f.mul0 ? f.mul0[c] * ta : ta;
-    if (f.out1) f.out1[c] = tb;
-  }
-  if (threadIdx.x == 0) atomicExch(&g_ve_arrivals[f.slot], 0u);   // ready for the next launch that draws this slot
 }
 
 // body(i, vec): vec = true handles elements i .. i + 3, false the single element i
@@ -138,7 +105,7 @@ __global__ __launch_bounds__(VE_NT) void van_bias_gelu_fwd_kernel(const float* _
 
 __global__ __launch_bounds__(VE_NT) void van_bias_gelu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                   const float* __restrict__ bias, int C, int HW, int al,
-                                                                  float* __restrict__ gx, const VeFold f) {
+                                                                  float* __restrict__ gx, float* __restrict__ partial) {
   const VeSlice v = ve_slice(C, HW);
   const float b = bias ? bias[v.c] : 0.f;
   const float *gp = gy + v.base, *xp = x + v.base;
@@ -157,7 +124,7 @@ __global__ __launch_bounds__(VE_NT) void van_bias_gelu_bwd_kernel(const float* _
       acc += r;
     }
   });
-  if (f.partial) ve_reduce_fold(acc, 0.f, C, f);
+  if (partial) ve_reduce_store(acc, 0.f, C, partial);
 }
 
 __global__ __launch_bounds__(VE_NT) void van_gate_fwd_kernel(const float* __restrict__ u, const float* __restrict__ a,
@@ -180,7 +147,7 @@ __global__ __launch_bounds__(VE_NT) void van_gate_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(VE_NT) void van_gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u,
                                                              const float* __restrict__ a, const float* __restrict__ bias,
                                                              int C, int HW, int al, float* __restrict__ gu,
-                                                             float* __restrict__ ga, const VeFold f) {
+                                                             float* __restrict__ ga, float* __restrict__ partial) {
   const VeSlice v = ve_slice(C, HW);
   const float b = bias ? bias[v.c] : 0.f;
   const float *gp = g + v.base, *up = u + v.base, *ap = a + v.base;
@@ -200,7 +167,7 @@ __global__ __launch_bounds__(VE_NT) void van_gate_bwd_kernel(const float* __rest
       acc += r;
     }
   });
-  if (f.partial) ve_reduce_fold(acc, 0.f, C, f);
+  if (partial) ve_reduce_store(acc, 0.f, C, partial);
 }
 
 __global__ __launch_bounds__(VE_NT) void van_residual_fwd_kernel(const float* __restrict__ x, const float* __restrict__ p,
@@ -226,7 +193,7 @@ __global__ __launch_bounds__(VE_NT) void van_residual_fwd_kernel(const float* __
 __global__ __launch_bounds__(VE_NT) void van_residual_bwd_kernel(const float* __restrict__ g, const float* __restrict__ p,
                                                                  const float* __restrict__ bias, const float* __restrict__ sc,
                                                                  const float* __restrict__ scale, int C, int HW, int al,
-                                                                 float* __restrict__ gpo, const VeFold f) {
+                                                                 float* __restrict__ gpo, float* __restrict__ partial) {
   const VeSlice v = ve_slice(C, HW);
   const float b = bias ? bias[v.c] : 0.f, ls = scale[v.c];
   const float *gp = g + v.base, *pp = p + v.base, *sp = sc ? sc + v.base : nullptr;
@@ -246,7 +213,30 @@ __global__ __launch_bounds__(VE_NT) void van_residual_bwd_kernel(const float* __
       acc_f += t * (pp[i] + b + (sp ? sp[i] : 0.f));
     }
   });
-  ve_reduce_fold(acc_g, acc_f, C, f);
+  ve_reduce_store(acc_g, acc_f, C, partial);
+}
+
+// one wave per channel: out0[c] = mul0[c] * sum of the first partials, out1[c] = sum of the second ones (fixed order)
+__global__ __launch_bounds__(256) void van_finish_kernel(const float* __restrict__ partial, int C, int S,
+                                                         const float* __restrict__ mul0, float* __restrict__ out0,
+                                                         float* __restrict__ out1) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float2 p = *reinterpret_cast<const float2*>(partial + ((long long)c * S + s) * 2);
+    a += p.x;
+    b += p.y;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off);
+    b += __shfl_down(b, off);
+  }
+  if (lane == 0) {
+    if (out0) out0[c] = mul0 ? mul0[c] * a : a;
+    if (out1) out1[c] = b;
+  }
 }
 
 static inline int ve_slices(int N, int C, int HW) {
@@ -259,11 +249,6 @@ static inline int ve_slices(int N, int C, int HW) {
 
 static inline bool ve_ok(int N, int C, int HW) {
   return N >= 0 && C > 0 && HW >= 0 && (long long)N * C <= 65535;
-}
-
-static inline int ve_next_slot() {
-  static std::atomic<unsigned> n{0};
-  return (int)(n.fetch_add(1u, std::memory_order_relaxed) % VE_SLOTS);
 }
 
 static inline int ve_aligned(int HW, std::initializer_list<const void*> ptrs) {
@@ -304,9 +289,11 @@ extern "C" int rsdet_van_bias_gelu_bwd_f32(const float* gy, const float* x, cons
   if (!gy || !x || !gx) return RSDET_EINVAL;
   if (gbias && (!ws || ws_bytes < rsdet_van_ws_size(N, C, HW))) return RSDET_EINVAL;
   const int S = ve_slices(N, C, HW);
-  const VeFold f{gbias ? (float*)ws : nullptr, nullptr, gbias, nullptr, ve_next_slot()};
   hipLaunchKernelGGL(van_bias_gelu_bwd_kernel, dim3(S, N * C), dim3(VE_NT), 0, (hipStream_t)stream, gy, x, bias, C, HW,
-                     ve_aligned(HW, {gy, x, gx}), gx, f);
+                     ve_aligned(HW, {gy, x, gx}), gx, gbias ? (float*)ws : nullptr);
+  if (gbias)
+    hipLaunchKernelGGL(van_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
+                       N * S, (const float*)nullptr, gbias, (float*)nullptr);
   return rsdet_launch_status();
 }
 
@@ -331,9 +318,11 @@ extern "C" int rsdet_van_gate_bwd_f32(const float* g, const float* u, const floa
   if (!g || !u || !a || !gu || !ga) return RSDET_EINVAL;
   if (gbias && (!ws || ws_bytes < rsdet_van_ws_size(N, C, HW))) return RSDET_EINVAL;
   const int S = ve_slices(N, C, HW);
-  const VeFold f{gbias ? (float*)ws : nullptr, nullptr, gbias, nullptr, ve_next_slot()};
   hipLaunchKernelGGL(van_gate_bwd_kernel, dim3(S, N * C), dim3(VE_NT), 0, (hipStream_t)stream, g, u, a, bias, C, HW,
-                     ve_aligned(HW, {g, u, a, gu, ga}), gu, ga, f);
+                     ve_aligned(HW, {g, u, a, gu, ga}), gu, ga, gbias ? (float*)ws : nullptr);
+  if (gbias)
+    hipLaunchKernelGGL(van_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
+                       N * S, (const float*)nullptr, gbias, (float*)nullptr);
   return rsdet_launch_status();
 }
 
@@ -358,8 +347,10 @@ extern "C" int rsdet_van_residual_bwd_f32(const float* g, const float* p, const 
   }
   if (!g || !p || !scale || !gp || !ws || ws_bytes < rsdet_van_ws_size(N, C, HW)) return RSDET_EINVAL;
   const int S = ve_slices(N, C, HW);
-  const VeFold f{(float*)ws, scale, gbias, gscale, ve_next_slot()};
   hipLaunchKernelGGL(van_residual_bwd_kernel, dim3(S, N * C), dim3(VE_NT), 0, (hipStream_t)stream, g, p, bias, shortcut,
-                     scale, C, HW, ve_aligned(HW, {g, p, shortcut, gp}), gp, f);
+                     scale, C, HW, ve_aligned(HW, {g, p, shortcut, gp}), gp, (float*)ws);
+  if (gbias || gscale)
+    hipLaunchKernelGGL(van_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
+                       N * S, scale, gbias, gscale);
   return rsdet_launch_status();
 }

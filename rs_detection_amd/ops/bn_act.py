@@ -17,6 +17,20 @@ from rs_detection_amd import _lib
 _RELU_MASK = os.environ.get("RSDET_BN_RELU_MASK", "1") != "0"   # A/B switch: 0 = the backward reads y for the ReLU gate
 
 
+_SHAPE_MEMO = {}     # shape-derived answers of the library (mask bytes, workspace bytes, "NHWC kernels take C"): one ctypes
+                     # call each per (question, shape) instead of per invocation -- the trunk asks ~150 times per step
+
+
+def _memo(fn_name, *args):
+    key = (fn_name,) + args
+    v = _SHAPE_MEMO.get(key)
+    if v is None:
+        if len(_SHAPE_MEMO) > 4096:
+            _SHAPE_MEMO.clear()
+        v = _SHAPE_MEMO[key] = getattr(_lib.load(), fn_name)(*args)
+    return v
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, weight, bias, mean, var, eps, relu):
@@ -30,7 +44,7 @@ class _BNAct(torch.autograd.Function):
         # backward reads that instead of y (19 % less traffic there; RSDET_BN_RELU_MASK=0 keeps y)
         mask = None
         if ctx.nhwc and relu and _RELU_MASK and any(ctx.needs_input_grad[:4]):
-            nb = lib.rsdet_bn_act_relu_mask_bytes(N, C, H * W, int(tag == "bf16"))
+            nb = _memo("rsdet_bn_act_relu_mask_bytes", N, C, H * W, int(tag == "bf16"))
             if nb:
                 mask = torch.empty((nb,), dtype=torch.uint8, device=x.device)
         if mask is not None:
@@ -66,8 +80,8 @@ class _BNAct(torch.autograd.Function):
         gres = (torch.empty_like(gy) if ctx.relu else gy) if need_res else None
         gw = torch.empty_like(weight) if need_w else None
         gb = torch.empty_like(mean) if need_b else None
-        ws_size = lib.rsdet_bn_act_backward_nhwc_ws_size if ctx.nhwc else lib.rsdet_bn_act_backward_ws_size
-        ws_bytes = ws_size(N, C, H * W) if (need_w or need_b) else 0
+        ws_bytes = _memo("rsdet_bn_act_backward_nhwc_ws_size" if ctx.nhwc else "rsdet_bn_act_backward_ws_size", N, C,
+                         H * W) if (need_w or need_b) else 0
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gy.device) if ws_bytes else None
         tag = "bf16" if ctx.y_dtype == torch.bfloat16 else "f32"
         if ctx.has_mask:
@@ -97,7 +111,7 @@ def _layout_ok(x, other=None):
     if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last):
         if other is not None and not (other.is_contiguous(memory_format=torch.channels_last) and not other.is_contiguous()):
             return False
-        return bool(_lib.load().rsdet_bn_act_nhwc_supported(int(x.shape[1])))
+        return bool(_memo("rsdet_bn_act_nhwc_supported", int(x.shape[1])))
     return False
 
 

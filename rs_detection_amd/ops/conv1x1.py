@@ -18,13 +18,15 @@ import os
 import torch
 import torch.nn.functional as F
 
+from ._amp import light_custom_bwd, light_custom_fwd
+
 _ON = os.environ.get("RSDET_CONV1X1_GEMM", "1") == "1"   # A/B switch
 _FWD_MAX_PIXELS = 65536
 
 
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.bfloat16)
+    @light_custom_fwd(torch.bfloat16)
     def forward(ctx, x, w, bias):
         B, C, H, W = x.shape
         O = w.shape[0]
@@ -44,7 +46,7 @@ class _Conv1x1(torch.autograd.Function):
         return y
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
+    @light_custom_bwd
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         B, C, H, W = x.shape

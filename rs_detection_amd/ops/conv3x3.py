@@ -16,6 +16,8 @@ import os
 import torch
 import torch.nn.functional as F
 
+from ._amp import light_custom_bwd, light_custom_fwd
+
 _ON = os.environ.get("RSDET_CONV3X3_BWD_AS_FWD", "1") == "1"   # A/B switch
 # fp32: measured neutral on the step (50.5 vs 50.5 ms: MIOpen's fp32 backward-data solver is as fast as its forward one
 # there), so only bf16 takes this route by default
@@ -37,7 +39,7 @@ def _flipped(w):
 
 class _Conv3x3Same(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.bfloat16)
+    @light_custom_fwd(torch.bfloat16)
     def forward(ctx, x, w, bias):
         if w.dtype != x.dtype:
             w = w.to(x.dtype)
@@ -47,7 +49,7 @@ class _Conv3x3Same(torch.autograd.Function):
         return y
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
+    @light_custom_bwd
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
