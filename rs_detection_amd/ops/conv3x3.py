@@ -59,8 +59,14 @@ class _Conv3x3Same(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = F.conv2d(gy, _flipped(w), None, 1, 1)
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1]
+            # bf16 layers whose channel counts fill the kernel's 256-wide tiles: our split-K weight gradient (two
+            # launches, no zero-fill / cast launches around it); RSDET_CONV3X3_WRW_TRUNK=0 keeps MIOpen's
+            if (_WRW_TRUNK and x.dtype == torch.bfloat16 and w.shape[0] % _WRW_TRUNK_O == 0
+                    and w.shape[1] % 64 == 0):
+                gw = _mfma_wrw(gy, x, w.dtype)
+            if gw is None:
+                gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1]
         if ctx.bias_dtype is not None and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32).to(ctx.bias_dtype)
         return gx, gw, gb
@@ -70,6 +76,8 @@ class _Conv3x3Same(torch.autograd.Function):
 # The head canvas in bf16: conv + bias + ReLU + gap mask as ONE launch of our own implicit-GEMM kernel
 # (csrc/conv3x3_mfma.hip), backward-data through the same kernel on the flipped weights.
 _MFMA = os.environ.get("RSDET_CONV3X3_MFMA", "1") == "1"      # A/B switch
+_WRW_TRUNK = os.environ.get("RSDET_CONV3X3_WRW_TRUNK", "0") == "1"          # A/B switch (experiment)
+_WRW_TRUNK_O = int(os.environ.get("RSDET_CONV3X3_WRW_TRUNK_O", "256"))      # output-channel multiple it takes
 _MFMA_TM = 224                                                  # positions of one row a workgroup covers (C3_TM)
 
 
