@@ -76,8 +76,11 @@ class _Conv3x3Same(torch.autograd.Function):
 # The head canvas in bf16: conv + bias + ReLU + gap mask as ONE launch of our own implicit-GEMM kernel
 # (csrc/conv3x3_mfma.hip), backward-data through the same kernel on the flipped weights.
 _MFMA = os.environ.get("RSDET_CONV3X3_MFMA", "1") == "1"      # A/B switch
-_WRW_TRUNK = os.environ.get("RSDET_CONV3X3_WRW_TRUNK", "0") == "1"          # A/B switch (experiment)
-_WRW_TRUNK_O = int(os.environ.get("RSDET_CONV3X3_WRW_TRUNK_O", "256"))      # output-channel multiple it takes
+# the same weight-gradient kernel for the other square bf16 3x3 layers (ResNet conv2 of layers 2-4, the FPN output
+# convolutions): bf16 step 16.03 -> 15.88 ms with output-channel multiples of 128 (half-filled 256-wide tiles still beat
+# MIOpen's kernel + zero-fill + cast launches there), 15.90 with multiples of 256 only (profiles/README.md, round 4)
+_WRW_TRUNK = os.environ.get("RSDET_CONV3X3_WRW_TRUNK", "1") == "1"          # A/B switch
+_WRW_TRUNK_O = int(os.environ.get("RSDET_CONV3X3_WRW_TRUNK_O", "128"))      # output-channel multiple it takes
 _MFMA_TM = 224                                                  # positions of one row a workgroup covers (C3_TM)
 
 
