@@ -1,5 +1,7 @@
 """Does the assembled model LEARN?  Train on the rendered synthetic DOTA-format set (data/synthetic.py, render=True) and
-report the loss curve + mAP on the training images.  python profiles/scripts/learn_proof.py [s2anet|orcnn] [f32|bf16] [iters]"""
+report the loss curve + mAP on the training images.  python profiles/scripts/learn_proof.py [s2anet|orcnn] [f32|bf16] [iters]
+Environment: TILE (256; 1024 = the bench's tile, whose 196-wide head canvas takes the conv3x3_mfma kernels), MF=channels_last
+(the bench's bf16 layout), BACKBONE, LR."""
 import os
 import sys
 import time
@@ -41,7 +43,8 @@ def make_runner(model="s2anet", dtype="f32", tile=256, classes=4, lr=None, image
     cfg.max_epoch = 10 ** 6
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
-    r = Runner(cfg, device=dev, distributed=False, amp_dtype=torch.bfloat16 if dtype == "bf16" else None)
+    mf = torch.channels_last if os.environ.get("MF", "") == "channels_last" else None      # (the bench's bf16 layout)
+    r = Runner(cfg, device=dev, distributed=False, amp_dtype=torch.bfloat16 if dtype == "bf16" else None, memory_format=mf)
     r.build_datasets()
     return r
 
@@ -67,7 +70,8 @@ if __name__ == "__main__":
     model = sys.argv[1] if len(sys.argv) > 1 else "s2anet"
     dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
-    r = make_runner(model, dtype, backbone=os.environ.get("BACKBONE"), lr=float(os.environ["LR"]) if "LR" in os.environ else None)
+    r = make_runner(model, dtype, tile=int(os.environ.get("TILE", "256")), backbone=os.environ.get("BACKBONE"),
+                    lr=float(os.environ["LR"]) if "LR" in os.environ else None)
     t0 = time.time()
     losses = train(r, iters)
     print("trained %d iters in %.1f s" % (iters, time.time() - t0))
