@@ -220,6 +220,11 @@ int rsdet_nms_rotated_f32(const float* dets, int n, int box_len, const int* orde
  * a box is suppressed when IoU > thr with an earlier kept box.  keep_sorted (n) uint8, by sorted
  * position.  Workspace rsdet_nms_hbb_ws_size(n), 16-byte aligned. */
 size_t rsdet_nms_hbb_ws_size(int n);
+/* Horizontal-box IoU (iof = 0) / IoF (iof = 1) matrix, not aligned: models/boxes/iou_calculator.py:164-257 (bbox_overlaps,
+ * the default calculator of MaxIoUAssigner -- the Oriented RPN's assignment of configs/orcnn) in one pass, bit-identical to
+ * the tensor form.  boxes: rows of `stride` >= 4 floats (x1, y1, x2, y2, ...); out (n1, n2). */
+int rsdet_bbox_overlaps_f32(const float* boxes1, int n1, int stride1, const float* boxes2, int n2, int stride2, int iof,
+                            float eps, float* out, void* stream);
 int rsdet_nms_hbb_sorted_f32(const float* boxes_sorted, int n, float thr, int plus_one,
                              uint8_t* keep_sorted, void* ws, size_t ws_bytes, void* stream);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "rsdet_nms_rotated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
     "rsdet_nms_hbb_ws_size": (c_size_t, [c_int]),
+    "rsdet_bbox_overlaps_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "rsdet_nms_hbb_sorted_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_assign_ws_size": (c_size_t, [c_int]),
     "rsdet_assign_wrt_overlaps_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_float,

@@ -42,6 +42,18 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
         return bboxes1.new_zeros((rows,) if is_aligned else (rows, cols))
     a1 = (bboxes1[:, 2] - bboxes1[:, 0]) * (bboxes1[:, 3] - bboxes1[:, 1])
     a2 = (bboxes2[:, 2] - bboxes2[:, 0]) * (bboxes2[:, 3] - bboxes2[:, 1])
+    if (not is_aligned and bboxes1.is_cuda and bboxes1.dtype == torch.float32 and bboxes2.dtype == torch.float32
+            and bboxes1.dim() == 2 and bboxes2.dim() == 2 and not (bboxes1.requires_grad or bboxes2.requires_grad)):
+        # one pass instead of ten over (rows, cols[, 2]) intermediates (csrc/assign.hip: bbox_overlaps_kernel): the same
+        # operations in the same order, bit-identical; the Oriented RPN assigns 400 gts to 400 000 anchors with this
+        from rs_detection_amd import _lib
+        b1 = bboxes1 if bboxes1.stride(1) == 1 else bboxes1.contiguous()
+        b2 = bboxes2 if bboxes2.stride(1) == 1 else bboxes2.contiguous()
+        out = torch.empty((rows, cols), dtype=torch.float32, device=bboxes1.device)
+        rc = _lib.load().rsdet_bbox_overlaps_f32(_lib.ptr(b1), rows, b1.stride(0), _lib.ptr(b2), cols, b2.stride(0),
+                                                 int(mode == 'iof'), float(eps), _lib.ptr(out), _lib.stream_ptr())
+        if rc == _lib.RSDET_OK:
+            return out
     if is_aligned:
         lt = torch.max(bboxes1[:, :2], bboxes2[:, :2])
         rb = torch.min(bboxes1[:, 2:4], bboxes2[:, 2:4])

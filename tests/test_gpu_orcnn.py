@@ -221,3 +221,31 @@ def test_config3_van_b3_1024_train_step_and_eval(cuda):
     polys, scores, labels = res[0]
     assert polys.shape[1] == 8 and polys.shape[0] == scores.shape[0] == labels.shape[0]
     assert torch.isfinite(polys).all() and torch.isfinite(scores).all()
+
+
+@pytest.mark.parametrize("K,A,mode", [(37, 5000, "iou"), (400, 20011, "iou"), (1, 3, "iof"), (64, 257, "iof")])
+def test_hbb_overlaps_kernel_is_bit_identical_to_the_tensor_form(cuda, K, A, mode):
+    """models/boxes/iou_calculator.bbox_overlaps on the GPU (csrc/assign.hip: bbox_overlaps_kernel, one pass) against the
+    reference's tensor expression (iou_calculator.py:164-257) evaluated by torch on the same device: same operations in
+    the same order -> every element equal, degenerate and disjoint boxes included; 5-column inputs (a score column) are
+    read through their row stride."""
+    from rs_detection_amd.models.boxes.iou_calculator import BboxOverlaps2D
+    g = torch.Generator().manual_seed(K + A)
+    def boxes(n):
+        xy = torch.rand((n, 2), generator=g) * 900
+        wh = torch.rand((n, 2), generator=g) * 200
+        b = torch.cat([xy, xy + wh, torch.rand((n, 1), generator=g)], 1)
+        b[::7, 2:4] = b[::7, :2]                              # zero-area boxes
+        return b.to(cuda)
+    b1, b2 = boxes(K), boxes(A)
+    got = BboxOverlaps2D()(b1, b2, mode)
+    x1, x2 = b1[:, :4], b2[:, :4]
+    a1 = (x1[:, 2] - x1[:, 0]) * (x1[:, 3] - x1[:, 1])
+    a2 = (x2[:, 2] - x2[:, 0]) * (x2[:, 3] - x2[:, 1])
+    lt = torch.max(x1[:, None, :2], x2[None, :, :2])
+    rb = torch.min(x1[:, None, 2:4], x2[None, :, 2:4])
+    wh = (rb - lt).clamp(min=0)
+    ov = wh[..., 0] * wh[..., 1]
+    union = a1[:, None] + a2[None, :] - ov if mode == "iou" else a1[:, None].expand_as(ov)
+    want = ov / torch.max(union, union.new_tensor(1e-6))
+    assert got.shape == want.shape and torch.equal(got, want)
