@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from rs_detection_amd.ops import van_fused
 from rs_detection_amd.ops.bn_act import scale_residual
+from rs_detection_amd.ops.conv1x1 import conv1x1_nchw
 from rs_detection_amd.ops.dwconv import DepthwiseConv2d
 from rs_detection_amd.utils.registry import BACKBONES
 
@@ -58,7 +59,7 @@ class Mlp(nn.Module):
 
     def hidden(self, x):
         """Everything up to fc2's input."""
-        h = F.conv2d(x, self.fc1.weight, None)
+        h = conv1x1_nchw(x, self.fc1.weight)
         return self.drop(self.act(self.dwconv(h, self.fc1.bias)))
 
 
@@ -73,7 +74,7 @@ class AttentionModule(nn.Module):
         # u * (conv1(...) + bias): the 1x1 convolution without its bias, bias + gate as one pass (ops/van_fused.py)
         a = self.conv_spatial(self.conv0(x))
         if van_fused.applies(x):
-            return van_fused.gate(x, F.conv2d(a, self.conv1.weight, None), self.conv1.bias)
+            return van_fused.gate(x, conv1x1_nchw(a, self.conv1.weight), self.conv1.bias)
         return x * self.conv1(a)
 
 
@@ -91,7 +92,7 @@ class SpatialAttention(nn.Module):
     def gated(self, x):
         """Everything up to proj_2's input; proj_1's bias + GELU as one pass when the fused kernels apply."""
         if van_fused.applies(x) and isinstance(self.activation, nn.GELU) and self.activation.approximate == 'none':
-            u = van_fused.bias_gelu(F.conv2d(x, self.proj_1.weight, None), self.proj_1.bias)
+            u = van_fused.bias_gelu(conv1x1_nchw(x, self.proj_1.weight), self.proj_1.bias)
         else:
             u = self.activation(self.proj_1(x))
         return self.spatial_gating_unit(u)
@@ -129,9 +130,9 @@ class Block(nn.Module):
             # + residual as ONE pass each way (ops/van_fused.py); nothing sits between them when drop-path and dropout
             # are inactive
             xn = self.norm1(x)
-            p = F.conv2d(self.attn.gated(xn), self.attn.proj_2.weight, None)
+            p = conv1x1_nchw(self.attn.gated(xn), self.attn.proj_2.weight)
             x = van_fused.residual(x, p, self.attn.proj_2.bias, xn, self.layer_scale_1)
-            p = F.conv2d(self.mlp.hidden(self.norm2(x)), self.mlp.fc2.weight, None)
+            p = conv1x1_nchw(self.mlp.hidden(self.norm2(x)), self.mlp.fc2.weight)
             return van_fused.residual(x, p, self.mlp.fc2.bias, None, self.layer_scale_2)
         x = scale_residual(x, self.drop_path(self.attn(self.norm1(x))), self.layer_scale_1)
         return scale_residual(x, self.drop_path(self.mlp(self.norm2(x))), self.layer_scale_2)

@@ -79,3 +79,53 @@ def conv1x1(conv, x):
     if conv1x1_applies(conv, x):
         return _Conv1x1.apply(x, conv.weight, conv.bias)
     return conv(x)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# NCHW fp32 maps (the VAN backbone of Oriented R-CNN): the weight gradient of a 1x1 convolution on LARGE maps as a
+# split-K batched GEMM on strided views.  gw = sum_{n, s} gy[n][:, K-slice s] @ x[n][:, K-slice s]^T: both operands are
+# K-contiguous as they lie (no layout change), where MIOpen's best solver for this layout is an NHWC kernel between two
+# transposes and a zero-fill.  Device time per call (profiles/README.md, round 4; 2 tiles): 64 -> 512 at 256^2 206 ->
+# 94 us, 128 -> 1024 at 128^2 146 -> 87 us, 64 -> 64 46 -> 32 us; from 64^2 maps down MIOpen is as fast or faster and
+# keeps the call.  Forward and backward-data stay with MIOpen.
+_NCHW_WRW = os.environ.get("RSDET_CONV1X1_NCHW_WRW", "1") == "1"     # A/B switch
+_NCHW_WRW_MIN_PIXELS = 128 * 128
+_NCHW_WRW_SPLITS = 16
+
+
+class _Conv1x1NCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                     (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            N, C, H, W = x.shape
+            O, HW, S = w.shape[0], H * W, _NCHW_WRW_SPLITS
+            k = HW // S
+            part = torch.empty((N * S, O, C), dtype=x.dtype, device=x.device)
+            for n in range(N):
+                a = gy[n].view(O, S, k).permute(1, 0, 2)            # (S, O, k): strides (k, HW, 1)
+                b = x[n].view(C, S, k).permute(1, 2, 0)             # (S, k, C): strides (k, 1, HW)
+                torch.bmm(a, b, out=part[n * S:(n + 1) * S])
+            gw = part.sum(0).view(O, C, 1, 1)
+        return gx, gw
+
+
+def conv1x1_nchw(x, weight):
+    """``F.conv2d(x, weight)`` for a bias-free 1x1 convolution; on large NCHW fp32 CUDA maps outside autocast the weight
+    gradient is the split-K batched GEMM above."""
+    if (_NCHW_WRW and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.is_contiguous() and not torch.is_autocast_enabled() and torch.is_grad_enabled() and weight.requires_grad
+            and tuple(weight.shape[2:]) == (1, 1) and x.shape[2] * x.shape[3] >= _NCHW_WRW_MIN_PIXELS
+            and (x.shape[2] * x.shape[3]) % (_NCHW_WRW_SPLITS * 64) == 0):
+        return _Conv1x1NCHW.apply(x, weight)
+    return F.conv2d(x, weight, None)

@@ -111,3 +111,26 @@ def test_van_block_fused_equals_unfused(cuda, monkeypatch):
     names = ["y", "gx"] + [n for n, _ in blocks.named_parameters()]
     for n, a, b in zip(names, *outs):
         assert float((a - b).abs().max()) <= 2e-4 * (float(b.abs().max()) + 1e-6), n
+
+
+@pytest.mark.parametrize("C,O,H,W", [(64, 512, 128, 128), (128, 64, 128, 256), (64, 64, 256, 256)])
+def test_conv1x1_nchw_split_k_weight_gradient(cuda, C, O, H, W):
+    """ops/conv1x1.conv1x1_nchw: forward and input gradient are MIOpen's; the weight gradient is a split-K batched GEMM
+    on strided views of the NCHW maps -- against nn.functional.conv2d's own gradients (fp32 sums in another order)."""
+    from rs_detection_amd.ops import conv1x1 as c1
+    torch.manual_seed(C + O)
+    x = torch.randn((2, C, H, W), device=cuda)
+    w = torch.randn((O, C, 1, 1), device=cuda) * 0.05
+    g = torch.randn((2, O, H, W), device=cuda)
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = c1.conv1x1_nchw(xa, wa)
+    assert "Conv1x1NCHW" in type(y.grad_fn).__name__
+    y.backward(g)
+    xb, wb = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y2 = F.conv2d(xb, wb)
+    y2.backward(g)
+    assert torch.equal(y.detach(), y2.detach())
+    _close(xa.grad, xb.grad, 1e-6)
+    _close(wa.grad, wb.grad, 2e-5)
+    small = torch.randn((2, C, 32, 32), device=cuda, requires_grad=True)
+    assert "Conv1x1NCHW" not in type(c1.conv1x1_nchw(small, wa).grad_fn).__name__      # small maps stay with MIOpen
