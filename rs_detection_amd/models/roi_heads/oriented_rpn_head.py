@@ -167,12 +167,14 @@ class OrientedRPNHead(nn.Module):
         if len(pos_inds) > 0:
             pos_t = sampling_result.pos_gt_bboxes if self.reg_decoded_bbox else \
                 self.bbox_coder.encode(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes)
+            # (index_fill_ for the constants: `t[idx] = 1.0` builds the value on the host and copies it over, one device
+            #  synchronisation per statement)
             bbox_targets[pos_inds, :] = pos_t
-            bbox_weights[pos_inds, :] = 1.0
-            labels[pos_inds] = 1  # only the RPN passes gt_labels=None: FG is 1 (:323-325)
-            label_weights[pos_inds] = 1.0 if self.pos_weight <= 0 else self.pos_weight
+            bbox_weights.index_fill_(0, pos_inds, 1.0)
+            labels.index_fill_(0, pos_inds, 1)  # only the RPN passes gt_labels=None: FG is 1 (:323-325)
+            label_weights.index_fill_(0, pos_inds, 1.0 if self.pos_weight <= 0 else float(self.pos_weight))
         if len(neg_inds) > 0:
-            label_weights[neg_inds] = 1.0
+            label_weights.index_fill_(0, neg_inds, 1.0)
         if self.unmap_outputs:
             total = flat_anchors.size(0)
             labels = self.unmap(labels, total, inside, fill=self.background_label)
