@@ -106,8 +106,12 @@ def event_time(fn, iters, warmup=3, graph=True):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-ROOFLINE_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_roofline.json" % r) for r in (4, 3, 2))
-                      if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04_roofline.json"))
+ROOFLINE_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_roofline.json" % r) for r in (5, 4, 3, 2))
+                      if os.path.exists(f)), os.path.join(ROOT, "profiles", "r05_roofline.json"))
+# `traffic` (PMC bytes) and `issue` (SQ counters) of the roofline objects are NOT measured by this process (rocprofv3
+# counter passes cannot run inside it): they are read from the committed counter table and labelled so in the line
+COUNTER_SOURCE = "committed profile: profiles/%s (rocprofv3 --pmc passes of profiles/scripts/roofline.sh)" % \
+    os.path.basename(ROOFLINE_FILE)
 FAST_ROW = "box_iou_rotated_fast(two-tier clipper, 1 launch; prepared anchors cached, gts prepared in the tile)"
 AT_ROW = "anchor_target_rotated(fused: IoU + assign + encode + weights; 2 launches)"
 BN_ROW = "bn_act_forward_kernel<f32>(bn + residual + relu; 4x256x256x256, NCHW)"
@@ -487,6 +491,68 @@ def timed_region(runner, batches, steps, rdist, device):
     return dt, loss_v, t_enq
 
 
+def extra_leg(model, amp, mf, steps, rank, device, rdist, bf16_params):
+    """A short timed leg of ANOTHER BASELINE config on this GPU (own Runner, own resident batches, torn down after):
+    {value tiles/s, ms_per_step, host_enqueue_ms_per_step, steps}.  Same timed_region as the headline."""
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.runner.runner import Runner
+    if model == "orcnn_van3":
+        cfg, batch, ncls = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")), 2, 10
+    else:
+        cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r101_fpn_1x_dota_rotate_balance_ms.py"))
+        batch, ncls = BATCH_PER_GPU, 15
+    torch.manual_seed(0)
+    r = Runner(cfg, device=device, memory_format=mf, amp_dtype=amp, bf16_params=bf16_params)
+    bs = make_batches(N_BATCHES, batch, rank, ncls, device, mf, model == "orcnn_van3")
+    for i in range(2 * N_BATCHES):
+        r.train_step(*bs[i % N_BATCHES])
+    dt, loss, enq = timed_region(r, bs, steps, rdist, device)
+    out = {"value": batch * steps / dt, "unit": "tiles/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "host_enqueue_ms_per_step": enq / steps * 1e3, "final_loss": loss, "tiles_per_step": batch,
+           "dtype": "bf16" if amp is not None else "f32"}
+    del r, bs
+    torch.cuda.empty_cache()
+    return out
+
+
+def ddp_overhead_leg(cfg, device, b16, steps, warm, bf16_params, rdist, enq_plain_ms, ms_plain):
+    """The bf16 S2ANet leg again with DDP FORCED ON in a one-rank ``nccl`` (= RCCL) process group: the reducer's bucket
+    views, the bf16 compress hook and one all-reduce per bucket through RCCL run on this single GPU.  What it reports
+    is the host time DDP adds to the enqueue of a step (the bf16 step is host-paced: this, not xGMI, is the first
+    scaling risk of one Python process per GPU).  Any failure to bring RCCL up is reported in the object, not raised."""
+    import torch.distributed as dist
+    from rs_detection_amd.runner.runner import Runner
+    made = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(rdist.free_port()))
+            dist.init_process_group(backend="nccl", rank=0, world_size=1)
+            made = True
+        torch.manual_seed(0)
+        r = Runner(cfg, device=device, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
+                   bf16_params=bf16_params, distributed="force")
+        assert r.ddp is not r.model
+        for i in range(warm):
+            r.train_step(*b16[i % N_BATCHES])
+        dt, loss, enq = timed_region(r, b16, steps, rdist, device)
+        out = {"backend": dist.get_backend(), "world": 1, "ms_per_step": dt / steps * 1e3,
+               "host_enqueue_ms_per_step": enq / steps * 1e3, "host_overhead_ms": enq / steps * 1e3 - enq_plain_ms,
+               "step_overhead_ms": dt / steps * 1e3 - ms_plain, "final_loss": loss,
+               "grad_wire_dtype": "bf16" if r.grad_dtype == torch.bfloat16 else "f32"}
+        del r
+    except Exception as e:  # noqa: BLE001
+        out = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    finally:
+        if made:
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+    torch.cuda.empty_cache()
+    return out
+
+
 def fresh_k_batches(batches, n, rank, ncls, device, orcnn):
     """`n` target sets with a K tuple never seen before (a real DOTA stream brings new gt counts every step),
     on the images of the resident batches: every step then misses the per-K-tuple tile table of the anchor-target path
@@ -524,7 +590,10 @@ def main():
     ap.add_argument("--kernels-out", default=None, help="where the full per-kernel table goes (default: "
                     "gpurun_out/bench_kernels.json when that directory exists, else ./bench_kernels.json); the JSON "
                     "line itself carries the 12 rows with the most time")
-    ap.add_argument("--bf16-params", choices=["0", "1"], default=os.environ.get("RSDET_BF16_PARAMS", "1"),
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short Oriented R-CNN VAN-B3 (configs[3]) / S2ANet-R101 bf16 (configs[4]) / DDP-overhead "
+                         "legs the default single-GPU line carries as flat scalars")
+    ap.add_argument("--bf16-params", choices=["0", "1"], default="1",
                     help="bf16 legs: conv / linear weights held in bf16 with fp32 masters in the fused optimizer "
                          "(csrc/optim.hip; 1, default) or fp32 parameters under autocast + foreach SGD (0)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -603,19 +672,16 @@ def main():
     if not args.no_kernels:
         # one extra UNTIMED step under torch's flop counter (convs + GEMMs, fwd + bwd).  On EVERY rank: the step
         # contains DDP's gradient all-reduce, a rank that skipped it would leave the others hanging.
-        # Counted on the reference's level-by-level head (RSDET_S2A_PACKED=0 for this one step): the canvas of the timed
-        # step convolves 13-15 % gap pixels too, and those are not algorithmic flops.
+        # Counted on the reference's level-by-level head (``bbox_head.packed = False`` for this one step): the canvas of
+        # the timed step convolves 13-15 % gap pixels too, and those are not algorithmic flops.
         from torch.utils.flop_counter import FlopCounterMode
-        prev = os.environ.get("RSDET_S2A_PACKED")
-        os.environ["RSDET_S2A_PACKED"] = "0"
+        head = runner.model.bbox_head
+        head.packed = False
         try:
             with FlopCounterMode(display=False) as fc:
                 runner.train_step(images, targets)
         finally:
-            if prev is None:
-                del os.environ["RSDET_S2A_PACKED"]
-            else:
-                os.environ["RSDET_S2A_PACKED"] = prev
+            head.packed = True
         step_flops = float(fc.get_total_flops())
     orcnn = args.model == "orcnn_van3"
     timed_batches = batches
@@ -662,8 +728,31 @@ def main():
                     "flop_roofline": None if step_flops is None else {
                         "bound": "mfma", "achieved": step_flops / (dt16 / steps16) / 1e12, "unit": "TFLOP/s",
                         "peak": 2500.0, "frac": step_flops / (dt16 / steps16) / 1e12 / 2500.0}}
-        del r16, b16
+        del r16
         torch.cuda.empty_cache()
+        # what DDP adds to the HOST side of that (host-paced) step: the same leg under an `nccl` (= RCCL) process group of
+        # one rank with DDP forced on -- bucket views, bf16 compress hook, one all-reduce per bucket through RCCL
+        ddp_leg = None
+        if world == 1 and not args.no_extra_legs:
+            ddp_leg = ddp_overhead_leg(cfg, device, b16, steps16, warm16, args.bf16_params == "1", rdist,
+                                       enq16 / steps16 * 1e3, dt16 / steps16 * 1e3)
+        del b16
+        torch.cuda.empty_cache()
+    else:
+        ddp_leg = None
+
+    # the other BASELINE configs' single-GPU numbers, as short legs with their own Runner (flat scalars in the line)
+    extra = {}
+    if args.dtype == "f32" and args.model == "s2anet_r50" and world == 1 and not args.no_extra_legs:
+        try:
+            del runner
+        except NameError:
+            pass
+        del batches
+        torch.cuda.empty_cache()
+        extra["r101_bf16"] = extra_leg("s2anet_r101", torch.bfloat16, torch.channels_last, 12, rank, device, rdist,
+                                       args.bf16_params == "1")
+        extra["orcnn"] = extra_leg("orcnn_van3", None, None, 8, rank, device, rdist, False)
 
     if rank != 0:
         rdist.barrier()          # rank 0 is still timing its kernel table: leave the group together
@@ -721,6 +810,17 @@ def main():
         "bf16_ms_per_step": bf16_leg["ms_per_step"] if bf16_leg else None,
         "bf16_flop_frac": bf16_leg["flop_roofline"]["frac"] if bf16_leg and bf16_leg["flop_roofline"] else None,
         "bf16_host_enqueue_ms_per_step": bf16_leg["host_enqueue_ms_per_step"] if bf16_leg else None,
+        # configs[4]'s model (S2ANet-R101-FPN, bf16 autocast, channels_last, 4 tiles) and configs[3]'s (Oriented R-CNN +
+        # VAN-B3, fp32, 2 tiles) on this one GPU: short legs, own Runner each (`--model s2anet_r101 --dtype bf16` /
+        # `--model orcnn_van3` time them in full)
+        "r101_bf16_tiles_per_s": extra["r101_bf16"]["value"] if extra.get("r101_bf16") else None,
+        "r101_bf16_ms_per_step": extra["r101_bf16"]["ms_per_step"] if extra.get("r101_bf16") else None,
+        "r101_bf16_host_enqueue_ms_per_step": extra["r101_bf16"]["host_enqueue_ms_per_step"] if extra.get("r101_bf16") else None,
+        "orcnn_tiles_per_s": extra["orcnn"]["value"] if extra.get("orcnn") else None,
+        "orcnn_ms_per_step": extra["orcnn"]["ms_per_step"] if extra.get("orcnn") else None,
+        "orcnn_host_enqueue_ms_per_step": extra["orcnn"]["host_enqueue_ms_per_step"] if extra.get("orcnn") else None,
+        "ddp_host_overhead_ms": ddp_leg.get("host_overhead_ms") if ddp_leg else None,
+        "ddp": ddp_leg,
         "rotated_iou_mpairs_per_s": dense["mpairs_per_s"] if dense else None,
         # the oriented-box call the timed step itself makes (twice per step: FAM and ODM targets).  Priced against HBM as
         # the contract asks; its algorithmic bytes are tiny (no K x A matrix is written), so the HBM fraction only says
@@ -728,9 +828,11 @@ def main():
         "roofline": ({k: roof[k] for k in keys} | {
             "bound": "hbm", "bound_note": "latency / VALU-issue bound (5.3 MB algorithmic per call)",
             "kernel": "rsdet_anchor_target_rotated_f32 (tile + finish launches)",
-            "traffic_source": "profiles/%s" % os.path.basename(ROOFLINE_FILE),
+            "source": {"us_per_launch / achieved / frac": "measured in this run (HIP events)",
+                       "traffic / issue": COUNTER_SOURCE},
             "us_per_launch": roof["us"], "shape": dense["shape"] if dense else None,
             "issue": issue.get("anchor_target")}) if roof else None,
+        "counter_source": COUNTER_SOURCE,
         # the standalone north-star kernel (dense K x A rotated IoU, the matrix written to HBM), not on the step's path
         "roofline_dense_iou": ({k: dense[k] for k in keys} | {
             "kernel": "rsdet_box_iou_rotated_grouped_f32 (bit-exact, 3 launches)",

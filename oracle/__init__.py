@@ -10,6 +10,9 @@ Two layers:
   this repo's own restatement, each function citing reference file:line);
 * ``oracle.ref`` -- ctypes bindings of ``_ref/libjdet_ref.so`` = the reference's own
   embedded CPU sources compiled by ``build_ref.py`` (None when not built);
+* ``oracle.ref_hip`` -- ctypes bindings of ``_ref/libjdet_ref_hip.so`` = the reference's CUDA-only
+  kernels (DCN, RROIAlign, FeatureRefine, poly NMS) compiled AS DEVICE CODE for gfx950 by
+  ``build_ref_hip.py`` (hipcc, no macro shim): takes torch CUDA tensors, GPU tests only;
 * NumPy restatements of the reference's Jittor tensor code (box coder, anchor
   grid, AlignConv offsets, losses) in ``oracle.np_*`` functions below.
 
@@ -52,6 +55,9 @@ def build(force=False):
     ref = os.path.join(_HERE, "_ref", "libjdet_ref.so")
     if os.path.isdir("/root/reference") and (force or not os.path.exists(ref)):
         subprocess.check_call(["python3", os.path.join(_HERE, "build_ref.py")])
+    ref_hip = os.path.join(_HERE, "_ref", "libjdet_ref_hip.so")
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(ref_hip)):
+        subprocess.check_call(["python3", os.path.join(_HERE, "build_ref_hip.py")])
 
 
 class _COracle:
@@ -323,8 +329,128 @@ class _RefOracle:
         return gi.reshape(grad_out.shape)
 
 
+class _RefHipOracle:
+    """The reference's CUDA-only kernels as gfx950 device code (oracle/build_ref_hip.py).  Arguments and results are
+    torch CUDA tensors (float32, contiguous); every call runs on the null stream between two device synchronisations.
+    ``available`` is False when the library was not built (no /root/reference at build time)."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "_ref", "libjdet_ref_hip.so")
+        self.available = os.path.exists(path)
+        self.lib = ctypes.CDLL(path) if self.available else None
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _run(self, fn, *args):
+        import torch
+        torch.cuda.synchronize()
+        rc = fn(*args)
+        torch.cuda.synchronize()
+        assert rc == 0, "reference HIP launch failed: %d" % rc
+
+    @staticmethod
+    def _g(geom):
+        return [int(geom[k]) for k in ("kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw")]
+
+    def deform_im2col(self, im, offset, geom, dg=1):
+        """dcn_v1.py:309-339; im (B,C,H,W), offset (B,2*kh*kw*dg,Ho,Wo) -> columns (C*kh*kw, B, Ho, Wo)."""
+        import torch
+        B, C, H, W = im.shape
+        Ho, Wo = offset.shape[2:]
+        kh, kw = int(geom["kh"]), int(geom["kw"])
+        col = torch.empty((C * kh * kw, B, Ho, Wo), dtype=torch.float32, device=im.device)
+        self._run(self.lib.ref_hip_dcn_im2col, self._p(im.contiguous()), self._p(offset.contiguous()), C, H, W,
+                  *self._g(geom), B, dg, self._p(col))
+        return col
+
+    def deform_col2im(self, col, offset, im_shape, geom, dg=1):
+        """dcn_v1.py:376-410 -> grad_im (B,C,H,W)."""
+        import torch
+        B, C, H, W = im_shape
+        gim = torch.empty((B, C, H, W), dtype=torch.float32, device=col.device)
+        self._run(self.lib.ref_hip_dcn_col2im, self._p(col.contiguous()), self._p(offset.contiguous()), C, H, W,
+                  *self._g(geom), B, dg, self._p(gim))
+        return gim
+
+    def deform_col2im_coord(self, col, im, offset, geom, dg=1):
+        """dcn_v1.py:341-373 -> grad_offset, same shape as offset."""
+        import torch
+        B, C, H, W = im.shape
+        goff = torch.empty_like(offset.contiguous())
+        self._run(self.lib.ref_hip_dcn_col2im_coord, self._p(col.contiguous()), self._p(im.contiguous()),
+                  self._p(offset.contiguous()), C, H, W, *self._g(geom), B, dg, self._p(goff))
+        return goff
+
+    def rroi_forward(self, feat, rois, out_hw, scale, sample_num):
+        """roi_align_rotated_v1.py:300-325."""
+        import torch
+        N, C, H, W = feat.shape
+        R = rois.shape[0]
+        out = torch.empty((R, C, out_hw[0], out_hw[1]), dtype=torch.float32, device=feat.device)
+        self._run(self.lib.ref_hip_rroi_forward, self._p(feat.contiguous()), self._p(rois.contiguous()), R, C, H, W,
+                  out_hw[0], out_hw[1], ctypes.c_float(scale), ctypes.c_float(sample_num), self._p(out))
+        return out
+
+    def rroi_backward(self, grad_out, rois, feat_shape, scale, sample_num):
+        """roi_align_rotated_v1.py:327-351."""
+        import torch
+        N, C, H, W = feat_shape
+        R, _, PH, PW = grad_out.shape
+        g = torch.empty((N, C, H, W), dtype=torch.float32, device=grad_out.device)
+        self._run(self.lib.ref_hip_rroi_backward, self._p(grad_out.contiguous()), self._p(rois.contiguous()), R, N, C, H,
+                  W, PH, PW, ctypes.c_float(scale), ctypes.c_float(sample_num), self._p(g))
+        return g
+
+    def fr_forward(self, feat, boxes, scale, points):
+        """fr.py:234-240; boxes (N,H,W,5)."""
+        import torch
+        N, C, H, W = feat.shape
+        out = torch.empty_like(feat.contiguous())
+        self._run(self.lib.ref_hip_fr_forward, self._p(feat.contiguous()), self._p(boxes.contiguous()), N, C, H, W,
+                  int(points), ctypes.c_float(scale), self._p(out))
+        return out
+
+    def fr_backward(self, top, boxes, scale, points):
+        """fr.py:244-252."""
+        import torch
+        N, C, H, W = top.shape
+        out = torch.empty_like(top.contiguous())
+        self._run(self.lib.ref_hip_fr_backward, self._p(top.contiguous()), self._p(boxes.contiguous()), N, C, H, W,
+                  int(points), ctypes.c_float(scale), self._p(out))
+        return out
+
+    def poly_nms_sorted(self, boxes_sorted, thr):
+        """nms_poly.py:197-229 on score-sorted (n, 9) boxes -> bool keep (n,) in the sorted order."""
+        n = boxes_sorted.shape[0]
+        keep = np.zeros(n, np.uint8)
+        if n:
+            self._run(self.lib.ref_hip_poly_nms, self._p(boxes_sorted.contiguous()), n, ctypes.c_float(thr), _up(keep))
+        return keep.astype(bool)
+
+    def poly_iou_pairs(self, p, q):
+        """devPolyIoU (nms_poly.py:135-150) of p[i], q[i] (n, 8) each."""
+        import torch
+        out = torch.empty((p.shape[0],), dtype=torch.float32, device=p.device)
+        if p.shape[0]:
+            self._run(self.lib.ref_hip_poly_iou_pairs, self._p(p.contiguous()), self._p(q.contiguous()), p.shape[0],
+                      self._p(out))
+        return out
+
+
 _c = None
 _ref = None
+_ref_hip = None
+
+
+def ref_hip():
+    global _ref_hip
+    if _ref_hip is None:
+        build()
+        _ref_hip = _RefHipOracle()
+    return _ref_hip
+
 
 
 def c():

@@ -251,7 +251,6 @@ def check(rc, what):
 
 
 _RAW_STREAM = None
-_SLOW_STREAM = os.environ.get("RSDET_SLOW_STREAM", "0") == "1"   # A/B switch
 
 
 def stream_ptr():
@@ -263,7 +262,7 @@ def stream_ptr():
     if _RAW_STREAM is None:
         get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
         _RAW_STREAM = (get, dev) if (get is not None and dev is not None) else False
-    if _RAW_STREAM and not _SLOW_STREAM:
+    if _RAW_STREAM:
         return ctypes.c_void_p(_RAW_STREAM[0](_RAW_STREAM[1]()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

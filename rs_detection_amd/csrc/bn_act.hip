@@ -516,13 +516,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc_kernel(const T* __re
   }
 }
 
-static inline bool bn_vec8() {   // A/B switch: RSDET_BN_VEC8=0 keeps the four-channel bf16 kernels
-  static const bool on = [] {
-    const char* e = getenv("RSDET_BN_VEC8");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+static inline bool bn_vec8() { return true; }   // the eight-channel bf16 kernels wherever C % 8 == 0
 
 // rows per workgroup / number of workgroups of the NHWC backward
 static inline void bn_nhwc_split(long long rows, int C, int* rows_per, int* S, int vec = 4) {
@@ -531,12 +525,8 @@ static inline void bn_nhwc_split(long long rows, int C, int* rows_per, int* S, i
   long long per = (long long)RL * 8;                       // ~8 rows per thread
   long long s = (rows + per - 1) / per;
   // slices the finish kernel folds.  2 048: bf16 step 18.7 -> 18.3 ms against 4 096 (the finish reads half the
-  // partials), 512 starves the main pass (19.1); fp32 step flat (profiles/r03_canvas_ab.txt).  RSDET_BN_SCAP: A/B.
-  static const long long cap = [] {
-    const char* e = getenv("RSDET_BN_SCAP");
-    const long long v = e ? atoll(e) : 0;
-    return v >= 64 ? v : 2048LL;
-  }();
+  // partials), 512 starves the main pass (19.1); fp32 step flat (profiles/r03_canvas_ab.txt).
+  const long long cap = 2048;
   if (s > cap) {
     s = cap;
     per = (rows + s - 1) / s;

@@ -113,6 +113,8 @@ class S2ANetHead(nn.Module):
         self.anchor_generators = [AnchorGeneratorRotatedS2ANet(b, anchor_scales, anchor_ratios)
                                   for b in self.anchor_base_sizes]
         self.base_anchors = dict()  # anchor cache, keyed (level, featmap_size, device)
+        self.packed = True          # shared-weight towers on the pyramid canvas (forward_packed); False = the level loop
+        self.canvas_groups = None   # None = by dtype (_level_groups); 'all' | 'split'
         self._built = {}
         self._init_anchor_cat = {}   # level-concatenated grid per (featmap sizes, device)
         self._init_layers()
@@ -230,11 +232,8 @@ class S2ANetHead(nn.Module):
         """Both losses of one module over all levels as one HIP pass each way (ops/s2a_loss.py, csrc/losses.hip) --
         when the configured modules are the sigmoid FocalLoss + SmoothL1Loss with 'mean' reduction, the maps are on the
         GPU in one storage type, and the regression loss is on the encoded deltas.  None otherwise."""
-        import os
         from rs_detection_amd.models.losses.focal_loss import FocalLoss
         from rs_detection_amd.models.losses.smooth_l1_loss import SmoothL1Loss
-        if os.environ.get("RSDET_NO_FUSED_LOSS", "0") == "1":
-            return None
         if type(cls_loss) is not FocalLoss or type(bbox_loss) is not SmoothL1Loss:
             return None
         if cls_loss.reduction != 'mean' or bbox_loss.reduction != 'mean' or cfg.get('reg_decoded_bbox', False):
@@ -372,10 +371,9 @@ class S2ANetHead(nn.Module):
         return gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore
 
     def _packed_ok(self, feats):
-        """The canvas path (forward_packed) applies to GPU feature maps of one dtype / shape family; CPU tensors and the
-        A/B switch RSDET_S2A_PACKED=0 take the reference's per-level loop."""
-        import os
-        if os.environ.get("RSDET_S2A_PACKED", "1") == "0" or len(feats) < 2 or len(feats) > 8:
+        """The canvas path (forward_packed) applies to GPU feature maps of one dtype / shape family; CPU tensors and a
+        head with ``packed = False`` (tests, the bench's flop count) take the reference's per-level loop."""
+        if not self.packed or len(feats) < 2 or len(feats) > 8:
             return False
         f0 = feats[0]
         return (f0.is_cuda and f0.dtype in (torch.float32, torch.bfloat16)
@@ -445,9 +443,8 @@ class S2ANetHead(nn.Module):
         forward_single: no canvas, no gap pixels to pay for) + one canvas for the small levels.  Measured on the step
         (4 x 1024^2, profiles/r03_canvas_ab.txt): the fp32 step is GPU-bound and the all-levels canvas has 15 % more
         pixels than the five maps together, so 'split' wins there (57.3 -> 55.9 ms; 'all' 59.6); the bf16 step is bound
-        by launches, so 'all' wins (22.7 -> 19.9 ms; 'split' 20.3).  RSDET_S2A_GROUPS overrides."""
-        import os
-        mode = os.environ.get("RSDET_S2A_GROUPS") or ("all" if dtype == torch.bfloat16 else "split")
+        by launches, so 'all' wins (22.7 -> 19.9 ms; 'split' 20.3).  ``self.canvas_groups`` ('all' | 'split') overrides."""
+        mode = self.canvas_groups or ("all" if dtype == torch.bfloat16 else "split")
         if mode == "split" and n > 2:
             return [(0, 1), (1, n)]
         return [(0, n)]

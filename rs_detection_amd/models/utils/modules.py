@@ -15,8 +15,8 @@ from rs_detection_amd.ops.conv3x3 import (conv3x3_applies, conv3x3_same, fast_co
 from rs_detection_amd.utils.registry import BRICKS, build_from_cfg
 from .weight_init import kaiming_init, constant_init
 
-_FUSE_BIAS_RELU = os.environ.get("RSDET_NO_FUSED_BIAS_RELU", "0") != "1"  # A/B switch
-_FUSE_BIAS_RELU_AMP = os.environ.get("RSDET_FUSED_BIAS_RELU_AMP", "1") == "1"  # A/B switch: also under bf16 autocast
+_FUSE_BIAS_RELU = True
+_FUSE_BIAS_RELU_AMP = True      # also under bf16 autocast
 
 BRICKS.register_module(name="Conv2d", module=nn.Conv2d)
 BRICKS.register_module(name="ReLU", module=nn.ReLU)

@@ -22,6 +22,10 @@ def light_custom_fwd(cast_inputs):
                         ctx._light_amp = False
                         return slow(ctx, *args)
                 ctx._light_amp = True
+                # what custom_fwd(cast_inputs=...) would leave on the context: if backward() is called INSIDE an autocast
+                # block the wrapper below falls to torch's custom_bwd, which reads these two
+                ctx._fwd_used_autocast = False
+                ctx._dtype = torch.get_autocast_dtype('cuda')
                 return fwd(ctx, *args)
             ctx._light_amp = False
             return slow(ctx, *args)

@@ -285,15 +285,14 @@ def anchor_target_rotated(anchors, gt_cat, gt_labels_cat, row_offsets, ks, pos_i
     anchors (A,5) shared or (G,A,5) per image; gt_cat (sumK,5); gt_labels_cat (sumK,) int32 or None;
     row_offsets (G+1) int32 on the device; ks: the same counts as Python ints (host-known, no sync).
 
-    ``two_tier`` (default False; ``RSDET_AT_TWO_TIER=1`` flips the default): the Green-integral IoU on every
+    ``two_tier`` (default False): the Green-integral IoU on every
     overlapping pair and the reference-order clipper only where a decision could depend on the difference
     (include/rsdet.h).  Every output but ``max_overlaps`` is bit-identical to ``two_tier=False``.  Measured at the
     S2ANet step shape: 50.6 us against 46.7 for the all-exact form -- nearly every 16 x 256 tile still needs ONE round
     of the clipper (the candidates for its gts' row maxima), and one round is what the all-exact form needs for a
     typical tile too; the launch is bound by that per-tile latency chain, not by clipper throughput.  It
     does 9x less clipper work, which is what matters when gts are dense (hundreds of gts per tile region)."""
-    if two_tier is None:
-        two_tier = os.environ.get("RSDET_AT_TWO_TIER", "0") == "1"
+    two_tier = bool(two_tier)
     _lib.require_cuda_f32(anchors, gt_cat)
     lib = _lib.load()
     an, gt = anchors.contiguous(), gt_cat.contiguous()

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from rs_detection_amd import _lib
 
 
-_RELU_MASK = os.environ.get("RSDET_BN_RELU_MASK", "1") != "0"   # A/B switch: 0 = the backward reads y for the ReLU gate
+_RELU_MASK = True   # the backward reads the one-bit ReLU gate (False: it reads y; kept for the equivalence test)
 
 
 _SHAPE_MEMO = {}     # shape-derived answers of the library (mask bytes, workspace bytes, "NHWC kernels take C"): one ctypes
@@ -41,7 +41,7 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty_like(x)
         tag = "bf16" if x.dtype == torch.bfloat16 else "f32"
         # channels_last + ReLU + a backward to come: the forward leaves the ReLU gate as one bit per element and the
-        # backward reads that instead of y (19 % less traffic there; RSDET_BN_RELU_MASK=0 keeps y)
+        # backward reads that instead of y (19 % less traffic there)
         mask = None
         if ctx.nhwc and relu and _RELU_MASK and any(ctx.needs_input_grad[:4]):
             nb = _memo("rsdet_bn_act_relu_mask_bytes", N, C, H * W, int(tag == "bf16"))
@@ -100,7 +100,7 @@ class _BNAct(torch.autograd.Function):
         return gx, gres, gw, gb, None, None, None, None
 
 
-_NO_FUSED_BN = os.environ.get("RSDET_NO_FUSED_BN", "0") == "1"  # A/B switch
+_NO_FUSED_BN = False   # True: torch's batch_norm + relu (what the fused kernels are tested against)
 
 
 def _layout_ok(x, other=None):

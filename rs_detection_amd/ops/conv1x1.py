@@ -20,11 +20,11 @@ import torch.nn.functional as F
 
 from ._amp import light_custom_bwd, light_custom_fwd
 
-_ON = os.environ.get("RSDET_CONV1X1_GEMM", "1") == "1"   # A/B switch
+_ON = True
 _FWD_MAX_PIXELS = 65536
 
 
-_WRW_GEMM = os.environ.get("RSDET_CONV1X1_WRW_GEMM", "1") == "1"   # A/B switch
+_WRW_GEMM = True    # the weight gradient as a split-K batched GEMM (False: MIOpen's kernel)
 
 
 def _wrw_split_k(gy2, x, w):
@@ -33,7 +33,8 @@ def _wrw_split_k(gy2, x, w):
     plain GEMM has K = all pixels and only (O/256)(C/256) tiles to spread over 256 CUs -- 5-10 x slower than MIOpen;
     with S ~ P / 1024 (bf16) or P / 2048 (fp32) slices it is 25-35 % (bf16: 36 -> 25 us per call on the trunk shapes)
     and 5-12 % (fp32) faster than MIOpen's kernel + zero-fill (+ cast) launches (scratch/wrw1x1_nhwc.py, round 4).
-    Partial products are rounded to the map's dtype before the (fp32-accumulated) sum: 3-4e-3 relative in bf16."""
+    The S partial products come back in fp32 (``out_dtype``: the GEMM's own accumulator, not rounded to bf16) and are
+    summed in fp32: ONE rounding of the result, as in MIOpen's kernel."""
     P, O = gy2.shape
     C = x.shape[1]
     S = max(1, min(64, P // (1024 if x.dtype == torch.bfloat16 else 2048)))
@@ -42,8 +43,9 @@ def _wrw_split_k(gy2, x, w):
     x2 = x.permute(0, 2, 3, 1).reshape(P, C)
     if S == 1:
         return torch.mm(gy2.t(), x2).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
-    part = torch.bmm(gy2.view(S, P // S, O).transpose(1, 2), x2.view(S, P // S, C))
-    return part.sum(0).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
+    a, b = gy2.view(S, P // S, O).transpose(1, 2), x2.view(S, P // S, C)
+    part = torch.bmm(a, b, out_dtype=torch.float32) if x.dtype == torch.bfloat16 else torch.bmm(a, b)
+    return part.sum(0).to(x.dtype).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -112,7 +114,7 @@ def conv1x1(conv, x):
 # transposes and a zero-fill.  Device time per call (profiles/README.md, round 4; 2 tiles): 64 -> 512 at 256^2 206 ->
 # 94 us, 128 -> 1024 at 128^2 146 -> 87 us, 64 -> 64 46 -> 32 us; from 64^2 maps down MIOpen is as fast or faster and
 # keeps the call.  Forward and backward-data stay with MIOpen.
-_NCHW_WRW = os.environ.get("RSDET_CONV1X1_NCHW_WRW", "1") == "1"     # A/B switch
+_NCHW_WRW = True
 _NCHW_WRW_MIN_PIXELS = 128 * 128
 _NCHW_WRW_SPLITS = 16
 

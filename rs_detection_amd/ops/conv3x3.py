@@ -18,10 +18,10 @@ import torch.nn.functional as F
 
 from ._amp import light_custom_bwd, light_custom_fwd
 
-_ON = os.environ.get("RSDET_CONV3X3_BWD_AS_FWD", "1") == "1"   # A/B switch
+_ON = True
 # fp32: measured neutral on the step (50.5 vs 50.5 ms: MIOpen's fp32 backward-data solver is as fast as its forward one
-# there), so only bf16 takes this route by default
-_F32 = os.environ.get("RSDET_CONV3X3_BWD_AS_FWD_F32", "0") == "1"
+# there), so only bf16 takes this route
+_F32 = False
 
 
 def _flipped(w):
@@ -60,7 +60,7 @@ class _Conv3x3Same(torch.autograd.Function):
             gx = F.conv2d(gy, _flipped(w), None, 1, 1)
         if ctx.needs_input_grad[1]:
             # bf16 layers whose channel counts fill the kernel's 256-wide tiles: our split-K weight gradient (two
-            # launches, no zero-fill / cast launches around it); RSDET_CONV3X3_WRW_TRUNK=0 keeps MIOpen's
+            # launches, no zero-fill / cast launches around it)
             if (_WRW_TRUNK and x.dtype == torch.bfloat16 and w.shape[0] % _WRW_TRUNK_O == 0
                     and w.shape[1] % 64 == 0):
                 gw = _mfma_wrw(gy, x, w.dtype)
@@ -75,12 +75,12 @@ class _Conv3x3Same(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------------------------
 # The head canvas in bf16: conv + bias + ReLU + gap mask as ONE launch of our own implicit-GEMM kernel
 # (csrc/conv3x3_mfma.hip), backward-data through the same kernel on the flipped weights.
-_MFMA = os.environ.get("RSDET_CONV3X3_MFMA", "1") == "1"      # A/B switch
+_MFMA = True
 # the same weight-gradient kernel for the other square bf16 3x3 layers (ResNet conv2 of layers 2-4, the FPN output
 # convolutions): bf16 step 16.03 -> 15.88 ms with output-channel multiples of 128 (half-filled 256-wide tiles still beat
 # MIOpen's kernel + zero-fill + cast launches there), 15.90 with multiples of 256 only (profiles/README.md, round 4)
-_WRW_TRUNK = os.environ.get("RSDET_CONV3X3_WRW_TRUNK", "1") == "1"          # A/B switch
-_WRW_TRUNK_O = int(os.environ.get("RSDET_CONV3X3_WRW_TRUNK_O", "128"))      # output-channel multiple it takes
+_WRW_TRUNK = True
+_WRW_TRUNK_O = 128                                              # output-channel multiple it takes
 _MFMA_TM = 224                                                  # positions of one row a workgroup covers (C3_TM)
 
 
@@ -96,7 +96,7 @@ def _mfma_conv(x, w_cl, bias, live, relu):
     return y
 
 
-_MFMA_WRW = os.environ.get("RSDET_CONV3X3_MFMA_WRW", "1") == "1"      # A/B switch
+_MFMA_WRW = True
 
 
 def _mfma_wrw(g, x, out_dtype):

@@ -25,9 +25,8 @@ __all__ = ["DeformConv", "deform_conv", "deformable_im2col", "deformable_col2im"
            "deformable_im2col_nhwc", "deformable_col2im_nhwc"]
 
 
-# bf16 columns + bf16 products under bf16 autocast (what autocast does to every other convolution of the step);
-# RSDET_ALIGNCONV_BF16=0 keeps AlignConv in fp32 inside an autocast step
-_LOWP_ALIGNCONV = os.environ.get("RSDET_ALIGNCONV_BF16", "1") == "1"
+# bf16 columns + bf16 products under bf16 autocast (what autocast does to every other convolution of the step)
+_LOWP_ALIGNCONV = True
 
 
 def _pair(x):
@@ -276,9 +275,9 @@ def _dcn_backward_channels_last(ctx, grad_output):
 DeformConvFunctionNHWC._backward_channels_last = staticmethod(_dcn_backward_channels_last)
 
 
-# AlignConv on the bf16 matrix cores as an implicit GEMM (csrc/alignconv_mfma.hip); RSDET_ALIGNCONV_MFMA=0 keeps the
-# im2col + rocBLAS form of the bf16 step
-_MFMA_ALIGNCONV = os.environ.get("RSDET_ALIGNCONV_MFMA", "1") == "1"
+# AlignConv on the matrix cores as an implicit GEMM (csrc/alignconv_mfma.hip) wherever _mfma_geom covers the call; the
+# im2col + rocBLAS form serves the other geometries (tests set this False to compare the two)
+_MFMA_ALIGNCONV = True
 
 
 def _mfma_geom(input, weight, stride, padding, dilation, deformable_groups):

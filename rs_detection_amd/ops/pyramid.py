@@ -7,7 +7,7 @@ shared-weight convolutions run once instead of once per level (csrc/canvas.hip; 
   levels = pyramid_unpack(canvas, lay)               the inverse (gaps dropped); each is the other's backward
   y = canvas_bias_act(x, bias, lay, relu)            act(x + bias) with the gap pixels put back to zero
 
-Level 0 sits at the canvas origin, the other levels in a column to its right (RSDET_CANVAS_TALL=1: level 1 under it and
+Level 0 sits at the canvas origin, the other levels in a column to its right (``tall=True``: level 1 under it and
 the rest beside level 1), one gap pixel between neighbours: the gap is the zero padding a 3x3 / padding-1 convolution of a single level would see, so canvas convolution == per-level
 convolution at every level pixel provided the INPUT's gaps are zero -- which pack and canvas_bias_act maintain.
 GPU only (no CPU fallback): the callers keep the reference's per-level loop for CPU tensors."""
@@ -32,8 +32,7 @@ class CanvasLayout:
         sizes = [tuple(int(v) for v in s) for s in sizes]
         assert 1 <= len(sizes) <= 8
         self.sizes = sizes
-        if tall is None:
-            tall = os.environ.get("RSDET_CANVAS_TALL", "0") == "1"
+        tall = bool(tall)
         H0, W0 = sizes[0]
         rects = [(0, 0, H0, W0)]
         if tall and len(sizes) > 1:

@@ -9,6 +9,8 @@ import torch.nn as nn
 from .. import _lib
 from .layout import nhwc_to_nchw, transpose_last2
 
+_NCHW_GATHER = False    # backward writes NCHW directly (slower kernel, see backward()); the default turns the layout
+
 __all__ = ["ROIAlignRotated_v1", "roi_align_rotated_v1", "rroi_align"]
 
 
@@ -58,9 +60,8 @@ def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, varian
         # gather form: no fp32 atomics (csrc/rroi_align.hip); channels-last in, channels-last out.
         # (rsdet_rroi_align_*_backward_gather_nchw_f32 writes NCHW directly and is correct, but its 64-pixel tile
         # walks each pixel's entry chain serially: 321 us against ~35 us for this one-wave-per-pixel kernel at
-        # 2 x 256 x 256 x 256 -- measured round 2, RSDET_RROI_NCHW=1 selects it; the transposes stay for now.)
-        import os
-        nchw = os.environ.get("RSDET_RROI_NCHW", "0") == "1"
+        # 2 x 256 x 256 x 256 -- measured round 2; ``_NCHW_GATHER = True`` selects it (its equivalence test does); the transposes stay for now.)
+        nchw = _NCHW_GATHER
         go_t = transpose_last2(go.view(R, C, PH * PW))            # (R, 49, C): channels-last rows for the gather
         g = torch.empty((N, C, H, W) if nchw else (N, H, W, C), dtype=go.dtype, device=go.device)
         ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)

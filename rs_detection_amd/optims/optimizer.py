@@ -84,7 +84,7 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
             if st is None:
                 continue
             for k, v in st.items():
-                if isinstance(v, torch.Tensor) and v.is_floating_point():
+                if k != "step" and isinstance(v, torch.Tensor) and v.is_floating_point():
                     self.state[p][k] = v.detach().to(device=p.device, dtype=torch.float32).clone()
         self._params_key = None          # the device table points at the old state tensors
 
@@ -247,6 +247,25 @@ class FusedAdamW(FusedSGD):
         self.grad_clip = grad_clip
         self.lr = lr
         self._params_key = None
+
+    # -- state interchange with torch.optim.AdamW (a checkpoint written by one resumes under the other: the Runner
+    #    picks the fused form on a GPU and torch's on the CPU).  torch keeps the step count PER PARAMETER
+    #    (``state[p]['step']``, a float32 scalar), this class once per group: ``state_dict`` writes the group's count
+    #    into every parameter's state, ``load_state_dict`` reads it back from there when the saved group has none.
+    def state_dict(self):
+        g = self.param_groups[0]
+        for p in g["params"]:
+            if p.requires_grad:
+                self._ensure_state(p)["step"] = torch.tensor(float(g.get("step", 0)), dtype=torch.float32)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        g = self.param_groups[0]
+        if not any("step" in sg for sg in state_dict["param_groups"]):
+            counts = [int(st["step"]) for st in state_dict["state"].values() if "step" in st]
+            g["step"] = max(counts) if counts else 0
+        g["step"] = int(g.get("step", 0))
 
     def _launch(self, lib, _lib, g, clip):
         g["step"] = int(g.get("step", 0)) + 1

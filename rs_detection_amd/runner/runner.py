@@ -23,7 +23,7 @@ from rs_detection_amd.utils.registry import MODELS, OPTIMS, SCHEDULERS, build_fr
 
 class Runner:
     def __init__(self, cfg, device=None, distributed=None, memory_format=None, amp_dtype=None, grad_dtype="auto",
-                 bf16_params=None):
+                 bf16_params=None, fused_optimizer=True):
         self.cfg = cfg
         from rs_detection_amd.utils.miopen_db import use_packaged_miopen_db
         use_packaged_miopen_db()  # tuned MIOpen solver records of the shipped configs (before the first convolution)
@@ -48,8 +48,11 @@ class Runner:
         # SGD + both copies in two launches).  Removes, per step, one fp32->bf16 cast per weight (autocast), one
         # bf16->fp32 cast per weight gradient and the foreach passes of clip_grad_norm_ / SGD (~250 launches of ~1 700).
         # BatchNorm parameters, the ARF weight of ORConv2d (fp32 kernels) and every other parameter stay fp32.
-        if bf16_params is None:      # on by default wherever it applies (bf16 autocast + SGD, no SWA phase): what bench.py times
-            bf16_params = os.environ.get("RSDET_BF16_PARAMS", "1") == "1"
+        # On by default wherever it applies (bf16 autocast + SGD, no SWA phase): what bench.py times.  NOTE for exporters:
+        # ``model.state_dict()`` of such a Runner holds ROUNDED bf16 weights -- ``Runner.state_dict_fp32()`` / ``save()``
+        # return the unrounded fp32 values (README.md); ``bf16_params=False`` keeps fp32 weights.
+        if bf16_params is None:
+            bf16_params = True
         # Not with an SWA phase: ``optimizer_swa`` is a plain optimizer over the same parameters and would update the bf16
         # copies while FusedSGD's fp32 masters went stale (and the checkpoint, which stores the masters, lost the phase).
         self.bf16_params = bool(bf16_params) and amp_dtype == torch.bfloat16 and device.type == "cuda" and \
@@ -68,16 +71,16 @@ class Runner:
         opt_cfg = cfg.optimizer
         # The two-launch clip + SGD step (optims.FusedSGD, csrc/optim.hip) serves fp32 parameters as well: same
         # arithmetic as torch's clip_grad_norm_ + SGD (tests/test_gpu_optim.py), ~15 foreach launches fewer per step.
-        # RSDET_FUSED_SGD=0 keeps torch.optim.SGD.
+        # ``fused_optimizer=False`` keeps torch.optim.SGD / AdamW (what the fused steps are tested against).
         fused_ok = (device.type == "cuda" and bool(cfg.optimizer) and cfg.optimizer.get("type") == "SGD"
                     and not cfg.optimizer.get("dampening", 0) and not cfg.optimizer.get("nesterov", False)
-                    and os.environ.get("RSDET_FUSED_SGD", "1") != "0")
+                    and bool(fused_optimizer))
         if self.bf16_params or fused_ok:
             opt_cfg = dict(cfg.optimizer, type="FusedSGD")
-        # AdamW (configs/orcnn): the same two launches with the AdamW update (optims.FusedAdamW); RSDET_FUSED_ADAMW=0
-        # keeps torch.optim.AdamW (foreach: ~130 launches and 2.9 ms per step on VAN-B3)
+        # AdamW (configs/orcnn): the same two launches with the AdamW update (optims.FusedAdamW) instead
+        # of torch.optim.AdamW (foreach: ~130 launches and 2.9 ms per step on VAN-B3)
         elif (device.type == "cuda" and bool(cfg.optimizer) and cfg.optimizer.get("type") == "AdamW"
-              and os.environ.get("RSDET_FUSED_ADAMW", "1") != "0"):
+              and bool(fused_optimizer)):
             opt_cfg = dict(cfg.optimizer, type="FusedAdamW")
         self.optimizer = build_from_cfg(opt_cfg, OPTIMS, params=params) if cfg.optimizer else None
         if frozen_masters and self.optimizer is not None:
@@ -94,7 +97,9 @@ class Runner:
             distributed = self.world > 1
         # gradient buckets travel in bf16 when the step computes in bf16 (BASELINE configs[2..4]); fp32 otherwise
         self.grad_dtype = (amp_dtype if amp_dtype == torch.bfloat16 else None) if grad_dtype == "auto" else grad_dtype
-        self.ddp = rdist.wrap_ddp(self.model, device, grad_dtype=self.grad_dtype) if distributed else self.model
+        # distributed="force": DDP even in a one-rank process group (the RCCL reducer path on one GPU: tests, bench)
+        self.ddp = rdist.wrap_ddp(self.model, device, grad_dtype=self.grad_dtype, force=(distributed == "force")) \
+            if distributed else self.model
         self.iter, self.epoch = 0, 0
         self.max_epoch = cfg.max_epoch if hasattr(cfg, "max_epoch") else None
         self.max_iter = cfg.max_iter if hasattr(cfg, "max_iter") else None
@@ -296,6 +301,17 @@ class Runner:
             return None
         return save_checkpoint(path, self.model, self.optimizer, self.scheduler,
                                meta=dict(epoch=self.epoch, iter=self.iter, config=dict(self.cfg) if hasattr(self.cfg, "keys") else None))
+
+    def state_dict_fp32(self):
+        """``model.state_dict()`` with every floating-point entry in fp32 and UNROUNDED: where the Runner holds a weight
+        in bf16 (``bf16_params``) the value comes from the optimizer's fp32 master (trainable weights) or the Runner's
+        kept original (frozen weights).  What an exporter / external evaluator should read instead of
+        ``model.state_dict()``; ``save()`` writes the same values."""
+        sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()) for k, v in self.model.state_dict().items()}
+        if self.optimizer is not None and hasattr(self.optimizer, "master_state_dict"):
+            for k, v in self.optimizer.master_state_dict(self.model).items():
+                sd[k] = v.detach().float()
+        return sd
 
     def load(self, load_path, model_only=False):
         from .checkpoint import read_checkpoint, model_parameters, load_parameters

@@ -72,8 +72,13 @@ def gpu_numa_nodes(sysfs="/sys"):
 
 
 def _visible_gpu(local_rank):
-    """Physical index of the GPU this rank will open: the local rank through the *_VISIBLE_DEVICES remapping."""
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    """Physical index of the GPU this rank will open: the local rank through the *_VISIBLE_DEVICES remapping.  None
+    (= "do not guess": the caller falls back to the even split) for UUID lists and when BOTH a ROCR and a HIP / CUDA
+    mask are set -- the runtime applies them one after the other and the composition is not ours to re-derive."""
+    masks = [var for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(var)]
+    if "ROCR_VISIBLE_DEVICES" in masks and len(masks) > 1:
+        return None
+    for var in masks:
         v = os.environ.get(var)
         if v:
             ids = [x.strip() for x in v.split(",") if x.strip()]
@@ -81,6 +86,37 @@ def _visible_gpu(local_rank):
                 return int(ids[local_rank])
             return None                 # UUIDs or fewer devices than ranks: do not guess
     return local_rank
+
+
+def gpu_numa_node_by_pci(pci_addr, sysfs="/sys"):
+    """NUMA node of the GPU at PCI address 'dddd:bb:dd.f' (None if unknown)."""
+    node = _read(os.path.join(sysfs, "bus", "pci", "devices", pci_addr, "numa_node"))
+    return int(node) if node not in (None, "", "-1") else None
+
+
+def check_pinning(device_index, cores, sysfs=None, log=None):
+    """After the device is open: does the socket the rank was pinned to (from the sysfs enumeration order, an
+    ASSUMPTION about HIP's device order) match the node of the GPU it really opened (by PCI address, a fact)?  Reports
+    through ``log`` (default: stderr) -- once per rank, a wrong guess costs the cross-socket hop silently otherwise.
+    Returns (gpu_node, pinned_nodes) or None where the information is not there."""
+    import sys
+    sysfs = sysfs or os.environ.get("RSDET_SYSFS_ROOT", "/sys")
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:                    # noqa: BLE001  (older torch: no PCI fields)
+        return None
+    node = gpu_numa_node_by_pci(addr, sysfs)
+    if node is None or not cores:
+        return None
+    node_cpus = set(_cpulist(_read(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist"))))
+    on_node = bool(node_cpus) and set(cores) <= node_cpus
+    rank = env_world()[0]
+    msg = "rank %d: GPU %d at %s on NUMA node %d, pinned to %d cores %s that node" % (
+        rank, device_index, addr, node, len(cores), "ON" if on_node else "NOT ALL ON")
+    if not on_node or rank == 0:
+        (log or (lambda m: print(m, file=sys.stderr)))(msg)
+    return node, on_node
 
 
 def _sibling_groups(cores, sysfs="/sys"):
@@ -170,11 +206,12 @@ def pick_backend():
     return "nccl" if (n >= world and n > 0) else "gloo"
 
 
-def init_distributed(backend=None, timeout_s=1800):
-    """Initialise the default process group from torchrun env vars (no-op for world size 1)."""
+def init_distributed(backend=None, timeout_s=1800, force=False):
+    """Initialise the default process group from torchrun env vars (no-op for world size 1 unless ``force``: a
+    one-rank group, which is how the RCCL reducer path is exercised on a single GPU -- tests/test_gpu_dist.py)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
-        pin_rank_to_cores()             # before this process's first GPU call (set_device / NCCL init below)
+    if (world > 1 or force) and not dist.is_initialized():
+        cores = pin_rank_to_cores()     # before this process's first GPU call (set_device / NCCL init below)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -184,6 +221,8 @@ def init_distributed(backend=None, timeout_s=1800):
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=timeout_s))
+        if backend == "nccl" and cores:
+            check_pinning(torch.cuda.current_device(), cores)    # the GPU really opened vs the socket pinned to
     return rank, local_rank, world
 
 
@@ -192,7 +231,8 @@ def shutdown():
         dist.destroy_process_group()
 
 
-def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_parameters=False, static_graph=None):
+def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_parameters=False, static_graph=None,
+             force=False):
     """DDP with gradient-as-bucket-view; 64 MB buckets: the 145 MB fp32 gradient set of
     S2ANet-R50 goes out as ~3 large all-reduces (per-link-bound ring over xGMI favours few,
     large messages) that overlap with the backbone backward.
@@ -204,14 +244,17 @@ def wrap_ddp(model, device, bucket_cap_mb=64, grad_dtype=None, find_unused_param
     The model's only graph-less parameters (RotationInvariantPooling's unused conv/BN) are frozen
     (``requires_grad=False``), so DDP never waits for them and ``find_unused_parameters`` can stay off.
 
-    ``static_graph`` (default: env ``RSDET_DDP_STATIC_GRAPH``, off).  Evaluated in round 3 and left off: the steps use
+    ``static_graph`` (default off).  Evaluated in round 3 and left off: the steps use
     the same parameters in the same order every iteration, so it is legal, but with torch 2.10 + ROCm the 2-rank
     harness (tests/dist_worker.py: a second backward through an un-wrapped copy sharing the parameters) trips the
     reducer's internal assert `expect_autograd_hooks_` (reducer.cpp:1703) under static_graph=True; plain DDP passes the
-    same harness, and the bookkeeping it would save is ~0.1 ms of a 23-57 ms step."""
-    if static_graph is None:
-        static_graph = os.environ.get("RSDET_DDP_STATIC_GRAPH", "0") == "1"
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    same harness, and the bookkeeping it would save is ~0.1 ms of a 23-57 ms step.
+
+    ``force``: wrap at world size 1 too (a one-rank process group must exist): the whole reducer path -- bucket views,
+    compress hook, the all-reduce through RCCL -- then runs on one GPU, which is how it is tested without a node and how
+    ``bench.py`` measures what DDP adds to the host side of a step (``ddp_host_overhead_ms``)."""
+    static_graph = bool(static_graph)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if device.type == "cuda" else None

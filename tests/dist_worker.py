@@ -56,15 +56,16 @@ def flat_grads(model):
 def main():
     model_name, dtype, out = sys.argv[1], sys.argv[2], sys.argv[3]
     size = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+    force = len(sys.argv) > 5 and sys.argv[5] == "force"     # a ONE-rank group with DDP forced on (RCCL on one GPU)
     from rs_detection_amd.utils import dist as rdist
     from rs_detection_amd.utils.general import parse_losses
-    rank, local_rank, world = rdist.init_distributed()
+    rank, local_rank, world = rdist.init_distributed(force=force)
     assert torch.cuda.is_available()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     amp = torch.bfloat16 if dtype == "bf16" else None
     # "f32cl": the fp32 step in channels_last (the bench's layout): canvas head, 1x1 GEMM split, FusedSGD under DDP
-    runner = build_runner(model_name, dev, amp, distributed=True, channels_last=dtype == "f32cl")
+    runner = build_runner(model_name, dev, amp, distributed="force" if force else True, channels_last=dtype == "f32cl")
     assert runner.ddp is not runner.model, "DDP wrapper missing"
     assert (runner.grad_dtype == torch.bfloat16) == (dtype == "bf16")
 
@@ -122,6 +123,8 @@ def main():
     res = dict(rank=rank, world=world, backend=dist.get_backend(), loss=loss, grad_rel_err=rel, grad_max_abs=maxabs,
                grad_norm=float(want.norm()), noise=noise, local_rel_err=local_rel, param_spread=spread, final_loss=float(total.detach()),
                n_grad=int(got.numel()), finite=bool(torch.isfinite(flat).all()),
+               sync_mean=rdist.sync_mean(dict(a=torch.tensor(1.0 + rank), b=torch.tensor(3.0)), dev),
+               comm_hook=(runner.ddp._comm_hooks[0][0].__qualname__ if getattr(runner.ddp, "_comm_hooks", None) else None),
                bf16_params=bool(runner.bf16_params), optimizer=type(runner.optimizer).__name__,
                bucket_view=bool(getattr(runner.ddp, "gradient_as_bucket_view", False)))
     with open("%s.rank%d.json" % (out, rank), "w") as f:

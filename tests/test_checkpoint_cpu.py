@@ -148,3 +148,34 @@ def test_fused_sgd_state_dict_keeps_fp32_state_for_bf16_parameters():
     assert torch.equal(b.state[p2]["master"], a.state[p]["master"])
     assert torch.equal(b.state[p2]["momentum_buffer"], a.state[p]["momentum_buffer"])
     assert torch.equal(b.state[q2]["momentum_buffer"], a.state[q]["momentum_buffer"]) and "master" not in b.state[q2]
+
+
+def test_fused_adamw_state_dict_interchanges_with_torch_adamw():
+    """FusedAdamW keeps one step count per group, torch.optim.AdamW one per parameter; each loads the
+    other's state_dict (no GPU needed: only the state plumbing runs here)."""
+    import copy
+    import torch
+    from rs_detection_amd.optims.optimizer import AdamW, FusedAdamW
+    torch.manual_seed(0)
+    m = torch.nn.Linear(4, 3)
+    ta = AdamW(m.parameters(), lr=1e-3, weight_decay=0.05)
+    for _ in range(7):
+        m(torch.randn(2, 4)).sum().backward()
+        ta.step()
+        ta.zero_grad()
+    fa = FusedAdamW(copy.deepcopy(m).parameters(), lr=1e-3, weight_decay=0.05)
+    fa.load_state_dict(copy.deepcopy(ta.state_dict()))
+    assert fa.param_groups[0]["step"] == 7                      # taken from the per-parameter counts
+    p0 = fa.param_groups[0]["params"][0]
+    assert fa.state[p0]["exp_avg"].dtype == torch.float32 and fa.state[p0]["step"].numel() == 1
+    m3 = copy.deepcopy(m)
+    tb = AdamW(m3.parameters(), lr=1e-3, weight_decay=0.05)
+    tb.load_state_dict(copy.deepcopy(fa.state_dict()))          # used to raise KeyError: 'step'
+    m3(torch.randn(2, 4)).sum().backward()
+    tb.step()
+    assert float(tb.state[next(iter(m3.parameters()))]["step"]) == 8.0
+    fb = FusedAdamW(copy.deepcopy(m).parameters(), lr=1e-3, weight_decay=0.05)
+    fb.param_groups[0]["step"] = 11
+    fc = FusedAdamW(copy.deepcopy(m).parameters(), lr=1e-3, weight_decay=0.05)
+    fc.load_state_dict(fb.state_dict())
+    assert fc.param_groups[0]["step"] == 11

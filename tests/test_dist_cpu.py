@@ -314,3 +314,68 @@ def test_eight_rank_gloo_smoke_shards_sync_and_gather():
     cores = [set(o[7]) for o in out]
     if len(os.sched_getaffinity(0)) >= 8:                                        # init_distributed pinned every rank
         assert all(cores[i].isdisjoint(cores[j]) for i in range(8) for j in range(i))
+
+
+def _force_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from rs_detection_amd.utils import dist as rdist
+    assert rdist.init_distributed(backend="gloo") == (0, 0, 1) and not dist.is_initialized()   # world 1: no group ...
+    rdist.init_distributed(backend="gloo", force=True)                                         # ... unless forced
+    assert dist.is_initialized() and dist.get_world_size() == 1
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    assert rdist.wrap_ddp(model, torch.device("cpu")) is model
+    ddp = rdist.wrap_ddp(model, torch.device("cpu"), bucket_cap_mb=1, grad_dtype=torch.bfloat16, force=True)
+    assert ddp is not model and ddp._comm_hooks
+    x = torch.randn(2, 3, 8, 8)
+    ddp(x).square().mean().backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    model(x).square().mean().backward()
+    ok = all(torch.allclose(a, p.grad, rtol=2e-2, atol=1e-4) for a, p in zip(got, model.parameters()))   # bf16 wire
+    q.put(bool(ok))
+    rdist.shutdown()
+
+
+def test_forced_one_rank_group_runs_the_reducer_path():
+    """wrap_ddp(force=True) in a one-rank process group: the reducer (buckets, compress hook, all-reduce) runs although
+    there is nobody to reduce with -- the form tests/test_gpu_dist.py uses to put the step through RCCL on one GPU."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    ok = q.get(timeout=120)
+    p.join(60)
+    assert ok and p.exitcode == 0
+
+
+def test_visible_gpu_does_not_guess_through_composed_masks(monkeypatch):
+    from rs_detection_amd.utils import dist as rdist
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert rdist._visible_gpu(3) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    assert rdist._visible_gpu(1) == 5
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2,3,4,5,6,7")
+    assert rdist._visible_gpu(1) is None            # ROCR and HIP masks compose: do not re-derive, take the even split
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert rdist._visible_gpu(1) == 1
+
+
+def test_check_pinning_reports_the_node_of_the_opened_gpu(tmp_path, monkeypatch):
+    from rs_detection_amd.utils import dist as rdist
+    root = tmp_path / "sys"
+    (root / "bus" / "pci" / "devices" / "0000:c1:00.0").mkdir(parents=True)
+    (root / "bus" / "pci" / "devices" / "0000:c1:00.0" / "numa_node").write_text("1\n")
+    (root / "devices" / "system" / "node" / "node1").mkdir(parents=True)
+    (root / "devices" / "system" / "node" / "node1" / "cpulist").write_text("8-15\n")
+
+    class P:
+        pci_domain_id, pci_bus_id, pci_device_id = 0, 0xc1, 0
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: P)
+    said = []
+    assert rdist.check_pinning(0, [8, 9, 10], sysfs=str(root), log=said.append) == (1, True)
+    assert rdist.check_pinning(0, [0, 1], sysfs=str(root), log=said.append) == (1, False)
+    assert "NOT ALL ON" in said[-1]

@@ -21,13 +21,14 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def _run(model, dtype, tmp_path, size=256, world=2, extra_env=None):
+def _run(model, dtype, tmp_path, size=256, world=2, extra_env=None, force=False):
     from rs_detection_amd.utils import dist as rdist
     env = dict(os.environ, **(extra_env or {}))
     if torch.cuda.device_count() < world:
         env["RSDET_DIST_BACKEND"] = "gloo"
     out = str(tmp_path / "res")
-    rc, text = rdist.launch_ranks(world, [WORKER, model, dtype, out, str(size)], env=env, timeout=900)
+    rc, text = rdist.launch_ranks(world, [WORKER, model, dtype, out, str(size)] + (["force"] if force else []),
+                                  env=env, timeout=900)
     assert rc == 0, "a rank failed (rc %d)\n%s" % (rc, text[-2000:])
     return [json.load(open("%s.rank%d.json" % (out, r))) for r in range(world)]
 
@@ -54,6 +55,29 @@ def test_two_rank_ddp_real_model(model, dtype, tol, tmp_path):
             assert r["optimizer"] == "FusedSGD" and r["bucket_view"], r
             assert r["bf16_params"] == (dtype == "bf16"), r
     assert res[0]["loss"] != res[1]["loss"]          # the ranks really worked on different shards
+
+
+@pytest.mark.timeout(1000)
+@pytest.mark.parametrize("model,dtype,tol", [("s2anet", "f32cl", 1e-3), ("s2anet", "bf16", 0.1), ("orcnn", "f32", 5e-3)])
+def test_rccl_reducer_path_on_one_gpu(model, dtype, tol, tmp_path):
+    """The backend the node will run: an ``nccl`` (= RCCL) process group of ONE rank with DDP forced on
+    (``Runner(distributed="force")``): bucket views, the bf16 compress hook, FusedSGD's gradient-pointer ring on
+    bucket-view gradients, ``sync_mean`` and the MIN / MAX all-reduces of the worker all go through RCCL on this GPU.
+    With one shard the all-reduced mean IS the un-wrapped model's gradient: equal to the run-to-run noise of the
+    single-process computation (reference collective: optims/optimizer.py:30-31, utils/general.py:30-48)."""
+    _need_gpu()
+    (r,) = _run(model, dtype, tmp_path, world=1, extra_env={"RSDET_DIST_BACKEND": "nccl"}, force=True)
+    print(r)
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["finite"]
+    assert r["bucket_view"] and r["grad_norm"] > 0 and r["n_grad"] > 1e6
+    assert r["grad_rel_err"] < max(tol, 3 * r["noise"]), r
+    assert r["local_rel_err"] < max(tol, 3 * r["noise"]), r
+    assert r["param_spread"] == 0.0
+    assert r["sync_mean"] == {"a": 1.0, "b": 3.0}
+    if model == "s2anet":
+        assert r["optimizer"] == "FusedSGD" and r["bf16_params"] == (dtype == "bf16")
+        if dtype == "bf16":
+            assert r["comm_hook"] is not None          # bf16 on the wire
 
 
 @pytest.mark.timeout(1500)

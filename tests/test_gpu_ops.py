@@ -709,7 +709,7 @@ def test_deform_conv_bf16_autocast_path_tracks_fp32(cuda):
     gradients stay within bf16 accuracy of the fp32 path (relative to the largest value), and the output is bf16."""
     from rs_detection_amd.ops import dcn_v1
     from rs_detection_amd.ops.dcn_v1 import DeformConv
-    saved, dcn_v1._LOWP_ALIGNCONV = dcn_v1._LOWP_ALIGNCONV, True     # the default (RSDET_ALIGNCONV_BF16=0 turns it off)
+    saved, dcn_v1._LOWP_ALIGNCONV = dcn_v1._LOWP_ALIGNCONV, True     # the default
     torch.manual_seed(5)
     B, C, O, H, W = 2, 32, 48, 24, 40
     m = DeformConv(C, O, 3, padding=1).to(cuda)
@@ -1018,8 +1018,10 @@ def test_rroi_backward_nchw_form_equals_channels_last_form(cuda, monkeypatch):
         rois = _t(_rois(rng, R, N, W * 4), cuda)
         go = _t(rng.standard_normal((R, C, 7, 7)).astype(np.float32), cuda)
         grads = []
-        for flag in ("0", "1"):
-            monkeypatch.setenv("RSDET_RROI_NCHW", flag)
+        import importlib
+        rroi_mod = importlib.import_module("rs_detection_amd.ops.roi_align_rotated_v1")   # (the package attribute is the function)
+        for flag in (False, True):
+            monkeypatch.setattr(rroi_mod, "_NCHW_GATHER", flag)
             f = feat.clone().requires_grad_(True)
             roi_align_rotated_v1(f, rois, (7, 7), 0.25, 2).backward(go)
             grads.append(f.grad)

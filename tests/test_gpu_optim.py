@@ -133,7 +133,7 @@ def test_runner_bf16_params_step_matches_autocast_step(cuda, tmp_path):
 
 
 def test_runner_fp32_fused_sgd_tracks_torch_sgd(cuda, monkeypatch):
-    """The fp32 Runner takes FusedSGD by default; RSDET_FUSED_SGD=0 restores torch.optim.SGD + clip_grad_norm_.  Same
+    """The fp32 Runner takes FusedSGD by default; ``fused_optimizer=False`` restores torch.optim.SGD + clip_grad_norm_.  Same
     arithmetic: after three steps from the same seed the parameters agree to fp32 round-off of the (atomic, hence not
     bit-reproducible) weight-gradient kernels."""
     from rs_detection_amd.config import Config
@@ -149,11 +149,10 @@ def test_runner_fp32_fused_sgd_tracks_torch_sgd(cuda, monkeypatch):
         targets.append(t)
     out = {}
     for tag, fused in (("fused", "1"), ("torch", "0"), ("torch again", "0")):
-        monkeypatch.setenv("RSDET_FUSED_SGD", fused)
         torch.manual_seed(0)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            r = Runner(cfg, device=cuda, distributed=False)
+            r = Runner(cfg, device=cuda, distributed=False, fused_optimizer=(fused == "1"))
         assert type(r.optimizer).__name__ == ("FusedSGD" if fused == "1" else "SGD")
         losses = [float(r.train_step(images, targets)[0]) for _ in range(3)]
         out[tag] = (losses, {n: p.detach().clone() for n, p in r.model.named_parameters() if p.requires_grad})
@@ -204,6 +203,39 @@ def test_fused_adamw_equals_torch_adamw(cuda, clip):
         one_step(step)
     for pa, pb in zip(a, b):
         torch.testing.assert_close(pb, pa, rtol=5e-6, atol=5e-7)
+
+
+def test_adamw_state_crosses_between_torch_and_fused_mid_run(cuda):
+    """A run resumed under the OTHER AdamW (checkpoint written by torch.optim.AdamW on the CPU path / before the fused
+    optimizer existed, loaded into FusedAdamW, and back) continues the same trajectory: the step count -- per parameter
+    in torch's state, per group in ours -- crosses over, so the bias corrections do not restart on warmed moments."""
+    from rs_detection_amd.optims.optimizer import AdamW, FusedAdamW
+    ref, a, b = (_params(cuda, 0, [torch.float32]) for _ in range(3))
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, grad_clip=dict(max_norm=35, norm_type=2))
+    o_ref = AdamW(ref, **kw)
+    g = torch.Generator().manual_seed(1)
+    grads = [[(torch.randn(p.shape, generator=g) * 0.3).to(cuda) for p in ref] for _ in range(9)]
+
+    def run(opt, ps, steps):
+        for s in steps:
+            for p, gr in zip(ps, grads[s]):
+                p.grad = gr.clone().contiguous(memory_format=torch.channels_last) if p.dim() == 4 and not p.is_contiguous() else gr.clone()
+            opt.step()
+
+    run(o_ref, ref, range(9))
+    oa = AdamW(a, **kw)
+    run(oa, a, range(3))                                    # torch for 3 steps ...
+    ob = FusedAdamW(a, **kw)
+    ob.load_state_dict(oa.state_dict())                     # ... fused for the next 3 ...
+    assert ob.param_groups[0]["step"] == 3
+    run(ob, a, range(3, 6))
+    sd = ob.state_dict()
+    assert all(float(st["step"]) == 6.0 for st in sd["state"].values())
+    oc = AdamW(a, **kw)
+    oc.load_state_dict(sd)                                  # ... and torch again for the last 3
+    run(oc, a, range(6, 9))
+    for pr, pa in zip(ref, a):
+        torch.testing.assert_close(pa, pr, rtol=1e-5, atol=1e-6)
 
 
 def test_runner_builds_fused_adamw_for_the_orcnn_config(cuda):

@@ -132,11 +132,11 @@ def _run(head, feats, packed, train):
         p.grad = None
     xs = [f.clone().requires_grad_(True) for f in feats]
     if packed:
-        os.environ["RSDET_S2A_GROUPS"] = packed
+        head.canvas_groups = packed
         try:
             outs = head.forward_levels(xs)
         finally:
-            del os.environ["RSDET_S2A_GROUPS"]
+            head.canvas_groups = None
     else:
         outs = tuple(map(list, zip(*[head.forward_single(x, s) for x, s in zip(xs, head.anchor_strides)])))
     maps = [m for group in outs for m in group if m is not None]
@@ -217,7 +217,7 @@ def test_head_canvas_path_bf16_channels_last(cuda):
 
 def test_model_train_step_uses_the_canvas(cuda, monkeypatch):
     """The whole S2ANet model: the step goes through forward_packed by default and through the loop with
-    RSDET_S2A_PACKED=0, same losses."""
+    ``bbox_head.packed = False``, same losses."""
     import rs_detection_amd.models  # noqa: F401
     from rs_detection_amd.config import Config
     from rs_detection_amd.utils.registry import MODELS, build_from_cfg
@@ -232,7 +232,7 @@ def test_model_train_step_uses_the_canvas(cuda, monkeypatch):
     monkeypatch.setattr(type(model.bbox_head), "forward_packed", lambda self, f, **kw: calls.append(1) or orig(self, f, **kw))
     out_c = model(imgs, targets)
     assert calls == [1]
-    monkeypatch.setenv("RSDET_S2A_PACKED", "0")
+    monkeypatch.setattr(model.bbox_head, "packed", False)
     out_l = model(imgs, targets)
     assert calls == [1]
     for k in out_l:
@@ -284,7 +284,7 @@ def test_model_eval_detections_canvas_equals_loop(cuda, monkeypatch):
         t["img_size"], t["pad_shape"] = (256, 320), (256, 320)
     with torch.no_grad():
         det_c = model(imgs, targets)
-        monkeypatch.setenv("RSDET_S2A_PACKED", "0")
+        monkeypatch.setattr(model.bbox_head, "packed", False)
         det_l = model(imgs, targets)
     assert len(det_c) == len(det_l) == 2
     n = 0
