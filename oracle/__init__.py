@@ -421,21 +421,23 @@ class _RefHipOracle:
                   int(points), ctypes.c_float(scale), self._p(out))
         return out
 
-    def poly_nms_sorted(self, boxes_sorted, thr):
-        """nms_poly.py:197-229 on score-sorted (n, 9) boxes -> bool keep (n,) in the sorted order."""
+    def poly_nms_sorted(self, boxes_sorted, thr, contract=True):
+        """nms_poly.py:197-229 on score-sorted (n, 9) boxes -> bool keep (n,) in the sorted order.  ``contract=False``:
+        the build of the same text with floating-point contraction off."""
         n = boxes_sorted.shape[0]
         keep = np.zeros(n, np.uint8)
+        fn = self.lib.ref_hip_poly_nms if contract else self.lib.ref_hip_nofma_poly_nms
         if n:
-            self._run(self.lib.ref_hip_poly_nms, self._p(boxes_sorted.contiguous()), n, ctypes.c_float(thr), _up(keep))
+            self._run(fn, self._p(boxes_sorted.contiguous()), n, ctypes.c_float(thr), _up(keep))
         return keep.astype(bool)
 
-    def poly_iou_pairs(self, p, q):
+    def poly_iou_pairs(self, p, q, contract=True):
         """devPolyIoU (nms_poly.py:135-150) of p[i], q[i] (n, 8) each."""
         import torch
         out = torch.empty((p.shape[0],), dtype=torch.float32, device=p.device)
+        fn = self.lib.ref_hip_poly_iou_pairs if contract else self.lib.ref_hip_nofma_poly_iou_pairs
         if p.shape[0]:
-            self._run(self.lib.ref_hip_poly_iou_pairs, self._p(p.contiguous()), self._p(q.contiguous()), p.shape[0],
-                      self._p(out))
+            self._run(fn, self._p(p.contiguous()), self._p(q.contiguous()), p.shape[0], self._p(out))
         return out
 
 

@@ -208,6 +208,12 @@ def main():
     tu += "namespace ref_rroi {\nusing std::min; using std::max;\n" + header("roi_align_rotated_v1.py", "CUDA_HEADER") + "\n}\n" + LAUNCH_RROI
     tu += "namespace ref_fr {\nusing std::min; using std::max;\n" + header("fr.py", "HEADER") + "\n}\n" + LAUNCH_FR
     tu += "namespace ref_poly {\n" + header("nms_poly.py", "HEADER") + "\n}\n" + LAUNCH_POLY
+    # the same polygon text once more with floating-point contraction OFF (nvcc -fmad=false / a CPU build): its signed
+    # triangle sums cancel to ~1e-3 of the IoU, so the reference's own results move by that much with the compiler's
+    # contraction choice; rsdet_poly_* follows the uncontracted arithmetic and must equal THIS build bit for bit
+    tu += ("#pragma clang fp contract(off)\nnamespace ref_poly_nofma {\n" + header("nms_poly.py", "HEADER") + "\n}\n"
+           + LAUNCH_POLY.replace("ref_poly", "ref_poly_nofma").replace("ref_hip_poly", "ref_hip_nofma_poly")
+           + "#pragma clang fp contract(fast)\n")
     os.makedirs(OUT_DIR, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="jdet_ref_hip_")
     try:

@@ -34,7 +34,7 @@ struct DwGeom {
   static constexpr int WIN = DW_ROWS + (K - 1) * D;
   // the kernel-column loop stays rolled for 7x7: unrolled, the compiler keeps all seven 26-value column windows live
   // (235 VGPRs, two waves per SIMD); rolled it is one window at a time
-  static constexpr int KW_UNROLL = K >= 7 ? 1 : K;
+  static constexpr int KW_UNROLL = K >= 5 ? 1 : K;
 };
 
 // coalesced staging of the (tile + halo) window of one plane, zero outside the plane
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
     for (int kh = 0; kh < K; ++kh) {
       const float wv = s_w[kh * K + kw];
 #pragma unroll
-      for (int r = 0; r < DW_ROWS; ++r) acc[r] += wv * win[r + kh * D];
+      for (int r = 0; r < DW_ROWS; ++r) acc[r] = __builtin_fmaf(wv, win[r + kh * D], acc[r]);   // (the TU is built -ffp-contract=off)
     }
   }
   const int ox = tx0 + tx;
@@ -114,55 +114,68 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
   }
 }
 
-// partial[(c * nslots + slot) * (K*K + 1) + t], slot = n * tiles + tile; t = K*K is the bias gradient
+// partial[(c * nslots + slot) * (K*K + 1) + t], slot = n * gridDim.y + blockIdx.y; t = K*K is the bias gradient.
+// A workgroup walks `tpw` tiles of ONE plane and keeps its K*K + 1 sums in REGISTERS across them (one per thread and
+// tap); the cross-lane reduction (6 butterfly steps per tap) runs ONCE per workgroup at the end.  The first form
+// reduced after every tile: 49 taps x 6 ds_bpermute per thread and tile made the 7x7 / 5x5 gradients of VAN's
+// attention branch instruction-bound at 0.1 of the HBM rate (profiles/r04_e_bench_kernels.json).
 template <int K, int D>
 __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                              const float* __restrict__ in_bias, int C, int H, int W,
-                                                             int tiles_x, int nslots, float* __restrict__ partial) {
+                                                             int tiles_x, int ntiles, int tpw, int nslots,
+                                                             float* __restrict__ partial) {
   using G = DwGeom<K, D>;
   constexpr int T = K * K + 1;
   __shared__ float s[G::LH * G::LWP];
   __shared__ float s_red[DW_NT / 64][T];
   const int plane = blockIdx.x, c = plane % C, n = plane / C;
-  const int ty0 = (blockIdx.y / tiles_x) * DW_TH, tx0 = (blockIdx.y % tiles_x) * DW_TW;
-  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s, in_bias ? in_bias[c] : 0.f);
   const int tx = threadIdx.x % DW_TW, tr = (threadIdx.x / DW_TW) * DW_ROWS;
-  float g[DW_ROWS];
-  {
-    const int ox = tx0 + tx;
-    const float* gp = gy + (long long)plane * H * W;
+  const float add = in_bias ? in_bias[c] : 0.f;
+  const float* xp = x + (long long)plane * H * W;
+  const float* gp = gy + (long long)plane * H * W;
+  float acc[T];
 #pragma unroll
-    for (int r = 0; r < DW_ROWS; ++r) {
-      const int oy = ty0 + tr + r;
-      g[r] = (ox < W && oy < H) ? gp[(long long)oy * W + ox] : 0.f;
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  const int t_begin = blockIdx.y * tpw, t_end = min(ntiles, t_begin + tpw);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int ty0 = (tile / tiles_x) * DW_TH, tx0 = (tile % tiles_x) * DW_TW;
+    if (tile != t_begin) __syncthreads();                      // the previous tile's window reads are done
+    dw_stage<K, D>(xp, H, W, ty0, tx0, s, add);
+    float g[DW_ROWS];
+    {
+      const int ox = tx0 + tx;
+#pragma unroll
+      for (int r = 0; r < DW_ROWS; ++r) {
+        const int oy = ty0 + tr + r;
+        g[r] = (ox < W && oy < H) ? gp[(long long)oy * W + ox] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r) acc[K * K] += g[r];
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+      float win[G::WIN];
+#pragma unroll
+      for (int i = 0; i < G::WIN; ++i) win[i] = s[(tr + i) * G::LWP + tx + kw * D];
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < DW_ROWS; ++r) v = __builtin_fmaf(g[r], win[r + kh * D], v);
+        acc[kh * K + kw] += v;
+      }
+      if (K >= 7) asm volatile("" ::: "memory");               // one column window live at a time (register budget)
     }
   }
-  __syncthreads();
-  // per kernel column: K partial sums (one per kernel row) over this thread's 8 outputs, reduced over the wave with
-  // butterflies and parked in LDS; the bias gradient rides along as one more value
+  // one reduction per workgroup: wave butterflies, then the four waves through LDS, in a fixed order
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    float v = 0.f;
 #pragma unroll
-    for (int r = 0; r < DW_ROWS; ++r) v += g[r];
+  for (int t = 0; t < T; ++t) {
+    float v = acc[t];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) s_red[wave][K * K] = v;
-  }
-#pragma unroll G::KW_UNROLL
-  for (int kw = 0; kw < K; ++kw) {
-    float win[G::WIN];
-#pragma unroll
-    for (int i = 0; i < G::WIN; ++i) win[i] = s[(tr + i) * G::LWP + tx + kw * D];
-#pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-      float v = 0.f;
-#pragma unroll
-      for (int r = 0; r < DW_ROWS; ++r) v += g[r] * win[r + kh * D];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) s_red[wave][kh * K + kw] = v;
-    }
+    if (lane == 0) s_red[wave][t] = v;
   }
   __syncthreads();
   if (threadIdx.x < T) {
@@ -278,19 +291,23 @@ extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const flo
     return RSDET_OK;
   }
   if (!grad_y || !x || !ws || ws_bytes < rsdet_dwconv2d_backward_weight_ws_size(N, C, H, W, K)) return RSDET_EINVAL;
-  const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH;
-  const int nslots = N * tx * ty;
-  const dim3 grid(N * C, tx * ty);
+  const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH, ntiles = tx * ty;
+  // tiles per workgroup: as many as still leave ~1 500 workgroups (6 per CU) to the launch
+  long long tpw = ((long long)N * C * ntiles) / 1536;
+  tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
+  const int groups = (int)((ntiles + tpw - 1) / tpw);
+  const int nslots = N * groups;                 // <= N * ntiles: the workspace of the one-tile form always suffices
+  const dim3 grid(N * C, groups);
   float* partial = (float*)ws;
   if (K == 3)
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<3, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, nslots,
-                       partial);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<3, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, ntiles,
+                       (int)tpw, nslots, partial);
   else if (K == 5)
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<5, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, nslots,
-                       partial);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<5, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, ntiles,
+                       (int)tpw, nslots, partial);
   else
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 3>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, nslots,
-                       partial);
+    hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 3>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, ntiles,
+                       (int)tpw, nslots, partial);
   hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, partial, nslots, K * K + 1, grad_weight,
                      grad_bias);
   return rsdet_launch_status();

@@ -19,7 +19,8 @@ import torch
 
 from .. import _lib
 
-__all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "box_iou_rotated_fast", "anchor_target_rotated"]
+__all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "box_iou_rotated_fast", "anchor_target_rotated",
+           "GridSpec", "s2anet_grid_spec", "box_iou_rotated_grid"]
 
 _TI = 16  # rows per tile (csrc/anchor_target.hip T_TI)
 _prepared_cache = {}
@@ -220,6 +221,68 @@ def box_iou_rotated_fast(boxes1, boxes2, row_offsets=None, ks=None, max_rows=Non
                                             _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,
                                             _lib.ptr(ious), _lib.stream_ptr())
     _lib.check(rc, "rsdet_box_iou_rotated_fast_f32")
+    return ious
+
+
+class GridSpec:
+    """A column set that is one box per cell of a pyramid of regular grids (include/rsdet.h: RsdetGridLevel): per level
+    (H, W, stride, x0, y0, max_rad[, max_shift]); columns level by level, x fastest.  ``exact=True``: the boxes ARE the
+    generated anchors (max_shift 0, max_rad from the anchor size); ``exact=False``: a refinement of them -- the bounds
+    are measured on the device per call (rsdet_iou_grid_bounds_f32, no sync)."""
+    __slots__ = ("levels", "n", "exact", "_arr")
+
+    def __init__(self, levels, exact=True):
+        self.levels, self.exact = [tuple(l) for l in levels], bool(exact)
+        arr = (_lib.GridLevel * len(self.levels))()
+        at = 0
+        for k, (H, W, stride, x0, y0, max_rad) in enumerate(self.levels):
+            arr[k] = _lib.GridLevel(at, int(H), int(W), float(x0), float(y0), float(stride), 0.0, float(max_rad))
+            at += int(H) * int(W)
+        self._arr, self.n = arr, at
+
+
+def s2anet_grid_spec(featmap_sizes, strides, scale=4.0, exact=True):
+    """The grid of AnchorGeneratorRotatedS2ANet (anchor_generator.py:22-78): level l has one (scale * s) square anchor per
+    cell, centre (0.5 (s - 1) + j s, 0.5 (s - 1) + i s).  max_rad = the prepared radius of that square, rounded up."""
+    lv = []
+    for (H, W), s in zip(featmap_sizes, strides):
+        side = float(scale) * float(s)
+        lv.append((int(H), int(W), float(s), 0.5 * (s - 1), 0.5 * (s - 1), (side * 1.0001 + 1e-3) * 1.0005))
+    return GridSpec(lv, exact=exact)
+
+
+def box_iou_rotated_grid(boxes1, boxes2, grid, row_offsets=None, version=0, out=None, prepared=None,
+                         cache_prepared=False, prepared1=None):
+    """``box_iou_rotated_fast`` -- the same values, bit for bit -- for columns that are a pyramid grid (``grid``: a
+    GridSpec): the cells a gt can touch are a closed-form window per level, nothing is tested pair by pair, and one
+    workgroup composes one row x 4 096 columns in LDS and stores every element once (csrc/iou_grid.hip).
+    ``boxes2`` (A,5) shared or (G,A,5) per group with ``row_offsets`` (G+1) int32 on the device."""
+    _lib.require_cuda_f32(boxes1, boxes2)
+    lib = _lib.load()
+    b1, b2 = boxes1.contiguous(), boxes2.contiguous()
+    n1, A = b1.shape[0], b2.shape[-2]
+    per_group = 1 if b2.dim() == 3 else 0
+    G = (row_offsets.numel() - 1) if row_offsets is not None else 1
+    if grid.n != A:
+        raise _lib.RsdetError("grid spec covers %d columns, boxes2 has %d" % (grid.n, A))
+    ious = out if out is not None else torch.empty((n1, A), dtype=torch.float32, device=b1.device)
+    if n1 == 0 or A == 0:
+        return ious
+    prep = prepared if prepared is not None else prepare_boxes(b2, cache=cache_prepared)
+    assert prep.n_per_group == A and prep.groups == (G if per_group else 1)
+    bounds = None
+    if not grid.exact:
+        bounds = torch.empty((prep.groups, len(grid.levels), 2), dtype=torch.float32, device=b1.device)
+        rc = lib.rsdet_iou_grid_bounds_f32(_lib.ptr(prep.buf), A, prep.groups, grid._arr, len(grid.levels),
+                                           _lib.ptr(bounds), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_iou_grid_bounds_f32")
+    if prepared1 is not None:
+        assert prepared1.n_total == n1 and prepared1.groups == 1
+    rc = lib.rsdet_box_iou_rotated_grid_f32(_lib.ptr(b1), n1, b1.shape[-1], _lib.ptr(row_offsets), G,
+                                            _lib.ptr(prepared1.buf) if prepared1 is not None else None,
+                                            _lib.ptr(prep.buf), A, per_group, grid._arr, len(grid.levels),
+                                            _lib.ptr(bounds), version, _lib.ptr(ious), _lib.stream_ptr())
+    _lib.check(rc, "rsdet_box_iou_rotated_grid_f32")
     return ious
 
 

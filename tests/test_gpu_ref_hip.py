@@ -140,8 +140,11 @@ def test_feature_refine_against_reference_device_code(cuda, rh, N, C, H, points)
 
 @pytest.mark.parametrize("n", [2000, 333])
 def test_poly_nms_against_reference_device_code(cuda, rh, n):
-    """Polygon NMS (nms_poly.py:135-231): pair IoUs of the reference's devPolyIoU within 1e-4 of ours (device FMA
-    contraction moves the last bits of its signed triangle sums), keep list identical."""
+    """Polygon NMS (nms_poly.py:135-231).  The reference sums signed fp32 triangle intersections of ~1e5 px^2 each, so
+    its own IoUs move by ~3e-3 with the compiler's FMA contraction (measured here: device build with contraction on vs
+    off).  rsdet_poly_* follows the UNCONTRACTED arithmetic (the CPU / -fmad=false semantics the golden fixtures pin):
+    bit-identical to the reference text compiled with contraction off, within that contraction noise of the default
+    build; keep lists identical to the former, and to the latter up to pairs that sit inside the noise of the threshold."""
     from rs_detection_amd.ops import poly_nms, poly_iou_f32
     from rs_detection_amd.ops.box_coder import rotated_box_to_poly
     from rs_detection_amd.utils import synthetic as syn
@@ -153,11 +156,18 @@ def test_poly_nms_against_reference_device_code(cuda, rh, n):
     m = min(n, 400)
     ours = poly_iou_f32(srt[:m, :8].contiguous(), srt[:m, :8].contiguous())
     ii, jj = torch.meshgrid(torch.arange(m, device=cuda), torch.arange(m, device=cuda), indexing="ij")
-    theirs = rh.poly_iou_pairs(srt[ii.reshape(-1), :8].contiguous(), srt[jj.reshape(-1), :8].contiguous()).view(m, m)
-    assert float((ours - theirs).abs().max()) <= 1e-4
+    pa, pb = srt[ii.reshape(-1), :8].contiguous(), srt[jj.reshape(-1), :8].contiguous()
+    exact = rh.poly_iou_pairs(pa, pb, contract=False).view(m, m)
+    assert (ours == exact).all(), float((ours - exact).abs().max())
+    fma = rh.poly_iou_pairs(pa, pb, contract=True).view(m, m)
+    noise = float((fma - exact).abs().max())
+    print("poly IoU: contraction moves the reference by", noise)
+    assert noise <= 1e-2
     for thr in (0.1, 0.5):
-        keep_ref = rh.poly_nms_sorted(srt, thr)
-        want = order.cpu().numpy()[keep_ref]
         got = poly_nms(dets, thr).cpu().numpy()
-        # a pair within the contraction noise of the threshold may legitimately flip: none on these inputs
-        assert len(got) == len(want) and (np.sort(got) == np.sort(want)).all(), (thr, len(got), len(want))
+        want = order.cpu().numpy()[rh.poly_nms_sorted(srt, thr, contract=False)]
+        assert len(got) == len(want) and (got == want).all(), (thr, len(got), len(want))
+        other = order.cpu().numpy()[rh.poly_nms_sorted(srt, thr, contract=True)]
+        diff = len(set(got.tolist()) ^ set(other.tolist()))
+        print("poly NMS thr %g: %d kept, %d differ under contraction" % (thr, len(got), diff))
+        assert diff <= max(4, n // 50)

@@ -2,9 +2,16 @@
 // whoever makes it (torch, MIOpen, rocBLAS / hipBLASLt, librsdet_hip.so).  Test infrastructure for
 // tests/test_gpu_guards.py -- the "launches per step" regression guard without a profiler in the loop.
 //   g++ -O2 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include launch_counter.cpp -o liblaunch_counter.so -ldl
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <dlfcn.h>
+#include <link.h>
 #include <hip/hip_runtime_api.h>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 static std::atomic<long long> g_launches{0}, g_fills{0}, g_copies{0};
 
@@ -14,7 +21,28 @@ long long rsdet_lc_fills() { return g_fills.load(); }
 long long rsdet_lc_copies() { return g_copies.load(); }
 }
 
-template <class F> static F next_sym(const char* name) { return reinterpret_cast<F>(dlsym(RTLD_NEXT, name)); }
+// The real entry point.  RTLD_NEXT only sees the GLOBAL lookup scope; Python loads torch's libraries RTLD_LOCAL, so
+// libamdhip64 is usually not in it (the preloaded shim still wins the lookup for the callers: LD_PRELOAD objects are
+// searched first for every object).  Fallback: find the loaded libamdhip64 by walking the link maps.
+static int find_hip(struct dl_phdr_info* info, size_t, void* out) {
+  if (info->dlpi_name && strstr(info->dlpi_name, "libamdhip64")) {
+    *static_cast<void**>(out) = dlopen(info->dlpi_name, RTLD_NOW | RTLD_NOLOAD);
+    return 1;
+  }
+  return 0;
+}
+static void* real_sym(const char* name) {
+  if (void* p = dlsym(RTLD_NEXT, name)) return p;
+  static void* hip = nullptr;
+  if (!hip) dl_iterate_phdr(find_hip, &hip);
+  void* p = hip ? dlsym(hip, name) : nullptr;
+  if (!p) {
+    fprintf(stderr, "launch_counter: cannot resolve %s\n", name);
+    abort();
+  }
+  return p;
+}
+template <class F> static F next_sym(const char* name) { return reinterpret_cast<F>(real_sym(name)); }
 #define NEXT(name) static auto real = next_sym<decltype(&name)>(#name)
 
 extern "C" {
