@@ -191,7 +191,7 @@ def kernel_rooflines(device, targets):
     from rs_detection_amd.ops.anchor_target import s2anet_grid_spec
     spec = s2anet_grid_spec([(TILE // s_, TILE // s_) for s_ in (8, 16, 32, 64, 128)], (8, 16, 32, 64, 128))
     if spec.n == A:
-        t4 = event_time(lambda: ops.box_iou_rotated_grid(gt, anchors, spec, ro, out=ov, prepared=prep), 50)
+        t4 = event_time(lambda: ops.box_iou_rotated_grid(gt, anchors, spec, out=ov), 50)
         out[GRID_ROW] = dict(
             bound="hbm", achieved=by / t4 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t4 / 1e9 / HBM_PEAK_GBS,
             traffic=pmc_traffic("box_iou_rotated_grid (1 launch)", (n1, A) == (556, 21824)), us=t4 * 1e6,

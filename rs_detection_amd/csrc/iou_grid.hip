@@ -44,20 +44,45 @@ struct GridArgs {
   const float* boxes1;
   const BoxPre* pre1;
   int stride1, n1;
-  const BoxPre* pre2;
-  long long slab;            // prepared boxes per group (even pitch), 0 when the columns are shared
   int n2, chunks;
-  const int* row_offsets;    // n_groups + 1 (device) or nullptr
-  int n_groups;
   RsdetGridLevel lv[GR_MAXL];
   int nl;
-  const float* bounds;       // optional (groups, nl, 2) device floats: max centre displacement, max prepared radius
   int vec4;
   float* out;
 };
 
+// The prepared form of the GENERATED anchor of cell (i, j) is prepare_box() (rsdet_geom.h) of (cx, cy, w, h, theta = 0),
+// operation by operation -- cos(0) = 1, sin(0) = 0 exactly, so the fp64 sincos drops out and the result is bit-identical.
+// Everything but the centre is a constant of the level: kept once per workgroup in LDS.
+struct GrLevelPre {
+  int col0, W;
+  float x0, y0, stride;
+  float cw, sw, ch, sh, area, rad, lu, lv;
+};
+__device__ __forceinline__ GrLevelPre grid_level_pre(const RsdetGridLevel& L) {
+  GrLevelPre p;
+  const float c2 = 0.5f, s2 = 0.0f;
+  p.col0 = L.col0, p.W = L.W, p.x0 = L.x0, p.y0 = L.y0, p.stride = L.stride;
+  p.cw = c2 * L.box_w;
+  p.sw = s2 * L.box_w;
+  p.ch = c2 * L.box_h;
+  p.sh = s2 * L.box_h;
+  p.area = L.box_w * L.box_h;
+  p.rad = 0.5f * (fabsf(L.box_w) + fabsf(L.box_h)) * 1.0001f + 1e-3f;
+  p.lu = sqrtf(p.cw * p.cw + p.sw * p.sw);
+  p.lv = sqrtf(p.ch * p.ch + p.sh * p.sh);
+  return p;
+}
+__device__ __forceinline__ BoxPre grid_cell_box(const GrLevelPre& L, int i, int j) {
+  BoxPre p;
+  p.cx = L.x0 + (float)j * L.stride;
+  p.cy = L.y0 + (float)i * L.stride;
+  p.cw = L.cw, p.sw = L.sw, p.ch = L.ch, p.sh = L.sh, p.area = L.area, p.rad = L.rad, p.lu = L.lu, p.lv = L.lv;
+  return p;
+}
+
 struct GrWin {
-  int col0, W, i0, j0, nj, cnt;      // candidate k of the level: cell (i0 + k / nj, j0 + k % nj)
+  int i0, j0, nj, cnt;      // candidate k of the level: cell (i0 + k / nj, j0 + k % nj)
 };
 
 template <int VERSION>
@@ -66,11 +91,12 @@ __global__ __launch_bounds__(GR_NT) void iou_grid_kernel(const GridArgs a) {
   __shared__ unsigned long long s_flag[GR_WORDS];
   __shared__ unsigned short s_end[GR_WORDS];
   __shared__ F2 s_pts[kQuadSlots * 16];
-  __shared__ GrWin s_win[GR_MAXL];
-  __shared__ unsigned s_dirty[GR_MAXL];
+  __shared__ GrLevelPre s_lv[GR_MAXL];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = (int)blockIdx.x / a.chunks, ch = (int)blockIdx.x - row * a.chunks;
+  // chunk-major, last chunk first: the chunks of the upper pyramid levels (every gt has candidates there) start first,
+  // the level-0 chunks -- most of them untouched by a given gt -- fill in behind them
+  const int ch = a.chunks - 1 - (int)blockIdx.x / a.n1, row = (int)blockIdx.x % a.n1;
   const int c0 = ch * GR_CHUNK, c1 = min(a.n2, c0 + GR_CHUNK), ncol = c1 - c0;
 
   // ---- the row: raw values first (centre + sizes are all the windows need)
@@ -84,66 +110,51 @@ __global__ __launch_bounds__(GR_NT) void iou_grid_kernel(const GridArgs a) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) rraw[k] = rp[k];
   }
-  int g = 0;
-  if (a.row_offsets && (a.slab || a.bounds)) {       // the row's group: the last g with row_offsets[g] <= row
-    for (int b = 0; b < a.n_groups; b += 64) {
-      const int gg = b + lane;
-      const bool le = gg < a.n_groups && a.row_offsets[gg] <= row;
-      g += __popcll(__ballot(le));
-    }
-    g = max(g - 1, 0);
-  }
   const float rcx = rraw[0], rcy = rraw[1];
   const float rrad = a.pre1 ? rraw[7] : 0.5f * (fabsf(rraw[2]) + fabsf(rraw[3])) * 1.0001f + 1e-3f;   // == prepare_box
   const bool finite = fabsf(rcx) < 1e30f && fabsf(rcy) < 1e30f && rrad < 1e30f;   // NaN / Inf rows: every cell is a candidate
 
-  // ---- per level (lane l < nl of wave 0): the cell window inside this chunk, and the 1 KB segments it can reach
-  if (tid < GR_MAXL) {
-    GrWin w{0, 1, 0, 0, 0, 0};
-    unsigned dirty = 0u;
-    if (tid < a.nl) {
-      const RsdetGridLevel L = a.lv[tid];
-      float shift = L.max_shift, lrad = L.max_rad;
-      if (a.bounds) {
-        shift = a.bounds[((long long)g * a.nl + tid) * 2 + 0];
-        lrad = a.bounds[((long long)g * a.nl + tid) * 2 + 1];
-      }
-      // grid rows of the level whose columns fall into [c0, c1)
-      const int lo = max(c0 - L.col0, 0), hi = min(c1 - L.col0, L.H * L.W) - 1;
-      int i0 = lo / L.W, i1 = hi / L.W, j0 = 0, j1 = L.W - 1;
-      bool any = hi >= lo;
-      const bool bounded = finite && shift < 1e30f && lrad < 1e30f;    // (a NaN bound fails both compares)
-      if (any && bounded) {
-        // surely_disjoint keeps pairs with |d| <= (r_gt + r_col) * sqrt(1.0001); window: that radius plus the level's
-        // displacement bound, widened by far more than the rounding of these few operations
-        const float R = (rrad + lrad) * 1.0002f + shift + 0.02f + 1e-5f * (fabsf(rcx) + fabsf(rcy));
-        const float inv = 1.0f / L.stride;
-        const float fj0 = floorf((rcx - R - L.x0) * inv), fj1 = ceilf((rcx + R - L.x0) * inv);
-        const float fi0 = floorf((rcy - R - L.y0) * inv), fi1 = ceilf((rcy + R - L.y0) * inv);
-        // (clamped as floats: the quotient of a far-away gt does not fit an int)
-        const float cj0 = fmaxf(fj0, 0.f), cj1 = fminf(fj1, (float)(L.W - 1));
-        const float ci0 = fmaxf(fi0, (float)i0), ci1 = fminf(fi1, (float)i1);
-        any = cj1 >= cj0 && ci1 >= ci0;
-        if (any) j0 = (int)cj0, j1 = (int)cj1, i0 = (int)ci0, i1 = (int)ci1;
-      }
-      if (any) {
-        w.col0 = L.col0, w.W = L.W, w.i0 = i0, w.j0 = j0, w.nj = j1 - j0 + 1;
-        w.cnt = (i1 - i0 + 1) * w.nj;
-        const int first = max(L.col0 + i0 * L.W + j0, c0) - c0, last = min(L.col0 + i1 * L.W + j1, c1 - 1) - c0;
-        const int s0 = first / GR_SEG, s1 = last / GR_SEG;
-        dirty = (s1 >= 31 ? 0xffffffffu : ((2u << s1) - 1u)) & ~((1u << s0) - 1u);
-      }
+  // ---- per level: the cell window inside this chunk and the 1 KB segments it can reach.  Lane l of every wave works
+  // out level l; the results travel to all lanes as wave-uniform values (v_readlane): no LDS round trip, no barrier
+  GrWin mywin{0, 0, 1, 0};
+  unsigned mydirty = 0u;
+  if (lane < a.nl) {
+    const RsdetGridLevel L = a.lv[lane];
+    const int lo = max(c0 - L.col0, 0), hi = min(c1 - L.col0, L.H * L.W) - 1;    // the level's columns in [c0, c1)
+    int i0 = lo / L.W, i1 = hi / L.W, j0 = 0, j1 = L.W - 1;
+    bool any = hi >= lo;
+    if (any && finite) {
+      // surely_disjoint keeps pairs with |d| <= (r_gt + r_cell) * sqrt(1.0001); the window is that radius widened by
+      // far more than the rounding of these few operations
+      const float lrad = 0.5f * (fabsf(L.box_w) + fabsf(L.box_h)) * 1.0001f + 1e-3f;
+      const float R = (rrad + lrad) * 1.0002f + 0.02f + 1e-5f * (fabsf(rcx) + fabsf(rcy));
+      const float inv = 1.0f / L.stride;
+      const float fj0 = floorf((rcx - R - L.x0) * inv), fj1 = ceilf((rcx + R - L.x0) * inv);
+      const float fi0 = floorf((rcy - R - L.y0) * inv), fi1 = ceilf((rcy + R - L.y0) * inv);
+      // (clamped as floats: the quotient of a far-away gt does not fit an int)
+      const float cj0 = fmaxf(fj0, 0.f), cj1 = fminf(fj1, (float)(L.W - 1));
+      const float ci0 = fmaxf(fi0, (float)i0), ci1 = fminf(fi1, (float)i1);
+      any = cj1 >= cj0 && ci1 >= ci0;
+      if (any) j0 = (int)cj0, j1 = (int)cj1, i0 = (int)ci0, i1 = (int)ci1;
     }
-    s_win[tid] = w;
-    s_dirty[tid] = dirty;
+    if (any) {
+      mywin.i0 = i0, mywin.j0 = j0, mywin.nj = j1 - j0 + 1, mywin.cnt = (i1 - i0 + 1) * mywin.nj;
+      const int first = max(L.col0 + i0 * L.W + j0, c0) - c0, last = min(L.col0 + i1 * L.W + j1, c1 - 1) - c0;
+      const int s0 = first / GR_SEG, s1 = last / GR_SEG;
+      mydirty = (s1 >= 31 ? 0xffffffffu : ((2u << s1) - 1u)) & ~((1u << s0) - 1u);
+    }
   }
-  lds_barrier();
+  GrWin win[GR_MAXL];
   unsigned dirty = 0u;
   int total = 0;
 #pragma unroll
   for (int l = 0; l < GR_MAXL; ++l) {
-    dirty |= s_dirty[l];
-    total += s_win[l].cnt;
+    win[l].i0 = __builtin_amdgcn_readlane(mywin.i0, l);
+    win[l].j0 = __builtin_amdgcn_readlane(mywin.j0, l);
+    win[l].nj = __builtin_amdgcn_readlane(mywin.nj, l);
+    win[l].cnt = __builtin_amdgcn_readlane(mywin.cnt, l);
+    dirty |= (unsigned)__builtin_amdgcn_readlane((int)mydirty, l);
+    total += win[l].cnt;
   }
   const int nseg = (ncol + GR_SEG - 1) / GR_SEG;
   float* orow = a.out + (long long)row * a.n2 + c0;
@@ -170,6 +181,7 @@ __global__ __launch_bounds__(GR_NT) void iou_grid_kernel(const GridArgs a) {
 #pragma unroll
     for (int k = 0; k < GR_CHUNK / 4 / GR_NT; ++k) v4[tid + k * GR_NT] = z;
     if (tid < GR_WORDS) s_flag[tid] = 0ull;
+    if (tid < a.nl) s_lv[tid] = grid_level_pre(a.lv[tid]);
   }
   // the row, prepared (fp64 sincos: the same BoxPre the other entry points use), every lane for itself -- uniform
   BoxPre rb;
@@ -182,29 +194,25 @@ __global__ __launch_bounds__(GR_NT) void iou_grid_kernel(const GridArgs a) {
   }
   lds_barrier();
 
-  // ---- candidates: the cells of the windows.  Column box from the prepared set; the tile kernel's tests in its order
-  const BoxPre* cols = a.pre2 + (long long)g * a.slab;
+  // ---- candidates: the cells of the windows; the tile kernel's tests in the tile kernel's order
   for (int k = tid; k < total; k += GR_NT) {
     int kk = k, l = 0;
 #pragma unroll
     for (int q = 0; q < GR_MAXL - 1; ++q) {
-      const int c = s_win[q].cnt;
-      if (l == q && kk >= c) {
-        kk -= c;
+      if (l == q && kk >= win[q].cnt) {
+        kk -= win[q].cnt;
         l = q + 1;
       }
     }
-    const GrWin w = s_win[l];
-    const int di = kk / w.nj, dj = kk - di * w.nj;
-    const int col = w.col0 + (w.i0 + di) * w.W + (w.j0 + dj);
-    if (col < c0 || col >= c1) continue;
-    BoxPre cb;
-    {
-      const float2* cp = reinterpret_cast<const float2*>(cols + col);
-      float2* cd = reinterpret_cast<float2*>(&cb);
+    int wi0 = win[0].i0, wj0 = win[0].j0, wnj = win[0].nj;
 #pragma unroll
-      for (int q = 0; q < 5; ++q) cd[q] = cp[q];
-    }
+    for (int q = 1; q < GR_MAXL; ++q)
+      if (l == q) wi0 = win[q].i0, wj0 = win[q].j0, wnj = win[q].nj;
+    const int di = kk / wnj, dj = kk - di * wnj;
+    const int ci = wi0 + di, cj = wj0 + dj;
+    const int col = s_lv[l].col0 + ci * s_lv[l].W + cj;
+    if (col < c0 || col >= c1) continue;
+    const BoxPre cb = grid_cell_box(s_lv[l], ci, cj);
     const float dx = rb.cx - cb.cx, dy = rb.cy - cb.cy, rr = rb.rad + cb.rad;
     if (dx * dx + dy * dy > rr * rr * 1.0001f) continue;                    // == surely_disjoint(rb, cb)
     if (sat_disjoint<VERSION>(rb, cb)) continue;
@@ -230,14 +238,12 @@ __global__ __launch_bounds__(GR_NT) void iou_grid_kernel(const GridArgs a) {
       const bool on = q < nflag;
       int word, bit;
       locate_bit<GR_WORDS>(s_flag, s_end, on ? q : 0, word, bit);
-      const int at = (word << 6) | bit;
-      BoxPre cb;
-      {
-        const float2* cp = reinterpret_cast<const float2*>(cols + c0 + at);
-        float2* cd = reinterpret_cast<float2*>(&cb);
-#pragma unroll
-        for (int qq = 0; qq < 5; ++qq) cd[qq] = cp[qq];
-      }
+      const int at = (word << 6) | bit, col = c0 + at;
+      int l = 0;
+      for (int qq = 1; qq < a.nl; ++qq)
+        if (col >= s_lv[qq].col0) l = qq;
+      const int rel = col - s_lv[l].col0, ci = rel / s_lv[l].W, cj = rel - ci * s_lv[l].W;
+      const BoxPre cb = grid_cell_box(s_lv[l], ci, cj);
       const float v = pair_iou_quad<VERSION>(rb, cb, qscr, lane);
       if (on && (lane & 3) == 0) s_val[at] = v;
       lds_wave_order();
@@ -260,39 +266,9 @@ __global__ __launch_bounds__(GR_NT) void iou_grid_kernel(const GridArgs a) {
   }
 }
 
-// per-level bounds of a column set that is a grid moved by a refinement: max |centre - cell centre| and max prepared
-// radius, per (group, level).  One workgroup per (level, group); the maxima are exact (max is order-free).
-__global__ __launch_bounds__(256) void iou_grid_bounds_kernel(const BoxPre* __restrict__ pre2, long long slab, GridArgs a,
-                                                              float* __restrict__ bounds) {
-  __shared__ float s_m[2][4];
-  const int l = blockIdx.x, g = blockIdx.y;
-  const RsdetGridLevel L = a.lv[l];
-  const BoxPre* cols = pre2 + (long long)g * slab + L.col0;
-  float ms = 0.f, mr = 0.f;
-  bool bad = false;
-  for (int k = threadIdx.x; k < L.H * L.W; k += 256) {
-    const int i = k / L.W, j = k - i * L.W;
-    const float dx = cols[k].cx - (L.x0 + j * L.stride), dy = cols[k].cy - (L.y0 + i * L.stride);
-    const float d = sqrtf(dx * dx + dy * dy) * 1.0001f + 1e-3f, r = cols[k].rad;
-    bad |= !(d < 1e30f) || !(r < 1e30f);
-    ms = fmaxf(ms, d), mr = fmaxf(mr, r);
-  }
-  if (bad) ms = mr = INFINITY;     // a non-finite column: the windows of this level cover it all
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ms = fmaxf(ms, __shfl_xor(ms, off)), mr = fmaxf(mr, __shfl_xor(mr, off));
-  if ((threadIdx.x & 63) == 0) s_m[0][threadIdx.x >> 6] = ms, s_m[1][threadIdx.x >> 6] = mr;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    bounds[((long long)g * a.nl + l) * 2 + 0] = fmaxf(fmaxf(s_m[0][0], s_m[0][1]), fmaxf(s_m[0][2], s_m[0][3]));
-    bounds[((long long)g * a.nl + l) * 2 + 1] = fmaxf(fmaxf(s_m[1][0], s_m[1][1]), fmaxf(s_m[1][2], s_m[1][3]));
-  }
-}
-
 }  // namespace rsdet
 
 using namespace rsdet;
-
-static inline size_t grid_up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 static int grid_levels_ok(const RsdetGridLevel* levels, int n_levels, int n2) {
   if (!levels || n_levels < 1 || n_levels > GR_MAXL) return 0;
@@ -306,35 +282,18 @@ static int grid_levels_ok(const RsdetGridLevel* levels, int n_levels, int n2) {
 
 extern "C" int rsdet_box_iou_rotated_grid_chunk(void) { return GR_CHUNK; }
 
-extern "C" int rsdet_iou_grid_bounds_f32(const void* prepared2, int n2, int n_groups, const RsdetGridLevel* levels,
-                                         int n_levels, float* bounds, void* stream) {
-  if (n2 <= 0 || n_groups < 1 || !prepared2 || !bounds || !grid_levels_ok(levels, n_levels, n2)) return RSDET_EINVAL;
-  GridArgs a{};
-  for (int l = 0; l < n_levels; ++l) a.lv[l] = levels[l];
-  a.nl = n_levels;
-  hipLaunchKernelGGL(iou_grid_bounds_kernel, dim3(n_levels, n_groups), dim3(256), 0, (hipStream_t)stream,
-                     (const BoxPre*)prepared2, (long long)((n2 + 1) & ~1), a, bounds);
-  return rsdet_launch_status();
-}
-
-extern "C" int rsdet_box_iou_rotated_grid_f32(const float* boxes1, int n1, int stride1, const int* row_offsets,
-                                              int n_groups, const void* prepared1, const void* prepared2, int n2,
-                                              int per_group, const RsdetGridLevel* levels, int n_levels,
-                                              const float* bounds, int version, float* ious, void* stream) {
-  if (n1 < 0 || n2 < 0 || n_groups < 1 || stride1 < 5 || (version != 0 && version != 1)) return RSDET_EINVAL;
+extern "C" int rsdet_box_iou_rotated_grid_f32(const float* boxes1, int n1, int stride1, const void* prepared1, int n2,
+                                              const RsdetGridLevel* levels, int n_levels, int version, float* ious,
+                                              void* stream) {
+  if (n1 < 0 || n2 < 0 || stride1 < 5 || (version != 0 && version != 1)) return RSDET_EINVAL;
   if (n1 == 0 || n2 == 0) return RSDET_OK;
-  if (!boxes1 || !prepared2 || !ious || !grid_levels_ok(levels, n_levels, n2)) return RSDET_EINVAL;
-  if (!row_offsets && n_groups != 1) return RSDET_EINVAL;
+  if (!boxes1 || !ious || !grid_levels_ok(levels, n_levels, n2)) return RSDET_EINVAL;
   GridArgs a{};
   a.boxes1 = boxes1, a.stride1 = stride1, a.n1 = n1;
   a.pre1 = (const BoxPre*)prepared1;
-  a.pre2 = (const BoxPre*)prepared2;
-  a.slab = per_group ? (long long)((n2 + 1) & ~1) : 0;
   a.n2 = n2, a.chunks = (n2 + GR_CHUNK - 1) / GR_CHUNK;
-  a.row_offsets = row_offsets, a.n_groups = n_groups;
   for (int l = 0; l < n_levels; ++l) a.lv[l] = levels[l];
   a.nl = n_levels;
-  a.bounds = bounds;
   a.vec4 = ((n2 & 3) == 0 && ((uintptr_t)ious & 15) == 0) ? 1 : 0;
   a.out = ious;
   const long long grid = (long long)n1 * a.chunks;
@@ -343,6 +302,5 @@ extern "C" int rsdet_box_iou_rotated_grid_f32(const float* boxes1, int n1, int s
     hipLaunchKernelGGL(iou_grid_kernel<0>, dim3((unsigned)grid), dim3(GR_NT), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(iou_grid_kernel<1>, dim3((unsigned)grid), dim3(GR_NT), 0, (hipStream_t)stream, a);
-  (void)grid_up256;
   return rsdet_launch_status();
 }

@@ -86,10 +86,82 @@ class BaseSampler:
         return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
 
     @staticmethod
+    def priorities(n, device):
+        """One uniform draw per candidate: "the k candidates with the largest draws" is a uniform k-subset, which is what
+        ``gallery[randperm(len(gallery))[:k]]`` (sampler.py:139-149) draws -- without knowing len(gallery) on the host."""
+        return torch.rand((n,), device=device)
+
+    def sample_masked(self, assign_result, bboxes, gt_bboxes, gt_labels=None, valid=None):
+        """``sample`` (sampler.py:57-111) with FIXED-SIZE outputs and no host synchronisation: the train step's form.
+        Same distribution of samples: min(#pos, num * pos_fraction) positives and negatives up to ``num`` (``neg_pos_ub``
+        honoured), each a uniform subset.  ``valid`` (n,) bool: rows of ``bboxes`` that are padding (a fixed-size
+        proposal list) are neither positive nor negative.  Does not modify ``assign_result``."""
+        gt_bboxes, bboxes = gt_bboxes.to(torch.float32), bboxes.to(torch.float32)
+        if bboxes.dim() < 2:
+            bboxes = bboxes[None, :]
+        bboxes = bboxes[:, :self.box_dim]
+        dev = bboxes.device
+        gt_inds, labels = assign_result.gt_inds, assign_result.labels
+        if valid is not None:
+            gt_inds = torch.where(valid, gt_inds, torch.full_like(gt_inds, -1))
+        if self.add_gt_as_proposals:
+            K = gt_bboxes.shape[0]
+            bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+            gt_inds = torch.cat([torch.arange(1, K + 1, dtype=gt_inds.dtype, device=dev), gt_inds])
+            if labels is not None:
+                labels = torch.cat([gt_labels.to(labels.dtype), labels])
+        n, num = bboxes.shape[0], int(self.num)
+        r = self.priorities(n, dev)
+        minus = torch.full_like(r, -1.0)
+        kp, kn = min(int(self.num * self.pos_fraction), n), min(num, n)
+        pk, pi = torch.topk(torch.where(gt_inds > 0, r, minus), kp)
+        pv = pk >= 0
+        n_pos = pv.sum()
+        quota = num - n_pos
+        if self.neg_pos_ub >= 0:
+            quota = torch.minimum(quota, (self.neg_pos_ub * n_pos.clamp(min=1)).long())
+        nk, ni = torch.topk(torch.where(gt_inds == 0, r, minus), kn)
+        nv = (nk >= 0) & (torch.arange(kn, device=dev) < quota)
+        inds = torch.cat([pi, ni])
+        is_pos = torch.cat([pv, torch.zeros_like(nv)])
+        val = torch.cat([pv, nv])
+        # the reference's order: positives by ascending index, negatives by ascending index (its `.unique()`), rest last
+        key = torch.where(val, (~is_pos).long(), torch.full_like(inds, 2)) * (n + 1) + inds
+        order = torch.argsort(key)[:num]
+        inds, is_pos, val = inds[order], is_pos[order], val[order]
+        if inds.numel() < num:                     # fewer boxes than slots: pad with unused slots
+            pad = num - inds.numel()
+            inds = torch.cat([inds, inds.new_zeros(pad)])
+            is_pos = torch.cat([is_pos, is_pos.new_zeros(pad)])
+            val = torch.cat([val, val.new_zeros(pad)])
+        is_pos = is_pos & val
+        gi = (gt_inds[inds].long() - 1).clamp(min=0)
+        if gt_bboxes.shape[0] > 0:
+            pos_gt = gt_bboxes[gi, :]
+        else:
+            pos_gt = gt_bboxes.new_zeros((num, max(gt_bboxes.shape[-1], 4)))
+        return MaskedSamples(inds=inds, is_pos=is_pos, valid=val, bboxes=bboxes[inds], pos_gt_bboxes=pos_gt,
+                             pos_gt_labels=labels[inds] if labels is not None else None, n_pos=n_pos,
+                             n_neg=(val & ~is_pos).sum(), num_gts=gt_bboxes.shape[0])
+
+    @staticmethod
     def _sorted(inds):
         """``inds.unique()`` of the reference (sampler.py:95,100) for index lists that hold no duplicates (a subset of
         nonzero's output): the ascending order, without unique's size synchronisation."""
         return torch.sort(inds)[0] if inds.numel() > 1 else inds
+
+
+class MaskedSamples:
+    """What ``BaseSampler.sample_masked`` returns: exactly ``num`` rows whatever the data -- the sampled boxes in the
+    reference's order (positives by ascending index, then negatives by ascending index), unused slots last -- with
+    masks instead of index lists of data-dependent length.  Everything is a device tensor; nothing was synchronised.
+      inds (num,) int64 rows of the (gt-extended) box list; is_pos / valid (num,) bool; bboxes (num, d);
+      pos_gt_bboxes (num, d) and pos_gt_labels (num,) -- defined where is_pos; n_pos / n_neg 0-d int64."""
+    __slots__ = ("inds", "is_pos", "valid", "bboxes", "pos_gt_bboxes", "pos_gt_labels", "n_pos", "n_neg", "num_gts")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
 
 
 @BOXES.register_module()

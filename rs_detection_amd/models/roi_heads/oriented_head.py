@@ -154,7 +154,9 @@ class OrientedHead(nn.Module):
         return torch.cat([obb2poly(bboxes), scores.unsqueeze(1)], dim=1), labels
 
     def forward_single(self, x, sampling_results, test=False):
-        if test:
+        if test is None:                        # ready-made (R, 1 + dim) RoIs
+            rois = sampling_results
+        elif test:
             rois = self.arb2roi(sampling_results, bbox_type=self.start_bbox_type)
         else:
             rois = self.arb2roi([r.bboxes for r in sampling_results], bbox_type=self.start_bbox_type)
@@ -183,7 +185,9 @@ class OrientedHead(nn.Module):
         return (self.fc_cls(x_cls) if self.with_cls else None), (self.fc_reg(x_reg) if self.with_reg else None), rois
 
     def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_targets_decode, bbox_weights,
-             reduction_override=None):
+             reduction_override=None, num_samples=None):
+        """``num_samples``: the number of sampled RoIs when ``rois`` is a fixed-size list with unused slots (0-d tensor);
+        None = every row is a sample (the reference's `bbox_targets.size(0)`, oriented_head.py:421)."""
         losses = dict()
         if cls_score is not None and cls_score.numel() > 0:
             avg = (label_weights > 0).sum().float().clamp(min=1.)
@@ -200,7 +204,8 @@ class OrientedHead(nn.Module):
                 idx = labels.clamp(min=0, max=self.num_classes - 1).long()
                 pred = bbox_pred.view(bbox_pred.size(0), -1, self.reg_dim)[torch.arange(bbox_pred.size(0)), idx]
             w = bbox_weights * pos[:, None].to(bbox_weights.dtype)
-            losses['orcnn_bbox_loss'] = self.loss_bbox(pred, bbox_targets, w, avg_factor=bbox_targets.size(0),
+            losses['orcnn_bbox_loss'] = self.loss_bbox(pred, bbox_targets, w,
+                                                       avg_factor=bbox_targets.size(0) if num_samples is None else num_samples,
                                                        reduction_override=reduction_override)
         return losses
 
@@ -253,8 +258,40 @@ class OrientedHead(nn.Module):
             bboxes = bboxes.view(bboxes.size(0), -1)
         return self.get_results(bboxes, scores, bbox_type=self.end_bbox_type)
 
+    def _forward_train_masked(self, x, proposal_list, targets):
+        """The training branch on FIXED-SIZE data, no host synchronisation: ``proposal_list[i]`` = (dets (P, 6), real
+        (P,) bool) from OrientedRPNHead (its unused rows are neither positive nor negative), ``sampler.sample_masked``
+        gives exactly ``num`` RoIs per image in the reference's order with masks for what the reference expresses by
+        list lengths; targets and losses are the reference's sums over the same samples (:566-588, :426-496, :354-424).
+        An unused slot still travels through RoIAlign and the FCs (as a copy of some real box) with all its weights 0."""
+        dev = x[0].device
+        rois, labels, lweights, btargets, bweights, counts = [], [], [], [], [], []
+        for i, t in enumerate(targets):
+            obb = torch.as_tensor(t["rboxes"]).to(dev).float().clone()
+            obb[:, -1] *= -1
+            lab = torch.as_tensor(t["labels"]).to(dev) - 1
+            props, real = proposal_list[i]
+            ar = self.assigner.assign(props, obb, None, lab)
+            ms = self.sampler.sample_masked(ar, props, obb, lab, valid=real)
+            rois.append(torch.cat([ms.bboxes.new_full((ms.bboxes.size(0), 1), i), ms.bboxes], dim=-1))
+            labels.append(torch.where(ms.is_pos, ms.pos_gt_labels.long(), torch.full_like(ms.inds, self.num_classes)))
+            w = ms.valid.to(ms.bboxes.dtype)
+            if self.pos_weight > 0:
+                w = torch.where(ms.is_pos, torch.full_like(w, float(self.pos_weight)), w)
+            lweights.append(w)
+            bt = ms.pos_gt_bboxes if self.reg_decoded_bbox else self.bbox_coder.encode(ms.bboxes, ms.pos_gt_bboxes)
+            btargets.append(torch.where(ms.is_pos[:, None], bt, torch.zeros_like(bt)))
+            bweights.append(ms.is_pos[:, None].to(bt.dtype).expand(-1, self.reg_dim))
+            counts.append(ms.n_pos + ms.n_neg)
+        rois = torch.cat(rois, 0)
+        scores, deltas, rois = self.forward_single(x, rois, test=None)
+        return self.loss(scores, deltas, rois, torch.cat(labels), torch.cat(lweights), torch.cat(btargets), None,
+                         torch.cat(bweights), num_samples=torch.stack(counts).sum())
+
     def forward(self, x, proposal_list, targets):
         dev = x[0].device
+        if self.training and len(proposal_list) and isinstance(proposal_list[0], tuple):
+            return self._forward_train_masked(x, proposal_list, targets)
         if self.training:
             gt_obb, gt_labels = [], []
             for t in targets:

@@ -46,6 +46,7 @@ class OrientedRPNHead(nn.Module):
         self.sampler = build_from_cfg(sampler, BOXES)
         self.anchor_generator = build_from_cfg(anchor_generator, BOXES)
         self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self.masked = True      # train step on fixed-size samples / proposals (no host synchronisation)
         self._init_layers()
 
     def _init_layers(self):
@@ -91,7 +92,10 @@ class OrientedRPNHead(nn.Module):
         x = F.relu(self.rpn_conv(x))
         return self.rpn_cls(x), self.rpn_reg(x)
 
-    def _get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape):
+    def _get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape, fixed=False):
+        """``fixed=True`` (the train step): the same proposals as a FIXED-SIZE list -- (nms_post, 6) rows in the same
+        order, zero rows behind the last proposal, plus the (nms_post,) bool mask of the real ones -- built without the
+        two host synchronisations of the reference's form (the `valid.all()` test and the boolean `dets[keep]`)."""
         level_ids, mlvl_scores, mlvl_valid_anchors, mlvl_bbox_pred = [], [], [], []
         for idx in range(len(cls_scores)):
             cls, reg = cls_scores[idx], bbox_preds[idx]
@@ -111,6 +115,8 @@ class OrientedRPNHead(nn.Module):
         anchors, reg, scores = torch.cat(mlvl_valid_anchors), torch.cat(mlvl_bbox_pred), torch.cat(mlvl_scores)
         proposals = self.bbox_coder.decode(anchors, reg.float(), max_shape=img_shape)
         ids = torch.cat(level_ids)
+        if fixed:
+            return self._nms_fixed(proposals, scores, ids)
         if self.min_bbox_size >= 0:
             valid = (proposals[:, 2] > self.min_bbox_size) & (proposals[:, 3] > self.min_bbox_size)
             if not bool(valid.all()):
@@ -122,7 +128,41 @@ class OrientedRPNHead(nn.Module):
         dets = torch.cat([proposals, scores.unsqueeze(1)], dim=1)[keep, :]
         return dets[:self.nms_post]
 
-    def get_bboxes(self, cls_scores, bbox_preds, targets):
+    def _nms_fixed(self, proposals, scores, ids):
+        """The tail of _get_bboxes_single on masks: too-small boxes are sorted behind every real one (score -1) and
+        never kept, the NMS keep flags (score order) are turned into output slots by a prefix count, and the kept rows
+        are scattered into a (nms_post + 1)-row buffer whose last row collects everything that is not an output."""
+        from rs_detection_amd import _lib
+        n, dev = proposals.shape[0], proposals.device
+        ok = torch.ones((n,), dtype=torch.bool, device=dev)
+        if self.min_bbox_size >= 0:
+            ok = (proposals[:, 2] > self.min_bbox_size) & (proposals[:, 3] > self.min_bbox_size)
+        hprop = obb2hbb(proposals)
+        inf = torch.full_like(hprop, float("inf"))                                 # the extent of the REAL boxes
+        max_coordinate = torch.where(ok[:, None], hprop, -inf).max() - torch.where(ok[:, None], hprop, inf).min()
+        hprop = hprop + (ids.to(hprop.dtype) * (max_coordinate + 1))[:, None]
+        key = torch.where(ok, scores, torch.full_like(scores, -1.0))
+        order = torch.argsort(key, descending=True, stable=True)
+        boxes = hprop[order].float().contiguous()
+        keep = torch.empty((n,), dtype=torch.uint8, device=dev)
+        lib = _lib.load()
+        ws_bytes = lib.rsdet_nms_hbb_ws_size(n)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        rc = lib.rsdet_nms_hbb_sorted_f32(_lib.ptr(boxes), n, float(self.nms_thresh), 1, _lib.ptr(keep), _lib.ptr(ws),
+                                          ws_bytes, _lib.stream_ptr())
+        _lib.check(rc, "rsdet_nms_hbb_sorted_f32")
+        kept = keep.bool() & ok[order]
+        slot = torch.cumsum(kept, 0) - 1
+        P = int(self.nms_post)
+        slot = torch.where(kept & (slot < P), slot, torch.full_like(slot, P))
+        dets = torch.cat([proposals, scores.unsqueeze(1)], dim=1)[order]
+        out = dets.new_zeros((P + 1, dets.shape[1]))
+        out.index_copy_(0, slot, dets)          # (row P receives the discards, in no particular order)
+        flags = torch.zeros((P + 1,), dtype=torch.bool, device=dev)
+        flags.index_fill_(0, slot, True)
+        return out[:P], flags[:P]
+
+    def get_bboxes(self, cls_scores, bbox_preds, targets, fixed=False):
         assert len(cls_scores) == len(bbox_preds)
         num_levels = len(cls_scores)
         featmap_sizes = [tuple(cls_scores[i].shape[-2:]) for i in range(num_levels)]
@@ -131,7 +171,7 @@ class OrientedRPNHead(nn.Module):
         for img_id, target in enumerate(targets):
             cls_list = [cls_scores[i][img_id].detach() for i in range(num_levels)]
             reg_list = [bbox_preds[i][img_id].detach() for i in range(num_levels)]
-            out.append(self._get_bboxes_single(cls_list, reg_list, mlvl_anchors, target['img_size']))
+            out.append(self._get_bboxes_single(cls_list, reg_list, mlvl_anchors, target['img_size'], fixed=fixed))
         return out
 
     def _get_targets_single(self, anchors_list, valid_flag_list, target):
@@ -183,6 +223,62 @@ class OrientedRPNHead(nn.Module):
             bbox_weights = self.unmap(bbox_weights, total, inside)
         return labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds, sampling_result
 
+    def _get_targets_single_masked(self, anchors_list, valid_flag_list, target):
+        """_get_targets_single on fixed-size samples (sampler.sample_masked): the same target maps, no host
+        synchronisation.  Index lists become (index, mask) pairs; a masked-out slot writes into one spare row behind the
+        maps.  Returns (labels, label_weights, bbox_targets, bbox_weights, n_pos, n_neg) with 0-d device counts."""
+        dev = anchors_list[0].device
+        gt_bboxes = torch.as_tensor(target["rboxes"]).to(dev).float().clone()
+        gt_bboxes[:, -1] *= -1
+        ign = target.get("rboxes_ignore")
+        gt_ignore = None
+        if ign is not None and torch.as_tensor(ign).numel() > 0:
+            gt_ignore = torch.as_tensor(ign).to(dev).float().clone()
+            gt_ignore[:, -1] *= -1
+        geom = self._inside_geometry(anchors_list, valid_flag_list, target["img_size"])
+        if not geom["any"]:
+            return (None,) * 6
+        flat_anchors, inside, anchors = geom["flat"], geom["idx"], geom["anchors"]
+        a_type, g_type = get_bbox_type(anchors), get_bbox_type(gt_bboxes)
+        tgt = bbox2type(gt_bboxes, a_type)
+        tgt_ign = None if gt_ignore is None else bbox2type(gt_ignore, a_type)
+        assign_result = self.assigner.assign(anchors, tgt, tgt_ign, None)
+        ms = self.sampler.sample_masked(assign_result, anchors, tgt)
+        pos_gt = ms.pos_gt_bboxes
+        if a_type != g_type:
+            gi = (assign_result.gt_inds[ms.inds].long() - 1).clamp(min=0)
+            pos_gt = gt_bboxes[gi, :] if gt_bboxes.numel() else gt_bboxes.new_zeros((ms.inds.numel(), get_bbox_dim(g_type)))
+        n = anchors.shape[0]
+        at_pos = torch.where(ms.is_pos, ms.inds, torch.full_like(ms.inds, n))       # spare row n: masked-out slots
+        at_any = torch.where(ms.valid, ms.inds, torch.full_like(ms.inds, n))
+        pos_t = pos_gt if self.reg_decoded_bbox else self.bbox_coder.encode(ms.bboxes, pos_gt)
+        pos_t = torch.where(ms.is_pos[:, None], pos_t, torch.zeros_like(pos_t))
+        bbox_targets = anchors.new_zeros((n + 1, self.reg_dim)).index_copy_(0, at_pos, pos_t)[:n]
+        bbox_weights = anchors.new_zeros((n + 1, self.reg_dim)).index_fill_(0, at_pos, 1.0)[:n]
+        labels = anchors.new_full((n + 1,), self.background_label, dtype=torch.long).index_fill_(0, at_pos, 1)[:n]
+        label_weights = anchors.new_zeros((n + 1,)).index_fill_(0, at_any, 1.0)
+        if self.pos_weight > 0:
+            label_weights.index_fill_(0, at_pos, float(self.pos_weight))
+        label_weights = label_weights[:n]
+        if self.unmap_outputs:
+            total = flat_anchors.size(0)
+            labels = self.unmap(labels, total, inside, fill=self.background_label)
+            label_weights = self.unmap(label_weights, total, inside)
+            bbox_targets = self.unmap(bbox_targets, total, inside)
+            bbox_weights = self.unmap(bbox_weights, total, inside)
+        return labels, label_weights, bbox_targets, bbox_weights, ms.n_pos, ms.n_neg
+
+    def get_targets_masked(self, anchor_list, valid_flag_list, targets):
+        """get_targets with device-side counts: num_total_pos / num_total_neg are 0-d tensors (sum_img max(count, 1))."""
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        (all_labels, all_lw, all_bt, all_bw, npos, nneg) = multi_apply(self._get_targets_single_masked, anchor_list,
+                                                                         valid_flag_list, targets)
+        num_total_pos = torch.stack([c.clamp(min=1) for c in npos]).sum()
+        num_total_neg = torch.stack([c.clamp(min=1) for c in nneg]).sum()
+        return (images_to_levels(all_labels, num_level_anchors), images_to_levels(all_lw, num_level_anchors),
+                images_to_levels(all_bt, num_level_anchors), images_to_levels(all_bw, num_level_anchors),
+                num_total_pos, num_total_neg)
+
     def get_targets(self, anchor_list, valid_flag_list, targets):
         num_level_anchors = [a.size(0) for a in anchor_list[0]]
         (all_labels, all_lw, all_bt, all_bw, pos_l, neg_l, _) = multi_apply(self._get_targets_single, anchor_list,
@@ -223,7 +319,10 @@ class OrientedRPNHead(nn.Module):
         mla = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
         anchor_list = [mla for _ in range(len(targets))]
         valid_flag_list = [self._valid_flags(featmap_sizes, t['pad_shape'], dev) for t in targets]
-        (labels_list, lw_list, bt_list, bw_list, npos, nneg) = self.get_targets(anchor_list, valid_flag_list, targets)
+        # the train step's form: fixed-size samples, counts on the device (no host synchronisation); `masked = False`
+        # keeps the reference-shaped index lists (what the known-answer tests of the head read)
+        get = self.get_targets_masked if self.masked else self.get_targets
+        (labels_list, lw_list, bt_list, bw_list, npos, nneg) = get(anchor_list, valid_flag_list, targets)
         num_level_anchors = [a.size(0) for a in anchor_list[0]]
         all_anchor_list = images_to_levels([torch.cat(a) for a in anchor_list], num_level_anchors)
         losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list,
@@ -231,6 +330,8 @@ class OrientedRPNHead(nn.Module):
         return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
 
     def forward(self, features, targets):
+        """Training: (fixed-size proposals, their masks) + losses -- see _get_bboxes_single(fixed=True); evaluation:
+        the reference's variable-length proposal lists."""
         outs = multi_apply(self.forward_single, features)
         losses = self.loss(*outs, targets) if self.training else dict()
-        return self.get_bboxes(*outs, targets), losses
+        return self.get_bboxes(*outs, targets, fixed=self.training and self.masked), losses

@@ -225,63 +225,70 @@ def box_iou_rotated_fast(boxes1, boxes2, row_offsets=None, ks=None, max_rows=Non
 
 
 class GridSpec:
-    """A column set that is one box per cell of a pyramid of regular grids (include/rsdet.h: RsdetGridLevel): per level
-    (H, W, stride, x0, y0, max_rad[, max_shift]); columns level by level, x fastest.  ``exact=True``: the boxes ARE the
-    generated anchors (max_shift 0, max_rad from the anchor size); ``exact=False``: a refinement of them -- the bounds
-    are measured on the device per call (rsdet_iou_grid_bounds_f32, no sync)."""
-    __slots__ = ("levels", "n", "exact", "_arr")
+    """The GENERATED anchors of a pyramid of regular grids (include/rsdet.h: RsdetGridLevel): per level
+    (H, W, stride, x0, y0, box_w, box_h); level l holds the boxes (x0 + j stride, y0 + i stride, box_w, box_h, 0), x
+    fastest, levels one after the other."""
+    __slots__ = ("levels", "n", "_arr", "_checked")
 
-    def __init__(self, levels, exact=True):
-        self.levels, self.exact = [tuple(l) for l in levels], bool(exact)
+    def __init__(self, levels):
+        self.levels = [tuple(l) for l in levels]
         arr = (_lib.GridLevel * len(self.levels))()
         at = 0
-        for k, (H, W, stride, x0, y0, max_rad) in enumerate(self.levels):
-            arr[k] = _lib.GridLevel(at, int(H), int(W), float(x0), float(y0), float(stride), 0.0, float(max_rad))
+        for k, (H, W, stride, x0, y0, bw, bh) in enumerate(self.levels):
+            arr[k] = _lib.GridLevel(at, int(H), int(W), float(x0), float(y0), float(stride), float(bw), float(bh))
             at += int(H) * int(W)
-        self._arr, self.n = arr, at
+        self._arr, self.n, self._checked = arr, at, {}
+
+    def boxes(self, device):
+        """The column set the spec stands for, as an (n, 5) float32 tensor."""
+        out = []
+        for (H, W, stride, x0, y0, bw, bh) in self.levels:
+            xs = torch.arange(W, dtype=torch.float32, device=device) * stride + x0
+            ys = torch.arange(H, dtype=torch.float32, device=device) * stride + y0
+            b = torch.zeros((H, W, 5), dtype=torch.float32, device=device)
+            b[..., 0], b[..., 1], b[..., 2], b[..., 3] = xs[None, :], ys[:, None], bw, bh
+            out.append(b.reshape(-1, 5))
+        return torch.cat(out)
+
+    def matches(self, boxes2):
+        """Is ``boxes2`` exactly this grid?  One device comparison (and synchronisation) per tensor: remembered for its
+        (storage, version), like the prepared-box cache -- the FAM anchors are the same tensor every step."""
+        key = (boxes2.data_ptr(), tuple(boxes2.shape), boxes2._version, boxes2.device.index)
+        hit = self._checked.get(key)
+        if hit is None:
+            if len(self._checked) > 16:
+                self._checked.clear()
+            hit = tuple(boxes2.shape) == (self.n, 5) and bool((boxes2 == self.boxes(boxes2.device)).all())
+            self._checked[key] = hit
+        return hit
 
 
-def s2anet_grid_spec(featmap_sizes, strides, scale=4.0, exact=True):
+def s2anet_grid_spec(featmap_sizes, strides, scale=4.0):
     """The grid of AnchorGeneratorRotatedS2ANet (anchor_generator.py:22-78): level l has one (scale * s) square anchor per
-    cell, centre (0.5 (s - 1) + j s, 0.5 (s - 1) + i s).  max_rad = the prepared radius of that square, rounded up."""
-    lv = []
-    for (H, W), s in zip(featmap_sizes, strides):
-        side = float(scale) * float(s)
-        lv.append((int(H), int(W), float(s), 0.5 * (s - 1), 0.5 * (s - 1), (side * 1.0001 + 1e-3) * 1.0005))
-    return GridSpec(lv, exact=exact)
+    cell, centre (0.5 (s - 1) + j s, 0.5 (s - 1) + i s), angle 0."""
+    return GridSpec([(int(H), int(W), float(s), 0.5 * (s - 1), 0.5 * (s - 1), float(scale) * s, float(scale) * s)
+                     for (H, W), s in zip(featmap_sizes, strides)])
 
 
-def box_iou_rotated_grid(boxes1, boxes2, grid, row_offsets=None, version=0, out=None, prepared=None,
-                         cache_prepared=False, prepared1=None):
-    """``box_iou_rotated_fast`` -- the same values, bit for bit -- for columns that are a pyramid grid (``grid``: a
-    GridSpec): the cells a gt can touch are a closed-form window per level, nothing is tested pair by pair, and one
-    workgroup composes one row x 4 096 columns in LDS and stores every element once (csrc/iou_grid.hip).
-    ``boxes2`` (A,5) shared or (G,A,5) per group with ``row_offsets`` (G+1) int32 on the device."""
+def box_iou_rotated_grid(boxes1, boxes2, grid, version=0, out=None, prepared1=None):
+    """``box_iou_rotated_fast`` -- the same values, bit for bit -- when ``boxes2`` (A, 5) are the generated anchors of a
+    pyramid grid (``grid``: a GridSpec; checked against ``boxes2`` once per tensor): a cell's box and the window of cells
+    a gt can touch are closed forms, so the columns are never read and nothing is tested pair by pair; one workgroup
+    composes one row x 4 096 columns in LDS and stores every element once (csrc/iou_grid.hip)."""
     _lib.require_cuda_f32(boxes1, boxes2)
     lib = _lib.load()
-    b1, b2 = boxes1.contiguous(), boxes2.contiguous()
-    n1, A = b1.shape[0], b2.shape[-2]
-    per_group = 1 if b2.dim() == 3 else 0
-    G = (row_offsets.numel() - 1) if row_offsets is not None else 1
-    if grid.n != A:
-        raise _lib.RsdetError("grid spec covers %d columns, boxes2 has %d" % (grid.n, A))
+    b1 = boxes1.contiguous()
+    n1, A = b1.shape[0], boxes2.shape[-2]
+    if grid.n != A or boxes2.dim() != 2 or not grid.matches(boxes2):
+        raise _lib.RsdetError("boxes2 is not the grid the spec describes (%d columns against %d)" % (A, grid.n))
     ious = out if out is not None else torch.empty((n1, A), dtype=torch.float32, device=b1.device)
     if n1 == 0 or A == 0:
         return ious
-    prep = prepared if prepared is not None else prepare_boxes(b2, cache=cache_prepared)
-    assert prep.n_per_group == A and prep.groups == (G if per_group else 1)
-    bounds = None
-    if not grid.exact:
-        bounds = torch.empty((prep.groups, len(grid.levels), 2), dtype=torch.float32, device=b1.device)
-        rc = lib.rsdet_iou_grid_bounds_f32(_lib.ptr(prep.buf), A, prep.groups, grid._arr, len(grid.levels),
-                                           _lib.ptr(bounds), _lib.stream_ptr())
-        _lib.check(rc, "rsdet_iou_grid_bounds_f32")
     if prepared1 is not None:
         assert prepared1.n_total == n1 and prepared1.groups == 1
-    rc = lib.rsdet_box_iou_rotated_grid_f32(_lib.ptr(b1), n1, b1.shape[-1], _lib.ptr(row_offsets), G,
-                                            _lib.ptr(prepared1.buf) if prepared1 is not None else None,
-                                            _lib.ptr(prep.buf), A, per_group, grid._arr, len(grid.levels),
-                                            _lib.ptr(bounds), version, _lib.ptr(ious), _lib.stream_ptr())
+    rc = lib.rsdet_box_iou_rotated_grid_f32(_lib.ptr(b1), n1, b1.shape[-1],
+                                            _lib.ptr(prepared1.buf) if prepared1 is not None else None, A, grid._arr,
+                                            len(grid.levels), version, _lib.ptr(ious), _lib.stream_ptr())
     _lib.check(rc, "rsdet_box_iou_rotated_grid_f32")
     return ious
 

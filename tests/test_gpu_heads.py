@@ -122,19 +122,30 @@ def test_oriented_rpn_get_bboxes_single_known_answer(cuda):
 
 
 # ---- Oriented R-CNN heads: known answers with a FIXED sampling choice --------------------------------
+_PRIORITY = np.random.default_rng(7919).random(1 << 20)        # one fixed draw per candidate INDEX (float64: no ties)
+
+
 def _fixed_choice_np(gallery, num):
-    """stands in for gallery[randperm(len)[:num]] on both sides (jt.randperm is not reproducible across frameworks)"""
-    return gallery[np.random.default_rng(len(gallery) * 7919 + num).permutation(len(gallery))[:num]]
+    """stands in for gallery[randperm(len)[:num]] on both sides (jt.randperm is not reproducible across frameworks): the
+    `num` candidates with the largest fixed draws -- a choice BOTH forms of the sampler can be handed: the reference-shaped
+    one through ``random_choice(gallery, num)``, the fixed-size one (the train step's) through ``priorities(n)``."""
+    return gallery[np.argsort(-_PRIORITY[gallery], kind="stable")[:num]]
 
 
 @pytest.fixture
 def fixed_choice(monkeypatch):
     from rs_detection_amd.models.boxes.sampler import RandomSampler
+    table = {}
+
+    def pri(dev):
+        if dev not in table:
+            table[dev] = torch.from_numpy(_PRIORITY).to(dev)
+        return table[dev]
 
     def choice(gallery, num):
-        idx = np.random.default_rng(gallery.numel() * 7919 + num).permutation(gallery.numel())[:num]
-        return gallery[torch.from_numpy(idx).to(gallery.device)]
+        return gallery[torch.topk(pri(gallery.device)[gallery], num)[1]]
     monkeypatch.setattr(RandomSampler, "random_choice", staticmethod(choice))
+    monkeypatch.setattr(RandomSampler, "priorities", staticmethod(lambda n, dev: pri(dev)[:n]))
     return _fixed_choice_np
 
 
@@ -163,7 +174,14 @@ def test_oriented_rpn_loss_known_answer(cuda, fixed_choice):
         targets.append(dict(rboxes=rb, rboxes_ignore=None, img_size=(size, size), pad_shape=(size, size)))
     t = lambda xs: [torch.from_numpy(x).to(cuda) for x in xs]
     tt = [dict(x, rboxes=torch.from_numpy(x["rboxes"]).to(cuda)) for x in targets]
+    assert rpn.masked                                   # the train step's form: fixed-size samples, counts on the device
     got = rpn.loss(t(cls), t(reg), tt)
+    rpn.masked = False                                  # ... and the reference-shaped index lists: the same losses
+    got_lists = rpn.loss(t(cls), t(reg), tt)
+    rpn.masked = True
+    for k in got:
+        for a, b in zip(got[k], got_lists[k]):
+            assert abs(float(a) - float(b)) <= 1e-5 * max(abs(float(b)), 1e-3), (k, float(a), float(b))
     want, per = H.np_oriented_rpn_loss(cls, reg, targets, cfg, fixed_choice)
     assert sum(len(p[4]) for p in per) > 20 and all(len(p[5]) > 100 for p in per)       # the sampler had to choose
     for k in ("loss_rpn_cls", "loss_rpn_bbox"):
@@ -181,6 +199,9 @@ def test_oriented_rpn_loss_known_answer(cuda, fixed_choice):
         assert (bw.cpu().numpy() == per[i][3]).all()
         np.testing.assert_allclose(bt.cpu().numpy(), per[i][2], rtol=1e-4, atol=1e-4)
         assert (pos.cpu().numpy() == per[i][4]).all() and (neg.cpu().numpy() == per[i][5]).all()
+        mlab, mlw, mbt, mbw, npos, nneg = rpn._get_targets_single_masked(mla, vf, tg)      # the fixed-size form
+        assert (mlab == lab).all() and (mlw == lw).all() and (mbw == bw).all() and torch.equal(mbt, bt)
+        assert int(npos) == len(per[i][4]) and int(nneg) == len(per[i][5])
 
 
 def test_oriented_head_known_answers(cuda, fixed_choice):
@@ -222,6 +243,15 @@ def test_oriented_head_known_answers(cuda, fixed_choice):
         np.testing.assert_array_equal(res.pos_gt_bboxes.cpu().numpy(), want["pos_gt_bboxes"])
         assert (res.pos_gt_labels.cpu().numpy() == want["pos_gt_labels"]).all()
         samples.append(want), results.append(res)
+        # the fixed-size form of the same draw (what the train step runs): the same rows in the same order + masks
+        ms = head.sampler.sample_masked(head.assigner.assign(pr, obb, None, lab0), pr, obb, lab0)
+        npos, nneg = len(want["pos_inds"]), len(want["neg_inds"])
+        assert int(ms.n_pos) == npos and int(ms.n_neg) == nneg and ms.inds.numel() == 512
+        assert (ms.inds[:npos].cpu().numpy() == want["pos_inds"]).all()
+        assert (ms.inds[npos:npos + nneg].cpu().numpy() == want["neg_inds"]).all()
+        assert bool(ms.is_pos[:npos].all()) and not bool(ms.is_pos[npos:].any()) and bool(ms.valid[:npos + nneg].all())
+        np.testing.assert_array_equal(ms.bboxes[:npos].cpu().numpy(), want["pos_bboxes"])
+        np.testing.assert_array_equal(ms.pos_gt_bboxes[:npos].cpu().numpy(), want["pos_gt_bboxes"])
     assert len(samples[1]["pos_inds"]) == 128                          # the positive cap was hit: the choice mattered
     labels, lw, bt, _, bw = head.get_bboxes_targets(results)
     wl, wlw, wbt, wbw = H.np_oriented_head_targets(samples, cfg, 10)

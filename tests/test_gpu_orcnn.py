@@ -118,6 +118,66 @@ def test_oriented_rcnn_train_step_and_eval(cuda):
     assert polys.shape[1] == 8 and polys.shape[0] == scores.shape[0] == labels.shape[0]
 
 
+def test_train_step_on_fixed_size_samples_equals_the_index_list_form_and_never_synchronises(cuda, monkeypatch):
+    """The train step of Oriented R-CNN runs on FIXED-SIZE proposal lists and samples (OrientedRPNHead.masked:
+    sampler.sample_masked, _nms_fixed, OrientedHead._forward_train_masked) so that nothing brings a count to the host.
+    Given the same draws it is the reference-shaped step (index lists of data-dependent length, oriented_rpn_head.py:
+    274-366, oriented_head.py:566-588) loss for loss; and under torch's sync debug mode it raises nowhere."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.models.boxes.sampler import RandomSampler
+    from rs_detection_amd.utils.registry import MODELS, build_from_cfg
+    from rs_detection_amd.utils import synthetic as syn
+    cfg = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")).dump()["model"]
+    cfg["backbone"] = dict(type="van_b0", img_size=256, num_stages=4, out_indices=(0, 1, 2, 3))
+    cfg["neck"]["in_channels"] = [32, 64, 160, 256]
+    torch.manual_seed(0)
+    model = build_from_cfg(cfg, MODELS).to(cuda).train()
+    images = torch.randn(2, 3, 256, 256, device=cuda)
+    targets = []
+    for t in syn.synthetic_targets(2, img=256, num_classes=10):
+        t = dict(t)
+        t["rboxes"] = torch.from_numpy(t["rboxes"][:14]).to(cuda)
+        t["labels"] = torch.from_numpy(t["labels"][:14]).to(cuda)
+        t["hboxes"] = None
+        targets.append(t)
+    pri = torch.from_numpy(np.random.default_rng(5).random(1 << 20)).to(cuda)          # float64: no ties
+    monkeypatch.setattr(RandomSampler, "priorities", staticmethod(lambda n, dev: pri[:n]))
+    monkeypatch.setattr(RandomSampler, "random_choice",
+                        staticmethod(lambda gallery, num: gallery[torch.topk(pri[gallery], num)[1]]))
+    for m in model.modules():                    # same batch statistics in both passes
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.momentum = 0.0
+    assert model.rpn.masked
+    fixed = model(images, targets)
+    model.rpn.masked = False
+    lists = model(images, targets)
+    model.rpn.masked = True
+    for k in lists:
+        a = torch.stack(list(fixed[k])) if isinstance(fixed[k], (list, tuple)) else fixed[k]
+        b = torch.stack(list(lists[k])) if isinstance(lists[k], (list, tuple)) else lists[k]
+        assert torch.allclose(a.float().reshape(-1), b.float().reshape(-1), rtol=2e-4, atol=1e-6), (k, a, b)
+    # proposals: the fixed-size list holds the variable-length list's rows, in order, then zero rows
+    feats = model.neck(model.backbone(images))
+    with torch.no_grad():
+        outs = [list(o) for o in zip(*[model.rpn.forward_single(f) for f in feats])]
+        fx = model.rpn.get_bboxes(*outs, targets, fixed=True)
+        vl = model.rpn.get_bboxes(*outs, targets, fixed=False)
+    for (d, real), v in zip(fx, vl):
+        n = v.shape[0]
+        assert d.shape[0] == model.rpn.nms_post and int(real.sum()) == n and bool(real[:n].all())
+        assert torch.equal(d[:n], v) and not bool(d[n:].any())
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        from rs_detection_amd.utils.general import parse_losses
+        total, _ = parse_losses(model(images, targets))
+        total.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert bool(torch.isfinite(total))
+
+
 def test_batched_inference_equals_per_image_inference(cuda):
     """Every image pools its RoI features from ITS OWN pyramid slice (the reference hands the whole batch to a
     per-image call whose RoIs all carry batch index 0, oriented_head.py:610-613: images i>0 then read image 0)."""
