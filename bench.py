@@ -113,7 +113,6 @@ ROOFLINE_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_roofline
 COUNTER_SOURCE = "committed profile: profiles/%s (rocprofv3 --pmc passes of profiles/scripts/roofline.sh)" % \
     os.path.basename(ROOFLINE_FILE)
 FAST_ROW = "box_iou_rotated_fast(two-tier clipper, 1 launch; prepared anchors cached, gts prepared in the tile)"
-GRID_ROW = "box_iou_rotated_grid(two-tier clipper, 1 launch; cell windows in closed form, one row x 4096 columns per workgroup)"
 AT_ROW = "anchor_target_rotated(fused: IoU + assign + encode + weights; 2 launches)"
 BN_ROW = "bn_act_forward_kernel<f32>(bn + residual + relu; 4x256x256x256, NCHW)"
 BN_ROW_CL = "bn_act_forward_nhwc_kernel<f32>(bn + residual + relu; 4x256x256x256, layer1 of the channels_last step)"
@@ -186,16 +185,6 @@ def kernel_rooflines(device, targets):
         bound="hbm", achieved=by / t3 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t3 / 1e9 / HBM_PEAK_GBS,
         traffic=pmc_traffic("box_iou_rotated_fast (1 launch)", (n1, A) == (556, 21824)), us=t3 * 1e6,
         mpairs_per_s=n1 * A / t3 / 1e6)
-    # -- the same values (bit for bit) for a column set that IS a pyramid grid (the FAM anchors): candidate cells in closed
-    #    form, no pair-wise detection, every element stored once (csrc/iou_grid.hip)
-    from rs_detection_amd.ops.anchor_target import s2anet_grid_spec
-    spec = s2anet_grid_spec([(TILE // s_, TILE // s_) for s_ in (8, 16, 32, 64, 128)], (8, 16, 32, 64, 128))
-    if spec.n == A:
-        t4 = event_time(lambda: ops.box_iou_rotated_grid(gt, anchors, spec, out=ov), 50)
-        out[GRID_ROW] = dict(
-            bound="hbm", achieved=by / t4 / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t4 / 1e9 / HBM_PEAK_GBS,
-            traffic=pmc_traffic("box_iou_rotated_grid (1 launch)", (n1, A) == (556, 21824)), us=t4 * 1e6,
-            mpairs_per_s=n1 * A / t4 / 1e6)
     # -- what the train step runs since round 2: fused sparse anchor targets (IoU of the overlapping pairs only ->
     #    assignment -> encode -> weights / counts, no matrix): bytes = boxes in + 56 B of targets per anchor out
     t2 = event_time(lambda: ops.anchor_target_rotated(anchors, gt, lab, ro, ks, 0.5, 0.4, 0.0, prepared=prep,
@@ -854,12 +843,6 @@ def main():
             "us_per_launch": kernels[FAST_ROW]["us"], "mpairs_per_s": kernels[FAST_ROW]["mpairs_per_s"],
             "issue": issue.get("dense_iou_two_tier")})
         if FAST_ROW in kernels else None,
-        # the same matrix, bit for bit, through the entry point for GRID-structured columns (what these anchors are)
-        "roofline_dense_iou_grid": ({k: kernels[GRID_ROW][k] for k in keys} | {
-            "kernel": "rsdet_box_iou_rotated_grid_f32 (1 launch; == rsdet_box_iou_rotated_fast_f32 bit for bit)",
-            "us_per_launch": kernels[GRID_ROW]["us"], "mpairs_per_s": kernels[GRID_ROW]["mpairs_per_s"],
-            "issue": issue.get("dense_iou_grid")})
-        if GRID_ROW in kernels else None,
         "roofline_nms": ({k: kernels[NMS_ROW][k] for k in keys} | {
             "kernel": "rsdet_nms_rotated (prepare + mask + sweep), M=5344, 15 classes, label-major",
             "us_per_launch": kernels[NMS_ROW]["us"], "mpairs_per_s": kernels[NMS_ROW]["mpairs_per_s"],

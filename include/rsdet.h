@@ -122,25 +122,6 @@ int rsdet_box_iou_rotated_fast_f32(const float* boxes1, int n1, int stride1, con
                                    const void* prepared1, const void* prepared2, int n2, int per_group,
                                    int heavy_from_col, int version, float* ious, void* stream);
 
-/* The same dense IoU matrix (same values, bit for bit, as rsdet_box_iou_rotated_fast_f32) when the COLUMNS are the
- * GENERATED anchors of a pyramid of regular grids -- AnchorGeneratorRotatedS2ANet, models/boxes/anchor_generator.py:7-91:
- * level l holds H x W boxes (x0 + j * stride, y0 + i * stride, box_w, box_h, 0), x fastest, levels one after the other.
- * The columns are never read: a cell's prepared box is a closed form, and so is the window of cells a gt can touch, so
- * nothing is tested pair by pair; one workgroup composes one row x rsdet_box_iou_rotated_grid_chunk() columns in LDS
- * and stores every element once (csrc/iou_grid.hip).  The caller vouches that the column set it means IS that grid
- * (ops/anchor_target.py checks it once per anchor tensor).  Replaces ops/box_iou_rotated.py:502-509 for the FAM call
- * of the S2ANet head (roi_heads/s2anet_head.py:254-289: gts against get_init_anchors()).  boxes1 / prepared1 as
- * rsdet_box_iou_rotated_fast_f32 (one column set for all rows: no groups). */
-#define RSDET_GRID_MAX_LEVELS 8
-typedef struct RsdetGridLevel {
-  int col0, H, W;
-  float x0, y0, stride;
-  float box_w, box_h;
-} RsdetGridLevel;
-int rsdet_box_iou_rotated_grid_chunk(void);
-int rsdet_box_iou_rotated_grid_f32(const float* boxes1, int n1, int stride1, const void* prepared1, int n2,
-                                   const RsdetGridLevel* levels, int n_levels, int version, float* ious, void* stream);
-
 /* anchor_target for a whole batch WITHOUT the (K, A) matrix: rotated IoU of the surviving pairs only
  * (1.2 % at S2ANet shapes) -> MaxIoUAssigner (column max / first argmax, thresholds, low-quality
  * rule with gt_max_assign_all = True: the LAST gt whose IoU equals its row maximum; a gt that

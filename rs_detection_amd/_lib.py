@@ -23,12 +23,6 @@ class DcnGeom(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("C", "H", "W", "kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw", "B", "dg")]
 
 
-class GridLevel(ctypes.Structure):
-    """struct RsdetGridLevel (include/rsdet.h): one pyramid level of a grid-structured column set."""
-    _fields_ = [("col0", c_int), ("H", c_int), ("W", c_int), ("x0", c_float), ("y0", c_float), ("stride", c_float),
-                ("box_w", c_float), ("box_h", c_float)]
-
-
 # name -> (restype, argtypes); must list every symbol include/rsdet.h declares.
 SIGNATURES = {
     "rsdet_abi_version": (c_int, []),
@@ -44,9 +38,6 @@ SIGNATURES = {
     "rsdet_box_iou_rotated_fast_rows_per_tile": (c_int, []),
     "rsdet_box_iou_rotated_fast_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "rsdet_box_iou_rotated_grid_chunk": (c_int, []),
-    "rsdet_box_iou_rotated_grid_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
-                                               c_void_p]),
     "rsdet_box_iou_rotated_split_state_bytes": (c_size_t, []),
     "rsdet_box_iou_rotated_split_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "rsdet_box_iou_rotated_split_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,

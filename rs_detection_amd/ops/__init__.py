@@ -17,5 +17,5 @@ from .fr import feature_refine, FR, FeatureRefineModule  # noqa: F401,E402
 from .convex_sort import convex_sort  # noqa: F401,E402
 from .dwconv import DepthwiseConv2d, dwconv2d  # noqa: F401,E402
 from .anchor_target import (prepare_boxes, row_tile_table, box_iou_rotated_tiled, box_iou_rotated_fast,  # noqa: F401,E402
-                            anchor_target_rotated, box_iou_rotated_grid, s2anet_grid_spec, GridSpec)
+                            anchor_target_rotated)
 from .s2a_loss import s2a_level_losses  # noqa: F401,E402

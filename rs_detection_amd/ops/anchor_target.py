@@ -19,8 +19,7 @@ import torch
 
 from .. import _lib
 
-__all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "box_iou_rotated_fast", "anchor_target_rotated",
-           "GridSpec", "s2anet_grid_spec", "box_iou_rotated_grid"]
+__all__ = ["prepare_boxes", "row_tile_table", "box_iou_rotated_tiled", "box_iou_rotated_fast", "anchor_target_rotated"]
 
 _TI = 16  # rows per tile (csrc/anchor_target.hip T_TI)
 _prepared_cache = {}
@@ -221,75 +220,6 @@ def box_iou_rotated_fast(boxes1, boxes2, row_offsets=None, ks=None, max_rows=Non
                                             _lib.ptr(prep.buf), A, per_group, prep.heavy_from, version,
                                             _lib.ptr(ious), _lib.stream_ptr())
     _lib.check(rc, "rsdet_box_iou_rotated_fast_f32")
-    return ious
-
-
-class GridSpec:
-    """The GENERATED anchors of a pyramid of regular grids (include/rsdet.h: RsdetGridLevel): per level
-    (H, W, stride, x0, y0, box_w, box_h); level l holds the boxes (x0 + j stride, y0 + i stride, box_w, box_h, 0), x
-    fastest, levels one after the other."""
-    __slots__ = ("levels", "n", "_arr", "_checked")
-
-    def __init__(self, levels):
-        self.levels = [tuple(l) for l in levels]
-        arr = (_lib.GridLevel * len(self.levels))()
-        at = 0
-        for k, (H, W, stride, x0, y0, bw, bh) in enumerate(self.levels):
-            arr[k] = _lib.GridLevel(at, int(H), int(W), float(x0), float(y0), float(stride), float(bw), float(bh))
-            at += int(H) * int(W)
-        self._arr, self.n, self._checked = arr, at, {}
-
-    def boxes(self, device):
-        """The column set the spec stands for, as an (n, 5) float32 tensor."""
-        out = []
-        for (H, W, stride, x0, y0, bw, bh) in self.levels:
-            xs = torch.arange(W, dtype=torch.float32, device=device) * stride + x0
-            ys = torch.arange(H, dtype=torch.float32, device=device) * stride + y0
-            b = torch.zeros((H, W, 5), dtype=torch.float32, device=device)
-            b[..., 0], b[..., 1], b[..., 2], b[..., 3] = xs[None, :], ys[:, None], bw, bh
-            out.append(b.reshape(-1, 5))
-        return torch.cat(out)
-
-    def matches(self, boxes2):
-        """Is ``boxes2`` exactly this grid?  One device comparison (and synchronisation) per tensor: remembered for its
-        (storage, version), like the prepared-box cache -- the FAM anchors are the same tensor every step."""
-        key = (boxes2.data_ptr(), tuple(boxes2.shape), boxes2._version, boxes2.device.index)
-        hit = self._checked.get(key)
-        if hit is None:
-            if len(self._checked) > 16:
-                self._checked.clear()
-            hit = tuple(boxes2.shape) == (self.n, 5) and bool((boxes2 == self.boxes(boxes2.device)).all())
-            self._checked[key] = hit
-        return hit
-
-
-def s2anet_grid_spec(featmap_sizes, strides, scale=4.0):
-    """The grid of AnchorGeneratorRotatedS2ANet (anchor_generator.py:22-78): level l has one (scale * s) square anchor per
-    cell, centre (0.5 (s - 1) + j s, 0.5 (s - 1) + i s), angle 0."""
-    return GridSpec([(int(H), int(W), float(s), 0.5 * (s - 1), 0.5 * (s - 1), float(scale) * s, float(scale) * s)
-                     for (H, W), s in zip(featmap_sizes, strides)])
-
-
-def box_iou_rotated_grid(boxes1, boxes2, grid, version=0, out=None, prepared1=None):
-    """``box_iou_rotated_fast`` -- the same values, bit for bit -- when ``boxes2`` (A, 5) are the generated anchors of a
-    pyramid grid (``grid``: a GridSpec; checked against ``boxes2`` once per tensor): a cell's box and the window of cells
-    a gt can touch are closed forms, so the columns are never read and nothing is tested pair by pair; one workgroup
-    composes one row x 4 096 columns in LDS and stores every element once (csrc/iou_grid.hip)."""
-    _lib.require_cuda_f32(boxes1, boxes2)
-    lib = _lib.load()
-    b1 = boxes1.contiguous()
-    n1, A = b1.shape[0], boxes2.shape[-2]
-    if grid.n != A or boxes2.dim() != 2 or not grid.matches(boxes2):
-        raise _lib.RsdetError("boxes2 is not the grid the spec describes (%d columns against %d)" % (A, grid.n))
-    ious = out if out is not None else torch.empty((n1, A), dtype=torch.float32, device=b1.device)
-    if n1 == 0 or A == 0:
-        return ious
-    if prepared1 is not None:
-        assert prepared1.n_total == n1 and prepared1.groups == 1
-    rc = lib.rsdet_box_iou_rotated_grid_f32(_lib.ptr(b1), n1, b1.shape[-1],
-                                            _lib.ptr(prepared1.buf) if prepared1 is not None else None, A, grid._arr,
-                                            len(grid.levels), version, _lib.ptr(ious), _lib.stream_ptr())
-    _lib.check(rc, "rsdet_box_iou_rotated_grid_f32")
     return ious
 
 
