@@ -516,10 +516,12 @@ def extra_leg(model, amp, mf, steps, rank, device, rdist, bf16_params):
 
 
 def ddp_overhead_leg(cfg, device, b16, steps, warm, bf16_params, rdist, enq_plain_ms, ms_plain):
-    """The bf16 S2ANet leg again with DDP FORCED ON in a one-rank ``nccl`` (= RCCL) process group: the reducer's bucket
-    views, the bf16 compress hook and one all-reduce per bucket through RCCL run on this single GPU.  What it reports
-    is the host time DDP adds to the enqueue of a step (the bf16 step is host-paced: this, not xGMI, is the first
-    scaling risk of one Python process per GPU).  Any failure to bring RCCL up is reported in the object, not raised."""
+    """The bf16 S2ANet leg again with the data-parallel gradient reduction FORCED ON in a one-rank ``nccl`` (= RCCL)
+    process group: the buckets, their multi-tensor copies and one all-reduce per bucket through RCCL run on this single
+    GPU.  Reported: the host time it adds to the enqueue of a step (the bf16 step is host-paced: this, not xGMI, is the
+    first scaling risk of one Python process per GPU) for the product's reducer (utils/reducer.GradReducer) and, beside
+    it, for torch's DistributedDataParallel (bucket views + bf16 compress hook).  A failure to bring RCCL up is
+    reported in the object, not raised."""
     import torch.distributed as dist
     from rs_detection_amd.runner.runner import Runner
     made = False
@@ -529,18 +531,25 @@ def ddp_overhead_leg(cfg, device, b16, steps, warm, bf16_params, rdist, enq_plai
             os.environ.setdefault("MASTER_PORT", str(rdist.free_port()))
             dist.init_process_group(backend="nccl", rank=0, world_size=1)
             made = True
-        torch.manual_seed(0)
-        r = Runner(cfg, device=device, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
-                   bf16_params=bf16_params, distributed="force")
-        assert r.ddp is not r.model
-        for i in range(warm):
-            r.train_step(*b16[i % N_BATCHES])
-        dt, loss, enq = timed_region(r, b16, steps, rdist, device)
-        out = {"backend": dist.get_backend(), "world": 1, "ms_per_step": dt / steps * 1e3,
-               "host_enqueue_ms_per_step": enq / steps * 1e3, "host_overhead_ms": enq / steps * 1e3 - enq_plain_ms,
-               "step_overhead_ms": dt / steps * 1e3 - ms_plain, "final_loss": loss,
-               "grad_wire_dtype": "bf16" if r.grad_dtype == torch.bfloat16 else "f32"}
-        del r
+        out = {"backend": dist.get_backend(), "world": 1}
+        for tag, mode in (("reducer", "force"), ("torch_ddp", "ddp-force")):
+            torch.manual_seed(0)
+            r = Runner(cfg, device=device, memory_format=torch.channels_last, amp_dtype=torch.bfloat16,
+                       bf16_params=bf16_params, distributed=mode)
+            assert (r.reducer is not None) if tag == "reducer" else (r.ddp is not r.model)
+            for i in range(warm):
+                r.train_step(*b16[i % N_BATCHES])
+            dt, loss, enq = timed_region(r, b16, steps, rdist, device)
+            leg = {"ms_per_step": dt / steps * 1e3, "host_enqueue_ms_per_step": enq / steps * 1e3,
+                   "host_overhead_ms": enq / steps * 1e3 - enq_plain_ms, "step_overhead_ms": dt / steps * 1e3 - ms_plain,
+                   "final_loss": loss}
+            if tag == "reducer":
+                leg["wire"], leg["buckets"] = r.reducer.wire_dtypes, len(r.reducer.buckets)
+                out.update(leg)              # the product's numbers at the top level of the object
+            else:
+                out["torch_ddp"] = leg
+            del r
+            torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001
         out = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     finally:

@@ -187,6 +187,69 @@ __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_kernel(const float* __rest
   }
 }
 
+// The one-tile form (a workgroup = one tile, the cross-lane reduction after it): what the 7x7 / dilation-3 layers keep --
+// their K*K = 49 running sums in registers (98 VGPRs, the kernel-column loop unrolled for static indices) cost more in
+// occupancy than the amortised reductions return (VAN-B3 step, rocprofv3: 38.3 us per call in this form, 46.3 in the
+// multi-tile one).  partial[(c * nslots + slot) * (K*K + 1) + t], slot = n * tiles + tile; t = K*K is the bias gradient
+template <int K, int D>
+__global__ __launch_bounds__(DW_NT) void dwconv_wgrad_tile_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                             const float* __restrict__ in_bias, int C, int H, int W,
+                                                             int tiles_x, int nslots, float* __restrict__ partial) {
+  using G = DwGeom<K, D>;
+  constexpr int T = K * K + 1;
+  __shared__ float s[G::LH * G::LWP];
+  __shared__ float s_red[DW_NT / 64][T];
+  const int plane = blockIdx.x, c = plane % C, n = plane / C;
+  const int ty0 = (blockIdx.y / tiles_x) * DW_TH, tx0 = (blockIdx.y % tiles_x) * DW_TW;
+  dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s, in_bias ? in_bias[c] : 0.f);
+  const int tx = threadIdx.x % DW_TW, tr = (threadIdx.x / DW_TW) * DW_ROWS;
+  float g[DW_ROWS];
+  {
+    const int ox = tx0 + tx;
+    const float* gp = gy + (long long)plane * H * W;
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r) {
+      const int oy = ty0 + tr + r;
+      g[r] = (ox < W && oy < H) ? gp[(long long)oy * W + ox] : 0.f;
+    }
+  }
+  __syncthreads();
+  // per kernel column: K partial sums (one per kernel row) over this thread's 8 outputs, reduced over the wave with
+  // butterflies and parked in LDS; the bias gradient rides along as one more value
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; ++r) v += g[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) s_red[wave][K * K] = v;
+  }
+#pragma unroll 1
+  for (int kw = 0; kw < K; ++kw) {
+    float win[G::WIN];
+#pragma unroll
+    for (int i = 0; i < G::WIN; ++i) win[i] = s[(tr + i) * G::LWP + tx + kw * D];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < DW_ROWS; ++r) v = __builtin_fmaf(g[r], win[r + kh * D], v);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) s_red[wave][kh * K + kw] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < T) {
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < DW_NT / 64; ++wv) v += s_red[wv][threadIdx.x];
+    const int slot = n * gridDim.y + blockIdx.y;
+    partial[((long long)c * nslots + slot) * T + threadIdx.x] = v;
+  }
+}
+
 // one wave per channel: fixed-order sum of its nslots partial rows
 __global__ __launch_bounds__(64) void dwconv_wgrad_finish_kernel(const float* __restrict__ partial, int nslots, int T,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
@@ -296,7 +359,7 @@ extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const flo
   long long tpw = ((long long)N * C * ntiles) / 1536;
   tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
   const int groups = (int)((ntiles + tpw - 1) / tpw);
-  const int nslots = N * groups;                 // <= N * ntiles: the workspace of the one-tile form always suffices
+  const int nslots = K == 7 ? N * ntiles : N * groups;   // (7x7: the one-tile kernel below; <= N * ntiles either way)
   const dim3 grid(N * C, groups);
   float* partial = (float*)ws;
   if (K == 3)
@@ -306,8 +369,8 @@ extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const flo
     hipLaunchKernelGGL((dwconv_wgrad_kernel<5, 1>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, ntiles,
                        (int)tpw, nslots, partial);
   else
-    hipLaunchKernelGGL((dwconv_wgrad_kernel<7, 3>), grid, dim3(DW_NT), 0, s, grad_y, x, in_bias, C, H, W, tx, ntiles,
-                       (int)tpw, nslots, partial);
+    hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7, 3>), dim3(N * C, ntiles), dim3(DW_NT), 0, s, grad_y, x, in_bias, C,
+                       H, W, tx, N * ntiles, partial);
   hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, partial, nslots, K * K + 1, grad_weight,
                      grad_bias);
   return rsdet_launch_status();

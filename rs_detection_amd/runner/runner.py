@@ -97,9 +97,18 @@ class Runner:
             distributed = self.world > 1
         # gradient buckets travel in bf16 when the step computes in bf16 (BASELINE configs[2..4]); fp32 otherwise
         self.grad_dtype = (amp_dtype if amp_dtype == torch.bfloat16 else None) if grad_dtype == "auto" else grad_dtype
-        # distributed="force": DDP even in a one-rank process group (the RCCL reducer path on one GPU: tests, bench)
-        self.ddp = rdist.wrap_ddp(self.model, device, grad_dtype=self.grad_dtype, force=(distributed == "force")) \
-            if distributed else self.model
+        # Data parallelism: the bucketed gradient mean of utils/reducer.py (one multi-tensor copy + one all-reduce per
+        # 64 MB bucket, flushed from inside backward; its module docstring says why not torch's DDP on a host-paced step).
+        #   distributed=True / "force"   own reducer ("force": also in a one-rank group -- RCCL on one GPU: tests, bench)
+        #   distributed="ddp" / "ddp-force"   torch.nn.parallel.DistributedDataParallel, what the reducer is tested against
+        self.reducer = None
+        self.ddp = self.model
+        if distributed in ("ddp", "ddp-force"):
+            self.ddp = rdist.wrap_ddp(self.model, device, grad_dtype=self.grad_dtype, force=(distributed == "ddp-force"))
+        elif distributed and torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                (self.world > 1 or distributed == "force"):
+            from rs_detection_amd.utils.reducer import GradReducer
+            self.reducer = GradReducer(self.model)
         self.iter, self.epoch = 0, 0
         self.max_epoch = cfg.max_epoch if hasattr(cfg, "max_epoch") else None
         self.max_iter = cfg.max_iter if hasattr(cfg, "max_iter") else None
@@ -127,6 +136,8 @@ class Runner:
         opt = self.optimizer_swa if swa else self.optimizer
         opt.zero_grad(set_to_none=True)
         total.backward()
+        if self.reducer is not None:
+            self.reducer.reduce()        # gradient mean over the ranks (most of it already in flight: utils/reducer.py)
         opt.step()
         if swa:
             if self.scheduler_swa is not None:

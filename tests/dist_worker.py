@@ -56,7 +56,9 @@ def flat_grads(model):
 def main():
     model_name, dtype, out = sys.argv[1], sys.argv[2], sys.argv[3]
     size = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-    force = len(sys.argv) > 5 and sys.argv[5] == "force"     # a ONE-rank group with DDP forced on (RCCL on one GPU)
+    flags = sys.argv[5].split("+") if len(sys.argv) > 5 else []
+    force = "force" in flags          # a ONE-rank group with the reducer forced on (RCCL on one GPU)
+    torch_ddp = "ddp" in flags        # torch's DistributedDataParallel instead of utils/reducer.GradReducer
     from rs_detection_amd.utils import dist as rdist
     from rs_detection_amd.utils.general import parse_losses
     rank, local_rank, world = rdist.init_distributed(force=force)
@@ -65,11 +67,16 @@ def main():
     torch.cuda.set_device(dev)
     amp = torch.bfloat16 if dtype == "bf16" else None
     # "f32cl": the fp32 step in channels_last (the bench's layout): canvas head, 1x1 GEMM split, FusedSGD under DDP
-    runner = build_runner(model_name, dev, amp, distributed="force" if force else True, channels_last=dtype == "f32cl")
-    assert runner.ddp is not runner.model, "DDP wrapper missing"
+    mode = ("ddp-force" if force else "ddp") if torch_ddp else ("force" if force else True)
+    runner = build_runner(model_name, dev, amp, distributed=mode, channels_last=dtype == "f32cl")
+    if torch_ddp:
+        assert runner.ddp is not runner.model and runner.reducer is None, "DDP wrapper missing"
+    else:
+        assert runner.reducer is not None and runner.ddp is runner.model, "gradient reducer missing"
     assert (runner.grad_dtype == torch.bfloat16) == (dtype == "bf16")
+    reducer = runner.reducer
 
-    def fwd_bwd(module, images, targets, seed):
+    def fwd_bwd(module, images, targets, seed, reduce=False):
         torch.manual_seed(seed)                # the RoI / RPN samplers draw from torch's generator
         module.zero_grad(set_to_none=True)
         if amp is not None:
@@ -79,6 +86,8 @@ def main():
             losses = module(images, targets)
         total, _ = parse_losses(losses)
         total.backward()
+        if reduce and reducer is not None:
+            reducer.reduce()                   # what Runner.train_step does between backward() and the optimizer step
         return float(total.detach())
 
     # -- single-process reference: an un-wrapped copy on every shard, averaged
@@ -102,11 +111,11 @@ def main():
     images, targets = make_batch(model_name, rank, dev, size)
     fwd_bwd(ref_model, images, targets, 100 + rank)
     own = flat_grads(ref_model).clone()
-    with runner.ddp.no_sync():               # diagnostic: the wrapped module's LOCAL gradients == the plain module's
-        fwd_bwd(runner.ddp, images, targets, 100 + rank)
+    with (runner.ddp if torch_ddp else reducer).no_sync():   # diagnostic: LOCAL gradients == the plain module's
+        fwd_bwd(runner.ddp, images, targets, 100 + rank, reduce=True)
     local = flat_grads(runner.model)
     local_rel = float((local - own).norm() / own.norm().clamp_min(1e-12))
-    loss = fwd_bwd(runner.ddp, images, targets, 100 + rank)
+    loss = fwd_bwd(runner.ddp, images, targets, 100 + rank, reduce=True)
     got = flat_grads(runner.model)
     rel = float((got - want).norm() / want.norm().clamp_min(1e-12))
     maxabs = float((got - want).abs().max())
@@ -125,8 +134,13 @@ def main():
                n_grad=int(got.numel()), finite=bool(torch.isfinite(flat).all()),
                sync_mean=rdist.sync_mean(dict(a=torch.tensor(1.0 + rank), b=torch.tensor(3.0)), dev),
                comm_hook=(runner.ddp._comm_hooks[0][0].__qualname__ if getattr(runner.ddp, "_comm_hooks", None) else None),
+               reducer="torch_ddp" if torch_ddp else "GradReducer",
+               wire=None if reducer is None else reducer.wire_dtypes,
+               n_buckets=None if reducer is None else len(reducer.buckets),
+               grads_in_buckets=None if reducer is None else all(
+                   reducer.owns(p.grad) for p in runner.model.parameters() if p.requires_grad and p.grad is not None),
                bf16_params=bool(runner.bf16_params), optimizer=type(runner.optimizer).__name__,
-               bucket_view=bool(getattr(runner.ddp, "gradient_as_bucket_view", False)))
+               bucket_view=bool(getattr(runner.ddp, "gradient_as_bucket_view", False)) if torch_ddp else True)
     with open("%s.rank%d.json" % (out, rank), "w") as f:
         json.dump(res, f)
     rdist.barrier()

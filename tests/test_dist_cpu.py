@@ -379,3 +379,55 @@ def test_check_pinning_reports_the_node_of_the_opened_gpu(tmp_path, monkeypatch)
     assert rdist.check_pinning(0, [8, 9, 10], sysfs=str(root), log=said.append) == (1, True)
     assert rdist.check_pinning(0, [0, 1], sysfs=str(root), log=said.append) == (1, False)
     assert "NOT ALL ON" in said[-1]
+
+
+def _reducer_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from rs_detection_amd.utils import dist as rdist
+    from rs_detection_amd.utils.reducer import GradReducer
+    rdist.init_distributed(backend="gloo")
+    torch.manual_seed(rank)                      # different weights per rank: the reducer's broadcast must fix that
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    model = model.to(memory_format=torch.channels_last)
+    model[2].bias.requires_grad_(False)          # a frozen parameter is not part of any bucket
+    red = GradReducer(model, bucket_cap_mb=0.0001)
+    params = [p for p in model.parameters() if p.requires_grad]
+    x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(100 + rank))
+
+    def backward():
+        for p in model.parameters():
+            p.grad = None
+        (model(x).square().mean() * (rank + 1)).backward()
+        red.reduce()
+        return torch.cat([p.grad.reshape(-1) for p in params])
+    backward()
+    got = backward()                             # second step: the buckets are reused
+    owned = all(red.owns(p.grad) for p in params) and all(p.grad.stride() == p.stride() for p in params)
+    with red.no_sync():
+        local = backward()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    ws = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    q.put((rank, float((got - sum(gathered) / world).abs().max()), float((ws[0] - ws[1]).abs().max()), len(red.buckets),
+           owned, not any(red.owns(p.grad) for p in params)))      # (under no_sync the gradients stay local tensors)
+    rdist.shutdown()
+
+
+def test_grad_reducer_two_ranks_gloo():
+    """utils/reducer.GradReducer: bucketed mean of the gradients over two ranks == the mean of the local gradients
+    (optims/optimizer.py:30-31 of the reference: all-reduce with op "mean"); every rank starts from rank 0's weights;
+    p.grad ends up a view into a bucket with the parameter's own strides (channels_last included)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    [p.join(60) for p in ps]
+    for rank, err, spread, nb, owned, strides in res:
+        assert err <= 1e-7 and spread == 0.0 and nb == 2 and owned and strides, res

@@ -21,24 +21,29 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def _run(model, dtype, tmp_path, size=256, world=2, extra_env=None, force=False):
+def _run(model, dtype, tmp_path, size=256, world=2, extra_env=None, force=False, torch_ddp=False):
     from rs_detection_amd.utils import dist as rdist
     env = dict(os.environ, **(extra_env or {}))
     if torch.cuda.device_count() < world:
         env["RSDET_DIST_BACKEND"] = "gloo"
     out = str(tmp_path / "res")
-    rc, text = rdist.launch_ranks(world, [WORKER, model, dtype, out, str(size)] + (["force"] if force else []),
+    flags = "+".join((["force"] if force else []) + (["ddp"] if torch_ddp else []))
+    rc, text = rdist.launch_ranks(world, [WORKER, model, dtype, out, str(size)] + ([flags] if flags else []),
                                   env=env, timeout=900)
     assert rc == 0, "a rank failed (rc %d)\n%s" % (rc, text[-2000:])
     return [json.load(open("%s.rank%d.json" % (out, r))) for r in range(world)]
 
 
 @pytest.mark.timeout(1000)
-@pytest.mark.parametrize("model,dtype,tol", [("s2anet", "f32", 1e-3), ("s2anet", "f32cl", 1e-3), ("s2anet", "bf16", 0.1),
-                                             ("orcnn", "f32", 5e-3), ("orcnn", "bf16", 0.1)])
-def test_two_rank_ddp_real_model(model, dtype, tol, tmp_path):
+@pytest.mark.parametrize("model,dtype,tol,torch_ddp", [
+    ("s2anet", "f32", 1e-3, False), ("s2anet", "f32cl", 1e-3, False), ("s2anet", "bf16", 0.1, False),
+    ("orcnn", "f32", 5e-3, False), ("orcnn", "bf16", 0.1, False),
+    ("s2anet", "bf16", 0.1, True), ("orcnn", "f32", 5e-3, True)])          # the same harness through torch's DDP
+def test_two_rank_ddp_real_model(model, dtype, tol, torch_ddp, tmp_path):
+    """Two ranks of the real model: gradients after the data-parallel reduction (utils/reducer.GradReducer, or torch's
+    DistributedDataParallel where ``torch_ddp``) == the mean over the shards of a single un-wrapped model's."""
     _need_gpu()
-    res = _run(model, dtype, tmp_path)
+    res = _run(model, dtype, tmp_path, torch_ddp=torch_ddp)
     print(res)
     for r in res:
         assert r["world"] == 2 and r["finite"]
@@ -50,19 +55,24 @@ def test_two_rank_ddp_real_model(model, dtype, tol, tmp_path):
         assert r["param_spread"] == 0.0, r           # bit-identical parameters on both ranks after two steps
         assert r["grad_norm"] > 0 and r["n_grad"] > 1e6
         if model == "s2anet":
-            # the two train steps above ran FusedSGD (its per-step gradient-pointer ring) on gradients that are VIEWS
-            # into DDP's buckets; in bf16 additionally with bf16 parameters and the bf16 compress hook on the buckets
+            # the two train steps above ran FusedSGD on gradients that are VIEWS into the reducer's buckets; in bf16 with
+            # bf16 parameters, whose gradients travel as bf16
             assert r["optimizer"] == "FusedSGD" and r["bucket_view"], r
             assert r["bf16_params"] == (dtype == "bf16"), r
+        if not torch_ddp:
+            assert r["reducer"] == "GradReducer" and r["grads_in_buckets"] and 1 <= r["n_buckets"] <= 8, r
+            if dtype == "bf16" and model == "s2anet":
+                assert "torch.bfloat16" in r["wire"], r
     assert res[0]["loss"] != res[1]["loss"]          # the ranks really worked on different shards
 
 
 @pytest.mark.timeout(1000)
 @pytest.mark.parametrize("model,dtype,tol", [("s2anet", "f32cl", 1e-3), ("s2anet", "bf16", 0.1), ("orcnn", "f32", 5e-3)])
 def test_rccl_reducer_path_on_one_gpu(model, dtype, tol, tmp_path):
-    """The backend the node will run: an ``nccl`` (= RCCL) process group of ONE rank with DDP forced on
-    (``Runner(distributed="force")``): bucket views, the bf16 compress hook, FusedSGD's gradient-pointer ring on
-    bucket-view gradients, ``sync_mean`` and the MIN / MAX all-reduces of the worker all go through RCCL on this GPU.
+    """The backend the node will run: an ``nccl`` (= RCCL) process group of ONE rank with the gradient reducer forced on
+    (``Runner(distributed="force")``): bucket views, bf16 buckets, the asynchronous all-reduces flushed from inside
+    backward, FusedSGD on bucket-view gradients, ``sync_mean`` and the MIN / MAX all-reduces of the worker all go through
+    RCCL on this GPU.
     With one shard the all-reduced mean IS the un-wrapped model's gradient: equal to the run-to-run noise of the
     single-process computation (reference collective: optims/optimizer.py:30-31, utils/general.py:30-48)."""
     _need_gpu()
@@ -74,10 +84,11 @@ def test_rccl_reducer_path_on_one_gpu(model, dtype, tol, tmp_path):
     assert r["local_rel_err"] < max(tol, 3 * r["noise"]), r
     assert r["param_spread"] == 0.0
     assert r["sync_mean"] == {"a": 1.0, "b": 3.0}
+    assert r["reducer"] == "GradReducer" and r["grads_in_buckets"]
     if model == "s2anet":
         assert r["optimizer"] == "FusedSGD" and r["bf16_params"] == (dtype == "bf16")
         if dtype == "bf16":
-            assert r["comm_hook"] is not None          # bf16 on the wire
+            assert "torch.bfloat16" in r["wire"]       # bf16 on the wire
 
 
 @pytest.mark.timeout(1500)

@@ -251,7 +251,9 @@ def test_config3_van_b3_1024_train_step_and_eval(cuda):
     h = model.bbox_head.bbox_roi_extractor.register_forward_pre_hook(grab)
     props = {}
     def count(mod, args, out):
-        props["n"] = [len(p) for p in out[0]]        # (a hook that returns a value would replace the output)
+        # training: (fixed-size proposals, mask of the real ones) per image -- count the real ones
+        props["n"] = [int(p[1].sum()) if isinstance(p, tuple) else len(p) for p in out[0]]
+        # (a hook that returns a value would replace the output)
     hp = model.rpn.register_forward_hook(count)
     model.train()
     losses = model(images, [t])
