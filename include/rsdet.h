@@ -370,6 +370,24 @@ int rsdet_alignconv_fwd_mfma_f32(const float* im_nhwc, const float* offset, cons
  * Optional fused epilogue: bias (O fp32, NULL = none), relu, live (H*W bytes shared by all images, NULL = all live): positions whose byte
  * is 0 -- the gap pixels of the pyramid canvas -- are written as zeros.  C % 64 == 0, O % 32 == 0. */
 int rsdet_conv3x3_mfma_supported(int B, int H, int W, int C, int O);
+/* 1x1 convolution + frozen-statistics BatchNorm + residual add + ReLU of a channels-last bf16 map as ONE launch
+ * (csrc/gemm1x1_mfma.hip: the conv3x3 kernel's tile and fragment machinery at K = C, the per-channel affine map, the
+ * residual and the activation in the epilogue; the convolution's raw output never reaches memory).  Replaces conv1 /
+ * conv3 / downsample + bn (+ identity) + relu of the reference's Bottleneck, models/backbones/resnet.py:57-93, in the
+ * norm_eval mode of :177-184.  x (M, K), weight (N, K), residual / out (M, N) row-major bf16, M = B*H*W positions;
+ * running_mean / running_var / gamma / beta fp32 (N) -- mean == var == NULL: a plain convolution with `beta` as its
+ * bias; gamma NULL: 1; beta NULL: 0.  K % 64 == 0, N % 32 == 0.
+ * Its backward through the BatchNorm: rsdet_bn_act_backward_nhwc_fromy_bf16 (the normalised input of the scale
+ * gradient is recovered from the output: xhat = (y - residual - beta) / gamma wherever the ReLU passed the value). */
+int rsdet_gemm1x1_mfma_supported(long long M, int N, int K);
+int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* weight, long long M, int N, int K,
+                                  const float* running_mean, const float* running_var, const float* gamma,
+                                  const float* beta, float eps, const uint16_t* residual, int relu, uint16_t* out,
+                                  void* stream);
+int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
+                                          const float* running_var, const float* weight, const float* bias, float eps,
+                                          int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
+                                          float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* weight, const float* bias, const uint8_t* live, int B,
                                 int H, int W, int C, int O, int relu, uint16_t* out, void* stream);
 /* Weight gradient of the same convolution (csrc/conv3x3_wrw_mfma.hip): split-K implicit GEMM over groups of image rows,

@@ -38,6 +38,12 @@ SIGNATURES = {
     "rsdet_box_iou_rotated_fast_rows_per_tile": (c_int, []),
     "rsdet_box_iou_rotated_fast_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_gemm1x1_mfma_supported": (c_int, [c_ll, c_int, c_int]),
+    "rsdet_conv1x1_bn_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "rsdet_bn_act_backward_nhwc_fromy_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_void_p, c_size_t, c_void_p]),
     "rsdet_box_iou_rotated_split_state_bytes": (c_size_t, []),
     "rsdet_box_iou_rotated_split_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "rsdet_box_iou_rotated_split_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,

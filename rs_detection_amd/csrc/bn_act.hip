@@ -354,7 +354,12 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ weight, float eps,
     long long rows, int C, int rows_per, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
-    float* __restrict__ partial, const unsigned char* __restrict__ mask) {
+    float* __restrict__ partial, const unsigned char* __restrict__ mask, const bf16_t* __restrict__ fy_res = nullptr,
+    const float* __restrict__ fy_bias = nullptr, int from_y = 0) {
+  // from_y (the backward of csrc/gemm1x1_mfma.hip's fused convolution + BatchNorm, whose pre-BatchNorm value x never
+  // reached memory): the normalised input the scale gradient needs is recovered from the OUTPUT,
+  // xhat = (y - residual - beta) / gamma, exact wherever the ReLU let the value through -- and nowhere else does the
+  // gradient count (g = 0 there).  gamma == 0: the term is dropped (the forward carries no information about xhat).
   __shared__ float s_red[BN_NT][17];   // 17: the fold below reads a column of 16 across rows
   const int G = C >> 3, S = gridDim.x, s = blockIdx.x;
   const int RL = BN_NT / G;            // G is a divisor of 256 (host-checked)
@@ -371,6 +376,17 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
   } else {
     sc = is;
   }
+  F8 fb, fiw;
+  if (from_y) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fb.v[k] = 0.f, fiw.v[k] = 1.f;
+    if (fy_bias) fb = ldp8(fy_bias + c0);
+    if (weight) {
+      const F8 w = ldp8(weight + c0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fiw.v[k] = w.v[k] != 0.f ? 1.0f / w.v[k] : 0.f;
+    }
+  }
   float acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
@@ -381,13 +397,14 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
   for (long long r = r0 + rl; r < r1; r += RL) {
     const long long base = r * C + c0;
     F8 g = ld8(dy + base);
+    F8 o;
+    if ((RELU && !mask) || (from_y && partial)) o = ld8(y + base);
     if (RELU) {
       if (mask) {         // one byte instead of the 16 bytes of y
         const unsigned b = mask[base >> 3];
 #pragma unroll
         for (int k = 0; k < 8; ++k) g.v[k] = ((b >> k) & 1u) ? g.v[k] : 0.f;
       } else {
-        const F8 o = ld8(y + base);
 #pragma unroll
         for (int k = 0; k < 8; ++k) g.v[k] = o.v[k] > 0.f ? g.v[k] : 0.f;
       }
@@ -399,6 +416,14 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
         const F8 v = ld8(x + base);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[8 + k] += g.v[k] * ((v.v[k] - m.v[k]) * is.v[k]);
+      } else if (from_y) {
+        if (fy_res) {
+          const F8 r = ld8(fy_res + base);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o.v[k] -= r.v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[8 + k] += g.v[k] * ((o.v[k] - fb.v[k]) * fiw.v[k]);
       }
     }
     if (dres) st8(dres + base, g);
@@ -799,6 +824,41 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char
     if (J == 1) RSDET_BN_BWD(false, 1); else if (J == 2) RSDET_BN_BWD(false, 2); else RSDET_BN_BWD(false, 4);
   }
 #undef RSDET_BN_BWD
+  if (need_param)
+    hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
+                       grad_bias);
+  return rsdet_launch_status();
+}
+
+// Backward of the fused 1x1 convolution + BatchNorm + residual + ReLU (csrc/gemm1x1_mfma.hip): as
+// rsdet_bn_act_backward_nhwc_bf16, but the scale gradient's normalised input comes from the OUTPUT y (the kernel's
+// from_y note).  bf16, C / 8 a divisor of 256.  grad_x = the gradient with respect to the CONVOLUTION's raw output.
+extern "C" int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
+                                                     const float* running_var, const float* weight, const float* bias,
+                                                     float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
+                                                     uint16_t* grad_residual, float* grad_weight, float* grad_bias,
+                                                     void* ws, size_t ws_bytes, void* stream) {
+  if (N < 0 || HW < 0 || !bn_nhwc_ok(C) || !bn_nhwc8_ok(C)) return RSDET_EINVAL;
+  if (N == 0 || HW == 0) return RSDET_OK;
+  if (!grad_y || !y || !running_var) return RSDET_EINVAL;
+  const bool need_param = grad_weight || grad_bias;
+  if (need_param && (!ws || ws_bytes < rsdet_bn_act_backward_nhwc_ws_size(N, C, HW))) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const long long rows = (long long)N * HW;
+  int per, S;
+  bn_nhwc_split(rows, C, &per, &S, 8);
+  float* partial = need_param ? (float*)ws : nullptr;
+  const bf16_t *gy = grad_y, *yy = y, *rr = residual;
+  const int fy = grad_weight ? 1 : 0;          // (only the scale gradient needs xhat)
+  // running_mean is not needed in this form: pass running_var for it (the kernel loads it, nothing reads it)
+  if (relu)
+    hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<true>), dim3(S), dim3(BN_NT), 0, s, gy, yy, (const bf16_t*)nullptr,
+                       running_var, running_var, weight, eps, rows, C, per, (bf16_t*)grad_x, (bf16_t*)grad_residual,
+                       partial, (const unsigned char*)nullptr, rr, bias, fy);
+  else
+    hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<false>), dim3(S), dim3(BN_NT), 0, s, gy, yy, (const bf16_t*)nullptr,
+                       running_var, running_var, weight, eps, rows, C, per, (bf16_t*)grad_x, (bf16_t*)grad_residual,
+                       partial, (const unsigned char*)nullptr, rr, bias, fy);
   if (need_param)
     hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
                        grad_bias);
