@@ -6,19 +6,25 @@
 //   /root/reference/python/jdet/models/backbones/resnet.py:57-93 (norm_eval: BatchNorm in eval mode, :177-184, so
 //   bn(x) = x * gamma / sqrt(var + eps) + (beta - mean * gamma / sqrt(var + eps)) is a per-channel affine map),
 // which the step ran as a library GEMM (ops/conv1x1.py) followed by a `bn_act` pass over the result (csrc/bn_act.hip:
-// read conv output + residual, write y: 0.86 ms and 48 launches of the 15.9 ms bf16 step).  Here the conv output never
-// reaches HBM: out[p, o] = relu((sum_c x[p, c] W[o, c]) * s[o] + t[o] + res[p, o]).
+// read conv output + residual, write y).  Here the conv output never reaches HBM:
+//   out[p, o] = relu((sum_c x[p, c] W[o, c]) * s[o] + t[o] + res[p, o]).
 //
-//   GEMM   M = positions (B*H*W), N = output channels, K = input channels; both operands K-contiguous as they lie.
-//   tile   one workgroup = 224 positions x 256 output channels (the tile of csrc/conv3x3_mfma.hip: 2 x 4 waves of
-//          112 x 64, v_mfma_f32_16x16x32_bf16, 28 accumulators per wave); K in steps of 64 channels;
-//   LDS    A tile 224 x 128 B and B tile 256 x 128 B per step, both by LDS-DMA (global_load_lds, 16 B per lane) into a
-//          two-slot ring, 16-byte chunk c of row r in slot c ^ (r & 7) (conflict-free ds_read_b128 fragments; the
-//          swizzle is applied on the DMA's SOURCE address); one barrier per step: wait for tile s -> barrier -> issue
-//          tile s + 1 into the slot step s - 1 read -> the 56 MFMAs of step s;
-//   frags  hand-issued ds_read_b128 a sub-step ahead with counted lgkmcnt (the conv3x3 kernel's sub-step macro);
-//   D = W-fragment x X-fragment: a lane ends up with four consecutive output channels of one position: 8-byte
-//          stores, per-channel scale / shift in registers.
+// These GEMMs are STREAMS, not matrix-core problems: M = 4 096 .. 262 144 positions against N, K <= 2 048 channels;
+// the bytes of x / res / out set the time (e.g. 64 -> 256 channels at 4 x 256^2: 300 MB for 8.6 GFLOP), so the kernel
+// is built to keep HBM loads in flight, not to fill the MFMA pipe:
+//   * PERSISTENT workgroups (one per CU): a workgroup owns one 64 NI-channel column panel and walks its share of the
+//     128-position row tiles; (tile, 64-channel K step) pairs form ONE flat sequence of steps;
+//   * a ring of 3 LDS slots (A tile 128 x 128 B + W tile 64 NI x 128 B), filled by LDS-DMA (global_load_lds, 16 B per
+//     lane) TWO steps ahead of the MFMAs across tile boundaries: the next tile's loads are in flight while this
+//     tile's epilogue stores leave; `s_waitcnt vmcnt(N)` is counted by hand (loads, LDS-DMA and stores complete in
+//     issue order), raw s_barrier (a __syncthreads would drain the DMA queue);
+//   * fragments: ds_read_b128 from the XOR-swizzled image (16-byte chunk c of row r in slot c ^ (r & 7), swizzle on the
+//     DMA's SOURCE address: conflict-free), issued a k-32 sub-step ahead with counted lgkmcnt;
+//     v_mfma_f32_16x16x32_bf16, D = W-fragment x X-fragment (a lane holds 4 consecutive channels of one position);
+//   * epilogue in registers: v_permlane16_swap pairs two fragments so that a lane owns EIGHT consecutive channels:
+//     16-byte residual loads (issued before the tile's last MFMAs) and 16-byte stores, the affine map from a
+//     scale / shift table in LDS.
+// 8 waves = 2 (64 positions) x 4 (16 NI channels); NI = 2 (N tile 128) or 4 (N tile 256).
 // The arithmetic is the convolution's and the BatchNorm's own: bf16 products, fp32 accumulation, the affine map and the
 // residual in fp32, ONE rounding to bf16 (the two-launch form rounded the conv output to bf16 first).
 #include <hip/hip_runtime.h>
@@ -33,14 +39,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 g1_bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned g1_u32x4;
 typedef __attribute__((ext_vector_type(4))) float g1_f32x4;
 
-constexpr int G1_TM = 224, G1_TN = 256, G1_NW = 8;
-constexpr int G1_A_BYTES = G1_TM * 128, G1_B_BYTES = G1_TN * 128;           // 28 672, 32 768
-constexpr int G1_SLOT = G1_A_BYTES + G1_B_BYTES;                             // 61 440
-constexpr int G1_LDS_BYTES = 2 * G1_SLOT;                                    // 122 880
-constexpr int G1_A_PIECES = G1_A_BYTES / 1024, G1_B_PIECES = G1_B_BYTES / 1024;   // 28, 32 (1 KiB = 8 rows x 128 B)
-constexpr int G1_A_ITERS = (G1_A_PIECES + G1_NW - 1) / G1_NW;                // 4 (waves 4..7 issue 3)
-constexpr int G1_B_OPS = G1_B_PIECES / G1_NW;                                // 4
-constexpr int G1_MI = 7, G1_NI = 4, G1_WM = 112;
+constexpr int G1_TM = 128, G1_NW = 8, G1_MI = 4, G1_STAGES = 3;
+constexpr int G1_A_BYTES = G1_TM * 128;                                      // 16 384
+constexpr int G1_A_OPS = G1_A_BYTES / 1024 / G1_NW;                          // LDS-DMA operations per wave and tile: 2
 
 __device__ const uint4 g1_zero_line[8] = {};   // 128 B of zeros: rows past the end of the matrix
 
@@ -49,14 +50,14 @@ struct G1Geom {
   int N, K;
 };
 
-// epilogue parameters (all per output channel n unless said otherwise; null = absent)
+// epilogue parameters (all per output channel n; null = absent)
 struct G1Epi {
   const float* mean;     // BatchNorm running mean / var / weight / bias: scale = gamma / sqrt(var + eps),
   const float* var;      //   shift = beta - mean * scale; mean == var == null: plain convolution (scale 1)
   const float* gamma;
   const float* beta;     // with mean == null: a plain bias
   float eps;
-  const bf16_t* res;     // [M][N] residual added before the activation, or null
+  const bf16_t* res;     // [M][N] residual added before the activation (RES kernels), or null
   int relu;
 };
 
@@ -64,157 +65,77 @@ template <int N>
 __device__ __forceinline__ void g1_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+__device__ __forceinline__ void g1_wait_vm_n(int n) {   // n is wave-uniform and one of the multiples of 2 below
+  switch (n) {
+#define G1_VMCASE(k) case k: g1_wait_vm<k>(); break;
+    G1_VMCASE(0) G1_VMCASE(2) G1_VMCASE(4) G1_VMCASE(6) G1_VMCASE(8) G1_VMCASE(10) G1_VMCASE(12) G1_VMCASE(14)
+    G1_VMCASE(16) G1_VMCASE(18) G1_VMCASE(20) G1_VMCASE(22) G1_VMCASE(24) G1_VMCASE(26) G1_VMCASE(28) G1_VMCASE(30)
+    G1_VMCASE(32) G1_VMCASE(34) G1_VMCASE(36) G1_VMCASE(38) G1_VMCASE(40)
+#undef G1_VMCASE
+    default: g1_wait_vm<0>(); break;
+  }
+}
 template <int N>
 __device__ __forceinline__ void g1_wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
-template <int OFF>
+__device__ __forceinline__ void g1_wait_lgkm_n(int n) {   // n: a compile-time constant after unrolling
+  switch (n) {
+#define G1_LGCASE(k) case k: g1_wait_lgkm<k>(); break;
+    G1_LGCASE(0) G1_LGCASE(1) G1_LGCASE(2) G1_LGCASE(3) G1_LGCASE(4) G1_LGCASE(5) G1_LGCASE(6) G1_LGCASE(7)
+    G1_LGCASE(8) G1_LGCASE(9) G1_LGCASE(10) G1_LGCASE(11) G1_LGCASE(12) G1_LGCASE(13) G1_LGCASE(14) G1_LGCASE(15)
+#undef G1_LGCASE
+    default: g1_wait_lgkm<0>(); break;
+  }
+}
 __device__ __forceinline__ void g1_lds_read(g1_u32x4& dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
 }
 __device__ __forceinline__ void g1_landed(g1_u32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void g1_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void g1_load16(g1_u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// rows (16 lanes) 1 and 3 of x trade places with rows 0 and 2 of y
+__device__ __forceinline__ void g1_swap16(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+}
 
-// grid: rsdet_xcd_band_grid(m_tiles, n_tiles); block 512.
+template <typename T, T V>
+struct g1_const {
+  static constexpr T value = V;
+};
+
+// persistent grid of 8 * n_tiles * mm workgroups (host: ~one per CU); workgroup id -> (XCD x, slot): column panel
+// n = slot % n_tiles, row lane = (slot / n_tiles) * 8 + x -- the workgroups that stream the SAME rows sit on one XCD
+// (ids x, x + 8, ...: round-robin placement; speed only) and share the rows in its L2.
+template <int NI, bool RES>
 __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel(
     const bf16_t* __restrict__ a, const bf16_t* __restrict__ w, G1Geom g, G1Epi e, int m_tiles, int n_tiles,
     bf16_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[G1_LDS_BYTES];
-  const RsdetBandItem item = rsdet_xcd_band(blockIdx.x, m_tiles, n_tiles);
-  if (!item.valid) return;
+  constexpr int TN = 64 * NI, B_BYTES = TN * 128, SLOT = G1_A_BYTES + B_BYTES, B_OPS = B_BYTES / 1024 / G1_NW;
+  constexpr int NP = NI / 2;                       // fragment pairs of a wave = 16-byte stores per position
+  constexpr int E_OPS = G1_MI * NP, R_OPS = RES ? E_OPS : 0, AB_OPS = G1_A_OPS + B_OPS;
+  constexpr int TAB = G1_STAGES * SLOT;            // scale / shift table behind the ring (ONE shared array: a second
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[TAB + TN * 8];   // one would drain the DMA queue, guide 5.4(a))
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long p0 = (long long)item.outer * G1_TM;
-  const int n_base = item.inner * G1_TN;
-  const int steps = g.K >> 6;
+  const int xcd = (int)(blockIdx.x & 7u), slot_id = (int)(blockIdx.x >> 3);
+  const int n_t = slot_id % n_tiles, lanes_m = (int)(gridDim.x >> 3) / n_tiles * 8;
+  const int m_lane = (slot_id / n_tiles) * 8 + xcd;
+  if (m_lane >= m_tiles) return;
+  const int my_tiles = (m_tiles - m_lane + lanes_m - 1) / lanes_m;
+  const int KS = g.K >> 6, S = my_tiles * KS;
+  const int n_base = n_t * TN;
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g1_zero_line);
-  const int prow = lane >> 3;                       // row of the lane inside a piece = (LDS row) & 7
+  const int prow = lane >> 3;                       // row of the lane inside a 1 KiB piece = (LDS row) & 7
   const int chunk = (lane & 7) ^ prow;              // the source chunk that belongs in the lane's slot
-  // per-lane source offsets (elements) of the A and B pieces this wave moves; -1: a row past the matrix
-  long long a_off[G1_A_ITERS], b_off[G1_B_OPS];
-#pragma unroll
-  for (int it = 0; it < G1_A_ITERS; ++it) {
-    const long long p = p0 + (wave + it * G1_NW) * 8 + prow;
-    a_off[it] = p < g.M ? p * g.K + chunk * 8 : -1;
-  }
-#pragma unroll
-  for (int it = 0; it < G1_B_OPS; ++it) {
-    const int r = (wave + it * G1_NW) * 8 + prow;
-    b_off[it] = (long long)min(n_base + r, g.N - 1) * g.K + chunk * 8;
-  }
-  auto issue = [&](int s) {
-    unsigned char* slot = lds + (s & 1) * G1_SLOT;
-    const int k0 = s * 64;
-#pragma unroll
-    for (int it = 0; it < G1_A_ITERS; ++it) {
-      const int piece = wave + it * G1_NW;
-      if (piece < G1_A_PIECES) {
-        const bf16_t* src = a_off[it] >= 0 ? a + a_off[it] + k0 : zero + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < G1_B_OPS; ++it) {
-      const int piece = wave + it * G1_NW;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + b_off[it] + k0),
-                                       (__attribute__((address_space(3))) void*)(slot + G1_A_BYTES + piece * 1024), 16,
-                                       0, 0);
-    }
-  };
 
-  g1_f32x4 acc[G1_MI][G1_NI];
-#pragma unroll
-  for (int mi = 0; mi < G1_MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < G1_NI; ++ni)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[mi][ni][k] = 0.f;
-
-  const int wm = wave >> 2, wn = wave & 3;
-  const int q4 = lane >> 4, l15 = lane & 15;
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  // fragment addresses: position row = wm * 112 + mi * 16 + (lane & 15), weight row = wn * 64 + ni * 16 + (lane & 15);
-  // 16-byte slot (4 ks + (lane >> 4)) ^ (row & 7): wm * 112, mi * 16, ni * 16 are 0 mod 8 and 4 ks is bit 2 of the slot:
-  // one base per lane, XOR 64 for the second k-32 sub-step, immediates mi * 2048 / ni * 2048
-  const unsigned a_lane = (unsigned)((wm * G1_WM + l15) * 128 + ((q4 ^ (l15 & 7)) << 4));
-  const unsigned b_lane = (unsigned)(G1_A_BYTES + (wn * 64 + l15) * 128 + ((q4 ^ (l15 & 7)) << 4));
-  g1_u32x4 fa[2][G1_MI], fb[2][G1_NI];
-#define G1_RA(buf, mi, ab) g1_lds_read<(mi) * 2048>(fa[buf][mi], ab)
-#define G1_RB(buf, ni, bb) g1_lds_read<(ni) * 2048>(fb[buf][ni], bb)
-  // read order of a sub-step: B0, A0 .. A6, B1, B2, B3 -- the order the MFMAs (weight-fragment major) first need them
-#define G1_READ(buf, idx, ab, bb)                  \
-  switch (idx) {                                   \
-    case 0: G1_RB(buf, 0, bb); break;              \
-    case 1: G1_RA(buf, 0, ab); break;              \
-    case 2: G1_RA(buf, 1, ab); break;              \
-    case 3: G1_RA(buf, 2, ab); break;              \
-    case 4: G1_RA(buf, 3, ab); break;              \
-    case 5: G1_RA(buf, 4, ab); break;              \
-    case 6: G1_RA(buf, 5, ab); break;              \
-    case 7: G1_RA(buf, 6, ab); break;              \
-    case 8: G1_RB(buf, 1, bb); break;              \
-    case 9: G1_RB(buf, 2, bb); break;              \
-    default: G1_RB(buf, 3, bb); break;             \
-  }
-  static_assert(G1_MI == 7 && G1_NI == 4, "read order and wait counts below are written out for 7 x 4 fragments");
-  // One sub-step (k = 32): 28 MFMAs on register set CUR, whose 11 reads were all ISSUED during the previous sub-step;
-  // the 11 reads of the next sub-step go out one per MFMA into set 1 - CUR.  LDS reads return in issue order: at MFMA j
-  // the first 2 + j (j < 7), 9 / 10 / 11 (from j = 7 / 14 / 21) of the CURRENT set are needed.  `more` false (second
-  // sub-step of a step: the next fragments lie behind the barrier): the counts run down.
-#define G1_SUBSTEP(CUR, more, ab, bb)                                                                                   \
-  {                                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < G1_MI * G1_NI; ++j) {                                                         \
-      const int ni = j / G1_MI, mi = j - ni * G1_MI;                                                                    \
-      if (more) {                                                                                                       \
-        if (j < 11) G1_READ(1 - CUR, j, ab, bb);                                                                        \
-        if (j <= 7) g1_wait_lgkm<10>();                                                                                 \
-        else if (j == 14) g1_wait_lgkm<12>();                                                                           \
-        else if (j == 21) g1_wait_lgkm<11>();                                                                           \
-      } else {                                                                                                          \
-        if (j == 0) g1_wait_lgkm<9>();                                                                                  \
-        else if (j == 1) g1_wait_lgkm<8>();                                                                             \
-        else if (j == 2) g1_wait_lgkm<7>();                                                                             \
-        else if (j == 3) g1_wait_lgkm<6>();                                                                             \
-        else if (j == 4) g1_wait_lgkm<5>();                                                                             \
-        else if (j == 5) g1_wait_lgkm<4>();                                                                             \
-        else if (j == 6) g1_wait_lgkm<3>();                                                                             \
-        else if (j == 7) g1_wait_lgkm<2>();                                                                             \
-        else if (j == 14) g1_wait_lgkm<1>();                                                                            \
-        else if (j == 21) g1_wait_lgkm<0>();                                                                            \
-      }                                                                                                                 \
-      if (ni == 0) g1_landed(fa[CUR][mi]);                                                                              \
-      if (mi == 0) g1_landed(fb[CUR][ni]);                                                                              \
-      /* D = W-fragment x X-fragment: rows = output channels, columns = positions (4 consecutive channels per lane) */ \
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g1_bf16x8, fb[CUR][ni]),                 \
-                                                            __builtin_bit_cast(g1_bf16x8, fa[CUR][mi]), acc[mi][ni], 0, \
-                                                            0, 0);                                                      \
-    }                                                                                                                   \
-  }
-
-  // ---- schedule: tile s was issued during step s - 1 (tile 0 before the loop) and nothing younger is in flight when
-  // step s starts, so `vmcnt(0)` is exactly "tile s has landed" for this wave's pieces; the barrier extends that to all
-  // eight waves AND says everybody has finished reading the other slot (step s - 1), which tile s + 1 may now overwrite
-  issue(0);
-  for (int s = 0; s < steps; ++s) {
-    g1_wait_vm<0>();
-    __syncthreads();
-    if (s + 1 < steps) issue(s + 1);
-    const unsigned ab = lds_base + (s & 1) * G1_SLOT + a_lane, bb = lds_base + (s & 1) * G1_SLOT + b_lane;
-#pragma unroll
-    for (int idx = 0; idx < 11; ++idx) G1_READ(0, idx, ab, bb);
-    G1_SUBSTEP(0, true, ab ^ 64u, bb ^ 64u);
-    G1_SUBSTEP(1, false, ab, bb);
-  }
-
-  // ---- epilogue: lane holds channels n_base + wn * 64 + ni * 16 + 4 (lane >> 4) + 0..3 of position
-  // p0 + wm * 112 + mi * 16 + (lane & 15)
-  const int ob = n_base + wn * 64 + 4 * q4;
-  float sc[G1_NI][4], sh[G1_NI][4];
-#pragma unroll
-  for (int ni = 0; ni < G1_NI; ++ni)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int o = min(ob + 16 * ni + k, g.N - 1);
+  // ---- scale / shift table (fp32, TN + TN) in LDS
+  {
+    float* tab = reinterpret_cast<float*>(lds + TAB);
+    for (int c = tid; c < TN; c += 64 * G1_NW) {
+      const int o = min(n_base + c, g.N - 1);
       float s1 = 1.f, t1 = 0.f;
       if (e.mean) {
         const float is = 1.0f / sqrtf(e.var[o] + e.eps);
@@ -223,31 +144,182 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
       } else if (e.beta) {
         t1 = e.beta[o];
       }
-      sc[ni][k] = s1, sh[ni][k] = t1;
+      tab[c] = s1, tab[TN + c] = t1;
+    }
+  }
+  long long b_off[B_OPS];
+#pragma unroll
+  for (int it = 0; it < B_OPS; ++it) {
+    const int r = (wave + it * G1_NW) * 8 + prow;
+    b_off[it] = (long long)min(n_base + r, g.N - 1) * g.K + chunk * 8;
+  }
+  // issue cursor: the flat step the next DMA belongs to
+  int i_tile = 0, i_k = 0;
+  auto issue = [&](int s) {
+    unsigned char* slot = lds + (s % G1_STAGES) * SLOT;
+    const long long p0 = ((long long)m_lane + (long long)i_tile * lanes_m) * G1_TM;
+    const int k0 = i_k * 64;
+#pragma unroll
+    for (int it = 0; it < G1_A_OPS; ++it) {
+      const int piece = wave + it * G1_NW;
+      const long long p = p0 + piece * 8 + prow;
+      const bf16_t* src = p < g.M ? a + p * g.K + chunk * 8 + k0 : zero + chunk * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
     }
 #pragma unroll
-  for (int mi = 0; mi < G1_MI; ++mi) {
-    const long long p = p0 + wm * G1_WM + mi * 16 + l15;
-    if (p >= g.M) continue;
-    bf16_t* orow = out + p * g.N;
-    const bf16_t* rrow = e.res ? e.res + p * g.N : nullptr;
+    for (int it = 0; it < B_OPS; ++it) {
+      const int piece = wave + it * G1_NW;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + b_off[it] + k0),
+                                       (__attribute__((address_space(3))) void*)(slot + G1_A_BYTES + piece * 1024), 16,
+                                       0, 0);
+    }
+    if (++i_k == KS) i_k = 0, ++i_tile;
+  };
+
+  g1_f32x4 acc[G1_MI][NI];
 #pragma unroll
-    for (int ni = 0; ni < G1_NI; ++ni) {
-      const int o = ob + 16 * ni;
-      if (o >= g.N) continue;               // (N % 32 == 0 and quads start at multiples of 4: inside or outside as a whole)
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rrow) r = ld4(rrow + o);
-      float v[4];
-      v[0] = acc[mi][ni][0] * sc[ni][0] + sh[ni][0] + r.x;
-      v[1] = acc[mi][ni][1] * sc[ni][1] + sh[ni][1] + r.y;
-      v[2] = acc[mi][ni][2] * sc[ni][2] + sh[ni][2] + r.z;
-      v[3] = acc[mi][ni][3] * sc[ni][3] + sh[ni][3] + r.w;
-      if (e.relu) {
+  for (int mi = 0; mi < G1_MI; ++mi)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[mi][ni][k] = 0.f;
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  // fragment addresses: position row = wm * 64 + mi * 16 + (lane & 15), weight row = wn * 16 NI + ni * 16 + (lane & 15);
+  // 16-byte slot (4 ks + (lane >> 4)) ^ (row & 7): every row offset above is 0 mod 8, 4 ks is bit 2 of the slot: one
+  // base per lane, XOR 64 for the second k-32 sub-step, + mi * 2048 / ni * 2048
+  const unsigned a_lane = (unsigned)((wm * 64 + l15) * 128 + ((q4 ^ (l15 & 7)) << 4));
+  const unsigned b_lane = (unsigned)(G1_A_BYTES + (wn * 16 * NI + l15) * 128 + ((q4 ^ (l15 & 7)) << 4));
+  g1_u32x4 fa[2][G1_MI], fb[2][NI];
+  constexpr int NR = G1_MI + NI;                    // fragment reads of a sub-step, in the order B0, A0 .. A3, B1 ..
+  auto read_frag = [&](int buf, int idx, unsigned ab, unsigned bb) {
+    if (idx == 0) g1_lds_read(fb[buf][0], bb);
+    else if (idx <= G1_MI) g1_lds_read(fa[buf][idx - 1], ab + (idx - 1) * 2048);
+    else g1_lds_read(fb[buf][idx - G1_MI], bb + (idx - G1_MI) * 2048);
+  };
+  // One sub-step (k = 32): MI * NI MFMAs (weight-fragment major) on register set `cur`, whose NR reads were all ISSUED
+  // during the previous sub-step; with `more`, the NR reads of the next sub-step go out one per MFMA into the other set.
+  // LDS reads return in issue order: MFMA j needs the first mi + 2 reads of its set (ni == 0) or the first MI + ni + 1;
+  // outstanding may be NR - needed + (next-set reads issued so far).
+  auto substep = [&](auto cur_c, auto more_c, unsigned ab, unsigned bb) {
+    constexpr int CUR = decltype(cur_c)::value;
+    constexpr bool MORE = decltype(more_c)::value;
+#pragma unroll
+    for (int j = 0; j < G1_MI * NI; ++j) {
+      const int ni = j / G1_MI, mi = j - ni * G1_MI;
+      if (MORE && j < NR) read_frag(1 - CUR, j, ab, bb);
+      if (ni == 0 || mi == 0) {
+        const int needed = ni == 0 ? mi + 2 : G1_MI + ni + 1;
+        const int issued_next = MORE ? (j + 1 < NR ? j + 1 : NR) : 0;
+        g1_wait_lgkm_n(NR - needed + issued_next);
       }
-      st4(orow + o, make_float4(v[0], v[1], v[2], v[3]));
+      if (ni == 0) g1_landed(fa[CUR][mi]);
+      if (mi == 0) g1_landed(fb[CUR][ni]);
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g1_bf16x8, fb[CUR][ni]),
+                                                            __builtin_bit_cast(g1_bf16x8, fa[CUR][mi]), acc[mi][ni], 0,
+                                                            0, 0);
     }
+  };
+  using C0 = g1_const<int, 0>;
+  using C1 = g1_const<int, 1>;
+  using BT = g1_const<bool, true>;
+  using BF = g1_const<bool, false>;
+
+  // ---- the flat step loop.  Vector-memory operations of a wave, in issue order, per step i:
+  //   [R residual loads, if i ends a tile] -> [A + B LDS-DMA of step i + 2, if it exists] -> (MFMAs) -> [E stores, if i
+  //   ends a tile].  They complete in that order, so "tile s has landed" = all but the N youngest are done, with
+  //   N = (stores of step s - 2) + (residual loads + stores of step s - 1) + (DMA of step s + 1).
+  issue(0);
+  if (S > 1) issue(1);
+  g1_u32x4 rres[RES ? E_OPS : 1];
+  int t_idx = 0, k_idx = 0;                        // tile / K step of the current step
+  bool end1 = false, end2 = false;                 // did step s - 1 / s - 2 end a tile?
+  for (int s = 0; s < S; ++s) {
+    const bool last_k = k_idx == KS - 1;
+    g1_wait_vm_n((s + 1 < S ? AB_OPS : 0) + (end2 ? E_OPS : 0) + (end1 ? R_OPS + E_OPS : 0));
+    g1_barrier();
+    const long long p_tile = ((long long)m_lane + (long long)t_idx * lanes_m) * G1_TM;
+    // epilogue geometry of this lane: position rows p_tile + wm * 64 + mi * 16 + l15; after the permlane swap pair p
+    // holds channels n_base + wn * 16 NI + 16 (2 p + (q4 & 1)) + 8 (q4 >> 1) + 0..7
+    const int ch0 = wn * 16 * NI + 16 * (q4 & 1) + 8 * (q4 >> 1);
+    if (RES && last_k) {
+#pragma unroll
+      for (int mi = 0; mi < G1_MI; ++mi) {
+        const long long p = min(p_tile + wm * 64 + mi * 16 + l15, g.M - 1);
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+          g1_load16(rres[RES ? mi * NP + pp : 0], e.res + p * g.N + min(n_base + ch0 + 32 * pp, g.N - 8));
+      }
+    }
+    if (s + 2 < S) issue(s + 2);
+    const unsigned ab = lds_base + (s % G1_STAGES) * SLOT + a_lane, bb = lds_base + (s % G1_STAGES) * SLOT + b_lane;
+#pragma unroll
+    for (int idx = 0; idx < NR; ++idx) read_frag(0, idx, ab, bb);
+    substep(C0{}, BT{}, ab ^ 64u, bb ^ 64u);
+    substep(C1{}, BF{}, ab, bb);
+    if (last_k) {
+      if (RES) {
+        g1_wait_vm_n(s + 2 < S ? AB_OPS : 0);      // the residual loads are older than the DMA issued above
+#pragma unroll
+        for (int r = 0; r < E_OPS; ++r) g1_landed(rres[RES ? r : 0]);
+      }
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const int c = ch0 + 32 * pp;
+        // (table reads in inline asm: an ordinary LDS load beside outstanding LDS-DMA makes the compiler drain the queue)
+        g1_u32x4 s_lo, s_hi, t_lo, t_hi;
+        const unsigned tb = lds_base + TAB + c * 4;
+        g1_lds_read(s_lo, tb), g1_lds_read(s_hi, tb + 16), g1_lds_read(t_lo, tb + TN * 4), g1_lds_read(t_hi, tb + TN * 4 + 16);
+        g1_wait_lgkm<0>();
+        g1_landed(s_lo), g1_landed(s_hi), g1_landed(t_lo), g1_landed(t_hi);
+        float sc[8], sh[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sc[k] = __uint_as_float(s_lo[k]), sc[4 + k] = __uint_as_float(s_hi[k]);
+          sh[k] = __uint_as_float(t_lo[k]), sh[4 + k] = __uint_as_float(t_hi[k]);
+        }
+        const bool in_n = n_base + c < g.N;         // (N % 32 == 0 and c % 8 == 0: inside or outside as a whole)
+#pragma unroll
+        for (int mi = 0; mi < G1_MI; ++mi) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float x = acc[mi][2 * pp][k], y = acc[mi][2 * pp + 1][k];
+            g1_swap16(x, y);
+            v[k] = x, v[4 + k] = y;
+            acc[mi][2 * pp][k] = 0.f, acc[mi][2 * pp + 1][k] = 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
+          if (RES) {
+            const g1_u32x4 r = rres[RES ? mi * NP + pp : 0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[2 * k] += __uint_as_float(r[k] << 16);
+              v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u);
+            }
+          }
+          if (e.relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+          }
+          const long long p = p_tile + wm * 64 + mi * 16 + l15;
+          if (p < g.M && in_n) {
+            uint4 o;
+            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+            o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+            *reinterpret_cast<uint4*>(out + p * g.N + n_base + c) = o;
+          }
+        }
+      }
+    }
+    end2 = end1, end1 = last_k;
+    if (++k_idx == KS) k_idx = 0, ++t_idx;
   }
 }
 
@@ -272,9 +344,24 @@ extern "C" int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* 
   if (!x || !weight || !out || ((running_mean == nullptr) != (running_var == nullptr))) return RSDET_EINVAL;
   G1Geom g{M, N, K};
   G1Epi e{running_mean, running_var, gamma, beta, eps, (const bf16_t*)residual, relu};
-  const int m_tiles = (int)((M + G1_TM - 1) / G1_TM), n_tiles = (N + G1_TN - 1) / G1_TN;
-  const dim3 grid((unsigned)rsdet_xcd_band_grid(m_tiles, n_tiles));
-  hipLaunchKernelGGL(gemm1x1_bn_act_mfma_bf16_kernel, grid, dim3(64 * G1_NW), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)weight, g, e, m_tiles, n_tiles, (bf16_t*)out);
+  const int m_tiles = (int)((M + G1_TM - 1) / G1_TM);
+  // N tile: 256 channels where N fills it AND that still leaves ~a workgroup per CU (row tiles x panels), else 128
+  const int ni = ((N % 256 == 0 || N > 1024) && (long long)m_tiles * ((N + 255) / 256) >= 192) ? 4 : 2;
+  const int tn = 64 * ni, n_tiles = (N + tn - 1) / tn;
+  // persistent grid: 8 XCD groups x n_tiles panels x mm row lanes per XCD, ~256 workgroups in all
+  int mm = 256 / (8 * n_tiles);
+  if (mm < 1) mm = 1;
+  const int need = (m_tiles + 7) / 8;
+  if (mm > need) mm = need;
+  const dim3 grid((unsigned)(8 * n_tiles * mm));
+#define G1_LAUNCH(NI_, RES_)                                                                                       \
+  hipLaunchKernelGGL((gemm1x1_bn_act_mfma_bf16_kernel<NI_, RES_>), grid, dim3(64 * G1_NW), 0, (hipStream_t)stream, \
+                     (const bf16_t*)x, (const bf16_t*)weight, g, e, m_tiles, n_tiles, (bf16_t*)out)
+  if (ni == 4) {
+    if (residual) G1_LAUNCH(4, true); else G1_LAUNCH(4, false);
+  } else {
+    if (residual) G1_LAUNCH(2, true); else G1_LAUNCH(2, false);
+  }
+#undef G1_LAUNCH
   return rsdet_launch_status();
 }

@@ -97,5 +97,9 @@ def test_fused_form_tracks_the_two_launch_form_through_a_bottleneck(cuda):
             outs.append([y.detach().float(), xi.grad.float()] + [p.grad.float() for p in blk.parameters()])
         finally:
             conv_bn._ON = True
-    for a, b in zip(*outs):
-        assert _rel(a, b) <= 3e-2, _rel(a, b)
+    # outputs: bf16 resolution.  Gradients: the two forms round the pre-activation differently, so the ReLU gates of the
+    # few elements within a rounding of zero differ -- each such element moves its gradient by 100 % (measured: 6 % of the
+    # gradient norm for ~0.4 % flipped gates); the per-operation test above compares gradients under ONE gate
+    assert _rel(outs[0][0], outs[1][0]) <= 3e-2
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert _rel(a, b) <= 0.12, _rel(a, b)
