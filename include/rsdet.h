@@ -384,6 +384,10 @@ int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* weight, lon
                                   const float* running_mean, const float* running_var, const float* gamma,
                                   const float* beta, float eps, const uint16_t* residual, int relu, uint16_t* out,
                                   void* stream);
+/* out[i] = sum_s partial[s][i], fp32 sums in slab order, stored fp32 or rounded once to bf16 (out_bf16): the fold of the
+ * split-K 1x1 weight gradient (ops/conv1x1.py; the reference's cuDNN weight gradient, resnet.py:101-126 backward).
+ * n % 4 == 0. */
+int rsdet_sum_slabs_f32(const float* partial, int S, long long n, void* out, int out_bf16, void* stream);
 int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
                                           const float* running_var, const float* weight, const float* bias, float eps,
                                           int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,

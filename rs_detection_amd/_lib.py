@@ -38,6 +38,7 @@ SIGNATURES = {
     "rsdet_box_iou_rotated_fast_rows_per_tile": (c_int, []),
     "rsdet_box_iou_rotated_fast_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_sum_slabs_f32": (c_int, [c_void_p, c_int, c_ll, c_void_p, c_int, c_void_p]),
     "rsdet_gemm1x1_mfma_supported": (c_int, [c_ll, c_int, c_int]),
     "rsdet_conv1x1_bn_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),

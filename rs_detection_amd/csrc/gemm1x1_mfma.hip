@@ -323,9 +323,36 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   }
 }
 
+// out[i] = sum_s partial[s][i] in slab order (fp32 sums), written as fp32 or rounded ONCE to bf16: the fold of a split-K
+// product (the 1x1 weight gradients of ops/conv1x1.py: S partial (O, C) products of a batched GEMM).  One thread per 4.
+template <typename T>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ partial, int S, long long n,
+                                                        T* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (long long)s * n + i);
+    acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+  }
+  st4(out + i, acc);
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
+
+extern "C" int rsdet_sum_slabs_f32(const float* partial, int S, long long n, void* out, int out_bf16, void* stream) {
+  if (S < 1 || n < 0 || (n & 3)) return RSDET_EINVAL;
+  if (n == 0) return RSDET_OK;
+  if (!partial || !out) return RSDET_EINVAL;
+  const dim3 grid((unsigned)((n / 4 + 255) / 256));
+  if (out_bf16)
+    hipLaunchKernelGGL((sum_slabs_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, n, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL((sum_slabs_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, n, (float*)out);
+  return rsdet_launch_status();
+}
 
 extern "C" int rsdet_gemm1x1_mfma_supported(long long M, int N, int K) {
   if (M < 1 || N < 32 || (N & 31) || K < 64 || (K & 63)) return 0;

@@ -45,6 +45,15 @@ def _wrw_split_k(gy2, x, w):
         return torch.mm(gy2.t(), x2).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
     a, b = gy2.view(S, P // S, O).transpose(1, 2), x2.view(S, P // S, C)
     part = torch.bmm(a, b, out_dtype=torch.float32) if x.dtype == torch.bfloat16 else torch.bmm(a, b)
+    if part.dtype == torch.float32 and (O * C) % 4 == 0:
+        # fold of the S fp32 partial products as one pass of our own (fp32 sums, one rounding, written in the weight's
+        # channels_last storage = the (O, C) matrix) instead of a reduction launch + a cast launch
+        from .. import _lib
+        gw = torch.empty((O, C, 1, 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        rc = _lib.load().rsdet_sum_slabs_f32(_lib.ptr(part), S, O * C, _lib.ptr(gw), int(x.dtype == torch.bfloat16),
+                                             _lib.stream_ptr())
+        _lib.check(rc, "rsdet_sum_slabs_f32")
+        return gw
     return part.sum(0).to(x.dtype).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
 
 
