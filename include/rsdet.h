@@ -388,6 +388,30 @@ int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* weight, lon
  * split-K 1x1 weight gradient (ops/conv1x1.py; the reference's cuDNN weight gradient, resnet.py:101-126 backward).
  * n % 4 == 0. */
 int rsdet_sum_slabs_f32(const float* partial, int S, long long n, void* out, int out_bf16, void* stream);
+/* ... with row r of the (n / row_len, row_len) result multiplied by gamma[r] / sqrt(running_var[r] + eps) before the
+ * rounding: the weight gradient of a convolution that feeds an eval-mode BatchNorm, formed from the gradient of the
+ * BatchNorm's OUTPUT (ops/bottleneck.py).  row_len % 4 == 0, n % row_len == 0; gamma NULL: 1. */
+int rsdet_sum_slabs_rowscale_f32(const float* partial, int S, long long n, int row_len, const float* running_var,
+                                 const float* gamma, float eps, void* out, int out_bf16, void* stream);
+/* out (C, O) = transpose of weight (O, C), column o scaled by gamma[o] / sqrt(running_var[o] + eps) (running_var NULL:
+ * plain transpose): the weight operand of rsdet_conv1x1_dgrad_bf16. */
+int rsdet_weight_transpose_scale_bf16(const uint16_t* weight, int O, int C, const float* running_var, const float* gamma,
+                                      float eps, uint16_t* out, void* stream);
+/* Backward-data of a 1x1 convolution through the streaming GEMM of rsdet_conv1x1_bn_act_fwd_bf16, with the NEXT backward
+ * step of the Bottleneck (/root/reference/python/jdet/models/backbones/resnet.py:57-93, backward of :80-91) in its
+ * epilogue: grad_in[p, c] = epi(sum_o grad_out[p, o] wt[c, o]); grad_out (M, O), wt (C, O), grad_in / side (M, C) bf16.
+ *   mode 0: identity.
+ *   mode 2: the convolution's input was side = relu(bn(.)) of an eval-mode BatchNorm over its C channels (running_var,
+ *           gamma, beta): grad_in = [side > 0] acc gamma / sqrt(var + eps) -- the gradient of THAT BatchNorm's input --
+ *           grad_beta[c] = sum_p [side > 0] acc, grad_gamma[c] = sum_p [side > 0] acc (side - beta) / gamma (either NULL:
+ *           not formed; ws of rsdet_conv1x1_dgrad_ws_size bytes when one is wanted).
+ *   mode 3: grad_in = acc + side (the gradient arriving through the identity branch).
+ * C % 32 == 0, O % 64 == 0 (rsdet_gemm1x1_mfma_supported(M, C, O)). */
+size_t rsdet_conv1x1_dgrad_ws_size(long long M, int C, int O);
+int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t* wt, long long M, int C, int O, int mode,
+                             const uint16_t* side, const float* running_var, const float* gamma, const float* beta,
+                             float eps, float* grad_gamma, float* grad_beta, void* ws, size_t ws_bytes,
+                             uint16_t* grad_in, void* stream);
 int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
                                           const float* running_var, const float* weight, const float* bias, float eps,
                                           int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,

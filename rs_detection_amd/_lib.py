@@ -40,6 +40,13 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rsdet_sum_slabs_f32": (c_int, [c_void_p, c_int, c_ll, c_void_p, c_int, c_void_p]),
     "rsdet_gemm1x1_mfma_supported": (c_int, [c_ll, c_int, c_int]),
+    "rsdet_sum_slabs_rowscale_f32": (c_int, [c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                                             c_void_p]),
+    "rsdet_weight_transpose_scale_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                                                  c_void_p]),
+    "rsdet_conv1x1_dgrad_ws_size": (c_size_t, [c_ll, c_int, c_int]),
+    "rsdet_conv1x1_dgrad_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "rsdet_conv1x1_bn_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "rsdet_bn_act_backward_nhwc_fromy_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -57,9 +57,17 @@ struct G1Epi {
   const float* gamma;
   const float* beta;     // with mean == null: a plain bias
   float eps;
-  const bf16_t* res;     // [M][N] residual added before the activation (RES kernels), or null
+  const bf16_t* res;     // [M][N] side operand: EPI 1 the residual added before the activation; EPI 2 the tensor whose
+                         //   sign gates the result (y > 0); EPI 3 an addend
   int relu;
+  float* partial;        // EPI 2: [(n * S + slice) * 2 + {0, 1}] per-workgroup sums of the gated value and of
+  int slices;            //   gated value * (y - beta) / gamma (csrc/bn_act.hip's finish kernel folds them), or null
 };
+// EPI: 0 = forward, no side operand; 1 = forward + residual;
+//      2 = backward-data INTO a BatchNorm + ReLU: out = (acc * [side > 0]) * scale, scale = gamma / sqrt(var + eps) of
+//          THAT BatchNorm (mean unused), sums for its beta / gamma gradients with xhat = (side - beta) / gamma;
+//      3 = backward-data + addend: out = acc + side (the identity branch's gradient).
+constexpr int G1_FWD = 0, G1_FWD_RES = 1, G1_BWD_GATE = 2, G1_BWD_ADD = 3;
 
 template <int N>
 __device__ __forceinline__ void g1_wait_vm() {
@@ -109,21 +117,28 @@ struct g1_const {
 // persistent grid of 8 * n_tiles * mm workgroups (host: ~one per CU); workgroup id -> (XCD x, slot): column panel
 // n = slot % n_tiles, row lane = (slot / n_tiles) * 8 + x -- the workgroups that stream the SAME rows sit on one XCD
 // (ids x, x + 8, ...: round-robin placement; speed only) and share the rows in its L2.
-template <int NI, bool RES>
+template <int NI, int EPI>
 __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel(
     const bf16_t* __restrict__ a, const bf16_t* __restrict__ w, G1Geom g, G1Epi e, int m_tiles, int n_tiles,
     bf16_t* __restrict__ out) {
   constexpr int TN = 64 * NI, B_BYTES = TN * 128, SLOT = G1_A_BYTES + B_BYTES, B_OPS = B_BYTES / 1024 / G1_NW;
+  constexpr bool RES = EPI != G1_FWD;              // a 16-byte side operand per output chunk
   constexpr int NP = NI / 2;                       // fragment pairs of a wave = 16-byte stores per position
   constexpr int E_OPS = G1_MI * NP, R_OPS = RES ? E_OPS : 0, AB_OPS = G1_A_OPS + B_OPS;
-  constexpr int TAB = G1_STAGES * SLOT;            // scale / shift table behind the ring (ONE shared array: a second
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[TAB + TN * 8];   // one would drain the DMA queue, guide 5.4(a))
+  constexpr int TAB = G1_STAGES * SLOT;            // per-channel tables behind the ring (ONE shared array: a second
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[TAB + TN * 16];  // one would drain the DMA queue, guide 5.4(a))
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xcd = (int)(blockIdx.x & 7u), slot_id = (int)(blockIdx.x >> 3);
   const int n_t = slot_id % n_tiles, lanes_m = (int)(gridDim.x >> 3) / n_tiles * 8;
   const int m_lane = (slot_id / n_tiles) * 8 + xcd;
-  if (m_lane >= m_tiles) return;
+  if (m_lane >= m_tiles) {                          // an idle row lane still owns a slice of the sums: zeros
+    if (EPI == G1_BWD_GATE && e.partial)
+      for (int c = tid; c < TN; c += 64 * G1_NW)
+        if (n_t * TN + c < g.N)
+          *reinterpret_cast<float2*>(e.partial + ((long long)(n_t * TN + c) * e.slices + m_lane) * 2) = make_float2(0.f, 0.f);
+    return;
+  }
   const int my_tiles = (m_tiles - m_lane + lanes_m - 1) / lanes_m;
   const int KS = g.K >> 6, S = my_tiles * KS;
   const int n_base = n_t * TN;
@@ -131,20 +146,28 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   const int prow = lane >> 3;                       // row of the lane inside a 1 KiB piece = (LDS row) & 7
   const int chunk = (lane & 7) ^ prow;              // the source chunk that belongs in the lane's slot
 
-  // ---- scale / shift table (fp32, TN + TN) in LDS
+  // ---- per-channel tables (fp32) in LDS: [0] scale, [1] shift (forward) or beta (EPI 2), [2] 1 / gamma (EPI 2)
   {
     float* tab = reinterpret_cast<float*>(lds + TAB);
     for (int c = tid; c < TN; c += 64 * G1_NW) {
       const int o = min(n_base + c, g.N - 1);
-      float s1 = 1.f, t1 = 0.f;
-      if (e.mean) {
+      float s1 = 1.f, t1 = 0.f, ig = 1.f;
+      if (EPI == G1_BWD_GATE) {
+        if (e.var) s1 = 1.0f / sqrtf(e.var[o] + e.eps);
+        if (e.gamma) {
+          const float gm = e.gamma[o];
+          s1 *= gm;
+          ig = gm != 0.f ? 1.0f / gm : 0.f;
+        }
+        if (e.beta) t1 = e.beta[o];
+      } else if (e.mean) {
         const float is = 1.0f / sqrtf(e.var[o] + e.eps);
         s1 = e.gamma ? is * e.gamma[o] : is;
         t1 = (e.beta ? e.beta[o] : 0.f) - e.mean[o] * s1;
       } else if (e.beta) {
         t1 = e.beta[o];
       }
-      tab[c] = s1, tab[TN + c] = t1;
+      tab[c] = s1, tab[TN + c] = t1, tab[2 * TN + c] = ig;
     }
   }
   long long b_off[B_OPS];
@@ -235,6 +258,11 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   issue(0);
   if (S > 1) issue(1);
   g1_u32x4 rres[RES ? E_OPS : 1];
+  float sum1[EPI == G1_BWD_GATE ? NP : 1][8], sum2[EPI == G1_BWD_GATE ? NP : 1][8];   // EPI 2: this lane's running sums
+#pragma unroll
+  for (int pp = 0; pp < (EPI == G1_BWD_GATE ? NP : 1); ++pp)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum1[pp][k] = 0.f, sum2[pp][k] = 0.f;
   int t_idx = 0, k_idx = 0;                        // tile / K step of the current step
   bool end1 = false, end2 = false;                 // did step s - 1 / s - 2 end a tile?
   for (int s = 0; s < S; ++s) {
@@ -270,16 +298,20 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
       for (int pp = 0; pp < NP; ++pp) {
         const int c = ch0 + 32 * pp;
         // (table reads in inline asm: an ordinary LDS load beside outstanding LDS-DMA makes the compiler drain the queue)
-        g1_u32x4 s_lo, s_hi, t_lo, t_hi;
+        g1_u32x4 s_lo, s_hi, t_lo, t_hi, g_lo, g_hi;
         const unsigned tb = lds_base + TAB + c * 4;
         g1_lds_read(s_lo, tb), g1_lds_read(s_hi, tb + 16), g1_lds_read(t_lo, tb + TN * 4), g1_lds_read(t_hi, tb + TN * 4 + 16);
+        if (EPI == G1_BWD_GATE) g1_lds_read(g_lo, tb + TN * 8), g1_lds_read(g_hi, tb + TN * 8 + 16);
         g1_wait_lgkm<0>();
         g1_landed(s_lo), g1_landed(s_hi), g1_landed(t_lo), g1_landed(t_hi);
-        float sc[8], sh[8];
+        if (EPI == G1_BWD_GATE) g1_landed(g_lo), g1_landed(g_hi);
+        float sc[8], sh[8], ig[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           sc[k] = __uint_as_float(s_lo[k]), sc[4 + k] = __uint_as_float(s_hi[k]);
           sh[k] = __uint_as_float(t_lo[k]), sh[4 + k] = __uint_as_float(t_hi[k]);
+          ig[k] = EPI == G1_BWD_GATE ? __uint_as_float(g_lo[k]) : 1.f;
+          ig[4 + k] = EPI == G1_BWD_GATE ? __uint_as_float(g_hi[k]) : 1.f;
         }
         const bool in_n = n_base + c < g.N;         // (N % 32 == 0 and c % 8 == 0: inside or outside as a whole)
 #pragma unroll
@@ -292,21 +324,40 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
             v[k] = x, v[4 + k] = y;
             acc[mi][2 * pp][k] = 0.f, acc[mi][2 * pp + 1][k] = 0.f;
           }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
+          float side[8];
           if (RES) {
             const g1_u32x4 r = rres[RES ? mi * NP + pp : 0];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              v[2 * k] += __uint_as_float(r[k] << 16);
-              v[2 * k + 1] += __uint_as_float(r[k] & 0xffff0000u);
+              side[2 * k] = __uint_as_float(r[k] << 16);
+              side[2 * k + 1] = __uint_as_float(r[k] & 0xffff0000u);
             }
           }
-          if (e.relu) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-          }
           const long long p = p_tile + wm * 64 + mi * 16 + l15;
+          if (EPI == G1_BWD_GATE) {
+            const bool row_ok = p < g.M;            // (rows past the end carry a clamped side operand: keep them out of the sums)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float gz = (side[k] > 0.f && row_ok) ? v[k] : 0.f;
+              sum1[pp][k] += gz;
+              sum2[pp][k] = __builtin_fmaf(gz, (side[k] - sh[k]) * ig[k], sum2[pp][k]);
+              v[k] = gz * sc[k];
+            }
+          } else if (EPI == G1_BWD_ADD) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += side[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sh[k]);
+            if (RES) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[k] += side[k];
+            }
+            if (e.relu) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+          }
           if (p < g.M && in_n) {
             uint4 o;
             o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
@@ -321,13 +372,44 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
     end2 = end1, end1 = last_k;
     if (++k_idx == KS) k_idx = 0, ++t_idx;
   }
+  if (EPI == G1_BWD_GATE && e.partial) {
+    // this workgroup's sums over all its rows: lanes l15 = 0..15 of a 16-lane row hold different positions of the same
+    // 8 channels -> butterfly over the row; the two position halves (wm) meet in LDS (the ring is idle now); fixed order
+    g1_wait_vm<0>();
+    g1_barrier();
+    float* red = reinterpret_cast<float*>(lds);                        // [wm][TN][2]
+    const int ch0 = wn * 16 * NI + 16 * (q4 & 1) + 8 * (q4 >> 1);
+#pragma unroll
+    for (int pp = 0; pp < (EPI == G1_BWD_GATE ? NP : 1); ++pp)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float a1 = sum1[pp][k], a2 = sum2[pp][k];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) a1 += __shfl_xor(a1, off), a2 += __shfl_xor(a2, off);
+        if (l15 == 0) {
+          red[(wm * TN + ch0 + 32 * pp + k) * 2 + 0] = a1;
+          red[(wm * TN + ch0 + 32 * pp + k) * 2 + 1] = a2;
+        }
+      }
+    __syncthreads();
+    const int slice = (slot_id / n_tiles) * 8 + xcd;                   // = m_lane: the row lanes of this column panel
+    for (int c = tid; c < TN; c += 64 * G1_NW)
+      if (n_base + c < g.N) {
+        e.partial[((long long)(n_base + c) * e.slices + slice) * 2 + 0] = red[c * 2] + red[(TN + c) * 2];
+        e.partial[((long long)(n_base + c) * e.slices + slice) * 2 + 1] = red[c * 2 + 1] + red[(TN + c) * 2 + 1];
+      }
+  }
 }
 
 // out[i] = sum_s partial[s][i] in slab order (fp32 sums), written as fp32 or rounded ONCE to bf16: the fold of a split-K
 // product (the 1x1 weight gradients of ops/conv1x1.py: S partial (O, C) products of a batched GEMM).  One thread per 4.
+// With `var`: row r = i / row_len of the result is multiplied by gamma[r] / sqrt(var[r] + eps) (gamma NULL = 1) before
+// the rounding -- the weight gradient of a convolution whose OUTPUT feeds an eval-mode BatchNorm, formed from the
+// gradient of the BatchNorm's output (the scale commutes with the sum over positions).
 template <typename T>
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ partial, int S, long long n,
-                                                        T* __restrict__ out) {
+                                                        T* __restrict__ out, const float* __restrict__ var,
+                                                        const float* __restrict__ gamma, float eps, int row_len) {
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -335,22 +417,105 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     const float4 v = *reinterpret_cast<const float4*>(partial + (long long)s * n + i);
     acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
   }
+  if (var) {                                         // (row_len % 4 == 0: the four values share a row)
+    const int r = (int)(i / row_len);
+    float sc = 1.0f / sqrtf(var[r] + eps);
+    if (gamma) sc *= gamma[r];
+    acc.x *= sc, acc.y *= sc, acc.z *= sc, acc.w *= sc;
+  }
   st4(out + i, acc);
+}
+
+// out[c][o] = w[o][c] * scale[o], scale[o] = gamma[o] / sqrt(var[o] + eps) (var NULL: 1): the (C, O) operand of the
+// backward-data GEMM of a 1x1 convolution (O, C) whose output feeds an eval-mode BatchNorm -- the BatchNorm's backward
+// scale rides in the weights, so the GEMM reads the gradient of the BatchNorm's OUTPUT.  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void weight_transpose_scale_kernel(const bf16_t* __restrict__ w, int O, int C,
+                                                                     const float* __restrict__ var,
+                                                                     const float* __restrict__ gamma, float eps,
+                                                                     bf16_t* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = o0 + ty + 8 * j, c = c0 + tx;
+    float v = 0.f;
+    if (o < O && c < C) {
+      v = bf2f(w[(long long)o * C + c]);
+      if (var) {
+        float sc = 1.0f / sqrtf(var[o] + eps);
+        if (gamma) sc *= gamma[o];
+        v *= sc;
+      }
+    }
+    tile[ty + 8 * j][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, o = o0 + tx;
+    if (o < O && c < C) out[(long long)c * O + o] = f2bf(tile[tx][ty + 8 * j]);
+  }
+}
+
+// (C, S, 2) partial sums -> dbias[c] = sum_s [0], dweight[c] = sum_s [1]; one wave per channel, fixed order (the twin of
+// csrc/bn_act.hip's bn_act_bwd_finish_kernel for the sums the backward-data epilogue leaves)
+__global__ __launch_bounds__(256) void g1_sums_finish_kernel(const float* __restrict__ partial, int C, int S,
+                                                             float* __restrict__ dweight, float* __restrict__ dbias) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float2 p = *reinterpret_cast<const float2*>(partial + ((long long)c * S + s) * 2);
+    a += p.x, b += p.y;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off), b += __shfl_down(b, off);
+  if (lane == 0) {
+    if (dbias) dbias[c] = a;
+    if (dweight) dweight[c] = b;
+  }
 }
 
 }  // namespace rsdet
 
 using namespace rsdet;
 
-extern "C" int rsdet_sum_slabs_f32(const float* partial, int S, long long n, void* out, int out_bf16, void* stream) {
+static int sum_slabs_launch(const float* partial, int S, long long n, void* out, int out_bf16, const float* var,
+                            const float* gamma, float eps, int row_len, void* stream) {
   if (S < 1 || n < 0 || (n & 3)) return RSDET_EINVAL;
+  if (var && (row_len < 4 || (row_len & 3) || n % row_len)) return RSDET_EINVAL;
   if (n == 0) return RSDET_OK;
   if (!partial || !out) return RSDET_EINVAL;
   const dim3 grid((unsigned)((n / 4 + 255) / 256));
   if (out_bf16)
-    hipLaunchKernelGGL((sum_slabs_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, n, (bf16_t*)out);
+    hipLaunchKernelGGL((sum_slabs_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, n, (bf16_t*)out,
+                       var, gamma, eps, row_len);
   else
-    hipLaunchKernelGGL((sum_slabs_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, n, (float*)out);
+    hipLaunchKernelGGL((sum_slabs_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, n, (float*)out,
+                       var, gamma, eps, row_len);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_sum_slabs_f32(const float* partial, int S, long long n, void* out, int out_bf16, void* stream) {
+  return sum_slabs_launch(partial, S, n, out, out_bf16, nullptr, nullptr, 0.f, 4, stream);
+}
+
+// the same with row r of the (n / row_len, row_len) result scaled by gamma[r] / sqrt(running_var[r] + eps)
+extern "C" int rsdet_sum_slabs_rowscale_f32(const float* partial, int S, long long n, int row_len,
+                                            const float* running_var, const float* gamma, float eps, void* out,
+                                            int out_bf16, void* stream) {
+  if (!running_var) return RSDET_EINVAL;
+  return sum_slabs_launch(partial, S, n, out, out_bf16, running_var, gamma, eps, row_len, stream);
+}
+
+// out (C, O) = transpose(weight (O, C)) with column o scaled by gamma[o] / sqrt(running_var[o] + eps) (running_var NULL:
+// plain transpose) -- the weight operand of rsdet_conv1x1_dgrad_bf16
+extern "C" int rsdet_weight_transpose_scale_bf16(const uint16_t* weight, int O, int C, const float* running_var,
+                                                 const float* gamma, float eps, uint16_t* out, void* stream) {
+  if (O < 1 || C < 1 || !weight || !out) return RSDET_EINVAL;
+  hipLaunchKernelGGL(weight_transpose_scale_kernel, dim3((C + 31) / 32, (O + 31) / 32), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)weight, O, C, running_var, gamma, eps, (bf16_t*)out);
   return rsdet_launch_status();
 }
 
@@ -359,6 +524,31 @@ extern "C" int rsdet_gemm1x1_mfma_supported(long long M, int N, int K) {
   if (M * (long long)(N > K ? N : K) >= (1ll << 40)) return 0;
   return 1;
 }
+
+// the persistent grid of one launch: 8 XCD groups x n_tiles column panels x mm row lanes per XCD, ~256 workgroups
+struct G1Grid {
+  int ni, m_tiles, n_tiles, mm;
+  unsigned blocks() const { return (unsigned)(8 * n_tiles * mm); }
+  int row_lanes() const { return 8 * mm; }
+};
+static G1Grid g1_grid(long long M, int N, bool narrow_only) {
+  G1Grid r;
+  r.m_tiles = (int)((M + G1_TM - 1) / G1_TM);
+  // N tile: 256 channels where N fills it AND that still leaves ~a workgroup per CU (row tiles x panels), else 128
+  r.ni = (!narrow_only && (N % 256 == 0 || N > 1024) && (long long)r.m_tiles * ((N + 255) / 256) >= 192) ? 4 : 2;
+  const int tn = 64 * r.ni;
+  r.n_tiles = (N + tn - 1) / tn;
+  r.mm = 256 / (8 * r.n_tiles);
+  if (r.mm < 1) r.mm = 1;
+  const int need = (r.m_tiles + 7) / 8;
+  if (r.mm > need) r.mm = need;
+  return r;
+}
+
+#define G1_LAUNCH(NI_, EPI_)                                                                                             \
+  hipLaunchKernelGGL((gemm1x1_bn_act_mfma_bf16_kernel<NI_, EPI_>), dim3(gr.blocks()), dim3(64 * G1_NW), 0,                \
+                     (hipStream_t)stream, (const bf16_t*)a_ptr, (const bf16_t*)b_ptr, g, e, gr.m_tiles, gr.n_tiles,       \
+                     (bf16_t*)out)
 
 // out[p, o] = act((sum_c x[p, c] weight[o, c]) * scale[o] + shift[o] + residual[p, o]),  x (M, K) / weight (N, K) /
 // residual, out (M, N) bf16 row-major; scale / shift from the BatchNorm's running statistics and affine parameters
@@ -370,25 +560,61 @@ extern "C" int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* 
   if (!rsdet_gemm1x1_mfma_supported(M, N, K)) return RSDET_EINVAL;
   if (!x || !weight || !out || ((running_mean == nullptr) != (running_var == nullptr))) return RSDET_EINVAL;
   G1Geom g{M, N, K};
-  G1Epi e{running_mean, running_var, gamma, beta, eps, (const bf16_t*)residual, relu};
-  const int m_tiles = (int)((M + G1_TM - 1) / G1_TM);
-  // N tile: 256 channels where N fills it AND that still leaves ~a workgroup per CU (row tiles x panels), else 128
-  const int ni = ((N % 256 == 0 || N > 1024) && (long long)m_tiles * ((N + 255) / 256) >= 192) ? 4 : 2;
-  const int tn = 64 * ni, n_tiles = (N + tn - 1) / tn;
-  // persistent grid: 8 XCD groups x n_tiles panels x mm row lanes per XCD, ~256 workgroups in all
-  int mm = 256 / (8 * n_tiles);
-  if (mm < 1) mm = 1;
-  const int need = (m_tiles + 7) / 8;
-  if (mm > need) mm = need;
-  const dim3 grid((unsigned)(8 * n_tiles * mm));
-#define G1_LAUNCH(NI_, RES_)                                                                                       \
-  hipLaunchKernelGGL((gemm1x1_bn_act_mfma_bf16_kernel<NI_, RES_>), grid, dim3(64 * G1_NW), 0, (hipStream_t)stream, \
-                     (const bf16_t*)x, (const bf16_t*)weight, g, e, m_tiles, n_tiles, (bf16_t*)out)
-  if (ni == 4) {
-    if (residual) G1_LAUNCH(4, true); else G1_LAUNCH(4, false);
+  G1Epi e{running_mean, running_var, gamma, beta, eps, (const bf16_t*)residual, relu, nullptr, 0};
+  const G1Grid gr = g1_grid(M, N, false);
+  const void *a_ptr = x, *b_ptr = weight;
+  if (gr.ni == 4) {
+    if (residual) G1_LAUNCH(4, G1_FWD_RES); else G1_LAUNCH(4, G1_FWD);
   } else {
-    if (residual) G1_LAUNCH(2, true); else G1_LAUNCH(2, false);
+    if (residual) G1_LAUNCH(2, G1_FWD_RES); else G1_LAUNCH(2, G1_FWD);
   }
-#undef G1_LAUNCH
   return rsdet_launch_status();
 }
+
+// Backward-data of a 1x1 convolution as the same streaming GEMM: grad_in[p, c] = epi(sum_o grad_out[p, o] wt[c, o]),
+// grad_out (M, O), wt (C, O) (rsdet_weight_transpose_scale_bf16), grad_in / side (M, C), all bf16 row-major.
+//   mode 0: epi = identity.
+//   mode 2: the convolution's INPUT was side = relu(bn(.)) of an eval-mode BatchNorm (running_var, gamma, beta of THAT
+//           BatchNorm over the C channels): grad_in = [side > 0] acc gamma / sqrt(var + eps) = the gradient of that
+//           BatchNorm's input; grad_gamma[c] = sum_p [side > 0] acc (side - beta) / gamma, grad_beta[c] = sum_p [side > 0] acc
+//           (either NULL: not formed; both NULL: no workspace needed).
+//   mode 3: grad_in = acc + side (the gradient that reaches the same tensor through the identity branch).
+// ws: rsdet_conv1x1_dgrad_ws_size(M, C, O) bytes for mode 2 with sums.
+extern "C" size_t rsdet_conv1x1_dgrad_ws_size(long long M, int C, int O) {
+  if (!rsdet_gemm1x1_mfma_supported(M, C, O)) return 0;
+  const G1Grid gr = g1_grid(M, C, true);
+  return (size_t)C * gr.row_lanes() * 2 * sizeof(float);
+}
+
+extern "C" int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t* wt, long long M, int C, int O, int mode,
+                                        const uint16_t* side, const float* running_var, const float* gamma,
+                                        const float* beta, float eps, float* grad_gamma, float* grad_beta, void* ws,
+                                        size_t ws_bytes, uint16_t* grad_in, void* stream) {
+  if (!rsdet_gemm1x1_mfma_supported(M, C, O)) return RSDET_EINVAL;
+  if (!grad_out || !wt || !grad_in || (mode != 0 && mode != G1_BWD_GATE && mode != G1_BWD_ADD)) return RSDET_EINVAL;
+  if (mode != 0 && !side) return RSDET_EINVAL;
+  G1Geom g{M, C, O};
+  const void *a_ptr = grad_out, *b_ptr = wt;
+  uint16_t* out = grad_in;
+  if (mode == G1_BWD_GATE) {
+    const bool sums = grad_gamma || grad_beta;
+    if (grad_gamma && (!gamma || !beta)) return RSDET_EINVAL;
+    const G1Grid gr = g1_grid(M, C, true);
+    if (sums && (!ws || ws_bytes < rsdet_conv1x1_dgrad_ws_size(M, C, O))) return RSDET_EINVAL;
+    G1Epi e{nullptr, running_var, gamma, beta, eps, (const bf16_t*)side, 0, sums ? (float*)ws : nullptr, gr.row_lanes()};
+    G1_LAUNCH(2, G1_BWD_GATE);
+    if (sums)
+      hipLaunchKernelGGL(g1_sums_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
+                         gr.row_lanes(), grad_gamma, grad_beta);
+    return rsdet_launch_status();
+  }
+  const G1Grid gr = g1_grid(M, C, false);
+  G1Epi e{nullptr, nullptr, nullptr, nullptr, 0.f, (const bf16_t*)side, 0, nullptr, 0};
+  if (mode == G1_BWD_ADD) {
+    if (gr.ni == 4) G1_LAUNCH(4, G1_BWD_ADD); else G1_LAUNCH(2, G1_BWD_ADD);
+  } else {
+    if (gr.ni == 4) G1_LAUNCH(4, G1_FWD); else G1_LAUNCH(2, G1_FWD);
+  }
+  return rsdet_launch_status();
+}
+#undef G1_LAUNCH

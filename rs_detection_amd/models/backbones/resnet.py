@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from rs_detection_amd.ops.bn_act import bn_act, bn_relu_maxpool
 from rs_detection_amd.ops.conv1x1 import conv1x1
+from rs_detection_amd.ops.bottleneck import bottleneck, bottleneck_applies
 from rs_detection_amd.ops.conv_bn import conv_bn_act
 from rs_detection_amd.ops.conv3x3 import fast_conv
 from rs_detection_amd.utils.registry import BACKBONES
@@ -64,6 +65,9 @@ class Bottleneck(nn.Module):
         # conv1 / conv3 / a stride-1 downsample are 1x1: GEMMs on views when the step runs channels_last (ops/conv1x1.py)
         # in the bf16 channels_last step the 1x1 convolutions take their BatchNorm tail into the GEMM's epilogue: one
         # launch each (ops/conv_bn.py, csrc/gemm1x1_mfma.hip)
+        # an identity block of the bf16 step as ONE autograd node with a hand-ordered backward (ops/bottleneck.py)
+        if bottleneck_applies(self, x):
+            return bottleneck(self, x)
         idt = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
         out = conv_bn_act(self.conv1, self.bn1, x)
         out = bn_act(fast_conv(self.conv2, out), self.bn2)      # stride-1 3x3: backward-data via the forward solver

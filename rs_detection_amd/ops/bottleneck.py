@@ -1,0 +1,206 @@
+"""A whole identity Bottleneck of the bf16 trunk as ONE autograd node with a hand-ordered backward.
+
+The reference block (/root/reference/python/jdet/models/backbones/resnet.py:57-93; forward :80-91) is
+
+    y1 = relu(bn1(conv1(x)));  y2 = relu(bn2(conv2(y1)));  y3 = relu(bn3(conv3(y2)) + x)
+
+with every BatchNorm in eval mode (norm_eval, :177-184).  Round 5's first stage put the BatchNorm tails of the two 1x1
+convolutions into the GEMM's epilogue (ops/conv_bn.py).  With the block as one node the BACKWARD can be ordered by hand,
+and three of its passes over the block's widest tensors disappear:
+
+  * the gradient of conv3's raw output (gz * gamma3 / sqrt(var3 + eps)) is never written: the BatchNorm's scale rides in
+    the transposed weights of the backward-data GEMM and in the fold of the weight gradient, both of which read gz = gy *
+    [y3 > 0] -- which is ALSO the identity branch's gradient, so one tensor serves three consumers;
+  * bn2's backward (gate by y2 > 0, scale, the beta / gamma sums) is the EPILOGUE of conv3's backward-data GEMM
+    (csrc/gemm1x1_mfma.hip, mode 2): conv3's input gradient never reaches memory ungated, conv2's raw output and its ReLU
+    bit mask are not kept for the backward at all;
+  * the sum of the two gradients that reach x (through conv1 and through the identity) is the epilogue of conv1's
+    backward-data GEMM (mode 3) instead of an elementwise pass over three tensors of the block's widest shape.
+
+Same sums as the per-operator route; the gradient of gamma uses xhat recovered from the stored output, exact wherever the
+gate is open (ops/conv_bn.py), and the scale folded into bf16 weights is rounded once more than on the per-operator
+route (tests/test_gpu_bottleneck.py pins both against the fp32 composite).
+
+Applies to: identity blocks (no downsample, stride 1, groups 1) on CUDA with bf16 channels_last activations, bf16
+weights (Runner(bf16_params=True)), eval-mode affine BatchNorms with fp32 parameters, every parameter trainable, channel
+counts the kernels tile -- the 10 of 13 trainable blocks of ResNet-50, 27 of 30 of ResNet-101.  Everything else runs
+the per-operator forward of models/backbones/resnet.py."""
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from .bn_act import _memo
+from .conv1x1 import _wrw_split_k
+from .conv3x3 import _flipped, _mfma_wrw
+
+_ON = True      # False: the per-operator route (what this node is tested against)
+
+
+def _cl_empty(B, C, H, W, device):
+    return torch.empty((B, C, H, W), dtype=torch.bfloat16, device=device, memory_format=torch.channels_last)
+
+
+def _conv_bn_fwd(lib, x, w, bn, residual):
+    gamma, beta, mean, var, eps = bn
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    y = _cl_empty(B, O, H, W, x.device)
+    rc = lib.rsdet_conv1x1_bn_act_fwd_bf16(_lib.ptr(x), _lib.ptr(w), B * H * W, O, C, _lib.ptr(mean), _lib.ptr(var),
+                                           _lib.ptr(gamma), _lib.ptr(beta), eps, _lib.ptr(residual), 1, _lib.ptr(y),
+                                           _lib.stream_ptr())
+    _lib.check(rc, "rsdet_conv1x1_bn_act_fwd_bf16")
+    return y
+
+
+def _transposed(lib, w, scale_bn):
+    """(O, C, 1, 1) -> the (C, O) operand of the backward-data GEMM, column o scaled by the BatchNorm behind the
+    convolution when ``scale_bn`` is given."""
+    O, C = w.shape[0], w.shape[1]
+    out = torch.empty((C, O), dtype=torch.bfloat16, device=w.device)
+    var = gamma = None
+    eps = 0.0
+    if scale_bn is not None:
+        gamma, _, _, var, eps = scale_bn
+    rc = lib.rsdet_weight_transpose_scale_bf16(_lib.ptr(w), O, C, _lib.ptr(var), _lib.ptr(gamma), eps, _lib.ptr(out),
+                                               _lib.stream_ptr())
+    _lib.check(rc, "rsdet_weight_transpose_scale_bf16")
+    return out
+
+
+class _Bottleneck(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, ga1, be1, ga2, be2, ga3, be3, stats, pad):
+        lib = _lib.load()
+        (m1, v1, e1), (m2, v2, e2), (m3, v3, e3) = stats
+        y1 = _conv_bn_fwd(lib, x, w1, (ga1, be1, m1, v1, e1), None)
+        c2 = F.conv2d(y1, w2, None, 1, pad, pad)
+        B, C1, H, W = c2.shape
+        y2 = torch.empty_like(c2)
+        rc = lib.rsdet_bn_act_forward_nhwc_bf16(_lib.ptr(c2), None, _lib.ptr(m2), _lib.ptr(v2), _lib.ptr(ga2),
+                                                _lib.ptr(be2), e2, B, C1, H * W, 1, _lib.ptr(y2), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_bn_act_forward_nhwc_bf16")
+        del c2
+        y3 = _conv_bn_fwd(lib, y2, w3, (ga3, be3, m3, v3, e3), x)
+        ctx.save_for_backward(x, y1, y2, y3, w1, w2, w3, ga1, be1, ga2, be2, ga3, be3)
+        ctx.stats, ctx.pad = stats, pad
+        return y3
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, y1, y2, y3, w1, w2, w3, ga1, be1, ga2, be2, ga3, be3 = ctx.saved_tensors
+        (m1, v1, e1), (m2, v2, e2), (m3, v3, e3) = ctx.stats
+        B, C0, H, W = x.shape
+        C1 = w1.shape[0]
+        P, HW = B * H * W, H * W
+        dev = x.device
+        st = _lib.stream_ptr()
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def ws_for(fn, *shape):
+            nb = _memo(fn, *shape)
+            return torch.empty((nb,), dtype=torch.uint8, device=dev), nb
+
+        # ---- 1: through relu(. + x): gz = gy [y3 > 0] (conv3's branch AND the identity's), bn3's parameter gradients
+        gz = torch.empty_like(gy)
+        gga3, gbe3 = torch.empty((C0,), **f32), torch.empty((C0,), **f32)
+        ws, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C0, HW)
+        rc = lib.rsdet_bn_act_backward_nhwc_fromy_bf16(_lib.ptr(gy), _lib.ptr(y3), _lib.ptr(x), _lib.ptr(v3), _lib.ptr(ga3),
+                                                       _lib.ptr(be3), e3, B, C0, HW, 1, None, _lib.ptr(gz), _lib.ptr(gga3),
+                                                       _lib.ptr(gbe3), _lib.ptr(ws), nb, st)
+        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_bf16")
+        gz2 = gz.permute(0, 2, 3, 1).reshape(P, C0)
+        # ---- 2: conv3's weight gradient from gz, bn3's scale applied in the fold
+        gw3 = _wrw_split_k(gz2, y2, w3, rowscale=(v3, ga3, e3))
+        # ---- 3: conv3's backward-data with bn3's scale in the weights and bn2's backward in the epilogue
+        gc2 = _cl_empty(B, C1, H, W, dev)
+        gga2, gbe2 = torch.empty((C1,), **f32), torch.empty((C1,), **f32)
+        ws, nb = ws_for("rsdet_conv1x1_dgrad_ws_size", P, C1, C0)
+        wt3 = _transposed(lib, w3, (ga3, be3, m3, v3, e3))
+        rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gz), _lib.ptr(wt3), P, C1, C0, 2, _lib.ptr(y2), _lib.ptr(v2),
+                                          _lib.ptr(ga2), _lib.ptr(be2), e2, _lib.ptr(gga2), _lib.ptr(gbe2), _lib.ptr(ws), nb,
+                                          _lib.ptr(gc2), st)
+        _lib.check(rc, "rsdet_conv1x1_dgrad_bf16")
+        # ---- 4: conv2 (3x3): backward-data through the forward solver on the flipped weights, our split-K weight gradient
+        pad = ctx.pad
+        gw2 = None
+        if pad == 1:
+            gc1 = F.conv2d(gc2, _flipped(w2), None, 1, 1)
+            if C1 % 128 == 0:
+                gw2 = _mfma_wrw(gc2, y1, w2.dtype)
+            if gw2 is None:
+                gw2 = torch.ops.aten.convolution_backward(gc2, y1, w2, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                          (False, True, False))[1]
+        else:
+            gc1, gw2, _ = torch.ops.aten.convolution_backward(gc2, y1, w2, None, (1, 1), (pad, pad), (pad, pad), False,
+                                                              (0, 0), 1, (True, True, False))
+            gc1 = gc1.contiguous(memory_format=torch.channels_last)
+        del gc2
+        # ---- 5: bn1's backward from y1: gc1 [y1 > 0] gamma1 / sqrt(var1 + eps), its parameter gradients
+        g1, gc1 = gc1, torch.empty_like(gc1)
+        gga1, gbe1 = torch.empty((C1,), **f32), torch.empty((C1,), **f32)
+        ws, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C1, HW)
+        rc = lib.rsdet_bn_act_backward_nhwc_fromy_bf16(_lib.ptr(g1), _lib.ptr(y1), None, _lib.ptr(v1), _lib.ptr(ga1),
+                                                       _lib.ptr(be1), e1, B, C1, HW, 1, _lib.ptr(gc1), None, _lib.ptr(gga1),
+                                                       _lib.ptr(gbe1), _lib.ptr(ws), nb, st)
+        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_bf16")
+        gc1_2 = gc1.permute(0, 2, 3, 1).reshape(P, C1)
+        # ---- 6: conv1's weight gradient
+        gw1 = _wrw_split_k(gc1_2, x, w1)
+        # ---- 7: conv1's backward-data + the identity branch's gz
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(gz)
+            rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gc1), _lib.ptr(_transposed(lib, w1, None)), P, C0, C1, 3, _lib.ptr(gz),
+                                              None, None, None, 0.0, None, None, None, 0, _lib.ptr(gx), st)
+            _lib.check(rc, "rsdet_conv1x1_dgrad_bf16")
+        return gx, gw1, gw2, gw3, gga1, gbe1, gga2, gbe2, gga3, gbe3, None, None
+
+
+def _bn_ok(bn):
+    return (type(bn) is torch.nn.BatchNorm2d and not bn.training and bn.running_mean is not None
+            and bn.running_mean.dtype == torch.float32 and bn.weight is not None and bn.weight.dtype == torch.float32
+            and bn.weight.requires_grad and bn.bias.requires_grad)
+
+
+def _conv_ok(conv, k):
+    return (type(conv) is torch.nn.Conv2d and conv.kernel_size == (k, k) and conv.stride == (1, 1) and conv.groups == 1
+            and conv.bias is None and conv.padding_mode == 'zeros' and conv.weight.dtype == torch.bfloat16
+            and conv.weight.requires_grad)
+
+
+def bottleneck_applies(block, x):
+    """Does the one-node form take this models/backbones/resnet.py Bottleneck on this input?  (module docstring)"""
+    if not (_ON and block.downsample is None and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+            and x.dtype == torch.bfloat16 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    c1, c2, c3 = block.conv1, block.conv2, block.conv3
+    if not (_conv_ok(c1, 1) and _conv_ok(c2, 3) and _conv_ok(c3, 1) and _bn_ok(block.bn1) and _bn_ok(block.bn2)
+            and _bn_ok(block.bn3)):
+        return False
+    if not (c1.padding == (0, 0) and c3.padding == (0, 0) and c2.padding == c2.dilation and c2.padding[0] == c2.padding[1]
+            and c1.dilation == (1, 1) and c3.dilation == (1, 1)):
+        return False
+    B, C0, H, W = x.shape
+    C1 = c1.out_channels
+    if not (c3.out_channels == C0 and c2.in_channels == C1 and c2.out_channels == C1 and c3.in_channels == C1):
+        return False
+    P = B * H * W
+
+    def nhwc8(c):           # the eight-channel BatchNorm backward pass: C / 8 divides 256
+        return c % 8 == 0 and c <= 2048 and 256 % (c // 8) == 0
+    return (nhwc8(C0) and nhwc8(C1) and bool(_memo("rsdet_gemm1x1_mfma_supported", P, C1, C0))
+            and bool(_memo("rsdet_gemm1x1_mfma_supported", P, C0, C1)))
+
+
+def bottleneck(block, x):
+    """``block(x)`` for a Bottleneck that bottleneck_applies() accepted."""
+    bn1, bn2, bn3 = block.bn1, block.bn2, block.bn3
+    stats = ((bn1.running_mean, bn1.running_var, float(bn1.eps)), (bn2.running_mean, bn2.running_var, float(bn2.eps)),
+             (bn3.running_mean, bn3.running_var, float(bn3.eps)))
+    return _Bottleneck.apply(x, block.conv1.weight, block.conv2.weight, block.conv3.weight, bn1.weight, bn1.bias,
+                             bn2.weight, bn2.bias, bn3.weight, bn3.bias, stats, int(block.conv2.padding[0]))

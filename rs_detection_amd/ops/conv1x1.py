@@ -27,20 +27,27 @@ _FWD_MAX_PIXELS = 65536
 _WRW_GEMM = True    # the weight gradient as a split-K batched GEMM (False: MIOpen's kernel)
 
 
-def _wrw_split_k(gy2, x, w):
+def _wrw_split_k(gy2, x, w, rowscale=None):
     """Weight gradient gw[o, c] = sum_p gy2[p, o] x2[p, c] as a SPLIT-K batched GEMM on views: the pixel axis cut into S
     slices, one (O, P/S) x (P/S, C) product per slice (torch.bmm on views, no copies), the S partial results summed.  A
     plain GEMM has K = all pixels and only (O/256)(C/256) tiles to spread over 256 CUs -- 5-10 x slower than MIOpen;
     with S ~ P / 1024 (bf16) or P / 2048 (fp32) slices it is 25-35 % (bf16: 36 -> 25 us per call on the trunk shapes)
     and 5-12 % (fp32) faster than MIOpen's kernel + zero-fill (+ cast) launches (scratch/wrw1x1_nhwc.py, round 4).
     The S partial products come back in fp32 (``out_dtype``: the GEMM's own accumulator, not rounded to bf16) and are
-    summed in fp32: ONE rounding of the result, as in MIOpen's kernel."""
+    summed in fp32: ONE rounding of the result, as in MIOpen's kernel.
+    ``rowscale = (running_var, gamma, eps)``: row o of the result times gamma[o] / sqrt(running_var[o] + eps) before the
+    rounding -- gy2 is then the gradient of the OUTPUT of an eval-mode BatchNorm behind the convolution (ops/bottleneck.py)."""
     P, O = gy2.shape
     C = x.shape[1]
     S = max(1, min(64, P // (1024 if x.dtype == torch.bfloat16 else 2048)))
     while S > 1 and P % S:
         S //= 2
     x2 = x.permute(0, 2, 3, 1).reshape(P, C)
+    if rowscale is not None and not (S > 1 and x.dtype == torch.bfloat16 and C % 4 == 0):
+        var, gamma, eps = rowscale
+        sc = torch.rsqrt(var + eps) * (1.0 if gamma is None else gamma)
+        gw = (torch.mm(gy2.t(), x2).float() * sc[:, None]).to(x.dtype)
+        return gw.view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
     if S == 1:
         return torch.mm(gy2.t(), x2).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
     a, b = gy2.view(S, P // S, O).transpose(1, 2), x2.view(S, P // S, C)
@@ -50,6 +57,13 @@ def _wrw_split_k(gy2, x, w):
         # channels_last storage = the (O, C) matrix) instead of a reduction launch + a cast launch
         from .. import _lib
         gw = torch.empty((O, C, 1, 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        if rowscale is not None:
+            var, gamma, eps = rowscale
+            rc = _lib.load().rsdet_sum_slabs_rowscale_f32(_lib.ptr(part), S, O * C, C, _lib.ptr(var), _lib.ptr(gamma),
+                                                          float(eps), _lib.ptr(gw), int(x.dtype == torch.bfloat16),
+                                                          _lib.stream_ptr())
+            _lib.check(rc, "rsdet_sum_slabs_rowscale_f32")
+            return gw
         rc = _lib.load().rsdet_sum_slabs_f32(_lib.ptr(part), S, O * C, _lib.ptr(gw), int(x.dtype == torch.bfloat16),
                                              _lib.stream_ptr())
         _lib.check(rc, "rsdet_sum_slabs_f32")

@@ -1,0 +1,191 @@
+"""GPU: the identity Bottleneck as one autograd node (ops/bottleneck.py) and the backward-data GEMM with the next backward
+step in its epilogue (csrc/gemm1x1_mfma.hip, rsdet_conv1x1_dgrad_bf16) against plain fp32 torch references of the same
+arithmetic.  Floating point: bf16 operands, fp32 accumulation, one rounding per stored tensor -- tolerances are the bf16
+resolution (2^-8) of the compared quantity's range, written at each assert."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12))
+
+
+def _bf(t):
+    return t.bfloat16()
+
+
+@pytest.mark.parametrize("M,C,O", [(4096, 128, 512), (1000, 256, 1024), (130, 32, 64), (128 * 9, 128, 256),
+                                   (16384, 512, 2048), (77, 96, 192)])
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_dgrad_gemm_modes_against_fp32(cuda, M, C, O, mode):
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    assert lib.rsdet_gemm1x1_mfma_supported(M, C, O)
+    g = torch.Generator().manual_seed(M + C + O + mode)
+    go = _bf(torch.randn(M, O, generator=g)).to(cuda)
+    w = _bf(torch.randn(O, C, generator=g) / O ** 0.5).to(cuda)                  # the convolution's (O, C) weight
+    side = _bf(torch.randn(M, C, generator=g)).to(cuda)
+    var = torch.empty(C).uniform_(0.5, 2, generator=g).to(cuda)
+    gamma = torch.empty(C).uniform_(0.5, 1.5, generator=g).to(cuda)
+    gamma[0] = 0.0                                                               # a dead channel: its xhat term drops
+    beta = (torch.randn(C, generator=g) * 0.3).to(cuda)
+    eps = 1e-5
+    wt = torch.empty((C, O), dtype=torch.bfloat16, device=cuda)
+    _lib.check(lib.rsdet_weight_transpose_scale_bf16(_lib.ptr(w), O, C, None, None, 0.0, _lib.ptr(wt), _lib.stream_ptr()), "t")
+    assert torch.equal(wt, w.t().contiguous())
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=cuda)
+    gg = torch.full((C,), float("nan"), device=cuda)
+    gb = torch.full((C,), float("nan"), device=cuda)
+    nb = lib.rsdet_conv1x1_dgrad_ws_size(M, C, O)
+    ws = torch.empty((max(nb, 1),), dtype=torch.uint8, device=cuda)
+    rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(go), _lib.ptr(wt), M, C, O, mode, _lib.ptr(side) if mode else None,
+                                      _lib.ptr(var), _lib.ptr(gamma), _lib.ptr(beta), eps,
+                                      _lib.ptr(gg) if mode == 2 else None, _lib.ptr(gb) if mode == 2 else None,
+                                      _lib.ptr(ws), nb, _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "rsdet_conv1x1_dgrad_bf16")
+    acc = go.float() @ w.float()
+    if mode == 0:
+        ref = acc
+    elif mode == 3:
+        ref = acc + side.float()
+    else:
+        gate = (side.float() > 0).float()
+        gz = acc * gate
+        ref = gz * (gamma * torch.rsqrt(var + eps))
+        ig = torch.where(gamma != 0, 1.0 / gamma, torch.zeros_like(gamma))
+        ref_gb = gz.sum(0)
+        ref_gg = (gz * ((side.float() - beta) * ig)).sum(0)
+        # fp32 sums over M products of bf16-valued operands, in another order than torch's: 1e-4 of the sum's scale
+        tol = 1e-4 * float(gz.abs().sum(0).max()) + 1e-5
+        assert float((gb - ref_gb).abs().max()) <= tol
+        tol = 1e-4 * float((gz * ((side.float() - beta) * ig)).abs().sum(0).max()) + 1e-5
+        assert float((gg - ref_gg).abs().max()) <= tol
+    assert not torch.isnan(out.float()).any()
+    # one bf16 rounding of the result: 2^-8 of its range (+ the accumulation-order noise of an O-term fp32 sum)
+    assert float((out.float() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-5
+
+
+def test_weight_transpose_scale_and_rowscale_fold(cuda):
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for O, C in ((512, 128), (96, 40), (33, 7)):
+        w = _bf(torch.randn(O, C, generator=g)).to(cuda)
+        var = torch.empty(O).uniform_(0.5, 2, generator=g).to(cuda)
+        gamma = torch.empty(O).uniform_(0.5, 1.5, generator=g).to(cuda)
+        out = torch.empty((C, O), dtype=torch.bfloat16, device=cuda)
+        _lib.check(lib.rsdet_weight_transpose_scale_bf16(_lib.ptr(w), O, C, _lib.ptr(var), _lib.ptr(gamma), 1e-5,
+                                                         _lib.ptr(out), _lib.stream_ptr()), "t")
+        ref = (w.float() * (gamma * torch.rsqrt(var + 1e-5))[:, None]).t()
+        assert float((out.float() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max())
+    S, O, C = 5, 24, 16
+    part = torch.randn(S, O, C, generator=g).to(cuda)
+    var = torch.empty(O).uniform_(0.5, 2, generator=g).to(cuda)
+    gamma = torch.empty(O).uniform_(0.5, 1.5, generator=g).to(cuda)
+    for gm in (gamma, None):
+        for bf in (0, 1):
+            out = torch.empty((O, C), dtype=torch.bfloat16 if bf else torch.float32, device=cuda)
+            _lib.check(lib.rsdet_sum_slabs_rowscale_f32(_lib.ptr(part), S, O * C, C, _lib.ptr(var), _lib.ptr(gm), 1e-5,
+                                                        _lib.ptr(out), bf, _lib.stream_ptr()), "f")
+            acc = part[0].clone()
+            for s in range(1, S):
+                acc += part[s]
+            sc = torch.rsqrt(var + 1e-5) * (1.0 if gm is None else gm)
+            ref = acc * sc[:, None]
+            if bf:
+                assert float((out.float() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max())
+            else:
+                assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # argument checks
+    assert lib.rsdet_sum_slabs_rowscale_f32(_lib.ptr(part), S, O * C, 6, _lib.ptr(var), None, 1e-5, _lib.ptr(out), 1,
+                                            _lib.stream_ptr()) != 0
+    assert lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(part), _lib.ptr(part), 128, 48, 64, 2, None, None, None, None, 0.0, None,
+                                        None, None, 0, _lib.ptr(out), _lib.stream_ptr()) != 0
+
+
+def _block(cuda, inplanes, planes, dilation=1, seed=0):
+    from rs_detection_amd.models.backbones.resnet import Bottleneck
+    torch.manual_seed(seed)
+    blk = Bottleneck(inplanes, planes, dilation=dilation).to(cuda)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = m.weight.data.bfloat16().contiguous(memory_format=torch.channels_last)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.uniform_(0.5, 1.5), m.bias.normal_(0, 0.2), m.running_mean.normal_(0, 0.2), m.running_var.uniform_(0.5, 2)
+    return blk.eval()                            # norm_eval: BatchNorm in eval mode, gradients still flow
+
+
+@pytest.mark.parametrize("B,inplanes,planes,H,W,dil", [(2, 512, 128, 48, 40, 1), (1, 256, 64, 33, 29, 1),
+                                                       (2, 1024, 256, 16, 16, 1), (1, 512, 128, 24, 24, 2)])
+def test_one_node_bottleneck_against_the_fp32_composite_under_its_own_gates(cuda, B, inplanes, planes, H, W, dil):
+    """Forward: bf16 resolution.  Backward: every gradient against fp32 autograd of the same composite with the ReLU gates
+    of the node's own stored activations (elements within a rounding of zero would otherwise flip 100 % of their
+    gradient, which measures the rounding of the FORWARD, not the backward under test)."""
+    from rs_detection_amd.ops import bottleneck as bt, conv_bn
+    blk = _block(cuda, inplanes, planes, dil)
+    x = torch.randn(B, inplanes, H, W, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    go = torch.randn(B, inplanes, H, W, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    xi = x.clone().requires_grad_(True)
+    assert bt.bottleneck_applies(blk, xi)
+    y = blk(xi)
+    assert "_Bottleneck" in type(y.grad_fn).__name__
+    y.backward(go)
+    with torch.no_grad():                        # the node's intermediates, through the same kernels
+        from rs_detection_amd.ops.bn_act import bn_act
+        y1 = conv_bn.conv_bn_act(blk.conv1, blk.bn1, x)
+        y2 = bn_act(F.conv2d(y1, blk.conv2.weight, None, 1, dil, dil), blk.bn2)
+    P = {k: v.detach().float().requires_grad_(True) for k, v in blk.named_parameters()}
+    xf = x.float().requires_grad_(True)
+
+    def bn(t, n):
+        m = getattr(blk, n)
+        return F.batch_norm(t, m.running_mean, m.running_var, P[n + ".weight"], P[n + ".bias"], False, 0.0, m.eps)
+    a1 = bn(F.conv2d(xf, P["conv1.weight"]), "bn1")
+    a1 = a1 * (y1 > 0).float()
+    assert float((a1 - y1.float()).abs().max()) <= 2 ** -8 * float(a1.abs().max()) + 1e-6
+    z2 = bn(F.conv2d(y1.float() + (a1 - a1.detach()), P["conv2.weight"], None, 1, dil, dil), "bn2")
+    a2 = z2 * (y2 > 0).float()
+    assert float((a2 - y2.float()).abs().max()) <= 2 * 2 ** -8 * float(a2.abs().max())   # conv2's output + y2: two roundings
+    z3 = bn(F.conv2d(y2.float() + (a2 - a2.detach()), P["conv3.weight"]), "bn3") + xf
+    a3 = z3 * (y > 0).float()
+    assert float((a3 - y.float()).abs().max()) <= 3 * 2 ** -8 * float(a3.abs().max())   # three stored bf16 tensors deep
+    a3.backward(go.float())
+    assert _rel(xi.grad, xf.grad) <= 2e-2, _rel(xi.grad, xf.grad)
+    for k, v in blk.named_parameters():
+        tol = 4e-2 if k.endswith("bn1.weight") or k.endswith("bn2.weight") or k.endswith("bn3.weight") else 2.5e-2
+        assert _rel(v.grad, P[k].grad) <= tol, (k, _rel(v.grad, P[k].grad))
+
+
+def test_one_node_bottleneck_tracks_the_per_operator_route(cuda):
+    from rs_detection_amd.ops import bottleneck as bt
+    blk = _block(cuda, 512, 128)
+    x = torch.randn(2, 512, 40, 48, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    g = torch.randn(2, 512, 40, 48, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for on in (True, False):
+        bt._ON = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            blk.zero_grad()
+            y = blk(xi)
+            assert ("_Bottleneck" in type(y.grad_fn).__name__) == on
+            y.backward(g)
+            outs.append([y.detach().float(), xi.grad.float()] + [p.grad.float() for p in blk.parameters()])
+        finally:
+            bt._ON = True
+    assert _rel(outs[0][0], outs[1][0]) <= 1e-3                  # the same forward arithmetic (bn2 with / without the gate bit mask)
+    # gradients: bn2's gate is read from the stored bf16 y2 on both routes; the scale folded into the bf16 weights and the
+    # ungated bf16 intermediate the per-operator route stores round differently
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert _rel(a, b) <= 2e-2, _rel(a, b)
+    # not taken: a block with a downsample branch, frozen parameters, fp32 input, no grad
+    from rs_detection_amd.models.backbones.resnet import Bottleneck
+    assert not bt.bottleneck_applies(blk, x.float())
+    with torch.no_grad():
+        assert not bt.bottleneck_applies(blk, x)
+    blk.conv1.weight.requires_grad_(False)
+    assert not bt.bottleneck_applies(blk, x)
