@@ -408,6 +408,9 @@ int rsdet_weight_transpose_scale_bf16(const uint16_t* weight, int O, int C, cons
  *   mode 3: grad_in = acc + side (the gradient arriving through the identity branch).
  * C % 32 == 0, O % 64 == 0 (rsdet_gemm1x1_mfma_supported(M, C, O)). */
 size_t rsdet_conv1x1_dgrad_ws_size(long long M, int C, int O);
+/* mode 2 with ws but neither gradient pointer: the per-slice sums stay in ws as (C, S, 2) floats, S = this, for
+ * rsdet_bn_sums_finish_multi_f32 to fold. */
+int rsdet_conv1x1_dgrad_slices(long long M, int C, int O);
 int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t* wt, long long M, int C, int O, int mode,
                              const uint16_t* side, const float* running_var, const float* gamma, const float* beta,
                              float eps, float* grad_gamma, float* grad_beta, void* ws, size_t ws_bytes,
@@ -416,6 +419,17 @@ int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t
                                           const float* running_var, const float* weight, const float* bias, float eps,
                                           int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
                                           float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+/* rsdet_bn_act_backward_nhwc_fromy_bf16 with the per-slice sums LEFT in ws as (C, S, 2) floats ([0] bias, [1] scale; S =
+ * rsdet_bn_act_backward_nhwc_fromy_slices), and the fold of up to 4 such tables -- from this pass or from
+ * rsdet_conv1x1_dgrad_bf16's mode 2 -- as ONE launch: job j -> grad_bias[j][c] = sum_s [0], grad_weight[j][c] = sum_s [1].
+ * The three BatchNorms of a Bottleneck's backward (ops/bottleneck.py) end in one fold instead of three. */
+int rsdet_bn_act_backward_nhwc_fromy_slices(int N, int C, int HW);
+int rsdet_bn_act_backward_nhwc_fromy_sums_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
+                                               const float* running_var, const float* weight, const float* bias,
+                                               float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
+                                               uint16_t* grad_residual, void* ws, size_t ws_bytes, void* stream);
+int rsdet_bn_sums_finish_multi_f32(int n, const float* const* partial, const int* C, const int* S,
+                                   float* const* grad_weight, float* const* grad_bias, void* stream);
 int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* weight, const float* bias, const uint8_t* live, int B,
                                 int H, int W, int C, int O, int relu, uint16_t* out, void* stream);
 /* Weight gradient of the same convolution (csrc/conv3x3_wrw_mfma.hip): split-K implicit GEMM over groups of image rows,
@@ -481,6 +495,13 @@ int rsdet_rroi_align_v0_backward_gather_nchw_f32(const float* grad_out_t, const 
  * inverted on integers in ws, then every pixel sums its terms -- no fp32 atomics, grad_in written exactly once. */
 int rsdet_feature_refine_forward_f32(const float* feat, const float* best_bboxes, int N, int C, int H, int W,
                                      float spatial_scale, int points, float* out, void* stream);
+/* The forward on CHANNELS-LAST maps feat / out (N,H,W,C) (a channels_last step hands them over as they are; pairs with
+ * the channels-last backward below, so neither direction turns a layout): a sample is a contiguous channel vector, read
+ * by 16-byte-per-lane wave-wide loads.  Same sums in the same order as the NCHW entry.  C % 4 == 0 with C / 4 a power of
+ * two up to 64 or a multiple of 64 (rsdet_feature_refine_forward_nhwc_supported), H W C < 2^31, 16-byte aligned maps. */
+int rsdet_feature_refine_forward_nhwc_supported(int C);
+int rsdet_feature_refine_forward_nhwc_f32(const float* feat, const float* best_bboxes, int N, int C, int H, int W,
+                                          float spatial_scale, int points, float* out, void* stream);
 size_t rsdet_feature_refine_backward_ws_size(int N, int H, int W, int points);
 int rsdet_feature_refine_backward_nhwc_f32(const float* grad_out_nhwc, const float* best_bboxes, int N, int C,
                                            int H, int W, float spatial_scale, int points, float* grad_in_nhwc,

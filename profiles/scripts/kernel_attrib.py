@@ -48,10 +48,11 @@ def main():
         targets.append(t)
     batches = [(images, targets)]
 
+    inner = runner
+
     class _R:
         def train_step(self, b):
-            return runner.train_step(*b)
-    runner_ = runner
+            return inner.train_step(*b)
     runner = _R()
     for i in range(6):
         runner.train_step(batches[i % len(batches)])

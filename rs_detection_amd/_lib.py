@@ -45,6 +45,12 @@ SIGNATURES = {
     "rsdet_weight_transpose_scale_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                                   c_void_p]),
     "rsdet_conv1x1_dgrad_ws_size": (c_size_t, [c_ll, c_int, c_int]),
+    "rsdet_conv1x1_dgrad_slices": (c_int, [c_ll, c_int, c_int]),
+    "rsdet_bn_act_backward_nhwc_fromy_slices": (c_int, [c_int, c_int, c_int]),
+    "rsdet_bn_act_backward_nhwc_fromy_sums_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                           c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                           c_void_p, c_size_t, c_void_p]),
+    "rsdet_bn_sums_finish_multi_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_conv1x1_dgrad_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "rsdet_conv1x1_bn_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -169,6 +175,9 @@ SIGNATURES = {
                                                         c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_feature_refine_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
                                                  c_void_p, c_void_p]),
+    "rsdet_feature_refine_forward_nhwc_supported": (c_int, [c_int]),
+    "rsdet_feature_refine_forward_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                                      c_void_p, c_void_p]),
     "rsdet_feature_refine_backward_ws_size": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rsdet_feature_refine_backward_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
                                                        c_void_p, c_void_p, c_size_t, c_void_p]),

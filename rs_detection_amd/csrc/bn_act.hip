@@ -833,15 +833,15 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char
 // Backward of the fused 1x1 convolution + BatchNorm + residual + ReLU (csrc/gemm1x1_mfma.hip): as
 // rsdet_bn_act_backward_nhwc_bf16, but the scale gradient's normalised input comes from the OUTPUT y (the kernel's
 // from_y note).  bf16, C / 8 a divisor of 256.  grad_x = the gradient with respect to the CONVOLUTION's raw output.
-extern "C" int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
-                                                     const float* running_var, const float* weight, const float* bias,
-                                                     float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
-                                                     uint16_t* grad_residual, float* grad_weight, float* grad_bias,
-                                                     void* ws, size_t ws_bytes, void* stream) {
+static int bn_act_backward_nhwc_fromy(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
+                                      const float* running_var, const float* weight, const float* bias, float eps, int N,
+                                      int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
+                                      float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, bool sums_only,
+                                      void* stream) {
   if (N < 0 || HW < 0 || !bn_nhwc_ok(C) || !bn_nhwc8_ok(C)) return RSDET_EINVAL;
   if (N == 0 || HW == 0) return RSDET_OK;
   if (!grad_y || !y || !running_var) return RSDET_EINVAL;
-  const bool need_param = grad_weight || grad_bias;
+  const bool need_param = grad_weight || grad_bias || sums_only;
   if (need_param && (!ws || ws_bytes < rsdet_bn_act_backward_nhwc_ws_size(N, C, HW))) return RSDET_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const long long rows = (long long)N * HW;
@@ -849,7 +849,7 @@ extern "C" int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, con
   bn_nhwc_split(rows, C, &per, &S, 8);
   float* partial = need_param ? (float*)ws : nullptr;
   const bf16_t *gy = grad_y, *yy = y, *rr = residual;
-  const int fy = grad_weight ? 1 : 0;          // (only the scale gradient needs xhat)
+  const int fy = (grad_weight || sums_only) ? 1 : 0;          // (only the scale gradient needs xhat)
   // running_mean is not needed in this form: pass running_var for it (the kernel loads it, nothing reads it)
   if (relu)
     hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<true>), dim3(S), dim3(BN_NT), 0, s, gy, yy, (const bf16_t*)nullptr,
@@ -859,9 +859,89 @@ extern "C" int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, con
     hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<false>), dim3(S), dim3(BN_NT), 0, s, gy, yy, (const bf16_t*)nullptr,
                        running_var, running_var, weight, eps, rows, C, per, (bf16_t*)grad_x, (bf16_t*)grad_residual,
                        partial, (const unsigned char*)nullptr, rr, bias, fy);
-  if (need_param)
+  if (need_param && !sums_only)
     hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
                        grad_bias);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
+                                                     const float* running_var, const float* weight, const float* bias,
+                                                     float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
+                                                     uint16_t* grad_residual, float* grad_weight, float* grad_bias,
+                                                     void* ws, size_t ws_bytes, void* stream) {
+  return bn_act_backward_nhwc_fromy(grad_y, y, residual, running_var, weight, bias, eps, N, C, HW, relu, grad_x,
+                                    grad_residual, grad_weight, grad_bias, ws, ws_bytes, false, stream);
+}
+
+// The same pass with the per-slice sums LEFT in ws as (C, S, 2) floats ([0] the bias sum, [1] the scale sum), S =
+// rsdet_bn_act_backward_nhwc_fromy_slices(N, C, HW): several such passes of one autograd node (ops/bottleneck.py) are
+// folded by ONE rsdet_bn_sums_finish_multi_f32 launch.
+extern "C" int rsdet_bn_act_backward_nhwc_fromy_slices(int N, int C, int HW) {
+  if (N <= 0 || HW <= 0 || !bn_nhwc_ok(C) || !bn_nhwc8_ok(C)) return 0;
+  int per, S;
+  bn_nhwc_split((long long)N * HW, C, &per, &S, 8);
+  return S;
+}
+extern "C" int rsdet_bn_act_backward_nhwc_fromy_sums_bf16(const uint16_t* grad_y, const uint16_t* y,
+                                                          const uint16_t* residual, const float* running_var,
+                                                          const float* weight, const float* bias, float eps, int N, int C,
+                                                          int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
+                                                          void* ws, size_t ws_bytes, void* stream) {
+  if (!ws) return RSDET_EINVAL;
+  return bn_act_backward_nhwc_fromy(grad_y, y, residual, running_var, weight, bias, eps, N, C, HW, relu, grad_x,
+                                    grad_residual, nullptr, nullptr, ws, ws_bytes, true, stream);
+}
+
+// Up to RSDET_BN_FINISH_JOBS (C, S, 2) partial-sum tables folded by one launch: job j -> grad_bias[j][c] = sum_s [0],
+// grad_weight[j][c] = sum_s [1] (either pointer NULL: skipped).  One wave per channel, fixed order.
+constexpr int BN_FINISH_JOBS = 4;
+struct BnFinishJobs {
+  const float* partial[BN_FINISH_JOBS];
+  float* dweight[BN_FINISH_JOBS];
+  float* dbias[BN_FINISH_JOBS];
+  int C[BN_FINISH_JOBS], S[BN_FINISH_JOBS], block0[BN_FINISH_JOBS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void bn_sums_finish_multi_kernel(BnFinishJobs jobs) {
+  int j = 0;
+  while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
+  const int c = ((int)blockIdx.x - jobs.block0[j]) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int C = jobs.C[j], S = jobs.S[j];
+  if (c >= C) return;
+  const float* partial = jobs.partial[j];
+  float a = 0.f, b = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float2 p = *reinterpret_cast<const float2*>(partial + ((long long)c * S + s) * 2);
+    a += p.x;
+    b += p.y;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off);
+    b += __shfl_down(b, off);
+  }
+  if (lane == 0) {
+    if (jobs.dbias[j]) jobs.dbias[j][c] = a;
+    if (jobs.dweight[j]) jobs.dweight[j][c] = b;
+  }
+}
+extern "C" int rsdet_bn_sums_finish_multi_f32(int n, const float* const* partial, const int* C, const int* S,
+                                              float* const* grad_weight, float* const* grad_bias, void* stream) {
+  if (n < 0 || n > BN_FINISH_JOBS) return RSDET_EINVAL;
+  if (n == 0) return RSDET_OK;
+  if (!partial || !C || !S || !grad_weight || !grad_bias) return RSDET_EINVAL;
+  BnFinishJobs jobs;
+  jobs.n = n;
+  int blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!partial[j] || C[j] < 1 || S[j] < 1) return RSDET_EINVAL;
+    jobs.partial[j] = partial[j], jobs.dweight[j] = grad_weight[j], jobs.dbias[j] = grad_bias[j];
+    jobs.C[j] = C[j], jobs.S[j] = S[j], jobs.block0[j] = blocks;
+    blocks += (C[j] + 3) / 4;
+  }
+  jobs.block0[n] = blocks;
+  hipLaunchKernelGGL(bn_sums_finish_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs);
   return rsdet_launch_status();
 }
 

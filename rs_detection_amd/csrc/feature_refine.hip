@@ -115,6 +115,81 @@ __global__ __launch_bounds__(256) void fr_forward_kernel(const float* __restrict
   }
 }
 
+// ---- channels-last forward -------------------------------------------------------------------------------------------
+// feat / out (N, H, W, C): a sample is a CONTIGUOUS channel vector, so the 4 * POINTS + 1 reads of a position are
+// wave-wide 16-byte-per-lane loads of consecutive addresses instead of 21 gathers per channel whose lanes scatter over
+// rows (the NCHW form above: L2-gather-bound at 0.04 of the HBM roofline).  LPP = min(64, C / 4) lanes own one position
+// (4 channels each), 64 / LPP positions per wave pass, channel chunks of 256 for wider maps.  The footprints are computed
+// redundantly by the lanes of a position (~150 VALU instructions against 21 KB of loads per 256 channels).  The four
+// waves of a workgroup take NEIGHBOURING positions at the same time (their corner pixels overlap: L1 hits), workgroup
+// ids are mapped so that each XCD's L2 sees one contiguous band of rows.  Same sums in the same order as the NCHW form.
+template <int POINTS>
+__global__ __launch_bounds__(256) void fr_forward_nhwc_kernel(const float* __restrict__ feat,
+                                                              const float* __restrict__ boxes, float scale, int C, int H,
+                                                              int W, long long npos, int lpp, int per_block, int nblocks,
+                                                              float* __restrict__ out) {
+  const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+  const int band = (nblocks + 7) >> 3;
+  const int chunk = xcd * band + slot;
+  if (slot >= band || chunk >= nblocks) return;
+  const int tid = threadIdx.x;
+  const int ppb = 256 / lpp;                          // positions the workgroup's lanes cover at once
+  const int sub = tid / lpp, cl = tid - sub * lpp;     // position slot of this lane, its float4 inside a 4 * lpp chunk
+  const long long HW = (long long)H * W;
+  const long long p_end = min(npos, (long long)(chunk + 1) * per_block);
+  for (long long p = (long long)chunk * per_block + sub; p < p_end; p += ppb) {
+    const long long n = p / HW;
+    const FrPoints pt = fr_points(boxes + p * 5, scale, POINTS);
+    int o[POINTS][4];                                 // element offsets inside the image (H W C < 2^31: host-checked)
+    float w[POINTS][4];
+#pragma unroll
+    for (int i = 0; i < POINTS; ++i) {
+      const Bil b = bilinear(H, W, pt.py[i], pt.px[i]);
+      const bool in = b.yl >= 0;                      // outside: weight 0 on a valid address (fr.py:26-28 returns 0)
+      o[i][0] = (in ? b.yl * W + b.xl : 0) * C;
+      o[i][1] = (in ? b.yl * W + b.xh : 0) * C;
+      o[i][2] = (in ? b.yh * W + b.xl : 0) * C;
+      o[i][3] = (in ? b.yh * W + b.xh : 0) * C;
+      w[i][0] = b.w1, w[i][1] = b.w2, w[i][2] = b.w3, w[i][3] = b.w4;
+    }
+    const float* img = feat + n * HW * C;
+    for (int c = cl * 4; c < C; c += lpp * 4) {
+      float4 acc = *reinterpret_cast<const float4*>(feat + p * C + c);
+      // (written as two groups of loads; the compiler issues all 4 POINTS + 1 vectors of a lane back to back anyway --
+      // 21 KB in flight per wave, 192 registers, 2 waves per SIMD: enough requests in flight for a memory-bound pass)
+      constexpr int SPLIT = POINTS > 3 ? 3 : POINTS;
+      float4 v[SPLIT][4];
+#pragma unroll
+      for (int i = 0; i < SPLIT; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] = *reinterpret_cast<const float4*>(img + o[i][k] + c);
+#pragma unroll
+      for (int i = 0; i < SPLIT; ++i) {                // :55-63, :166-169 -- the NCHW form's expression per channel
+        acc.x += w[i][0] * v[i][0].x + w[i][1] * v[i][1].x + w[i][2] * v[i][2].x + w[i][3] * v[i][3].x;
+        acc.y += w[i][0] * v[i][0].y + w[i][1] * v[i][1].y + w[i][2] * v[i][2].y + w[i][3] * v[i][3].y;
+        acc.z += w[i][0] * v[i][0].z + w[i][1] * v[i][1].z + w[i][2] * v[i][2].z + w[i][3] * v[i][3].z;
+        acc.w += w[i][0] * v[i][0].w + w[i][1] * v[i][1].w + w[i][2] * v[i][2].w + w[i][3] * v[i][3].w;
+      }
+      if (POINTS > SPLIT) {
+        float4 u[POINTS - SPLIT > 0 ? POINTS - SPLIT : 1][4];
+#pragma unroll
+        for (int i = SPLIT; i < POINTS; ++i)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) u[i - SPLIT][k] = *reinterpret_cast<const float4*>(img + o[i][k] + c);
+#pragma unroll
+        for (int i = SPLIT; i < POINTS; ++i) {
+          const int j = i - SPLIT;
+          acc.x += w[i][0] * u[j][0].x + w[i][1] * u[j][1].x + w[i][2] * u[j][2].x + w[i][3] * u[j][3].x;
+          acc.y += w[i][0] * u[j][0].y + w[i][1] * u[j][1].y + w[i][2] * u[j][2].y + w[i][3] * u[j][3].y;
+          acc.z += w[i][0] * u[j][0].z + w[i][1] * u[j][1].z + w[i][2] * u[j][2].z + w[i][3] * u[j][3].z;
+          acc.w += w[i][0] * u[j][0].w + w[i][1] * u[j][1].w + w[i][2] * u[j][2].w + w[i][3] * u[j][3].w;
+        }
+      }
+      *reinterpret_cast<float4*>(out + p * C + c) = acc;
+    }
+  }
+}
+
 // ---- backward: invert (position, point, corner) -> pixel ---------------------------------------------------
 // item = position * (points + 1) + k; k == points is the identity term (fr.py:213 atomicAdd(bottom_diff + index)).
 struct FrItem {
@@ -211,6 +286,38 @@ extern "C" int rsdet_feature_refine_forward_f32(const float* feat, const float* 
   else
     hipLaunchKernelGGL(fr_forward_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, feat, best_bboxes,
                        spatial_scale, C, H, W, bx, bx * N, cz, out);
+  return rsdet_launch_status();
+}
+
+// feat, out: (N, H, W, C) channels-last fp32; C % 4 == 0 and C / 4 a power of two up to 64 or a multiple of 64.
+extern "C" int rsdet_feature_refine_forward_nhwc_supported(int C) {
+  if (C < 4 || (C & 3)) return 0;
+  const int q = C / 4;
+  return (q >= 64) ? (q % 64 == 0) : ((q & (q - 1)) == 0);
+}
+extern "C" int rsdet_feature_refine_forward_nhwc_f32(const float* feat, const float* best_bboxes, int N, int C, int H,
+                                                     int W, float spatial_scale, int points, float* out, void* stream) {
+  int rc = fr_check(N, C, H, W, points);
+  if (rc) return rc;
+  if (N == 0 || C == 0) return RSDET_OK;
+  if (!rsdet_feature_refine_forward_nhwc_supported(C)) return RSDET_EINVAL;
+  if (!feat || !best_bboxes || !out || (((uintptr_t)feat | (uintptr_t)out) & 15)) return RSDET_EINVAL;
+  if ((long long)H * W * C > 0x7fffffffLL) return RSDET_EINVAL;
+  const long long npos = (long long)N * H * W;
+  const int lpp = C / 4 >= 64 ? 64 : C / 4;
+  // positions per workgroup: ~8 passes of its 256 / lpp position slots, but at least ~2 048 workgroups when there is work
+  const int ppb = 256 / lpp;
+  long long per = (long long)ppb * 8;
+  while (per > ppb && (npos + per - 1) / per < 2048) per -= ppb;
+  const long long nblocks = (npos + per - 1) / per;
+  if (nblocks > 0x7fffff00LL) return RSDET_EINVAL;
+  const unsigned grid = (unsigned)(((nblocks + 7) / 8) * 8);
+  if (points == 1)
+    hipLaunchKernelGGL(fr_forward_nhwc_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, best_bboxes,
+                       spatial_scale, C, H, W, npos, lpp, (int)per, (int)nblocks, out);
+  else
+    hipLaunchKernelGGL(fr_forward_nhwc_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, best_bboxes,
+                       spatial_scale, C, H, W, npos, lpp, (int)per, (int)nblocks, out);
   return rsdet_launch_status();
 }
 

@@ -579,11 +579,15 @@ extern "C" int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* 
 //           BatchNorm's input; grad_gamma[c] = sum_p [side > 0] acc (side - beta) / gamma, grad_beta[c] = sum_p [side > 0] acc
 //           (either NULL: not formed; both NULL: no workspace needed).
 //   mode 3: grad_in = acc + side (the gradient that reaches the same tensor through the identity branch).
-// ws: rsdet_conv1x1_dgrad_ws_size(M, C, O) bytes for mode 2 with sums.
-extern "C" size_t rsdet_conv1x1_dgrad_ws_size(long long M, int C, int O) {
+// ws: rsdet_conv1x1_dgrad_ws_size(M, C, O) bytes for mode 2 with sums.  Mode 2 with ws but NEITHER gradient pointer: the
+// per-slice sums stay in ws as (C, S, 2) floats, S = rsdet_conv1x1_dgrad_slices(M, C, O), for
+// rsdet_bn_sums_finish_multi_f32 (csrc/bn_act.hip) to fold together with other passes' sums.
+extern "C" int rsdet_conv1x1_dgrad_slices(long long M, int C, int O) {
   if (!rsdet_gemm1x1_mfma_supported(M, C, O)) return 0;
-  const G1Grid gr = g1_grid(M, C, true);
-  return (size_t)C * gr.row_lanes() * 2 * sizeof(float);
+  return g1_grid(M, C, true).row_lanes();
+}
+extern "C" size_t rsdet_conv1x1_dgrad_ws_size(long long M, int C, int O) {
+  return (size_t)C * rsdet_conv1x1_dgrad_slices(M, C, O) * 2 * sizeof(float);
 }
 
 extern "C" int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t* wt, long long M, int C, int O, int mode,
@@ -597,13 +601,13 @@ extern "C" int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t
   const void *a_ptr = grad_out, *b_ptr = wt;
   uint16_t* out = grad_in;
   if (mode == G1_BWD_GATE) {
-    const bool sums = grad_gamma || grad_beta;
-    if (grad_gamma && (!gamma || !beta)) return RSDET_EINVAL;
+    const bool fold = grad_gamma || grad_beta, sums = fold || ws;
+    if (sums && (!gamma || !beta)) return RSDET_EINVAL;
     const G1Grid gr = g1_grid(M, C, true);
     if (sums && (!ws || ws_bytes < rsdet_conv1x1_dgrad_ws_size(M, C, O))) return RSDET_EINVAL;
     G1Epi e{nullptr, running_var, gamma, beta, eps, (const bf16_t*)side, 0, sums ? (float*)ws : nullptr, gr.row_lanes()};
     G1_LAUNCH(2, G1_BWD_GATE);
-    if (sums)
+    if (fold)
       hipLaunchKernelGGL(g1_sums_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
                          gr.row_lanes(), grad_gamma, grad_beta);
     return rsdet_launch_status();

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
+#include "rsdet_bf16.h"
 
 namespace rsdet {
 
@@ -72,9 +73,77 @@ __global__ __launch_bounds__(256) void weight_flip_transpose_kernel(const E* __r
   }
 }
 
+// ---- every prepared weight operand of a step in ONE launch --------------------------------------------------------------
+// The backward of a bf16 step wants, per convolution weight (O, T, C) (channels_last (O, C, kh, kw), T = kh kw taps), the
+// operand (C, T, O) with the taps reversed -- the flipped weights of "backward-data through the forward solver"
+// (ops/conv3x3.py; T = 9) and the transposed weights of the 1x1 backward-data GEMM (ops/bottleneck.py; T = 1), the latter
+// optionally with column o scaled by gamma[o] / sqrt(var[o] + eps) of the BatchNorm behind the convolution.  The weights
+// change once per optimizer step, so all of them are prepared by one launch after it (ops/weight_prep.py) instead of
+// one small launch per use: 37 launches -> 1 in the S2ANet-R50 step.  32 x 32 (o, c) tiles through LDS.
+struct WpEntry {         // 64 bytes, packed by the host (ops/weight_prep.py)
+  const bf16_t* src;
+  bf16_t* dst;
+  const float* var;      // NULL: no scale
+  const float* gamma;    // NULL: 1
+  int O, C, T;
+  float eps;
+  int tile0;             // first tile (workgroup) of this entry
+  int tiles_c;           // ceil(C / 32)
+  int tiles_o;           // ceil(O / 32)
+  int pad;
+};
+static_assert(sizeof(WpEntry) == 64, "host packs 64-byte records");
+
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const WpEntry* __restrict__ entries, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;                           // the last entry whose tile0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (entries[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WpEntry e = entries[lo];
+  int l = (int)blockIdx.x - e.tile0;
+  const int per_tap = e.tiles_c * e.tiles_o;
+  const int t = l / per_tap;
+  l -= t * per_tap;
+  const int o0 = (l / e.tiles_c) * 32, c0 = (l % e.tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = o0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (o < e.O && c < e.C) {
+      v = bf2f(e.src[((long long)o * e.T + t) * e.C + c]);
+      if (e.var) {
+        float sc = 1.0f / sqrtf(e.var[o] + e.eps);
+        if (e.gamma) sc *= e.gamma[o];
+        v *= sc;
+      }
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, o = o0 + tx;
+    if (o < e.O && c < e.C) e.dst[((long long)c * e.T + (e.T - 1 - t)) * e.O + o] = f2bf(tile[tx][ty + 8 * i]);
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
+
+// entries: n 64-byte WpEntry records in DEVICE memory (layout above; tile0 ascending from 0, entry j owning T * tiles_c *
+// tiles_o tiles), total_tiles their sum.  An unscaled entry copies bit patterns (bf16 -> fp32 -> bf16 is exact).
+extern "C" int rsdet_weight_prep_multi_bf16(const void* entries, int n, int total_tiles, void* stream) {
+  if (n < 0 || total_tiles < 0) return RSDET_EINVAL;
+  if (n == 0 || total_tiles == 0) return RSDET_OK;
+  if (!entries) return RSDET_EINVAL;
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const WpEntry*)entries, n);
+  return rsdet_launch_status();
+}
 
 extern "C" int rsdet_transpose_last2_f32(const float* in, float* out, int B, int R, int C, void* stream) {
   if (B < 0 || R < 0 || C < 0) return RSDET_EINVAL;

@@ -25,15 +25,19 @@ Applies to: identity blocks (no downsample, stride 1, groups 1) on CUDA with bf1
 weights (Runner(bf16_params=True)), eval-mode affine BatchNorms with fp32 parameters, every parameter trainable, channel
 counts the kernels tile -- the 10 of 13 trainable blocks of ResNet-50, 27 of 30 of ResNet-101.  Everything else runs
 the per-operator forward of models/backbones/resnet.py."""
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
 from .. import _lib
+from . import weight_prep as wprep
 from .bn_act import _memo
 from .conv1x1 import _wrw_split_k
-from .conv3x3 import _flipped, _mfma_wrw
+from .conv3x3 import _mfma_wrw
 
 _ON = True      # False: the per-operator route (what this node is tested against)
+_PTR3, _INT3 = ctypes.c_void_p * 3, ctypes.c_int * 3
 
 
 def _cl_empty(B, C, H, W, device):
@@ -52,21 +56,6 @@ def _conv_bn_fwd(lib, x, w, bn, residual):
     return y
 
 
-def _transposed(lib, w, scale_bn):
-    """(O, C, 1, 1) -> the (C, O) operand of the backward-data GEMM, column o scaled by the BatchNorm behind the
-    convolution when ``scale_bn`` is given."""
-    O, C = w.shape[0], w.shape[1]
-    out = torch.empty((C, O), dtype=torch.bfloat16, device=w.device)
-    var = gamma = None
-    eps = 0.0
-    if scale_bn is not None:
-        gamma, _, _, var, eps = scale_bn
-    rc = lib.rsdet_weight_transpose_scale_bf16(_lib.ptr(w), O, C, _lib.ptr(var), _lib.ptr(gamma), eps, _lib.ptr(out),
-                                               _lib.stream_ptr())
-    _lib.check(rc, "rsdet_weight_transpose_scale_bf16")
-    return out
-
-
 class _Bottleneck(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w2, w3, ga1, be1, ga2, be2, ga3, be3, stats, pad):
@@ -83,6 +72,9 @@ class _Bottleneck(torch.autograd.Function):
         y3 = _conv_bn_fwd(lib, y2, w3, (ga3, be3, m3, v3, e3), x)
         ctx.save_for_backward(x, y1, y2, y3, w1, w2, w3, ga1, be1, ga2, be2, ga3, be3)
         ctx.stats, ctx.pad = stats, pad
+        # the operands of the backward that are functions of the weights alone: one launch per optimizer step for all
+        # blocks (ops/weight_prep.py)
+        ctx.prep = (wprep.entry(w1), wprep.entry(w2, flip=True) if pad == 1 else None, wprep.entry(w3, bn=(v3, ga3, e3)))
         return y3
 
     @staticmethod
@@ -104,31 +96,32 @@ class _Bottleneck(torch.autograd.Function):
             nb = _memo(fn, *shape)
             return torch.empty((nb,), dtype=torch.uint8, device=dev), nb
 
-        # ---- 1: through relu(. + x): gz = gy [y3 > 0] (conv3's branch AND the identity's), bn3's parameter gradients
+        # the beta / gamma sums of the three BatchNorms: per-slice partial tables, folded by ONE launch at the end
+        gsum = torch.empty((2, 2 * C1 + C0), **f32)            # row 0: the gamma gradients (bn1 | bn2 | bn3), row 1: beta
+        gga1, gga2, gga3 = gsum[0, :C1], gsum[0, C1:2 * C1], gsum[0, 2 * C1:]
+        gbe1, gbe2, gbe3 = gsum[1, :C1], gsum[1, C1:2 * C1], gsum[1, 2 * C1:]
+        # ---- 1: through relu(. + x): gz = gy [y3 > 0] (conv3's branch AND the identity's), bn3's sums
         gz = torch.empty_like(gy)
-        gga3, gbe3 = torch.empty((C0,), **f32), torch.empty((C0,), **f32)
-        ws, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C0, HW)
-        rc = lib.rsdet_bn_act_backward_nhwc_fromy_bf16(_lib.ptr(gy), _lib.ptr(y3), _lib.ptr(x), _lib.ptr(v3), _lib.ptr(ga3),
-                                                       _lib.ptr(be3), e3, B, C0, HW, 1, None, _lib.ptr(gz), _lib.ptr(gga3),
-                                                       _lib.ptr(gbe3), _lib.ptr(ws), nb, st)
-        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_bf16")
+        ws3, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C0, HW)
+        rc = lib.rsdet_bn_act_backward_nhwc_fromy_sums_bf16(_lib.ptr(gy), _lib.ptr(y3), _lib.ptr(x), _lib.ptr(v3),
+                                                            _lib.ptr(ga3), _lib.ptr(be3), e3, B, C0, HW, 1, None,
+                                                            _lib.ptr(gz), _lib.ptr(ws3), nb, st)
+        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_sums_bf16")
         gz2 = gz.permute(0, 2, 3, 1).reshape(P, C0)
         # ---- 2: conv3's weight gradient from gz, bn3's scale applied in the fold
         gw3 = _wrw_split_k(gz2, y2, w3, rowscale=(v3, ga3, e3))
         # ---- 3: conv3's backward-data with bn3's scale in the weights and bn2's backward in the epilogue
         gc2 = _cl_empty(B, C1, H, W, dev)
-        gga2, gbe2 = torch.empty((C1,), **f32), torch.empty((C1,), **f32)
-        ws, nb = ws_for("rsdet_conv1x1_dgrad_ws_size", P, C1, C0)
-        wt3 = _transposed(lib, w3, (ga3, be3, m3, v3, e3))
+        ws2, nb = ws_for("rsdet_conv1x1_dgrad_ws_size", P, C1, C0)
+        wt3 = ctx.prep[2].tensor()
         rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gz), _lib.ptr(wt3), P, C1, C0, 2, _lib.ptr(y2), _lib.ptr(v2),
-                                          _lib.ptr(ga2), _lib.ptr(be2), e2, _lib.ptr(gga2), _lib.ptr(gbe2), _lib.ptr(ws), nb,
-                                          _lib.ptr(gc2), st)
+                                          _lib.ptr(ga2), _lib.ptr(be2), e2, None, None, _lib.ptr(ws2), nb, _lib.ptr(gc2), st)
         _lib.check(rc, "rsdet_conv1x1_dgrad_bf16")
         # ---- 4: conv2 (3x3): backward-data through the forward solver on the flipped weights, our split-K weight gradient
         pad = ctx.pad
         gw2 = None
         if pad == 1:
-            gc1 = F.conv2d(gc2, _flipped(w2), None, 1, 1)
+            gc1 = F.conv2d(gc2, ctx.prep[1].tensor(), None, 1, 1)
             if C1 % 128 == 0:
                 gw2 = _mfma_wrw(gc2, y1, w2.dtype)
             if gw2 is None:
@@ -141,12 +134,18 @@ class _Bottleneck(torch.autograd.Function):
         del gc2
         # ---- 5: bn1's backward from y1: gc1 [y1 > 0] gamma1 / sqrt(var1 + eps), its parameter gradients
         g1, gc1 = gc1, torch.empty_like(gc1)
-        gga1, gbe1 = torch.empty((C1,), **f32), torch.empty((C1,), **f32)
-        ws, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C1, HW)
-        rc = lib.rsdet_bn_act_backward_nhwc_fromy_bf16(_lib.ptr(g1), _lib.ptr(y1), None, _lib.ptr(v1), _lib.ptr(ga1),
-                                                       _lib.ptr(be1), e1, B, C1, HW, 1, _lib.ptr(gc1), None, _lib.ptr(gga1),
-                                                       _lib.ptr(gbe1), _lib.ptr(ws), nb, st)
-        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_bf16")
+        ws1, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C1, HW)
+        rc = lib.rsdet_bn_act_backward_nhwc_fromy_sums_bf16(_lib.ptr(g1), _lib.ptr(y1), None, _lib.ptr(v1), _lib.ptr(ga1),
+                                                            _lib.ptr(be1), e1, B, C1, HW, 1, _lib.ptr(gc1), None,
+                                                            _lib.ptr(ws1), nb, st)
+        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_sums_bf16")
+        # ---- the three folds as one launch
+        S = (_memo("rsdet_bn_act_backward_nhwc_fromy_slices", B, C1, HW), _memo("rsdet_conv1x1_dgrad_slices", P, C1, C0),
+             _memo("rsdet_bn_act_backward_nhwc_fromy_slices", B, C0, HW))
+        rc = lib.rsdet_bn_sums_finish_multi_f32(3, _PTR3(ws1.data_ptr(), ws2.data_ptr(), ws3.data_ptr()), _INT3(C1, C1, C0),
+                                                _INT3(*S), _PTR3(gga1.data_ptr(), gga2.data_ptr(), gga3.data_ptr()),
+                                                _PTR3(gbe1.data_ptr(), gbe2.data_ptr(), gbe3.data_ptr()), st)
+        _lib.check(rc, "rsdet_bn_sums_finish_multi_f32")
         gc1_2 = gc1.permute(0, 2, 3, 1).reshape(P, C1)
         # ---- 6: conv1's weight gradient
         gw1 = _wrw_split_k(gc1_2, x, w1)
@@ -154,7 +153,7 @@ class _Bottleneck(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(gz)
-            rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gc1), _lib.ptr(_transposed(lib, w1, None)), P, C0, C1, 3, _lib.ptr(gz),
+            rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gc1), _lib.ptr(ctx.prep[0].tensor()), P, C0, C1, 3, _lib.ptr(gz),
                                               None, None, None, 0.0, None, None, None, 0, _lib.ptr(gx), st)
             _lib.check(rc, "rsdet_conv1x1_dgrad_bf16")
         return gx, gw1, gw2, gw3, gga1, gbe1, gga2, gbe2, gga3, gbe3, None, None
@@ -168,8 +167,8 @@ def _bn_ok(bn):
 
 def _conv_ok(conv, k):
     return (type(conv) is torch.nn.Conv2d and conv.kernel_size == (k, k) and conv.stride == (1, 1) and conv.groups == 1
-            and conv.bias is None and conv.padding_mode == 'zeros' and conv.weight.dtype == torch.bfloat16
-            and conv.weight.requires_grad)
+            and conv.bias is None and conv.padding_mode == 'zeros' and conv.weight.requires_grad
+            and wprep.applies(conv.weight))
 
 
 def bottleneck_applies(block, x):

@@ -16,6 +16,7 @@ import os
 import torch
 import torch.nn.functional as F
 
+from . import weight_prep as wprep
 from ._amp import light_custom_bwd, light_custom_fwd
 
 _ON = True
@@ -45,6 +46,8 @@ class _Conv3x3Same(torch.autograd.Function):
             w = w.to(x.dtype)
         y = F.conv2d(x, w, None if bias is None else bias.to(x.dtype), 1, 1)
         ctx.save_for_backward(x, w)
+        # a bf16 Parameter: its flipped form comes from the once-per-optimizer-step launch of ops/weight_prep.py
+        ctx.prep = wprep.entry(w, flip=True) if wprep.applies(w) else None
         ctx.bias_dtype = None if bias is None else bias.dtype
         return y
 
@@ -57,7 +60,7 @@ class _Conv3x3Same(torch.autograd.Function):
             gy = gy.to(x.dtype)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = F.conv2d(gy, _flipped(w), None, 1, 1)
+            gx = F.conv2d(gy, ctx.prep.tensor() if ctx.prep is not None else _flipped(w), None, 1, 1)
         if ctx.needs_input_grad[1]:
             # bf16 layers whose channel counts fill the kernel's 256-wide tiles: our split-K weight gradient (two
             # launches, no zero-fill / cast launches around it)
@@ -163,6 +166,7 @@ class _Conv3x3BiasReLU(torch.autograd.Function):
         bf = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
         y = _mfma_conv(xb, wb, bf, live, True)
         ctx.save_for_backward(xb, wb, y)
+        ctx.prep = wprep.entry(w, flip=True) if (wb is w and wprep.applies(w)) else None
         ctx.in_dtype, ctx.w_dtype = x.dtype, w.dtype
         ctx.bias_dtype = None if bias is None else bias.dtype
         return y
@@ -177,7 +181,7 @@ class _Conv3x3BiasReLU(torch.autograd.Function):
         g, gb = _bias_relu_backward(gy, y, need_b)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            wf = _flipped(wb)
+            wf = ctx.prep.tensor() if ctx.prep is not None else _flipped(wb)
             B, O, H, W = g.shape
             if _lib_supported(B, H, W, O, wf.shape[0]):
                 gx = _mfma_conv(g, wf, None, None, False)

@@ -19,14 +19,27 @@ class FeatureRefineFunction(torch.autograd.Function):
         assert points in [1, 5]  # fr.py:261
         _lib.require_cuda_f32(features, best_rbboxes)
         lib = _lib.load()
-        features, best_rbboxes = features.contiguous(), best_rbboxes.contiguous()
         N, C, H, W = features.shape
+        # a channels_last map stays channels_last both ways (csrc/feature_refine.hip: the NHWC forward; the backward's
+        # gather is channels-last natively): no layout turn in either direction
+        cl = (features.dim() == 4 and not features.is_contiguous()
+              and features.is_contiguous(memory_format=torch.channels_last)
+              and bool(lib.rsdet_feature_refine_forward_nhwc_supported(C)))
+        best_rbboxes = best_rbboxes.contiguous()
+        if not cl:
+            features = features.contiguous()
         if best_rbboxes.numel() != N * H * W * 5:
             raise _lib.RsdetError("best_rbboxes must hold (N, H, W, 5) = %s boxes, got %s"
                                   % ((N, H, W, 5), tuple(best_rbboxes.shape)))
         ctx.save_for_backward(best_rbboxes)
         ctx.cfg = (float(spatial_scale), int(points))
         out = torch.empty_like(features)
+        if cl:
+            rc = lib.rsdet_feature_refine_forward_nhwc_f32(_lib.ptr(features), _lib.ptr(best_rbboxes), N, C, H, W,
+                                                           float(spatial_scale), int(points), _lib.ptr(out),
+                                                           _lib.stream_ptr())
+            _lib.check(rc, "rsdet_feature_refine_forward_nhwc_f32")
+            return out
         rc = lib.rsdet_feature_refine_forward_f32(_lib.ptr(features), _lib.ptr(best_rbboxes), N, C, H, W,
                                                   float(spatial_scale), int(points), _lib.ptr(out), _lib.stream_ptr())
         _lib.check(rc, "rsdet_feature_refine_forward_f32")
@@ -47,14 +60,16 @@ def feature_refine_backward(grad_output, boxes, scale, points):
     N, C, H, W = grad_output.shape
     if N == 0 or C == 0:
         return torch.zeros_like(grad_output)
-    go = nchw_to_nhwc(grad_output.contiguous())  # channels-last rows for the gather
+    cl = not grad_output.is_contiguous() and grad_output.is_contiguous(memory_format=torch.channels_last)
+    # channels-last rows for the gather: a channels_last gradient IS that matrix, an NCHW one is turned (and turned back)
+    go = grad_output.permute(0, 2, 3, 1) if cl else nchw_to_nhwc(grad_output.contiguous())
     gi = torch.empty_like(go)
     ws_bytes = lib.rsdet_feature_refine_backward_ws_size(N, H, W, points)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
     rc = lib.rsdet_feature_refine_backward_nhwc_f32(_lib.ptr(go), _lib.ptr(boxes), N, C, H, W, scale, points,
                                                     _lib.ptr(gi), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
     _lib.check(rc, "rsdet_feature_refine_backward_nhwc_f32")
-    return nhwc_to_nchw(gi)
+    return gi.permute(0, 3, 1, 2) if cl else nhwc_to_nchw(gi)
 
 
 def feature_refine(features, best_rbboxes, spatial_scale, points=1):

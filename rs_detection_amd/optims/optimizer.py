@@ -216,6 +216,10 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         if rc != _lib.RSDET_OK:
             self._state_buf.zero_()
         _lib.check(rc, self._ENTRY)
+        # the kernel wrote the parameters through raw pointers (no torch version counter moved): operands derived from
+        # the weights (ops/weight_prep.py) are stale from here on
+        from rs_detection_amd.ops.weight_prep import bump_epoch
+        bump_epoch()
         return None
 
     _ENTRY = "rsdet_mt_sgd_step"

@@ -189,3 +189,52 @@ def test_one_node_bottleneck_tracks_the_per_operator_route(cuda):
         assert not bt.bottleneck_applies(blk, x)
     blk.conv1.weight.requires_grad_(False)
     assert not bt.bottleneck_applies(blk, x)
+
+
+def test_prepared_weights_follow_every_kind_of_update(cuda):
+    """ops/weight_prep.py: one launch prepares every registered operand; torch in-place updates (version counter), our
+    fused optimizer (epoch), a reassigned .data (pointer) all make the next request recompute; dead weights drop out."""
+    import gc
+    from rs_detection_amd.ops import weight_prep as wp
+    from rs_detection_amd.ops.conv3x3 import _flipped
+    from rs_detection_amd.optims.optimizer import FusedSGD
+    g = torch.Generator().manual_seed(3)
+
+    def par(*shape):
+        t = torch.randn(*shape, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+        return torch.nn.Parameter(t)
+    w3, w1, wodd = par(96, 64, 3, 3), par(128, 40, 1, 1), par(33, 7, 3, 3)
+    var = torch.empty(128).uniform_(0.5, 2, generator=g).to(cuda)
+    gamma = torch.nn.Parameter(torch.empty(128).uniform_(0.5, 1.5, generator=g).to(cuda))
+    assert wp.applies(w3) and wp.applies(w1) and not wp.applies(w3.detach()) and not wp.applies(w3.float())
+    e3, e1, e1s, eo = wp.entry(w3, flip=True), wp.entry(w1), wp.entry(w1, bn=(var, gamma, 1e-5)), wp.entry(wodd, flip=True)
+    assert wp.entry(w3, flip=True) is e3
+
+    def check():
+        assert torch.equal(e3.tensor(), _flipped(w3.detach()))
+        assert torch.equal(eo.tensor(), _flipped(wodd.detach()))
+        assert torch.equal(e1.tensor(), w1.detach().reshape(128, 40).t().contiguous())
+        ref = (w1.detach().reshape(128, 40).float() * (gamma.detach() * torch.rsqrt(var + 1e-5))[:, None]).t()
+        assert float((e1s.tensor().float() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max())
+    check()
+    with torch.no_grad():
+        w3.mul_(2.0), w1.add_(1.0)                                     # torch in-place: version counters
+    check()
+    opt = FusedSGD([w3, w1, wodd, gamma], lr=0.1, momentum=0.9, weight_decay=0.0)
+    before = w3.detach().clone()
+    for p in (w3, w1, wodd, gamma):
+        p.grad = torch.ones_like(p)
+    opt.step()                                                         # raw-pointer writes: the epoch
+    assert not torch.equal(before, w3.detach())
+    check()
+    w1.data = (w1.detach() * 0.5).contiguous()                         # a new storage: the pointer
+    check()
+    reg = e3.reg
+    n = len(reg._live())
+    del eo, wodd, opt
+    gc.collect()
+    assert len(reg._live()) == n - 1
+    with torch.no_grad():
+        w3.mul_(0.5)
+    check_alive = torch.equal(e3.tensor(), _flipped(w3.detach()))      # the table was rebuilt without the dead entry
+    assert check_alive

@@ -286,6 +286,33 @@ def test_feature_refine_forward_backward(cuda, oracle_c, N, C, H, W, stride, poi
     assert torch.isfinite(lin)
 
 
+@pytest.mark.parametrize("N,C,H,W,stride,points", [(2, 16, 32, 32, 8.0, 5), (1, 256, 128, 128, 8.0, 5),
+                                                    (2, 256, 64, 64, 16.0, 1), (1, 512, 19, 23, 16.0, 5),
+                                                    (3, 4, 9, 7, 8.0, 5), (1, 12, 16, 16, 8.0, 5)])
+def test_feature_refine_channels_last_matches_the_nchw_form(cuda, oracle_c, N, C, H, W, stride, points):
+    """A channels_last map runs the NHWC forward (csrc/feature_refine.hip) and the channels-last gather backward with no
+    layout turn: output and gradient come back channels_last, the output is BIT-identical to the NCHW kernel's (same
+    sums, same order), the gradient within the backward's own tolerance of the oracle.  C = 12 (C / 4 not a power of two)
+    is not taken by the NHWC kernel: the op falls to the NCHW form and still answers."""
+    from rs_detection_amd import _lib
+    from rs_detection_amd.ops.fr import FR
+    rng = np.random.default_rng(11 * H + points + C)
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    boxes = _fr_boxes(rng, N, H, W, stride)
+    taken = bool(_lib.load().rsdet_feature_refine_forward_nhwc_supported(C))
+    assert taken == (C != 12)
+    ref = FR(1.0 / stride, points)(_t(feat, cuda), _t(boxes, cuda))
+    fc = _t(feat, cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = FR(1.0 / stride, points)(fc, _t(boxes, cuda))
+    assert torch.equal(out, ref)
+    if taken and C > 1 and H * W > 1:
+        assert out.is_contiguous(memory_format=torch.channels_last) and not out.is_contiguous()
+    go = rng.standard_normal(feat.shape).astype(np.float32)
+    out.backward(_t(go, cuda).contiguous(memory_format=torch.channels_last))
+    wantg = oracle_c.feature_refine_backward(go, boxes, 1.0 / stride, points)
+    assert np.abs(fc.grad.cpu().numpy() - wantg).max() <= 1e-4 * max(1.0, np.abs(wantg).max())
+
+
 def test_feature_refine_module_and_linearity(cuda):
     """FeatureRefineModule (fr.py:291-347) steps; FR is linear in the features: FR(a+b) = FR(a) + FR(b)."""
     from rs_detection_amd.ops.fr import FR, FeatureRefineModule
