@@ -367,6 +367,15 @@ def next_row_kernels(device):
     t = event_time(lambda: rroi_align_backward(go, rois, (N, C, H, H), (7, 7), 0.25, 2, "v1"), 10, 2)
     row("rroi_idx_count+scan+fill+rroi_gather(backward; incl. the two layout permutes and a %d MB output)"
         % (N * C * H * H * 4 // 2 ** 20), 4 * (R * C * 49 + N * C * H * H), t)
+    import importlib
+    rmod = importlib.import_module("rs_detection_amd.ops.roi_align_rotated_v1")
+    was = rmod._NCHW_GATHER
+    for flag in (False, True):
+        rmod._NCHW_GATHER = flag
+        t = event_time(lambda: rroi_align_backward(go, rois, (N, C, H, H), (7, 7), 0.25, 2, "v1"), 10, 2)
+        row("rroi backward, %s" % ("NCHW written by the gather (one layout turn: grad_out)" if flag else
+                                   "channels-last gather + two layout turns"), 4 * (R * C * 49 + N * C * H * H), t)
+    rmod._NCHW_GATHER = was
     del feat, go
     # -- depthwise convolutions of the VAN backbone (a20): stage-1 shapes of VAN-B3 on two 1024^2 tiles;
     #    bytes = one read + one write of the tensor (forward / backward-data), two reads (backward-weight)
@@ -398,6 +407,14 @@ def next_row_kernels(device):
         go = torch.randn(N, C, H, H, device=device)
         t = event_time(lambda: feature_refine_backward(go, bx, 0.125, pts), 10, 2)
         row("fr_idx_count+scan+fill+gather<%d>(backward; incl. the two layout permutes)" % pts, by, t)
+        # the same op on a channels_last map (what a channels_last step hands over): NHWC forward, no permutes backward
+        fcl = f.detach().contiguous(memory_format=torch.channels_last)
+        t = event_time(lambda: ops.feature_refine(fcl, bx, 0.125, pts), 10, 2)
+        row("fr_forward_nhwc_kernel<%d>(channels_last map)" % pts, by, t)
+        gocl = go.contiguous(memory_format=torch.channels_last)
+        t = event_time(lambda: feature_refine_backward(gocl, bx, 0.125, pts), 10, 2)
+        row("fr_idx_count+scan+fill+gather<%d>(backward; channels_last gradient, no permutes)" % pts, by, t)
+        del fcl, gocl
     del f, go
     # -- convex_sort (f4): the poly_iou_loss shape, 24 candidate points per pair, 20 000 pairs
     nbs, npts = 20000, 24

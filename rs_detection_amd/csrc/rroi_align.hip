@@ -288,6 +288,117 @@ __global__ __launch_bounds__(256) void rroi_gather_nchw_kernel(const float* __re
   }
 }
 
+// Round 5 form of the NCHW-writing gather (taken for C % 4 == 0 when the caller asks for NCHW): what the note above asked
+// for.  Measured at the same 2 x 256 x 256 x 256 level, 512 RoIs (profiles/r05_q_rroi_bwd_kernels.txt): 143.5 us -- against
+// 321 us for the round-2 form below, but still more than the channels-last gather (59.7 us) + the layout turn of its
+// result (58 us), which therefore stays the default (ops/roi_align_rotated_v1.py: _NCHW_GATHER).  Batches of 4 or 16 rows
+// in flight per wave: no difference (222.8 us for the call either way); v_readlane instead of the LDS crossbar for the
+// wave-uniform lane reads: 222.8 -> 207.6 us.  What is left is the imbalance of the walk: the entries cluster where RoIs
+// overlap, a 64-pixel tile there carries thousands of entries on four waves, and 2 workgroups per CU (66 KB of LDS
+// each) cannot hide them.  The index build (count 15 + fill 18 + scan 13 + fills 10 us) is a third of the whole call
+// (170 us) in either form -- the next thing to attack for the 0.25 the call was asked to reach (it stands at 0.12).
+//   * a wave owns 16 consecutive pixels, whose entries are ONE contiguous range of the CSR arrays: it walks that range
+//     flat, 64 entries per coalesced fetch (lane = entry), RG2_DEPTH gradient rows in flight (addresses from registers), and
+//     flushes the accumulator to LDS whenever the walk crosses a pixel boundary -- no per-pixel round trip for the
+//     entries, no serial (pixel, chunk) steps; a pixel's terms are still added in entry order;
+//   * lanes = 4 channels each (256 channels per pass): a gradient row is one 1 KB wave-wide load, a flush one
+//     conflict-free 16-byte LDS write per lane (pitch 260 floats);
+//   * write-out: lane = pixel; a 16-byte LDS read gives 4 channels of the lane's pixel (pitch 260: eight lanes cover
+//     the 32 banks), each stored as part of a 256-byte run of its channel plane.
+// The caller needs neither the (N,H,W,C) -> (N,C,H,W) turn of the whole feature gradient (128 MB each way at a
+// 2 x 256 x 256 x 256 level) nor a pre-zeroed output.
+constexpr int RG2_PITCH = 260;
+#ifndef RG2_DEPTH
+#define RG2_DEPTH 16      // gradient rows in flight per wave (16 KB)
+#endif
+// lane `idx` of v for a WAVE-UNIFORM idx: v_readlane (a few cycles) instead of the LDS crossbar of __shfl (~100 cycles of
+// dependent latency per entry in the walk below)
+__device__ __forceinline__ int rg2_lane(int v, int idx) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx));
+}
+__global__ __launch_bounds__(256) void rroi_gather_nchw_tile_kernel(const float* __restrict__ go_t,
+                                                                    const int* __restrict__ start,
+                                                                    const int* __restrict__ ent_row,
+                                                                    const float* __restrict__ ent_w, long long npix, int C,
+                                                                    int HW, float* __restrict__ grad_nchw) {
+  __shared__ __attribute__((aligned(16))) float s_tile[RG_PIX * RG2_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long p0 = (long long)rsdet_xcd_contiguous(blockIdx.x, gridDim.x) * RG_PIX;
+  const long long pw = p0 + lane;  // this lane's pixel in the write phase
+  const long long n_w = pw / HW, hw_w = pw - n_w * HW;
+  const long long pb = p0 + wave * 16;
+  // the 17 entry boundaries of this wave's 16 pixels: one coalesced load (pixels past the end: empty)
+  const int my_start = lane <= 16 ? start[min(pb + lane, npix)] : 0;
+  const int e_lo = rg2_lane(my_start, 0), e_hi = rg2_lane(my_start, 16);
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool c_ok = c < C;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;                                   // the pixel the walk is in
+    int bound = rg2_lane(my_start, 1);           // first entry of pixel k + 1
+    float* my_rows = s_tile + (wave * 16) * RG2_PITCH + lane * 4;
+    for (int eb = e_lo; eb < e_hi; eb += 64) {
+      const int ne = min(64, e_hi - eb);
+      int row = 0;
+      float w = 0.f;
+      if (lane < ne) {
+        row = ent_row[eb + lane];
+        w = ent_w[eb + lane];
+      }
+      for (int i = 0; i < ne; i += RG2_DEPTH) {
+        float4 v[RG2_DEPTH];
+        float wi[RG2_DEPTH];
+#pragma unroll
+        for (int j = 0; j < RG2_DEPTH; ++j) {
+          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          wi[j] = 0.f;
+          if (i + j < ne) {                      // wave-uniform
+            const int r = rg2_lane(row, i + j);
+            wi[j] = __int_as_float(rg2_lane(__float_as_int(w), i + j));
+            if (c_ok) v[j] = *reinterpret_cast<const float4*>(go_t + (long long)r * C + c);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < RG2_DEPTH; ++j) {
+          if (i + j < ne) {
+            const int e = eb + i + j;
+            while (e >= bound) {                 // the walk leaves pixel k: its sum is complete
+              *reinterpret_cast<float4*>(my_rows + k * RG2_PITCH) = acc;
+              acc = make_float4(0.f, 0.f, 0.f, 0.f);
+              ++k;
+              bound = rg2_lane(my_start, min(k + 1, 16));
+            }
+            acc.x += wi[j] * v[j].x, acc.y += wi[j] * v[j].y, acc.z += wi[j] * v[j].z, acc.w += wi[j] * v[j].w;
+          }
+        }
+      }
+    }
+    for (; k < 16; ++k) {                        // the last pixel with entries, then the empty ones behind it
+      *reinterpret_cast<float4*>(my_rows + k * RG2_PITCH) = acc;
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (pw < npix) {
+      const float* mine = s_tile + lane * RG2_PITCH + wave * 64;
+      float* dst = grad_nchw + (n_w * C + c0 + wave * 64) * HW + hw_w;
+#pragma unroll 4
+      for (int cc = 0; cc < 64; cc += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(mine + cc);
+        const int ch = c0 + wave * 64 + cc;
+        if (ch + 3 < C) {
+          dst[(long long)(cc + 0) * HW] = v.x, dst[(long long)(cc + 1) * HW] = v.y;
+          dst[(long long)(cc + 2) * HW] = v.z, dst[(long long)(cc + 3) * HW] = v.w;
+        } else {
+          if (ch + 0 < C) dst[(long long)(cc + 0) * HW] = v.x;
+          if (ch + 1 < C) dst[(long long)(cc + 1) * HW] = v.y;
+          if (ch + 2 < C) dst[(long long)(cc + 2) * HW] = v.z;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -338,8 +449,13 @@ void rsdet_launch_pixel_gather(const float* rows, const int* start, const int* e
 
 static void launch_pixel_gather_nchw(const float* rows, const int* start, const int* ent_row, const float* ent_w,
                                      long long npix, int C, int HW, float* out_nchw, hipStream_t s) {
-  hipLaunchKernelGGL(rroi_gather_nchw_kernel, dim3((unsigned)((npix + RG_PIX - 1) / RG_PIX)), dim3(256), 0, s, rows,
-                     start, ent_row, ent_w, npix, C, HW, out_nchw);
+  const dim3 grid((unsigned)((npix + RG_PIX - 1) / RG_PIX));
+  if (C % 4 == 0 && (((uintptr_t)rows) & 15) == 0)
+    hipLaunchKernelGGL(rroi_gather_nchw_tile_kernel, grid, dim3(256), 0, s, rows, start, ent_row, ent_w, npix, C, HW,
+                       out_nchw);
+  else
+    hipLaunchKernelGGL(rroi_gather_nchw_kernel, grid, dim3(256), 0, s, rows, start, ent_row, ent_w, npix, C, HW,
+                       out_nchw);
 }
 
 static inline size_t rroi_align256(size_t b) { return (b + 255) & ~(size_t)255; }

@@ -1040,7 +1040,7 @@ def test_rroi_backward_nchw_form_equals_channels_last_form(cuda, monkeypatch):
     """rsdet_rroi_align_v1_backward_gather_nchw_f32 (NCHW written directly) == the default channels-last gather."""
     from rs_detection_amd.ops import roi_align_rotated_v1
     rng = np.random.default_rng(8)
-    for (N, C, H, W, R) in ((2, 256, 64, 64, 60), (1, 20, 37, 41, 9), (3, 64, 16, 16, 5)):
+    for (N, C, H, W, R) in ((2, 256, 64, 64, 60), (1, 20, 37, 41, 9), (3, 64, 16, 16, 5), (1, 512, 23, 27, 30), (2, 18, 9, 9, 4)):
         feat = _t(rng.standard_normal((N, C, H, W)).astype(np.float32), cuda)
         rois = _t(_rois(rng, R, N, W * 4), cuda)
         go = _t(rng.standard_normal((R, C, 7, 7)).astype(np.float32), cuda)
