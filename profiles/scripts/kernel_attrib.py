@@ -21,7 +21,7 @@ os.chdir(ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--model", default="s2anet_r50")
+    ap.add_argument("--model", default="s2anet_r50", choices=["s2anet_r50", "s2anet_r101", "orcnn_van3"])
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--filter", default="")
     ap.add_argument("--top", type=int, default=70)
@@ -35,19 +35,17 @@ def main():
     from rs_detection_amd.utils import synthetic as syn
     dev = torch.device("cuda", 0)
     b16 = args.dtype == "bf16"
-    cfg = bench.s2anet_cfg()
-    if args.model == "s2anet_r101":
-        cfg["model"]["backbone"]["type"] = "Resnet101"
-    runner = Runner(cfg, device=dev, amp_dtype=torch.bfloat16 if b16 else None,
-                    memory_format=torch.channels_last, bf16_params=b16)
-    images = torch.randn(4, 3, 1024, 1024, device=dev).contiguous(memory_format=torch.channels_last)
-    targets = []
-    for t in syn.synthetic_targets(4, rank=0, it=0, num_classes=15):
-        t = dict(t)
-        t["rboxes"], t["labels"] = torch.from_numpy(t["rboxes"]).to(dev), torch.from_numpy(t["labels"]).to(dev)
-        targets.append(t)
-    batches = [(images, targets)]
-
+    orcnn = args.model == "orcnn_van3"
+    if orcnn:
+        from rs_detection_amd.config import Config
+        cfg, batch, ncls = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")), 2, 10
+    else:
+        cfg, batch, ncls = bench.s2anet_cfg(), 4, 15
+        if args.model == "s2anet_r101":
+            cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r101_fpn_1x_dota_rotate_balance_ms.py"))
+    mf = None if orcnn else torch.channels_last
+    runner = Runner(cfg, device=dev, amp_dtype=torch.bfloat16 if b16 else None, memory_format=mf, bf16_params=b16)
+    batches = bench.make_batches(2, batch, 0, ncls, dev, mf, orcnn)
     inner = runner
 
     class _R:

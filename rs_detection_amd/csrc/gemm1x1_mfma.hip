@@ -28,6 +28,7 @@
 // The arithmetic is the convolution's and the BatchNorm's own: bf16 products, fp32 accumulation, the affine map and the
 // residual in fp32, ONE rounding to bf16 (the two-launch form rounded the conv output to bf16 first).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "rsdet_api_internal.h"
@@ -39,7 +40,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 g1_bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned g1_u32x4;
 typedef __attribute__((ext_vector_type(4))) float g1_f32x4;
 
-constexpr int G1_TM = 128, G1_NW = 8, G1_MI = 4, G1_STAGES = 3;
+constexpr int G1_TM = 128, G1_NW = 8, G1_MI = 4;
 constexpr int G1_A_BYTES = G1_TM * 128;                                      // 16 384
 constexpr int G1_A_OPS = G1_A_BYTES / 1024 / G1_NW;                          // LDS-DMA operations per wave and tile: 2
 
@@ -117,7 +118,7 @@ struct g1_const {
 // persistent grid of 8 * n_tiles * mm workgroups (host: ~one per CU); workgroup id -> (XCD x, slot): column panel
 // n = slot % n_tiles, row lane = (slot / n_tiles) * 8 + x -- the workgroups that stream the SAME rows sit on one XCD
 // (ids x, x + 8, ...: round-robin placement; speed only) and share the rows in its L2.
-template <int NI, int EPI>
+template <int NI, int EPI, int G1_STAGES>
 __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel(
     const bf16_t* __restrict__ a, const bf16_t* __restrict__ w, G1Geom g, G1Epi e, int m_tiles, int n_tiles,
     bf16_t* __restrict__ out) {
@@ -255,8 +256,10 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   //   [R residual loads, if i ends a tile] -> [A + B LDS-DMA of step i + 2, if it exists] -> (MFMAs) -> [E stores, if i
   //   ends a tile].  They complete in that order, so "tile s has landed" = all but the N youngest are done, with
   //   N = (stores of step s - 2) + (residual loads + stores of step s - 1) + (DMA of step s + 1).
-  issue(0);
-  if (S > 1) issue(1);
+  constexpr int LEAD = G1_STAGES - 1;               // DMA lead in steps: step s + LEAD is issued during step s
+#pragma unroll
+  for (int l = 0; l < LEAD; ++l)
+    if (l < S) issue(l);
   g1_u32x4 rres[RES ? E_OPS : 1];
   float sum1[EPI == G1_BWD_GATE ? NP : 1][8], sum2[EPI == G1_BWD_GATE ? NP : 1][8];   // EPI 2: this lane's running sums
 #pragma unroll
@@ -264,10 +267,16 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
 #pragma unroll
     for (int k = 0; k < 8; ++k) sum1[pp][k] = 0.f, sum2[pp][k] = 0.f;
   int t_idx = 0, k_idx = 0;                        // tile / K step of the current step
-  bool end1 = false, end2 = false;                 // did step s - 1 / s - 2 end a tile?
+  unsigned ended = 0u;                             // bit d - 1: did step s - d end a tile?
   for (int s = 0; s < S; ++s) {
     const bool last_k = k_idx == KS - 1;
-    g1_wait_vm_n((s + 1 < S ? AB_OPS : 0) + (end2 ? E_OPS : 0) + (end1 ? R_OPS + E_OPS : 0));
+    // younger than the DMA of step s (issued during step s - LEAD): the stores of step s - LEAD, then for every step
+    // j = s - LEAD + 1 .. s - 1 its residual loads, the DMA of step j + LEAD and its stores
+    int young = ((ended >> (LEAD - 1)) & 1u) ? E_OPS : 0;
+#pragma unroll
+    for (int d = 1; d < LEAD; ++d)
+      young += (((ended >> (d - 1)) & 1u) ? R_OPS + E_OPS : 0) + (s - d + LEAD < S ? AB_OPS : 0);
+    g1_wait_vm_n(young);
     g1_barrier();
     const long long p_tile = ((long long)m_lane + (long long)t_idx * lanes_m) * G1_TM;
     // epilogue geometry of this lane: position rows p_tile + wm * 64 + mi * 16 + l15; after the permlane swap pair p
@@ -282,15 +291,21 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
           g1_load16(rres[RES ? mi * NP + pp : 0], e.res + p * g.N + min(n_base + ch0 + 32 * pp, g.N - 8));
       }
     }
-    if (s + 2 < S) issue(s + 2);
+#if !defined(G1_ABL) || G1_ABL != 2
+    if (s + LEAD < S) issue(s + LEAD);
+#else
+    if (s + LEAD < S && s < 1) issue(s + LEAD);     // (ablation 2: compute only -- timing build, wrong values)
+#endif
     const unsigned ab = lds_base + (s % G1_STAGES) * SLOT + a_lane, bb = lds_base + (s % G1_STAGES) * SLOT + b_lane;
+#if !defined(G1_ABL) || G1_ABL != 1
 #pragma unroll
     for (int idx = 0; idx < NR; ++idx) read_frag(0, idx, ab, bb);
     substep(C0{}, BT{}, ab ^ 64u, bb ^ 64u);
     substep(C1{}, BF{}, ab, bb);
+#endif                                              // (ablation 1: data movement only -- timing build, wrong values)
     if (last_k) {
       if (RES) {
-        g1_wait_vm_n(s + 2 < S ? AB_OPS : 0);      // the residual loads are older than the DMA issued above
+        g1_wait_vm_n(s + LEAD < S ? AB_OPS : 0);   // the residual loads are older than the DMA issued above
 #pragma unroll
         for (int r = 0; r < E_OPS; ++r) g1_landed(rres[RES ? r : 0]);
       }
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
         }
       }
     }
-    end2 = end1, end1 = last_k;
+    ended = (ended << 1) | (last_k ? 1u : 0u);
     if (++k_idx == KS) k_idx = 0, ++t_idx;
   }
   if (EPI == G1_BWD_GATE && e.partial) {
@@ -545,10 +560,20 @@ static G1Grid g1_grid(long long M, int N, bool narrow_only) {
   return r;
 }
 
-#define G1_LAUNCH(NI_, EPI_)                                                                                             \
-  hipLaunchKernelGGL((gemm1x1_bn_act_mfma_bf16_kernel<NI_, EPI_>), dim3(gr.blocks()), dim3(64 * G1_NW), 0,                \
+#define G1_LAUNCH_S(NI_, EPI_, ST_)                                                                                      \
+  hipLaunchKernelGGL((gemm1x1_bn_act_mfma_bf16_kernel<NI_, EPI_, ST_>), dim3(gr.blocks()), dim3(64 * G1_NW), 0,           \
                      (hipStream_t)stream, (const bf16_t*)a_ptr, (const bf16_t*)b_ptr, g, e, gr.m_tiles, gr.n_tiles,       \
                      (bf16_t*)out)
+// Ring depth 3 for both tile widths.  Round 5 measured a 4-slot ring (DMA lead 3 steps) for the 128-channel tile: no
+// change on any trunk shape (sum over the 12 shapes of profiles/scripts/gemm1x1_check.py 377.0 vs 376.6 us), and two
+// ablation builds (-DG1_ABL=1: no fragment reads / MFMAs; -DG1_ABL=2: no DMA after the first step) BOTH run within 10 %
+// of the full kernel (profiles/r05_t_gemm1x1_ablation.txt): the two halves overlap, and each is bound on its own -- the
+// movement half at ~12 bytes / clock / CU, i.e. ~85 cycles per 1 KB LDS-DMA piece per CU (32 pieces per step), which is
+// the guide's per-piece issue cost, not latency (hence no gain from a longer lead).  40-50 % of the pieces re-load the
+// SAME weight panel from L2 for every row tile: keeping the panel resident in LDS where it fits (K <= 256 at 256
+// channels: conv3 forward and conv1 backward-data, the epilogue-heavy shapes) is the next step for this kernel.
+#define G1_LAUNCH_4(EPI_) G1_LAUNCH_S(4, EPI_, 3)
+#define G1_LAUNCH_2(EPI_) G1_LAUNCH_S(2, EPI_, 3)
 
 // out[p, o] = act((sum_c x[p, c] weight[o, c]) * scale[o] + shift[o] + residual[p, o]),  x (M, K) / weight (N, K) /
 // residual, out (M, N) bf16 row-major; scale / shift from the BatchNorm's running statistics and affine parameters
@@ -564,9 +589,9 @@ extern "C" int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* 
   const G1Grid gr = g1_grid(M, N, false);
   const void *a_ptr = x, *b_ptr = weight;
   if (gr.ni == 4) {
-    if (residual) G1_LAUNCH(4, G1_FWD_RES); else G1_LAUNCH(4, G1_FWD);
+    if (residual) G1_LAUNCH_4(G1_FWD_RES); else G1_LAUNCH_4(G1_FWD);
   } else {
-    if (residual) G1_LAUNCH(2, G1_FWD_RES); else G1_LAUNCH(2, G1_FWD);
+    if (residual) G1_LAUNCH_2(G1_FWD_RES); else G1_LAUNCH_2(G1_FWD);
   }
   return rsdet_launch_status();
 }
@@ -606,7 +631,7 @@ extern "C" int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t
     const G1Grid gr = g1_grid(M, C, true);
     if (sums && (!ws || ws_bytes < rsdet_conv1x1_dgrad_ws_size(M, C, O))) return RSDET_EINVAL;
     G1Epi e{nullptr, running_var, gamma, beta, eps, (const bf16_t*)side, 0, sums ? (float*)ws : nullptr, gr.row_lanes()};
-    G1_LAUNCH(2, G1_BWD_GATE);
+    G1_LAUNCH_2(G1_BWD_GATE);
     if (fold)
       hipLaunchKernelGGL(g1_sums_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
                          gr.row_lanes(), grad_gamma, grad_beta);
@@ -615,10 +640,12 @@ extern "C" int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t
   const G1Grid gr = g1_grid(M, C, false);
   G1Epi e{nullptr, nullptr, nullptr, nullptr, 0.f, (const bf16_t*)side, 0, nullptr, 0};
   if (mode == G1_BWD_ADD) {
-    if (gr.ni == 4) G1_LAUNCH(4, G1_BWD_ADD); else G1_LAUNCH(2, G1_BWD_ADD);
+    if (gr.ni == 4) G1_LAUNCH_4(G1_BWD_ADD); else G1_LAUNCH_2(G1_BWD_ADD);
   } else {
-    if (gr.ni == 4) G1_LAUNCH(4, G1_FWD); else G1_LAUNCH(2, G1_FWD);
+    if (gr.ni == 4) G1_LAUNCH_4(G1_FWD); else G1_LAUNCH_2(G1_FWD);
   }
   return rsdet_launch_status();
 }
-#undef G1_LAUNCH
+#undef G1_LAUNCH_2
+#undef G1_LAUNCH_4
+#undef G1_LAUNCH_S
