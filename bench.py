@@ -302,7 +302,52 @@ def kernel_rooflines(device, targets):
                          frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None, us=t * 1e6, mboxes_per_s=M / t / 1e6,
                          same_class_pairs=same_cls, mpairs_per_s=same_cls / t / 1e6)
     out.update(bn_act_rows(device, len(ks)))
+    out.update(gemm1x1_rows(device, len(ks)))
     out.update(next_row_kernels(device))
+    return out
+
+
+def gemm1x1_rows(device, B):
+    """The streaming 1x1 GEMM of the bf16 trunk (csrc/gemm1x1_mfma.hip) at the layer2 shapes of the step (B x 128 x 128
+    maps, 512 <-> 128 channels): forward with the BatchNorm + identity + ReLU epilogue, backward-data with the next
+    BatchNorm's backward in the epilogue (mode 2) and with the identity branch's gradient added (mode 3).  HBM-bound:
+    bytes = every operand once (bf16): M K + N K + M N out (+ M N side)."""
+    from rs_detection_amd import _lib as _L
+    lib = _L.load()
+    out = {}
+    M, C0, C1 = B * 128 * 128, 512, 128
+    if not (lib.rsdet_gemm1x1_mfma_supported(M, C0, C1) and lib.rsdet_gemm1x1_mfma_supported(M, C1, C0)):
+        return out
+    bf = dict(dtype=torch.bfloat16, device=device)
+    y2, x = torch.randn(M, C1, **bf), torch.randn(M, C0, **bf)
+    w3 = (torch.randn(C0, C1, device=device) / C1 ** 0.5).bfloat16()
+    wt3, wt1 = w3.t().contiguous(), (torch.randn(C0, C1, device=device) / C1 ** 0.5).bfloat16()
+    st = [torch.rand(C0, device=device) + 0.5 for _ in range(4)]
+    st1 = [torch.rand(C1, device=device) + 0.5 for _ in range(3)]
+    y3, gz, gc2, gx = torch.empty(M, C0, **bf), torch.randn(M, C0, **bf), torch.empty(M, C1, **bf), torch.empty(M, C0, **bf)
+    gc1 = torch.randn(M, C1, **bf)
+    nb = lib.rsdet_conv1x1_dgrad_ws_size(M, C1, C0)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=device)
+    gg, gb = torch.empty(C1, device=device), torch.empty(C1, device=device)
+    s_ = _L.stream_ptr()
+
+    def row(name, by, fn):
+        t = event_time(fn, 20, 3)
+        out[name] = dict(bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+                         traffic=None, us=t * 1e6, tflops=2.0 * M * C0 * C1 / t / 1e12)
+    row("gemm1x1_bn_act_mfma_bf16_kernel<4,1>(conv3 + bn + identity + relu forward, %dx128 -> 512)" % M,
+        2 * (M * C1 + C0 * C1 + 2 * M * C0),
+        lambda: lib.rsdet_conv1x1_bn_act_fwd_bf16(_L.ptr(y2), _L.ptr(w3), M, C0, C1, _L.ptr(st[0]), _L.ptr(st[1]),
+                                                  _L.ptr(st[2]), _L.ptr(st[3]), 1e-5, _L.ptr(x), 1, _L.ptr(y3), s_))
+    row("gemm1x1_bn_act_mfma_bf16_kernel<2,2>+finish(conv3 backward-data + bn2 backward in the epilogue, %dx512 -> 128)" % M,
+        2 * (M * C0 + C0 * C1 + 2 * M * C1),
+        lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gz), _L.ptr(wt3), M, C1, C0, 2, _L.ptr(y2), _L.ptr(st1[0]),
+                                             _L.ptr(st1[1]), _L.ptr(st1[2]), 1e-5, _L.ptr(gg), _L.ptr(gb), _L.ptr(ws), nb,
+                                             _L.ptr(gc2), s_))
+    row("gemm1x1_bn_act_mfma_bf16_kernel<4,3>(conv1 backward-data + identity gradient, %dx128 -> 512)" % M,
+        2 * (M * C1 + C0 * C1 + 2 * M * C0),
+        lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gc1), _L.ptr(wt1), M, C0, C1, 3, _L.ptr(gz), None, None, None, 0.0, None,
+                                             None, None, 0, _L.ptr(gx), s_))
     return out
 
 

@@ -432,6 +432,14 @@ int rsdet_bn_sums_finish_multi_f32(int n, const float* const* partial, const int
                                    float* const* grad_weight, float* const* grad_bias, void* stream);
 int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* weight, const float* bias, const uint8_t* live, int B,
                                 int H, int W, int C, int O, int relu, uint16_t* out, void* stream);
+/* Backward-data of the SECOND convolution of a conv + ReLU tower (s2anet_head.py:130-170: stacked ConvModules) through the
+ * same kernel on the flipped weights, with the FIRST convolution's ReLU / bias backward in its epilogue:
+ * grad_c1 = [c1 > 0] conv3x3(grad, weight_flipped), grad_bias1[o] = sum over positions of grad_c1 (NULL: not formed; ws of
+ * rsdet_conv3x3_dgrad_gate_ws_size bytes when wanted).  grad (B,H,W,C), c1 / grad_c1 (B,H,W,O) bf16 channels-last. */
+size_t rsdet_conv3x3_dgrad_gate_ws_size(int B, int H, int W, int O);
+int rsdet_conv3x3_dgrad_gate_mfma_bf16(const uint16_t* grad, const uint16_t* weight_flipped, const uint16_t* c1, int B,
+                                       int H, int W, int C, int O, uint16_t* grad_c1, float* grad_bias1, void* ws,
+                                       size_t ws_bytes, void* stream);
 /* Weight gradient of the same convolution (csrc/conv3x3_wrw_mfma.hip): split-K implicit GEMM over groups of image rows,
  * fragments by transposing LDS reads (both operands are position-major), fp32 partial tiles folded in a fixed order by a
  * second launch.  grad_out (B, H, W, O), x (B, H, W, C) channels-last bf16; grad_weight (O, 3, 3, C) bf16 (out_bf16 != 0)

@@ -221,6 +221,9 @@ SIGNATURES = {
     "rsdet_conv3x3_wrw_mfma_ws_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "rsdet_conv3x3_wrw_mfma_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                             c_size_t, c_void_p]),
+    "rsdet_conv3x3_dgrad_gate_ws_size": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "rsdet_conv3x3_dgrad_gate_mfma_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_conv3x3_fwd_mfma_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_void_p, c_void_p]),
     "rsdet_bn_act_relu_mask_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

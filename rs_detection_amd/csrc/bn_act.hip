@@ -893,6 +893,10 @@ extern "C" int rsdet_bn_act_backward_nhwc_fromy_sums_bf16(const uint16_t* grad_y
                                     grad_residual, nullptr, nullptr, ws, ws_bytes, true, stream);
 }
 
+void rsdet_launch_sums_finish(const float* partial, int C, int S, float* dweight, float* dbias, hipStream_t stream) {
+  hipLaunchKernelGGL(rsdet::bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, partial, C, S, dweight, dbias);
+}
+
 // Up to RSDET_BN_FINISH_JOBS (C, S, 2) partial-sum tables folded by one launch: job j -> grad_bias[j][c] = sum_s [0],
 // grad_weight[j][c] = sum_s [1] (either pointer NULL: skipped).  One wave per channel, fixed order.
 constexpr int BN_FINISH_JOBS = 4;

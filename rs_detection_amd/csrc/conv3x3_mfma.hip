@@ -78,9 +78,16 @@ __device__ __forceinline__ void c3_landed(c3_u32x4& v) { asm volatile("" : "+v"(
 typedef __attribute__((ext_vector_type(4))) float c3_f32x4;
 constexpr int C3V_MI = 7, C3V_NI = 4, C3V_WM = 112;
 
+// GATE (the backward-data of the SECOND convolution of a conv + ReLU tower, run as this kernel on the flipped weights):
+// the result is the gradient of the first convolution's ReLU output c1, so its own backward step -- zero where c1 <= 0,
+// and the per-channel sum of what is left (the first convolution's bias gradient) -- happens here: `gate` = c1 (same
+// shape as out), `partial` = (O, m_tiles, 2) floats, [0] = this row tile's sum, for rsdet_launch_sums_finish.  The gate
+// pass over the tower's widest tensor (read 2, write 1) and its finish launch are gone.
+template <bool GATE>
 __global__ __launch_bounds__(64 * C3_NW, 1) void conv3x3_fwd_mfma_bf16_kernel(
     const bf16_t* __restrict__ im, const bf16_t* __restrict__ wt, const float* __restrict__ bias,
-    const unsigned char* __restrict__ live, C3Geom g, int m_tiles, int n_tiles, int relu, bf16_t* __restrict__ out) {
+    const unsigned char* __restrict__ live, C3Geom g, int m_tiles, int n_tiles, int relu, bf16_t* __restrict__ out,
+    const bf16_t* __restrict__ gate, float* __restrict__ partial) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[C3_LDS_BYTES];
   const RsdetBandItem item = rsdet_xcd_band(blockIdx.x, m_tiles, n_tiles);
   if (!item.valid) return;
@@ -254,6 +261,12 @@ __global__ __launch_bounds__(64 * C3_NW, 1) void conv3x3_fwd_mfma_bf16_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) bq[ni][k] = (bias && ob + 16 * ni + k < g.O) ? bias[ob + 16 * ni + k] : 0.f;
   bf16_t* orow = out + (((long long)b * g.H + y) * g.W) * g.O;
+  const bf16_t* grow = GATE ? gate + (((long long)b * g.H + y) * g.W) * g.O : nullptr;
+  float csum[C3V_NI][4];
+#pragma unroll
+  for (int ni = 0; ni < C3V_NI; ++ni)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) csum[ni][k] = 0.f;
 #pragma unroll
   for (int mi = 0; mi < C3V_MI; ++mi) {
     const int pl = wm * C3V_WM + mi * 16 + (lane & 15), x = x0 + pl;
@@ -270,10 +283,44 @@ __global__ __launch_bounds__(64 * C3_NW, 1) void conv3x3_fwd_mfma_bf16_kernel(
         if (relu) tt = fmaxf(tt, 0.f);
         v[k] = lv ? tt : 0.f;
       }
+      if (GATE) {
+        const uint2 sd = *reinterpret_cast<const uint2*>(grow + (long long)x * g.O + o);
+        const float s0 = __uint_as_float(sd.x << 16), s1 = __uint_as_float(sd.x & 0xffff0000u);
+        const float s2 = __uint_as_float(sd.y << 16), s3 = __uint_as_float(sd.y & 0xffff0000u);
+        v[0] = s0 > 0.f ? v[0] : 0.f, v[1] = s1 > 0.f ? v[1] : 0.f;
+        v[2] = s2 > 0.f ? v[2] : 0.f, v[3] = s3 > 0.f ? v[3] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) csum[ni][k] += v[k];
+      }
       uint2 pk;
       pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
       pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
       *reinterpret_cast<uint2*>(orow + (long long)x * g.O + o) = pk;
+    }
+  }
+  if (GATE && partial) {
+    // this row tile's channel sums: the 16 lanes of a row hold different positions of the same 4 channels -> butterfly;
+    // the two position halves (wm) meet in LDS (every wave is past its last fragment read after the barrier); fixed order
+#pragma unroll
+    for (int ni = 0; ni < C3V_NI; ++ni)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) csum[ni][k] += __shfl_xor(csum[ni][k], off);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);                        // [wm][C3_TN]
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int ni = 0; ni < C3V_NI; ++ni)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wm * C3_TN + wn * 64 + 16 * ni + 4 * q4 + k] = csum[ni][k];
+    }
+    __syncthreads();
+    if (tid < C3_TN && n_base + tid < g.O) {
+      float2 r;
+      r.x = red[tid] + red[C3_TN + tid];
+      r.y = 0.f;
+      *reinterpret_cast<float2*>(partial + ((long long)(n_base + tid) * m_tiles + item.outer) * 2) = r;
     }
   }
 }
@@ -299,7 +346,34 @@ extern "C" int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* we
   const int m_tiles = B * H * ((W + C3_TM - 1) / C3_TM);
   const int n_tiles = (O + C3_TN - 1) / C3_TN;
   const dim3 grid((unsigned)rsdet_xcd_band_grid(m_tiles, n_tiles));
-  hipLaunchKernelGGL(conv3x3_fwd_mfma_bf16_kernel, grid, dim3(64 * C3_NW), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)weight, bias, live, g, m_tiles, n_tiles, relu, (bf16_t*)out);
+  hipLaunchKernelGGL(conv3x3_fwd_mfma_bf16_kernel<false>, grid, dim3(64 * C3_NW), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)weight, bias, live, g, m_tiles, n_tiles, relu, (bf16_t*)out,
+                     (const bf16_t*)nullptr, (float*)nullptr);
+  return rsdet_launch_status();
+}
+
+// Backward-data of the second convolution of a conv + ReLU tower with the FIRST convolution's ReLU / bias backward in the
+// epilogue (kernel note above): grad_c1 = [c1 > 0] conv3x3(grad, weight_flipped), grad_bias1[o] = sum over positions of
+// grad_c1 (NULL: not formed).  grad (B, H, W, C), c1 / grad_c1 (B, H, W, O) bf16 channels-last; weight_flipped (O, 3, 3, C)
+// (ops/weight_prep.py).  ws: rsdet_conv3x3_dgrad_gate_ws_size bytes when grad_bias1 is wanted.
+extern "C" size_t rsdet_conv3x3_dgrad_gate_ws_size(int B, int H, int W, int O) {
+  if (B < 1 || H < 1 || W < 1 || O < 1) return 0;
+  return (size_t)O * ((size_t)B * H * ((W + C3_TM - 1) / C3_TM)) * 2 * sizeof(float);
+}
+extern "C" int rsdet_conv3x3_dgrad_gate_mfma_bf16(const uint16_t* grad, const uint16_t* weight_flipped, const uint16_t* c1,
+                                                  int B, int H, int W, int C, int O, uint16_t* grad_c1, float* grad_bias1,
+                                                  void* ws, size_t ws_bytes, void* stream) {
+  if (!rsdet_conv3x3_mfma_supported(B, H, W, C, O)) return RSDET_EINVAL;
+  if (!grad || !weight_flipped || !c1 || !grad_c1) return RSDET_EINVAL;
+  if (grad_bias1 && (!ws || ws_bytes < rsdet_conv3x3_dgrad_gate_ws_size(B, H, W, O))) return RSDET_EINVAL;
+  C3Geom g{B, H, W, C, O};
+  const int m_tiles = B * H * ((W + C3_TM - 1) / C3_TM);
+  const int n_tiles = (O + C3_TN - 1) / C3_TN;
+  const dim3 grid((unsigned)rsdet_xcd_band_grid(m_tiles, n_tiles));
+  float* partial = grad_bias1 ? (float*)ws : nullptr;
+  hipLaunchKernelGGL(conv3x3_fwd_mfma_bf16_kernel<true>, grid, dim3(64 * C3_NW), 0, (hipStream_t)stream,
+                     (const bf16_t*)grad, (const bf16_t*)weight_flipped, (const float*)nullptr,
+                     (const unsigned char*)nullptr, g, m_tiles, n_tiles, 0, (bf16_t*)grad_c1, (const bf16_t*)c1, partial);
+  if (grad_bias1) rsdet_launch_sums_finish(partial, O, m_tiles, nullptr, grad_bias1, (hipStream_t)stream);
   return rsdet_launch_status();
 }

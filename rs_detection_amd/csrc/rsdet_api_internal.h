@@ -61,5 +61,7 @@ void rsdet_launch_index_scan(int* cnt, long long n, int* chunk_sum, int* start, 
 // Gather stage shared by the gather-form backward kernels (defined in rroi_align.hip): one wave per output pixel
 // sums  out[pix, :] = sum_{e in [start[pix], start[pix+1])} ent_w[e] * rows[ent_row[e], :]  over C channels
 // (rows and out channels-last); every element of out is written exactly once.
+// csrc/bn_act.hip: (C, S, 2) per-slice partial sums -> dbias[c] = sum_s [0], dweight[c] = sum_s [1] (either NULL: skipped)
+void rsdet_launch_sums_finish(const float* partial, int C, int S, float* dweight, float* dbias, hipStream_t stream);
 void rsdet_launch_pixel_gather(const float* rows, const int* start, const int* ent_row, const float* ent_w,
                                long long npix, int C, float* out_nhwc, hipStream_t stream);

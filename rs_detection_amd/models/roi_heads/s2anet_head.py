@@ -383,6 +383,19 @@ class S2ANetHead(nn.Module):
                         for c in list(self.fam_reg_convs) + list(self.fam_cls_convs) + list(self.odm_reg_convs)
                         + list(self.odm_cls_convs)))
 
+    @staticmethod
+    def _tower(convs, x, lay):
+        """The stacked ConvModules of one tower on the canvas (:207-252 of the reference runs them level by level).  A
+        pair of plain conv + bias + ReLU layers that our 3x3 kernel takes runs as ONE autograd node whose backward folds
+        the first layer's ReLU gate into the second layer's backward-data (ops/conv3x3.py: _Conv3x3Tower2)."""
+        from rs_detection_amd.ops.conv3x3 import conv3x3_tower2, conv3x3_tower2_applies
+        if (len(convs) == 2 and torch.is_grad_enabled() and all(m._fused_bias_relu(x, True) for m in convs)
+                and conv3x3_tower2_applies(x, convs[0].conv, convs[1].conv)):
+            return conv3x3_tower2(x, convs[0].conv, convs[1].conv, lay.live)
+        for conv in convs:
+            x = conv(x, canvas=lay)
+        return x
+
     def forward_packed(self, feats, first_level=0):
         """forward_single (:207-252) for SEVERAL levels at once: the level maps laid side by side in one canvas
         (ops/pyramid.py), every shared-weight convolution of the FAM and ODM towers run once on it -- 13 convolution
@@ -398,14 +411,10 @@ class S2ANetHead(nn.Module):
         strides = self.anchor_strides[first_level:first_level + len(feats)]
         lay = canvas_layout(sizes, feats[0].device)
         xc = pyramid_pack(feats, lay)
-        reg = xc
-        for conv in self.fam_reg_convs:
-            reg = conv(reg, canvas=lay)
+        reg = self._tower(self.fam_reg_convs, xc, lay)
         fam_bbox_preds = pyramid_unpack(conv2d_bias(self.fam_reg, reg), lay)
         if self.training:
-            cls = xc
-            for conv in self.fam_cls_convs:
-                cls = conv(cls, canvas=lay)
+            cls = self._tower(self.fam_cls_convs, xc, lay)
             fam_cls_scores = pyramid_unpack(conv2d_bias(self.fam_cls, cls), lay)
         else:
             fam_cls_scores = [None] * len(feats)
@@ -430,10 +439,8 @@ class S2ANetHead(nn.Module):
             or_feat = or_feat * lay.live_f.to(or_feat.dtype)
         odm_reg_feat = or_feat
         odm_cls_feat = self.or_pool(or_feat) if self.with_orconv else or_feat
-        for conv in self.odm_reg_convs:
-            odm_reg_feat = conv(odm_reg_feat, canvas=lay)
-        for conv in self.odm_cls_convs:
-            odm_cls_feat = conv(odm_cls_feat, canvas=lay)
+        odm_reg_feat = self._tower(self.odm_reg_convs, odm_reg_feat, lay)
+        odm_cls_feat = self._tower(self.odm_cls_convs, odm_cls_feat, lay)
         odm_cls_scores = pyramid_unpack(conv2d_bias(self.odm_cls, odm_cls_feat), lay)
         odm_bbox_preds = pyramid_unpack(conv2d_bias(self.odm_reg, odm_reg_feat), lay)
         return fam_cls_scores, fam_bbox_preds, refine_anchors, odm_cls_scores, odm_bbox_preds

@@ -230,6 +230,83 @@ def conv3x3_bias_relu(x, conv, live=None):
     return _Conv3x3BiasReLU.apply(x, conv.weight, conv.bias, live)
 
 
+_TOWER = True    # two stacked conv + ReLU layers of the head canvas as one autograd node (False: one node per layer)
+
+
+class _Conv3x3Tower2(torch.autograd.Function):
+    """``relu(conv(relu(conv(x, w1) + b1), w2) + b2)`` on the head canvas (the two stacked ConvModules of an S2ANet tower,
+    /root/reference/python/jdet/models/roi_heads/s2anet_head.py:130-170) as ONE node.  Forward: the two launches of
+    _Conv3x3BiasReLU.  Backward, ordered by hand: the second layer's ReLU gate + bias gradient (one pass), its
+    backward-data as csrc/conv3x3_mfma.hip on the flipped weights WITH THE FIRST LAYER'S gate and bias-gradient sums in
+    the epilogue (rsdet_conv3x3_dgrad_gate_mfma_bf16) -- the first layer's own gate pass over the canvas and its fold
+    launch are gone -- then the two weight gradients and the first layer's backward-data.  The gate reads the stored bf16
+    c1 exactly as the per-layer pass does: identical gradients (tests/test_gpu_pyramid.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, live):
+        xb = x.contiguous(memory_format=torch.channels_last)
+        c1 = _mfma_conv(xb, w1, b1, live, True)
+        c2 = _mfma_conv(c1, w2, b2, live, True)
+        ctx.save_for_backward(xb, c1, c2, w1, w2)
+        ctx.prep = (wprep.entry(w1, flip=True), wprep.entry(w2, flip=True))
+        return c2
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _lib
+        xb, c1, c2, w1, w2 = ctx.saved_tensors
+        lib = _lib.load()
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        g2, gb2 = _bias_relu_backward(gy, c2, ctx.needs_input_grad[4])
+        B, O1, H, W = c1.shape
+        g1 = torch.empty_like(c1)
+        need_b1 = ctx.needs_input_grad[2]
+        gb1 = torch.empty((O1,), dtype=torch.float32, device=c1.device) if need_b1 else None
+        nb = lib.rsdet_conv3x3_dgrad_gate_ws_size(B, H, W, O1) if need_b1 else 0
+        ws = torch.empty((nb,), dtype=torch.uint8, device=c1.device) if nb else None
+        rc = lib.rsdet_conv3x3_dgrad_gate_mfma_bf16(_lib.ptr(g2), _lib.ptr(ctx.prep[1].tensor()), _lib.ptr(c1), B, H, W,
+                                                    g2.shape[1], O1, _lib.ptr(g1), _lib.ptr(gb1), _lib.ptr(ws), nb,
+                                                    _lib.stream_ptr())
+        _lib.check(rc, "rsdet_conv3x3_dgrad_gate_mfma_bf16")
+        gw2 = _mfma_wrw(g2, c1, w2.dtype) if ctx.needs_input_grad[3] else None
+        if gw2 is None and ctx.needs_input_grad[3]:
+            gw2 = torch.ops.aten.convolution_backward(g2, c1, w2, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                      (False, True, False))[1]
+        del g2
+        gx = _mfma_conv(g1, ctx.prep[0].tensor(), None, None, False) if ctx.needs_input_grad[0] else None
+        gw1 = _mfma_wrw(g1, xb, w1.dtype) if ctx.needs_input_grad[1] else None
+        if gw1 is None and ctx.needs_input_grad[1]:
+            gw1 = torch.ops.aten.convolution_backward(g1, xb, w1, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                      (False, True, False))[1]
+        return gx, gw1, gb1, gw2, gb2, None
+
+
+def conv3x3_tower2_applies(x, conv_a, conv_b):
+    """Both layers take the MFMA kernel (conv3x3_mfma_applies), their weights are bf16 channels_last Parameters (the
+    prepared flipped operands of ops/weight_prep.py), biases fp32, square channel counts the backward's transposed
+    problems tile."""
+    if not (_TOWER and x.dtype == torch.bfloat16 and conv3x3_mfma_applies(x, conv_a)):
+        return False
+    for c in (conv_a, conv_b):
+        if not (type(c) is torch.nn.Conv2d and tuple(c.weight.shape[2:]) == (3, 3) and tuple(c.stride) == (1, 1)
+                and tuple(c.padding) == (1, 1) and tuple(c.dilation) == (1, 1) and c.groups == 1
+                and c.padding_mode == 'zeros' and wprep.applies(c.weight) and c.bias is not None
+                and c.bias.dtype == torch.float32 and c.weight.shape[0] % 64 == 0 and c.weight.shape[1] % 64 == 0):
+            return False
+    B, C, H, W = x.shape
+    return (conv_a.weight.shape[1] == C and conv_b.weight.shape[1] == conv_a.weight.shape[0]
+            and _lib_supported(B, H, W, conv_a.weight.shape[0], conv_b.weight.shape[0])
+            and _lib_supported(B, H, W, conv_b.weight.shape[0], conv_a.weight.shape[0])
+            and _lib_supported(B, H, W, conv_a.weight.shape[0], C))
+
+
+def conv3x3_tower2(x, conv_a, conv_b, live=None):
+    """The two-layer tower for a pair that conv3x3_tower2_applies() accepted."""
+    return _Conv3x3Tower2.apply(x, conv_a.weight, conv_a.bias, conv_b.weight, conv_b.bias, live)
+
+
 def conv3x3_applies(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1):
     return (_ON and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and weight.shape[0] == weight.shape[1]
             and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1

@@ -514,3 +514,49 @@ def test_conv3x3_wrw_mfma_equals_the_fp32_weight_gradient(cuda, B, C, O, H, W, o
                                               False, (0, 0), 1, (False, True, False))[1]
     err = float((gw.float() - ref).abs().max() / ref.abs().max())
     assert err <= (4e-3 if out_bf16 else 1e-5), err
+
+
+def test_two_layer_tower_node_equals_the_per_layer_nodes(cuda):
+    """S2ANetHead._tower: two stacked conv + bias + ReLU ConvModules on the bf16 canvas as ONE autograd node
+    (ops/conv3x3._Conv3x3Tower2: the first layer's ReLU gate and bias-gradient sums ride in the epilogue of the second
+    layer's backward-data) against the same two layers as two nodes.  The gate is read from the same stored bf16 tensor and
+    the backward-data arithmetic is the same kernel's, so outputs, input gradient and both weight gradients are
+    BIT-identical; the first layer's bias gradient differs by the bf16 rounding of its addends (4e-3 relative)."""
+    from rs_detection_amd.models.roi_heads.s2anet_head import S2ANetHead
+    from rs_detection_amd.models.utils.modules import ConvModule
+    from rs_detection_amd.ops import conv3x3 as c3
+    from rs_detection_amd.ops.pyramid import canvas_layout
+    lay = canvas_layout([(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], cuda)
+    torch.manual_seed(11)
+    tower = torch.nn.ModuleList([ConvModule(256, 256, 3, stride=1, padding=1) for _ in range(2)]).to(cuda)
+    for m in tower:
+        m.conv.weight.data = m.conv.weight.data.bfloat16().contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            m.conv.bias.normal_(0, 0.1)
+    x = (torch.randn((2, 256, lay.Hc, lay.Wc), device=cuda) * lay.live_f).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    go = torch.randn((2, 256, lay.Hc, lay.Wc), device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for on in (True, False):
+        c3._TOWER = on
+        try:
+            xa = x.clone().requires_grad_(True)
+            tower.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                t = S2ANetHead._tower(tower, xa, lay)
+            assert ("_Conv3x3Tower2" in type(t.grad_fn).__name__) == on
+            t.backward(go)
+            outs.append([t.detach(), xa.grad] + [m.conv.weight.grad.clone() for m in tower]
+                        + [m.conv.bias.grad.clone() for m in tower])
+        finally:
+            c3._TOWER = True
+    one, two = outs
+    for i in (0, 1, 2, 3, 5):        # output, grad_x, grad_w1, grad_w2, grad_b2
+        assert torch.equal(one[i], two[i]), i
+    # (the fused epilogue sums the fp32 values BEFORE their bf16 rounding, the per-layer pass sums the stored bf16 gradient:
+    #  ~1e5 roundings of 2^-9 each per channel -- the fused sum is the more accurate of the two)
+    assert float((one[4] - two[4]).abs().max()) <= 4e-3 * float(two[4].abs().max())
+    gaps = (lay.live == 0).view(1, 1, lay.Hc, lay.Wc).expand_as(one[0])
+    assert float(one[0][gaps].float().abs().max()) == 0.0
+    # not taken: fp32 canvas, three layers, no gradient mode
+    assert not c3.conv3x3_tower2_applies(x.float(), tower[0].conv, tower[1].conv)
