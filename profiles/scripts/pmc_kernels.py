@@ -244,5 +244,43 @@ for _ in range(3):
     opt.step()
 ALG4["mt_adamw_kernel"] = dict(call="FusedAdamW update, 60 M parameters (the norm launch is the SGD row's)", bytes=4 * 60_000_000 * (4 + 3))
 ALG.update(ALG4)
-json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
 torch.cuda.synchronize(); print("done (round 4 additions)")
+
+# ---- round 5: the streaming 1x1 GEMM of the bf16 trunk (csrc/gemm1x1_mfma.hip) forward and the two backward-data modes at
+# the layer2 shapes of the step; the tower's gate-fused backward-data (conv3x3_fwd_mfma<true>); FeatureRefine on
+# channels-last maps.  Same calls as bench.gemm1x1_rows / next_row_kernels.
+import bench as _bench
+_bench.gemm1x1_rows(dev, 4)
+M5, C0, C1 = 4 * 128 * 128, 512, 128
+ALG5 = {"gemm1x1_bn_act_mfma_bf16_kernel<4, 1, 3>": dict(call="conv1x1 + bn + identity + relu forward (65536 x 128 -> 512)",
+                                                         bytes=2 * (M5 * C1 + C0 * C1 + 2 * M5 * C0), flops=2.0 * M5 * C0 * C1),
+        "gemm1x1_bn_act_mfma_bf16_kernel<2, 2, 3>": dict(call="conv1x1 backward-data + bn backward in the epilogue (65536 x 512 -> 128)",
+                                                         bytes=2 * (M5 * C0 + C0 * C1 + 2 * M5 * C1), flops=2.0 * M5 * C0 * C1),
+        "gemm1x1_bn_act_mfma_bf16_kernel<4, 3, 3>": dict(call="conv1x1 backward-data + identity gradient (65536 x 128 -> 512)",
+                                                         bytes=2 * (M5 * C1 + C0 * C1 + 2 * M5 * C0), flops=2.0 * M5 * C0 * C1)}
+xq = torch.randn(Bc, Cc, Hc_, Wc_, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+c1q = torch.randn(Bc, Cc, Hc_, Wc_, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+oq = torch.empty_like(xq)
+gbq = torch.empty(Cc, device=dev)
+nbg = _lib_.rsdet_conv3x3_dgrad_gate_ws_size(Bc, Hc_, Wc_, Cc)
+wsg = torch.empty((nbg,), dtype=torch.uint8, device=dev)
+for _ in range(4):
+    _lib_.rsdet_conv3x3_dgrad_gate_mfma_bf16(_L.ptr(xq), _L.ptr(wq), _L.ptr(c1q), Bc, Hc_, Wc_, Cc, Cc, _L.ptr(oq), _L.ptr(gbq),
+                                             _L.ptr(wsg), nbg, _L.stream_ptr())
+ALG5["conv3x3_fwd_mfma_bf16_kernel<true>"] = dict(call="conv3x3_mfma bf16 backward-data + the previous layer's ReLU gate (head canvas)",
+                                                  bytes=2 * (3 * Bc * Hc_ * Wc_ * Cc + 9 * Cc * Cc),
+                                                  flops=2.0 * Bc * Hc_ * Wc_ * Cc * 9 * Cc)
+del xq, c1q, oq
+Nf, Cf, Hf = 2, 256, 128
+ff = torch.randn(Nf, Cf, Hf, Hf, device=dev).contiguous(memory_format=torch.channels_last)
+bxf = torch.rand(Nf, Hf, Hf, 5, device=dev) * 100
+from rs_detection_amd import ops as _ops
+for _ in range(3):
+    _ops.feature_refine(ff, bxf, 0.125, 5)
+    _ops.feature_refine(ff, bxf, 0.125, 1)
+ALG5["fr_forward_nhwc_kernel<5>"] = dict(call="fr_forward_nhwc<5>", bytes=4 * (2 * Nf * Cf * Hf * Hf + 5 * Nf * Hf * Hf))
+ALG5["fr_forward_nhwc_kernel<1>"] = dict(call="fr_forward_nhwc<1>", bytes=4 * (2 * Nf * Cf * Hf * Hf + 5 * Nf * Hf * Hf))
+# (the plain conv3x3 key of round 4 is a substring of the gated kernel's name: give the more specific key precedence)
+ALG = dict(list(ALG5.items()) + [(k, v) for k, v in ALG.items()])
+json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
+torch.cuda.synchronize(); print("done (round 5 additions)")
