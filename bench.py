@@ -329,7 +329,6 @@ def gemm1x1_rows(device, B):
     nb = lib.rsdet_conv1x1_dgrad_ws_size(M, C1, C0)
     ws = torch.empty((nb,), dtype=torch.uint8, device=device)
     gg, gb = torch.empty(C1, device=device), torch.empty(C1, device=device)
-    s_ = _L.stream_ptr()
 
     def row(name, by, fn):
         t = event_time(fn, 20, 3)
@@ -338,16 +337,16 @@ def gemm1x1_rows(device, B):
     row("gemm1x1_bn_act_mfma_bf16_kernel<4,1>(conv3 + bn + identity + relu forward, %dx128 -> 512)" % M,
         2 * (M * C1 + C0 * C1 + 2 * M * C0),
         lambda: lib.rsdet_conv1x1_bn_act_fwd_bf16(_L.ptr(y2), _L.ptr(w3), M, C0, C1, _L.ptr(st[0]), _L.ptr(st[1]),
-                                                  _L.ptr(st[2]), _L.ptr(st[3]), 1e-5, _L.ptr(x), 1, _L.ptr(y3), s_))
+                                                  _L.ptr(st[2]), _L.ptr(st[3]), 1e-5, _L.ptr(x), 1, _L.ptr(y3), _L.stream_ptr()))
     row("gemm1x1_bn_act_mfma_bf16_kernel<2,2>+finish(conv3 backward-data + bn2 backward in the epilogue, %dx512 -> 128)" % M,
         2 * (M * C0 + C0 * C1 + 2 * M * C1),
         lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gz), _L.ptr(wt3), M, C1, C0, 2, _L.ptr(y2), _L.ptr(st1[0]),
                                              _L.ptr(st1[1]), _L.ptr(st1[2]), 1e-5, _L.ptr(gg), _L.ptr(gb), _L.ptr(ws), nb,
-                                             _L.ptr(gc2), s_))
+                                             _L.ptr(gc2), _L.stream_ptr()))
     row("gemm1x1_bn_act_mfma_bf16_kernel<4,3>(conv1 backward-data + identity gradient, %dx128 -> 512)" % M,
         2 * (M * C1 + C0 * C1 + 2 * M * C0),
         lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gc1), _L.ptr(wt1), M, C0, C1, 3, _L.ptr(gz), None, None, None, 0.0, None,
-                                             None, None, 0, _L.ptr(gx), s_))
+                                             None, None, 0, _L.ptr(gx), _L.stream_ptr()))
     return out
 
 

@@ -4,7 +4,7 @@ TAG=${1:-r03_k}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python3 bench.py --dtype bf16 --no-cpu-baseline --steps 30 --warmup 5 > $O/${TAG}_bench_bf16.json 2>/dev/null
+python3 bench.py --dtype bf16 --no-cpu-baseline --steps 30 --warmup 5 > $O/${TAG}_bench_bf16.json 2> $O/${TAG}_bench_bf16.err
 python3 bench.py --model s2anet_r101 --dtype bf16 --no-cpu-baseline --steps 20 --warmup 5 > $O/${TAG}_bench_r101_bf16.json 2>/dev/null
 python3 bench.py --model orcnn_van3 --no-cpu-baseline --steps 10 --warmup 3 > $O/${TAG}_bench_orcnn.json 2>/dev/null
 python3 bench.py --gpus 2 --no-cpu-baseline --no-kernels --steps 5 --warmup 2 > $O/${TAG}_bench_gpus2_gloo.json 2>/dev/null
