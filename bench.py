@@ -744,14 +744,27 @@ def main():
         # contains DDP's gradient all-reduce, a rank that skipped it would leave the others hanging.
         # Counted on the reference's level-by-level head (``bbox_head.packed = False`` for this one step): the canvas of
         # the timed step convolves 13-15 % gap pixels too, and those are not algorithmic flops.
+        # ... and on the library routes (torch's counter sees aten convolutions and GEMMs, not the launches of our own
+        # C ABI: the fused 1x1 GEMMs, the one-node Bottleneck, the 3x3 MFMA kernels and AlignConv's implicit GEMM are
+        # switched to their aten equivalents for this one step -- same algorithmic flops).
         from torch.utils.flop_counter import FlopCounterMode
+        import importlib
         head = runner.model.bbox_head
         head.packed = False
+        routes = [("rs_detection_amd.ops.conv_bn", "_ON"), ("rs_detection_amd.ops.bottleneck", "_ON"),
+                  ("rs_detection_amd.ops.conv1x1", "_ON"), ("rs_detection_amd.ops.conv3x3", "_ON"),
+                  ("rs_detection_amd.ops.conv3x3", "_MFMA"), ("rs_detection_amd.ops.conv3x3", "_TOWER"),
+                  ("rs_detection_amd.ops.dcn_v1", "_MFMA_ALIGNCONV")]
+        saved = [(importlib.import_module(m), a, getattr(importlib.import_module(m), a)) for m, a in routes]
+        for mod, a, _ in saved:
+            setattr(mod, a, False)
         try:
             with FlopCounterMode(display=False) as fc:
                 runner.train_step(images, targets)
         finally:
             head.packed = True
+            for mod, a, v in saved:
+                setattr(mod, a, v)
         step_flops = float(fc.get_total_flops())
     orcnn = args.model == "orcnn_van3"
     timed_batches = batches

@@ -293,8 +293,8 @@ __global__ __launch_bounds__(64 * C3_NW, 1) void conv3x3_fwd_mfma_bf16_kernel(
         for (int k = 0; k < 4; ++k) csum[ni][k] += v[k];
       }
       uint2 pk;
-      pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      pk.x = f2bf2(v[0], v[1]);
+      pk.y = f2bf2(v[2], v[3]);
       *reinterpret_cast<uint2*>(orow + (long long)x * g.O + o) = pk;
     }
   }

@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void conv3x3_wrw_fold_kernel(const float* __re
   T* dst = out + ((long long)o * 9 + t) * g.C + c;
   if constexpr (sizeof(T) == 2) {
     uint2 pk;
-    pk.x = (uint32_t)f2bf(acc.x) | ((uint32_t)f2bf(acc.y) << 16);
-    pk.y = (uint32_t)f2bf(acc.z) | ((uint32_t)f2bf(acc.w) << 16);
+    pk.x = f2bf2(acc.x, acc.y);
+    pk.y = f2bf2(acc.z, acc.w);
     *reinterpret_cast<uint2*>(dst) = pk;
   } else {
     *reinterpret_cast<float4*>(dst) = acc;

@@ -110,6 +110,18 @@ __device__ __forceinline__ void g1_swap16(float& x, float& y) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
 }
 
+// -DG1_STAMP: a diagnostic build (scripts: profiles/scripts/gemm1x1_stamps.py) that records s_memrealtime (100 MHz) at
+// the phase boundaries of the first 512 workgroups into a buffer of its own; no output value depends on a stamp.
+#ifdef G1_STAMP
+__device__ unsigned long long g1_stamp_buf[512 * 64];
+#define G1_ST(i)                                                                                              \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 512 && (i) < 64) g1_stamp_buf[blockIdx.x * 64 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define G1_ST(i)
+#endif
+
 template <typename T, T V>
 struct g1_const {
   static constexpr T value = V;
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   constexpr int TAB = G1_STAGES * SLOT;            // per-channel tables behind the ring (ONE shared array: a second
   __shared__ __attribute__((aligned(1024))) unsigned char lds[TAB + TN * 16];  // one would drain the DMA queue, guide 5.4(a))
   const int tid = threadIdx.x, lane = tid & 63;
+  G1_ST(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xcd = (int)(blockIdx.x & 7u), slot_id = (int)(blockIdx.x >> 3);
   const int n_t = slot_id % n_tiles, lanes_m = (int)(gridDim.x >> 3) / n_tiles * 8;
@@ -260,6 +273,7 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
 #pragma unroll
   for (int l = 0; l < LEAD; ++l)
     if (l < S) issue(l);
+  G1_ST(1);
   g1_u32x4 rres[RES ? E_OPS : 1];
   float sum1[EPI == G1_BWD_GATE ? NP : 1][8], sum2[EPI == G1_BWD_GATE ? NP : 1][8];   // EPI 2: this lane's running sums
 #pragma unroll
@@ -278,6 +292,7 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
       young += (((ended >> (d - 1)) & 1u) ? R_OPS + E_OPS : 0) + (s - d + LEAD < S ? AB_OPS : 0);
     g1_wait_vm_n(young);
     g1_barrier();
+    G1_ST(2 + 4 * s);
     const long long p_tile = ((long long)m_lane + (long long)t_idx * lanes_m) * G1_TM;
     // epilogue geometry of this lane: position rows p_tile + wm * 64 + mi * 16 + l15; after the permlane swap pair p
     // holds channels n_base + wn * 16 NI + 16 (2 p + (q4 & 1)) + 8 (q4 >> 1) + 0..7
@@ -303,12 +318,14 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
     substep(C0{}, BT{}, ab ^ 64u, bb ^ 64u);
     substep(C1{}, BF{}, ab, bb);
 #endif                                              // (ablation 1: data movement only -- timing build, wrong values)
+    G1_ST(3 + 4 * s);
     if (last_k) {
       if (RES) {
         g1_wait_vm_n(s + LEAD < S ? AB_OPS : 0);   // the residual loads are older than the DMA issued above
 #pragma unroll
         for (int r = 0; r < E_OPS; ++r) g1_landed(rres[RES ? r : 0]);
       }
+      G1_ST(4 + 4 * s);
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp) {
         const int c = ch0 + 32 * pp;
@@ -375,18 +392,20 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
           }
           if (p < g.M && in_n) {
             uint4 o;
-            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-            o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+            o.x = f2bf2(v[0], v[1]);
+            o.y = f2bf2(v[2], v[3]);
+            o.z = f2bf2(v[4], v[5]);
+            o.w = f2bf2(v[6], v[7]);
             *reinterpret_cast<uint4*>(out + p * g.N + n_base + c) = o;
           }
         }
       }
     }
+    if (last_k) G1_ST(5 + 4 * s);
     ended = (ended << 1) | (last_k ? 1u : 0u);
     if (++k_idx == KS) k_idx = 0, ++t_idx;
   }
+  G1_ST(63);
   if (EPI == G1_BWD_GATE && e.partial) {
     // this workgroup's sums over all its rows: lanes l15 = 0..15 of a 16-lane row hold different positions of the same
     // 8 channels -> butterfly over the row; the two position halves (wm) meet in LDS (the ring is idle now); fixed order
@@ -655,3 +674,15 @@ extern "C" int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t
 #undef G1_LAUNCH_2
 #undef G1_LAUNCH_4
 #undef G1_LAUNCH_S
+
+#ifdef G1_STAMP
+extern "C" int rsdet_g1_stamps_read(unsigned long long* dst, int clear) {
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(rsdet::g1_stamp_buf), sizeof(unsigned long long) * 512 * 64) != hipSuccess)
+    return RSDET_ELAUNCH;
+  if (clear) {
+    static unsigned long long z[512 * 64];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rsdet::g1_stamp_buf), z, sizeof(z)) != hipSuccess) return RSDET_ELAUNCH;
+  }
+  return RSDET_OK;
+}
+#endif

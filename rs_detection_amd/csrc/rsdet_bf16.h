@@ -14,11 +14,17 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even; NaN stays NaN
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// fp32 -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; rounds 1-4
+// did the same rounding with ~6 integer instructions per value -- a third of the vector instructions of the GEMM
+// epilogues, which in-kernel stamps showed to be VALU-bound: profiles/r05_g1_stamps.txt).  Same result bit for bit on
+// every non-NaN input; a NaN comes back as the hardware's quiet NaN instead of the payload-preserving one.
+typedef __attribute__((ext_vector_type(2))) float rsdet_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 rsdet_bf16x2;
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {      // two values packed as they lie in memory
+  const rsdet_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rsdet_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
   const uint2 r = *reinterpret_cast<const uint2*>(p);
   return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
@@ -26,8 +32,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   uint2 r;
-  r.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-  r.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+  r.x = f2bf2(v.x, v.y);
+  r.y = f2bf2(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = r;
 }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return bf2f(*p); }
@@ -48,10 +54,10 @@ __device__ __forceinline__ F8 ld8(const bf16_t* p) {
 }
 __device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
   uint4 r;
-  r.x = (uint32_t)f2bf(a.v[0]) | ((uint32_t)f2bf(a.v[1]) << 16);
-  r.y = (uint32_t)f2bf(a.v[2]) | ((uint32_t)f2bf(a.v[3]) << 16);
-  r.z = (uint32_t)f2bf(a.v[4]) | ((uint32_t)f2bf(a.v[5]) << 16);
-  r.w = (uint32_t)f2bf(a.v[6]) | ((uint32_t)f2bf(a.v[7]) << 16);
+  r.x = f2bf2(a.v[0], a.v[1]);
+  r.y = f2bf2(a.v[2], a.v[3]);
+  r.z = f2bf2(a.v[4], a.v[5]);
+  r.w = f2bf2(a.v[6], a.v[7]);
 #ifdef RSDET_BN8_NT
   __builtin_nontemporal_store(r.x, reinterpret_cast<uint32_t*>(p));
   __builtin_nontemporal_store(r.y, reinterpret_cast<uint32_t*>(p) + 1);
