@@ -122,6 +122,21 @@ __device__ unsigned long long g1_stamp_buf[512 * 64];
 #define G1_ST(i)
 #endif
 
+// four swaps behind ONE hazard gap (a v_permlane16_swap needs a wait state after a VALU write of its operands; the four
+// pairs are independent)
+__device__ __forceinline__ void g1_swap16x4(float& x0, float& y0, float& x1, float& y1, float& x2, float& y2, float& x3,
+                                            float& y3) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+               "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+               : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(x3), "+v"(y3));
+}
+// max(v, 0) as ONE instruction (fmaxf adds a canonicalising v_max before it; a NaN input gives 0 either way)
+__device__ __forceinline__ float g1_relu(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 template <typename T, T V>
 struct g1_const {
   static constexpr T value = V;
@@ -160,30 +175,6 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   const int prow = lane >> 3;                       // row of the lane inside a 1 KiB piece = (LDS row) & 7
   const int chunk = (lane & 7) ^ prow;              // the source chunk that belongs in the lane's slot
 
-  // ---- per-channel tables (fp32) in LDS: [0] scale, [1] shift (forward) or beta (EPI 2), [2] 1 / gamma (EPI 2)
-  {
-    float* tab = reinterpret_cast<float*>(lds + TAB);
-    for (int c = tid; c < TN; c += 64 * G1_NW) {
-      const int o = min(n_base + c, g.N - 1);
-      float s1 = 1.f, t1 = 0.f, ig = 1.f;
-      if (EPI == G1_BWD_GATE) {
-        if (e.var) s1 = 1.0f / sqrtf(e.var[o] + e.eps);
-        if (e.gamma) {
-          const float gm = e.gamma[o];
-          s1 *= gm;
-          ig = gm != 0.f ? 1.0f / gm : 0.f;
-        }
-        if (e.beta) t1 = e.beta[o];
-      } else if (e.mean) {
-        const float is = 1.0f / sqrtf(e.var[o] + e.eps);
-        s1 = e.gamma ? is * e.gamma[o] : is;
-        t1 = (e.beta ? e.beta[o] : 0.f) - e.mean[o] * s1;
-      } else if (e.beta) {
-        t1 = e.beta[o];
-      }
-      tab[c] = s1, tab[TN + c] = t1, tab[2 * TN + c] = ig;
-    }
-  }
   long long b_off[B_OPS];
 #pragma unroll
   for (int it = 0; it < B_OPS; ++it) {
@@ -241,9 +232,13 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   // during the previous sub-step; with `more`, the NR reads of the next sub-step go out one per MFMA into the other set.
   // LDS reads return in issue order: MFMA j needs the first mi + 2 reads of its set (ni == 0) or the first MI + ni + 1;
   // outstanding may be NR - needed + (next-set reads issued so far).
-  auto substep = [&](auto cur_c, auto more_c, unsigned ab, unsigned bb) {
+  // FIRST: the first sub-step of a tile starts its accumulators from the inline constant 0 (the epilogue then has no
+  // 64 registers per lane to clear: ~1 of its ~8 vector instructions per element, and the epilogue is VALU-bound).
+  auto substep = [&](auto cur_c, auto more_c, auto first_c, unsigned ab, unsigned bb) {
     constexpr int CUR = decltype(cur_c)::value;
     constexpr bool MORE = decltype(more_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value;
+    const g1_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < G1_MI * NI; ++j) {
       const int ni = j / G1_MI, mi = j - ni * G1_MI;
@@ -256,8 +251,8 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
       if (ni == 0) g1_landed(fa[CUR][mi]);
       if (mi == 0) g1_landed(fb[CUR][ni]);
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g1_bf16x8, fb[CUR][ni]),
-                                                            __builtin_bit_cast(g1_bf16x8, fa[CUR][mi]), acc[mi][ni], 0,
-                                                            0, 0);
+                                                            __builtin_bit_cast(g1_bf16x8, fa[CUR][mi]),
+                                                            FIRST ? zero4 : acc[mi][ni], 0, 0, 0);
     }
   };
   using C0 = g1_const<int, 0>;
@@ -274,6 +269,32 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   for (int l = 0; l < LEAD; ++l)
     if (l < S) issue(l);
   G1_ST(1);
+  // (the tables are built AFTER the first tiles' DMA is in flight -- stamps: 2.8 us from kernel start to the first DMA when
+  //  the parameter loads came first; their LDS writes are ordered before the first epilogue by the step barriers)
+  // ---- per-channel tables (fp32) in LDS: [0] scale, [1] shift (forward) or beta (EPI 2), [2] 1 / gamma (EPI 2)
+  {
+    float* tab = reinterpret_cast<float*>(lds + TAB);
+    for (int c = tid; c < TN; c += 64 * G1_NW) {
+      const int o = min(n_base + c, g.N - 1);
+      float s1 = 1.f, t1 = 0.f, ig = 1.f;
+      if (EPI == G1_BWD_GATE) {
+        if (e.var) s1 = 1.0f / sqrtf(e.var[o] + e.eps);
+        if (e.gamma) {
+          const float gm = e.gamma[o];
+          s1 *= gm;
+          ig = gm != 0.f ? 1.0f / gm : 0.f;
+        }
+        if (e.beta) t1 = e.beta[o];
+      } else if (e.mean) {
+        const float is = 1.0f / sqrtf(e.var[o] + e.eps);
+        s1 = e.gamma ? is * e.gamma[o] : is;
+        t1 = (e.beta ? e.beta[o] : 0.f) - e.mean[o] * s1;
+      } else if (e.beta) {
+        t1 = e.beta[o];
+      }
+      tab[c] = s1, tab[TN + c] = t1, tab[2 * TN + c] = ig;
+    }
+  }
   g1_u32x4 rres[RES ? E_OPS : 1];
   float sum1[EPI == G1_BWD_GATE ? NP : 1][8], sum2[EPI == G1_BWD_GATE ? NP : 1][8];   // EPI 2: this lane's running sums
 #pragma unroll
@@ -315,8 +336,9 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
 #if !defined(G1_ABL) || G1_ABL != 1
 #pragma unroll
     for (int idx = 0; idx < NR; ++idx) read_frag(0, idx, ab, bb);
-    substep(C0{}, BT{}, ab ^ 64u, bb ^ 64u);
-    substep(C1{}, BF{}, ab, bb);
+    if (k_idx == 0) substep(C0{}, BT{}, BT{}, ab ^ 64u, bb ^ 64u);
+    else substep(C0{}, BT{}, BF{}, ab ^ 64u, bb ^ 64u);
+    substep(C1{}, BF{}, BF{}, ab, bb);
 #endif                                              // (ablation 1: data movement only -- timing build, wrong values)
     G1_ST(3 + 4 * s);
     if (last_k) {
@@ -348,14 +370,14 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
         const bool in_n = n_base + c < g.N;         // (N % 32 == 0 and c % 8 == 0: inside or outside as a whole)
 #pragma unroll
         for (int mi = 0; mi < G1_MI; ++mi) {
+          // (swapped IN PLACE: the accumulators are dead after this epilogue -- the next tile starts from the constant 0 --
+          //  but the compiler cannot see that through the flat step loop and would copy all 64 of them first)
           float v[8];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float x = acc[mi][2 * pp][k], y = acc[mi][2 * pp + 1][k];
-            g1_swap16(x, y);
-            v[k] = x, v[4 + k] = y;
-            acc[mi][2 * pp][k] = 0.f, acc[mi][2 * pp + 1][k] = 0.f;
-          }
+          for (int k = 0; k < 4; ++k) v[k] = acc[mi][2 * pp][k], v[4 + k] = acc[mi][2 * pp + 1][k];
+          g1_swap16x4(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[mi][2 * pp][k] = v[k], acc[mi][2 * pp + 1][k] = v[4 + k];   // (= "acc is dead")
           float side[8];
           if (RES) {
             const g1_u32x4 r = rres[RES ? mi * NP + pp : 0];
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
             }
             if (e.relu) {
 #pragma unroll
-              for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+              for (int k = 0; k < 8; ++k) v[k] = g1_relu(v[k]);
             }
           }
           if (p < g.M && in_n) {
