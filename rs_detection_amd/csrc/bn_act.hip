@@ -349,7 +349,12 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc8_kernel(const bf16_t* _
   if (RELU && mask) mask[q] = (unsigned char)b0, mask[q + half] = (unsigned char)b1;
 }
 
-template <bool RELU>
+// CFG >= 0: which optional operands exist is a COMPILE-TIME mask (bit 0 mask, 1 x, 2 from_y, 3 fy_res, 4 dres, 5 dx,
+// 6 partial); CFG = -1: decided from the pointers at run time.  The run-time form branches (uniformly) six times per
+// row inside the loop, which keeps the compiler from batching the loads of the four unrolled rows: two or three loads
+// in flight per lane, 0.40-0.45 of the HBM roofline.  The configurations the bf16 step uses are instantiated branch-free.
+constexpr int BN8_MASK = 1, BN8_X = 2, BN8_FROMY = 4, BN8_FYRES = 8, BN8_DRES = 16, BN8_DX = 32, BN8_PARTIAL = 64;
+template <bool RELU, int CFG = -1>
 __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ weight, float eps,
@@ -361,6 +366,13 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
   // xhat = (y - residual - beta) / gamma, exact wherever the ReLU let the value through -- and nowhere else does the
   // gradient count (g = 0 there).  gamma == 0: the term is dropped (the forward carries no information about xhat).
   __shared__ float s_red[BN_NT][17];   // 17: the fold below reads a column of 16 across rows
+  const bool has_mask = CFG >= 0 ? (CFG & BN8_MASK) != 0 : mask != nullptr;
+  const bool has_x = CFG >= 0 ? (CFG & BN8_X) != 0 : x != nullptr;
+  const bool is_fy = CFG >= 0 ? (CFG & BN8_FROMY) != 0 : from_y != 0;
+  const bool has_fyres = CFG >= 0 ? (CFG & BN8_FYRES) != 0 : fy_res != nullptr;
+  const bool has_dres = CFG >= 0 ? (CFG & BN8_DRES) != 0 : dres != nullptr;
+  const bool has_dx = CFG >= 0 ? (CFG & BN8_DX) != 0 : dx != nullptr;
+  const bool has_partial = CFG >= 0 ? (CFG & BN8_PARTIAL) != 0 : partial != nullptr;
   const int G = C >> 3, S = gridDim.x, s = blockIdx.x;
   const int RL = BN_NT / G;            // G is a divisor of 256 (host-checked)
   const int t = threadIdx.x, rl = t / G, c0 = (t % G) * 8;
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     sc = is;
   }
   F8 fb, fiw;
-  if (from_y) {
+  if (is_fy) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) fb.v[k] = 0.f, fiw.v[k] = 1.f;
     if (fy_bias) fb = ldp8(fy_bias + c0);
@@ -398,9 +410,9 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     const long long base = r * C + c0;
     F8 g = ld8(dy + base);
     F8 o;
-    if ((RELU && !mask) || (from_y && partial)) o = ld8(y + base);
+    if ((RELU && !has_mask) || (is_fy && has_partial)) o = ld8(y + base);
     if (RELU) {
-      if (mask) {         // one byte instead of the 16 bytes of y
+      if (has_mask) {         // one byte instead of the 16 bytes of y
         const unsigned b = mask[base >> 3];
 #pragma unroll
         for (int k = 0; k < 8; ++k) g.v[k] = ((b >> k) & 1u) ? g.v[k] : 0.f;
@@ -409,15 +421,15 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
         for (int k = 0; k < 8; ++k) g.v[k] = o.v[k] > 0.f ? g.v[k] : 0.f;
       }
     }
-    if (partial) {
+    if (has_partial) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += g.v[k];
-      if (x) {
+      if (has_x) {
         const F8 v = ld8(x + base);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[8 + k] += g.v[k] * ((v.v[k] - m.v[k]) * is.v[k]);
-      } else if (from_y) {
-        if (fy_res) {
+      } else if (is_fy) {
+        if (has_fyres) {
           const F8 r = ld8(fy_res + base);
 #pragma unroll
           for (int k = 0; k < 8; ++k) o.v[k] -= r.v[k];
@@ -426,15 +438,15 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
         for (int k = 0; k < 8; ++k) acc[8 + k] += g.v[k] * ((o.v[k] - fb.v[k]) * fiw.v[k]);
       }
     }
-    if (dres) st8(dres + base, g);
-    if (dx) {
+    if (has_dres) st8(dres + base, g);
+    if (has_dx) {
       F8 d;
 #pragma unroll
       for (int k = 0; k < 8; ++k) d.v[k] = g.v[k] * sc.v[k];
       st8(dx + base, d);
     }
   }
-  if (!partial) return;
+  if (!has_partial) return;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s_red[t][k] = acc[k];
   __syncthreads();
@@ -451,6 +463,37 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
       partial[((long long)(t * 8 + k) * S + s) * 2 + 1] = tot[8 + k];
     }
   }
+}
+
+// launch the instantiation that matches the operands (branch-free loop) or the run-time form
+template <bool RELU>
+static void bn_act_bwd_nhwc8_launch(int S, hipStream_t s, const bf16_t* dy, const bf16_t* y, const bf16_t* x,
+                                    const float* mean, const float* var, const float* weight, float eps, long long rows,
+                                    int C, int per, bf16_t* dx, bf16_t* dres, float* partial, const unsigned char* mask,
+                                    const bf16_t* fy_res, const float* fy_bias, int from_y) {
+  const int cfg = (mask ? BN8_MASK : 0) | (x ? BN8_X : 0) | (from_y ? BN8_FROMY : 0) | (fy_res ? BN8_FYRES : 0) |
+                  (dres ? BN8_DRES : 0) | (dx ? BN8_DX : 0) | (partial ? BN8_PARTIAL : 0);
+#define BN8_CASE(CFG_)                                                                                              \
+  case CFG_:                                                                                                         \
+    hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<RELU, CFG_>), dim3(S), dim3(BN_NT), 0, s, dy, y, x, mean, var, weight, \
+                       eps, rows, C, per, dx, dres, partial, mask, fy_res, fy_bias, from_y);                         \
+    return;
+  switch (cfg) {
+    BN8_CASE(BN8_FROMY | BN8_FYRES | BN8_DRES | BN8_PARTIAL)             // the Bottleneck node: gate + bn3 sums
+    BN8_CASE(BN8_FROMY | BN8_DX | BN8_PARTIAL)                           // ... bn1's backward; conv + bn without identity
+    BN8_CASE(BN8_FROMY | BN8_FYRES | BN8_DRES | BN8_DX | BN8_PARTIAL)    // conv + bn + identity (per-operator route)
+    BN8_CASE(BN8_FROMY | BN8_DRES | BN8_DX | BN8_PARTIAL)
+    BN8_CASE(BN8_DX | BN8_PARTIAL)                                       // bias + ReLU of the head towers
+    BN8_CASE(BN8_DX)
+    BN8_CASE(BN8_MASK | BN8_X | BN8_DX | BN8_PARTIAL)                    // bn_act with the ReLU bit mask
+    BN8_CASE(BN8_MASK | BN8_X | BN8_DRES | BN8_DX | BN8_PARTIAL)
+    BN8_CASE(BN8_X | BN8_DX | BN8_PARTIAL)
+    BN8_CASE(BN8_X | BN8_DRES | BN8_DX | BN8_PARTIAL)
+    default: break;
+  }
+#undef BN8_CASE
+  hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<RELU, -1>), dim3(S), dim3(BN_NT), 0, s, dy, y, x, mean, var, weight, eps, rows,
+                     C, per, dx, dres, partial, mask, fy_res, fy_bias, from_y);
 }
 
 static inline bool bn_nhwc8_ok(int C) {   // eight channels per lane: C / 8 a divisor of 256
@@ -802,11 +845,11 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char
     if (bn_nhwc8_ok(C) && bn_vec8()) {
       bn_nhwc_split(rows, C, &per, &S, 8);   // never more slices than the four-channel split the workspace is sized for
       if (relu)
-        hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<true>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
-                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask);
+        bn_act_bwd_nhwc8_launch<true>(S, s, grad_y, y, x, running_mean, running_var, weight, eps, rows, C, per, grad_x,
+                                      grad_residual, partial, mask, nullptr, nullptr, 0);
       else
-        hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<false>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,
-                           running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask);
+        bn_act_bwd_nhwc8_launch<false>(S, s, grad_y, y, x, running_mean, running_var, weight, eps, rows, C, per, grad_x,
+                                       grad_residual, partial, mask, nullptr, nullptr, 0);
       if (need_param)
         hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
                            grad_bias);
@@ -852,13 +895,13 @@ static int bn_act_backward_nhwc_fromy(const uint16_t* grad_y, const uint16_t* y,
   const int fy = (grad_weight || sums_only) ? 1 : 0;          // (only the scale gradient needs xhat)
   // running_mean is not needed in this form: pass running_var for it (the kernel loads it, nothing reads it)
   if (relu)
-    hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<true>), dim3(S), dim3(BN_NT), 0, s, gy, yy, (const bf16_t*)nullptr,
-                       running_var, running_var, weight, eps, rows, C, per, (bf16_t*)grad_x, (bf16_t*)grad_residual,
-                       partial, (const unsigned char*)nullptr, rr, bias, fy);
+    bn_act_bwd_nhwc8_launch<true>(S, s, gy, yy, (const bf16_t*)nullptr, running_var, running_var, weight, eps, rows, C, per,
+                                  (bf16_t*)grad_x, (bf16_t*)grad_residual, partial, (const unsigned char*)nullptr, rr, bias,
+                                  fy);
   else
-    hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<false>), dim3(S), dim3(BN_NT), 0, s, gy, yy, (const bf16_t*)nullptr,
-                       running_var, running_var, weight, eps, rows, C, per, (bf16_t*)grad_x, (bf16_t*)grad_residual,
-                       partial, (const unsigned char*)nullptr, rr, bias, fy);
+    bn_act_bwd_nhwc8_launch<false>(S, s, gy, yy, (const bf16_t*)nullptr, running_var, running_var, weight, eps, rows, C, per,
+                                   (bf16_t*)grad_x, (bf16_t*)grad_residual, partial, (const unsigned char*)nullptr, rr, bias,
+                                   fy);
   if (need_param && !sums_only)
     hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
                        grad_bias);
