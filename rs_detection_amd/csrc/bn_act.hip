@@ -215,20 +215,12 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc_kernel(const T* __restr
 // G <= 256 -> 256 / G row lanes share a group column; G > 256 -> a thread owns groups t, t + 256, ... (J of them).
 // Per-thread partial sums of g and g * xhat stay in registers over its rows, row lanes fold in LDS in a fixed order,
 // and `partial` gets the same (C, S, 2) layout the NCHW form hands to bn_act_bwd_finish_kernel.
-// CFG >= 0: the optional operands as a COMPILE-TIME mask (BNC_* bits); -1: from the pointers at run time.  See the
-// eight-channel kernel below: the run-time form's uniform branches inside the row loop keep the loads from batching.
-constexpr int BNC_MASK = 1, BNC_X = 2, BNC_DRES = 16, BNC_DX = 32, BNC_PARTIAL = 64;
-template <bool RELU, typename T, int J, int CFG = -1>
+template <bool RELU, typename T, int J>
 __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ weight, float eps, long long rows, int C, int rows_per,
     T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial, const unsigned char* __restrict__ mask) {
   __shared__ float s_red[BN_NT][8];
-  const bool has_mask = CFG >= 0 ? (CFG & BNC_MASK) != 0 : mask != nullptr;
-  const bool has_x = CFG >= 0 ? (CFG & BNC_X) != 0 : x != nullptr;
-  const bool has_dres = CFG >= 0 ? (CFG & BNC_DRES) != 0 : dres != nullptr;
-  const bool has_dx = CFG >= 0 ? (CFG & BNC_DX) != 0 : dx != nullptr;
-  const bool has_partial = CFG >= 0 ? (CFG & BNC_PARTIAL) != 0 : partial != nullptr;
   const int G = C >> 2, S = gridDim.x, s = blockIdx.x;
   const int RL = J == 1 ? max(BN_NT / G, 1) : 1;
   const int t = threadIdx.x;
@@ -252,12 +244,12 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
 #ifndef RSDET_BN4_UNROLL
 #define RSDET_BN4_UNROLL 1
 #endif
-#pragma unroll (CFG >= 0 ? 4 : RSDET_BN4_UNROLL)
+#pragma unroll RSDET_BN4_UNROLL
     for (long long r = r0 + rl; r < r1; r += RL) {
       const long long base = r * C + c0;
       float4 g = ld4(dy + base);
       if (RELU) {
-        if (has_mask) {       // one byte instead of the 16 / 8 bytes of y
+        if (mask) {       // one byte instead of the 16 / 8 bytes of y
           const unsigned b = mask[base >> 2];
           g.x = (b & 1u) ? g.x : 0.f, g.y = (b & 2u) ? g.y : 0.f, g.z = (b & 4u) ? g.z : 0.f, g.w = (b & 8u) ? g.w : 0.f;
         } else {
@@ -265,19 +257,19 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
           g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
         }
       }
-      if (has_partial) {
+      if (partial) {
         acc[j][0] += g.x, acc[j][1] += g.y, acc[j][2] += g.z, acc[j][3] += g.w;
-        if (has_x) {
+        if (x) {
           const float4 v = ld4(x + base);
           acc[j][4] += g.x * ((v.x - m.x) * is0), acc[j][5] += g.y * ((v.y - m.y) * is1);
           acc[j][6] += g.z * ((v.z - m.z) * is2), acc[j][7] += g.w * ((v.w - m.w) * is3);
         }
       }
-      if (has_dres) st4(dres + base, g);
-      if (has_dx) st4(dx + base, make_float4(g.x * (is0 * w.x), g.y * (is1 * w.y), g.z * (is2 * w.z), g.w * (is3 * w.w)));
+      if (dres) st4(dres + base, g);
+      if (dx) st4(dx + base, make_float4(g.x * (is0 * w.x), g.y * (is1 * w.y), g.z * (is2 * w.z), g.w * (is3 * w.w)));
     }
   }
-  if (!has_partial) return;
+  if (!partial) return;
   if (J == 1) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) s_red[t][k] = acc[0][k];
@@ -866,37 +858,6 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char
   }
   const int G = C / 4;
   const int J = G <= BN_NT ? 1 : (G + BN_NT - 1) / BN_NT;
-  // one lane group per channel group (J == 1: every map of the fp32 step) with a configuration the step uses: the
-  // branch-free instantiation
-  if (J == 1) {
-    const int cfg = (mask ? BNC_MASK : 0) | (x ? BNC_X : 0) | (grad_residual ? BNC_DRES : 0) | (grad_x ? BNC_DX : 0) |
-                    (partial ? BNC_PARTIAL : 0);
-#define RSDET_BN_BWD_C(R, CFG_)                                                                                     \
-  hipLaunchKernelGGL((bn_act_bwd_nhwc_kernel<R, T, 1, CFG_>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean, \
-                     running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask)
-#define RSDET_BN_BWD_CASE(CFG_)                                                                                     \
-  case CFG_:                                                                                                        \
-    if (relu) RSDET_BN_BWD_C(true, CFG_); else RSDET_BN_BWD_C(false, CFG_);                                         \
-    done = true;                                                                                                    \
-    break;
-    bool done = false;
-    switch (cfg) {
-      RSDET_BN_BWD_CASE(BNC_MASK | BNC_X | BNC_DX | BNC_PARTIAL)
-      RSDET_BN_BWD_CASE(BNC_MASK | BNC_X | BNC_DRES | BNC_DX | BNC_PARTIAL)
-      RSDET_BN_BWD_CASE(BNC_X | BNC_DX | BNC_PARTIAL)
-      RSDET_BN_BWD_CASE(BNC_X | BNC_DRES | BNC_DX | BNC_PARTIAL)
-      RSDET_BN_BWD_CASE(BNC_DX | BNC_PARTIAL)
-      default: break;
-    }
-#undef RSDET_BN_BWD_CASE
-#undef RSDET_BN_BWD_C
-    if (done) {
-      if (need_param)
-        hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
-                           grad_bias);
-      return rsdet_launch_status();
-    }
-  }
 #define RSDET_BN_BWD(R, JJ)                                                                                        \
   hipLaunchKernelGGL((bn_act_bwd_nhwc_kernel<R, T, JJ>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,   \
                      running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask)
