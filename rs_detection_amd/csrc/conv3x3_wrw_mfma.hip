@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256) void conv3x3_wrw_fold_kernel(const float* __re
   const int tile = (ob * 3 + ki) * cchunks + cc;
   const float* p = partial + (long long)tile * (W3_TN * W3_TM) + (long long)ol * W3_TM + kj * 64 + cl;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8                         // (eight independent loads in flight; the additions keep their order)
   for (int gi = 0; gi < n_groups; ++gi) {
     const float4 v = *reinterpret_cast<const float4*>(p + (long long)gi * n_tiles * (W3_TN * W3_TM));
     acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;

@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8                         // (eight independent loads in flight; the additions keep their order)
   for (int s = 0; s < S; ++s) {
     const float4 v = *reinterpret_cast<const float4*>(partial + (long long)s * n + i);
     acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
