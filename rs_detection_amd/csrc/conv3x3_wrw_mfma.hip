@@ -238,39 +238,57 @@ __global__ __launch_bounds__(64 * W3_NW, 1) void conv3x3_wrw_mfma_bf16_kernel(
   // s - 1 used), so at that point only the operations of chunks 2s + 2, 2s + 3 may still be in flight
   const bool xw = wave < W3_X_PIECES;                      // this wave also moves an X piece per chunk
   for (int c = 0; c < 4 && c < NC; ++c) issue_next();
-  const int steps = (NC + 1) >> 1;
-  for (int s = 0; s < steps; ++s) {
-    const int c0 = 2 * s, ahead = min(NC, c0 + 4) - min(NC, c0 + 2);   // chunks issued after those of this step: 0..2
-    if (ahead == 2) {
-      if (xw) w3_wait_vm<2 * (W3_G_OPS + 1)>(); else w3_wait_vm<2 * W3_G_OPS>();
-    } else if (ahead == 1) {
-      if (xw) w3_wait_vm<W3_G_OPS + 1>(); else w3_wait_vm<W3_G_OPS>();
-    } else {
-      w3_wait_vm<0>();
-    }
+  // Full steps (two chunks) in a branch-free body, the odd last chunk peeled behind the loop: with "two chunks or one"
+  // decided inside the body the two paths' accumulators met in 96 phi copies per step (v_mov_b32: a third as many
+  // vector instructions again as the step has MFMAs, issued after them -- found by counting the SQ's VALU instructions
+  // against the MFMAs, profiles/r05_roofline.json: 15.1 k vs 3.6 k per wave).
+#define W3_STEP_HEAD(s_)                                                                                               \
+  {                                                                                                                    \
+    const int c0_ = 2 * (s_), ahead = min(NC, c0_ + 4) - min(NC, c0_ + 2); /* chunks issued after this step's: 0..2 */ \
+    if (ahead == 2) {                                                                                                  \
+      if (xw) w3_wait_vm<2 * (W3_G_OPS + 1)>(); else w3_wait_vm<2 * W3_G_OPS>();                                       \
+    } else if (ahead == 1) {                                                                                           \
+      if (xw) w3_wait_vm<W3_G_OPS + 1>(); else w3_wait_vm<W3_G_OPS>();                                                 \
+    } else {                                                                                                           \
+      w3_wait_vm<0>();                                                                                                 \
+    }                                                                                                                  \
+    W3_BARRIER();                                                                                                      \
+    /* (the two chunks of a step sit in consecutive slots: 2s mod 6 is even) */                                        \
+    W3_RG(0, 0, 0); W3_RG(0, 1, 0); W3_RG(0, 2, 0); W3_RG(0, 3, 0);                                                    \
+    W3_RX(0, 0, 0);                                                                                                    \
+    /* the refill of the slots step s - 1 used goes out while those ten reads are in flight */                         \
+    W3_REFILL(c0_);                                                                                                    \
+  }
 #ifndef W3_AB_NO_BARRIER
-    __syncthreads();
+#define W3_BARRIER() __syncthreads()
+#else
+#define W3_BARRIER()
 #endif
-    // (the two chunks of a step sit in consecutive slots: 2s mod 6 is even)
-    W3_RG(0, 0, 0); W3_RG(0, 1, 0); W3_RG(0, 2, 0); W3_RG(0, 3, 0);
-    W3_RX(0, 0, 0);
-    // the refill of the slots step s - 1 used goes out while those ten reads are in flight
 #ifndef W3_AB_NO_DMA
-    if (c0 + 4 < NC) issue_next();
-    if (c0 + 5 < NC) issue_next();
+#define W3_REFILL(c0_)                  \
+  if ((c0_) + 4 < NC) issue_next();     \
+  if ((c0_) + 5 < NC) issue_next()
+#else
+#define W3_REFILL(c0_)
 #endif
-    if (c0 + 1 < NC) {
-      W3_CHUNK(0, true)            // (its first wait, lgkmcnt(2), covers the ten reads above)
-      W3_CHUNK(1, false)
-    } else {
-      W3_CHUNK(0, false)
-    }
-    const int adv = (c0 % W3_SLOTS) == W3_SLOTS - 2 ? -(W3_SLOTS - 2) * W3_SLOT : 2 * W3_SLOT;   // next step's first slot
+  const int full = NC >> 1;
+  for (int s = 0; s < full; ++s) {
+    W3_STEP_HEAD(s)
+    W3_CHUNK(0, true)            // (its first wait, lgkmcnt(2), covers the ten reads above)
+    W3_CHUNK(1, false)
+    const int adv = ((2 * s) % W3_SLOTS) == W3_SLOTS - 2 ? -(W3_SLOTS - 2) * W3_SLOT : 2 * W3_SLOT;   // next step's first slot
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) ga[ni] += adv;
 #pragma unroll
     for (int mi = 0; mi < 6; ++mi) xa[mi][0] += adv, xa[mi][1] += adv;
   }
+  if (NC & 1) {
+    W3_STEP_HEAD(full)
+    W3_CHUNK(0, false)
+  }
+#undef W3_STEP_HEAD
+#undef W3_BARRIER
+#undef W3_REFILL
 
   // ---- epilogue: D[row = (kj, c) local][col = o local]: lane holds rows 4 (lane >> 4) + 0..3 of n-tile mi and column
   // lane & 15 of o-tile ni: four consecutive c of one o -> one 16-byte store into the [o][192] partial tile
