@@ -44,10 +44,26 @@ __device__ __forceinline__ void dw_stage(const float* __restrict__ plane, int H,
   // `add`: a per-channel constant the PRODUCER of this tensor owed it (the bias of the 1x1 convolution in front of
   // the depthwise one, ops/dwconv.py in_bias): added to the in-bounds elements only, the zero padding stays zero
   using G = DwGeom<K, D>;
-  for (int i = threadIdx.x; i < G::LH * G::LW; i += DW_NT) {
+  // every load of the window is ISSUED before the first LDS write: the rolled form of this loop (9 .. 22 trips of
+  // load -> wait -> write per thread) paid one global-memory latency per trip, which is what held the stencil kernels
+  // at 0.26-0.40 of the HBM roofline (round 5: 327 instructions in the 3x3 kernel, TWO of them loads)
+  constexpr int TOTAL = G::LH * G::LW, TRIPS = (TOTAL + DW_NT - 1) / DW_NT;
+  float v[TRIPS];
+#pragma unroll
+  for (int k = 0; k < TRIPS; ++k) {
+    const int i = threadIdx.x + k * DW_NT;
     const int r = i / G::LW, c = i - r * G::LW;
     const int y = y0 - G::halo + r, x = x0 - G::halo + c;
-    s[r * G::LWP + c] = (y >= 0 && y < H && x >= 0 && x < W) ? plane[(long long)y * W + x] + add : 0.f;
+    // (an UNCONDITIONAL load from a clamped address + a select: a conditional load is a branch and a wait per trip)
+    const bool in = i < TOTAL && y >= 0 && y < H && x >= 0 && x < W;
+    const float t = plane[in ? (long long)y * W + x : 0];
+    v[k] = in ? t + add : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < TRIPS; ++k) {
+    const int i = threadIdx.x + k * DW_NT;
+    const int r = i / G::LW, c = i - r * G::LW;
+    if (i < TOTAL) s[r * G::LWP + c] = v[k];
   }
 }
 
