@@ -142,23 +142,49 @@ _NCHW_WRW_MIN_PIXELS = 128 * 128
 _NCHW_WRW_SPLITS = 16
 
 
+# forward / backward-data of the NCHW 1x1 convolutions as batched GEMMs on views instead of MIOpen's 1x1 solver (which
+# launches the same kind of kernel behind a ~23 us host path).  Measured on the Oriented R-CNN step, same box, twice
+# (profiles/r05_orcnn_mm.txt): 65.5 / 65.9 ms through MIOpen, 66.8 / 66.5 ms as bmm on a stride-0 batch view of the
+# weight (torch.matmul(2-D, 3-D) COPIES the map: 92 ms) -- host time equal, the library's kernel choice slightly
+# better.  Off; the switch is what the equivalence test flips.
+_NCHW_MM = False
+
+
 class _Conv1x1NCHW(torch.autograd.Function):
+    """Bias-free 1x1 / stride-1 convolution of an NCHW fp32 map (the VAN block's five per block,
+    /root/reference/python/jdet/models/backbones/van.py:46-122): MIOpen forward and backward-data (or, with _NCHW_MM,
+    batched GEMMs on views: an NCHW map IS N row-major (C, H W) matrices), weight gradient as the split-K batched GEMM
+    below on large maps, MIOpen's kernel on small ones."""
+
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return F.conv2d(x, w, None)
+        if not _NCHW_MM:
+            return F.conv2d(x, w, None)
+        N, C, H, W = x.shape
+        O = w.shape[0]
+        # (bmm on a stride-0 batch view of the weight: torch.matmul(2-D, 3-D) folds the batch into the GEMM's N by COPYING
+        #  the map -- measured 92 ms per step against 67)
+        return torch.bmm(w.view(1, O, C).expand(N, O, C), x.view(N, C, H * W)).view(N, O, H, W)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gw = None
+        N, C, H, W = x.shape
+        O, HW = w.shape[0], H * W
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
-                                                     (True, False, False))[0]
-        if ctx.needs_input_grad[1]:
-            N, C, H, W = x.shape
-            O, HW, S = w.shape[0], H * W, _NCHW_WRW_SPLITS
+            if _NCHW_MM:
+                gx = torch.bmm(w.view(O, C).t().unsqueeze(0).expand(N, C, O), gy.view(N, O, HW)).view(N, C, H, W)
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
+        if ctx.needs_input_grad[1] and not (HW >= _NCHW_WRW_MIN_PIXELS and HW % (_NCHW_WRW_SPLITS * 64) == 0):
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        elif ctx.needs_input_grad[1]:
+            S = _NCHW_WRW_SPLITS
             k = HW // S
             part = torch.empty((N * S, O, C), dtype=x.dtype, device=x.device)
             for n in range(N):
@@ -170,11 +196,12 @@ class _Conv1x1NCHW(torch.autograd.Function):
 
 
 def conv1x1_nchw(x, weight):
-    """``F.conv2d(x, weight)`` for a bias-free 1x1 convolution; on large NCHW fp32 CUDA maps outside autocast the weight
-    gradient is the split-K batched GEMM above."""
+    """``F.conv2d(x, weight)`` for a bias-free 1x1 convolution; on NCHW fp32 CUDA maps outside autocast forward and
+    backward-data are batched GEMMs on views, and on large maps the weight gradient is the split-K batched GEMM above."""
     if (_NCHW_WRW and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32
             and x.is_contiguous() and not torch.is_autocast_enabled() and torch.is_grad_enabled() and weight.requires_grad
-            and tuple(weight.shape[2:]) == (1, 1) and x.shape[2] * x.shape[3] >= _NCHW_WRW_MIN_PIXELS
-            and (x.shape[2] * x.shape[3]) % (_NCHW_WRW_SPLITS * 64) == 0):
+            and tuple(weight.shape[2:]) == (1, 1) and weight.is_contiguous()
+            and (_NCHW_MM or (x.shape[2] * x.shape[3] >= _NCHW_WRW_MIN_PIXELS
+                              and (x.shape[2] * x.shape[3]) % (_NCHW_WRW_SPLITS * 64) == 0))):
         return _Conv1x1NCHW.apply(x, weight)
     return F.conv2d(x, weight, None)
