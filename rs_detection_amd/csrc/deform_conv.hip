@@ -155,9 +155,13 @@ __global__ __launch_bounds__(DCN_NT) void deform_im2col_taps_kernel(const float*
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load at dword alignment
-      pair_t a = {0.f, 0.f}, d = {0.f, 0.f};
-      if (f[tap].lo >= 0) a = *reinterpret_cast<const pair_t*>(imp + f[tap].lo);
-      if (f[tap].hi >= 0) d = *reinterpret_cast<const pair_t*>(imp + f[tap].hi);
+      // (unconditional loads from clamped offsets + selects: a load under a branch is followed by a wait, which
+      //  serialised the 18 pair loads of a channel)
+      const pair_t zero2 = {0.f, 0.f};
+      pair_t a = *reinterpret_cast<const pair_t*>(imp + max(f[tap].lo, 0));
+      pair_t d = *reinterpret_cast<const pair_t*>(imp + max(f[tap].hi, 0));
+      a = f[tap].lo >= 0 ? a : zero2;
+      d = f[tap].hi >= 0 ? d : zero2;
       const int l = f[tap].sel & 3, r = f[tap].sel >> 2;
       const float v1 = l == 1 ? a.x : (l == 2 ? a.y : 0.f), v2 = r == 2 ? a.y : (r == 1 ? a.x : 0.f);
       const float v3 = l == 1 ? d.x : (l == 2 ? d.y : 0.f), v4 = r == 2 ? d.y : (r == 1 ? d.x : 0.f);

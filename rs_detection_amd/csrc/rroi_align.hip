@@ -350,17 +350,16 @@ __global__ __launch_bounds__(256) void rroi_gather_nchw_tile_kernel(const float*
         float wi[RG2_DEPTH];
 #pragma unroll
         for (int j = 0; j < RG2_DEPTH; ++j) {
-          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          wi[j] = 0.f;
-          if (i + j < ne) {                      // wave-uniform
-            const int r = rg2_lane(row, i + j);
-            wi[j] = __int_as_float(rg2_lane(__float_as_int(w), i + j));
-            if (c_ok) v[j] = *reinterpret_cast<const float4*>(go_t + (long long)r * C + c);
-          }
+          // UNCONDITIONAL loads (entry index and channel clamped to valid ones; the unused values are never added): a
+          // load under a branch is followed by a wait for it, which had serialised the whole batch
+          const int ej = min(i + j, ne - 1);
+          const int r = rg2_lane(row, ej);
+          wi[j] = __int_as_float(rg2_lane(__float_as_int(w), ej));
+          v[j] = *reinterpret_cast<const float4*>(go_t + (long long)r * C + (c_ok ? c : 0));
         }
 #pragma unroll
         for (int j = 0; j < RG2_DEPTH; ++j) {
-          if (i + j < ne) {
+          if (i + j < ne) {                      // (wave-uniform)
             const int e = eb + i + j;
             while (e >= bound) {                 // the walk leaves pixel k: its sum is complete
               *reinterpret_cast<float4*>(my_rows + k * RG2_PITCH) = acc;
