@@ -409,7 +409,7 @@ def next_row_kernels(device):
     from rs_detection_amd.ops.roi_align_rotated_v1 import rroi_align_backward
     go = torch.randn(R, C, 7, 7, device=device)
     t = event_time(lambda: rroi_align_backward(go, rois, (N, C, H, H), (7, 7), 0.25, 2, "v1"), 10, 2)
-    row("rroi_idx_count+scan+fill+rroi_gather(backward; incl. the two layout permutes and a %d MB output)"
+    row("rroi_idx_count+scan+fill+rroi_gather(backward, default route; a %d MB output)"
         % (N * C * H * H * 4 // 2 ** 20), 4 * (R * C * 49 + N * C * H * H), t)
     import importlib
     rmod = importlib.import_module("rs_detection_amd.ops.roi_align_rotated_v1")

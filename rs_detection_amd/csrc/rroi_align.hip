@@ -288,15 +288,15 @@ __global__ __launch_bounds__(256) void rroi_gather_nchw_kernel(const float* __re
   }
 }
 
-// Round 5 form of the NCHW-writing gather (taken for C % 4 == 0 when the caller asks for NCHW): what the note above asked
-// for.  Measured at the same 2 x 256 x 256 x 256 level, 512 RoIs (profiles/r05_q_rroi_bwd_kernels.txt): 143.5 us -- against
-// 321 us for the round-2 form below, but still more than the channels-last gather (59.7 us) + the layout turn of its
-// result (58 us), which therefore stays the default (ops/roi_align_rotated_v1.py: _NCHW_GATHER).  Batches of 4 or 16 rows
-// in flight per wave: no difference (222.8 us for the call either way); v_readlane instead of the LDS crossbar for the
-// wave-uniform lane reads: 222.8 -> 207.6 us.  What is left is the imbalance of the walk: the entries cluster where RoIs
-// overlap, a 64-pixel tile there carries thousands of entries on four waves, and 2 workgroups per CU (66 KB of LDS
-// each) cannot hide them.  The index build (count 15 + fill 18 + scan 13 + fills 10 us) is a third of the whole call
-// (170 us) in either form -- the next thing to attack for the 0.25 the call was asked to reach (it stands at 0.12).
+// Round 5 form of the NCHW-writing gather (C % 4 == 0; the default of ops/roi_align_rotated_v1.py): what the note above
+// asked for.  Measured at the same 2 x 256 x 256 x 256 level, 512 RoIs: the CALL (index build + gradient-row turn + gather)
+// 146.7 us against 168.8 us for the channels-last gather + the layout turn of its result, 321 us for the round-2 NCHW form
+// below.  History of this kernel (profiles/r05_q_rroi_bwd_kernels.txt, r05_rroi_uncond.txt): first built with the row loads
+// of a batch under `if (i + j < ne)` -- 222.8 us for the call whether 4 or 16 rows per batch, because a load under a
+// (uniform) branch is followed by a wait for it: the "batch" was serial; v_readlane instead of the LDS crossbar for the
+// wave-uniform lane reads: 207.6; the loads made UNCONDITIONAL (clamped entry index, unused values never added): 146.7.
+// The index build (count 15 + fill 18 + scan 13 + fills 10 us) is now 40 % of the call, which stands at 0.136 of the
+// HBM roofline (asked: 0.25).
 //   * a wave owns 16 consecutive pixels, whose entries are ONE contiguous range of the CSR arrays: it walks that range
 //     flat, 64 entries per coalesced fetch (lane = entry), RG2_DEPTH gradient rows in flight (addresses from registers), and
 //     flushes the accumulator to LDS whenever the walk crosses a pixel boundary -- no per-pixel round trip for the

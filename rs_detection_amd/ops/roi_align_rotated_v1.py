@@ -9,7 +9,7 @@ import torch.nn as nn
 from .. import _lib
 from .layout import nhwc_to_nchw, transpose_last2
 
-_NCHW_GATHER = False    # backward writes NCHW directly (slower kernel, see backward()); the default turns the layout
+_NCHW_GATHER = True     # backward writes NCHW directly from the tiled gather (C % 4 == 0); False: channels-last gather + a layout turn
 
 __all__ = ["ROIAlignRotated_v1", "roi_align_rotated_v1", "rroi_align"]
 
@@ -57,11 +57,11 @@ def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, varian
     go = grad_output.contiguous()
     R, PH, PW = rois.shape[0], output_size[0], output_size[1]
     if sr > 0 and R > 0:
-        # gather form: no fp32 atomics (csrc/rroi_align.hip); channels-last in, channels-last out.
-        # (rsdet_rroi_align_*_backward_gather_nchw_f32 writes NCHW directly and is correct, but its 64-pixel tile
-        # walks each pixel's entry chain serially: 321 us against ~35 us for this one-wave-per-pixel kernel at
-        # 2 x 256 x 256 x 256 -- measured round 2; ``_NCHW_GATHER = True`` selects it (its equivalence test does); the transposes stay for now.)
-        nchw = _NCHW_GATHER
+        # gather form: no fp32 atomics (csrc/rroi_align.hip).  The gradient rows are turned channels-last once (small);
+        # the result is written in NCHW directly by the tiled gather (rroi_gather_nchw_tile_kernel: 147 us for the call at
+        # 2 x 256 x 256 x 256 with 512 RoIs) -- or, for C % 4 != 0 / _NCHW_GATHER = False, channels-last by the
+        # one-wave-per-pixel gather and turned afterwards (169 us).
+        nchw = _NCHW_GATHER and C % 4 == 0
         go_t = transpose_last2(go.view(R, C, PH * PW))            # (R, 49, C): channels-last rows for the gather
         g = torch.empty((N, C, H, W) if nchw else (N, H, W, C), dtype=go.dtype, device=go.device)
         ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)
