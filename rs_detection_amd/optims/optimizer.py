@@ -177,24 +177,38 @@ class FusedSGD(torch.optim.Optimizer, _Mixin):
         self._params_key = tuple(id(p) for p in params)
         self._grad_ptrs = None
 
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad's semantics without its per-parameter bookkeeping (1 ms per Oriented R-CNN step):
+        gradients dropped (set_to_none) or zeroed in place."""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                p.grad = None
+
     @torch.no_grad()
     def step(self, closure=None):
         from rs_detection_amd import _lib
         lib = _lib.load()
         g = self.param_groups[0]
-        params = [p for p in g["params"] if p.grad is not None]
+        # ONE pass over the parameters (700 of them for VAN-B3: `p.grad` is a property call, and three passes with a generic
+        # layout check cost 2.9 ms of host time per Oriented R-CNN step): the parameters that have a gradient, and the
+        # gradient pointers -- autograd hands out fresh gradient tensors after zero_grad(set_to_none=True); DDP's /
+        # the reducer's bucket views stay put and skip the upload below
+        params, ptrs = [], []
+        for p in g["params"]:
+            gr = p.grad
+            if gr is None:
+                continue
+            # (equal strides = same element order; only a gradient whose strides differ takes the dimension-wise check)
+            if gr.dtype != p.dtype or (gr.stride() != p.stride() and not self._same_order(gr, p)):
+                gr = p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(gr)
+            params.append(p)
+            ptrs.append(gr.data_ptr())
         if not params:
             return None
-        if getattr(self, "_params_key", None) != tuple(id(p) for p in params):
+        if getattr(self, "_params_key", None) != tuple(map(id, params)):
             self._build(params, lib)
-        # per step: the gradient pointers (autograd hands out fresh gradient tensors after zero_grad(set_to_none=True);
-        # DDP's bucket views stay put and skip the upload)
-        ptrs = []
-        for p in params:
-            gr = p.grad
-            if gr.dtype != p.dtype or not self._same_order(gr, p):   # rare: a gradient in another layout / dtype
-                gr = p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(gr)
-            ptrs.append(gr.data_ptr())
         if ptrs != self._grad_ptrs:
             import numpy as np
             k = self._ring_at
