@@ -20,7 +20,11 @@ def make_runner(model="s2anet", dtype="f32", tile=256, classes=4, lr=None, image
     warnings.simplefilter("ignore", RuntimeWarning)
     if model == "s2anet":
         cfg = Config(os.path.join(ROOT, "configs", "s2anet", "s2anet_r50_fpn_1x_dota.py"))
-        cfg.model["backbone"].update(pretrained=False, frozen_stages=-1, norm_eval=False)   # from scratch: BN must train
+        # from scratch: BN must train -- unless NORM_EVAL=1, which keeps the shipped configs' eval-mode BatchNorm (running
+        # statistics at their initial 0 / 1: the BatchNorms are per-channel affine layers) so that the bf16 trunk takes the
+        # round-5 routes that exist for eval-mode BatchNorm only (fused 1x1 conv + BN, the one-node Bottleneck)
+        ne = os.environ.get("NORM_EVAL", "0") == "1"
+        cfg.model["backbone"].update(pretrained=False, frozen_stages=-1, norm_eval=ne)
         if backbone:
             cfg.model["backbone"]["type"] = backbone
             if backbone in ("Resnet18", "Resnet34"):
@@ -67,6 +71,9 @@ def train(r, iters, log=25):
 
 
 if __name__ == "__main__":
+    if os.environ.get("ROUTES_OFF", "0") == "1":      # the per-operator routes of round 4 (A/B of the learning curve)
+        import rs_detection_amd.ops.bottleneck as _b, rs_detection_amd.ops.conv_bn as _c, rs_detection_amd.ops.conv3x3 as _t
+        _b._ON = _c._ON = _t._TOWER = False
     model = sys.argv[1] if len(sys.argv) > 1 else "s2anet"
     dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 300
