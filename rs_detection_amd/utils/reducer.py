@@ -42,6 +42,9 @@ class GradReducer:
             with torch.no_grad():
                 for p in model.parameters():
                     dist.broadcast(p.data, 0, group=process_group)
+            # (a write through .data moves no version counter: operands derived from the weights are stale now)
+            from rs_detection_amd.ops.weight_prep import bump_epoch
+            bump_epoch()
         cap = int(bucket_cap_mb * (1 << 20))
         self.buckets, by_dtype = [], {}
         for p in reversed(params):
