@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_finish_kernel(const float* __r
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   float a = 0.f, b = 0.f;
+#pragma unroll 8        // (eight loads in flight; the additions keep their order)
   for (int s = lane; s < S; s += 64) {
     const float2 p = *reinterpret_cast<const float2*>(partial + ((long long)c * S + s) * 2);
     a += p.x;
@@ -734,6 +735,7 @@ __global__ __launch_bounds__(64) void colsum_finish_kernel(const float* __restri
   const int c = threadIdx.x;
   if (c >= C) return;
   float a = 0.f;
+#pragma unroll 8        // (eight loads in flight; the additions keep their order)
   for (int s = 0; s < S; ++s) a += partial[(long long)s * C + c];
   out[c] = a;
 }
@@ -958,6 +960,7 @@ __global__ __launch_bounds__(256) void bn_sums_finish_multi_kernel(BnFinishJobs 
   if (c >= C) return;
   const float* partial = jobs.partial[j];
   float a = 0.f, b = 0.f;
+#pragma unroll 8        // (eight loads in flight; the additions keep their order)
   for (int s = lane; s < S; s += 64) {
     const float2 p = *reinterpret_cast<const float2*>(partial + ((long long)c * S + s) * 2);
     a += p.x;

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64) void dwconv_wgrad_finish_kernel(const float* __
   if (t >= T) return;
   const float* p = partial + (long long)c * nslots * T + t;
   float v = 0.f;
+#pragma unroll 8        // (eight loads in flight; the additions keep their order)
   for (int sl = 0; sl < nslots; ++sl) v += p[(long long)sl * T];
   if (t < T - 1)
     gw[c * (T - 1) + t] = v;

@@ -522,6 +522,7 @@ __global__ __launch_bounds__(256) void g1_sums_finish_kernel(const float* __rest
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   float a = 0.f, b = 0.f;
+#pragma unroll 8        // (eight loads in flight; the additions keep their order)
   for (int s = lane; s < S; s += 64) {
     const float2 p = *reinterpret_cast<const float2*>(partial + ((long long)c * S + s) * 2);
     a += p.x, b += p.y;
