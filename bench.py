@@ -338,15 +338,14 @@ def gemm1x1_rows(device, B):
         2 * (M * C1 + C0 * C1 + 2 * M * C0),
         lambda: lib.rsdet_conv1x1_bn_act_fwd_bf16(_L.ptr(y2), _L.ptr(w3), M, C0, C1, _L.ptr(st[0]), _L.ptr(st[1]),
                                                   _L.ptr(st[2]), _L.ptr(st[3]), 1e-5, _L.ptr(x), 1, _L.ptr(y3), _L.stream_ptr()))
-    row("gemm1x1_bn_act_mfma_bf16_kernel<2,2>+finish(conv3 backward-data + bn2 backward in the epilogue, %dx512 -> 128)" % M,
+    row("gemm1x1_bn_act_mfma_bf16_kernel<2,2>+finish(conv3 backward-data + bn2's gate and sums in the epilogue, %dx512 -> 128)" % M,
         2 * (M * C0 + C0 * C1 + 2 * M * C1),
-        lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gz), _L.ptr(wt3), M, C1, C0, 2, _L.ptr(y2), _L.ptr(st1[0]),
-                                             _L.ptr(st1[1]), _L.ptr(st1[2]), 1e-5, _L.ptr(gg), _L.ptr(gb), _L.ptr(ws), nb,
+        lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gz), _L.ptr(wt3), M, C1, C0, 2, _L.ptr(y2), _L.ptr(gb), _L.ptr(ws), nb,
                                              _L.ptr(gc2), _L.stream_ptr()))
     row("gemm1x1_bn_act_mfma_bf16_kernel<4,3>(conv1 backward-data + identity gradient, %dx128 -> 512)" % M,
         2 * (M * C1 + C0 * C1 + 2 * M * C0),
-        lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gc1), _L.ptr(wt1), M, C0, C1, 3, _L.ptr(gz), None, None, None, 0.0, None,
-                                             None, None, 0, _L.ptr(gx), _L.stream_ptr()))
+        lambda: lib.rsdet_conv1x1_dgrad_bf16(_L.ptr(gc1), _L.ptr(wt1), M, C0, C1, 3, _L.ptr(gz), None, None, 0,
+                                             _L.ptr(gx), _L.stream_ptr()))
     return out
 
 

@@ -377,8 +377,9 @@ int rsdet_conv3x3_mfma_supported(int B, int H, int W, int C, int O);
  * norm_eval mode of :177-184.  x (M, K), weight (N, K), residual / out (M, N) row-major bf16, M = B*H*W positions;
  * running_mean / running_var / gamma / beta fp32 (N) -- mean == var == NULL: a plain convolution with `beta` as its
  * bias; gamma NULL: 1; beta NULL: 0.  K % 64 == 0, N % 32 == 0.
- * Its backward through the BatchNorm: rsdet_bn_act_backward_nhwc_fromy_bf16 (the normalised input of the scale
- * gradient is recovered from the output: xhat = (y - residual - beta) / gamma wherever the ReLU passed the value). */
+ * Its backward through the BatchNorm: rsdet_bn_gate_sums_nhwc_bf16 (gate + grad_beta sums); the BatchNorm's scale rides
+ * in the weights of the backward-data GEMM and in the fold of the weight gradient, and grad_gamma comes from that fold's
+ * row dots (rsdet_bn_affine_grads_finish_multi_f32) -- exact for any gamma, zero included. */
 int rsdet_gemm1x1_mfma_supported(long long M, int N, int K);
 int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* weight, long long M, int N, int K,
                                   const float* running_mean, const float* running_var, const float* gamma,
@@ -390,9 +391,13 @@ int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* weight, lon
 int rsdet_sum_slabs_f32(const float* partial, int S, long long n, void* out, int out_bf16, void* stream);
 /* ... with row r of the (n / row_len, row_len) result multiplied by gamma[r] / sqrt(running_var[r] + eps) before the
  * rounding: the weight gradient of a convolution that feeds an eval-mode BatchNorm, formed from the gradient of the
- * BatchNorm's OUTPUT (ops/bottleneck.py).  row_len % 4 == 0, n % row_len == 0; gamma NULL: 1. */
+ * BatchNorm's OUTPUT (ops/bottleneck.py, ops/conv_bn.py).  row_len % 4 == 0, n % row_len == 0; gamma NULL: 1.
+ * weight (bf16, the result's shape: the convolution's own weight) and rowdot (n / row_len floats), both or neither:
+ * rowdot[r] = sum_i weight[r][i] U[r][i], U the unscaled fp32 sum = sum_p gz[p, r] conv[p, r] -- the term the
+ * BatchNorm's scale gradient needs (the reference's batch-norm backward, resnet.py:57-93 under norm_eval). */
 int rsdet_sum_slabs_rowscale_f32(const float* partial, int S, long long n, int row_len, const float* running_var,
-                                 const float* gamma, float eps, void* out, int out_bf16, void* stream);
+                                 const float* gamma, float eps, const uint16_t* weight, float* rowdot, void* out,
+                                 int out_bf16, void* stream);
 /* out (C, O) = transpose of weight (O, C), column o scaled by gamma[o] / sqrt(running_var[o] + eps) (running_var NULL:
  * plain transpose): the weight operand of rsdet_conv1x1_dgrad_bf16. */
 int rsdet_weight_transpose_scale_bf16(const uint16_t* weight, int O, int C, const float* running_var, const float* gamma,
@@ -401,35 +406,40 @@ int rsdet_weight_transpose_scale_bf16(const uint16_t* weight, int O, int C, cons
  * step of the Bottleneck (/root/reference/python/jdet/models/backbones/resnet.py:57-93, backward of :80-91) in its
  * epilogue: grad_in[p, c] = epi(sum_o grad_out[p, o] wt[c, o]); grad_out (M, O), wt (C, O), grad_in / side (M, C) bf16.
  *   mode 0: identity.
- *   mode 2: the convolution's input was side = relu(bn(.)) of an eval-mode BatchNorm over its C channels (running_var,
- *           gamma, beta): grad_in = [side > 0] acc gamma / sqrt(var + eps) -- the gradient of THAT BatchNorm's input --
- *           grad_beta[c] = sum_p [side > 0] acc, grad_gamma[c] = sum_p [side > 0] acc (side - beta) / gamma (either NULL:
- *           not formed; ws of rsdet_conv1x1_dgrad_ws_size bytes when one is wanted).
+ *   mode 2: the convolution's input was side = relu(bn(.)) of an eval-mode BatchNorm over its C channels:
+ *           grad_in = [side > 0] acc -- the gated gradient of THAT BatchNorm's OUTPUT (its scale rides in the weights of
+ *           the next backward step) -- and, with ws (rsdet_conv1x1_dgrad_ws_size bytes), its per-channel sums: folded
+ *           into grad_beta[c] = sum_p grad_in[p, c] when grad_beta is given, else left in ws as (C, S, 2) floats ([0]
+ *           the sum, [1] zero; S = rsdet_conv1x1_dgrad_slices) for rsdet_bn_affine_grads_finish_multi_f32.
  *   mode 3: grad_in = acc + side (the gradient arriving through the identity branch).
  * C % 32 == 0, O % 64 == 0 (rsdet_gemm1x1_mfma_supported(M, C, O)). */
 size_t rsdet_conv1x1_dgrad_ws_size(long long M, int C, int O);
-/* mode 2 with ws but neither gradient pointer: the per-slice sums stay in ws as (C, S, 2) floats, S = this, for
- * rsdet_bn_sums_finish_multi_f32 to fold. */
 int rsdet_conv1x1_dgrad_slices(long long M, int C, int O);
 int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t* wt, long long M, int C, int O, int mode,
-                             const uint16_t* side, const float* running_var, const float* gamma, const float* beta,
-                             float eps, float* grad_gamma, float* grad_beta, void* ws, size_t ws_bytes,
-                             uint16_t* grad_in, void* stream);
-int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
-                                          const float* running_var, const float* weight, const float* bias, float eps,
-                                          int N, int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
-                                          float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
-/* rsdet_bn_act_backward_nhwc_fromy_bf16 with the per-slice sums LEFT in ws as (C, S, 2) floats ([0] bias, [1] scale; S =
- * rsdet_bn_act_backward_nhwc_fromy_slices), and the fold of up to 4 such tables -- from this pass or from
- * rsdet_conv1x1_dgrad_bf16's mode 2 -- as ONE launch: job j -> grad_bias[j][c] = sum_s [0], grad_weight[j][c] = sum_s [1].
- * The three BatchNorms of a Bottleneck's backward (ops/bottleneck.py) end in one fold instead of three. */
-int rsdet_bn_act_backward_nhwc_fromy_slices(int N, int C, int HW);
-int rsdet_bn_act_backward_nhwc_fromy_sums_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
-                                               const float* running_var, const float* weight, const float* bias,
-                                               float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
-                                               uint16_t* grad_residual, void* ws, size_t ws_bytes, void* stream);
-int rsdet_bn_sums_finish_multi_f32(int n, const float* const* partial, const int* C, const int* S,
-                                   float* const* grad_weight, float* const* grad_bias, void* stream);
+                             const uint16_t* side, float* grad_beta, void* ws, size_t ws_bytes, uint16_t* grad_in,
+                             void* stream);
+/* Gate pass of the fused convolution + eval BatchNorm (+ identity) + ReLU nodes, whose pre-BatchNorm value is never
+ * stored: grad_z = grad_y [y > 0] (relu != 0; relu == 0: grad_z must be NULL, nothing is written) and the per-slice
+ * channel sums of grad_z left in ws as (C, S, 2) floats ([0] the sum, [1] zero; S = rsdet_bn_gate_sums_nhwc_slices; ws of
+ * rsdet_bn_act_backward_nhwc_ws_size bytes, NULL = no sums).  bf16 channels-last, C / 8 a divisor of 256. */
+int rsdet_bn_gate_sums_nhwc_slices(int N, int C, int HW);
+int rsdet_bn_gate_sums_nhwc_bf16(const uint16_t* grad_y, const uint16_t* y, int N, int C, int HW, int relu,
+                                 uint16_t* grad_z, void* ws, size_t ws_bytes, void* stream);
+/* The affine-parameter gradients of up to 4 eval-mode BatchNorms behind convolutions as ONE launch (the three of a
+ * Bottleneck's backward, ops/bottleneck.py).  Job j: partial[j] (C, S, 2) sums from the two passes above; rowdot[j] from
+ * the weight-gradient folds (rsdet_sum_slabs_rowscale_f32, rsdet_conv3x3_wrw_mfma_rowscale_bf16):
+ *   grad_beta[j][c] = sum_s partial[c][s][0];  grad_gamma[j][c] = (rowdot[c] - mean[c] grad_beta[c]) / sqrt(var[c] + eps)
+ * = sum_p gz[p, c] xhat[p, c] with the convolution output the forward computed, for ANY gamma (the reference's
+ * batch-norm backward under norm_eval, resnet.py:177-184).  rowdot[j] or grad_gamma[j] NULL: only grad_beta. */
+int rsdet_bn_affine_grads_finish_multi_f32(int n, const float* const* partial, const int* C, const int* S,
+                                           const float* const* rowdot, const float* const* running_mean,
+                                           const float* const* running_var, const float* eps, float* const* grad_gamma,
+                                           float* const* grad_beta, void* stream);
+/* The prepared weight operands of the backward (ops/weight_prep.py) refreshed by one launch: entries = n 64-byte records
+ * in DEVICE memory {src, dst, var, gamma (pointers), O, C, T, eps (float), tile0, tiles_c, tiles_o, pad}: dst (C, T, O) =
+ * src (O, T, C) with the taps reversed and row o scaled by gamma[o] / sqrt(var[o] + eps) (var NULL: copied).  tile0
+ * ascending from 0, entry j owning T * tiles_c * tiles_o 32 x 32 tiles; total_tiles their sum. */
+int rsdet_weight_prep_multi_bf16(const void* entries, int n, int total_tiles, void* stream);
 int rsdet_conv3x3_fwd_mfma_bf16(const uint16_t* x, const uint16_t* weight, const float* bias, const uint8_t* live, int B,
                                 int H, int W, int C, int O, int relu, uint16_t* out, void* stream);
 /* Backward-data of the SECOND convolution of a conv + ReLU tower (s2anet_head.py:130-170: stacked ConvModules) through the
@@ -448,6 +458,13 @@ int rsdet_conv3x3_wrw_mfma_supported(int B, int H, int W, int C, int O);
 size_t rsdet_conv3x3_wrw_mfma_ws_size(int B, int H, int W, int C, int O);
 int rsdet_conv3x3_wrw_mfma_bf16(const uint16_t* grad_out, const uint16_t* x, int B, int H, int W, int C, int O,
                                 void* grad_weight, int out_bf16, void* ws, size_t ws_bytes, void* stream);
+/* ... of a convolution whose output feeds an eval-mode BatchNorm (conv2 / bn2 of the Bottleneck), from the gradient of the
+ * BatchNorm's OUTPUT: row o times gamma[o] / sqrt(running_var[o] + eps) before the rounding, and rowdot[o] = sum of
+ * weight[o] * (the unscaled fp32 row) for rsdet_bn_affine_grads_finish_multi_f32.  weight (O, 3, 3, C) bf16. */
+int rsdet_conv3x3_wrw_mfma_rowscale_bf16(const uint16_t* grad_out, const uint16_t* x, int B, int H, int W, int C, int O,
+                                         const float* running_var, const float* gamma, float eps, const uint16_t* weight,
+                                         float* rowdot, void* grad_weight, int out_bf16, void* ws, size_t ws_bytes,
+                                         void* stream);
 int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, const uint16_t* weight,
                                   const rsdet_dcn_geom* g, int O, int out_nhwc, uint16_t* out, uint16_t* colT,
                                   void* stream);

@@ -40,24 +40,22 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rsdet_sum_slabs_f32": (c_int, [c_void_p, c_int, c_ll, c_void_p, c_int, c_void_p]),
     "rsdet_gemm1x1_mfma_supported": (c_int, [c_ll, c_int, c_int]),
-    "rsdet_sum_slabs_rowscale_f32": (c_int, [c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
-                                             c_void_p]),
+    "rsdet_sum_slabs_rowscale_f32": (c_int, [c_void_p, c_int, c_ll, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                             c_void_p, c_int, c_void_p]),
     "rsdet_weight_transpose_scale_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p,
                                                   c_void_p]),
     "rsdet_conv1x1_dgrad_ws_size": (c_size_t, [c_ll, c_int, c_int]),
     "rsdet_conv1x1_dgrad_slices": (c_int, [c_ll, c_int, c_int]),
-    "rsdet_bn_act_backward_nhwc_fromy_slices": (c_int, [c_int, c_int, c_int]),
-    "rsdet_bn_act_backward_nhwc_fromy_sums_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                           c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                                           c_void_p, c_size_t, c_void_p]),
-    "rsdet_bn_sums_finish_multi_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_bn_gate_sums_nhwc_slices": (c_int, [c_int, c_int, c_int]),
+    "rsdet_bn_gate_sums_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                             c_void_p]),
+    "rsdet_bn_affine_grads_finish_multi_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_conv1x1_dgrad_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+                                         c_size_t, c_void_p, c_void_p]),
+    "rsdet_weight_prep_multi_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rsdet_conv1x1_bn_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),
-    "rsdet_bn_act_backward_nhwc_fromy_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
-                                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                      c_void_p, c_size_t, c_void_p]),
     "rsdet_box_iou_rotated_split_state_bytes": (c_size_t, []),
     "rsdet_box_iou_rotated_split_ws_size": (c_size_t, [c_int, c_int, c_int]),
     "rsdet_box_iou_rotated_split_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
@@ -221,6 +219,9 @@ SIGNATURES = {
     "rsdet_conv3x3_wrw_mfma_ws_size": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "rsdet_conv3x3_wrw_mfma_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                             c_size_t, c_void_p]),
+    "rsdet_conv3x3_wrw_mfma_rowscale_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                     c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                                     c_size_t, c_void_p]),
     "rsdet_conv3x3_dgrad_gate_ws_size": (c_size_t, [c_int, c_int, c_int, c_int]),
     "rsdet_conv3x3_dgrad_gate_mfma_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -350,27 +350,23 @@ __global__ __launch_bounds__(BN_NT) void bn_act_fwd_nhwc8_kernel(const bf16_t* _
   if (RELU && mask) mask[q] = (unsigned char)b0, mask[q + half] = (unsigned char)b1;
 }
 
-// CFG >= 0: which optional operands exist is a COMPILE-TIME mask (bit 0 mask, 1 x, 2 from_y, 3 fy_res, 4 dres, 5 dx,
-// 6 partial); CFG = -1: decided from the pointers at run time.  The run-time form branches (uniformly) six times per
+// CFG >= 0: which optional operands exist is a COMPILE-TIME mask (bit 0 mask, 1 x, 4 dres, 5 dx, 6 partial); CFG = -1: decided from the pointers at run time.  The run-time form branches (uniformly) six times per
 // row inside the loop, which keeps the compiler from batching the loads of the four unrolled rows: two or three loads
 // in flight per lane, 0.40-0.45 of the HBM roofline.  The configurations the bf16 step uses are instantiated branch-free.
-constexpr int BN8_MASK = 1, BN8_X = 2, BN8_FROMY = 4, BN8_FYRES = 8, BN8_DRES = 16, BN8_DX = 32, BN8_PARTIAL = 64;
+constexpr int BN8_MASK = 1, BN8_X = 2, BN8_DRES = 16, BN8_DX = 32, BN8_PARTIAL = 64;
 template <bool RELU, int CFG = -1>
 __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ weight, float eps,
     long long rows, int C, int rows_per, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
-    float* __restrict__ partial, const unsigned char* __restrict__ mask, const bf16_t* __restrict__ fy_res = nullptr,
-    const float* __restrict__ fy_bias = nullptr, int from_y = 0) {
-  // from_y (the backward of csrc/gemm1x1_mfma.hip's fused convolution + BatchNorm, whose pre-BatchNorm value x never
-  // reached memory): the normalised input the scale gradient needs is recovered from the OUTPUT,
-  // xhat = (y - residual - beta) / gamma, exact wherever the ReLU let the value through -- and nowhere else does the
-  // gradient count (g = 0 there).  gamma == 0: the term is dropped (the forward carries no information about xhat).
+    float* __restrict__ partial, const unsigned char* __restrict__ mask) {
+  // Without x (the backward of csrc/gemm1x1_mfma.hip's fused convolution + BatchNorm, whose pre-BatchNorm value never
+  // reached memory) the pass forms the gated gradient and its per-channel sum only; the scale gradient then comes from
+  // the weight gradient (rsdet_bn_affine_grads_finish_multi_f32 below) -- NOT from xhat = (y - beta) / gamma of the stored
+  // output, whose bf16 rounding 1 / gamma would amplify (round 5 did that).
   __shared__ float s_red[BN_NT][17];   // 17: the fold below reads a column of 16 across rows
   const bool has_mask = CFG >= 0 ? (CFG & BN8_MASK) != 0 : mask != nullptr;
   const bool has_x = CFG >= 0 ? (CFG & BN8_X) != 0 : x != nullptr;
-  const bool is_fy = CFG >= 0 ? (CFG & BN8_FROMY) != 0 : from_y != 0;
-  const bool has_fyres = CFG >= 0 ? (CFG & BN8_FYRES) != 0 : fy_res != nullptr;
   const bool has_dres = CFG >= 0 ? (CFG & BN8_DRES) != 0 : dres != nullptr;
   const bool has_dx = CFG >= 0 ? (CFG & BN8_DX) != 0 : dx != nullptr;
   const bool has_partial = CFG >= 0 ? (CFG & BN8_PARTIAL) != 0 : partial != nullptr;
@@ -378,26 +374,20 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
   const int RL = BN_NT / G;            // G is a divisor of 256 (host-checked)
   const int t = threadIdx.x, rl = t / G, c0 = (t % G) * 8;
   const long long r0 = (long long)s * rows_per, r1 = min(rows, r0 + rows_per);
-  const F8 m = ldp8(mean + c0), vr = ldp8(var + c0);
-  F8 is, sc;
+  F8 m, is, sc;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) is.v[k] = 1.0f / sqrtf(vr.v[k] + eps);
-  if (weight) {
-    const F8 w = ldp8(weight + c0);
+  for (int k = 0; k < 8; ++k) m.v[k] = 0.f, is.v[k] = 1.f, sc.v[k] = 1.f;
+  if (has_x || has_dx) {               // (the gate-and-sum form takes no statistics: mean / var may be NULL there)
+    m = ldp8(mean + c0);
+    const F8 vr = ldp8(var + c0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sc.v[k] = is.v[k] * w.v[k];
-  } else {
-    sc = is;
-  }
-  F8 fb, fiw;
-  if (is_fy) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fb.v[k] = 0.f, fiw.v[k] = 1.f;
-    if (fy_bias) fb = ldp8(fy_bias + c0);
+    for (int k = 0; k < 8; ++k) is.v[k] = 1.0f / sqrtf(vr.v[k] + eps);
     if (weight) {
       const F8 w = ldp8(weight + c0);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) fiw.v[k] = w.v[k] != 0.f ? 1.0f / w.v[k] : 0.f;
+      for (int k = 0; k < 8; ++k) sc.v[k] = is.v[k] * w.v[k];
+    } else {
+      sc = is;
     }
   }
   float acc[16];
@@ -411,7 +401,7 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
     const long long base = r * C + c0;
     F8 g = ld8(dy + base);
     F8 o;
-    if ((RELU && !has_mask) || (is_fy && has_partial)) o = ld8(y + base);
+    if (RELU && !has_mask) o = ld8(y + base);
     if (RELU) {
       if (has_mask) {         // one byte instead of the 16 bytes of y
         const unsigned b = mask[base >> 3];
@@ -429,14 +419,6 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
         const F8 v = ld8(x + base);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[8 + k] += g.v[k] * ((v.v[k] - m.v[k]) * is.v[k]);
-      } else if (is_fy) {
-        if (has_fyres) {
-          const F8 r = ld8(fy_res + base);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) o.v[k] -= r.v[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[8 + k] += g.v[k] * ((o.v[k] - fb.v[k]) * fiw.v[k]);
       }
     }
     if (has_dres) st8(dres + base, g);
@@ -470,20 +452,17 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc8_kernel(
 template <bool RELU>
 static void bn_act_bwd_nhwc8_launch(int S, hipStream_t s, const bf16_t* dy, const bf16_t* y, const bf16_t* x,
                                     const float* mean, const float* var, const float* weight, float eps, long long rows,
-                                    int C, int per, bf16_t* dx, bf16_t* dres, float* partial, const unsigned char* mask,
-                                    const bf16_t* fy_res, const float* fy_bias, int from_y) {
-  const int cfg = (mask ? BN8_MASK : 0) | (x ? BN8_X : 0) | (from_y ? BN8_FROMY : 0) | (fy_res ? BN8_FYRES : 0) |
-                  (dres ? BN8_DRES : 0) | (dx ? BN8_DX : 0) | (partial ? BN8_PARTIAL : 0);
+                                    int C, int per, bf16_t* dx, bf16_t* dres, float* partial, const unsigned char* mask) {
+  const int cfg = (mask ? BN8_MASK : 0) | (x ? BN8_X : 0) | (dres ? BN8_DRES : 0) | (dx ? BN8_DX : 0) |
+                  (partial ? BN8_PARTIAL : 0);
 #define BN8_CASE(CFG_)                                                                                              \
   case CFG_:                                                                                                         \
     hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<RELU, CFG_>), dim3(S), dim3(BN_NT), 0, s, dy, y, x, mean, var, weight, \
-                       eps, rows, C, per, dx, dres, partial, mask, fy_res, fy_bias, from_y);                         \
+                       eps, rows, C, per, dx, dres, partial, mask);                                                  \
     return;
   switch (cfg) {
-    BN8_CASE(BN8_FROMY | BN8_FYRES | BN8_DRES | BN8_PARTIAL)             // the Bottleneck node: gate + bn3 sums
-    BN8_CASE(BN8_FROMY | BN8_DX | BN8_PARTIAL)                           // ... bn1's backward; conv + bn without identity
-    BN8_CASE(BN8_FROMY | BN8_FYRES | BN8_DRES | BN8_DX | BN8_PARTIAL)    // conv + bn + identity (per-operator route)
-    BN8_CASE(BN8_FROMY | BN8_DRES | BN8_DX | BN8_PARTIAL)
+    BN8_CASE(BN8_DRES | BN8_PARTIAL)                                     // gate + sums of the fused conv + bn nodes
+    BN8_CASE(BN8_PARTIAL)                                                // ... without ReLU: the sums alone
     BN8_CASE(BN8_DX | BN8_PARTIAL)                                       // bias + ReLU of the head towers
     BN8_CASE(BN8_DX)
     BN8_CASE(BN8_MASK | BN8_X | BN8_DX | BN8_PARTIAL)                    // bn_act with the ReLU bit mask
@@ -494,7 +473,7 @@ static void bn_act_bwd_nhwc8_launch(int S, hipStream_t s, const bf16_t* dy, cons
   }
 #undef BN8_CASE
   hipLaunchKernelGGL((bn_act_bwd_nhwc8_kernel<RELU, -1>), dim3(S), dim3(BN_NT), 0, s, dy, y, x, mean, var, weight, eps, rows,
-                     C, per, dx, dres, partial, mask, fy_res, fy_bias, from_y);
+                     C, per, dx, dres, partial, mask);
 }
 
 static inline bool bn_nhwc8_ok(int C) {   // eight channels per lane: C / 8 a divisor of 256
@@ -848,10 +827,10 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char
       bn_nhwc_split(rows, C, &per, &S, 8);   // never more slices than the four-channel split the workspace is sized for
       if (relu)
         bn_act_bwd_nhwc8_launch<true>(S, s, grad_y, y, x, running_mean, running_var, weight, eps, rows, C, per, grad_x,
-                                      grad_residual, partial, mask, nullptr, nullptr, 0);
+                                      grad_residual, partial, mask);
       else
         bn_act_bwd_nhwc8_launch<false>(S, s, grad_y, y, x, running_mean, running_var, weight, eps, rows, C, per, grad_x,
-                                       grad_residual, partial, mask, nullptr, nullptr, 0);
+                                       grad_residual, partial, mask);
       if (need_param)
         hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
                            grad_bias);
@@ -875,123 +854,102 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char
   return rsdet_launch_status();
 }
 
-// Backward of the fused 1x1 convolution + BatchNorm + residual + ReLU (csrc/gemm1x1_mfma.hip): as
-// rsdet_bn_act_backward_nhwc_bf16, but the scale gradient's normalised input comes from the OUTPUT y (the kernel's
-// from_y note).  bf16, C / 8 a divisor of 256.  grad_x = the gradient with respect to the CONVOLUTION's raw output.
-static int bn_act_backward_nhwc_fromy(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
-                                      const float* running_var, const float* weight, const float* bias, float eps, int N,
-                                      int C, int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
-                                      float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, bool sums_only,
-                                      void* stream) {
-  if (N < 0 || HW < 0 || !bn_nhwc_ok(C) || !bn_nhwc8_ok(C)) return RSDET_EINVAL;
-  if (N == 0 || HW == 0) return RSDET_OK;
-  if (!grad_y || !y || !running_var) return RSDET_EINVAL;
-  const bool need_param = grad_weight || grad_bias || sums_only;
-  if (need_param && (!ws || ws_bytes < rsdet_bn_act_backward_nhwc_ws_size(N, C, HW))) return RSDET_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  const long long rows = (long long)N * HW;
-  int per, S;
-  bn_nhwc_split(rows, C, &per, &S, 8);
-  float* partial = need_param ? (float*)ws : nullptr;
-  const bf16_t *gy = grad_y, *yy = y, *rr = residual;
-  const int fy = (grad_weight || sums_only) ? 1 : 0;          // (only the scale gradient needs xhat)
-  // running_mean is not needed in this form: pass running_var for it (the kernel loads it, nothing reads it)
-  if (relu)
-    bn_act_bwd_nhwc8_launch<true>(S, s, gy, yy, (const bf16_t*)nullptr, running_var, running_var, weight, eps, rows, C, per,
-                                  (bf16_t*)grad_x, (bf16_t*)grad_residual, partial, (const unsigned char*)nullptr, rr, bias,
-                                  fy);
-  else
-    bn_act_bwd_nhwc8_launch<false>(S, s, gy, yy, (const bf16_t*)nullptr, running_var, running_var, weight, eps, rows, C, per,
-                                   (bf16_t*)grad_x, (bf16_t*)grad_residual, partial, (const unsigned char*)nullptr, rr, bias,
-                                   fy);
-  if (need_param && !sums_only)
-    hipLaunchKernelGGL(bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, C, S, grad_weight,
-                       grad_bias);
-  return rsdet_launch_status();
-}
-
-extern "C" int rsdet_bn_act_backward_nhwc_fromy_bf16(const uint16_t* grad_y, const uint16_t* y, const uint16_t* residual,
-                                                     const float* running_var, const float* weight, const float* bias,
-                                                     float eps, int N, int C, int HW, int relu, uint16_t* grad_x,
-                                                     uint16_t* grad_residual, float* grad_weight, float* grad_bias,
-                                                     void* ws, size_t ws_bytes, void* stream) {
-  return bn_act_backward_nhwc_fromy(grad_y, y, residual, running_var, weight, bias, eps, N, C, HW, relu, grad_x,
-                                    grad_residual, grad_weight, grad_bias, ws, ws_bytes, false, stream);
-}
-
-// The same pass with the per-slice sums LEFT in ws as (C, S, 2) floats ([0] the bias sum, [1] the scale sum), S =
-// rsdet_bn_act_backward_nhwc_fromy_slices(N, C, HW): several such passes of one autograd node (ops/bottleneck.py) are
-// folded by ONE rsdet_bn_sums_finish_multi_f32 launch.
-extern "C" int rsdet_bn_act_backward_nhwc_fromy_slices(int N, int C, int HW) {
+// Gate pass of the fused 1x1 convolution + eval BatchNorm (+ identity) + ReLU nodes (csrc/gemm1x1_mfma.hip forward, whose
+// pre-BatchNorm value never reaches memory): grad_z = grad_y [y > 0] (relu != 0; relu == 0: grad_z = grad_y is not
+// written, pass NULL) and the per-slice channel sums of grad_z LEFT in ws as (C, S, 2) floats ([0] the sum, [1] zero),
+// S = rsdet_bn_gate_sums_nhwc_slices(N, C, HW), for rsdet_bn_affine_grads_finish_multi_f32 to fold.  grad_z is the gradient
+// of the BatchNorm's OUTPUT: the BatchNorm's scale gamma / sqrt(var + eps) rides in the weights of the backward-data GEMM
+// (ops/weight_prep.py) and in the fold of the weight gradient (rsdet_sum_slabs_rowscale_f32), so no scaled copy exists.
+// bf16 channels-last, C / 8 a divisor of 256.  ws NULL: no sums.
+extern "C" int rsdet_bn_gate_sums_nhwc_slices(int N, int C, int HW) {
   if (N <= 0 || HW <= 0 || !bn_nhwc_ok(C) || !bn_nhwc8_ok(C)) return 0;
   int per, S;
   bn_nhwc_split((long long)N * HW, C, &per, &S, 8);
   return S;
 }
-extern "C" int rsdet_bn_act_backward_nhwc_fromy_sums_bf16(const uint16_t* grad_y, const uint16_t* y,
-                                                          const uint16_t* residual, const float* running_var,
-                                                          const float* weight, const float* bias, float eps, int N, int C,
-                                                          int HW, int relu, uint16_t* grad_x, uint16_t* grad_residual,
-                                                          void* ws, size_t ws_bytes, void* stream) {
-  if (!ws) return RSDET_EINVAL;
-  return bn_act_backward_nhwc_fromy(grad_y, y, residual, running_var, weight, bias, eps, N, C, HW, relu, grad_x,
-                                    grad_residual, nullptr, nullptr, ws, ws_bytes, true, stream);
+extern "C" int rsdet_bn_gate_sums_nhwc_bf16(const uint16_t* grad_y, const uint16_t* y, int N, int C, int HW, int relu,
+                                            uint16_t* grad_z, void* ws, size_t ws_bytes, void* stream) {
+  if (N < 0 || HW < 0 || !bn_nhwc_ok(C) || !bn_nhwc8_ok(C)) return RSDET_EINVAL;
+  if (N == 0 || HW == 0) return RSDET_OK;
+  if (!grad_y || (relu && (!y || !grad_z)) || (!relu && grad_z) || (!relu && !ws)) return RSDET_EINVAL;
+  if (ws && ws_bytes < rsdet_bn_act_backward_nhwc_ws_size(N, C, HW)) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const long long rows = (long long)N * HW;
+  int per, S;
+  bn_nhwc_split(rows, C, &per, &S, 8);
+  const bf16_t* none = nullptr;
+  if (relu)
+    bn_act_bwd_nhwc8_launch<true>(S, s, grad_y, y, none, nullptr, nullptr, nullptr, 0.f, rows, C, per, (bf16_t*)nullptr,
+                                  (bf16_t*)grad_z, (float*)ws, (const unsigned char*)nullptr);
+  else
+    bn_act_bwd_nhwc8_launch<false>(S, s, grad_y, none, none, nullptr, nullptr, nullptr, 0.f, rows, C, per,
+                                   (bf16_t*)nullptr, (bf16_t*)nullptr, (float*)ws, (const unsigned char*)nullptr);
+  return rsdet_launch_status();
 }
 
 void rsdet_launch_sums_finish(const float* partial, int C, int S, float* dweight, float* dbias, hipStream_t stream) {
   hipLaunchKernelGGL(rsdet::bn_act_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, partial, C, S, dweight, dbias);
 }
 
-// Up to RSDET_BN_FINISH_JOBS (C, S, 2) partial-sum tables folded by one launch: job j -> grad_bias[j][c] = sum_s [0],
-// grad_weight[j][c] = sum_s [1] (either pointer NULL: skipped).  One wave per channel, fixed order.
+// The affine-parameter gradients of up to RSDET_BN_FINISH_JOBS eval-mode BatchNorms behind convolutions, one launch.
+// Job j: partial[j] = (C, S, 2) per-slice sums whose [0] column is sum_p gz[p, c] (gz = the gated gradient of the
+// BatchNorm's output);  rowdot[j][c] = sum_k W[c, k] U[c, k] with U = sum_p gz[p, c] patch[p, k] the UNSCALED weight
+// gradient of the convolution in fp32 (the folds form it: rsdet_sum_slabs_rowscale_f32, rsdet_conv3x3_wrw_mfma_rowscale_bf16)
+// -- which is sum_p gz[p, c] conv[p, c], the convolution output never having been stored.  Then
+//   grad_beta[c]  = sum_s partial[c][s][0]
+//   grad_gamma[c] = (rowdot[c] - mean[c] grad_beta[c]) / sqrt(var[c] + eps)          (= sum_p gz xhat, exactly)
+// rowdot[j] NULL: grad_gamma[j] is not written.  One wave per channel, fixed order.
 constexpr int BN_FINISH_JOBS = 4;
 struct BnFinishJobs {
   const float* partial[BN_FINISH_JOBS];
+  const float* rowdot[BN_FINISH_JOBS];
+  const float* mean[BN_FINISH_JOBS];
+  const float* var[BN_FINISH_JOBS];
   float* dweight[BN_FINISH_JOBS];
   float* dbias[BN_FINISH_JOBS];
+  float eps[BN_FINISH_JOBS];
   int C[BN_FINISH_JOBS], S[BN_FINISH_JOBS], block0[BN_FINISH_JOBS + 1];
   int n;
 };
-__global__ __launch_bounds__(256) void bn_sums_finish_multi_kernel(BnFinishJobs jobs) {
+__global__ __launch_bounds__(256) void bn_affine_finish_multi_kernel(BnFinishJobs jobs) {
   int j = 0;
   while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;
   const int c = ((int)blockIdx.x - jobs.block0[j]) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int C = jobs.C[j], S = jobs.S[j];
   if (c >= C) return;
   const float* partial = jobs.partial[j];
-  float a = 0.f, b = 0.f;
+  float a = 0.f;
 #pragma unroll 8        // (eight loads in flight; the additions keep their order)
-  for (int s = lane; s < S; s += 64) {
-    const float2 p = *reinterpret_cast<const float2*>(partial + ((long long)c * S + s) * 2);
-    a += p.x;
-    b += p.y;
-  }
+  for (int s = lane; s < S; s += 64) a += partial[((long long)c * S + s) * 2];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_down(a, off);
-    b += __shfl_down(b, off);
-  }
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
   if (lane == 0) {
     if (jobs.dbias[j]) jobs.dbias[j][c] = a;
-    if (jobs.dweight[j]) jobs.dweight[j][c] = b;
+    if (jobs.dweight[j] && jobs.rowdot[j])
+      jobs.dweight[j][c] = (jobs.rowdot[j][c] - jobs.mean[j][c] * a) * (1.0f / sqrtf(jobs.var[j][c] + jobs.eps[j]));
   }
 }
-extern "C" int rsdet_bn_sums_finish_multi_f32(int n, const float* const* partial, const int* C, const int* S,
-                                              float* const* grad_weight, float* const* grad_bias, void* stream) {
+extern "C" int rsdet_bn_affine_grads_finish_multi_f32(int n, const float* const* partial, const int* C, const int* S,
+                                                      const float* const* rowdot, const float* const* running_mean,
+                                                      const float* const* running_var, const float* eps,
+                                                      float* const* grad_gamma, float* const* grad_beta, void* stream) {
   if (n < 0 || n > BN_FINISH_JOBS) return RSDET_EINVAL;
   if (n == 0) return RSDET_OK;
-  if (!partial || !C || !S || !grad_weight || !grad_bias) return RSDET_EINVAL;
+  if (!partial || !C || !S || !rowdot || !running_mean || !running_var || !eps || !grad_gamma || !grad_beta)
+    return RSDET_EINVAL;
   BnFinishJobs jobs;
   jobs.n = n;
   int blocks = 0;
   for (int j = 0; j < n; ++j) {
     if (!partial[j] || C[j] < 1 || S[j] < 1) return RSDET_EINVAL;
-    jobs.partial[j] = partial[j], jobs.dweight[j] = grad_weight[j], jobs.dbias[j] = grad_bias[j];
+    if (grad_gamma[j] && rowdot[j] && (!running_mean[j] || !running_var[j])) return RSDET_EINVAL;
+    jobs.partial[j] = partial[j], jobs.rowdot[j] = rowdot[j], jobs.mean[j] = running_mean[j], jobs.var[j] = running_var[j];
+    jobs.dweight[j] = grad_gamma[j], jobs.dbias[j] = grad_beta[j], jobs.eps[j] = eps[j];
     jobs.C[j] = C[j], jobs.S[j] = S[j], jobs.block0[j] = blocks;
     blocks += (C[j] + 3) / 4;
   }
   jobs.block0[n] = blocks;
-  hipLaunchKernelGGL(bn_sums_finish_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs);
+  hipLaunchKernelGGL(bn_affine_finish_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs);
   return rsdet_launch_status();
 }
 

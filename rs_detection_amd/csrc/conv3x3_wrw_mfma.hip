@@ -338,6 +338,58 @@ __global__ __launch_bounds__(256) void conv3x3_wrw_fold_kernel(const float* __re
   }
 }
 
+// The same fold by ROWS for a convolution whose output feeds an eval-mode BatchNorm (ops/bottleneck.py: conv2 / bn2): one
+// workgroup per output channel o; row o of dW is multiplied by gamma[o] / sqrt(var[o] + eps) before the rounding (the
+// gradient arriving is that of the BatchNorm's OUTPUT), and rowdot[o] = sum_{t, c} w[o][t][c] U[o][t][c] with U the
+// unscaled fp32 sum -- sum_p gz[p, o] conv[p, o], what the BatchNorm's scale gradient is formed from
+// (rsdet_bn_affine_grads_finish_multi_f32, csrc/bn_act.hip).  Fixed order throughout.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_wrw_fold_rows_kernel(const float* __restrict__ partial, W3Geom g, int n_groups,
+                                                                    int n_tiles, T* __restrict__ out,
+                                                                    const float* __restrict__ var,
+                                                                    const float* __restrict__ gamma, float eps,
+                                                                    const bf16_t* __restrict__ w, float* __restrict__ rowdot) {
+  __shared__ float s_dot[256];
+  const int o = blockIdx.x, c4 = g.C >> 2, cchunks = g.C >> 6;
+  const int ob = o / W3_TN, ol = o - ob * W3_TN;
+  float sc = 1.0f / sqrtf(var[o] + eps);
+  if (gamma) sc *= gamma[o];
+  float d = 0.f;
+  for (int idx = threadIdx.x; idx < 9 * c4; idx += 256) {
+    const int cq = idx % c4, t = idx / c4;
+    const int c = cq * 4, ki = t / 3, kj = t - ki * 3, cc = c >> 6, cl = c & 63;
+    const int tile = (ob * 3 + ki) * cchunks + cc;
+    const float* p = partial + (long long)tile * (W3_TN * W3_TM) + (long long)ol * W3_TM + kj * 64 + cl;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int gi = 0; gi < n_groups; ++gi) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (long long)gi * n_tiles * (W3_TN * W3_TM));
+      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    const long long e = ((long long)o * 9 + t) * g.C + c;
+    const uint2 wq = *reinterpret_cast<const uint2*>(w + e);
+    d += acc.x * __uint_as_float(wq.x << 16) + acc.y * __uint_as_float(wq.x & 0xffff0000u) +
+         acc.z * __uint_as_float(wq.y << 16) + acc.w * __uint_as_float(wq.y & 0xffff0000u);
+    acc.x *= sc, acc.y *= sc, acc.z *= sc, acc.w *= sc;
+    T* dst = out + e;
+    if constexpr (sizeof(T) == 2) {
+      uint2 pk;
+      pk.x = f2bf2(acc.x, acc.y);
+      pk.y = f2bf2(acc.z, acc.w);
+      *reinterpret_cast<uint2*>(dst) = pk;
+    } else {
+      *reinterpret_cast<float4*>(dst) = acc;
+    }
+  }
+  s_dot[threadIdx.x] = d;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_dot[threadIdx.x] += s_dot[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowdot[o] = s_dot[0];
+}
+
 static inline int w3_groups(int B, int H, int C, int O) {
   const int tiles = 3 * (C / 64) * ((O + W3_TN - 1) / W3_TN);
   int n = 256 / tiles;                 // one round of workgroups on 256 CUs
@@ -364,8 +416,9 @@ extern "C" size_t rsdet_conv3x3_wrw_mfma_ws_size(int B, int H, int W, int C, int
 
 // grad_out (B, H, W, O) and x (B, H, W, C): channels-last bf16; grad_weight (O, 3, 3, C) = the storage of a
 // channels_last (O, C, 3, 3) tensor, bf16 (out_bf16 != 0) or fp32.
-extern "C" int rsdet_conv3x3_wrw_mfma_bf16(const uint16_t* grad_out, const uint16_t* x, int B, int H, int W, int C, int O,
-                                           void* grad_weight, int out_bf16, void* ws, size_t ws_bytes, void* stream) {
+static int w3_wrw(const uint16_t* grad_out, const uint16_t* x, int B, int H, int W, int C, int O, const float* var,
+                  const float* gamma, float eps, const uint16_t* weight, float* rowdot, void* grad_weight, int out_bf16,
+                  void* ws, size_t ws_bytes, void* stream) {
   if (!rsdet_conv3x3_wrw_mfma_supported(B, H, W, C, O)) return RSDET_EINVAL;
   if (!grad_out || !x || !grad_weight || !ws || ws_bytes < rsdet_conv3x3_wrw_mfma_ws_size(B, H, W, C, O) ||
       ((uintptr_t)ws & 15))
@@ -376,6 +429,15 @@ extern "C" int rsdet_conv3x3_wrw_mfma_bf16(const uint16_t* grad_out, const uint1
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(conv3x3_wrw_mfma_bf16_kernel, dim3(n_groups * n_tiles), dim3(64 * W3_NW), 0, s,
                      (const bf16_t*)grad_out, (const bf16_t*)x, g, n_groups, (float*)ws);
+  if (var) {
+    if (out_bf16)
+      hipLaunchKernelGGL((conv3x3_wrw_fold_rows_kernel<bf16_t>), dim3((unsigned)O), dim3(256), 0, s, (const float*)ws, g,
+                         n_groups, n_tiles, (bf16_t*)grad_weight, var, gamma, eps, (const bf16_t*)weight, rowdot);
+    else
+      hipLaunchKernelGGL((conv3x3_wrw_fold_rows_kernel<float>), dim3((unsigned)O), dim3(256), 0, s, (const float*)ws, g,
+                         n_groups, n_tiles, (float*)grad_weight, var, gamma, eps, (const bf16_t*)weight, rowdot);
+    return rsdet_launch_status();
+  }
   const long long n4 = (long long)O * 9 * (C / 4);
   if (out_bf16)
     hipLaunchKernelGGL((conv3x3_wrw_fold_kernel<bf16_t>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
@@ -384,4 +446,23 @@ extern "C" int rsdet_conv3x3_wrw_mfma_bf16(const uint16_t* grad_out, const uint1
     hipLaunchKernelGGL((conv3x3_wrw_fold_kernel<float>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
                        (const float*)ws, g, n_groups, n_tiles, (float*)grad_weight);
   return rsdet_launch_status();
+}
+
+extern "C" int rsdet_conv3x3_wrw_mfma_bf16(const uint16_t* grad_out, const uint16_t* x, int B, int H, int W, int C, int O,
+                                           void* grad_weight, int out_bf16, void* ws, size_t ws_bytes, void* stream) {
+  return w3_wrw(grad_out, x, B, H, W, C, O, nullptr, nullptr, 0.f, nullptr, nullptr, grad_weight, out_bf16, ws, ws_bytes,
+                stream);
+}
+
+// ... of a convolution whose output feeds an eval-mode BatchNorm, from the gradient of the BatchNorm's OUTPUT: row o of the
+// result times gamma[o] / sqrt(running_var[o] + eps) (gamma NULL: 1), and rowdot[o] = sum weight[o] * (the unscaled fp32
+// row) for the BatchNorm's scale gradient (conv3x3_wrw_fold_rows_kernel's note).  weight: the convolution's own (O, 3, 3, C)
+// bf16 weight.
+extern "C" int rsdet_conv3x3_wrw_mfma_rowscale_bf16(const uint16_t* grad_out, const uint16_t* x, int B, int H, int W, int C,
+                                                    int O, const float* running_var, const float* gamma, float eps,
+                                                    const uint16_t* weight, float* rowdot, void* grad_weight,
+                                                    int out_bf16, void* ws, size_t ws_bytes, void* stream) {
+  if (!running_var || !weight || !rowdot) return RSDET_EINVAL;
+  return w3_wrw(grad_out, x, B, H, W, C, O, running_var, gamma, eps, weight, rowdot, grad_weight, out_bf16, ws, ws_bytes,
+                stream);
 }

@@ -271,36 +271,29 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
   G1_ST(1);
   // (the tables are built AFTER the first tiles' DMA is in flight -- stamps: 2.8 us from kernel start to the first DMA when
   //  the parameter loads came first; their LDS writes are ordered before the first epilogue by the step barriers)
-  // ---- per-channel tables (fp32) in LDS: [0] scale, [1] shift (forward) or beta (EPI 2), [2] 1 / gamma (EPI 2)
-  {
+  // ---- per-channel tables (fp32) in LDS: [0] scale, [1] shift (the forward forms; the backward forms take none)
+  constexpr bool TABLES = EPI == G1_FWD || EPI == G1_FWD_RES;
+  if (TABLES) {
     float* tab = reinterpret_cast<float*>(lds + TAB);
     for (int c = tid; c < TN; c += 64 * G1_NW) {
       const int o = min(n_base + c, g.N - 1);
-      float s1 = 1.f, t1 = 0.f, ig = 1.f;
-      if (EPI == G1_BWD_GATE) {
-        if (e.var) s1 = 1.0f / sqrtf(e.var[o] + e.eps);
-        if (e.gamma) {
-          const float gm = e.gamma[o];
-          s1 *= gm;
-          ig = gm != 0.f ? 1.0f / gm : 0.f;
-        }
-        if (e.beta) t1 = e.beta[o];
-      } else if (e.mean) {
+      float s1 = 1.f, t1 = 0.f;
+      if (e.mean) {
         const float is = 1.0f / sqrtf(e.var[o] + e.eps);
         s1 = e.gamma ? is * e.gamma[o] : is;
         t1 = (e.beta ? e.beta[o] : 0.f) - e.mean[o] * s1;
       } else if (e.beta) {
         t1 = e.beta[o];
       }
-      tab[c] = s1, tab[TN + c] = t1, tab[2 * TN + c] = ig;
+      tab[c] = s1, tab[TN + c] = t1;
     }
   }
   g1_u32x4 rres[RES ? E_OPS : 1];
-  float sum1[EPI == G1_BWD_GATE ? NP : 1][8], sum2[EPI == G1_BWD_GATE ? NP : 1][8];   // EPI 2: this lane's running sums
+  float sum1[EPI == G1_BWD_GATE ? NP : 1][8];      // EPI 2: this lane's running sums of the gated gradient
 #pragma unroll
   for (int pp = 0; pp < (EPI == G1_BWD_GATE ? NP : 1); ++pp)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sum1[pp][k] = 0.f, sum2[pp][k] = 0.f;
+    for (int k = 0; k < 8; ++k) sum1[pp][k] = 0.f;
   int t_idx = 0, k_idx = 0;                        // tile / K step of the current step
   unsigned ended = 0u;                             // bit d - 1: did step s - d end a tile?
   for (int s = 0; s < S; ++s) {
@@ -352,20 +345,18 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
       for (int pp = 0; pp < NP; ++pp) {
         const int c = ch0 + 32 * pp;
         // (table reads in inline asm: an ordinary LDS load beside outstanding LDS-DMA makes the compiler drain the queue)
-        g1_u32x4 s_lo, s_hi, t_lo, t_hi, g_lo, g_hi;
-        const unsigned tb = lds_base + TAB + c * 4;
-        g1_lds_read(s_lo, tb), g1_lds_read(s_hi, tb + 16), g1_lds_read(t_lo, tb + TN * 4), g1_lds_read(t_hi, tb + TN * 4 + 16);
-        if (EPI == G1_BWD_GATE) g1_lds_read(g_lo, tb + TN * 8), g1_lds_read(g_hi, tb + TN * 8 + 16);
-        g1_wait_lgkm<0>();
-        g1_landed(s_lo), g1_landed(s_hi), g1_landed(t_lo), g1_landed(t_hi);
-        if (EPI == G1_BWD_GATE) g1_landed(g_lo), g1_landed(g_hi);
-        float sc[8], sh[8], ig[8];
+        float sc[8], sh[8];
+        if (TABLES) {
+          g1_u32x4 s_lo, s_hi, t_lo, t_hi;
+          const unsigned tb = lds_base + TAB + c * 4;
+          g1_lds_read(s_lo, tb), g1_lds_read(s_hi, tb + 16), g1_lds_read(t_lo, tb + TN * 4), g1_lds_read(t_hi, tb + TN * 4 + 16);
+          g1_wait_lgkm<0>();
+          g1_landed(s_lo), g1_landed(s_hi), g1_landed(t_lo), g1_landed(t_hi);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          sc[k] = __uint_as_float(s_lo[k]), sc[4 + k] = __uint_as_float(s_hi[k]);
-          sh[k] = __uint_as_float(t_lo[k]), sh[4 + k] = __uint_as_float(t_hi[k]);
-          ig[k] = EPI == G1_BWD_GATE ? __uint_as_float(g_lo[k]) : 1.f;
-          ig[4 + k] = EPI == G1_BWD_GATE ? __uint_as_float(g_hi[k]) : 1.f;
+          for (int k = 0; k < 4; ++k) {
+            sc[k] = __uint_as_float(s_lo[k]), sc[4 + k] = __uint_as_float(s_hi[k]);
+            sh[k] = __uint_as_float(t_lo[k]), sh[4 + k] = __uint_as_float(t_hi[k]);
+          }
         }
         const bool in_n = n_base + c < g.N;         // (N % 32 == 0 and c % 8 == 0: inside or outside as a whole)
 #pragma unroll
@@ -392,10 +383,8 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
             const bool row_ok = p < g.M;            // (rows past the end carry a clamped side operand: keep them out of the sums)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const float gz = (side[k] > 0.f && row_ok) ? v[k] : 0.f;
-              sum1[pp][k] += gz;
-              sum2[pp][k] = __builtin_fmaf(gz, (side[k] - sh[k]) * ig[k], sum2[pp][k]);
-              v[k] = gz * sc[k];
+              v[k] = (side[k] > 0.f && row_ok) ? v[k] : 0.f;
+              sum1[pp][k] += v[k];
             }
           } else if (EPI == G1_BWD_ADD) {
 #pragma unroll
@@ -433,26 +422,23 @@ __global__ __launch_bounds__(64 * G1_NW, 1) void gemm1x1_bn_act_mfma_bf16_kernel
     // 8 channels -> butterfly over the row; the two position halves (wm) meet in LDS (the ring is idle now); fixed order
     g1_wait_vm<0>();
     g1_barrier();
-    float* red = reinterpret_cast<float*>(lds);                        // [wm][TN][2]
+    float* red = reinterpret_cast<float*>(lds);                        // [wm][TN]
     const int ch0 = wn * 16 * NI + 16 * (q4 & 1) + 8 * (q4 >> 1);
 #pragma unroll
     for (int pp = 0; pp < (EPI == G1_BWD_GATE ? NP : 1); ++pp)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float a1 = sum1[pp][k], a2 = sum2[pp][k];
+        float a1 = sum1[pp][k];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) a1 += __shfl_xor(a1, off), a2 += __shfl_xor(a2, off);
-        if (l15 == 0) {
-          red[(wm * TN + ch0 + 32 * pp + k) * 2 + 0] = a1;
-          red[(wm * TN + ch0 + 32 * pp + k) * 2 + 1] = a2;
-        }
+        for (int off = 8; off > 0; off >>= 1) a1 += __shfl_xor(a1, off);
+        if (l15 == 0) red[wm * TN + ch0 + 32 * pp + k] = a1;
       }
     __syncthreads();
     const int slice = (slot_id / n_tiles) * 8 + xcd;                   // = m_lane: the row lanes of this column panel
     for (int c = tid; c < TN; c += 64 * G1_NW)
       if (n_base + c < g.N) {
-        e.partial[((long long)(n_base + c) * e.slices + slice) * 2 + 0] = red[c * 2] + red[(TN + c) * 2];
-        e.partial[((long long)(n_base + c) * e.slices + slice) * 2 + 1] = red[c * 2 + 1] + red[(TN + c) * 2 + 1];
+        *reinterpret_cast<float2*>(e.partial + ((long long)(n_base + c) * e.slices + slice) * 2) =
+            make_float2(red[c] + red[TN + c], 0.f);
       }
   }
 }
@@ -481,6 +467,50 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     acc.x *= sc, acc.y *= sc, acc.z *= sc, acc.w *= sc;
   }
   st4(out + i, acc);
+}
+
+// The same fold by ROWS, for the weight gradient of a convolution whose output feeds an eval-mode BatchNorm: beside the
+// scaled, rounded row it leaves rowdot[r] = sum_i w[r][i] U[r][i], U the UNSCALED fp32 sum -- which equals
+// sum_p gz[p, r] conv[p, r] (gz the gradient of the BatchNorm's output, conv the convolution's raw output, never stored):
+// the scale gradient of that BatchNorm is (rowdot - mean * sum_p gz) / sqrt(var + eps), exact for any gamma
+// (rsdet_bn_affine_grads_finish_multi_f32, csrc/bn_act.hip).  TPR threads per row (a power of two <= 256, four
+// consecutive elements each, strided over the row), 256 / TPR rows per workgroup; the dot is folded over a row's
+// threads by a fixed butterfly.
+template <typename T>
+__global__ __launch_bounds__(256) void sum_slabs_rows_kernel(const float* __restrict__ partial, int S, int rows, int row_len,
+                                                             int tpr, T* __restrict__ out, const float* __restrict__ var,
+                                                             const float* __restrict__ gamma, float eps,
+                                                             const bf16_t* __restrict__ w, float* __restrict__ rowdot) {
+  __shared__ float s_dot[256];
+  const int t = threadIdx.x, rl = t / tpr, j = t - rl * tpr;
+  const int r = blockIdx.x * (256 / tpr) + rl;
+  const long long n = (long long)rows * row_len;
+  float d = 0.f;
+  if (r < rows) {
+    float sc = 1.0f / sqrtf(var[r] + eps);
+    if (gamma) sc *= gamma[r];
+    for (int i = j * 4; i < row_len; i += tpr * 4) {
+      const long long e = (long long)r * row_len + i;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int s = 0; s < S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(partial + (long long)s * n + e);
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+      }
+      const uint2 wq = *reinterpret_cast<const uint2*>(w + e);
+      d += acc.x * __uint_as_float(wq.x << 16) + acc.y * __uint_as_float(wq.x & 0xffff0000u) +
+           acc.z * __uint_as_float(wq.y << 16) + acc.w * __uint_as_float(wq.y & 0xffff0000u);
+      acc.x *= sc, acc.y *= sc, acc.z *= sc, acc.w *= sc;
+      st4(out + e, acc);
+    }
+  }
+  s_dot[t] = d;
+  __syncthreads();
+  for (int off = tpr >> 1; off > 0; off >>= 1) {      // (tpr is a power of two: the groups never mix)
+    if (j < off) s_dot[t] += s_dot[t + off];
+    __syncthreads();
+  }
+  if (j == 0 && r < rows) rowdot[r] = s_dot[t];
 }
 
 // out[c][o] = w[o][c] * scale[o], scale[o] = gamma[o] / sqrt(var[o] + eps) (var NULL: 1): the (C, O) operand of the
@@ -540,11 +570,27 @@ __global__ __launch_bounds__(256) void g1_sums_finish_kernel(const float* __rest
 using namespace rsdet;
 
 static int sum_slabs_launch(const float* partial, int S, long long n, void* out, int out_bf16, const float* var,
-                            const float* gamma, float eps, int row_len, void* stream) {
+                            const float* gamma, float eps, int row_len, const uint16_t* weight, float* rowdot,
+                            void* stream) {
   if (S < 1 || n < 0 || (n & 3)) return RSDET_EINVAL;
   if (var && (row_len < 4 || (row_len & 3) || n % row_len)) return RSDET_EINVAL;
+  if ((weight == nullptr) != (rowdot == nullptr) || (rowdot && !var)) return RSDET_EINVAL;
   if (n == 0) return RSDET_OK;
   if (!partial || !out) return RSDET_EINVAL;
+  if (rowdot) {
+    if (n / row_len > 0x7fffffffll) return RSDET_EINVAL;
+    const int rows = (int)(n / row_len);
+    int tpr = 1;
+    while (tpr < 256 && tpr * 2 <= row_len / 4) tpr *= 2;
+    const dim3 grid((unsigned)((rows + 256 / tpr - 1) / (256 / tpr)));
+    if (out_bf16)
+      hipLaunchKernelGGL((sum_slabs_rows_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, rows, row_len,
+                         tpr, (bf16_t*)out, var, gamma, eps, (const bf16_t*)weight, rowdot);
+    else
+      hipLaunchKernelGGL((sum_slabs_rows_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, rows, row_len,
+                         tpr, (float*)out, var, gamma, eps, (const bf16_t*)weight, rowdot);
+    return rsdet_launch_status();
+  }
   const dim3 grid((unsigned)((n / 4 + 255) / 256));
   if (out_bf16)
     hipLaunchKernelGGL((sum_slabs_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, partial, S, n, (bf16_t*)out,
@@ -556,15 +602,17 @@ static int sum_slabs_launch(const float* partial, int S, long long n, void* out,
 }
 
 extern "C" int rsdet_sum_slabs_f32(const float* partial, int S, long long n, void* out, int out_bf16, void* stream) {
-  return sum_slabs_launch(partial, S, n, out, out_bf16, nullptr, nullptr, 0.f, 4, stream);
+  return sum_slabs_launch(partial, S, n, out, out_bf16, nullptr, nullptr, 0.f, 4, nullptr, nullptr, stream);
 }
 
-// the same with row r of the (n / row_len, row_len) result scaled by gamma[r] / sqrt(running_var[r] + eps)
+// the same with row r of the (n / row_len, row_len) result scaled by gamma[r] / sqrt(running_var[r] + eps).  weight (bf16,
+// the result's shape) and rowdot (n / row_len floats), both or neither: rowdot[r] = sum_i weight[r][i] * (the unscaled
+// fp32 sum)[r][i] -- what the BatchNorm's scale gradient is formed from (sum_slabs_rows_kernel's note).
 extern "C" int rsdet_sum_slabs_rowscale_f32(const float* partial, int S, long long n, int row_len,
-                                            const float* running_var, const float* gamma, float eps, void* out,
-                                            int out_bf16, void* stream) {
+                                            const float* running_var, const float* gamma, float eps,
+                                            const uint16_t* weight, float* rowdot, void* out, int out_bf16, void* stream) {
   if (!running_var) return RSDET_EINVAL;
-  return sum_slabs_launch(partial, S, n, out, out_bf16, running_var, gamma, eps, row_len, stream);
+  return sum_slabs_launch(partial, S, n, out, out_bf16, running_var, gamma, eps, row_len, weight, rowdot, stream);
 }
 
 // out (C, O) = transpose(weight (O, C)) with column o scaled by gamma[o] / sqrt(running_var[o] + eps) (running_var NULL:
@@ -646,16 +694,16 @@ extern "C" int rsdet_conv1x1_bn_act_fwd_bf16(const uint16_t* x, const uint16_t* 
 }
 
 // Backward-data of a 1x1 convolution as the same streaming GEMM: grad_in[p, c] = epi(sum_o grad_out[p, o] wt[c, o]),
-// grad_out (M, O), wt (C, O) (rsdet_weight_transpose_scale_bf16), grad_in / side (M, C), all bf16 row-major.
+// grad_out (M, O), wt (C, O) (rsdet_weight_transpose_scale_bf16 / ops/weight_prep.py), grad_in / side (M, C), all bf16
+// row-major.
 //   mode 0: epi = identity.
-//   mode 2: the convolution's INPUT was side = relu(bn(.)) of an eval-mode BatchNorm (running_var, gamma, beta of THAT
-//           BatchNorm over the C channels): grad_in = [side > 0] acc gamma / sqrt(var + eps) = the gradient of that
-//           BatchNorm's input; grad_gamma[c] = sum_p [side > 0] acc (side - beta) / gamma, grad_beta[c] = sum_p [side > 0] acc
-//           (either NULL: not formed; both NULL: no workspace needed).
+//   mode 2: the convolution's INPUT was side = relu(bn(.)) of an eval-mode BatchNorm: grad_in = [side > 0] acc = the gated
+//           gradient of that BatchNorm's OUTPUT (its scale rides in the weights of the next backward step, like this
+//           call's own wt may carry the scale of the BatchNorm behind this convolution); per-channel sums of grad_in
+//           (= that BatchNorm's grad_beta) with ws: folded into grad_beta when given, else LEFT in ws as (C, S, 2) floats
+//           ([0] the sum, [1] zero), S = rsdet_conv1x1_dgrad_slices(M, C, O), for rsdet_bn_affine_grads_finish_multi_f32.
 //   mode 3: grad_in = acc + side (the gradient that reaches the same tensor through the identity branch).
-// ws: rsdet_conv1x1_dgrad_ws_size(M, C, O) bytes for mode 2 with sums.  Mode 2 with ws but NEITHER gradient pointer: the
-// per-slice sums stay in ws as (C, S, 2) floats, S = rsdet_conv1x1_dgrad_slices(M, C, O), for
-// rsdet_bn_sums_finish_multi_f32 (csrc/bn_act.hip) to fold together with other passes' sums.
+// ws: rsdet_conv1x1_dgrad_ws_size(M, C, O) bytes (mode 2 with sums; NULL: no sums).
 extern "C" int rsdet_conv1x1_dgrad_slices(long long M, int C, int O) {
   if (!rsdet_gemm1x1_mfma_supported(M, C, O)) return 0;
   return g1_grid(M, C, true).row_lanes();
@@ -665,25 +713,23 @@ extern "C" size_t rsdet_conv1x1_dgrad_ws_size(long long M, int C, int O) {
 }
 
 extern "C" int rsdet_conv1x1_dgrad_bf16(const uint16_t* grad_out, const uint16_t* wt, long long M, int C, int O, int mode,
-                                        const uint16_t* side, const float* running_var, const float* gamma,
-                                        const float* beta, float eps, float* grad_gamma, float* grad_beta, void* ws,
-                                        size_t ws_bytes, uint16_t* grad_in, void* stream) {
+                                        const uint16_t* side, float* grad_beta, void* ws, size_t ws_bytes,
+                                        uint16_t* grad_in, void* stream) {
   if (!rsdet_gemm1x1_mfma_supported(M, C, O)) return RSDET_EINVAL;
   if (!grad_out || !wt || !grad_in || (mode != 0 && mode != G1_BWD_GATE && mode != G1_BWD_ADD)) return RSDET_EINVAL;
   if (mode != 0 && !side) return RSDET_EINVAL;
+  if (grad_beta && (mode != G1_BWD_GATE || !ws)) return RSDET_EINVAL;
   G1Geom g{M, C, O};
   const void *a_ptr = grad_out, *b_ptr = wt;
   uint16_t* out = grad_in;
   if (mode == G1_BWD_GATE) {
-    const bool fold = grad_gamma || grad_beta, sums = fold || ws;
-    if (sums && (!gamma || !beta)) return RSDET_EINVAL;
     const G1Grid gr = g1_grid(M, C, true);
-    if (sums && (!ws || ws_bytes < rsdet_conv1x1_dgrad_ws_size(M, C, O))) return RSDET_EINVAL;
-    G1Epi e{nullptr, running_var, gamma, beta, eps, (const bf16_t*)side, 0, sums ? (float*)ws : nullptr, gr.row_lanes()};
+    if (ws && ws_bytes < rsdet_conv1x1_dgrad_ws_size(M, C, O)) return RSDET_EINVAL;
+    G1Epi e{nullptr, nullptr, nullptr, nullptr, 0.f, (const bf16_t*)side, 0, (float*)ws, gr.row_lanes()};
     G1_LAUNCH_2(G1_BWD_GATE);
-    if (fold)
+    if (grad_beta)
       hipLaunchKernelGGL(g1_sums_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
-                         gr.row_lanes(), grad_gamma, grad_beta);
+                         gr.row_lanes(), (float*)nullptr, grad_beta);
     return rsdet_launch_status();
   }
   const G1Grid gr = g1_grid(M, C, false);

@@ -8,18 +8,23 @@ with every BatchNorm in eval mode (norm_eval, :177-184).  Round 5's first stage 
 convolutions into the GEMM's epilogue (ops/conv_bn.py).  With the block as one node the BACKWARD can be ordered by hand,
 and three of its passes over the block's widest tensors disappear:
 
-  * the gradient of conv3's raw output (gz * gamma3 / sqrt(var3 + eps)) is never written: the BatchNorm's scale rides in
-    the transposed weights of the backward-data GEMM and in the fold of the weight gradient, both of which read gz = gy *
-    [y3 > 0] -- which is ALSO the identity branch's gradient, so one tensor serves three consumers;
-  * bn2's backward (gate by y2 > 0, scale, the beta / gamma sums) is the EPILOGUE of conv3's backward-data GEMM
-    (csrc/gemm1x1_mfma.hip, mode 2): conv3's input gradient never reaches memory ungated, conv2's raw output and its ReLU
-    bit mask are not kept for the backward at all;
+  * NO gradient of a convolution's raw output is ever written: every gated gradient (gz = gy [y3 > 0], [y2 > 0] ...,
+    [y1 > 0] ...) is the gradient of a BatchNorm's OUTPUT, and that BatchNorm's scale s = gamma / sqrt(var + eps) rides in
+    the prepared weights of the backward-data step that reads it (ops/weight_prep.py: (W3 s3)^T, flipped W2 s2,
+    (W1 s1)^T) and in the fold of the weight gradient that reads it (gw = s U).  gz of the block's output is ALSO the
+    identity branch's gradient, so one tensor serves three consumers;
+  * bn2's gate (y2 > 0) and bias-gradient sums are the EPILOGUE of conv3's backward-data GEMM (csrc/gemm1x1_mfma.hip,
+    mode 2): conv3's input gradient never reaches memory ungated, conv2's raw output and its ReLU bit mask are not kept
+    for the backward at all;
   * the sum of the two gradients that reach x (through conv1 and through the identity) is the epilogue of conv1's
-    backward-data GEMM (mode 3) instead of an elementwise pass over three tensors of the block's widest shape.
+    backward-data GEMM (mode 3) instead of an elementwise pass over three tensors of the block's widest shape;
+  * the three scale gradients come from the weight-gradient folds: sum_p gz[p, o] conv(x)[p, o] = sum_k W[o, k] U[o, k]
+    with U the unscaled fp32 weight gradient, so grad_gamma = (rowdot - mean grad_beta) / sqrt(var + eps) needs neither the
+    convolution output nor xhat = (y - beta) / gamma recovered from a bf16 output (what round 5 did: the rounding of y is
+    amplified by 1 / gamma -- wrong sign below gamma ~ 1e-3, nothing at gamma = 0).  Exact for any gamma.
 
-Same sums as the per-operator route; the gradient of gamma uses xhat recovered from the stored output, exact wherever the
-gate is open (ops/conv_bn.py), and the scale folded into bf16 weights is rounded once more than on the per-operator
-route (tests/test_gpu_bottleneck.py pins both against the fp32 composite).
+Same sums as the per-operator route; the scales folded into bf16 weights are rounded once more than there
+(tests/test_gpu_bottleneck.py pins both against the fp32 composite, small and zero gammas included).
 
 Applies to: identity blocks (no downsample, stride 1, groups 1) on CUDA with bf16 channels_last activations, bf16
 weights (Runner(bf16_params=True)), eval-mode affine BatchNorms with fp32 parameters, every parameter trainable, channel
@@ -37,7 +42,7 @@ from .conv1x1 import _wrw_split_k
 from .conv3x3 import _mfma_wrw
 
 _ON = True      # False: the per-operator route (what this node is tested against)
-_PTR3, _INT3 = ctypes.c_void_p * 3, ctypes.c_int * 3
+_PTR3, _INT3, _FLT3 = ctypes.c_void_p * 3, ctypes.c_int * 3, ctypes.c_float * 3
 
 
 def _cl_empty(B, C, H, W, device):
@@ -70,17 +75,18 @@ class _Bottleneck(torch.autograd.Function):
         _lib.check(rc, "rsdet_bn_act_forward_nhwc_bf16")
         del c2
         y3 = _conv_bn_fwd(lib, y2, w3, (ga3, be3, m3, v3, e3), x)
-        ctx.save_for_backward(x, y1, y2, y3, w1, w2, w3, ga1, be1, ga2, be2, ga3, be3)
+        ctx.save_for_backward(x, y1, y2, y3, w1, w2, w3, ga1, ga2, ga3)
         ctx.stats, ctx.pad = stats, pad
-        # the operands of the backward that are functions of the weights alone: one launch per optimizer step for all
-        # blocks (ops/weight_prep.py)
-        ctx.prep = (wprep.entry(w1), wprep.entry(w2, flip=True) if pad == 1 else None, wprep.entry(w3, bn=(v3, ga3, e3)))
+        # the operands of the backward that are functions of the weights (and BatchNorm scales) alone: one launch per
+        # optimizer step for all blocks (ops/weight_prep.py)
+        ctx.prep = (wprep.entry(w1, bn=(v1, ga1, e1)), wprep.entry(w2, bn=(v2, ga2, e2), flip=True) if pad == 1 else None,
+                    wprep.entry(w3, bn=(v3, ga3, e3)))
         return y3
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.load()
-        x, y1, y2, y3, w1, w2, w3, ga1, be1, ga2, be2, ga3, be3 = ctx.saved_tensors
+        x, y1, y2, y3, w1, w2, w3, ga1, ga2, ga3 = ctx.saved_tensors
         (m1, v1, e1), (m2, v2, e2), (m3, v3, e3) = ctx.stats
         B, C0, H, W = x.shape
         C1 = w1.shape[0]
@@ -96,67 +102,87 @@ class _Bottleneck(torch.autograd.Function):
             nb = _memo(fn, *shape)
             return torch.empty((nb,), dtype=torch.uint8, device=dev), nb
 
-        # the beta / gamma sums of the three BatchNorms: per-slice partial tables, folded by ONE launch at the end
+        # the beta / gamma gradients of the three BatchNorms: per-slice sum tables + the folds' row dots, ONE launch at the end
         gsum = torch.empty((2, 2 * C1 + C0), **f32)            # row 0: the gamma gradients (bn1 | bn2 | bn3), row 1: beta
         gga1, gga2, gga3 = gsum[0, :C1], gsum[0, C1:2 * C1], gsum[0, 2 * C1:]
         gbe1, gbe2, gbe3 = gsum[1, :C1], gsum[1, C1:2 * C1], gsum[1, 2 * C1:]
-        # ---- 1: through relu(. + x): gz = gy [y3 > 0] (conv3's branch AND the identity's), bn3's sums
+        # ---- 1: through relu(. + x): gz = gy [y3 > 0] (the gradient of bn3's output AND the identity's), its channel sums
         gz = torch.empty_like(gy)
         ws3, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C0, HW)
-        rc = lib.rsdet_bn_act_backward_nhwc_fromy_sums_bf16(_lib.ptr(gy), _lib.ptr(y3), _lib.ptr(x), _lib.ptr(v3),
-                                                            _lib.ptr(ga3), _lib.ptr(be3), e3, B, C0, HW, 1, None,
-                                                            _lib.ptr(gz), _lib.ptr(ws3), nb, st)
-        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_sums_bf16")
+        rc = lib.rsdet_bn_gate_sums_nhwc_bf16(_lib.ptr(gy), _lib.ptr(y3), B, C0, HW, 1, _lib.ptr(gz), _lib.ptr(ws3), nb, st)
+        _lib.check(rc, "rsdet_bn_gate_sums_nhwc_bf16")
         gz2 = gz.permute(0, 2, 3, 1).reshape(P, C0)
-        # ---- 2: conv3's weight gradient from gz, bn3's scale applied in the fold
-        gw3 = _wrw_split_k(gz2, y2, w3, rowscale=(v3, ga3, e3))
-        # ---- 3: conv3's backward-data with bn3's scale in the weights and bn2's backward in the epilogue
-        gc2 = _cl_empty(B, C1, H, W, dev)
+        # ---- 2: conv3's weight gradient from gz, bn3's scale applied in the fold; the fold's row dots -> bn3's gamma
+        gw3, d3 = _wrw_split_k(gz2, y2, w3, rowscale=(v3, ga3, e3), rowdot=True)
+        # ---- 3: conv3's backward-data with bn3's scale in the weights, bn2's gate + sums in the epilogue
+        g2 = _cl_empty(B, C1, H, W, dev)                       # the gated gradient of bn2's OUTPUT
         ws2, nb = ws_for("rsdet_conv1x1_dgrad_ws_size", P, C1, C0)
-        wt3 = ctx.prep[2].tensor()
-        rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gz), _lib.ptr(wt3), P, C1, C0, 2, _lib.ptr(y2), _lib.ptr(v2),
-                                          _lib.ptr(ga2), _lib.ptr(be2), e2, None, None, _lib.ptr(ws2), nb, _lib.ptr(gc2), st)
+        rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gz), _lib.ptr(ctx.prep[2].tensor()), P, C1, C0, 2, _lib.ptr(y2), None,
+                                          _lib.ptr(ws2), nb, _lib.ptr(g2), st)
         _lib.check(rc, "rsdet_conv1x1_dgrad_bf16")
-        # ---- 4: conv2 (3x3): backward-data through the forward solver on the flipped weights, our split-K weight gradient
+        # ---- 4: conv2 (3x3), bn2's scale in its operands: backward-data through the forward solver on the flipped,
+        #         scaled weights; our split-K weight gradient with the scale (and the row dots) in its fold
         pad = ctx.pad
-        gw2 = None
+        bn2 = (v2, ga2, e2)
+        gw2 = d2 = None
         if pad == 1:
-            gc1 = F.conv2d(gc2, ctx.prep[1].tensor(), None, 1, 1)
+            g1 = F.conv2d(g2, ctx.prep[1].tensor(), None, 1, 1)
             if C1 % 128 == 0:
-                gw2 = _mfma_wrw(gc2, y1, w2.dtype)
+                r = _mfma_wrw(g2, y1, w2.dtype, rowscale=bn2, weight=w2)
+                if r is not None:
+                    gw2, d2 = r
             if gw2 is None:
-                gw2 = torch.ops.aten.convolution_backward(gc2, y1, w2, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                          (False, True, False))[1]
+                u2 = torch.ops.aten.convolution_backward(g2, y1, w2, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (False, True, False))[1]
+                gw2, d2 = _scale_rows(u2, w2, bn2)
         else:
-            gc1, gw2, _ = torch.ops.aten.convolution_backward(gc2, y1, w2, None, (1, 1), (pad, pad), (pad, pad), False,
-                                                              (0, 0), 1, (True, True, False))
-            gc1 = gc1.contiguous(memory_format=torch.channels_last)
-        del gc2
-        # ---- 5: bn1's backward from y1: gc1 [y1 > 0] gamma1 / sqrt(var1 + eps), its parameter gradients
-        g1, gc1 = gc1, torch.empty_like(gc1)
+            sc2 = _scale_of(bn2)
+            w2s = (w2.float() * sc2[:, None, None, None]).to(w2.dtype).contiguous(memory_format=torch.channels_last)
+            g1, u2, _ = torch.ops.aten.convolution_backward(g2, y1, w2s, None, (1, 1), (pad, pad), (pad, pad), False,
+                                                            (0, 0), 1, (True, True, False))
+            g1 = g1.contiguous(memory_format=torch.channels_last)
+            gw2, d2 = _scale_rows(u2, w2, bn2)
+        del g2
+        # ---- 5: bn1's gate from y1 (the gradient of bn1's OUTPUT), its channel sums
+        gz1 = torch.empty_like(g1)
         ws1, nb = ws_for("rsdet_bn_act_backward_nhwc_ws_size", B, C1, HW)
-        rc = lib.rsdet_bn_act_backward_nhwc_fromy_sums_bf16(_lib.ptr(g1), _lib.ptr(y1), None, _lib.ptr(v1), _lib.ptr(ga1),
-                                                            _lib.ptr(be1), e1, B, C1, HW, 1, _lib.ptr(gc1), None,
-                                                            _lib.ptr(ws1), nb, st)
-        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_sums_bf16")
-        # ---- the three folds as one launch
-        S = (_memo("rsdet_bn_act_backward_nhwc_fromy_slices", B, C1, HW), _memo("rsdet_conv1x1_dgrad_slices", P, C1, C0),
-             _memo("rsdet_bn_act_backward_nhwc_fromy_slices", B, C0, HW))
-        rc = lib.rsdet_bn_sums_finish_multi_f32(3, _PTR3(ws1.data_ptr(), ws2.data_ptr(), ws3.data_ptr()), _INT3(C1, C1, C0),
-                                                _INT3(*S), _PTR3(gga1.data_ptr(), gga2.data_ptr(), gga3.data_ptr()),
-                                                _PTR3(gbe1.data_ptr(), gbe2.data_ptr(), gbe3.data_ptr()), st)
-        _lib.check(rc, "rsdet_bn_sums_finish_multi_f32")
-        gc1_2 = gc1.permute(0, 2, 3, 1).reshape(P, C1)
-        # ---- 6: conv1's weight gradient
-        gw1 = _wrw_split_k(gc1_2, x, w1)
-        # ---- 7: conv1's backward-data + the identity branch's gz
+        rc = lib.rsdet_bn_gate_sums_nhwc_bf16(_lib.ptr(g1), _lib.ptr(y1), B, C1, HW, 1, _lib.ptr(gz1), _lib.ptr(ws1), nb, st)
+        _lib.check(rc, "rsdet_bn_gate_sums_nhwc_bf16")
+        del g1
+        # ---- 6: conv1's weight gradient, bn1's scale in the fold
+        gw1, d1 = _wrw_split_k(gz1.permute(0, 2, 3, 1).reshape(P, C1), x, w1, rowscale=(v1, ga1, e1), rowdot=True)
+        # ---- the three BatchNorms' parameter gradients as one launch
+        S = (_memo("rsdet_bn_gate_sums_nhwc_slices", B, C1, HW), _memo("rsdet_conv1x1_dgrad_slices", P, C1, C0),
+             _memo("rsdet_bn_gate_sums_nhwc_slices", B, C0, HW))
+        rc = lib.rsdet_bn_affine_grads_finish_multi_f32(
+            3, _PTR3(ws1.data_ptr(), ws2.data_ptr(), ws3.data_ptr()), _INT3(C1, C1, C0), _INT3(*S),
+            _PTR3(d1.data_ptr(), d2.data_ptr(), d3.data_ptr()), _PTR3(m1.data_ptr(), m2.data_ptr(), m3.data_ptr()),
+            _PTR3(v1.data_ptr(), v2.data_ptr(), v3.data_ptr()), _FLT3(e1, e2, e3),
+            _PTR3(gga1.data_ptr(), gga2.data_ptr(), gga3.data_ptr()), _PTR3(gbe1.data_ptr(), gbe2.data_ptr(), gbe3.data_ptr()),
+            st)
+        _lib.check(rc, "rsdet_bn_affine_grads_finish_multi_f32")
+        # ---- 7: conv1's backward-data (bn1's scale in the weights) + the identity branch's gz
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(gz)
-            rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gc1), _lib.ptr(ctx.prep[0].tensor()), P, C0, C1, 3, _lib.ptr(gz),
-                                              None, None, None, 0.0, None, None, None, 0, _lib.ptr(gx), st)
+            rc = lib.rsdet_conv1x1_dgrad_bf16(_lib.ptr(gz1), _lib.ptr(ctx.prep[0].tensor()), P, C0, C1, 3, _lib.ptr(gz),
+                                              None, None, 0, _lib.ptr(gx), st)
             _lib.check(rc, "rsdet_conv1x1_dgrad_bf16")
         return gx, gw1, gw2, gw3, gga1, gbe1, gga2, gbe2, gga3, gbe3, None, None
+
+
+def _scale_of(bn):
+    var, gamma, eps = bn
+    return torch.rsqrt(var + eps) * gamma
+
+
+def _scale_rows(u, w, bn):
+    """(s u, rowdot) from an UNSCALED weight gradient u a library kernel produced (bf16): the layers our split-K kernels do
+    not tile (64-channel and dilated conv2)."""
+    uf = u.float()
+    d = (uf * w.float()).sum((1, 2, 3))
+    gw = (uf * _scale_of(bn)[:, None, None, None]).to(w.dtype)
+    return gw.contiguous(memory_format=torch.channels_last), d
 
 
 def _bn_ok(bn):

@@ -27,7 +27,7 @@ _FWD_MAX_PIXELS = 65536
 _WRW_GEMM = True    # the weight gradient as a split-K batched GEMM (False: MIOpen's kernel)
 
 
-def _wrw_split_k(gy2, x, w, rowscale=None):
+def _wrw_split_k(gy2, x, w, rowscale=None, rowdot=False):
     """Weight gradient gw[o, c] = sum_p gy2[p, o] x2[p, c] as a SPLIT-K batched GEMM on views: the pixel axis cut into S
     slices, one (O, P/S) x (P/S, C) product per slice (torch.bmm on views, no copies), the S partial results summed.  A
     plain GEMM has K = all pixels and only (O/256)(C/256) tiles to spread over 256 CUs -- 5-10 x slower than MIOpen;
@@ -36,20 +36,29 @@ def _wrw_split_k(gy2, x, w, rowscale=None):
     The S partial products come back in fp32 (``out_dtype``: the GEMM's own accumulator, not rounded to bf16) and are
     summed in fp32: ONE rounding of the result, as in MIOpen's kernel.
     ``rowscale = (running_var, gamma, eps)``: row o of the result times gamma[o] / sqrt(running_var[o] + eps) before the
-    rounding -- gy2 is then the gradient of the OUTPUT of an eval-mode BatchNorm behind the convolution (ops/bottleneck.py)."""
+    rounding -- gy2 is then the gradient of the OUTPUT of an eval-mode BatchNorm behind the convolution (ops/bottleneck.py).
+    ``rowdot`` (with rowscale): returns ``(gw, d)`` with d[o] = sum_c w[o, c] U[o, c], U the unscaled fp32 gradient =
+    sum_p gy2[p, o] conv(x)[p, o] -- the term that BatchNorm's scale gradient is formed from without the convolution's
+    output ever having been stored (csrc/bn_act.hip: rsdet_bn_affine_grads_finish_multi_f32)."""
     P, O = gy2.shape
     C = x.shape[1]
     S = max(1, min(64, P // (1024 if x.dtype == torch.bfloat16 else 2048)))
     while S > 1 and P % S:
         S //= 2
     x2 = x.permute(0, 2, 3, 1).reshape(P, C)
-    if rowscale is not None and not (S > 1 and x.dtype == torch.bfloat16 and C % 4 == 0):
+    assert rowscale is not None or not rowdot
+
+    def cl(t):
+        return t.view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
+    if rowscale is not None and not (x.dtype == torch.bfloat16 and C % 4 == 0 and w.dtype == torch.bfloat16
+                                     and w.is_contiguous(memory_format=torch.channels_last)):
         var, gamma, eps = rowscale
         sc = torch.rsqrt(var + eps) * (1.0 if gamma is None else gamma)
-        gw = (torch.mm(gy2.t(), x2).float() * sc[:, None]).to(x.dtype)
-        return gw.view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
-    if S == 1:
-        return torch.mm(gy2.t(), x2).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
+        u = torch.mm(gy2.t(), x2).float()
+        gw = cl((u * sc[:, None]).to(x.dtype))
+        return (gw, (u * w.reshape(O, C).float()).sum(1)) if rowdot else gw
+    if S == 1 and rowscale is None:
+        return cl(torch.mm(gy2.t(), x2))
     a, b = gy2.view(S, P // S, O).transpose(1, 2), x2.view(S, P // S, C)
     part = torch.bmm(a, b, out_dtype=torch.float32) if x.dtype == torch.bfloat16 else torch.bmm(a, b)
     if part.dtype == torch.float32 and (O * C) % 4 == 0:
@@ -59,16 +68,17 @@ def _wrw_split_k(gy2, x, w, rowscale=None):
         gw = torch.empty((O, C, 1, 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         if rowscale is not None:
             var, gamma, eps = rowscale
+            d = torch.empty((O,), dtype=torch.float32, device=x.device) if rowdot else None
             rc = _lib.load().rsdet_sum_slabs_rowscale_f32(_lib.ptr(part), S, O * C, C, _lib.ptr(var), _lib.ptr(gamma),
-                                                          float(eps), _lib.ptr(gw), int(x.dtype == torch.bfloat16),
-                                                          _lib.stream_ptr())
+                                                          float(eps), _lib.ptr(w) if rowdot else None, _lib.ptr(d),
+                                                          _lib.ptr(gw), int(x.dtype == torch.bfloat16), _lib.stream_ptr())
             _lib.check(rc, "rsdet_sum_slabs_rowscale_f32")
-            return gw
+            return (gw, d) if rowdot else gw
         rc = _lib.load().rsdet_sum_slabs_f32(_lib.ptr(part), S, O * C, _lib.ptr(gw), int(x.dtype == torch.bfloat16),
                                              _lib.stream_ptr())
         _lib.check(rc, "rsdet_sum_slabs_f32")
         return gw
-    return part.sum(0).to(x.dtype).view(O, C, 1, 1).contiguous(memory_format=torch.channels_last)
+    return cl(part.sum(0).to(x.dtype))
 
 
 class _Conv1x1(torch.autograd.Function):

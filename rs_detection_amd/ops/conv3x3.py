@@ -102,10 +102,14 @@ def _mfma_conv(x, w_cl, bias, live, relu):
 _MFMA_WRW = True
 
 
-def _mfma_wrw(g, x, out_dtype):
+def _mfma_wrw(g, x, out_dtype, rowscale=None, weight=None):
     """Weight gradient (O, C, 3, 3) channels_last of the 3x3 convolution from g (B,O,H,W) and x (B,C,H,W), both bf16
     channels_last (csrc/conv3x3_wrw_mfma.hip: split-K implicit GEMM + fold, two launches); None when the kernel does not
-    take the shape or the weight's dtype."""
+    take the shape or the weight's dtype.
+    ``rowscale = (running_var, gamma, eps)`` with ``weight`` (the convolution's own bf16 channels_last weight): g is the
+    gradient of the OUTPUT of an eval-mode BatchNorm behind the convolution -- row o of the result is scaled by gamma[o] /
+    sqrt(var[o] + eps) and ``(gw, rowdot)`` is returned, rowdot[o] = sum weight[o] * (the unscaled fp32 row) (the term
+    that BatchNorm's scale gradient is formed from, ops/bottleneck.py)."""
     from .. import _lib
     if out_dtype not in (torch.bfloat16, torch.float32):
         return None
@@ -117,6 +121,15 @@ def _mfma_wrw(g, x, out_dtype):
     gw = torch.empty((O, C, 3, 3), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     nb = lib.rsdet_conv3x3_wrw_mfma_ws_size(B, H, W, C, O)
     ws = torch.empty((nb,), dtype=torch.uint8, device=x.device)
+    if rowscale is not None:
+        var, gamma, eps = rowscale
+        d = torch.empty((O,), dtype=torch.float32, device=x.device)
+        rc = lib.rsdet_conv3x3_wrw_mfma_rowscale_bf16(_lib.ptr(g), _lib.ptr(x), B, H, W, C, O, _lib.ptr(var),
+                                                      _lib.ptr(gamma), float(eps), _lib.ptr(weight), _lib.ptr(d),
+                                                      _lib.ptr(gw), int(out_dtype == torch.bfloat16), _lib.ptr(ws), nb,
+                                                      _lib.stream_ptr())
+        _lib.check(rc, "rsdet_conv3x3_wrw_mfma_rowscale_bf16")
+        return gw, d
     rc = lib.rsdet_conv3x3_wrw_mfma_bf16(_lib.ptr(g), _lib.ptr(x), B, H, W, C, O, _lib.ptr(gw),
                                          int(out_dtype == torch.bfloat16), _lib.ptr(ws), nb, _lib.stream_ptr())
     _lib.check(rc, "rsdet_conv3x3_wrw_mfma_bf16")

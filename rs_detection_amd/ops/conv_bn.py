@@ -7,18 +7,26 @@ convolutions as library GEMMs on (positions, channels) views (ops/conv1x1.py) an
 over the result (ops/bn_act.py); here the tail sits in the GEMM's epilogue and the convolution's raw output never
 reaches memory: one launch and one autograd node instead of two, 0.86 ms of `bn_act` forward passes less per bf16 step.
 
-Backward (one node): the BatchNorm / ReLU / residual part is csrc/bn_act.hip's channels-last pass in its ``from_y`` form
-(the normalised input the scale gradient needs is recovered from the OUTPUT: xhat = (y - identity - beta) / gamma
-wherever the ReLU let the value through), then backward-data as a library GEMM and the weight gradient as the split-K
-batched GEMM of ops/conv1x1.py.
+Backward (one node): one gate pass gz = gy [y > 0] with the bias-gradient sums (csrc/bn_act.hip,
+rsdet_bn_gate_sums_nhwc_bf16); the BatchNorm's scale s = gamma / sqrt(var + eps) then rides in the WEIGHTS of the
+backward-data GEMM (gx = gz (W s)) and in the fold of the split-K weight gradient (gw = s U, U = gz^T x in fp32), and the
+scale gradient comes from that fold too: sum_p gz conv(x) = sum_c W[o, c] U[o, c], so
+grad_gamma = (rowdot - mean grad_beta) / sqrt(var + eps) -- the convolution output the forward computed, never stored
+and never recovered from the bf16 output (round 5 divided (y - beta) by gamma: unstable for small gamma, lost for
+gamma = 0).
 Applies to: CUDA, bf16 activations AND bf16 weights (``Runner(bf16_params=True)``), channels_last, 1x1 / stride 1 / no
 bias / groups 1, C % 64 == 0, O % 32 == 0, BatchNorm in eval mode with fp32 parameters.  Anything else takes
 ``bn_act(conv1x1(conv, x), bn, residual, relu)`` -- the same function in two launches."""
 import torch
 
+import ctypes
+
 from .. import _lib
+from . import weight_prep as wprep
 from .bn_act import _memo, bn_act
 from .conv1x1 import _wrw_split_k, conv1x1
+
+_P1, _I1, _F1 = ctypes.c_void_p * 1, ctypes.c_int * 1, ctypes.c_float * 1
 
 _ON = True      # False: always the two-launch form (what the fused form is tested against)
 
@@ -35,14 +43,16 @@ class _Conv1x1BNAct(torch.autograd.Function):
                                                _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(residual),
                                                int(relu), _lib.ptr(y), _lib.stream_ptr())
         _lib.check(rc, "rsdet_conv1x1_bn_act_fwd_bf16")
-        ctx.save_for_backward(x, w, y, residual, gamma, beta, var)
-        ctx.eps, ctx.relu = float(eps), bool(relu)
+        ctx.save_for_backward(x, w, y, gamma, mean, var)
+        ctx.eps, ctx.relu, ctx.has_res = float(eps), bool(relu), residual is not None
+        # the backward-data operand (W s)^T: refreshed with all the others once per optimizer step (ops/weight_prep.py)
+        ctx.prep = wprep.entry(w, bn=(var, gamma, float(eps))) if wprep.applies(w) else None
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.load()
-        x, w, y, residual, gamma, beta, var = ctx.saved_tensors
+        x, w, y, gamma, mean, var = ctx.saved_tensors
         B, C, H, W = x.shape
         O = w.shape[0]
         gy = gy.contiguous(memory_format=torch.channels_last)
@@ -50,30 +60,44 @@ class _Conv1x1BNAct(torch.autograd.Function):
             gy = gy.to(torch.bfloat16)
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_g = gamma is not None and ctx.needs_input_grad[2]
-        need_b = beta is not None and ctx.needs_input_grad[3]
-        need_res = residual is not None and ctx.needs_input_grad[7]
-        # ---- through relu / + identity / the BatchNorm's affine map: gc = gradient of the convolution's raw output
-        gc = torch.empty_like(gy) if (need_x or need_w) else None
-        gres = (torch.empty_like(gy) if ctx.relu else gy) if need_res else None
-        gg = torch.empty_like(gamma) if need_g else None
-        gb = torch.empty_like(beta) if need_b else None
-        ws_bytes = _memo("rsdet_bn_act_backward_nhwc_ws_size", B, O, H * W) if (need_g or need_b) else 0
+        need_b = ctx.needs_input_grad[3]
+        need_res = ctx.has_res and ctx.needs_input_grad[7]
+        # ---- through relu: gz = the gradient of the BatchNorm's OUTPUT (and of the identity branch), its channel sums
+        sums = need_g or need_b
+        gz = torch.empty_like(gy) if ctx.relu else gy
+        ws_bytes = _memo("rsdet_bn_act_backward_nhwc_ws_size", B, O, H * W) if sums else 0
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gy.device) if ws_bytes else None
-        rc = lib.rsdet_bn_act_backward_nhwc_fromy_bf16(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(residual), _lib.ptr(var),
-                                                       _lib.ptr(gamma), _lib.ptr(beta), ctx.eps, B, O, H * W,
-                                                       int(ctx.relu), _lib.ptr(gc),
-                                                       _lib.ptr(gres) if (need_res and ctx.relu) else None,
-                                                       _lib.ptr(gg), _lib.ptr(gb), _lib.ptr(ws), ws_bytes,
-                                                       _lib.stream_ptr())
-        _lib.check(rc, "rsdet_bn_act_backward_nhwc_fromy_bf16")
-        gx = gw = None
-        if need_x or need_w:
-            gc2 = gc.permute(0, 2, 3, 1).reshape(-1, O)
-            if need_x:
-                gx = torch.mm(gc2, w.reshape(O, C)).view(B, H, W, C).permute(0, 3, 1, 2)
-            if need_w:
-                gw = _wrw_split_k(gc2, x, w)
-        return gx, gw, gg, gb, None, None, None, gres, None
+        if ctx.relu or sums:
+            rc = lib.rsdet_bn_gate_sums_nhwc_bf16(_lib.ptr(gy), _lib.ptr(y), B, O, H * W, int(ctx.relu),
+                                                  _lib.ptr(gz) if ctx.relu else None, _lib.ptr(ws), ws_bytes,
+                                                  _lib.stream_ptr())
+            _lib.check(rc, "rsdet_bn_gate_sums_nhwc_bf16")
+        gx = gw = gg = gb = d = None
+        gz2 = gz.permute(0, 2, 3, 1).reshape(-1, O)
+        scale = (var, gamma, ctx.eps)
+        if need_w or need_g:
+            gw, d = _wrw_split_k(gz2, x, w, rowscale=scale, rowdot=True)
+        if need_x:
+            wt = ctx.prep.tensor() if ctx.prep is not None else _scaled_t(w, scale)        # (C, O) = (W s)^T
+            gx = torch.mm(gz2, wt.t()).view(B, H, W, C).permute(0, 3, 1, 2)
+        if sums:
+            gb = torch.empty((O,), dtype=torch.float32, device=gy.device)
+            gg = torch.empty((O,), dtype=torch.float32, device=gy.device) if need_g else None
+            S = _memo("rsdet_bn_gate_sums_nhwc_slices", B, O, H * W)
+            rc = lib.rsdet_bn_affine_grads_finish_multi_f32(
+                1, _P1(ws.data_ptr()), _I1(O), _I1(S), _P1(d.data_ptr() if need_g else None), _P1(mean.data_ptr()),
+                _P1(var.data_ptr()), _F1(ctx.eps), _P1(gg.data_ptr() if need_g else None), _P1(gb.data_ptr()),
+                _lib.stream_ptr())
+            _lib.check(rc, "rsdet_bn_affine_grads_finish_multi_f32")
+        return gx, (gw if need_w else None), gg, (gb if need_b else None), None, None, None, \
+            (gz if need_res else None), None
+
+
+def _scaled_t(w, scale):
+    var, gamma, eps = scale
+    sc = torch.rsqrt(var + eps) * (1.0 if gamma is None else gamma)
+    O, C = w.shape[0], w.shape[1]
+    return (w.reshape(O, C).float() * sc[:, None]).to(w.dtype).t().contiguous()
 
 
 def conv_bn_act_applies(conv, bn, x, residual):

@@ -11,8 +11,9 @@ Rounds 3-5 made them where they were used: one small launch (and one allocation)
 weights only change when an optimizer steps (or a checkpoint loads), so a registry keeps one persistent output per weight
 and recomputes ALL of them with one multi-tensor launch the first time any is asked for after a change.
 
-Staleness is detected two ways, both checked on every request: torch's own version counter of the weight (bumped by every
-in-place torch operation: torch optimizers, load_state_dict, copy_) and a package-wide epoch that our fused optimizers --
+Staleness is detected two ways, both checked on every request: torch's own version counters of the weight and of the folded
+BatchNorm's running_var / gamma (bumped by every in-place torch operation: torch optimizers, load_state_dict, copy_; the
+BatchNorm tensors are held weakly, an entry whose tensors died is dropped) and a package-wide epoch that our fused optimizers --
 which write through raw pointers and so do not touch version counters -- bump in step() (optims/optimizer.py).  Entries hold
 the Parameter weakly; a changed data pointer (p.data reassigned, module moved) rebuilds the device table.  The one edit
 neither sees is an in-place write through ``p.data`` (its alias has a version counter of its own): call bump_epoch() after it.
@@ -38,11 +39,30 @@ def bump_epoch():
 class Entry:
     __slots__ = ("w", "bn", "flip", "out", "version", "ptrs", "reg", "__weakref__")
 
+    def bn_tensors(self):
+        """(running_var, gamma, eps) of the folded BatchNorm (held weakly), or None; a dead reference makes the entry dead."""
+        if self.bn is None:
+            return None
+        var, gamma = self.bn[0](), (self.bn[1]() if self.bn[1] is not None else None)
+        if var is None or (self.bn[1] is not None and gamma is None):
+            return False
+        return var, gamma, self.bn[2]
+
+    def _stamp(self, w):
+        bn = self.bn_tensors()
+        if not bn:
+            return (w._version,)
+        var, gamma, _ = bn
+        return (w._version, var._version, var.data_ptr(), -1 if gamma is None else gamma._version,
+                0 if gamma is None else gamma.data_ptr())
+
     def tensor(self):
-        """The prepared operand, fresh with respect to the weight's current values."""
+        """The prepared operand, fresh with respect to the current values of the weight AND of the folded BatchNorm's
+        running_var / gamma (torch in-place edits of either bump their version counters: a partial load_state_dict, EMA /
+        SWA averaging, a manual re-initialisation)."""
         reg = self.reg
         w = self.w()
-        if reg.epoch != _EPOCH[0] or w is None or self.version != w._version or self.ptrs[0] != w.data_ptr():
+        if reg.epoch != _EPOCH[0] or w is None or self.ptrs[0] != w.data_ptr() or self.version != self._stamp(w):
             reg.refresh()
         return self.out
 
@@ -62,11 +82,16 @@ class _Registry:
             per = self.entries[w] = {}
         key = (None if bn is None else (id(bn[0]), id(bn[1]), float(bn[2])), bool(flip))
         e = per.get(key)
+        if e is not None and bn is not None:
+            cur = e.bn_tensors()             # (ids can be reused after a tensor died: the entry must hold THESE tensors)
+            if not cur or cur[0] is not bn[0] or cur[1] is not bn[1]:
+                e = None
         if e is None:
             O, C = w.shape[0], w.shape[1]
             T = w.shape[2] * w.shape[3]
             e = Entry()
-            e.w, e.bn, e.flip, e.reg = weakref.ref(w), bn, flip, self
+            e.w, e.flip, e.reg = weakref.ref(w), flip, self
+            e.bn = None if bn is None else (weakref.ref(bn[0]), None if bn[1] is None else weakref.ref(bn[1]), float(bn[2]))
             if T == 1:
                 e.out = torch.empty((C, O), dtype=torch.bfloat16, device=w.device)
             else:
@@ -80,7 +105,10 @@ class _Registry:
     def _live(self):
         out = []
         for w, per in list(self.entries.items()):
-            for e in per.values():
+            for key, e in list(per.items()):
+                if e.bn_tensors() is False:      # its BatchNorm's tensors are gone (buffer reassigned, module dropped)
+                    del per[key]
+                    continue
                 out.append((w, e))
         return out
 
@@ -91,7 +119,7 @@ class _Registry:
             var = gamma = None
             eps = 0.0
             if e.bn is not None:
-                var, gamma, eps = e.bn
+                var, gamma, eps = e.bn_tensors()
             ptrs = (w.data_ptr(), e.out.data_ptr(), 0 if var is None else var.data_ptr(),
                     0 if gamma is None else gamma.data_ptr())
             e.ptrs = ptrs
@@ -112,7 +140,7 @@ class _Registry:
                                                           _lib.stream_ptr())
             _lib.check(rc, "rsdet_weight_prep_multi_bf16")
         for w, e in live:
-            e.version = w._version
+            e.version = e._stamp(w)
         self.epoch = _EPOCH[0]
 
 

@@ -108,7 +108,11 @@ class Runner:
         elif distributed and torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 (self.world > 1 or distributed == "force"):
             from rs_detection_amd.utils.reducer import GradReducer
-            self.reducer = GradReducer(self.model)
+            self.reducer = GradReducer(self.model)       # (broadcasts rank 0's parameters and buffers)
+            if frozen_masters and self.world > 1:
+                # the fp32 originals of the frozen bf16 weights were taken BEFORE that broadcast: rank 0's as well
+                for k in sorted(frozen_masters):
+                    torch.distributed.broadcast(frozen_masters[k], 0)
         self.iter, self.epoch = 0, 0
         self.max_epoch = cfg.max_epoch if hasattr(cfg, "max_epoch") else None
         self.max_iter = cfg.max_iter if hasattr(cfg, "max_iter") else None
@@ -135,6 +139,8 @@ class Runner:
         swa = swa_factor is not None and self.optimizer_swa is not None
         opt = self.optimizer_swa if swa else self.optimizer
         opt.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self.reducer.begin_step()    # every gradient None: the buckets may leave from inside backward (utils/reducer.py)
         total.backward()
         if self.reducer is not None:
             self.reducer.reduce()        # gradient mean over the ranks (most of it already in flight: utils/reducer.py)

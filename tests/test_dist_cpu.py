@@ -397,14 +397,32 @@ def _reducer_worker(rank, world, port, q):
     params = [p for p in model.parameters() if p.requires_grad]
     x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(100 + rank))
 
-    def backward():
-        for p in model.parameters():
-            p.grad = None
+    launched_early = []
+
+    def backward(protocol=True, keep=False):
+        if not keep:
+            for p in model.parameters():
+                p.grad = None
+        if protocol:
+            red.begin_step()                     # (what Runner.train_step does between zero_grad and backward)
         (model(x).square().mean() * (rank + 1)).backward()
+        launched_early.append(red._next)         # buckets the hooks sent from inside backward
         red.reduce()
         return torch.cat([p.grad.reshape(-1) for p in params])
-    backward()
-    got = backward()                             # second step: the buckets are reused
+    backward()                                   # first step: records (and cross-checks) the used set, nothing leaves early
+    got = backward()                             # second step: armed -- every bucket leaves from inside backward
+    early = list(launched_early)
+    unarmed = backward(protocol=False)           # a caller without begin_step: same result, everything sent by reduce()
+    # gradients zeroed in place (zero_grad(set_to_none=False)): p.grad IS the bucket view when backward starts -- the hooks
+    # must NOT take "present" for "produced" (not armed), the sum lands in the bucket, the mean is the same
+    for p in params:
+        p.grad.zero_()
+    inplace = backward(keep=True)
+    same = float(max((unarmed - got).abs().max(), (inplace - got).abs().max()))
+    # accumulation: a local step under no_sync, then a synchronised one on top of it == mean over ranks of 2 x local
+    with red.no_sync():
+        backward()
+    accum = backward(keep=True)
     owned = all(red.owns(p.grad) for p in params) and all(p.grad.stride() == p.stride() for p in params)
     with red.no_sync():
         local = backward()
@@ -413,8 +431,10 @@ def _reducer_worker(rank, world, port, q):
     w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     ws = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(ws, w)
-    q.put((rank, float((got - sum(gathered) / world).abs().max()), float((ws[0] - ws[1]).abs().max()), len(red.buckets),
-           owned, not any(red.owns(p.grad) for p in params)))      # (under no_sync the gradients stay local tensors)
+    mean = sum(gathered) / world
+    q.put((rank, float((got - mean).abs().max()), float((ws[0] - ws[1]).abs().max()), len(red.buckets),
+           owned, not any(red.owns(p.grad) for p in params),       # (under no_sync the gradients stay local tensors)
+           early, launched_early[2:4], same, float((accum - 2 * mean).abs().max())))
     rdist.shutdown()
 
 
@@ -429,5 +449,92 @@ def test_grad_reducer_two_ranks_gloo():
     [p.start() for p in ps]
     res = sorted(q.get(timeout=180) for _ in range(2))
     [p.join(60) for p in ps]
-    for rank, err, spread, nb, owned, strides in res:
+    for rank, err, spread, nb, owned, strides, early, late, same, accum in res:
         assert err <= 1e-7 and spread == 0.0 and nb == 2 and owned and strides, res
+        assert early == [0, 2], res             # step 1 records the used set; step 2 (armed) sends both buckets from the hooks
+        assert late == [0, 0], res              # no begin_step / gradients present at the start: nothing leaves early
+        assert same <= 1e-7 and accum <= 1e-6, res
+
+
+def _reducer_mismatch_worker(rank, world, port, q):
+    """rank 1 leaves the middle layer out of its graph.  Round 5's reducer returned OK with every gradient
+    averaged against the wrong bucket; now every rank raises at the first reduce()."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from rs_detection_amd.utils import dist as rdist
+    from rs_detection_amd.utils.reducer import GradReducer
+    rdist.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(3)])
+    red = GradReducer(layers, bucket_cap_mb=0.0001)
+    x = torch.randn(4, 8)
+
+    def step(skip_middle):
+        for p in layers.parameters():
+            p.grad = None
+        red.begin_step()
+        h = layers[0](x)
+        if not skip_middle:
+            h = layers[1](h)
+        layers[2](h).square().mean().backward()
+        red.reduce()
+    msg = None
+    try:
+        step(skip_middle=(rank == 1))
+    except RuntimeError as e:
+        msg = str(e)
+    q.put((rank, "first", msg))
+    rdist.shutdown()
+
+
+def _reducer_drift_worker(rank, world, port, q):
+    """... and a used set that changes AFTER the first step is refused locally, before any collective of that step."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from rs_detection_amd.utils import dist as rdist
+    from rs_detection_amd.utils.reducer import GradReducer
+    rdist.init_distributed(backend="gloo", force=True)
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(3)])
+    red = GradReducer(layers, bucket_cap_mb=0.0001)
+    x = torch.randn(4, 8)
+
+    def step(skip_middle):
+        for p in layers.parameters():
+            p.grad = None
+        red.begin_step()
+        h = layers[0](x)
+        if not skip_middle:
+            h = layers[1](h)
+        layers[2](h).square().mean().backward()
+        red.reduce()
+    step(True)
+    unused_stay_none = layers[1].weight.grad is None and layers[0].weight.grad is not None
+    step(True)
+    msg = None
+    try:
+        step(False)
+    except RuntimeError as e:
+        msg = str(e)
+    q.put((unused_stay_none, msg))
+    rdist.shutdown()
+
+
+def test_grad_reducer_refuses_rank_dependent_and_drifting_graphs():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_reducer_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    [p.join(60) for p in ps]
+    for rank, _, msg in res:                    # BOTH ranks raise (nobody is left waiting in a collective)
+        assert msg is not None and "ranks disagree" in msg and "1.weight" in msg, res
+    p = ctx.Process(target=_reducer_drift_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    unused_stay_none, msg = q.get(timeout=120)
+    p.join(60)
+    assert unused_stay_none                     # a parameter no rank uses keeps grad None (no decay / momentum on it)
+    assert msg is not None and "must not change between steps" in msg and "1." in msg

@@ -2,8 +2,8 @@
 ops/conv_bn.py) against a plain fp32 torch reference of the same op (conv2d -> batch_norm(eval) -> add -> relu) and its
 autograd gradients -- the parity bar for a floating-point kernel: bf16 operands, fp32 accumulation, one rounding, so
 the forward agrees to bf16 resolution (2^-8 of the value range) and the gradients to the bf16 resolution of THEIR
-operands.  The scale gradient uses xhat recovered from the output (from_y form of csrc/bn_act.hip): compared with the
-fp32 autograd value as well."""
+operands.  The scale gradient comes from the weight-gradient fold's row dots (ops/conv_bn.py) -- compared with the fp32
+autograd value too, at ordinary AND at tiny / zero / negative gammas (where round 5's xhat-from-the-output form broke)."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +16,7 @@ def _rel(a, b):
     return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12))
 
 
-def _make(cuda, B, C, O, H, W, res, seed):
+def _make(cuda, B, C, O, H, W, res, seed, small_gamma=False):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, C, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
     conv = torch.nn.Conv2d(C, O, 1, bias=False).to(cuda)
@@ -25,6 +25,12 @@ def _make(cuda, B, C, O, H, W, res, seed):
     with torch.no_grad():
         bn.weight.copy_(torch.empty(O).uniform_(0.5, 1.5, generator=g)), bn.bias.copy_(torch.randn(O, generator=g) * 0.3)
         bn.running_mean.copy_(torch.randn(O, generator=g) * 0.3), bn.running_var.copy_(torch.empty(O).uniform_(0.5, 2, generator=g))
+        if small_gamma:                          # log-uniform in [1e-8, 1e-1], random signs, every fifth exactly 0; beta ~ 1
+            mag = 10.0 ** torch.empty(O).uniform_(-8, -1, generator=g)
+            sign = torch.where(torch.rand(O, generator=g) < 0.3, -1.0, 1.0)
+            bn.weight.copy_(mag * sign)
+            bn.weight[::5] = 0.0
+            bn.bias.copy_(torch.randn(O, generator=g) * 0.5 + 0.7)
     r = torch.randn(B, O, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last) if res else None
     return x, conv, bn, r
 
@@ -32,9 +38,10 @@ def _make(cuda, B, C, O, H, W, res, seed):
 @pytest.mark.parametrize("B,C,O,H,W,res,relu", [(4, 256, 128, 64, 64, False, True), (2, 128, 512, 40, 56, True, True),
                                                 (2, 512, 1024, 16, 16, False, False), (1, 64, 64, 37, 29, True, True),
                                                 (3, 2048, 512, 8, 8, False, True), (1, 64, 32, 5, 3, True, False)])
-def test_fused_conv_bn_act_forward_and_backward(cuda, B, C, O, H, W, res, relu):
+@pytest.mark.parametrize("small_gamma", [False, True])
+def test_fused_conv_bn_act_forward_and_backward(cuda, B, C, O, H, W, res, relu, small_gamma):
     from rs_detection_amd.ops import conv_bn
-    x, conv, bn, r = _make(cuda, B, C, O, H, W, res, B * C + O)
+    x, conv, bn, r = _make(cuda, B, C, O, H, W, res, B * C + O, small_gamma)
     assert conv_bn.conv_bn_act_applies(conv, bn, x, r)
     xg = x.clone().requires_grad_(True)
     rg = r.clone().requires_grad_(True) if res else None
@@ -61,7 +68,10 @@ def test_fused_conv_bn_act_forward_and_backward(cuda, B, C, O, H, W, res, relu):
     assert _rel(xg.grad, xf.grad) <= 1.5e-2, _rel(xg.grad, xf.grad)
     assert _rel(conv.weight.grad, wf.grad) <= 1.5e-2
     assert _rel(bn.bias.grad, bf.grad) <= 1e-2
-    assert _rel(bn.weight.grad, gf.grad) <= 3e-2, _rel(bn.weight.grad, gf.grad)     # xhat from the bf16 output
+    # the scale gradient: fp32 row dots of bf16-valued operands -- as tight as the bias gradient, whatever gamma is (round 5:
+    # 3e-2 at gamma in [0.5, 1.5] and garbage below 1e-3)
+    assert _rel(bn.weight.grad, gf.grad) <= 1e-2, _rel(bn.weight.grad, gf.grad)
+    assert float((bn.weight.grad - gf.grad).abs().max()) <= 1e-2 * float(gf.grad.abs().max())        # per channel, gamma == 0 included
     if res:
         assert _rel(rg.grad, rf.grad) <= 1e-2
 
