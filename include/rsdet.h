@@ -435,6 +435,83 @@ int rsdet_bn_affine_grads_finish_multi_f32(int n, const float* const* partial, c
                                            const float* const* rowdot, const float* const* running_mean,
                                            const float* const* running_var, const float* eps, float* const* grad_gamma,
                                            float* const* grad_beta, void* stream);
+/* The 1x1 convolutions of a VAN block on NCHW fp32 maps as streaming GEMMs on the fp32 matrix cores, the block's
+ * elementwise tails in their epilogues (csrc/van_gemm.hip; /root/reference/python/jdet/models/backbones/van.py:140-263:
+ * Mlp.fc1 / fc2, AttentionModule.conv1, SpatialAttention.proj_1 / proj_2 and the expressions around them, Block.execute;
+ * the backward-data GEMMs are the same call on transposed weights).  out (n_img, M, P) = epi(weight (M, K) . x (n_img, K, P)),
+ * fp32, pixels contiguous; r = output row (channel), v* (M) per-row vectors, s* maps of the output's shape:
+ *   epi 0  out0 = acc                              4  out0 = s0 v0[r] + acc v1[r] + v2[r] (+ s1 v3[r] if s1; v0 NULL: 1)
+ *       1  out0 = acc + v0[r]                      5  out0 = acc s0, out1 = acc s1
+ *       2  out0 = acc + v0[r], out1 = GELU(out0)   6  out0 = acc GELU'(s0)
+ *       3  out0 = acc + v0[r], out1 = out0 s0
+ * (GELU = the erf form of jt.nn.GELU.)  _supported: M a multiple of 160 / 128 (P % 64 == 0) or 64 (P % 128 == 0), K % 32 == 0;
+ * every pointer 16-byte aligned.  Exact fp32: a k-ordered fmaf chain per output element. */
+int rsdet_van_gemm_f32_supported(int M, int K, int P, int n_img);
+int rsdet_van_gemm_f32(const float* weight, const float* x, int M, int K, int P, int n_img, int epi, const float* v0,
+                       const float* v1, const float* v2, const float* v3, const float* s0, const float* s1, float* out0,
+                       float* out1, void* stream);
+/* Weight gradient of those convolutions: partial[s] (M, N) = sum over split s's (image, 32-pixel chunk) range of
+ * g[img][m][p] x[img][n][p] (g (n_img, M, P), x (n_img, N, P)); S = rsdet_van_wgrad_f32_splits partials, summed in order by a
+ * fold below.  M a multiple of 160 / 128 / 64, N of 64, P of 32. */
+int rsdet_van_wgrad_f32_supported(int M, int N, int P, int n_img);
+int rsdet_van_wgrad_f32_splits(int M, int N, int P, int n_img);
+int rsdet_van_wgrad_f32(const float* g, const float* x, int M, int N, int P, int n_img, float* partial, void* stream);
+/* Fold of the partials U = sum_s partial[s] (M, N), one launch per convolution, for a convolution whose output (plus
+ * bias) is multiplied by a per-channel layer scale before it meets the gradient g (Block.execute, van.py:258-261):
+ *   grad_w = row_scale[m] U[m][n] (row_scale NULL: 1);  grad_b[m] = row_scale[m] gs[m], gs = sum_p g[m, p] from the slice
+ *   partials gs_tab[(m * gs_ns + j) * gs_stride];  grad_rs[m] (the layer scale's gradient) = sum_n w[m][n] U[m][n] +
+ *   bias[m] gs[m] + sc[m] R2[m] + sh[m] R1[m]  (r_tab (M, r_ns, 2): slice partials of (sum_p g, sum_p g x) when the scaled sum
+ *   also holds the shortcut xn = x sc + sh; NULL: absent).  grad_b / grad_rs NULL: not formed.  N % 4 == 0. */
+typedef struct rsdet_van_rows_fold {
+  const float *partial, *row_scale, *w, *gs_tab, *bias, *r_tab, *sc, *sh;
+  float *grad_w, *grad_b, *grad_rs;
+  int S, M, N, gs_ns, gs_stride, r_ns;
+} rsdet_van_rows_fold;
+int rsdet_van_fold_rows_f32(const rsdet_van_rows_fold* f, void* stream);
+/* Fold for a convolution whose INPUT is a training-mode BatchNorm folded into its weights (Block.norm1 -> proj_1, norm2 ->
+ * fc1): partial (S, K, O) are TRANSPOSED unscaled weight gradients against the raw input (rsdet_van_wgrad_f32(x, g)).
+ * One launch produces grad_w (O, K) = sc[k] UT[k][o] + sh[k] gs[o], grad_b = gs, the BatchNorm's grad_gamma / grad_beta, and
+ * the per-channel constants v0..v3 with which the backward-data GEMM's epilogue (rsdet_van_gemm_f32 epi 4, s1 = the
+ * BatchNorm's input) applies the whole BatchNorm backward:  grad_x = s0 v0 + acc v1 + v2 + x v3.
+ * gs_tab: slice partials of sum_p g[o, p] at [(o * gs_ns + j) * gs_stride]; r_tab / ls: the (sum_p G, sum_p G x) slice
+ * partials (rsdet_van_chan_reduce_f32 mode 0) and layer scale of a second path into the BatchNorm's output (the
+ * attention's own shortcut), or NULL; cnt = images * pixels. */
+typedef struct rsdet_van_bn_fold {
+  const float *partial, *wt, *gs_tab, *r_tab, *ls, *mean, *rstd, *sc, *sh;
+  float *grad_w, *grad_b, *grad_gamma, *grad_beta, *v0, *v1, *v2, *v3;
+  int S, K, O, gs_ns, gs_stride, r_ns;
+  float cnt;
+} rsdet_van_bn_fold;
+int rsdet_van_fold_bn_f32(const rsdet_van_bn_fold* f, void* stream);
+/* Per-channel reductions of NCHW fp32 maps (N, C, P), one workgroup per (plane, slice), deterministic:
+ *   mode 0  tab[(c * ns + j) * 2 + {0, 1}] = slice partials of (sum_p a, sum_p a b)  (b NULL: 0)
+ *   mode 1  the slice's (mean, sum of squared deviations from that mean) of a: BatchNorm statistics
+ * ns = N * rsdet_van_chan_slices(P).  P % 4 == 0. */
+int rsdet_van_chan_slices(int P);
+int rsdet_van_chan_reduce_f32(const float* a, const float* b, int N, int C, int P, int mode, float* tab, void* stream);
+/* Training-mode BatchNorm folded into the 1x1 convolution behind it (nn.BatchNorm2d semantics: batch statistics, biased
+ * variance for the normalisation, running statistics updated with `momentum` and the unbiased variance;
+ * van.py:258-261 norm1 / norm2): from the mode-1 slice statistics tab (K, ns, 2) of slices of len pixels,
+ *   w_out[o][k] = w[o][k] sc[k],  b_out[o] = b[o] + sum_k w[o][k] sh[k],  sc = gamma rstd,  sh = beta - mean sc,
+ * and mean / rstd / sc / sh (K each) for the backward.  running_* / num_batches_tracked (int64) NULL: not updated.
+ * ls / b2 (K each; layer scale and bias of the LAST convolution of the half this BatchNorm opens) -> the constants of that
+ * convolution's residual epilogue: e0 = 1 + ls sc, e2 = ls (b2 + sh) with the attention's shortcut (shortcut != 0), else
+ * e0 = 1, e2 = ls b2. */
+typedef struct rsdet_van_bn_prep {
+  const float *tab, *gamma, *beta, *w, *b;
+  float *w_out, *b_out, *mean, *rstd, *sc, *sh, *running_mean, *running_var;
+  void* num_batches_tracked;
+  const float *ls, *b2;
+  float *e0, *e2;
+  int shortcut;
+  int O, K, ns, len;
+  float eps, momentum;
+} rsdet_van_bn_prep;
+int rsdet_van_bn_prep_f32(const rsdet_van_bn_prep* f, void* stream);
+/* n <= 5 weight transposes as one launch: dst[j] (K[j], O[j]) = transpose(src[j] (O[j], K[j])), row o of src scaled by
+ * row_scale[j][o] (NULL: 1): the operands of a block's backward-data GEMMs. */
+int rsdet_van_transposes_f32(int n, const float* const* src, const float* const* row_scale, float* const* dst, const int* O,
+                             const int* K, void* stream);
 /* The prepared weight operands of the backward (ops/weight_prep.py) refreshed by one launch: entries = n 64-byte records
  * in DEVICE memory {src, dst, var, gamma (pointers), O, C, T, eps (float), tile0, tiles_c, tiles_o, pad}: dst (C, T, O) =
  * src (O, T, C) with the taps reversed and row o scaled by gamma[o] / sqrt(var[o] + eps) (var NULL: copied).  tile0
@@ -577,6 +654,15 @@ int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float* weight, i
                                      int dilation, float* grad_x, float* grad_in_bias, void* ws, size_t ws_bytes,
                                      void* stream);
 size_t rsdet_dwconv2d_backward_weight_ws_size(int N, int C, int H, int W, int K);
+/* rsdet_dwconv2d_forward_f32 with a second output y_act = GELU(y) (erf form): Mlp.dwconv + Mlp.act as one pass
+ * (van.py:169-171); rsdet_dwconv2d_backward_data_f32 whose result meets a second gradient of the same tensor and a GELU:
+ * grad_x = (dwconv^T(grad_y) + add) * GELU'(gelu_arg), grad_sum[c] = sum of grad_x over the map (van.py:177-215: u =
+ * GELU(proj_1(x)) is read by conv0 AND by the gate). */
+int rsdet_dwconv2d_forward_act_f32(const float* x, const float* weight, const float* bias, int N, int C, int H, int W, int K,
+                                   int dilation, float* y, float* y_act, void* stream);
+int rsdet_dwconv2d_backward_data_act_f32(const float* grad_y, const float* weight, int N, int C, int H, int W, int K,
+                                         int dilation, const float* add, const float* gelu_arg, float* grad_x,
+                                         float* grad_sum, void* ws, size_t ws_bytes, void* stream);
 int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, const float* in_bias, int N, int C, int H,
                                        int W, int K, int dilation, float* grad_weight, float* grad_bias, void* ws,
                                        size_t ws_bytes, void* stream);

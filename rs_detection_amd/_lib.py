@@ -23,6 +23,27 @@ class DcnGeom(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("C", "H", "W", "kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw", "B", "dg")]
 
 
+class VanBnFold(ctypes.Structure):
+    """struct rsdet_van_bn_fold (include/rsdet.h)."""
+    _fields_ = ([(n, c_void_p) for n in ("partial", "wt", "gs_tab", "r_tab", "ls", "mean", "rstd", "sc", "sh", "grad_w",
+                                         "grad_b", "grad_gamma", "grad_beta", "v0", "v1", "v2", "v3")]
+                + [(n, c_int) for n in ("S", "K", "O", "gs_ns", "gs_stride", "r_ns")] + [("cnt", c_float)])
+
+
+class VanBnPrep(ctypes.Structure):
+    """struct rsdet_van_bn_prep (include/rsdet.h)."""
+    _fields_ = ([(n, c_void_p) for n in ("tab", "gamma", "beta", "w", "b", "w_out", "b_out", "mean", "rstd", "sc", "sh",
+                                         "running_mean", "running_var", "num_batches_tracked", "ls", "b2", "e0", "e2")]
+                + [(n, c_int) for n in ("shortcut", "O", "K", "ns", "len")] + [("eps", c_float), ("momentum", c_float)])
+
+
+class VanRowsFold(ctypes.Structure):
+    """struct rsdet_van_rows_fold (include/rsdet.h)."""
+    _fields_ = ([(n, c_void_p) for n in ("partial", "row_scale", "w", "gs_tab", "bias", "r_tab", "sc", "sh", "grad_w",
+                                         "grad_b", "grad_rs")]
+                + [(n, c_int) for n in ("S", "M", "N", "gs_ns", "gs_stride", "r_ns")])
+
+
 # name -> (restype, argtypes); must list every symbol include/rsdet.h declares.
 SIGNATURES = {
     "rsdet_abi_version": (c_int, []),
@@ -53,6 +74,22 @@ SIGNATURES = {
                                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_conv1x1_dgrad_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                          c_size_t, c_void_p, c_void_p]),
+    "rsdet_van_gemm_f32_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "rsdet_van_gemm_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_van_wgrad_f32_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "rsdet_van_wgrad_f32_splits": (c_int, [c_int, c_int, c_int, c_int]),
+    "rsdet_van_wgrad_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_van_fold_rows_f32": (c_int, [c_void_p, c_void_p]),
+    "rsdet_van_fold_bn_f32": (c_int, [c_void_p, c_void_p]),
+    "rsdet_van_chan_slices": (c_int, [c_int]),
+    "rsdet_van_chan_reduce_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_van_bn_prep_f32": (c_int, [c_void_p, c_void_p]),
+    "rsdet_van_transposes_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_dwconv2d_forward_act_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               c_void_p, c_void_p, c_void_p]),
+    "rsdet_dwconv2d_backward_data_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_weight_prep_multi_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rsdet_conv1x1_bn_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),

@@ -72,13 +72,26 @@ __device__ __forceinline__ void dw_stage(const float* __restrict__ plane, int H,
 // (backward-data).
 // in_bias (forward only): see dw_stage.  out_sum (backward-data only): per-workgroup sum of the tile it wrote, i.e. a
 // partial of sum(grad_x) per channel = the gradient of that producer bias; out_sum[(c * nslots + slot)].
+__device__ __forceinline__ float dw_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dw_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = expf(-0.5f * x * x) * 0.39894228040143267794f;
+  return cdf + x * pdf;
+}
+
 template <int K, int D, bool FLIP>
 __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ in_bias, int C, int H, int W,
                                                                int tiles_x, float* __restrict__ y,
-                                                               float* __restrict__ out_sum) {
+                                                               float* __restrict__ out_sum,
+                                                               float* __restrict__ y_act = nullptr,
+                                                               const float* __restrict__ ep_add = nullptr,
+                                                               const float* __restrict__ ep_gelu = nullptr) {
+  // y_act (forward): a second output GELU(y) (Mlp.act behind Mlp.dwconv, van.py:140-175).  ep_add / ep_gelu (backward-data):
+  // the value written (and summed) is (acc + ep_add) * GELU'(ep_gelu) -- the gradient through u = GELU(t1) of the two
+  // branches that read u (the depthwise pair and the gate), ops/van_block.py.
   using G = DwGeom<K, D>;
   __shared__ float s[G::LH * G::LWP];
   __shared__ float s_w[K * K];
@@ -113,8 +126,12 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
     for (int r = 0; r < DW_ROWS; ++r) {
       const int oy = ty0 + tr + r;
       if (oy < H) {
-        yp[(long long)oy * W + ox] = acc[r];
-        tile_sum += acc[r];
+        const long long o = (long long)oy * W + ox;
+        float v = acc[r];
+        if (FLIP && ep_gelu) v = (v + ep_add[(long long)plane * H * W + o]) * dw_gelu_grad(ep_gelu[(long long)plane * H * W + o]);
+        yp[o] = v;
+        if (!FLIP && y_act) y_act[(long long)plane * H * W + o] = dw_gelu(v);
+        tile_sum += v;
       }
     }
   }
@@ -295,18 +312,19 @@ static int dw_check(int N, int C, int H, int W, int K, int dil) {
 
 template <bool FLIP>
 static int dw_stencil(const float* x, const float* w, const float* bias, const float* in_bias, int N, int C, int H,
-                      int W, int K, int dil, float* y, float* out_sum, hipStream_t s) {
+                      int W, int K, int dil, float* y, float* out_sum, hipStream_t s, float* y_act = nullptr,
+                      const float* ep_add = nullptr, const float* ep_gelu = nullptr) {
   const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH;
   const dim3 grid(N * C, tx * ty);
   if (K == 3)
     hipLaunchKernelGGL((dwconv_stencil_kernel<3, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
-                       y, out_sum);
+                       y, out_sum, y_act, ep_add, ep_gelu);
   else if (K == 5)
     hipLaunchKernelGGL((dwconv_stencil_kernel<5, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
-                       y, out_sum);
+                       y, out_sum, y_act, ep_add, ep_gelu);
   else
     hipLaunchKernelGGL((dwconv_stencil_kernel<7, 3, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
-                       y, out_sum);
+                       y, out_sum, y_act, ep_add, ep_gelu);
   (void)dil;
   return rsdet_launch_status();
 }
@@ -318,6 +336,16 @@ extern "C" int rsdet_dwconv2d_forward_f32(const float* x, const float* in_bias, 
   if (N == 0 || C == 0) return RSDET_OK;
   if (!x || !weight || !y) return RSDET_EINVAL;
   return dw_stencil<false>(x, weight, bias, in_bias, N, C, H, W, K, dilation, y, nullptr, (hipStream_t)stream);
+}
+
+// ... with a second output y_act = GELU(y) (erf form): Mlp.dwconv + Mlp.act as one pass (van.py:169-171)
+extern "C" int rsdet_dwconv2d_forward_act_f32(const float* x, const float* weight, const float* bias, int N, int C, int H,
+                                              int W, int K, int dilation, float* y, float* y_act, void* stream) {
+  int rc = dw_check(N, C, H, W, K, dilation);
+  if (rc) return rc;
+  if (N == 0 || C == 0) return RSDET_OK;
+  if (!x || !weight || !y || !y_act) return RSDET_EINVAL;
+  return dw_stencil<false>(x, weight, bias, nullptr, N, C, H, W, K, dilation, y, nullptr, (hipStream_t)stream, y_act);
 }
 
 // floats of workspace per output of the reductions: one partial per (plane, tile)
@@ -349,6 +377,28 @@ extern "C" int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float
   const int nslots = (int)(dw_slots(N, C, H, W) / C);
   hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, (const float*)ws, nslots, 1,
                      (float*)nullptr, grad_in_bias);
+  return rsdet_launch_status();
+}
+
+// Backward-data whose result meets a second gradient of the same tensor and then a GELU: grad_x = (dwconv^T(grad_y) + add)
+// * GELU'(gelu_arg) -- the gradient of t1 in u = GELU(t1), u read by the depthwise pair AND by the gate (SpatialAttention /
+// AttentionModule, van.py:177-215); grad_sum[c] = sum over the map of grad_x (the gradient of the bias that produced t1).
+extern "C" int rsdet_dwconv2d_backward_data_act_f32(const float* grad_y, const float* weight, int N, int C, int H, int W,
+                                                    int K, int dilation, const float* add, const float* gelu_arg,
+                                                    float* grad_x, float* grad_sum, void* ws, size_t ws_bytes,
+                                                    void* stream) {
+  int rc = dw_check(N, C, H, W, K, dilation);
+  if (rc) return rc;
+  if (C == 0 || N == 0) return RSDET_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!grad_y || !weight || !grad_x || !add || !gelu_arg) return RSDET_EINVAL;
+  if (grad_sum && (!ws || ws_bytes < rsdet_dwconv2d_backward_data_ws_size(N, C, H, W))) return RSDET_EINVAL;
+  rc = dw_stencil<true>(grad_y, weight, nullptr, nullptr, N, C, H, W, K, dilation, grad_x, grad_sum ? (float*)ws : nullptr,
+                        s, nullptr, add, gelu_arg);
+  if (rc || !grad_sum) return rc;
+  const int nslots = (int)(dw_slots(N, C, H, W) / C);
+  hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, (const float*)ws, nslots, 1, (float*)nullptr,
+                     grad_sum);
   return rsdet_launch_status();
 }
 

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from rs_detection_amd.ops import van_fused
+from rs_detection_amd.ops import van_block, van_fused
 from rs_detection_amd.ops.bn_act import scale_residual
 from rs_detection_amd.ops.conv1x1 import conv1x1_nchw
 from rs_detection_amd.ops.dwconv import DepthwiseConv2d
@@ -123,6 +123,10 @@ class Block(nn.Module):
         self.layer_scale_2 = nn.Parameter(1e-2 * torch.ones(dim))
 
     def forward(self, x):
+        # the whole block as ONE autograd node on our fp32 MFMA GEMMs with fused tails (ops/van_block.py) where it applies:
+        # training-mode BatchNorms, idle drop-path / dropout, channel counts and map sizes the tiles divide
+        if self._idle() and van_block.applies(self, x):
+            return van_block.van_block(self, x)
         # x + drop_path(layer_scale * f) (van.py:121-122); the per-sample drop-path factor commutes with the per-channel
         # scale, so it is applied to f and scale + residual run as one fused pass (ops/bn_act.py: scale_residual)
         if self._fused(x):
@@ -137,10 +141,13 @@ class Block(nn.Module):
         x = scale_residual(x, self.drop_path(self.attn(self.norm1(x))), self.layer_scale_1)
         return scale_residual(x, self.drop_path(self.mlp(self.norm2(x))), self.layer_scale_2)
 
-    def _fused(self, x):
+    def _idle(self):
         idle_path = isinstance(self.drop_path, nn.Identity) or not self.training or self.drop_path.p == 0.
         idle_drop = not self.training or self.mlp.drop.p == 0.
-        return van_fused.applies(x) and idle_path and idle_drop
+        return idle_path and idle_drop
+
+    def _fused(self, x):
+        return van_fused.applies(x) and self._idle()
 
 
 class OverlapPatchEmbed(nn.Module):

@@ -1,0 +1,166 @@
+"""GPU: a VAN Block as one autograd node (ops/van_block.py: fp32 MFMA GEMMs with fused tails, csrc/van_gemm.hip) and its
+C-ABI pieces against plain torch references -- the block in float64 through torch's own operators (every fused op of the
+package falls back to the torch expression for float64), i.e. autograd of the composite the node replaces.  The node is
+exact fp32: output, all 23 gradients and the updated running statistics agree to <= 1e-4 relative (measured ~1e-6)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _block(cuda, dim, ratio, seed):
+    from rs_detection_amd.models.backbones.van import Block
+    torch.manual_seed(seed)
+    blk = Block(dim, mlp_ratio=ratio).to(cuda)
+    with torch.no_grad():            # away from the initialisation's symmetric points: every term of every gradient is live
+        for n, p in blk.named_parameters():
+            if "layer_scale" in n:
+                p.uniform_(0.05, 0.5)
+            elif "norm" in n and n.endswith("weight"):
+                p.uniform_(0.5, 1.5)
+            elif n.endswith("bias"):
+                p.normal_(0, 0.2)
+            elif p.dim() == 4 and p.shape[1] == 1:
+                p.normal_(0, 0.3 / p.shape[-1])
+            else:
+                p.normal_(0, 1.0 / p.shape[1] ** 0.5)
+        for bn in (blk.norm1, blk.norm2):
+            bn.running_mean.normal_(0, 0.1), bn.running_var.uniform_(0.5, 2)
+    return blk.train()
+
+
+@pytest.mark.parametrize("N,dim,ratio,H,W", [(2, 64, 8, 32, 32), (1, 128, 8, 16, 32), (2, 320, 4, 16, 16), (1, 512, 4, 8, 16),
+                                             (2, 64, 8, 128, 128)])
+def test_one_node_block_against_float64_autograd_of_the_composite(cuda, N, dim, ratio, H, W):
+    from rs_detection_amd.ops import van_block as vb
+    blk = _block(cuda, dim, ratio, N + dim)
+    ref = copy.deepcopy(blk).double()
+    x = (torch.randn(N, dim, H, W, device=cuda) * 1.5 + 0.3)
+    go = torch.randn(N, dim, H, W, device=cuda)
+    xi = x.clone().requires_grad_(True)
+    assert vb.applies(blk, xi)
+    y = blk(xi)
+    assert "_VanBlock" in type(y.grad_fn).__name__
+    y.backward(go)
+    xd = x.double().requires_grad_(True)
+    yd = ref(xd)
+    assert "_VanBlock" not in type(yd.grad_fn).__name__
+    yd.backward(go.double())
+    assert _rel(y, yd) <= 1e-5, _rel(y, yd)
+    assert _rel(xi.grad, xd.grad) <= 1e-4, _rel(xi.grad, xd.grad)
+    for (n, p), q in zip(blk.named_parameters(), ref.parameters()):
+        assert p.grad is not None and p.grad.shape == p.shape, n
+        assert _rel(p.grad, q.grad) <= 1e-4, (n, _rel(p.grad, q.grad))
+    for bn, bd in ((blk.norm1, ref.norm1), (blk.norm2, ref.norm2)):      # nn.BatchNorm2d's running-statistics update
+        assert _rel(bn.running_mean, bd.running_mean) <= 1e-5 and _rel(bn.running_var, bd.running_var) <= 1e-5
+        assert int(bn.num_batches_tracked) == int(bd.num_batches_tracked) == 1
+
+
+def test_block_node_tracks_the_per_operator_route_and_is_not_taken_where_it_does_not_apply(cuda):
+    from rs_detection_amd.ops import van_block as vb
+    blk = _block(cuda, 64, 8, 5)
+    x = torch.randn(2, 64, 64, 64, device=cuda)
+    g = torch.randn(2, 64, 64, 64, device=cuda)
+    outs = []
+    for on in (True, False):
+        vb._ON = on
+        try:
+            b2 = copy.deepcopy(blk)
+            xi = x.clone().requires_grad_(True)
+            y = b2(xi)
+            assert ("_VanBlock" in type(y.grad_fn).__name__) == on
+            y.backward(g)
+            outs.append([y.detach(), xi.grad] + [p.grad for p in b2.parameters()] + [b2.norm1.running_var, b2.norm2.running_mean])
+        finally:
+            vb._ON = True
+    for a, b in zip(*outs):
+        assert _rel(a, b) <= 1e-4, _rel(a, b)
+    # not taken: eval-mode BatchNorm, no grad, autocast, a frozen parameter, a map size the tiles do not divide
+    assert not vb.applies(copy.deepcopy(blk).eval(), x)
+    with torch.no_grad():
+        assert not vb.applies(blk, x)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not vb.applies(blk, x)
+    assert not vb.applies(blk, torch.randn(2, 64, 30, 30, device=cuda))
+    b3 = copy.deepcopy(blk)
+    b3.attn.proj_1.bias.requires_grad_(False)
+    assert not vb.applies(b3, x)
+    y = blk(torch.randn(2, 64, 30, 30, device=cuda, requires_grad=True))     # the per-operator route still serves it
+    assert "_VanBlock" not in type(y.grad_fn).__name__
+
+
+@pytest.mark.parametrize("M,Nn,P,n", [(64, 64, 4096, 2), (320, 1280, 256, 2), (128, 1024, 512, 1), (512, 512, 128, 3)])
+def test_wgrad_and_folds_through_the_c_abi(cuda, M, Nn, P, n):
+    """rsdet_van_wgrad_f32 + rsdet_van_fold_rows_f32 against float64 einsum; the row dots, bias and scale gradients."""
+    import ctypes
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(M + Nn)
+    g = torch.randn(n, M, P, generator=gen).to(cuda)
+    x = torch.randn(n, Nn, P, generator=gen).to(cuda)
+    w = torch.randn(M, Nn, generator=gen).to(cuda)
+    rs, bias = torch.randn(M, generator=gen).to(cuda), torch.randn(M, generator=gen).to(cuda)
+    assert lib.rsdet_van_wgrad_f32_supported(M, Nn, P, n)
+    S = lib.rsdet_van_wgrad_f32_splits(M, Nn, P, n)
+    part = torch.empty((S, M, Nn), device=cuda)
+    _lib.check(lib.rsdet_van_wgrad_f32(_lib.ptr(g), _lib.ptr(x), M, Nn, P, n, _lib.ptr(part), _lib.stream_ptr()), "w")
+    U = torch.einsum("nmp,nkp->mk", g.double(), x.double())
+    assert _rel(part.double().sum(0), U) <= 1e-6
+    ns = n * lib.rsdet_van_chan_slices(P)
+    tab = torch.empty((M, ns, 2), device=cuda)
+    _lib.check(lib.rsdet_van_chan_reduce_f32(_lib.ptr(g), None, n, M, P, 0, _lib.ptr(tab), _lib.stream_ptr()), "r")
+    gs = g.double().sum((0, 2))
+    assert _rel(tab[:, :, 0].double().sum(1), gs) <= 1e-6 and float(tab[:, :, 1].abs().max()) == 0.0
+    gw, gb, grs = torch.empty((M, Nn), device=cuda), torch.empty(M, device=cuda), torch.empty(M, device=cuda)
+    f = _lib.VanRowsFold(part.data_ptr(), rs.data_ptr(), w.data_ptr(), tab.data_ptr(), bias.data_ptr(), None, None, None,
+                         gw.data_ptr(), gb.data_ptr(), grs.data_ptr(), S, M, Nn, ns, 2, 0)
+    _lib.check(lib.rsdet_van_fold_rows_f32(ctypes.byref(f), _lib.stream_ptr()), "f")
+    assert _rel(gw, U * rs.double()[:, None]) <= 1e-6 and _rel(gb, gs * rs.double()) <= 1e-6
+    assert _rel(grs, (U * w.double()).sum(1) + bias.double() * gs) <= 1e-5
+    # unsupported geometry is refused, not mangled
+    assert not lib.rsdet_van_wgrad_f32_supported(96, 64, 256, 1) and not lib.rsdet_van_gemm_f32_supported(320, 48, 256, 1)
+    assert lib.rsdet_van_gemm_f32(_lib.ptr(w), _lib.ptr(x), 96, 64, 256, 1, 0, None, None, None, None, None, None,
+                                  _lib.ptr(part), None, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("M,K,P,n", [(320, 320, 256, 2), (64, 512, 1024, 1), (1024, 128, 512, 2), (512, 2048, 128, 1)])
+def test_gemm_epilogues_through_the_c_abi(cuda, M, K, P, n):
+    """rsdet_van_gemm_f32, every epilogue, against float64 matmul of the same fp32 operands."""
+    import torch.nn.functional as F
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(M + K + P)
+    w = (torch.randn(M, K, generator=gen) / K ** 0.5).to(cuda)
+    x = torch.randn(n, K, P, generator=gen).to(cuda)
+    v = [torch.randn(M, generator=gen).to(cuda) for _ in range(4)]
+    s0, s1 = torch.randn(n, M, P, generator=gen).to(cuda), torch.randn(n, M, P, generator=gen).to(cuda)
+
+    def run(epi, vv=(None,) * 4, ss=(None, None), two=False):
+        o0 = torch.full((n, M, P), float("nan"), device=cuda)
+        o1 = torch.full((n, M, P), float("nan"), device=cuda) if two else None
+        rc = lib.rsdet_van_gemm_f32(_lib.ptr(w), _lib.ptr(x), M, K, P, n, epi, *[_lib.ptr(t) for t in vv],
+                                    *[_lib.ptr(t) for t in ss], _lib.ptr(o0), _lib.ptr(o1), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_van_gemm_f32")
+        return o0, o1
+    ref = torch.matmul(w.double(), x.double())
+    col = lambda t: t.double()[None, :, None]
+    tol = 2e-6
+    assert _rel(run(0)[0], ref) <= tol
+    assert _rel(run(1, (v[0], None, None, None))[0], ref + col(v[0])) <= tol
+    o0, o1 = run(2, (v[0], None, None, None), two=True)
+    assert _rel(o0, ref + col(v[0])) <= tol and _rel(o1, F.gelu(ref + col(v[0]))) <= tol
+    o0, o1 = run(3, (v[0], None, None, None), (s0, None), two=True)
+    assert _rel(o0, ref + col(v[0])) <= tol and _rel(o1, (ref + col(v[0])) * s0.double()) <= tol
+    assert _rel(run(4, v, (s0, s1))[0], s0.double() * col(v[0]) + ref * col(v[1]) + col(v[2]) + s1.double() * col(v[3])) <= tol
+    assert _rel(run(4, (None, v[1], v[2], None), (s0, None))[0], s0.double() + ref * col(v[1]) + col(v[2])) <= tol
+    o0, o1 = run(5, ss=(s0, s1), two=True)
+    assert _rel(o0, ref * s0.double()) <= tol and _rel(o1, ref * s1.double()) <= tol
+    sd = s0.double()
+    gg = 0.5 * (1 + torch.erf(sd / 2 ** 0.5)) + sd * torch.exp(-0.5 * sd * sd) / (2 * torch.pi) ** 0.5
+    assert _rel(run(6, ss=(s0, None))[0], ref * gg) <= tol
