@@ -442,7 +442,7 @@ int rsdet_bn_affine_grads_finish_multi_f32(int n, const float* const* partial, c
  * fp32, pixels contiguous; r = output row (channel), v* (M) per-row vectors, s* maps of the output's shape:
  *   epi 0  out0 = acc                              4  out0 = s0 v0[r] + acc v1[r] + v2[r] (+ s1 v3[r] if s1; v0 NULL: 1)
  *       1  out0 = acc + v0[r]                      5  out0 = acc s0, out1 = acc s1
- *       2  out0 = acc + v0[r], out1 = GELU(out0)   6  out0 = acc GELU'(s0)
+ *       2  out0 = acc + v0[r], out1 = GELU(out0)   6  out0 = acc s0
  *       3  out0 = acc + v0[r], out1 = out0 s0
  * (GELU = the erf form of jt.nn.GELU.)  _supported: M a multiple of 160 / 128 (P % 64 == 0) or 64 (P % 128 == 0), K % 32 == 0;
  * every pointer 16-byte aligned.  Exact fp32: a k-ordered fmaf chain per output element. */
@@ -655,11 +655,12 @@ int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float* weight, i
                                      void* stream);
 size_t rsdet_dwconv2d_backward_weight_ws_size(int N, int C, int H, int W, int K);
 /* rsdet_dwconv2d_forward_f32 with a second output y_act = GELU(y) (erf form): Mlp.dwconv + Mlp.act as one pass
- * (van.py:169-171); rsdet_dwconv2d_backward_data_f32 whose result meets a second gradient of the same tensor and a GELU:
+ * (van.py:169-171); y_is_grad != 0: y receives GELU'(conv) instead of the convolution's value -- all the backward of the
+ * activation needs (the backward-data GEMM of fc2 multiplies by it in its epilogue); rsdet_dwconv2d_backward_data_f32 whose result meets a second gradient of the same tensor and a GELU:
  * grad_x = (dwconv^T(grad_y) + add) * GELU'(gelu_arg), grad_sum[c] = sum of grad_x over the map (van.py:177-215: u =
  * GELU(proj_1(x)) is read by conv0 AND by the gate). */
 int rsdet_dwconv2d_forward_act_f32(const float* x, const float* weight, const float* bias, int N, int C, int H, int W, int K,
-                                   int dilation, float* y, float* y_act, void* stream);
+                                   int dilation, int y_is_grad, float* y, float* y_act, void* stream);
 int rsdet_dwconv2d_backward_data_act_f32(const float* grad_y, const float* weight, int N, int C, int H, int W, int K,
                                          int dilation, const float* add, const float* gelu_arg, float* grad_x,
                                          float* grad_sum, void* ws, size_t ws_bytes, void* stream);

@@ -20,5 +20,5 @@ tot = sum(fam.values())
 print("kernel time per step: %.2f ms over %.0f steps" % (tot / steps, steps))
 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]):
     print("  %-42s %7.2f ms/step" % (k, v / steps))
-for t, c, n in sorted(rows, reverse=True)[:18]:
+for t, c, n in sorted(rows, reverse=True)[:int(sys.argv[3]) if len(sys.argv) > 3 else 18]:
     print("  %7.3f ms/step %6.0f calls/step  %s" % (t / steps, c / steps, n[:100]))

@@ -75,7 +75,7 @@ for M, K, P in shapes:
     o0, o1 = gemm(w, x, 5, s=(s0, s1), two=True)
     errs.append(max(float((o0 - ref * s0.double()).abs().max()), float((o1 - ref * s1.double()).abs().max())) / scale / 4)
     o0, _ = gemm(w, x, 6, s=(s0, None))
-    errs.append(float((o0 - ref * gelu_grad(s0)).abs().max()) / scale)
+    errs.append(float((o0 - ref * s0.double()).abs().max()) / scale / 4)
     us = t_us(lambda: gemm(w, x))
     us2 = t_us(lambda: gemm(w, x, 2, (v[0], None, None, None), two=True))
     us4 = t_us(lambda: gemm(w, x, 4, v, (s0, s1)))

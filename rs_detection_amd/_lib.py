@@ -87,7 +87,7 @@ SIGNATURES = {
     "rsdet_van_bn_prep_f32": (c_int, [c_void_p, c_void_p]),
     "rsdet_van_transposes_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_dwconv2d_forward_act_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                               c_void_p, c_void_p, c_void_p]),
+                                               c_int, c_void_p, c_void_p, c_void_p]),
     "rsdet_dwconv2d_backward_data_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_weight_prep_multi_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p]),

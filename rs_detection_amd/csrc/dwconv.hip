@@ -88,7 +88,8 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
                                                                float* __restrict__ out_sum,
                                                                float* __restrict__ y_act = nullptr,
                                                                const float* __restrict__ ep_add = nullptr,
-                                                               const float* __restrict__ ep_gelu = nullptr) {
+                                                               const float* __restrict__ ep_gelu = nullptr,
+                                                               int y_is_grad = 0) {
   // y_act (forward): a second output GELU(y) (Mlp.act behind Mlp.dwconv, van.py:140-175).  ep_add / ep_gelu (backward-data):
   // the value written (and summed) is (acc + ep_add) * GELU'(ep_gelu) -- the gradient through u = GELU(t1) of the two
   // branches that read u (the depthwise pair and the gate), ops/van_block.py.
@@ -129,8 +130,12 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
         const long long o = (long long)oy * W + ox;
         float v = acc[r];
         if (FLIP && ep_gelu) v = (v + ep_add[(long long)plane * H * W + o]) * dw_gelu_grad(ep_gelu[(long long)plane * H * W + o]);
-        yp[o] = v;
-        if (!FLIP && y_act) y_act[(long long)plane * H * W + o] = dw_gelu(v);
+        if (!FLIP && y_act) {
+          y_act[(long long)plane * H * W + o] = dw_gelu(v);
+          yp[o] = y_is_grad ? dw_gelu_grad(v) : v;
+        } else {
+          yp[o] = v;
+        }
         tile_sum += v;
       }
     }
@@ -313,18 +318,18 @@ static int dw_check(int N, int C, int H, int W, int K, int dil) {
 template <bool FLIP>
 static int dw_stencil(const float* x, const float* w, const float* bias, const float* in_bias, int N, int C, int H,
                       int W, int K, int dil, float* y, float* out_sum, hipStream_t s, float* y_act = nullptr,
-                      const float* ep_add = nullptr, const float* ep_gelu = nullptr) {
+                      const float* ep_add = nullptr, const float* ep_gelu = nullptr, int y_is_grad = 0) {
   const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH;
   const dim3 grid(N * C, tx * ty);
   if (K == 3)
     hipLaunchKernelGGL((dwconv_stencil_kernel<3, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
-                       y, out_sum, y_act, ep_add, ep_gelu);
+                       y, out_sum, y_act, ep_add, ep_gelu, y_is_grad);
   else if (K == 5)
     hipLaunchKernelGGL((dwconv_stencil_kernel<5, 1, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
-                       y, out_sum, y_act, ep_add, ep_gelu);
+                       y, out_sum, y_act, ep_add, ep_gelu, y_is_grad);
   else
     hipLaunchKernelGGL((dwconv_stencil_kernel<7, 3, FLIP>), grid, dim3(DW_NT), 0, s, x, w, bias, in_bias, C, H, W, tx,
-                       y, out_sum, y_act, ep_add, ep_gelu);
+                       y, out_sum, y_act, ep_add, ep_gelu, y_is_grad);
   (void)dil;
   return rsdet_launch_status();
 }
@@ -340,12 +345,14 @@ extern "C" int rsdet_dwconv2d_forward_f32(const float* x, const float* in_bias, 
 
 // ... with a second output y_act = GELU(y) (erf form): Mlp.dwconv + Mlp.act as one pass (van.py:169-171)
 extern "C" int rsdet_dwconv2d_forward_act_f32(const float* x, const float* weight, const float* bias, int N, int C, int H,
-                                              int W, int K, int dilation, float* y, float* y_act, void* stream) {
+                                              int W, int K, int dilation, int y_is_grad, float* y, float* y_act,
+                                              void* stream) {
   int rc = dw_check(N, C, H, W, K, dilation);
   if (rc) return rc;
   if (N == 0 || C == 0) return RSDET_OK;
   if (!x || !weight || !y || !y_act) return RSDET_EINVAL;
-  return dw_stencil<false>(x, weight, bias, nullptr, N, C, H, W, K, dilation, y, nullptr, (hipStream_t)stream, y_act);
+  return dw_stencil<false>(x, weight, bias, nullptr, N, C, H, W, K, dilation, y, nullptr, (hipStream_t)stream, y_act, nullptr,
+                           nullptr, y_is_grad);
 }
 
 // floats of workspace per output of the reductions: one partial per (plane, tile)

@@ -45,7 +45,7 @@ constexpr int VG_BIAS_GELU2 = 2;  // t = acc + v0[r]: out0 = t, out1 = GELU(t)
 constexpr int VG_GATE2 = 3;       // a = acc + v0[r]: out0 = a, out1 = a * s0
 constexpr int VG_AFFINE = 4;      // out0 = s0 * v0[r] + acc * v1[r] + v2[r] (+ s1 * v3[r] when s1)   (v0 NULL: 1)
 constexpr int VG_MUL2 = 5;        // out0 = acc * s0, out1 = acc * s1
-constexpr int VG_GELU_BWD = 6;    // out0 = acc * GELU'(s0)
+constexpr int VG_MUL1 = 6;        // out0 = acc * s0
 
 struct VgArgs {
   const float* A;   // (M, K) row-major
@@ -81,8 +81,24 @@ template <int OFF>
 __device__ __forceinline__ void vg_read32(float& dst, unsigned addr) {
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
-__device__ __forceinline__ void vg_landed(vg_u32x4& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void vg_landed(float& v) { asm volatile("" : "+v"(v)); }
+// MFMA as volatile asm: the builtin is not ordered against the volatile LDS reads / waits around it, and the compiler then
+// CLUSTERS them (40 MFMAs, then 13 reads + 7 LDS-DMA + the waits): a wave issues in order, so everything clustered behind
+// the last MFMA of a group runs while the matrix pipe idles -- measured 73 % of the MFMA rate with the data movement
+// switched off entirely.  With every instruction of the loop volatile, program order IS issue order and the reads / DMA of
+// the next group sit BETWEEN this group's MFMAs.
+__device__ __forceinline__ void vg_mfma(vg_f32x4& c, unsigned a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void vg_mfma(vg_f32x4& c, unsigned a, unsigned b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void vg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    vg_static_for<I + 1, N>(f);
+  }
+}
 
 // one workgroup per (image, pixel tile, row tile); id -> tile so that the workgroups of one XCD (ids x, x + 8, ...) walk a
 // contiguous range with the row tile fastest: the row tiles that share an x tile share it in that XCD's L2
@@ -119,18 +135,19 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
     const int blk = (c >> 2) ^ ((r >> 2) & 1);
     b_src[it] = Bn + (long long)r * a.P + blk * 16 + (c & 3) * 4;
   }
-  auto issue = [&](int kc) {
+  // LDS-DMA operation k (0 .. OPS - 1) of chunk kc
+  auto issue_one = [&](auto k_c, int kc) {
+    constexpr int KI = decltype(k_c)::value;
     unsigned char* slot = lds + (kc % VG_STAGES) * SLOT;
-#pragma unroll
-    for (int it = 0; it < A_OPS; ++it)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[it] + kc * VG_KC),
-                                       (__attribute__((address_space(3))) void*)(slot + (wave + 4 * it) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int it = 0; it < B_OPS; ++it)
+    if constexpr (KI < A_OPS)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[KI] + kc * VG_KC),
+                                       (__attribute__((address_space(3))) void*)(slot + (wave + 4 * KI) * 1024), 16, 0, 0);
+    else
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(b_src[it] + (long long)kc * VG_KC * a.P),
-          (__attribute__((address_space(3))) void*)(slot + A_BYTES + (wave + 4 * it) * 1024), 16, 0, 0);
+          (const __attribute__((address_space(1))) void*)(b_src[KI - A_OPS] + (long long)kc * VG_KC * a.P),
+          (__attribute__((address_space(3))) void*)(slot + A_BYTES + (wave + 4 * (KI - A_OPS)) * 1024), 16, 0, 0);
   };
+  auto issue = [&](int kc) { vg_static_for<0, OPS>([&](auto k_c) { issue_one(k_c, kc); }); };
 
   vg_f32x4 acc[MI][NI];
 #pragma unroll
@@ -149,34 +166,28 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
 
   vg_u32x4 fa[2][MI];
   float fb[2][NI][4];
-  auto read_group = [&](auto buf_c, auto g_c, unsigned slot_base) {
-    constexpr int BUF = decltype(buf_c)::value, G = decltype(g_c)::value;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) vg_read128(fa[BUF][mi], slot_base + ((a_lane + mi * 2048) ^ (G ? 64u : 0u)));
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      vg_read32<(G * 16 + 0) * TN * 4>(fb[BUF][ni][0], slot_base + b_lane[ni]);
-      vg_read32<(G * 16 + 1) * TN * 4>(fb[BUF][ni][1], slot_base + b_lane[ni]);
-      vg_read32<(G * 16 + 2) * TN * 4>(fb[BUF][ni][2], slot_base + b_lane[ni]);
-      vg_read32<(G * 16 + 3) * TN * 4>(fb[BUF][ni][3], slot_base + b_lane[ni]);
+  constexpr int NREADS = MI + 4 * NI, NMFMA = 4 * NI * MI;
+  static_assert(NREADS + OPS <= NMFMA, "the next group's reads and the LDS-DMA fit between this group's MFMAs");
+  // fragment read k (0 .. NREADS - 1) of 16-k group G of a slot, into register set BUF
+  auto read_one = [&](auto buf_c, auto g_c, auto k_c, unsigned slot_base) {
+    constexpr int BUF = decltype(buf_c)::value, G = decltype(g_c)::value, KI = decltype(k_c)::value;
+    if constexpr (KI < MI) {
+      vg_read128(fa[BUF][KI], slot_base + ((a_lane + KI * 2048) ^ (G ? 64u : 0u)));
+    } else {
+      constexpr int ni = (KI - MI) / 4, j = (KI - MI) % 4;
+      vg_read32<(G * 16 + j) * TN * 4>(fb[BUF][ni][j], slot_base + b_lane[ni]);
     }
   };
-  auto mfma_group = [&](auto buf_c) {
+  // the 4 NI MI MFMAs of register set BUF, hook(i) between MFMA i and i + 1
+  auto mfma_group = [&](auto buf_c, auto&& hook) {
     constexpr int BUF = decltype(buf_c)::value;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) vg_landed(fa[BUF][mi]);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) vg_landed(fb[BUF][ni][j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[BUF][mi][j]), fb[BUF][ni][j], acc[mi][ni],
-                                                             0, 0, 0);
+    vg_static_for<0, NMFMA>([&](auto i_c) {
+      constexpr int I = decltype(i_c)::value, j = I / (NI * MI), ni = (I / MI) % NI, mi = I % MI;
+#if !defined(VG_ABL) || VG_ABL != 1              // (ablation 1: data movement only -- a timing build, wrong values)
+      vg_mfma(acc[mi][ni], fa[BUF][mi][j], fb[BUF][ni][j]);
+#endif
+      hook(i_c);
+    });
   };
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
@@ -187,23 +198,49 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
     if (kc < nk) issue(kc);
   if (nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk == 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
   vg_barrier();
-  read_group(C0{}, C0{}, lds_base);
+  vg_static_for<0, NREADS>([&](auto k_c) { read_one(C0{}, C0{}, k_c, lds_base); });
   vg_wait_lgkm0();
   for (int s = 0; s < nk; ++s) {
     const unsigned slot_base = lds_base + (s % VG_STAGES) * SLOT;
-    read_group(C1{}, C1{}, slot_base);               // second half of chunk s
-    mfma_group(C0{});                                // (waits for ITS registers through the data dependence below)
+    const unsigned next_base = lds_base + ((s + 1) % VG_STAGES) * SLOT;
+    // first half of chunk s; the reads of its second half ride between the MFMAs
+#if defined(VG_ABL) && VG_ABL >= 3               // (ablation 3: MFMAs only; 4: + the barrier -- timing builds, wrong values)
+    mfma_group(C0{}, [&](auto) {});
+    const bool more = s + 1 < nk, dma = false;
+#if VG_ABL == 4
+    vg_barrier();
+#endif
+    mfma_group(C1{}, [&](auto) {});
+    (void)more, (void)dma, (void)slot_base, (void)next_base;
+    continue;
+#else
+    mfma_group(C0{}, [&](auto i_c) {
+      constexpr int I = decltype(i_c)::value;
+      if constexpr (I < NREADS) read_one(C1{}, C1{}, i_c, slot_base);
+    });
     vg_wait_lgkm0();
-    if (s + 1 < nk) {
+    const bool more = s + 1 < nk, dma = s + 3 < nk;
+    if (more) {
       // chunk s + 1 landed (mine: all but the operations of chunk s + 2); every wave has chunk s in registers
       if (s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
       vg_barrier();
-      if (s + 3 < nk) issue(s + 3);                  // into the slot chunk s just left
-      read_group(C0{}, C0{}, lds_base + ((s + 1) % VG_STAGES) * SLOT);
     }
-    mfma_group(C1{});
+#endif
+    // second half; between its MFMAs: the LDS-DMA of chunk s + 3 (into the slot chunk s just left), then the first reads
+    // of chunk s + 1
+    mfma_group(C1{}, [&](auto i_c) {
+      constexpr int I = decltype(i_c)::value;
+      if constexpr (I < OPS) {
+#if !defined(VG_ABL) || VG_ABL != 2              // (ablation 2: no DMA after the prologue -- a timing build, wrong values)
+        if (dma) issue_one(i_c, s + 3);
+#endif
+      } else if constexpr (I - OPS < NREADS) {
+        if (more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
+      }
+    });
     vg_wait_lgkm0();
   }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results: the compiler does not see their hazard)
   // ---- epilogue: accumulators -> LDS (row-major tile) -> 4 consecutive pixels per lane
   vg_wait_vm<0>();
   vg_barrier();
@@ -246,9 +283,9 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
       const float4 u = *reinterpret_cast<const float4*>(a.s0 + o), w = *reinterpret_cast<const float4*>(a.s1 + o);
       y0 = make_float4(v.x * u.x, v.y * u.y, v.z * u.z, v.w * u.w);
       y1 = make_float4(v.x * w.x, v.y * w.y, v.z * w.z, v.w * w.w);
-    } else if (EPI == VG_GELU_BWD) {
+    } else if (EPI == VG_MUL1) {
       const float4 x = *reinterpret_cast<const float4*>(a.s0 + o);
-      y0 = make_float4(v.x * vg_gelu_grad(x.x), v.y * vg_gelu_grad(x.y), v.z * vg_gelu_grad(x.z), v.w * vg_gelu_grad(x.w));
+      y0 = make_float4(v.x * x.x, v.y * x.y, v.z * x.z, v.w * x.w);
     }
     *reinterpret_cast<float4*>(a.out0 + o) = y0;
     if (EPI == VG_BIAS_GELU2 || EPI == VG_GATE2 || EPI == VG_MUL2) *reinterpret_cast<float4*>(a.out1 + o) = y1;
@@ -293,20 +330,19 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
     const int piece = wave + 4 * it, r = piece * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
     b_src[it] = x + (long long)(n0 + r) * P + c * 4;
   }
-  auto issue = [&](int kc) {
+  auto issue_one = [&](auto k_c, int kc) {
+    constexpr int KI = decltype(k_c)::value;
     unsigned char* slot = lds + (kc % VG_STAGES) * SLOT;
     const int q = q0 + kc, img = q / cpi, px = (q - img * cpi) * VG_KC;
-    const long long ao = (long long)img * M * P + px, bo = (long long)img * N * P + px;
-#pragma unroll
-    for (int it = 0; it < A_OPS; ++it)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[it] + ao),
-                                       (__attribute__((address_space(3))) void*)(slot + (wave + 4 * it) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int it = 0; it < B_OPS; ++it)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[it] + bo),
-                                       (__attribute__((address_space(3))) void*)(slot + A_BYTES + (wave + 4 * it) * 1024),
-                                       16, 0, 0);
+    if constexpr (KI < A_OPS)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[KI] + ((long long)img * M * P + px)),
+                                       (__attribute__((address_space(3))) void*)(slot + (wave + 4 * KI) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(b_src[KI - A_OPS] + ((long long)img * N * P + px)),
+          (__attribute__((address_space(3))) void*)(slot + A_BYTES + (wave + 4 * (KI - A_OPS)) * 1024), 16, 0, 0);
   };
+  auto issue = [&](int kc) { vg_static_for<0, OPS>([&](auto k_c) { issue_one(k_c, kc); }); };
 
   vg_f32x4 acc[MI][NI];
 #pragma unroll
@@ -318,27 +354,22 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
   const unsigned a_lane = (unsigned)((wm * MI * 16 + l15) * 128 + ((h ^ (l15 >> 1)) << 4));
   const unsigned b_lane = (unsigned)(A_BYTES + (wn * NI * 16 + l15) * 128 + ((h ^ (l15 >> 1)) << 4));
   vg_u32x4 fa[2][MI], fb[2][NI];
-  auto read_group = [&](auto buf_c, auto g_c, unsigned slot_base) {
-    constexpr int BUF = decltype(buf_c)::value, G = decltype(g_c)::value;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) vg_read128(fa[BUF][mi], slot_base + ((a_lane + mi * 2048) ^ (G ? 64u : 0u)));
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) vg_read128(fb[BUF][ni], slot_base + ((b_lane + ni * 2048) ^ (G ? 64u : 0u)));
+  constexpr int NREADS = MI + NI, NMFMA = 4 * NI * MI;
+  static_assert(NREADS + OPS <= NMFMA, "the next group's reads and the LDS-DMA fit between this group's MFMAs");
+  auto read_one = [&](auto buf_c, auto g_c, auto k_c, unsigned slot_base) {
+    constexpr int BUF = decltype(buf_c)::value, G = decltype(g_c)::value, KI = decltype(k_c)::value;
+    if constexpr (KI < MI)
+      vg_read128(fa[BUF][KI], slot_base + ((a_lane + KI * 2048) ^ (G ? 64u : 0u)));
+    else
+      vg_read128(fb[BUF][KI - MI], slot_base + ((b_lane + (KI - MI) * 2048) ^ (G ? 64u : 0u)));
   };
-  auto mfma_group = [&](auto buf_c) {
+  auto mfma_group = [&](auto buf_c, auto&& hook) {
     constexpr int BUF = decltype(buf_c)::value;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) vg_landed(fa[BUF][mi]);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) vg_landed(fb[BUF][ni]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[BUF][mi][j]), __uint_as_float(fb[BUF][ni][j]),
-                                                             acc[mi][ni], 0, 0, 0);
+    vg_static_for<0, NMFMA>([&](auto i_c) {
+      constexpr int I = decltype(i_c)::value, j = I / (NI * MI), ni = (I / MI) % NI, mi = I % MI;
+      vg_mfma(acc[mi][ni], fa[BUF][mi][j], fb[BUF][ni][j]);
+      hook(i_c);
+    });
   };
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
@@ -348,22 +379,32 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
       if (kc < nk) issue(kc);
     if (nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk == 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
     vg_barrier();
-    read_group(C0{}, C0{}, lds_base);
+    vg_static_for<0, NREADS>([&](auto k_c) { read_one(C0{}, C0{}, k_c, lds_base); });
     vg_wait_lgkm0();
     for (int s = 0; s < nk; ++s) {
       const unsigned slot_base = lds_base + (s % VG_STAGES) * SLOT;
-      read_group(C1{}, C1{}, slot_base);
-      mfma_group(C0{});
+      const unsigned next_base = lds_base + ((s + 1) % VG_STAGES) * SLOT;
+      mfma_group(C0{}, [&](auto i_c) {
+        constexpr int I = decltype(i_c)::value;
+        if constexpr (I < NREADS) read_one(C1{}, C1{}, i_c, slot_base);
+      });
       vg_wait_lgkm0();
-      if (s + 1 < nk) {
+      const bool more = s + 1 < nk, dma = s + 3 < nk;
+      if (more) {
         if (s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
         vg_barrier();
-        if (s + 3 < nk) issue(s + 3);
-        read_group(C0{}, C0{}, lds_base + ((s + 1) % VG_STAGES) * SLOT);
       }
-      mfma_group(C1{});
+      mfma_group(C1{}, [&](auto i_c) {
+        constexpr int I = decltype(i_c)::value;
+        if constexpr (I < OPS) {
+          if (dma) issue_one(i_c, s + 3);
+        } else if constexpr (I - OPS < NREADS) {
+          if (more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
+        }
+      });
       vg_wait_lgkm0();
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   }
   vg_wait_vm<0>();
   vg_barrier();
@@ -709,23 +750,23 @@ extern "C" int rsdet_van_gemm_f32_supported(int M, int K, int P, int n_img) {
     case VG_GATE2: VG_LAUNCH(MI_, NI_, VG_GATE2); break;                                                                \
     case VG_AFFINE: VG_LAUNCH(MI_, NI_, VG_AFFINE); break;                                                              \
     case VG_MUL2: VG_LAUNCH(MI_, NI_, VG_MUL2); break;                                                                  \
-    default: VG_LAUNCH(MI_, NI_, VG_GELU_BWD); break;                                                                   \
+    default: VG_LAUNCH(MI_, NI_, VG_MUL1); break;                                                                   \
   }
 
 // out (n_img, M, P) = epi(weight (M, K) . x (n_img, K, P)), all fp32, pixels contiguous.  epi (r = row, v* (M) vectors, s*
 // maps of the output's shape; out1 only where named):
 //   0 out0 = acc                         1 out0 = acc + v0[r]                  2 out0 = acc + v0[r], out1 = GELU(out0)
 //   3 out0 = acc + v0[r], out1 = out0 s0 4 out0 = s0 v0[r] + acc v1[r] + v2[r] (+ s1 v3[r]; v0 NULL: 1)
-//   5 out0 = acc s0, out1 = acc s1       6 out0 = acc GELU'(s0)
+//   5 out0 = acc s0, out1 = acc s1       6 out0 = acc s0
 extern "C" int rsdet_van_gemm_f32(const float* weight, const float* x, int M, int K, int P, int n_img, int epi,
                                   const float* v0, const float* v1, const float* v2, const float* v3, const float* s0,
                                   const float* s1, float* out0, float* out1, void* stream) {
   VgTile t;
-  if (!vg_pick(M, K, P, n_img, &t) || epi < 0 || epi > VG_GELU_BWD) return RSDET_EINVAL;
+  if (!vg_pick(M, K, P, n_img, &t) || epi < 0 || epi > VG_MUL1) return RSDET_EINVAL;
   if (!weight || !x || !out0) return RSDET_EINVAL;
   const bool two = epi == VG_BIAS_GELU2 || epi == VG_GATE2 || epi == VG_MUL2;
   if (two && !out1) return RSDET_EINVAL;
-  if ((epi == VG_GATE2 || epi == VG_AFFINE || epi == VG_MUL2 || epi == VG_GELU_BWD) && !s0) return RSDET_EINVAL;
+  if ((epi == VG_GATE2 || epi == VG_AFFINE || epi == VG_MUL2 || epi == VG_MUL1) && !s0) return RSDET_EINVAL;
   if (epi == VG_MUL2 && !s1) return RSDET_EINVAL;
   if (epi == VG_AFFINE && (!v1 || !v2 || (s1 && !v3))) return RSDET_EINVAL;
   if ((((uintptr_t)x | (uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)s0 | (uintptr_t)s1 | (uintptr_t)weight) & 15) || (P & 3))
@@ -753,12 +794,12 @@ static inline int vg_wgrad_mi(int M) { return M % 160 == 0 ? 5 : (M % 128 == 0 ?
 extern "C" int rsdet_van_wgrad_f32_supported(int M, int N, int P, int n_img) {
   return (vg_wgrad_mi(M) && N >= 64 && N % 64 == 0 && P >= 32 && P % 32 == 0 && n_img >= 1) ? 1 : 0;
 }
-// number of split-K partials rsdet_van_wgrad_f32 leaves: ~512 workgroups per launch, at least 4 chunks of 32 pixels each
+// number of split-K partials rsdet_van_wgrad_f32 leaves: <= 256 workgroups per launch, at least 4 chunks of 32 pixels each
 extern "C" int rsdet_van_wgrad_f32_splits(int M, int N, int P, int n_img) {
   if (!rsdet_van_wgrad_f32_supported(M, N, P, n_img)) return 0;
   const int tiles = (M / (32 * vg_wgrad_mi(M))) * (N / 64);
   const long long Q = (long long)(P / 32) * n_img;
-  long long S = 512 / tiles;
+  long long S = 256 / tiles;            // one workgroup per CU (84 KB of LDS each): ONE round of workgroups
   if (S > Q / 4) S = Q / 4;
   if (S < 1) S = 1;
   return (int)S;

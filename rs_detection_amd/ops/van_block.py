@@ -38,7 +38,7 @@ from .. import _lib
 
 _ON = True      # False: the per-operator route (what this node is tested against)
 
-_E_NONE, _E_BIAS, _E_BIAS_GELU2, _E_GATE2, _E_AFFINE, _E_MUL2, _E_GELU_BWD = range(7)
+_E_NONE, _E_BIAS, _E_BIAS_GELU2, _E_GATE2, _E_AFFINE, _E_MUL2, _E_MUL1 = range(7)
 _P5, _I5 = ctypes.c_void_p * 5, ctypes.c_int * 5
 
 
@@ -70,7 +70,8 @@ def _dw_fwd(lib, st, x, w, b, N, C, H, W, K, dil, act=False):
     y = torch.empty_like(x)
     if act:
         y2 = torch.empty_like(x)
-        _lib.check(lib.rsdet_dwconv2d_forward_act_f32(_p(x), _p(w), _p(b), N, C, H, W, K, dil, _p(y), _p(y2), st),
+        # (y = GELU'(conv): all the activation's backward needs; y2 = GELU(conv))
+        _lib.check(lib.rsdet_dwconv2d_forward_act_f32(_p(x), _p(w), _p(b), N, C, H, W, K, dil, 1, _p(y), _p(y2), st),
                    "rsdet_dwconv2d_forward_act_f32")
         return y, y2
     _lib.check(lib.rsdet_dwconv2d_forward_f32(_p(x), None, _p(w), _p(b), N, C, H, W, K, dil, _p(y), st),
@@ -126,7 +127,7 @@ class _VanBlock(torch.autograd.Function):
         w4f, b4f, st2, e2 = bn_fold(x1, g2, be2, wf1, bf1, R, bn2, ls2, bf2, False)
         h = torch.empty((N, R, H, W), **f32)
         _gemm(lib, st, w4f, x1, R, C, P, N, _E_BIAS, h, v=(b4f, None, None, None))
-        h2, h3 = _dw_fwd(lib, st, h, wd3, bd3, N, R, H, W, 3, 1, act=True)
+        d3, h3 = _dw_fwd(lib, st, h, wd3, bd3, N, R, H, W, 3, 1, act=True)      # GELU'(dwconv(h)), GELU(dwconv(h))
         out = torch.empty_like(x)
         _gemm(lib, st, wf2, h3, C, R, P, N, _E_AFFINE, out, v=(None, ls2, e2[1], None), s=(x1, None))
         # ---- the backward-data operands (functions of the parameters alone): five transposes, one launch
@@ -136,7 +137,7 @@ class _VanBlock(torch.autograd.Function):
                                           _P5(None, None, _p(ls1), None, _p(ls2)), _P5(*[_p(t) for t in wt]),
                                           _I5(C, C, C, R, C), _I5(C, C, C, C, R), st)
         _lib.check(rc, "rsdet_van_transposes_f32")
-        ctx.save_for_backward(x, t1, u, a0, a1, a2, gt, x1, h, h2, h3, st1, st2, wp1, wd5, wd7, wp2, bp2, ls1, wf1, wd3,
+        ctx.save_for_backward(x, t1, u, a0, a1, a2, gt, x1, h, d3, h3, st1, st2, wp1, wd5, wd7, wp2, bp2, ls1, wf1, wd3,
                               wf2, bf2, ls2, *wt)
         return out
 
@@ -144,7 +145,7 @@ class _VanBlock(torch.autograd.Function):
     def backward(ctx, gout):
         lib = _lib.load()
         st = _lib.stream_ptr()
-        (x, t1, u, a0, a1, a2, gt, x1, h, h2, h3, st1, st2, wp1, wd5, wd7, wp2, bp2, ls1, wf1, wd3, wf2, bf2, ls2,
+        (x, t1, u, a0, a1, a2, gt, x1, h, d3, h3, st1, st2, wp1, wd5, wd7, wp2, bp2, ls1, wf1, wd3, wf2, bf2, ls2,
          w1t, w2t, w3t, w4t, w5t) = ctx.saved_tensors
         N, C, H, W = x.shape
         P, R = H * W, wf1.shape[0]
@@ -175,8 +176,8 @@ class _VanBlock(torch.autograd.Function):
         tabg, nsg = _reduce(lib, st, gout, None, N, C, P, 0)                      # sum_p gout
         part, S = _wgrad(lib, st, gout, h3, C, R, P, N)
         gwf2, gbf2, gls2 = fold_rows(part, S, C, R, ls2, wf2, tabg, nsg, 2, bf2, None, 0, None, None, True)
-        gh2 = torch.empty_like(h2)                                                # through fc2 and the GELU
-        _gemm(lib, st, w5t, gout, R, C, P, N, _E_GELU_BWD, gh2, s=(h2, None))
+        gh2 = torch.empty_like(d3)                                                # through fc2 and the GELU
+        _gemm(lib, st, w5t, gout, R, C, P, N, _E_MUL1, gh2, s=(d3, None))
         gh, gsh = torch.empty_like(h), torch.empty((R,), **f32)                   # through the depthwise 3x3
         nb = lib.rsdet_dwconv2d_backward_data_ws_size(N, R, H, W)
         ws = torch.empty((max(nb, 4),), dtype=torch.uint8, device=dev)
