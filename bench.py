@@ -304,6 +304,80 @@ def kernel_rooflines(device, targets):
     out.update(bn_act_rows(device, len(ks)))
     out.update(gemm1x1_rows(device, len(ks)))
     out.update(next_row_kernels(device))
+    out.update(survey_8d_rows(device))
+    return out
+
+
+def survey_8d_rows(device):
+    """SURVEY 8(d)'s micro-bench sweeps in the driver-visible table: dense rotated IoU at K in {16, 100, 400}
+    gts of ONE tile against the 21 824-anchor grid -- exact grid and refined anchors (seed 7) -- through the two-tier kernel
+    (csrc/iou_fast.hip) and the bit-exact one; rotated NMS at M in {2 000, 5 344, 20 000} boxes in label-major order (as
+    ml_nms_rotated calls it) and plain score order.  frac = SURVEY 8(d)'s algorithmic bytes / time / 8 TB/s."""
+    from rs_detection_amd import ops
+    from rs_detection_amd.utils import synthetic as syn
+    from rs_detection_amd.ops.nms_rotated import _label_major_order
+    out = {}
+    rng = np.random.default_rng(3)
+    grids = (("exact grid", syn.s2anet_anchor_grid()), ("refined anchors (seed 7)", syn.refined_anchor_grid(7)))
+    for gname, grid in grids:
+        anchors = torch.from_numpy(np.ascontiguousarray(grid, dtype=np.float32)).to(device)
+        A = anchors.shape[0]
+        prep = ops.prepare_boxes(anchors, cache=False)
+        for K in (16, 100, 400):
+            gt = torch.from_numpy(syn.dota_gt_boxes(rng, K)).to(device)
+            ro = torch.tensor([0, K], dtype=torch.int32, device=device)
+            ov = torch.empty((K, A), device=device)
+            by = 20 * (K + A) + 4 * K * A
+            for kname, fn in (("two-tier", lambda: ops.box_iou_rotated_fast(gt, anchors, ro, ks=[K], out=ov, prepared=prep)),
+                              ("bit-exact", lambda: ops.box_iou_rotated_grouped(gt, ro, K, anchors, out=ov))):
+                t = event_time(fn, 30)
+                out["iou_sweep[%s, K=%d, %s]" % (kname, K, gname)] = dict(
+                    bound="hbm", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+                    traffic=None, us=t * 1e6, mpairs_per_s=K * A / t / 1e6, overlapping_pairs=int((ov != 0).sum()))
+    for M in (2000, 5344, 20000):
+        d, sc_, l = syn.nms_cluster_boxes(M)
+        d6 = torch.from_numpy(np.concatenate([d, l[:, None].astype(np.float32)], 1)).to(device)
+        sc, lab = torch.from_numpy(sc_).to(device), torch.from_numpy(l).to(device)
+        lorder = _label_major_order(sc, lab).int()
+        order = torch.argsort(sc, descending=True, stable=True).int()
+        by = 4 * 6 * M + 2 * 8 * M * ((M + 63) // 64) + M
+        for oname, fn in (("label-major", lambda: ops.nms_rotated_keep_mask(d6, lorder, 0.1, 6, label_major=True)),
+                          ("score order", lambda: ops.nms_rotated_keep_mask(d6, order, 0.1, 6))):
+            t = event_time(fn, 10, 2)
+            out["nms_sweep[M=%d, %s]" % (M, oname)] = dict(
+                bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+                traffic=None, us=t * 1e6, mboxes_per_s=M / t / 1e6)
+    return out
+
+
+def eval_leg(device, steps=10):
+    """The S2ANet TEST path (/root/reference/python/jdet/runner/runner.py:214-245 -> s2anet_head.py:510-601 get_bboxes ->
+    ops/nms_rotated.py:540-596 multiclass_nms_rotated) through Runner.predict on resident synthetic 1024^2 tiles: tiles/s
+    at B = 1 and B = 4, fp32 and bf16 autocast (channels_last), the detections left on the device as in the eval loop."""
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.runner.runner import Runner
+    from rs_detection_amd.utils.synthetic import synthetic_targets
+    out = {}
+    for tag, amp in (("f32", None), ("bf16", torch.bfloat16)):
+        torch.manual_seed(0)
+        r = Runner(s2anet_cfg(), device=device, memory_format=torch.channels_last, amp_dtype=amp)
+        for B in (1, 4):
+            im = torch.randn(B, 3, TILE, TILE, device=device)
+            tg = synthetic_targets(B, img=TILE)
+            with torch.no_grad():
+                for _ in range(3):
+                    r.predict(im, tg)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    r.predict(im, tg)
+                t_enq = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["%s_b%d" % (tag, B)] = {"tiles_per_s": B * steps / dt, "ms_per_call": dt / steps * 1e3,
+                                        "host_enqueue_ms_per_call": t_enq / steps * 1e3}
+        del r
+        torch.cuda.empty_cache()
     return out
 
 
@@ -706,6 +780,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the HIP hot path")
     device = torch.device("cuda", local_rank % torch.cuda.device_count())  # (% only matters for the 1-GPU gloo smoke test)
     torch.cuda.set_device(device)
+    rdist.require_rccl(world)            # a GPU per rank and yet not RCCL: refuse (non-zero exit of every rank)
+    facts = rdist.gather_objects(rdist.rank_facts(device))
     from rs_detection_amd import _lib
     _lib.load()
 
@@ -726,6 +802,8 @@ def main():
         cfg, batch, ncls = s2anet_cfg(), BATCH_PER_GPU, 15
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     runner = Runner(cfg, device=device, memory_format=mf, amp_dtype=amp, bf16_params=args.bf16_params == "1")
+    mg_buckets = len(runner.reducer.buckets) if runner.reducer is not None else None
+    mg_wire = runner.reducer.wire_dtypes if runner.reducer is not None else None
     # synthetic DOTA-shaped batches, resident in HBM before the timed region.  N_BATCHES different batches
     # rotate through the timed loop (step i runs batch i % N_BATCHES, the K cycle shifted by one slot per batch), so the
     # per-K-tuple tile tables and the prepared-box caches of the anchor-target path see new gts every step.
@@ -835,6 +913,8 @@ def main():
         extra["r101_bf16"] = extra_leg("s2anet_r101", torch.bfloat16, torch.channels_last, 12, rank, device, rdist,
                                        args.bf16_params == "1")
         extra["orcnn"] = extra_leg("orcnn_van3", None, None, 8, rank, device, rdist, False)
+        if rank == 0:
+            extra["eval"] = eval_leg(device)
 
     if rank != 0:
         rdist.barrier()          # rank 0 is still timing its kernel table: leave the group together
@@ -863,6 +943,8 @@ def main():
     rest = sorted((kv for kv in kernels.items() if not kv[0].startswith("conv3x3_")), key=lambda kv: -kv[1].get("us", 0.0))
     top = (first + rest)[:12]
     r3 = lambda x: None if x is None else float("%.4g" % x)
+    ev = lambda k: (extra["eval"][k]["tiles_per_s"] if extra.get("eval") else None)
+    kf = lambda row, key: (kernels[row][key] if row in kernels else None)
     peak_f = FP32_VALU_PEAK_TFLOPS if args.dtype == "f32" else 2500.0
     line = {
         "metric": METRICS[args.model],
@@ -901,6 +983,20 @@ def main():
         "orcnn_tiles_per_s": extra["orcnn"]["value"] if extra.get("orcnn") else None,
         "orcnn_ms_per_step": extra["orcnn"]["ms_per_step"] if extra.get("orcnn") else None,
         "orcnn_host_enqueue_ms_per_step": extra["orcnn"]["host_enqueue_ms_per_step"] if extra.get("orcnn") else None,
+        # the TEST path (Runner.predict incl. multiclass_nms_rotated) of configs[1]'s model on resident 1024^2 tiles
+        "eval_tiles_per_s_f32_b1": ev("f32_b1"), "eval_tiles_per_s_f32_b4": ev("f32_b4"),
+        "eval_tiles_per_s_bf16_b1": ev("bf16_b1"), "eval_tiles_per_s_bf16_b4": ev("bf16_b4"),
+        "eval_host_ms_per_call_bf16_b1": (extra["eval"]["bf16_b1"]["host_enqueue_ms_per_call"] if extra.get("eval") else None),
+        # SURVEY 8(d) sweeps (all rows: kernels_file): dense IoU at the largest single-tile K on refined anchors, NMS at 20 000
+        "iou_k400_refined_two_tier_frac": kf("iou_sweep[two-tier, K=400, refined anchors (seed 7)]", "frac"),
+        "iou_k400_refined_bit_exact_frac": kf("iou_sweep[bit-exact, K=400, refined anchors (seed 7)]", "frac"),
+        "nms_m20000_label_major_mboxes_per_s": kf("nms_sweep[M=20000, label-major]", "mboxes_per_s"),
+        "nms_m20000_score_order_mboxes_per_s": kf("nms_sweep[M=20000, score order]", "mboxes_per_s"),
+        # what the run itself saw of the node: one record per rank (device opened, its PCI address and NUMA node, cores
+        # pinned), the collective backend and the group size as torch.distributed reports them, the gradient buckets
+        "multi_gpu": {"visible_gpus": torch.cuda.device_count(), "backend": facts[0]["backend"],
+                      "group_world": facts[0]["group_world"], "ranks": facts,
+                      "grad_buckets": mg_buckets, "wire_dtypes": mg_wire},
         "ddp_host_overhead_ms": ddp_leg.get("host_overhead_ms") if ddp_leg else None,
         "ddp": ddp_leg,
         "rotated_iou_mpairs_per_s": dense["mpairs_per_s"] if dense else None,

@@ -512,6 +512,35 @@ int rsdet_van_bn_prep_f32(const rsdet_van_bn_prep* f, void* stream);
  * row_scale[j][o] (NULL: 1): the operands of a block's backward-data GEMMs. */
 int rsdet_van_transposes_f32(int n, const float* const* src, const float* const* row_scale, float* const* dst, const int* O,
                              const int* K, void* stream);
+/* A whole VAN Block (Block.execute, /root/reference/python/jdet/models/backbones/van.py:216-261, with Mlp :140-175,
+ * AttentionModule :177-192 and SpatialAttention :195-213 inside it) forward and backward as ONE call each
+ * (csrc/van_block.hip): the 13 + 29 launches of the pieces above into caller-provided fp32 arenas.  x / out / grad_out /
+ * grad_x: (N, C, H, W) NCHW; hidden width R; both BatchNorms in training mode (batch statistics; rm / rv / nbt = running
+ * mean / variance / num_batches_tracked (int64), updated as nn.BatchNorm2d does, NULL: not kept).
+ *   saved    rsdet_van_block_saved_floats            what the backward reads again (written by the forward)
+ *   scratch  rsdet_van_block_{forward,backward}_scratch_floats
+ *   grads    rsdet_van_block_grad_floats: the parameter gradients, 16-byte aligned slices in the order
+ *            g1 be1 wp1 bp1 wd5 bd5 wd7 bd7 wc1 bc1 wp2 bp2 ls1 g2 be2 wf1 bf1 wd3 bd3 wf2 bf2 ls2 (each rounded up to 4 floats)
+ * grad_x NULL: not formed.  _supported: every GEMM / weight-gradient shape of the block is one the kernels tile. */
+typedef struct rsdet_van_block {
+  int N, C, H, W, R;
+  const float *g1, *be1, *wp1, *bp1, *wd5, *bd5, *wd7, *bd7, *wc1, *bc1, *wp2, *bp2, *ls1, *g2, *be2, *wf1, *bf1, *wd3, *bd3,
+      *wf2, *bf2, *ls2;
+  float *rm1, *rv1;
+  void* nbt1;
+  float *rm2, *rv2;
+  void* nbt2;
+  float eps1, mom1, eps2, mom2;
+} rsdet_van_block;
+int rsdet_van_block_supported(const rsdet_van_block* b);
+size_t rsdet_van_block_saved_floats(const rsdet_van_block* b);
+size_t rsdet_van_block_grad_floats(const rsdet_van_block* b);
+size_t rsdet_van_block_forward_scratch_floats(const rsdet_van_block* b);
+size_t rsdet_van_block_backward_scratch_floats(const rsdet_van_block* b);
+int rsdet_van_block_forward_f32(const rsdet_van_block* b, const float* x, float* out, float* saved, float* scratch,
+                                void* stream);
+int rsdet_van_block_backward_f32(const rsdet_van_block* b, const float* x, const float* grad_out, const float* saved,
+                                 float* scratch, float* grad_x, float* grads, void* stream);
 /* The prepared weight operands of the backward (ops/weight_prep.py) refreshed by one launch: entries = n 64-byte records
  * in DEVICE memory {src, dst, var, gamma (pointers), O, C, T, eps (float), tile0, tiles_c, tiles_o, pad}: dst (C, T, O) =
  * src (O, T, C) with the taps reversed and row o scaled by gamma[o] / sqrt(var[o] + eps) (var NULL: copied).  tile0

@@ -37,6 +37,15 @@ class VanBnPrep(ctypes.Structure):
                 + [(n, c_int) for n in ("shortcut", "O", "K", "ns", "len")] + [("eps", c_float), ("momentum", c_float)])
 
 
+class VanBlock(ctypes.Structure):
+    """struct rsdet_van_block (include/rsdet.h)."""
+    PARAMS = ("g1", "be1", "wp1", "bp1", "wd5", "bd5", "wd7", "bd7", "wc1", "bc1", "wp2", "bp2", "ls1", "g2", "be2", "wf1",
+              "bf1", "wd3", "bd3", "wf2", "bf2", "ls2")
+    _fields_ = ([(n, c_int) for n in ("N", "C", "H", "W", "R")] + [(n, c_void_p) for n in PARAMS]
+                + [(n, c_void_p) for n in ("rm1", "rv1", "nbt1", "rm2", "rv2", "nbt2")]
+                + [(n, c_float) for n in ("eps1", "mom1", "eps2", "mom2")])
+
+
 class VanRowsFold(ctypes.Structure):
     """struct rsdet_van_rows_fold (include/rsdet.h)."""
     _fields_ = ([(n, c_void_p) for n in ("partial", "row_scale", "w", "gs_tab", "bias", "r_tab", "sc", "sh", "grad_w",
@@ -90,6 +99,13 @@ SIGNATURES = {
                                                c_int, c_void_p, c_void_p, c_void_p]),
     "rsdet_dwconv2d_backward_data_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_van_block_supported": (c_int, [c_void_p]),
+    "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),
+    "rsdet_van_block_grad_floats": (c_size_t, [c_void_p]),
+    "rsdet_van_block_forward_scratch_floats": (c_size_t, [c_void_p]),
+    "rsdet_van_block_backward_scratch_floats": (c_size_t, [c_void_p]),
+    "rsdet_van_block_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_van_block_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_weight_prep_multi_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rsdet_conv1x1_bn_act_fwd_bf16": (c_int, [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p]),

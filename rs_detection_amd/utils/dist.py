@@ -291,6 +291,39 @@ def sync_mean(values, device):
     return dict(zip(keys, t.tolist()))
 
 
+def rank_facts(device=None):
+    """What a multi-GPU run should be able to show about THIS rank: the device it opened (index, PCI address, the NUMA node of
+    that PCI function), the cores it is pinned to, the collective backend and the group size as the backend itself reports
+    it.  Gathered by bench.py into the line's ``multi_gpu`` object."""
+    rank, local_rank, world = env_world()
+    f = {"rank": rank, "local_rank": local_rank, "env_world": world, "visible_gpus": torch.cuda.device_count(),
+         "backend": None, "group_world": 1, "device": None, "pci": None, "numa_node": None,
+         "cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    if dist.is_available() and dist.is_initialized():
+        f["backend"], f["group_world"] = dist.get_backend(), dist.get_world_size()
+    if device is not None and getattr(device, "type", None) == "cuda":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        f["device"] = idx
+        try:
+            pr = torch.cuda.get_device_properties(idx)
+            f["pci"] = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            f["numa_node"] = gpu_numa_node_by_pci(f["pci"], os.environ.get("RSDET_SYSFS_ROOT", "/sys"))
+        except Exception:                # noqa: BLE001
+            pass
+    return f
+
+
+def require_rccl(world):
+    """A multi-rank job on a node that HAS a GPU per rank must reduce over RCCL: a silent fall-back to gloo (a stale
+    RSDET_DIST_BACKEND, a build without RCCL) would measure host-memory all-reduces.  Raises SystemExit (non-zero exit of
+    every rank, from the process that started them -- never a re-exec); ranks SHARING a GPU (the 2-rank tests on a 1-GPU
+    box) are the one legitimate gloo case."""
+    if world > 1 and dist.is_initialized() and torch.cuda.device_count() >= world and dist.get_backend() != "nccl":
+        raise SystemExit("rs_detection_amd: %d ranks on a node with %d visible GPUs, but the process group runs on %r -- the "
+                         "gradient all-reduce must go over RCCL / xGMI (unset RSDET_DIST_BACKEND?)"
+                         % (world, torch.cuda.device_count(), dist.get_backend()))
+
+
 def gather_objects(obj):
     """Every rank's picklable ``obj`` as a list on every rank (the sharded evaluation of Runner.val)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

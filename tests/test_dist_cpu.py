@@ -538,3 +538,22 @@ def test_grad_reducer_refuses_rank_dependent_and_drifting_graphs():
     p.join(60)
     assert unused_stay_none                     # a parameter no rank uses keeps grad None (no decay / momentum on it)
     assert msg is not None and "must not change between steps" in msg and "1." in msg
+
+
+def test_rank_facts_and_rccl_requirement(monkeypatch):
+    """bench.py's ``multi_gpu`` object is built from rank_facts(); a job with a GPU per rank that is NOT on RCCL is refused."""
+    from rs_detection_amd.utils import dist as rdist
+    f = rdist.rank_facts(torch.device("cpu"))
+    assert f["rank"] == 0 and f["group_world"] == 1 and f["backend"] is None and f["device"] is None
+    rdist.require_rccl(1)                                   # one rank: nothing to require
+    import torch.distributed as dist
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_backend", lambda *a: "gloo")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    with pytest.raises(SystemExit, match="RCCL"):
+        rdist.require_rccl(8)                               # 8 GPUs, 8 ranks, gloo: refused
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    rdist.require_rccl(2)                                   # two ranks SHARING one GPU (the 1-GPU tests): gloo is legitimate
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(dist, "get_backend", lambda *a: "nccl")
+    rdist.require_rccl(8)
