@@ -4,6 +4,12 @@ usage: step_breakdown.py <dir> <steps counted in the run (warmup + flop step + t
 import csv, glob, sys, collections
 d, steps = sys.argv[1], float(sys.argv[2])
 f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+# steps = 0: count them from a kernel that runs a known number of times per step (the VAN-B3 backbone: 38 blocks, one
+# rsdet::van_transposes_kernel launch each) -- the bench's set-up steps make the nominal count wrong
+if steps == 0:
+    for r in csv.DictReader(open(f)):
+        if "van_transposes_kernel" in r["Name"]:
+            steps = int(r["Calls"]) / 38.0
 fam = collections.defaultdict(float)
 rows = []
 for r in csv.DictReader(open(f)):

@@ -74,8 +74,9 @@ __device__ __forceinline__ void vg_wait_vm() {
 }
 __device__ __forceinline__ void vg_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void vg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <int OFF>
 __device__ __forceinline__ void vg_read128(vg_u32x4& dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void vg_read32(float& dst, unsigned addr) {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
   auto read_one = [&](auto buf_c, auto g_c, auto k_c, unsigned slot_base) {
     constexpr int BUF = decltype(buf_c)::value, G = decltype(g_c)::value, KI = decltype(k_c)::value;
     if constexpr (KI < MI) {
-      vg_read128(fa[BUF][KI], slot_base + ((a_lane + KI * 2048) ^ (G ? 64u : 0u)));
+      vg_read128<KI * 2048>(fa[BUF][KI], slot_base + (a_lane ^ (G ? 64u : 0u)));    // (+ mi * 2048 never touches bit 6)
     } else {
       constexpr int ni = (KI - MI) / 4, j = (KI - MI) % 4;
       vg_read32<(G * 16 + j) * TN * 4>(fb[BUF][ni][j], slot_base + b_lane[ni]);
@@ -200,46 +201,50 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
   vg_barrier();
   vg_static_for<0, NREADS>([&](auto k_c) { read_one(C0{}, C0{}, k_c, lds_base); });
   vg_wait_lgkm0();
-  for (int s = 0; s < nk; ++s) {
+  // One chunk.  DMA / MORE are compile-time in the steady state (s + 3 < nk): a run-time test around every read and
+  // LDS-DMA operation is a scalar branch in EVERY gap between two MFMAs (20 per chunk) -- the tail (the last three chunks)
+  // takes the run-time form.
+  auto chunk = [&](int s, auto dma_c, auto more_c, bool dma, bool more) {
+    constexpr bool DMA_CT = decltype(dma_c)::value != 0, MORE_CT = decltype(more_c)::value != 0;
     const unsigned slot_base = lds_base + (s % VG_STAGES) * SLOT;
     const unsigned next_base = lds_base + ((s + 1) % VG_STAGES) * SLOT;
-    // first half of chunk s; the reads of its second half ride between the MFMAs
 #if defined(VG_ABL) && VG_ABL >= 3               // (ablation 3: MFMAs only; 4: + the barrier -- timing builds, wrong values)
     mfma_group(C0{}, [&](auto) {});
-    const bool more = s + 1 < nk, dma = false;
 #if VG_ABL == 4
     vg_barrier();
 #endif
     mfma_group(C1{}, [&](auto) {});
-    (void)more, (void)dma, (void)slot_base, (void)next_base;
-    continue;
+    (void)dma, (void)more, (void)slot_base, (void)next_base;
 #else
+    // first half of chunk s; the reads of its second half ride between the MFMAs
     mfma_group(C0{}, [&](auto i_c) {
       constexpr int I = decltype(i_c)::value;
       if constexpr (I < NREADS) read_one(C1{}, C1{}, i_c, slot_base);
     });
     vg_wait_lgkm0();
-    const bool more = s + 1 < nk, dma = s + 3 < nk;
-    if (more) {
+    if (MORE_CT || more) {
       // chunk s + 1 landed (mine: all but the operations of chunk s + 2); every wave has chunk s in registers
-      if (s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+      if (DMA_CT || s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
       vg_barrier();
     }
-#endif
     // second half; between its MFMAs: the LDS-DMA of chunk s + 3 (into the slot chunk s just left), then the first reads
     // of chunk s + 1
     mfma_group(C1{}, [&](auto i_c) {
       constexpr int I = decltype(i_c)::value;
       if constexpr (I < OPS) {
 #if !defined(VG_ABL) || VG_ABL != 2              // (ablation 2: no DMA after the prologue -- a timing build, wrong values)
-        if (dma) issue_one(i_c, s + 3);
+        if (DMA_CT || dma) issue_one(i_c, s + 3);
 #endif
       } else if constexpr (I - OPS < NREADS) {
-        if (more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
+        if (MORE_CT || more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
       }
     });
     vg_wait_lgkm0();
-  }
+#endif
+  };
+  int s = 0;
+  for (; s + 3 < nk; ++s) chunk(s, C1{}, C1{}, true, true);
+  for (; s < nk; ++s) chunk(s, C0{}, C0{}, false, s + 1 < nk);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last MFMAs' results: the compiler does not see their hazard)
   // ---- epilogue: accumulators -> LDS (row-major tile) -> 4 consecutive pixels per lane
   vg_wait_vm<0>();
@@ -359,9 +364,9 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
   auto read_one = [&](auto buf_c, auto g_c, auto k_c, unsigned slot_base) {
     constexpr int BUF = decltype(buf_c)::value, G = decltype(g_c)::value, KI = decltype(k_c)::value;
     if constexpr (KI < MI)
-      vg_read128(fa[BUF][KI], slot_base + ((a_lane + KI * 2048) ^ (G ? 64u : 0u)));
+      vg_read128<KI * 2048>(fa[BUF][KI], slot_base + (a_lane ^ (G ? 64u : 0u)));
     else
-      vg_read128(fb[BUF][KI - MI], slot_base + ((b_lane + (KI - MI) * 2048) ^ (G ? 64u : 0u)));
+      vg_read128<(KI - MI) * 2048>(fb[BUF][KI - MI], slot_base + (b_lane ^ (G ? 64u : 0u)));
   };
   auto mfma_group = [&](auto buf_c, auto&& hook) {
     constexpr int BUF = decltype(buf_c)::value;
@@ -381,7 +386,8 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
     vg_barrier();
     vg_static_for<0, NREADS>([&](auto k_c) { read_one(C0{}, C0{}, k_c, lds_base); });
     vg_wait_lgkm0();
-    for (int s = 0; s < nk; ++s) {
+    auto chunk = [&](int s, auto dma_c, auto more_c, bool dma, bool more) {
+      constexpr bool DMA_CT = decltype(dma_c)::value != 0, MORE_CT = decltype(more_c)::value != 0;
       const unsigned slot_base = lds_base + (s % VG_STAGES) * SLOT;
       const unsigned next_base = lds_base + ((s + 1) % VG_STAGES) * SLOT;
       mfma_group(C0{}, [&](auto i_c) {
@@ -389,21 +395,23 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
         if constexpr (I < NREADS) read_one(C1{}, C1{}, i_c, slot_base);
       });
       vg_wait_lgkm0();
-      const bool more = s + 1 < nk, dma = s + 3 < nk;
-      if (more) {
-        if (s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+      if (MORE_CT || more) {
+        if (DMA_CT || s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
         vg_barrier();
       }
       mfma_group(C1{}, [&](auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < OPS) {
-          if (dma) issue_one(i_c, s + 3);
+          if (DMA_CT || dma) issue_one(i_c, s + 3);
         } else if constexpr (I - OPS < NREADS) {
-          if (more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
+          if (MORE_CT || more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
         }
       });
       vg_wait_lgkm0();
-    }
+    };
+    int s = 0;
+    for (; s + 3 < nk; ++s) chunk(s, C1{}, C1{}, true, true);
+    for (; s < nk; ++s) chunk(s, C0{}, C0{}, false, s + 1 < nk);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   }
   vg_wait_vm<0>();
