@@ -675,7 +675,8 @@ int rsdet_rotated_box_to_poly_f32(const float* boxes, int n, float* polys, void*
  * without its bias kernel; backward_data returns that bias' gradient = sum(grad_x) in grad_in_bias (NULL: not wanted;
  * ws of rsdet_dwconv2d_backward_data_ws_size bytes only when it is).  backward_weight takes the same in_bias, also
  * returns the bias gradient of the depthwise convolution itself (grad_bias may be NULL).  All sums run in a fixed order
- * (two stages through ws, no float atomics). */
+ * (two stages through ws, no float atomics).   ws WITHOUT grad_in_bias: the per-tile sums stay in ws as [c][slot] floats (ws_size / 4 / C
+ * slots per channel) for a consumer that folds them itself (rsdet_van_fold_bn_f32's gs_tab). */
 int rsdet_dwconv2d_forward_f32(const float* x, const float* in_bias, const float* weight, const float* bias, int N,
                                int C, int H, int W, int K, int dilation, float* y, void* stream);
 size_t rsdet_dwconv2d_backward_data_ws_size(int N, int C, int H, int W);

@@ -377,9 +377,10 @@ extern "C" int rsdet_dwconv2d_backward_data_f32(const float* grad_y, const float
     return RSDET_OK;
   }
   if (!grad_y || !weight || !grad_x) return RSDET_EINVAL;
-  if (grad_in_bias && (!ws || ws_bytes < rsdet_dwconv2d_backward_data_ws_size(N, C, H, W))) return RSDET_EINVAL;
-  rc = dw_stencil<true>(grad_y, weight, nullptr, nullptr, N, C, H, W, K, dilation, grad_x,
-                        grad_in_bias ? (float*)ws : nullptr, s);
+  // (ws without grad_in_bias: the per-tile sums stay in ws as [c][slot] floats, slot count = ws_size / 4 / C, for a consumer
+  //  that folds them itself -- rsdet_van_fold_bn_f32's gs_tab)
+  if ((grad_in_bias || ws) && (!ws || ws_bytes < rsdet_dwconv2d_backward_data_ws_size(N, C, H, W))) return RSDET_EINVAL;
+  rc = dw_stencil<true>(grad_y, weight, nullptr, nullptr, N, C, H, W, K, dilation, grad_x, (float*)ws, s);
   if (rc || !grad_in_bias) return rc;
   const int nslots = (int)(dw_slots(N, C, H, W) / C);
   hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, (const float*)ws, nslots, 1,
@@ -399,9 +400,9 @@ extern "C" int rsdet_dwconv2d_backward_data_act_f32(const float* grad_y, const f
   if (C == 0 || N == 0) return RSDET_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!grad_y || !weight || !grad_x || !add || !gelu_arg) return RSDET_EINVAL;
-  if (grad_sum && (!ws || ws_bytes < rsdet_dwconv2d_backward_data_ws_size(N, C, H, W))) return RSDET_EINVAL;
-  rc = dw_stencil<true>(grad_y, weight, nullptr, nullptr, N, C, H, W, K, dilation, grad_x, grad_sum ? (float*)ws : nullptr,
-                        s, nullptr, add, gelu_arg);
+  if ((grad_sum || ws) && (!ws || ws_bytes < rsdet_dwconv2d_backward_data_ws_size(N, C, H, W))) return RSDET_EINVAL;
+  rc = dw_stencil<true>(grad_y, weight, nullptr, nullptr, N, C, H, W, K, dilation, grad_x, (float*)ws, s, nullptr, add,
+                        gelu_arg);
   if (rc || !grad_sum) return rc;
   const int nslots = (int)(dw_slots(N, C, H, W) / C);
   hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, (const float*)ws, nslots, 1, (float*)nullptr,

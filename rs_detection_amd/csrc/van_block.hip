@@ -90,6 +90,14 @@ static size_t dw_ws_floats(const Dims& d, int ch) {
   return (m + 3) / 4;
 }
 
+// The channel sums of a depthwise backward-data result (the bias gradient of the 1x1 convolution before it): with few
+// tiles per plane the per-tile table goes to the fold as it is (gs_ns = slots), else the depthwise call folds it first.
+static int dw_slots_per_channel(const Dims& d, int ch) {
+  return (int)(rsdet_dwconv2d_backward_data_ws_size(d.N, ch, d.H, d.W) / 4 / (size_t)ch);
+}
+static bool gs_direct(const Dims& d, int ch) { return dw_slots_per_channel(d, ch) <= 16; }
+static size_t gs_floats(const Dims& d, int ch) { return gs_direct(d, ch) ? (size_t)ch * dw_slots_per_channel(d, ch) : (size_t)ch; }
+
 #define VB_CHECK(expr)       \
   do {                       \
     const int rc_ = (expr);  \
@@ -118,8 +126,8 @@ extern "C" size_t rsdet_van_block_backward_scratch_floats(const rsdet_van_block*
   if (!supported(b)) return 0;
   const Dims d = dims(b);
   // tab (C ns 2) x 3, partials, two hidden-width maps, five block-width maps, vectors, depthwise workspaces
-  return 3 * up4((size_t)d.C * d.ns * 2) + up4(max_part(d)) + 2 * up4(d.nrp) + 5 * up4(d.ncp) + up4(d.R) + up4(d.C) +
-         2 * up4(6 * (size_t)d.C) + up4(dw_ws_floats(d, d.R > d.C ? d.R : d.C));
+  return 3 * up4((size_t)d.C * d.ns * 2) + up4(max_part(d)) + 2 * up4(d.nrp) + 5 * up4(d.ncp) + up4(gs_floats(d, d.R)) +
+         up4(gs_floats(d, d.C)) + 2 * up4(6 * (size_t)d.C) + up4(dw_ws_floats(d, d.R > d.C ? d.R : d.C));
 }
 
 extern "C" int rsdet_van_block_forward_f32(const rsdet_van_block* b, const float* x, float* out, float* saved, float* scratch,
@@ -183,8 +191,10 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   float* gug = a.take(d.ncp);
   float* m1 = a.take(d.ncp);       // ga1, then gt1
   float* ga0 = a.take(d.ncp);
-  float* gsh = a.take(R);
-  float* gs1 = a.take(C);
+  float* gsh = a.take(gs_floats(d, R));
+  float* gs1 = a.take(gs_floats(d, C));
+  const bool dir_r = gs_direct(d, R), dir_c = gs_direct(d, C);
+  const int ns_r = dir_r ? dw_slots_per_channel(d, R) : 1, ns_c = dir_c ? dw_slots_per_channel(d, C) : 1;
   float* vec2 = a.take(6 * (size_t)C);   // (grad_gamma, grad_beta live in `grads`) v0..v3 of norm2 / norm1
   float* vec1 = a.take(6 * (size_t)C);
   const size_t dw_fl = dw_ws_floats(d, R > C ? R : C);
@@ -201,12 +211,15 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   }
   VB_CHECK(rsdet_van_gemm_f32(s.w5t, grad_out, R, C, P, N, 6, nullptr, nullptr, nullptr, nullptr, s.d3, nullptr, gh2, nullptr,
                               stream));
-  VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, gsh, dws, dw_bytes, stream));
+  if (dir_r)
+    VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, nullptr, gsh, (size_t)R * ns_r * 4, stream));
+  else
+    VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, gsh, dws, dw_bytes, stream));
   VB_CHECK(rsdet_dwconv2d_backward_weight_f32(gh2, s.h, nullptr, N, R, H, W, 3, 1, g.wd3, g.bd3, dws, dw_bytes, stream));
   VB_CHECK(rsdet_van_wgrad_f32(s.x1, gh, C, R, P, N, part, stream));
   {
     rsdet_van_bn_fold f{part, s.w4t, gsh, nullptr, nullptr, s.st2, s.st2 + C, s.st2 + 2 * C, s.st2 + 3 * C, g.wf1, g.bf1,
-                        g.g2, g.be2, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, S_cr, C, R, 1, 1, 0, cnt};
+                        g.g2, g.be2, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, S_cr, C, R, ns_r, 1, 0, cnt};
     VB_CHECK(rsdet_van_fold_bn_f32(&f, stream));
   }
   VB_CHECK(rsdet_van_gemm_f32(s.w4t, gh, C, R, P, N, 4, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, grad_out, s.x1, G, nullptr,
@@ -233,12 +246,16 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   VB_CHECK(rsdet_dwconv2d_backward_data_f32(ga1, b->wd7, N, C, H, W, 7, 3, ga0, nullptr, nullptr, 0, stream));
   VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga1, s.a0, nullptr, N, C, H, W, 7, 3, g.wd7, g.bd7, dws, dw_bytes, stream));
   float* gt1 = ga2;                 // (ga2 is dead: its consumers above are enqueued before this write)
-  VB_CHECK(rsdet_dwconv2d_backward_data_act_f32(ga0, b->wd5, N, C, H, W, 5, 1, gug, s.t1, gt1, gs1, dws, dw_bytes, stream));
+  if (dir_c)
+    VB_CHECK(rsdet_dwconv2d_backward_data_act_f32(ga0, b->wd5, N, C, H, W, 5, 1, gug, s.t1, gt1, nullptr, gs1,
+                                                  (size_t)C * ns_c * 4, stream));
+  else
+    VB_CHECK(rsdet_dwconv2d_backward_data_act_f32(ga0, b->wd5, N, C, H, W, 5, 1, gug, s.t1, gt1, gs1, dws, dw_bytes, stream));
   VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga0, s.u, nullptr, N, C, H, W, 5, 1, g.wd5, g.bd5, dws, dw_bytes, stream));
   VB_CHECK(rsdet_van_wgrad_f32(x, gt1, C, C, P, N, part, stream));
   {
     rsdet_van_bn_fold f{part, s.w1t, gs1, tabr, b->ls1, s.st1, s.st1 + C, s.st1 + 2 * C, s.st1 + 3 * C, g.wp1, g.bp1,
-                        g.g1, g.be1, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, S_cc, C, C, 1, 1, ns, cnt};
+                        g.g1, g.be1, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, S_cc, C, C, ns_c, 1, ns, cnt};
     VB_CHECK(rsdet_van_fold_bn_f32(&f, stream));
   }
   if (grad_x)
