@@ -533,6 +533,11 @@ typedef struct rsdet_van_block {
   float eps1, mom1, eps2, mom2;
 } rsdet_van_block;
 int rsdet_van_block_supported(const rsdet_van_block* b);
+/* 1: the backward's weight gradients, their folds and the depthwise weight gradients run on a side stream beside the chain
+ * that produces grad_x (joined before the call returns control of the buffers to `stream`); 0 (default: measured 2.5 %
+ * slower on the Oriented R-CNN step, the seven cross-stream edges per block cost more than the overlap returns): everything
+ * on `stream`.  Returns the previous setting; any other argument only queries. */
+int rsdet_van_block_side_stream(int on);
 size_t rsdet_van_block_saved_floats(const rsdet_van_block* b);
 size_t rsdet_van_block_grad_floats(const rsdet_van_block* b);
 size_t rsdet_van_block_forward_scratch_floats(const rsdet_van_block* b);

@@ -100,6 +100,7 @@ SIGNATURES = {
     "rsdet_dwconv2d_backward_data_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_van_block_supported": (c_int, [c_void_p]),
+    "rsdet_van_block_side_stream": (c_int, [c_int]),
     "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),
     "rsdet_van_block_grad_floats": (c_size_t, [c_void_p]),
     "rsdet_van_block_forward_scratch_floats": (c_size_t, [c_void_p]),

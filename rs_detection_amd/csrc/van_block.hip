@@ -98,6 +98,34 @@ static int dw_slots_per_channel(const Dims& d, int ch) {
 static bool gs_direct(const Dims& d, int ch) { return dw_slots_per_channel(d, ch) <= 16; }
 static size_t gs_floats(const Dims& d, int ch) { return gs_direct(d, ch) ? (size_t)ch * dw_slots_per_channel(d, ch) : (size_t)ch; }
 
+// ---- a side stream for the backward's off-chain work (weight gradients, their folds, the depthwise weight gradients): the
+// chain that produces grad_x is gemm -> depthwise -> gemm ...; the weight gradients hang off it and nothing downstream in
+// the block waits for them.  Issued on a second stream they overlap the chain: a memory-bound depthwise weight gradient
+// beside an MFMA-bound GEMM costs almost nothing, and every kernel's ~5 us of launch / prologue / epilogue hides behind the
+// other stream's main phase.  One stream and seven events per process (one process per GPU), created on first use.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ev[7] = {};
+  bool ok = false;
+};
+static SideStream* side_stream() {
+  static SideStream sd = [] {
+    SideStream x;
+    x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess;
+    for (auto& e : x.ev) x.ok = x.ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    return x;
+  }();
+  return &sd;
+}
+static int g_side_on = 0;   // measured (round 6, Oriented R-CNN VAN-B3 step, same box): 60.0 ms on one stream, 61.5 ms with the side
+                           // stream -- seven cross-stream edges per block cost more than the overlap returns; kept, off
+// `to` waits for everything enqueued on `from` so far
+static int edge(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+  if (from == to) return RSDET_OK;
+  if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) return RSDET_ELAUNCH;
+  return RSDET_OK;
+}
+
 #define VB_CHECK(expr)       \
   do {                       \
     const int rc_ = (expr);  \
@@ -107,6 +135,12 @@ static size_t gs_floats(const Dims& d, int ch) { return gs_direct(d, ch) ? (size
 }  // namespace
 
 extern "C" int rsdet_van_block_supported(const rsdet_van_block* b) { return supported(b) ? 1 : 0; }
+// 1: the backward's weight gradients run on a side stream beside the grad_x chain; 0 (default): everything on `stream`
+extern "C" int rsdet_van_block_side_stream(int on) {
+  const int prev = g_side_on;
+  if (on == 0 || on == 1) g_side_on = on;
+  return prev;
+}
 extern "C" size_t rsdet_van_block_saved_floats(const rsdet_van_block* b) {
   if (!supported(b)) return 0;
   Saved s;
@@ -126,8 +160,10 @@ extern "C" size_t rsdet_van_block_backward_scratch_floats(const rsdet_van_block*
   if (!supported(b)) return 0;
   const Dims d = dims(b);
   // tab (C ns 2) x 3, partials, two hidden-width maps, five block-width maps, vectors, depthwise workspaces
-  return 3 * up4((size_t)d.C * d.ns * 2) + up4(max_part(d)) + 2 * up4(d.nrp) + 5 * up4(d.ncp) + up4(gs_floats(d, d.R)) +
-         up4(gs_floats(d, d.C)) + 2 * up4(6 * (size_t)d.C) + up4(dw_ws_floats(d, d.R > d.C ? d.R : d.C));
+  // tab (C ns 2) x 3, partials x 2 (chain / side stream), two hidden-width maps, six block-width maps, vectors, depthwise
+  // workspaces x 2
+  return 3 * up4((size_t)d.C * d.ns * 2) + 2 * up4(max_part(d)) + 2 * up4(d.nrp) + 6 * up4(d.ncp) + up4(gs_floats(d, d.R)) +
+         up4(gs_floats(d, d.C)) + 2 * up4(6 * (size_t)d.C) + 2 * up4(dw_ws_floats(d, d.R > d.C ? d.R : d.C));
 }
 
 extern "C" int rsdet_van_block_forward_f32(const rsdet_van_block* b, const float* x, float* out, float* saved, float* scratch,
@@ -184,13 +220,15 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   float* tabr = a.take((size_t)C * ns * 2);
   float* tab2 = a.take((size_t)C * ns * 2);
   float* part = a.take(max_part(d));
+  float* part_s = a.take(max_part(d));
   float* gh2 = a.take(d.nrp);
   float* gh = a.take(d.nrp);
   float* G = a.take(d.ncp);
   float* ga2 = a.take(d.ncp);
   float* gug = a.take(d.ncp);
-  float* m1 = a.take(d.ncp);       // ga1, then gt1
+  float* ga1 = a.take(d.ncp);
   float* ga0 = a.take(d.ncp);
+  float* gt1 = a.take(d.ncp);
   float* gsh = a.take(gs_floats(d, R));
   float* gs1 = a.take(gs_floats(d, C));
   const bool dir_r = gs_direct(d, R), dir_c = gs_direct(d, C);
@@ -199,67 +237,75 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   float* vec1 = a.take(6 * (size_t)C);
   const size_t dw_fl = dw_ws_floats(d, R > C ? R : C);
   float* dws = a.take(dw_fl);
+  float* dws_s = a.take(dw_fl);
   const size_t dw_bytes = dw_fl * 4;
   const float cnt = (float)N * (float)P;
   const int S_cc = rsdet_van_wgrad_f32_splits(C, C, P, N), S_cr = rsdet_van_wgrad_f32_splits(C, R, P, N);
+  hipStream_t M = (hipStream_t)stream;
+  SideStream* sd = g_side_on ? side_stream() : nullptr;
+  hipStream_t S = (sd && sd->ok) ? sd->s : M;       // (no side stream: the same order on one stream)
+  hipEvent_t* ev = sd ? sd->ev : nullptr;
+  auto fork = [&](int i) { return S == M ? RSDET_OK : edge(M, S, ev[i]); };
   // ================= MLP half: out = x1 + ls2 (fc2(h3) + bf2)
-  VB_CHECK(rsdet_van_chan_reduce_f32(grad_out, nullptr, N, C, P, 0, tabg, stream));
-  VB_CHECK(rsdet_van_wgrad_f32(grad_out, s.h3, C, R, P, N, part, stream));
+  VB_CHECK(rsdet_van_chan_reduce_f32(grad_out, nullptr, N, C, P, 0, tabg, M));
+  VB_CHECK(fork(0));
+  VB_CHECK(rsdet_van_wgrad_f32(grad_out, s.h3, C, R, P, N, part_s, S));                                          // side
   {
-    rsdet_van_rows_fold f{part, b->ls2, b->wf2, tabg, b->bf2, nullptr, nullptr, nullptr, g.wf2, g.bf2, g.ls2, S_cr, C, R, ns, 2, 0};
-    VB_CHECK(rsdet_van_fold_rows_f32(&f, stream));
+    rsdet_van_rows_fold f{part_s, b->ls2, b->wf2, tabg, b->bf2, nullptr, nullptr, nullptr, g.wf2, g.bf2, g.ls2, S_cr, C, R, ns, 2, 0};
+    VB_CHECK(rsdet_van_fold_rows_f32(&f, S));                                                                    // side
   }
-  VB_CHECK(rsdet_van_gemm_f32(s.w5t, grad_out, R, C, P, N, 6, nullptr, nullptr, nullptr, nullptr, s.d3, nullptr, gh2, nullptr,
-                              stream));
+  VB_CHECK(rsdet_van_gemm_f32(s.w5t, grad_out, R, C, P, N, 6, nullptr, nullptr, nullptr, nullptr, s.d3, nullptr, gh2, nullptr, M));
+  VB_CHECK(fork(1));
+  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(gh2, s.h, nullptr, N, R, H, W, 3, 1, g.wd3, g.bd3, dws_s, dw_bytes, S));  // side
   if (dir_r)
-    VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, nullptr, gsh, (size_t)R * ns_r * 4, stream));
+    VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, nullptr, gsh, (size_t)R * ns_r * 4, M));
   else
-    VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, gsh, dws, dw_bytes, stream));
-  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(gh2, s.h, nullptr, N, R, H, W, 3, 1, g.wd3, g.bd3, dws, dw_bytes, stream));
-  VB_CHECK(rsdet_van_wgrad_f32(s.x1, gh, C, R, P, N, part, stream));
+    VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, gsh, dws, dw_bytes, M));
+  VB_CHECK(rsdet_van_wgrad_f32(s.x1, gh, C, R, P, N, part, M));
   {
     rsdet_van_bn_fold f{part, s.w4t, gsh, nullptr, nullptr, s.st2, s.st2 + C, s.st2 + 2 * C, s.st2 + 3 * C, g.wf1, g.bf1,
                         g.g2, g.be2, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, S_cr, C, R, ns_r, 1, 0, cnt};
-    VB_CHECK(rsdet_van_fold_bn_f32(&f, stream));
+    VB_CHECK(rsdet_van_fold_bn_f32(&f, M));
   }
-  VB_CHECK(rsdet_van_gemm_f32(s.w4t, gh, C, R, P, N, 4, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, grad_out, s.x1, G, nullptr,
-                              stream));
+  VB_CHECK(rsdet_van_gemm_f32(s.w4t, gh, C, R, P, N, 4, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, grad_out, s.x1, G, nullptr, M));
   // ================= attention half: x1 = x + ls1 (proj_2(gt) + bp2 + xn)
-  VB_CHECK(rsdet_van_chan_reduce_f32(G, x, N, C, P, 0, tabr, stream));
-  VB_CHECK(rsdet_van_wgrad_f32(G, s.gt, C, C, P, N, part, stream));
+  VB_CHECK(rsdet_van_chan_reduce_f32(G, x, N, C, P, 0, tabr, M));
+  VB_CHECK(fork(2));
+  VB_CHECK(rsdet_van_wgrad_f32(G, s.gt, C, C, P, N, part_s, S));                                                 // side
   {
-    rsdet_van_rows_fold f{part, b->ls1, b->wp2, tabr, b->bp2, tabr, s.st1 + 2 * C, s.st1 + 3 * C, g.wp2, g.bp2, g.ls1,
+    rsdet_van_rows_fold f{part_s, b->ls1, b->wp2, tabr, b->bp2, tabr, s.st1 + 2 * C, s.st1 + 3 * C, g.wp2, g.bp2, g.ls1,
                           S_cc, C, C, ns, 2, ns};
-    VB_CHECK(rsdet_van_fold_rows_f32(&f, stream));
+    VB_CHECK(rsdet_van_fold_rows_f32(&f, S));                                                                    // side
   }
-  VB_CHECK(rsdet_van_gemm_f32(s.w3t, G, C, C, P, N, 5, nullptr, nullptr, nullptr, nullptr, s.u, s.a2, ga2, gug, stream));
-  VB_CHECK(rsdet_van_chan_reduce_f32(ga2, nullptr, N, C, P, 0, tab2, stream));
-  VB_CHECK(rsdet_van_wgrad_f32(ga2, s.a1, C, C, P, N, part, stream));
+  VB_CHECK(rsdet_van_gemm_f32(s.w3t, G, C, C, P, N, 5, nullptr, nullptr, nullptr, nullptr, s.u, s.a2, ga2, gug, M));
+  VB_CHECK(fork(3));
+  VB_CHECK(rsdet_van_chan_reduce_f32(ga2, nullptr, N, C, P, 0, tab2, S));                                        // side
+  VB_CHECK(rsdet_van_wgrad_f32(ga2, s.a1, C, C, P, N, part_s, S));                                               // side
   {
-    rsdet_van_rows_fold f{part, nullptr, nullptr, tab2, nullptr, nullptr, nullptr, nullptr, g.wc1, g.bc1, nullptr,
+    rsdet_van_rows_fold f{part_s, nullptr, nullptr, tab2, nullptr, nullptr, nullptr, nullptr, g.wc1, g.bc1, nullptr,
                           S_cc, C, C, ns, 2, 0};
-    VB_CHECK(rsdet_van_fold_rows_f32(&f, stream));
+    VB_CHECK(rsdet_van_fold_rows_f32(&f, S));                                                                    // side
   }
-  float* ga1 = m1;
-  VB_CHECK(rsdet_van_gemm_f32(s.w2t, ga2, C, C, P, N, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ga1, nullptr,
-                              stream));
-  VB_CHECK(rsdet_dwconv2d_backward_data_f32(ga1, b->wd7, N, C, H, W, 7, 3, ga0, nullptr, nullptr, 0, stream));
-  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga1, s.a0, nullptr, N, C, H, W, 7, 3, g.wd7, g.bd7, dws, dw_bytes, stream));
-  float* gt1 = ga2;                 // (ga2 is dead: its consumers above are enqueued before this write)
+  VB_CHECK(rsdet_van_gemm_f32(s.w2t, ga2, C, C, P, N, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ga1, nullptr, M));
+  VB_CHECK(fork(4));
+  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga1, s.a0, nullptr, N, C, H, W, 7, 3, g.wd7, g.bd7, dws_s, dw_bytes, S));  // side
+  VB_CHECK(rsdet_dwconv2d_backward_data_f32(ga1, b->wd7, N, C, H, W, 7, 3, ga0, nullptr, nullptr, 0, M));
+  VB_CHECK(fork(5));
+  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga0, s.u, nullptr, N, C, H, W, 5, 1, g.wd5, g.bd5, dws_s, dw_bytes, S));   // side
   if (dir_c)
     VB_CHECK(rsdet_dwconv2d_backward_data_act_f32(ga0, b->wd5, N, C, H, W, 5, 1, gug, s.t1, gt1, nullptr, gs1,
-                                                  (size_t)C * ns_c * 4, stream));
+                                                  (size_t)C * ns_c * 4, M));
   else
-    VB_CHECK(rsdet_dwconv2d_backward_data_act_f32(ga0, b->wd5, N, C, H, W, 5, 1, gug, s.t1, gt1, gs1, dws, dw_bytes, stream));
-  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga0, s.u, nullptr, N, C, H, W, 5, 1, g.wd5, g.bd5, dws, dw_bytes, stream));
-  VB_CHECK(rsdet_van_wgrad_f32(x, gt1, C, C, P, N, part, stream));
+    VB_CHECK(rsdet_dwconv2d_backward_data_act_f32(ga0, b->wd5, N, C, H, W, 5, 1, gug, s.t1, gt1, gs1, dws, dw_bytes, M));
+  VB_CHECK(rsdet_van_wgrad_f32(x, gt1, C, C, P, N, part, M));
   {
     rsdet_van_bn_fold f{part, s.w1t, gs1, tabr, b->ls1, s.st1, s.st1 + C, s.st1 + 2 * C, s.st1 + 3 * C, g.wp1, g.bp1,
                         g.g1, g.be1, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, S_cc, C, C, ns_c, 1, ns, cnt};
-    VB_CHECK(rsdet_van_fold_bn_f32(&f, stream));
+    VB_CHECK(rsdet_van_fold_bn_f32(&f, M));
   }
   if (grad_x)
-    VB_CHECK(rsdet_van_gemm_f32(s.w1t, gt1, C, C, P, N, 4, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, G, x, grad_x, nullptr,
-                                stream));
+    VB_CHECK(rsdet_van_gemm_f32(s.w1t, gt1, C, C, P, N, 4, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, G, x, grad_x, nullptr, M));
+  // the caller's stream owns every buffer again once the side stream's work is behind it
+  if (S != M) VB_CHECK(edge(S, M, ev[6]));
   return RSDET_OK;
 }

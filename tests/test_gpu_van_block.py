@@ -95,6 +95,37 @@ def test_block_node_tracks_the_per_operator_route_and_is_not_taken_where_it_does
     assert "_VanBlock" not in type(y.grad_fn).__name__
 
 
+def test_side_stream_backward_is_bit_identical_to_the_one_stream_order(cuda):
+    """The backward's off-chain work (weight gradients, folds, depthwise weight gradients) on a side stream: the same
+    kernels on the same operands -- every gradient bit-equal to the one-stream order, over repeated steps (a missing
+    cross-stream edge would show as a race sooner or later)."""
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    blk = _block(cuda, 320, 4, 11)
+    x = torch.randn(2, 320, 32, 32, device=cuda)
+    go = torch.randn(2, 320, 32, 32, device=cuda)
+    res = {}
+    prev = lib.rsdet_van_block_side_stream(-1)
+    try:
+        for on in (0, 1):
+            lib.rsdet_van_block_side_stream(on)
+            outs = []
+            for it in range(6):
+                b2 = copy.deepcopy(blk)
+                xi = x.clone().requires_grad_(True)
+                y = b2(xi)
+                assert "_VanBlock" in type(y.grad_fn).__name__
+                y.backward(go)
+                outs.append([xi.grad.clone()] + [p.grad.clone() for p in b2.parameters()])
+            torch.cuda.synchronize()
+            for o in outs[1:]:
+                assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+            res[on] = outs[0]
+    finally:
+        lib.rsdet_van_block_side_stream(prev)
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+
+
 @pytest.mark.parametrize("M,Nn,P,n", [(64, 64, 4096, 2), (320, 1280, 256, 2), (128, 1024, 512, 1), (512, 512, 128, 3)])
 def test_wgrad_and_folds_through_the_c_abi(cuda, M, Nn, P, n):
     """rsdet_van_wgrad_f32 + rsdet_van_fold_rows_f32 against float64 einsum; the row dots, bias and scale gradients."""
