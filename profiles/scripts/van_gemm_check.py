@@ -76,6 +76,9 @@ for M, K, P in shapes:
     errs.append(max(float((o0 - ref * s0.double()).abs().max()), float((o1 - ref * s1.double()).abs().max())) / scale / 4)
     o0, _ = gemm(w, x, 6, s=(s0, None))
     errs.append(float((o0 - ref * s0.double()).abs().max()) / scale / 4)
+    o_f32, _ = gemm(w, x)
+    denom = float((w.double().abs() @ x.double().abs()).max())          # sum |a_k b_k|: what the error bound is relative to
+    e_f32 = float((o_f32 - ref).abs().max()) / denom
     us = t_us(lambda: gemm(w, x))
     us2 = t_us(lambda: gemm(w, x, 2, (v[0], None, None, None), two=True))
     us4 = t_us(lambda: gemm(w, x, 4, v, (s0, s1)))
@@ -86,6 +89,7 @@ for M, K, P in shapes:
     tot_own += us
     tot_lib += us_lib
     print("M %4d K %4d P %5d: max err / scale %.1e | plain %6.1f us (%5.1f TF/s, %.2f of 157.3)  gelu2 %6.1f  affine %6.1f | "
-          "MIOpen conv2d %6.1f us" % (M, K, P, max(errs), us, fl / us / 1e6, fl / us / 1e6 / 157.3, us2, us4, us_lib))
+          "MIOpen conv2d %6.1f us | max |err| / sum|ab| %.1e" % (M, K, P, max(errs), us, fl / us / 1e6, fl / us / 1e6 / 157.3, us2, us4,
+                                                                    us_lib, e_f32))
     assert max(errs) < 1e-5, errs
 print("sum over the 12 shapes: own %.1f us, library %.1f us" % (tot_own, tot_lib))
