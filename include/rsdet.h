@@ -546,6 +546,49 @@ int rsdet_van_block_forward_f32(const rsdet_van_block* b, const float* x, float*
                                 void* stream);
 int rsdet_van_block_backward_f32(const rsdet_van_block* b, const float* x, const float* grad_out, const float* saved,
                                  float* scratch, float* grad_x, float* grads, void* stream);
+
+/* ---- a20  the control path of the Oriented R-CNN heads (csrc/orpn.hip) ------------------------
+ * RandomSampler on masks.  Replaces models/boxes/sampler.py:57-111 (BaseSampler.sample) + :132-180 (RandomSampler: a uniform
+ * subset of min(#pos, num_pos) positives, then of the negatives up to `num`, neg_pos_ub honoured) in the fixed-size form of
+ * the train step: "the k candidates with the largest draws" of one uniform draw per candidate (pri, float or double) -- a
+ * uniform k-subset -- by an exact radix select, ties to the lower index.  Candidate i < k_gt is ground truth i (add_gt_as_
+ * proposals: its gt index is i + 1); candidate k_gt + j is row j of gt_inds (n_props, int32: > 0 positive, 0 negative, < 0
+ * neither), masked by valid (n_props uint8, NULL: all).  Outputs, `num` rows each (num <= 1024): inds (int64, into the
+ * gt-extended list: positives in ascending order, then negatives in ascending order, unused slots 0), is_pos / val (uint8),
+ * assigned (int64: the gt row of a positive, 0 elsewhere), counts (2 x int64: #pos, #neg).  No host synchronisation.
+ * ws: rsdet_sample_masked_ws_size(num) bytes, 16-byte aligned. */
+size_t rsdet_sample_masked_ws_size(int num);
+int rsdet_sample_masked(const int32_t* gt_inds, const uint8_t* valid, int n_props, int k_gt, const void* pri, int pri_f64,
+                        int num, int num_pos, float neg_pos_ub, int64_t* inds, uint8_t* is_pos, uint8_t* val,
+                        int64_t* assigned, int64_t* counts, void* ws, size_t ws_bytes, void* stream);
+/* MidpointOffsetCoder.decode (models/boxes/coder.py:372-433) with rectpoly2obb + regular_obb (ops/bbox_transforms.py:
+ * 507-548): anchors (n, 4) hbb + deltas (n, 6) -> out (n, 5) obb, w >= h, theta in [-pi/2, pi/2).  means / stds: 6 host
+ * floats (NULL: 0 / 1); max_ratio = |log(wh_ratio_clip)|.  obb2hbb: ops/bbox_transforms.py:572-578, (n, 5) -> (n, 4). */
+int rsdet_midpoint_offset_decode_f32(const float* anchors, const float* deltas, int n, const float* means, const float* stds,
+                                     float max_ratio, float* out, void* stream);
+int rsdet_obb2hbb_f32(const float* obb, int n, float* out, void* stream);
+/* The proposals of a batch.  Replaces models/roi_heads/oriented_rpn_head.py:135-222 (_get_bboxes_single per image: per level
+ * the nms_pre best scores in stable order, decode, boxes not larger than min_size dropped, one horizontal NMS over all
+ * levels with a per-level coordinate offset, the first nms_post survivors) for all images at once, in the fixed-size form
+ * of the train step: out (n_img, nms_post, 6) = (x, y, w, h, theta, score) rows in the reference's order with zero rows
+ * behind the last proposal, flags (n_img, nms_post) uint8 = which rows are proposals.  score[l]: the SIGMOID of the
+ * classification map of level l laid out PIXEL-MAJOR, (n_img, H_l, W_l, A) -- the reference's flattening, whose index breaks
+ * ties; reg[l]: (n_img, 6 A, H_l, W_l); anchors[l]: (H_l W_l A, 4) in the
+ * reference's flattening (pixel-major); hw[l] = H_l W_l.  Supported: <= 7 levels, A hw[l] < 2^21, nms_pre <= 2048,
+ * sum_l min(nms_pre, A hw[l]) <= 16384.  ws: rsdet_orpn_proposals_ws_size bytes, 16-byte aligned. */
+typedef struct rsdet_orpn_levels {
+  int n_img, n_levels, A, nms_pre, nms_post;
+  float nms_thr, min_size, max_ratio;
+  float means[6], stds[6];
+  int hw[8];
+  const float* score[8];
+  const float* reg[8];
+  const float* anchors[8];
+} rsdet_orpn_levels;
+int rsdet_orpn_proposals_supported(const rsdet_orpn_levels* d);
+int rsdet_orpn_proposals_n(const rsdet_orpn_levels* d); /* rows that enter the NMS per image */
+size_t rsdet_orpn_proposals_ws_size(const rsdet_orpn_levels* d);
+int rsdet_orpn_proposals_f32(const rsdet_orpn_levels* d, float* out, uint8_t* flags, void* ws, size_t ws_bytes, void* stream);
 /* The prepared weight operands of the backward (ops/weight_prep.py) refreshed by one launch: entries = n 64-byte records
  * in DEVICE memory {src, dst, var, gamma (pointers), O, C, T, eps (float), tile0, tiles_c, tiles_o, pad}: dst (C, T, O) =
  * src (O, T, C) with the taps reversed and row o scaled by gamma[o] / sqrt(var[o] + eps) (var NULL: copied).  tile0

@@ -119,6 +119,17 @@ def main():
         n += 1
         if n >= args.top:
             break
+    # the same launches by Python frame (library + torch kernels only): where a fused kernel would remove the most launches
+    by = collections.defaultdict(lambda: [0, 0.0])
+    for (short, op, frame), (cnt, dur) in rows:
+        if "rsdet::" in short:
+            continue
+        key = frame if frame != "?" else op.split(" > ")[0]
+        by[key][0] += cnt
+        by[key][1] += dur
+    print("\ncalls/step   us/step  python frame (or autograd node) -- kernels that are not rsdet::")
+    for key, (cnt, dur) in sorted(by.items(), key=lambda kv: -kv[1][0])[:60]:
+        print("%8.1f %9.1f  %s" % (cnt / args.steps, dur / args.steps, key))
 
 
 if __name__ == "__main__":

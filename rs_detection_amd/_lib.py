@@ -53,6 +53,14 @@ class VanRowsFold(ctypes.Structure):
                 + [(n, c_int) for n in ("S", "M", "N", "gs_ns", "gs_stride", "r_ns")])
 
 
+class OrpnLevels(ctypes.Structure):
+    """struct rsdet_orpn_levels (include/rsdet.h)."""
+    _fields_ = ([(n, c_int) for n in ("n_img", "n_levels", "A", "nms_pre", "nms_post")]
+                + [(n, c_float) for n in ("nms_thr", "min_size", "max_ratio")]
+                + [("means", c_float * 6), ("stds", c_float * 6), ("hw", c_int * 8), ("score", c_void_p * 8),
+                   ("reg", c_void_p * 8), ("anchors", c_void_p * 8)])
+
+
 # name -> (restype, argtypes); must list every symbol include/rsdet.h declares.
 SIGNATURES = {
     "rsdet_abi_version": (c_int, []),
@@ -99,6 +107,15 @@ SIGNATURES = {
                                                c_int, c_void_p, c_void_p, c_void_p]),
     "rsdet_dwconv2d_backward_data_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_sample_masked_ws_size": (c_size_t, [c_int]),
+    "rsdet_sample_masked": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_midpoint_offset_decode_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "rsdet_obb2hbb_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "rsdet_orpn_proposals_supported": (c_int, [c_void_p]),
+    "rsdet_orpn_proposals_n": (c_int, [c_void_p]),
+    "rsdet_orpn_proposals_ws_size": (c_size_t, [c_void_p]),
+    "rsdet_orpn_proposals_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_van_block_supported": (c_int, [c_void_p]),
     "rsdet_van_block_side_stream": (c_int, [c_int]),
     "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),

@@ -1,0 +1,887 @@
+// orpn.hip -- the control path of the Oriented R-CNN heads as a handful of launches.
+//
+// Reference: /root/reference/python/jdet/models/roi_heads/oriented_rpn_head.py:135-222 (_get_bboxes_single: per-level
+// top-nms_pre, MidpointOffsetCoder.decode, min-size filter, per-level offset, horizontal NMS, first nms_post),
+// models/boxes/coder.py:372-433 (MidpointOffsetCoder.decode), ops/bbox_transforms.py:501-671 (rectpoly2obb, obb2hbb,
+// regular_obb, regular_theta), models/boxes/sampler.py:57-180 (RandomSampler: a uniform k-subset of the positives, then of
+// the negatives).  As tensor operations those are ~280 launches per image for the proposals and ~70 per sampler call, all
+// a few microseconds of work each: 1 400 launches and 7 ms of a 60 ms Oriented R-CNN / VAN-B3 step.
+//
+// Both need "the k largest of n" with n up to ~1e6 and k <= 2 000, with the tie order of a STABLE sort (equal values: lower
+// index first).  That is an exact RADIX SELECT here, not a sort:
+//   * P passes over the n keys (3 for 32-bit keys, 6 for 64-bit), many workgroups each: pass p histograms digit p (11 bits
+//     from the top) of the keys whose higher digits equal the digits chosen so far, in LDS (wave-aggregated: the two most
+//     frequent digits of a wave cost one atomic each -- scores and uniform draws both put most keys of a wave in one bin),
+//     then adds its non-empty bins to the pass's global histogram;
+//   * no pass leaves state behind except its histogram: every workgroup of pass p + 1 re-derives the digits chosen by
+//     passes 0..p from those histograms (a 2 048-bin suffix search each), so there is no "last workgroup" protocol, no
+//     fence and no single-workgroup launch between passes -- the kernel boundary is the only ordering used;
+//   * an emit pass appends every key above the threshold to a list (exactly k - need of them) and the keys EQUAL to it to a
+//     tie list; the consumer takes the `need` lowest-indexed ties (by rank counting in LDS; when the tie list overflowed --
+//     a degenerate input such as all scores equal -- by an ordered scan of the input, slow and exact).
+// The consumers: sampler_final (both index lists in ascending order, the reference's `.unique()` order) and
+// orpn_sort_decode (one workgroup per image: decode, min-size mask, extent of the real boxes, a bitonic sort of <= 16 384
+// 64-bit keys in 128 KB of LDS, sorted boxes for the NMS) + orpn_finish (keep flags -> the first nms_post rows).
+#include <stdint.h>
+
+#include "rsdet_api_internal.h"
+
+namespace rsdet {
+
+typedef unsigned long long u64;
+
+constexpr int SEL_T = 256;         // threads per workgroup of the counting / emitting passes
+constexpr int SEL_CHUNK = 8192;    // keys per workgroup
+constexpr int SEL_BINS = 2048;     // 11-bit digits
+constexpr int SEL_TIE_CAP = 2048;  // ties kept per class before the ordered-scan fallback
+constexpr int SEL_MAXP = 6;
+
+template <class K>
+struct SelKey;
+template <>
+struct SelKey<unsigned> {
+  static constexpr int BITS = 32, P = 3;
+};
+template <>
+struct SelKey<u64> {
+  static constexpr int BITS = 64, P = 6;
+};
+template <class K>
+__device__ __forceinline__ int sel_shift(int p) {
+  const int s = SelKey<K>::BITS - 11 * (p + 1);
+  return s < 0 ? 0 : s;
+}
+template <class K>
+__device__ __forceinline__ int sel_width(int p) {
+  return p == SelKey<K>::P - 1 ? SelKey<K>::BITS - 11 * (SelKey<K>::P - 1) : 11;
+}
+template <class K>
+__device__ __forceinline__ unsigned sel_digit(K key, int p) {
+  return (unsigned)(key >> sel_shift<K>(p)) & ((1u << sel_width<K>(p)) - 1u);
+}
+// order-preserving integer images of the floating-point values
+__device__ __forceinline__ unsigned sel_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ u64 sel_key(double v) {
+  const u64 u = (u64)__double_as_longlong(v);
+  return u ^ ((u >> 63) ? ~0ull : (1ull << 63));
+}
+
+// per job; all zero on entry (the entry point's memset)
+template <int NC>
+struct SelWs {
+  unsigned hist[SEL_MAXP][NC][SEL_BINS];
+  unsigned fill[NC][2];  // emitted: [c][0] keys above the threshold, [c][1] keys equal to it
+  // left by workgroup 0 of the emit pass for the consumer:
+  u64 thr[NC];
+  unsigned need[NC], all[NC], total[NC];
+};
+
+struct SelPick {
+  u64 prefix;          // the digits chosen so far (key >> shift of the last chosen digit)
+  unsigned remaining;  // how many keys are still to be taken from those that match the prefix
+  unsigned all;        // the class has fewer than k members: every one is taken
+};
+
+// One suffix search over a 2 048-bin histogram by the whole workgroup (T threads, T | 2048): the highest bin b with
+// sum_{j >= b} hist[j] >= r.  -> bin, above = sum_{j > b}, total = sum of all bins; found = 0 when total < r.
+template <int T>
+__device__ __forceinline__ void sel_pick_bin(const unsigned* __restrict__ hist, unsigned r, unsigned* s_scr, unsigned& bin,
+                                             unsigned& above, unsigned& total, unsigned& found) {
+  constexpr int BPT = SEL_BINS / T, NW = T / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned h[BPT], v = 0;
+#pragma unroll
+  for (int j = 0; j < BPT; ++j) {
+    h[j] = hist[tid * BPT + j];
+    v += h[j];
+  }
+  unsigned x = v;  // inclusive suffix sum inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_down(x, off);
+    if (lane + off < 64) x += t;
+  }
+  __syncthreads();  // (s_scr may still be read from the previous call)
+  if (lane == 0) s_scr[wave] = x;
+  if (tid == 0) s_scr[NW + 2] = 0u;
+  __syncthreads();
+  unsigned hi = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const unsigned t = s_scr[w];
+    all += t;
+    if (w > wave) hi += t;
+  }
+  const unsigned incl = x + hi, excl = incl - v;
+  if (r >= 1u && excl < r && incl >= r) {
+    unsigned acc = excl;
+#pragma unroll
+    for (int j = BPT - 1; j >= 0; --j) {
+      if (acc < r && acc + h[j] >= r) {
+        s_scr[NW] = (unsigned)(tid * BPT + j);
+        s_scr[NW + 1] = acc;
+        s_scr[NW + 2] = 1u;
+      }
+      acc += h[j];
+    }
+  }
+  __syncthreads();
+  bin = s_scr[NW];
+  above = s_scr[NW + 1];
+  found = s_scr[NW + 2];
+  total = all;
+}
+
+// The digits chosen by passes 0 .. done-1, re-derived from their histograms by every workgroup that needs them.
+template <class K, int NC, int T, class Plan>
+__device__ __forceinline__ void sel_resolve(const SelWs<NC>* __restrict__ ws, int done, const Plan& plan, int job,
+                                            unsigned* s_scr, SelPick* pick, unsigned* total) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    pick[c].prefix = 0;
+    pick[c].remaining = 0;
+    pick[c].all = 0;
+    total[c] = 0;
+  }
+  for (int p = 0; p < done; ++p) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (p > 0 && pick[c].all) continue;
+      const unsigned r = p == 0 ? plan.k(job, c, total) : pick[c].remaining;
+      unsigned bin, above, tot, found;
+      sel_pick_bin<T>(ws->hist[p][c], r, s_scr, bin, above, tot, found);
+      if (p == 0) total[c] = tot;
+      if (r == 0u) {  // nothing wanted: a threshold no key exceeds, no ties taken
+        pick[c].prefix = (pick[c].prefix << sel_width<K>(p)) | ((1u << sel_width<K>(p)) - 1u);
+        pick[c].remaining = 0;
+      } else if (!found) {
+        pick[c].all = 1;  // (only at p == 0: fewer members than k)
+      } else {
+        pick[c].prefix = (pick[c].prefix << sel_width<K>(p)) | bin;
+        pick[c].remaining = r - above;
+      }
+    }
+  }
+}
+
+// one wave's keys into the LDS histogram: the wave's two most frequent digits cost one atomic each
+__device__ __forceinline__ void sel_count(unsigned* hist, bool active, unsigned digit) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const u64 m = __ballot(active);
+    if (!m) return;
+    const int lead = __ffsll((long long)m) - 1;
+    const unsigned d0 = __shfl(digit, lead);
+    const u64 same = __ballot(active && digit == d0);
+    if ((int)(threadIdx.x & 63) == lead) atomicAdd(hist + d0, (unsigned)__popcll(same));
+    active = active && digit != d0;
+  }
+  if (active) atomicAdd(hist + digit, 1u);
+}
+
+template <class K, int NC, class Src, class Plan>
+__global__ __launch_bounds__(SEL_T) void sel_hist_kernel(Src src, Plan plan, SelWs<NC>* __restrict__ wsb, int pass) {
+  const int job = blockIdx.y, n = src.count(job), tid = threadIdx.x;
+  const long long base = (long long)blockIdx.x * SEL_CHUNK;
+  if (base >= n) return;
+  SelWs<NC>* ws = wsb + job;
+  __shared__ unsigned s_hist[NC][SEL_BINS];
+  __shared__ unsigned s_scr[SEL_T / 64 + 4];
+  SelPick pick[NC];
+  unsigned total[NC];
+  sel_resolve<K, NC, SEL_T>(ws, pass, plan, job, s_scr, pick, total);
+  for (int i = tid; i < NC * SEL_BINS; i += SEL_T) (&s_hist[0][0])[i] = 0u;
+  __syncthreads();
+  const int end = (int)(base + SEL_CHUNK < n ? base + SEL_CHUNK : n);
+  for (int i0 = (int)base; i0 < end; i0 += SEL_T) {  // (whole waves stay in the loop: sel_count ballots)
+    const int i = i0 + tid;
+    int cls = -1;
+    K key = 0;
+    if (i < end) src.load(job, i, cls, key);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool act = cls == c && !pick[c].all && (pass == 0 || (key >> sel_shift<K>(pass - 1)) == (K)pick[c].prefix);
+      sel_count(s_hist[c], act, sel_digit<K>(key, pass));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NC * SEL_BINS; i += SEL_T) {
+    const unsigned v = (&s_hist[0][0])[i];
+    if (v) atomicAdd(&ws->hist[pass][0][0] + i, v);
+  }
+}
+
+template <class K, int NC, class Src, class Plan>
+__global__ __launch_bounds__(SEL_T) void sel_emit_kernel(Src src, Plan plan, SelWs<NC>* __restrict__ wsb,
+                                                         u64* __restrict__ above, int cap, unsigned* __restrict__ ties) {
+  const int job = blockIdx.y, n = src.count(job), tid = threadIdx.x, lane = tid & 63;
+  const long long base = (long long)blockIdx.x * SEL_CHUNK;
+  if (base >= n) return;
+  SelWs<NC>* ws = wsb + job;
+  __shared__ unsigned s_scr[SEL_T / 64 + 4];
+  SelPick pick[NC];
+  unsigned total[NC];
+  sel_resolve<K, NC, SEL_T>(ws, SelKey<K>::P, plan, job, s_scr, pick, total);
+  if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      ws->thr[c] = pick[c].prefix;
+      ws->need[c] = pick[c].all ? 0u : pick[c].remaining;
+      ws->all[c] = pick[c].all;
+      ws->total[c] = total[c];
+    }
+  }
+  const int end = (int)(base + SEL_CHUNK < n ? base + SEL_CHUNK : n);
+  const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  for (int i0 = (int)base; i0 < end; i0 += SEL_T) {
+    const int i = i0 + tid;
+    int cls = -1;
+    K key = 0;
+    if (i < end) src.load(job, i, cls, key);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool mine = cls == c;
+      const bool up = mine && (pick[c].all || key > (K)pick[c].prefix);
+      const bool eq = mine && !pick[c].all && key == (K)pick[c].prefix;
+      const u64 mu = __ballot(up), me = __ballot(eq);
+      if (mu) {
+        unsigned b = 0;
+        if (lane == 0) b = atomicAdd(&ws->fill[c][0], (unsigned)__popcll(mu));
+        b = __shfl(b, 0) + (unsigned)__popcll(mu & lt);
+        if (up && b < (unsigned)cap) above[((long long)job * NC + c) * cap + b] = ((u64)(unsigned)key << 32) | (unsigned)i;
+      }
+      if (me) {
+        unsigned b = 0;
+        if (lane == 0) b = atomicAdd(&ws->fill[c][1], (unsigned)__popcll(me));
+        b = __shfl(b, 0) + (unsigned)__popcll(me & lt);
+        if (eq && b < (unsigned)SEL_TIE_CAP) ties[((long long)job * NC + c) * SEL_TIE_CAP + b] = (unsigned)i;
+      }
+    }
+  }
+}
+
+// The `need` lowest-indexed keys equal to the threshold of class c, written to dst[0 .. need) in ASCENDING index order;
+// the whole workgroup (T threads) calls it.  ties: the emit pass's list (n_ties entries were seen, at most SEL_TIE_CAP
+// stored); when it overflowed, the input itself is scanned in index order.
+template <class K, int NC, int T, class Src>
+__device__ __forceinline__ void sel_take_ties(const Src& src, int job, int c, K thr, unsigned need, unsigned n_ties,
+                                              const unsigned* __restrict__ ties, unsigned* s_tie, unsigned* s_w,
+                                              unsigned* dst) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (need == 0u) return;
+  if (n_ties <= (unsigned)SEL_TIE_CAP) {
+    __syncthreads();
+    for (unsigned t = tid; t < n_ties; t += T) s_tie[t] = ties[t];
+    __syncthreads();
+    for (unsigned t = tid; t < n_ties; t += T) {
+      const unsigned me = s_tie[t];
+      unsigned rank = 0;
+      for (unsigned u = 0; u < n_ties; ++u) rank += s_tie[u] < me ? 1u : 0u;
+      if (rank < need) dst[rank] = me;
+    }
+    __syncthreads();
+    return;
+  }
+  const int n = src.count(job);
+  const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  unsigned base = 0;
+  for (int i0 = 0; i0 < n && base < need; i0 += T) {
+    const int i = i0 + tid;
+    int cls = -1;
+    K key = 0;
+    if (i < n) src.load(job, i, cls, key);
+    const bool eq = cls == c && key == thr;
+    const u64 m = __ballot(eq);
+    __syncthreads();
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned off = 0, tot = 0;
+    for (int w = 0; w < T / 64; ++w) {
+      const unsigned t = s_w[w];
+      tot += t;
+      if (w < wave) off += t;
+    }
+    const unsigned r = base + off + (unsigned)__popcll(m & lt);
+    if (eq && r < need) dst[r] = (unsigned)i;
+    base += tot;
+  }
+  __syncthreads();
+}
+
+// in-place bitonic sort of NP (a power of two) values in LDS by T threads; DESC: descending
+template <class V, int T, bool DESC>
+__device__ __forceinline__ void lds_bitonic(V* s, int NP) {
+  const int tid = threadIdx.x;
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (NP >> 1); t += T) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const V a = s[i], b = s[l];
+        const bool up = ((i & k) == 0) != DESC;
+        if ((a > b) == up) {
+          s[i] = b;
+          s[l] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ============================ RandomSampler on masks (sampler.py:57-180) ============================================
+struct SamplerSrc {
+  const int* gt_inds;          // (n_props) assigned gt index + 1, 0 = negative, -1 = ignore
+  const unsigned char* valid;  // (n_props) or NULL: rows that are padding are neither positive nor negative
+  const void* pri;             // (k_gt + n_props) one draw per candidate, float or double
+  int k_gt, n, f64;
+  __device__ __forceinline__ int count(int) const { return n; }
+  __device__ __forceinline__ int gt_of(int i) const {
+    if (i < k_gt) return i + 1;
+    return (valid == nullptr || valid[i - k_gt]) ? gt_inds[i - k_gt] : -1;
+  }
+  __device__ __forceinline__ void load(int, int i, int& cls, unsigned& key) const {
+    const int g = gt_of(i);
+    cls = g > 0 ? 0 : (g == 0 ? 1 : -1);
+    key = sel_key(static_cast<const float*>(pri)[i]);
+  }
+  __device__ __forceinline__ void load(int, int i, int& cls, u64& key) const {
+    const int g = gt_of(i);
+    cls = g > 0 ? 0 : (g == 0 ? 1 : -1);
+    key = sel_key(static_cast<const double*>(pri)[i]);
+  }
+};
+
+struct SamplerPlan {
+  int kp, kn, num;  // kp = min(int(num * pos_fraction), n), kn = min(num, n)
+  float ub;         // neg_pos_ub (< 0: none)
+  __device__ __forceinline__ unsigned k(int, int c, const unsigned* total) const {
+    if (c == 0) return (unsigned)kp;
+    const unsigned npos = total[0] < (unsigned)kp ? total[0] : (unsigned)kp;
+    long long quota = (long long)num - (long long)npos;
+    if (ub >= 0.f) {
+      const long long q2 = (long long)(ub * (float)(npos ? npos : 1u));
+      quota = quota < q2 ? quota : q2;
+    }
+    if (quota < 0) quota = 0;
+    if (quota > kn) quota = kn;
+    return (unsigned)quota;
+  }
+};
+
+template <class K>
+__global__ __launch_bounds__(1024) void sampler_final_kernel(SamplerSrc src, const SelWs<2>* __restrict__ ws,
+                                                             const u64* __restrict__ above, const unsigned* __restrict__ ties,
+                                                             int cap, int num, long long* __restrict__ inds,
+                                                             unsigned char* __restrict__ is_pos, unsigned char* __restrict__ val,
+                                                             long long* __restrict__ assigned, long long* __restrict__ counts) {
+  constexpr int T = 1024;
+  __shared__ unsigned s_list[2][1024];
+  __shared__ unsigned s_tie[SEL_TIE_CAP];
+  __shared__ unsigned s_w[T / 64];
+  const int tid = threadIdx.x;
+  unsigned cnt[2];
+  for (int c = 0; c < 2; ++c) {
+    s_list[c][tid] = 0xFFFFFFFFu;
+    __syncthreads();
+    const unsigned na = ws->fill[c][0] < (unsigned)cap ? ws->fill[c][0] : (unsigned)cap;
+    const unsigned need = ws->need[c], nt = ws->fill[c][1];
+    if ((unsigned)tid < na) s_list[c][tid] = (unsigned)above[(long long)c * cap + tid];
+    sel_take_ties<K, 2, T>(src, 0, c, (K)ws->thr[c], need, nt, ties + (long long)c * SEL_TIE_CAP, s_tie, s_w,
+                           s_list[c] + na);
+    cnt[c] = na + need;
+    lds_bitonic<unsigned, T, false>(s_list[c], 1024);
+  }
+  const unsigned np = cnt[0], nn = cnt[1];
+  if (tid < num) {
+    const unsigned s = (unsigned)tid;
+    unsigned idx = 0;
+    unsigned char p = 0, v = 0;
+    if (s < np) {
+      idx = s_list[0][s];
+      p = v = 1;
+    } else if (s < np + nn) {
+      idx = s_list[1][s - np];
+      v = 1;
+    }
+    inds[s] = (long long)idx;
+    is_pos[s] = p;
+    val[s] = v;
+    const int g = src.gt_of((int)idx) - 1;
+    assigned[s] = g > 0 ? (long long)g : 0ll;
+  }
+  if (tid == 0) {
+    counts[0] = (long long)np;
+    counts[1] = (long long)nn;
+  }
+}
+
+// ============================ Oriented RPN proposals (oriented_rpn_head.py:135-222) =================================
+struct F6 {
+  float v[6];
+};
+
+// regular_theta(t) = remainder(t + pi/2, pi) - pi/2 with Python-style remainder (bbox_transforms.py:501-505)
+__device__ __forceinline__ float orpn_regular_theta(float t) {
+  const float half_pi = 1.57079632679489661923f, pi = 3.14159265358979323846f;
+  const float x = t + half_pi;  // (theta - start, start = -pi/2)
+  float r = fmodf(x, pi);
+  if (r != 0.f && r < 0.f) r += pi;
+  return r + (-half_pi);
+}
+
+// MidpointOffsetCoder.decode for one anchor (coder.py:372-433) followed by rectpoly2obb + regular_obb
+// (bbox_transforms.py:525-548, :507-514): hbb anchor a (x1, y1, x2, y2) + 6 deltas -> obb (x, y, w, h, theta), w >= h.
+__device__ __forceinline__ void orpn_decode(const float* a, const float* dl, const F6& mean, const F6& stdv, float max_ratio,
+                                            float* o) {
+  float d[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = dl[k] * stdv.v[k] + mean.v[k];
+  const float dx = d[0], dy = d[1];
+  const float dw = fminf(fmaxf(d[2], -max_ratio), max_ratio), dh = fminf(fmaxf(d[3], -max_ratio), max_ratio);
+  const float px = (a[0] + a[2]) * 0.5f, py = (a[1] + a[3]) * 0.5f, pw = a[2] - a[0], ph = a[3] - a[1];
+  const float gw = pw * expf(dw), gh = ph * expf(dh);
+  const float gx = px + pw * dx, gy = py + ph * dy;
+  const float x1 = gx - gw * 0.5f, y1 = gy - gh * 0.5f, x2 = gx + gw * 0.5f, y2 = gy + gh * 0.5f;
+  const float da = fminf(fmaxf(d[4], -0.5f), 0.5f), db = fminf(fmaxf(d[5], -0.5f), 0.5f);
+  const float ga = gx + da * gw, ga_ = gx - da * gw, gb = gy + db * gh, gb_ = gy - db * gh;
+  float cx[4] = {ga - gx, x2 - gx, ga_ - gx, x1 - gx}, cy[4] = {y1 - gy, gb - gy, y2 - gy, gb_ - gy};
+  float diag[4], dmax = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    diag[k] = sqrtf(cx[k] * cx[k] + cy[k] * cy[k]);
+    dmax = k == 0 ? diag[0] : fmaxf(dmax, diag[k]);
+  }
+  float qx[4], qy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float sc = dmax / diag[k];
+    qx[k] = cx[k] * sc + gx;
+    qy[k] = cy[k] * sc + gy;
+  }
+  // rectpoly2obb
+  const float theta = atan2f(-(qy[1] - qy[0]), qx[1] - qx[0]);
+  const float Cos = cosf(theta), Sin = sinf(theta);
+  const float x = (qx[0] + qx[1] + qx[2] + qx[3]) / 4.f, y = (qy[0] + qy[1] + qy[2] + qy[3]) / 4.f;
+  float r0min = 0.f, r0max = 0.f, r1min = 0.f, r1max = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float ux = qx[k] - x, uy = qy[k] - y;
+    const float r0 = ux * Cos + uy * (-Sin), r1 = ux * Sin + uy * Cos;
+    r0min = k == 0 ? r0 : fminf(r0min, r0);
+    r0max = k == 0 ? r0 : fmaxf(r0max, r0);
+    r1min = k == 0 ? r1 : fminf(r1min, r1);
+    r1max = k == 0 ? r1 : fmaxf(r1max, r1);
+  }
+  const float w = r0max - r0min, h = r1max - r1min;
+  const bool wide = w > h;
+  o[0] = x;
+  o[1] = y;
+  o[2] = wide ? w : h;
+  o[3] = wide ? h : w;
+  o[4] = orpn_regular_theta(wide ? theta : theta + 1.57079632679489661923f);
+}
+
+// obb2hbb (bbox_transforms.py:572-578)
+__device__ __forceinline__ void orpn_obb2hbb(const float* b, float* o) {
+  const float Cos = cosf(b[4]), Sin = sinf(b[4]);
+  const float bx = fabsf(b[2] / 2.f * Cos) + fabsf(b[3] / 2.f * Sin), by = fabsf(b[2] / 2.f * Sin) + fabsf(b[3] / 2.f * Cos);
+  o[0] = b[0] - bx;
+  o[1] = b[1] - by;
+  o[2] = b[0] + bx;
+  o[3] = b[1] + by;
+}
+
+__global__ void orpn_decode_kernel(const float* __restrict__ anchors, const float* __restrict__ deltas, int n, F6 mean,
+                                   F6 stdv, float max_ratio, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a[4], d[6], o[5];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] = anchors[(long long)i * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = deltas[(long long)i * 6 + k];
+  orpn_decode(a, d, mean, stdv, max_ratio, o);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) out[(long long)i * 5 + k] = o[k];
+}
+
+__global__ void orpn_obb2hbb_kernel(const float* __restrict__ obb, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float b[5], o[4];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) b[k] = obb[(long long)i * 5 + k];
+  orpn_obb2hbb(b, o);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[(long long)i * 4 + k] = o[k];
+}
+
+struct LevelSrc {  // job = image * L + level; element i of a job = pixel * A + a: the score maps lie PIXEL-MAJOR (N, H, W, A),
+                   // the reference's flattening (cls.permute(1, 2, 0).reshape(-1)), so that ties go to the lower index of THAT
+  const float* score[8];
+  int cnt[8];  // A * HW
+  int L;
+  __device__ __forceinline__ int count(int job) const { return cnt[job % L]; }
+  __device__ __forceinline__ void load(int job, int i, int& cls, unsigned& key) const {
+    const int l = job % L, b = job / L;
+    cls = 0;
+    key = sel_key(score[l][(long long)b * cnt[l] + i]);
+  }
+};
+
+struct LevelPlan {
+  int nms_pre;
+  __device__ __forceinline__ unsigned k(int, int, const unsigned*) const { return (unsigned)nms_pre; }
+};
+
+struct OrpnArgs {
+  LevelSrc src;
+  const float* reg[8];      // (N, A * 6, H, W)
+  const float* anchors[8];  // (HW * A, 4), index pixel * A + a
+  int hw[8];
+  int A, nms_pre, n_tot;
+  F6 mean, stdv;
+  float max_ratio, min_size;
+};
+
+constexpr int ORPN_NP = 16384;  // keys sorted per image (128 KB of LDS)
+
+// composite sort key: (score bits + 1 for a real box, 0 for a too-small one) : 7 - level : 0x1FFFFF - index in the level
+// (index = pixel * A + a, the reference's flattening) -- descending order of it is the reference's stable argsort of
+// where(ok, score, -1) over the level-major list.
+__device__ __forceinline__ void orpn_unpack(u64 key, int& l, int& orig) {
+  l = 7 - (int)((key >> 21) & 7u);
+  orig = 0x1FFFFF - (int)(key & 0x1FFFFFu);
+}
+
+__device__ __forceinline__ float orpn_box_at(const OrpnArgs& a, int b, int l, int orig, float* obb, float* hbb, bool& ok) {
+  const int A = a.A, hw = a.hw[l], pix = orig / A, an = orig - pix * A;
+  float av[4], d[6];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) av[k] = a.anchors[l][(long long)orig * 4 + k];
+  const float* r = a.reg[l] + ((long long)b * A * 6 + an * 6) * hw + pix;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = r[(long long)k * hw];
+  orpn_decode(av, d, a.mean, a.stdv, a.max_ratio, obb);
+  orpn_obb2hbb(obb, hbb);
+  ok = a.min_size < 0.f || (obb[2] > a.min_size && obb[3] > a.min_size);
+  return a.src.score[l][(long long)b * a.src.cnt[l] + orig];
+}
+
+__global__ __launch_bounds__(1024) void orpn_sort_decode_kernel(OrpnArgs a, const SelWs<1>* __restrict__ wsb,
+                                                                const u64* __restrict__ above,
+                                                                const unsigned* __restrict__ ties, float* __restrict__ dets,
+                                                                float* __restrict__ boxes, unsigned char* __restrict__ okf) {
+  constexpr int T = 1024;
+  extern __shared__ u64 s_key[];  // ORPN_NP
+  __shared__ unsigned s_tie[SEL_TIE_CAP];
+  __shared__ unsigned s_sel[SEL_TIE_CAP];
+  __shared__ unsigned s_w[T / 64];
+  __shared__ float s_red[2][T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, L = a.src.L;
+  // ---- 1. the selected keys of every level -> composite keys
+  int at = 0;
+  for (int l = 0; l < L; ++l) {
+    const int job = b * L + l;
+    const SelWs<1>* ws = wsb + job;
+    const unsigned na = ws->fill[0][0] < (unsigned)a.nms_pre ? ws->fill[0][0] : (unsigned)a.nms_pre;
+    const unsigned need = ws->need[0], nt = ws->fill[0][1];
+    const unsigned thr = (unsigned)ws->thr[0];
+    sel_take_ties<unsigned, 1, T>(a.src, job, 0, thr, need, nt, ties + (long long)job * SEL_TIE_CAP, s_tie, s_w, s_sel);
+    for (unsigned t = tid; t < na + need; t += T) {
+      unsigned e, kbits;
+      if (t < na) {
+        const u64 v = above[(long long)job * a.nms_pre + t];
+        e = (unsigned)v;
+        kbits = (unsigned)(v >> 32);
+      } else {
+        e = s_sel[t - na];
+        kbits = thr;
+      }
+      const unsigned orig = e;  // (the score maps lie pixel-major: an element's position IS the reference's index)
+      const unsigned sb = kbits ^ 0x80000000u;  // scores are >= 0: the float's own bits
+      s_key[at + t] = ((u64)(sb + 1u) << 24) | ((u64)(7 - l) << 21) | (u64)(0x1FFFFFu - orig);
+    }
+    at += (int)(na + need);
+    __syncthreads();
+  }
+  const int n = at;  // == a.n_tot
+  for (int t = n + tid; t < ORPN_NP; t += T) s_key[t] = 0ull;
+  // ---- 2. decode once for the min-size mask and the extent of the real boxes
+  float vmax = -INFINITY, vmin = INFINITY;
+  for (int t = tid; t < n; t += T) {
+    int l, orig;
+    orpn_unpack(s_key[t], l, orig);
+    float obb[5], hbb[4];
+    bool ok;
+    orpn_box_at(a, b, l, orig, obb, hbb, ok);
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        vmax = fmaxf(vmax, hbb[k]);
+        vmin = fminf(vmin, hbb[k]);
+      }
+    } else {
+      s_key[t] &= 0xFFFFFFull;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    vmin = fminf(vmin, __shfl_xor(vmin, off));
+  }
+  if (lane == 0) {
+    s_red[0][wave] = vmax;
+    s_red[1][wave] = vmin;
+  }
+  // ---- 3. sort (lds_bitonic opens with a barrier)
+  lds_bitonic<u64, T, true>(s_key, ORPN_NP);
+  vmax = s_red[0][0];
+  vmin = s_red[1][0];
+  for (int w = 1; w < T / 64; ++w) {
+    vmax = fmaxf(vmax, s_red[0][w]);
+    vmin = fminf(vmin, s_red[1][w]);
+  }
+  const float step = (vmax - vmin) + 1.f;  // max_coordinate + 1
+  // ---- 4. the sorted list: (obb, score) rows, offset horizontal boxes for the NMS, the min-size mask
+  for (int t = tid; t < n; t += T) {
+    int l, orig;
+    orpn_unpack(s_key[t], l, orig);
+    float obb[5], hbb[4];
+    bool ok;
+    const float sc = orpn_box_at(a, b, l, orig, obb, hbb, ok);
+    float* d = dets + ((long long)b * a.n_tot + t) * 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] = obb[k];
+    d[5] = sc;
+    const float off = (float)l * step;
+    float* h = boxes + ((long long)b * a.n_tot + t) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = hbb[k] + off;
+    okf[(long long)b * a.n_tot + t] = ok ? 1 : 0;
+  }
+}
+
+// keep flags (sorted order) -> the first P kept real boxes, zero rows behind them (oriented_rpn_head.py:219-222)
+__global__ __launch_bounds__(1024) void orpn_finish_kernel(const unsigned char* __restrict__ keep,
+                                                           const unsigned char* __restrict__ okf,
+                                                           const float* __restrict__ dets, int n, int P,
+                                                           float* __restrict__ out, unsigned char* __restrict__ flags) {
+  constexpr int T = 1024;
+  __shared__ unsigned s_w[T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  keep += (long long)b * n;
+  okf += (long long)b * n;
+  dets += (long long)b * n * 6;
+  out += (long long)b * P * 6;
+  flags += (long long)b * P;
+  const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  unsigned base = 0;
+  for (int i0 = 0; i0 < n && base < (unsigned)P; i0 += T) {
+    const int i = i0 + tid;
+    const bool kept = i < n && keep[i] && okf[i];
+    const u64 m = __ballot(kept);
+    __syncthreads();
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned off = 0, tot = 0;
+    for (int w = 0; w < T / 64; ++w) {
+      const unsigned t = s_w[w];
+      tot += t;
+      if (w < wave) off += t;
+    }
+    const unsigned slot = base + off + (unsigned)__popcll(m & lt);
+    if (kept && slot < (unsigned)P) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) out[(long long)slot * 6 + k] = dets[(long long)i * 6 + k];
+      flags[slot] = 1;
+    }
+    base += tot;
+  }
+  if (base > (unsigned)P) base = (unsigned)P;
+  for (int s = (int)base + tid; s < P; s += T) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[(long long)s * 6 + k] = 0.f;
+    flags[s] = 0;
+  }
+}
+
+}  // namespace rsdet
+
+using namespace rsdet;
+
+static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+template <class K, int NC, class Src, class Plan>
+static void sel_run(const Src& src, const Plan& plan, int jobs, int n_max, SelWs<NC>* ws, u64* above, int cap,
+                    unsigned* ties, hipStream_t s) {
+  (void)hipMemsetAsync(ws, 0, sizeof(SelWs<NC>) * (size_t)jobs, s);
+  const dim3 grid((unsigned)((n_max + SEL_CHUNK - 1) / SEL_CHUNK), (unsigned)jobs);
+  for (int p = 0; p < SelKey<K>::P; ++p)
+    hipLaunchKernelGGL((sel_hist_kernel<K, NC, Src, Plan>), grid, dim3(SEL_T), 0, s, src, plan, ws, p);
+  hipLaunchKernelGGL((sel_emit_kernel<K, NC, Src, Plan>), grid, dim3(SEL_T), 0, s, src, plan, ws, above, cap, ties);
+}
+
+// ---- RandomSampler.sample_masked ------------------------------------------------------------------------------------
+extern "C" size_t rsdet_sample_masked_ws_size(int num) {
+  if (num <= 0) return 0;
+  return up256(sizeof(SelWs<2>)) + up256((size_t)2 * num * sizeof(u64)) + up256((size_t)2 * SEL_TIE_CAP * sizeof(unsigned));
+}
+
+extern "C" int rsdet_sample_masked(const int32_t* gt_inds, const uint8_t* valid, int n_props, int k_gt, const void* pri,
+                                   int pri_f64, int num, int num_pos, float neg_pos_ub, int64_t* inds, uint8_t* is_pos,
+                                   uint8_t* val, int64_t* assigned, int64_t* counts, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (n_props < 0 || k_gt < 0 || num <= 0 || num > 1024 || num_pos < 0) return RSDET_EINVAL;
+  const long long n = (long long)n_props + k_gt;
+  if (n <= 0 || n > 0x7FFFFFFFll) return RSDET_EINVAL;
+  if ((n_props && !gt_inds) || !pri || !inds || !is_pos || !val || !assigned || !counts || !ws ||
+      ws_bytes < rsdet_sample_masked_ws_size(num) || ((uintptr_t)ws & 15))
+    return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  SamplerSrc src{gt_inds, valid, pri, k_gt, (int)n, pri_f64};
+  SamplerPlan plan{(int)(num_pos < n ? num_pos : n), (int)(num < n ? num : n), num, neg_pos_ub};
+  char* w = (char*)ws;
+  SelWs<2>* st = (SelWs<2>*)w;
+  w += up256(sizeof(SelWs<2>));
+  u64* above = (u64*)w;
+  w += up256((size_t)2 * num * sizeof(u64));
+  unsigned* ties = (unsigned*)w;
+  if (pri_f64) {
+    sel_run<u64, 2>(src, plan, 1, (int)n, st, above, num, ties, s);
+    hipLaunchKernelGGL(sampler_final_kernel<u64>, dim3(1), dim3(1024), 0, s, src, st, above, ties, num, num,
+                       (long long*)inds, is_pos, val, (long long*)assigned, (long long*)counts);
+  } else {
+    sel_run<unsigned, 2>(src, plan, 1, (int)n, st, above, num, ties, s);
+    hipLaunchKernelGGL(sampler_final_kernel<unsigned>, dim3(1), dim3(1024), 0, s, src, st, above, ties, num, num,
+                       (long long*)inds, is_pos, val, (long long*)assigned, (long long*)counts);
+  }
+  return rsdet_launch_status();
+}
+
+// ---- MidpointOffsetCoder.decode, obb2hbb ---------------------------------------------------------------------------
+static F6 load6(const float* host, float dflt) {
+  F6 f;
+  for (int k = 0; k < 6; ++k) f.v[k] = host ? host[k] : dflt;
+  return f;
+}
+
+extern "C" int rsdet_midpoint_offset_decode_f32(const float* anchors, const float* deltas, int n, const float* means,
+                                                const float* stds, float max_ratio, float* out, void* stream) {
+  if (n < 0) return RSDET_EINVAL;
+  if (n == 0) return RSDET_OK;
+  if (!anchors || !deltas || !out) return RSDET_EINVAL;
+  hipLaunchKernelGGL(orpn_decode_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, anchors, deltas, n,
+                     load6(means, 0.f), load6(stds, 1.f), max_ratio, out);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_obb2hbb_f32(const float* obb, int n, float* out, void* stream) {
+  if (n < 0) return RSDET_EINVAL;
+  if (n == 0) return RSDET_OK;
+  if (!obb || !out) return RSDET_EINVAL;
+  hipLaunchKernelGGL(orpn_obb2hbb_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obb, n, out);
+  return rsdet_launch_status();
+}
+
+// ---- the proposals of a batch ---------------------------------------------------------------------------------------
+static int orpn_n_tot(const rsdet_orpn_levels* d) {
+  long long t = 0;
+  for (int l = 0; l < d->n_levels; ++l) {
+    const long long c = (long long)d->A * d->hw[l];
+    t += c < d->nms_pre ? c : d->nms_pre;
+  }
+  return t > 0x7FFFFFFF ? -1 : (int)t;
+}
+
+extern "C" int rsdet_orpn_proposals_supported(const rsdet_orpn_levels* d) {
+  if (!d || d->n_img <= 0 || d->n_levels <= 0 || d->n_levels > 7 || d->A <= 0 || d->nms_pre <= 0 ||
+      d->nms_pre > SEL_TIE_CAP || d->nms_post <= 0)
+    return 0;
+  for (int l = 0; l < d->n_levels; ++l)
+    if (d->hw[l] <= 0 || (long long)d->A * d->hw[l] > 0x1FFFFF) return 0;
+  const int n = orpn_n_tot(d);
+  return n > 0 && n <= ORPN_NP;
+}
+
+extern "C" int rsdet_orpn_proposals_n(const rsdet_orpn_levels* d) { return rsdet_orpn_proposals_supported(d) ? orpn_n_tot(d) : -1; }
+
+struct OrpnWs {
+  size_t st, above, ties, dets, boxes, okf, keep, nms, nms_each, total;
+};
+static OrpnWs orpn_ws(const rsdet_orpn_levels* d) {
+  OrpnWs o;
+  const size_t jobs = (size_t)d->n_img * d->n_levels, n = (size_t)orpn_n_tot(d), N = (size_t)d->n_img;
+  size_t at = 0;
+  o.st = at, at += up256(sizeof(SelWs<1>) * jobs);
+  o.above = at, at += up256(jobs * d->nms_pre * sizeof(u64));
+  o.ties = at, at += up256(jobs * SEL_TIE_CAP * sizeof(unsigned));
+  o.dets = at, at += up256(N * n * 6 * sizeof(float));
+  o.boxes = at, at += up256(N * n * 4 * sizeof(float));
+  o.okf = at, at += up256(N * n);
+  o.keep = at, at += up256(N * n);
+  o.nms_each = up256(rsdet_nms_hbb_ws_size((int)n));
+  o.nms = at, at += o.nms_each * N;
+  o.total = at;
+  return o;
+}
+
+extern "C" size_t rsdet_orpn_proposals_ws_size(const rsdet_orpn_levels* d) {
+  return rsdet_orpn_proposals_supported(d) ? orpn_ws(d).total : 0;
+}
+
+extern "C" int rsdet_orpn_proposals_f32(const rsdet_orpn_levels* d, float* out, uint8_t* flags, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  if (!rsdet_orpn_proposals_supported(d)) return RSDET_EINVAL;
+  const OrpnWs o = orpn_ws(d);
+  if (!out || !flags || !ws || ws_bytes < o.total || ((uintptr_t)ws & 15)) return RSDET_EINVAL;
+  OrpnArgs a;
+  int n_max = 0;
+  for (int l = 0; l < 8; ++l) {
+    const bool in = l < d->n_levels;
+    if (in && (!d->score[l] || !d->reg[l] || !d->anchors[l])) return RSDET_EINVAL;
+    a.src.score[l] = in ? d->score[l] : nullptr;
+    a.src.cnt[l] = in ? d->A * d->hw[l] : 0;
+    a.reg[l] = in ? d->reg[l] : nullptr;
+    a.anchors[l] = in ? d->anchors[l] : nullptr;
+    a.hw[l] = in ? d->hw[l] : 0;
+    if (a.src.cnt[l] > n_max) n_max = a.src.cnt[l];
+  }
+  a.src.L = d->n_levels;
+  a.A = d->A;
+  a.nms_pre = d->nms_pre;
+  a.n_tot = orpn_n_tot(d);
+  a.mean = load6(d->means, 0.f);
+  a.stdv = load6(d->stds, 1.f);
+  a.max_ratio = d->max_ratio;
+  a.min_size = d->min_size;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)ws;
+  SelWs<1>* st = (SelWs<1>*)(w + o.st);
+  u64* above = (u64*)(w + o.above);
+  unsigned* ties = (unsigned*)(w + o.ties);
+  float *dets = (float*)(w + o.dets), *boxes = (float*)(w + o.boxes);
+  unsigned char *okf = (unsigned char*)(w + o.okf), *keep = (unsigned char*)(w + o.keep);
+  const int jobs = d->n_img * d->n_levels, n = a.n_tot;
+  sel_run<unsigned, 1>(a.src, LevelPlan{d->nms_pre}, jobs, n_max, st, above, d->nms_pre, ties, s);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)orpn_sort_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ORPN_NP * (int)sizeof(u64)) != hipSuccess)
+      return RSDET_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(orpn_sort_decode_kernel, dim3(d->n_img), dim3(1024), ORPN_NP * sizeof(u64), s, a, st, above, ties,
+                     dets, boxes, okf);
+  for (int b = 0; b < d->n_img; ++b) {
+    const int rc = rsdet_nms_hbb_sorted_f32(boxes + (size_t)b * n * 4, n, d->nms_thr, 1, keep + (size_t)b * n,
+                                            w + o.nms + o.nms_each * b, o.nms_each, stream);
+    if (rc != RSDET_OK) return rc;
+  }
+  hipLaunchKernelGGL(orpn_finish_kernel, dim3(d->n_img), dim3(1024), 0, s, keep, okf, dets, n, d->nms_post, out, flags);
+  return rsdet_launch_status();
+}

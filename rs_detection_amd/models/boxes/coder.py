@@ -23,6 +23,7 @@ class DeltaXYWHABBoxCoder:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from rs_detection_amd.ops import orpn  # noqa: E402
 from rs_detection_amd.ops.bbox_transforms import obb2hbb, obb2poly, rectpoly2obb, regular_theta, regular_obb  # noqa: E402
 
 
@@ -56,6 +57,9 @@ class MidpointOffsetCoder:
     def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
         assert pred_bboxes.size(0) == bboxes.size(0)
         rep = pred_bboxes.size(1) // 6
+        if rep == 1 and orpn.decode_applies(bboxes, pred_bboxes):      # one kernel (csrc/orpn.hip) for ~50 tensor operations
+            return orpn.midpoint_offset_decode(bboxes, pred_bboxes, self.means, self.stds,
+                                               float(np.abs(np.log(wh_ratio_clip))))
         d = pred_bboxes * const_tensor(self.stds, pred_bboxes).repeat(rep) + const_tensor(self.means, pred_bboxes).repeat(rep)
         dx, dy, dw, dh, da, db = (d[:, k::6] for k in range(6))
         max_ratio = float(np.abs(np.log(wh_ratio_clip)))

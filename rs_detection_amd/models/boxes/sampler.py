@@ -16,6 +16,7 @@ def _pos_neg_indices(gt_inds):
     npos, nneg = torch.stack([pos.sum(), neg.sum()]).tolist()
     return (torch.nonzero_static(pos, size=int(npos)).squeeze(-1), torch.nonzero_static(neg, size=int(nneg)).squeeze(-1))
 
+from rs_detection_amd.ops import orpn
 from rs_detection_amd.utils.registry import BOXES
 
 
@@ -102,6 +103,23 @@ class BaseSampler:
         bboxes = bboxes[:, :self.box_dim]
         dev = bboxes.device
         gt_inds, labels = assign_result.gt_inds, assign_result.labels
+        # one radix select on the device (csrc/orpn.hip: 6 launches) instead of two top-k's, an argsort and ~40 small
+        # tensor operations; the tensor form below is the CPU path and what tests/test_gpu_orpn.py compares it with
+        K = gt_bboxes.shape[0] if self.add_gt_as_proposals else 0
+        num = int(self.num)
+        r = self.priorities(bboxes.shape[0] + K, dev)
+        if orpn.sampler_applies(gt_inds, r, num):
+            inds, is_pos, val, assigned, counts = orpn.sample_masked(gt_inds, valid, K, r, num,
+                                                                     int(self.num * self.pos_fraction), self.neg_pos_ub)
+            if self.add_gt_as_proposals:
+                bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+                if labels is not None:
+                    labels = torch.cat([gt_labels.to(labels.dtype), labels])
+            pos_gt = gt_bboxes[assigned, :] if gt_bboxes.shape[0] > 0 else \
+                gt_bboxes.new_zeros((num, max(gt_bboxes.shape[-1], 4)))
+            return MaskedSamples(inds=inds, is_pos=is_pos, valid=val, bboxes=bboxes[inds], pos_gt_bboxes=pos_gt,
+                                 pos_gt_labels=labels[inds] if labels is not None else None, n_pos=counts[0],
+                                 n_neg=counts[1], num_gts=gt_bboxes.shape[0], assigned=assigned)
         if valid is not None:
             gt_inds = torch.where(valid, gt_inds, torch.full_like(gt_inds, -1))
         if self.add_gt_as_proposals:
@@ -110,8 +128,7 @@ class BaseSampler:
             gt_inds = torch.cat([torch.arange(1, K + 1, dtype=gt_inds.dtype, device=dev), gt_inds])
             if labels is not None:
                 labels = torch.cat([gt_labels.to(labels.dtype), labels])
-        n, num = bboxes.shape[0], int(self.num)
-        r = self.priorities(n, dev)
+        n = bboxes.shape[0]
         minus = torch.full_like(r, -1.0)
         kp, kn = min(int(self.num * self.pos_fraction), n), min(num, n)
         pk, pi = torch.topk(torch.where(gt_inds > 0, r, minus), kp)
@@ -142,7 +159,7 @@ class BaseSampler:
             pos_gt = gt_bboxes.new_zeros((num, max(gt_bboxes.shape[-1], 4)))
         return MaskedSamples(inds=inds, is_pos=is_pos, valid=val, bboxes=bboxes[inds], pos_gt_bboxes=pos_gt,
                              pos_gt_labels=labels[inds] if labels is not None else None, n_pos=n_pos,
-                             n_neg=(val & ~is_pos).sum(), num_gts=gt_bboxes.shape[0])
+                             n_neg=(val & ~is_pos).sum(), num_gts=gt_bboxes.shape[0], assigned=gi)
 
     @staticmethod
     def _sorted(inds):
@@ -156,8 +173,10 @@ class MaskedSamples:
     reference's order (positives by ascending index, then negatives by ascending index), unused slots last -- with
     masks instead of index lists of data-dependent length.  Everything is a device tensor; nothing was synchronised.
       inds (num,) int64 rows of the (gt-extended) box list; is_pos / valid (num,) bool; bboxes (num, d);
-      pos_gt_bboxes (num, d) and pos_gt_labels (num,) -- defined where is_pos; n_pos / n_neg 0-d int64."""
-    __slots__ = ("inds", "is_pos", "valid", "bboxes", "pos_gt_bboxes", "pos_gt_labels", "n_pos", "n_neg", "num_gts")
+      pos_gt_bboxes (num, d) and pos_gt_labels (num,) -- defined where is_pos; n_pos / n_neg 0-d int64; assigned (num,)
+      int64 the ground-truth row of a positive (0 elsewhere)."""
+    __slots__ = ("inds", "is_pos", "valid", "bboxes", "pos_gt_bboxes", "pos_gt_labels", "n_pos", "n_neg", "num_gts",
+                 "assigned")
 
     def __init__(self, **kw):
         for k, v in kw.items():

@@ -3,15 +3,23 @@
 Same constructor, parameters (rpn_conv / rpn_cls / rpn_reg), losses and proposal routine.  gt theta is negated
 (:281-282); anchors are horizontal (611 072 per 1024^2 tile with 7 ratios); proposals go through the
 hbb NMS with per-level coordinate offsets (:213-219, the role of jt.nms)."""
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from rs_detection_amd.models.boxes.anchor_target import images_to_levels, anchor_inside_flags
-from rs_detection_amd.ops.bbox_transforms import obb2hbb, get_bbox_type, get_bbox_dim, bbox2type
+from rs_detection_amd.ops import orpn
+from rs_detection_amd.ops.bbox_transforms import obb2hbb as _obb2hbb_tensor, get_bbox_type, get_bbox_dim, bbox2type
 from rs_detection_amd.ops.nms import nms as hbb_nms
 from rs_detection_amd.utils.general import multi_apply
 from rs_detection_amd.utils.registry import BOXES, LOSSES, HEADS, build_from_cfg
+
+
+def obb2hbb(obboxes):
+    """ops/bbox_transforms.obb2hbb; as one kernel where that applies (both proposal routes then share its arithmetic)."""
+    return orpn.obb2hbb(obboxes) if orpn.obb2hbb_applies(obboxes) else _obb2hbb_tensor(obboxes)
 
 
 @HEADS.register_module()
@@ -167,6 +175,15 @@ class OrientedRPNHead(nn.Module):
         num_levels = len(cls_scores)
         featmap_sizes = [tuple(cls_scores[i].shape[-2:]) for i in range(num_levels)]
         mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=cls_scores[0].device)
+        coder = self.bbox_coder
+        if fixed and self.use_sigmoid_cls and self.cls_out_channels == 1 and type(coder).__name__ == "MidpointOffsetCoder" \
+                and orpn.proposals_apply(cls_scores, bbox_preds, mlvl_anchors, self.nms_pre, self.nms_post):
+            # the whole batch in 12 launches (csrc/orpn.hip); _get_bboxes_single below is the same routine image by image
+            with torch.no_grad():
+                dets, real = orpn.proposals([orpn.pixel_major_sigmoid(c.detach()) for c in cls_scores], [r.detach() for r in bbox_preds],
+                                           mlvl_anchors, self.nms_pre, self.nms_post, self.nms_thresh, self.min_bbox_size,
+                                           coder.means, coder.stds, abs(math.log(16 / 1000)))
+            return [(dets[i], real[i]) for i in range(len(targets))]
         out = []
         for img_id, target in enumerate(targets):
             cls_list = [cls_scores[i][img_id].detach() for i in range(num_levels)]
