@@ -589,6 +589,38 @@ int rsdet_orpn_proposals_supported(const rsdet_orpn_levels* d);
 int rsdet_orpn_proposals_n(const rsdet_orpn_levels* d); /* rows that enter the NMS per image */
 size_t rsdet_orpn_proposals_ws_size(const rsdet_orpn_levels* d);
 int rsdet_orpn_proposals_f32(const rsdet_orpn_levels* d, float* out, uint8_t* flags, void* ws, size_t ws_bytes, void* stream);
+/* The Oriented RPN's two losses evaluated on the SAMPLED anchors.  Replaces models/roi_heads/oriented_rpn_head.py:274-480
+ * (_get_targets_single's four dense target maps per image, images_to_levels, loss_single per level) for the configuration the
+ * reference trains: sigmoid classification with CrossEntropyLossForRcnn (losses/cross_entropy_loss.py:24-31), SmoothL1Loss
+ * (losses/smooth_l1_loss.py:5-24) on MidpointOffsetCoder.encode targets (boxes/coder.py:334-370), avg_factor = sum over
+ * the images of max(#pos, 1) + max(#neg, 1).  The dense maps are zero-weighted outside the samples, so the sums are the same.
+ * cls[l] (n_img, A, H_l, W_l) logits, reg[l] (n_img, 6 A, H_l, W_l); anchors (total, 4) level-major, index pixel * A + a
+ * inside a level; inside (int64) maps a sampled index to its row of `anchors` (NULL: identity); gt[b] (k_gt[b], 5) the
+ * ground truth of image b as the head sees it (theta negated); inds / is_pos / val / assigned (n_img, num) and counts
+ * (n_img, 2) from rsdet_sample_masked.  forward: losses (2, n_levels) = loss_cls per level then loss_bbox per level, each
+ * already times its weight; rec: rsdet_orpn_loss_rec_floats(n_img, num) floats kept for the backward.  backward: cls[l] /
+ * reg[l] are ZERO-FILLED gradient maps of those shapes (written through the const pointers), grad_losses (2, n_levels).
+ * n_img <= 16. */
+typedef struct rsdet_orpn_loss {
+  int n_img, n_levels, A, num;
+  int hw[8];
+  const float* cls[8];
+  const float* reg[8];
+  const float* anchors;
+  const int64_t* inside;
+  const float* gt[16];
+  int k_gt[16];
+  const int64_t* inds;
+  const uint8_t* is_pos;
+  const uint8_t* val;
+  const int64_t* assigned;
+  const int64_t* counts;
+  float means[6], stds[6];
+  float beta, w_cls, w_box, pos_weight;
+} rsdet_orpn_loss;
+int rsdet_orpn_loss_rec_floats(int n_img, int num);
+int rsdet_orpn_loss_forward_f32(const rsdet_orpn_loss* d, float* losses, float* rec, void* stream);
+int rsdet_orpn_loss_backward_f32(const rsdet_orpn_loss* d, const float* rec, const float* grad_losses, void* stream);
 /* The prepared weight operands of the backward (ops/weight_prep.py) refreshed by one launch: entries = n 64-byte records
  * in DEVICE memory {src, dst, var, gamma (pointers), O, C, T, eps (float), tile0, tiles_c, tiles_o, pad}: dst (C, T, O) =
  * src (O, T, C) with the taps reversed and row o scaled by gamma[o] / sqrt(var[o] + eps) (var NULL: copied).  tile0

@@ -61,6 +61,16 @@ class OrpnLevels(ctypes.Structure):
                    ("reg", c_void_p * 8), ("anchors", c_void_p * 8)])
 
 
+class OrpnLoss(ctypes.Structure):
+    """struct rsdet_orpn_loss (include/rsdet.h)."""
+    _fields_ = ([(n, c_int) for n in ("n_img", "n_levels", "A", "num")]
+                + [("hw", c_int * 8), ("cls", c_void_p * 8), ("reg", c_void_p * 8), ("anchors", c_void_p), ("inside", c_void_p),
+                   ("gt", c_void_p * 16), ("k_gt", c_int * 16)]
+                + [(n, c_void_p) for n in ("inds", "is_pos", "val", "assigned", "counts")]
+                + [("means", c_float * 6), ("stds", c_float * 6)]
+                + [(n, c_float) for n in ("beta", "w_cls", "w_box", "pos_weight")])
+
+
 # name -> (restype, argtypes); must list every symbol include/rsdet.h declares.
 SIGNATURES = {
     "rsdet_abi_version": (c_int, []),
@@ -116,6 +126,9 @@ SIGNATURES = {
     "rsdet_orpn_proposals_n": (c_int, [c_void_p]),
     "rsdet_orpn_proposals_ws_size": (c_size_t, [c_void_p]),
     "rsdet_orpn_proposals_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_orpn_loss_rec_floats": (c_int, [c_int, c_int]),
+    "rsdet_orpn_loss_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_orpn_loss_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_van_block_supported": (c_int, [c_void_p]),
     "rsdet_van_block_side_stream": (c_int, [c_int]),
     "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),

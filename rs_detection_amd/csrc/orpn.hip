@@ -710,6 +710,165 @@ __global__ __launch_bounds__(1024) void orpn_finish_kernel(const unsigned char* 
   }
 }
 
+
+// ============================ the Oriented RPN's losses on the SAMPLES (oriented_rpn_head.py:274-480) ===============
+// The reference builds four dense target maps per image (labels, label weights, encoded boxes, box weights over all
+// 611 072 anchors), cuts them into levels and evaluates both losses densely -- with weights that are zero outside the
+// <= 256 sampled anchors of each image.  The same sums over the samples alone: one workgroup looks every sample up
+// (level, pixel, anchor), encodes the positives' targets (MidpointOffsetCoder.encode, coder.py:334-370), evaluates the
+// weighted BCE-with-logits and smooth-L1 terms, reduces them per level, and leaves the per-sample derivatives for a
+// backward pass that scatters them into zero gradient maps.
+struct OrpnLossArgs {
+  const float* cls[8];  // forward: (N, A, H, W) logits;          backward: gradient maps (written)
+  const float* reg[8];  // forward: (N, 6 A, H, W) predictions;   backward: gradient maps (written)
+  int hw[8];
+  int n_img, L, A, num;
+  const float* anchors;      // (total, 4) level-major
+  const long long* inside;   // (n_inside) or NULL
+  const float* gt[16];
+  int k_gt[16];
+  const long long* inds;
+  const unsigned char* is_pos;
+  const unsigned char* val;
+  const long long* assigned;
+  const long long* counts;
+  F6 mean, stdv;
+  float beta, w_cls, w_box, pos_weight;
+};
+
+constexpr int ORPN_REC = 12;  // words per sample: level, cls offset, reg offset, hw, dcls, dreg[6], pad
+
+// MidpointOffsetCoder.encode (coder.py:334-370): hbb proposal p, obb ground truth g -> 6 normalised deltas
+__device__ __forceinline__ void orpn_encode(const float* p, const float* g, const F6& mean, const F6& stdv, float* o) {
+  const float px = (p[0] + p[2]) * 0.5f, py = (p[1] + p[3]) * 0.5f, pw = p[2] - p[0], ph = p[3] - p[1];
+  float hbb[4];
+  orpn_obb2hbb(g, hbb);
+  const float Cos = cosf(g[4]), Sin = sinf(g[4]);
+  const float v1x = g[2] / 2.f * Cos, v1y = -g[2] / 2.f * Sin, v2x = -g[3] / 2.f * Sin, v2y = -g[3] / 2.f * Cos;
+  const float qx[4] = {g[0] + v1x + v2x, g[0] + v1x - v2x, g[0] - v1x - v2x, g[0] - v1x + v2x};
+  const float qy[4] = {g[1] + v1y + v2y, g[1] + v1y - v2y, g[1] - v1y - v2y, g[1] - v1y + v2y};
+  const float gx = (hbb[0] + hbb[2]) * 0.5f, gy = (hbb[1] + hbb[3]) * 0.5f, gw = hbb[2] - hbb[0], gh = hbb[3] - hbb[1];
+  const float y_min = fminf(fminf(qy[0], qy[1]), fminf(qy[2], qy[3]));
+  const float x_max = fmaxf(fmaxf(qx[0], qx[1]), fmaxf(qx[2], qx[3]));
+  float ga = -INFINITY, gb = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ga = fmaxf(ga, fabsf(qy[k] - y_min) > 0.1f ? -1000.f : qx[k]);
+    gb = fmaxf(gb, fabsf(qx[k] - x_max) > 0.1f ? -1000.f : qy[k]);
+  }
+  const float d[6] = {(gx - px) / pw, (gy - py) / ph, logf(gw / pw), logf(gh / ph), (ga - gx) / gw, (gb - gy) / gh};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[k] = (d[k] - mean.v[k]) / stdv.v[k];
+}
+
+__global__ __launch_bounds__(1024) void orpn_loss_fwd_kernel(OrpnLossArgs a, float* __restrict__ losses,
+                                                             float* __restrict__ rec) {
+  constexpr int T = 1024;
+  __shared__ float s_part[2][8][T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, S = a.n_img * a.num;
+  float avg = 0.f;
+  {
+    long long np = 0, nn = 0;
+    for (int b = 0; b < a.n_img; ++b) {
+      const long long p = a.counts[2 * b], n = a.counts[2 * b + 1];
+      np += p > 1 ? p : 1;
+      nn += n > 1 ? n : 1;
+    }
+    avg = (float)(np + nn);
+  }
+  float acc_c[8], acc_b[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) acc_c[l] = acc_b[l] = 0.f;
+  for (int s = tid; s < S; s += T) {
+    const int b = s / a.num;
+    int level = -1, cls_off = 0, reg_off = 0, hw = 0;
+    float dcls = 0.f, dreg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.val[s]) {
+      const long long i = a.inds[s], flat = a.inside ? a.inside[i] : i;
+      long long start = 0;
+      int l = 0;
+      for (; l < a.L - 1; ++l) {
+        const long long c = (long long)a.A * a.hw[l];
+        if (flat < start + c) break;
+        start += c;
+      }
+      const int j = (int)(flat - start);
+      hw = a.hw[l];
+      const int pix = j / a.A, an = j - pix * a.A;
+      level = l;
+      cls_off = (b * a.A + an) * hw + pix;
+      reg_off = (b * a.A + an) * 6 * hw + pix;
+      const bool pos = a.is_pos[s] != 0;
+      const float x = a.cls[l][cls_off], y = pos ? 1.f : 0.f;
+      const float w = (pos && a.pos_weight > 0.f) ? a.pos_weight : 1.f;
+      // binary_cross_entropy_with_logits: (1 - y) x - log_sigmoid(x), log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+      const float bce = (1.f - y) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
+      acc_c[l] += w * bce;
+      dcls = w * (1.f / (1.f + expf(-x)) - y) / avg * a.w_cls;
+      if (pos) {
+        float anc[4], g[5], t[6];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) anc[k] = a.anchors[flat * 4 + k];
+        const float* gp = a.gt[b] + a.assigned[s] * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g[k] = gp[k];
+        orpn_encode(anc, g, a.mean, a.stdv, t);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const float df = a.reg[l][reg_off + k * hw] - t[k], ad = fabsf(df);
+          sum += ad < a.beta ? 0.5f * ad * ad / a.beta : ad - 0.5f * a.beta;
+          const float gk = ad < a.beta ? df / a.beta : (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+          dreg[k] = gk / avg * a.w_box;
+        }
+        acc_b[l] += sum;
+      }
+    }
+    float* r = rec + (long long)s * ORPN_REC;
+    r[0] = __int_as_float(level);
+    r[1] = __int_as_float(cls_off);
+    r[2] = __int_as_float(reg_off);
+    r[3] = __int_as_float(hw);
+    r[4] = dcls;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[5 + k] = dreg[k];
+    r[11] = 0.f;
+  }
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    float c = acc_c[l], bx = acc_b[l];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      c += __shfl_xor(c, off);
+      bx += __shfl_xor(bx, off);
+    }
+    if (lane == 0) {
+      s_part[0][l][wave] = c;
+      s_part[1][l][wave] = bx;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * a.L) {
+    const int which = tid / a.L, l = tid - which * a.L;
+    float v = 0.f;
+    for (int w = 0; w < T / 64; ++w) v += s_part[which][l][w];
+    losses[tid] = v / avg * (which ? a.w_box : a.w_cls);
+  }
+}
+
+__global__ void orpn_loss_bwd_kernel(OrpnLossArgs a, const float* __restrict__ rec, const float* __restrict__ g) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_img * a.num) return;
+  const float* r = rec + (long long)s * ORPN_REC;
+  const int l = __float_as_int(r[0]);
+  if (l < 0) return;
+  const int cls_off = __float_as_int(r[1]), reg_off = __float_as_int(r[2]), hw = __float_as_int(r[3]);
+  const float gc = g[l], gb = g[a.L + l];
+  const_cast<float*>(a.cls[l])[cls_off] = r[4] * gc;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) const_cast<float*>(a.reg[l])[reg_off + k * hw] = r[5 + k] * gb;
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -883,5 +1042,54 @@ extern "C" int rsdet_orpn_proposals_f32(const rsdet_orpn_levels* d, float* out, 
     if (rc != RSDET_OK) return rc;
   }
   hipLaunchKernelGGL(orpn_finish_kernel, dim3(d->n_img), dim3(1024), 0, s, keep, okf, dets, n, d->nms_post, out, flags);
+  return rsdet_launch_status();
+}
+
+// ---- the Oriented RPN's losses on the samples -----------------------------------------------------------------------
+static int orpn_loss_args(const rsdet_orpn_loss* d, OrpnLossArgs& a, bool forward) {
+  if (!d || d->n_img <= 0 || d->n_img > 16 || d->n_levels <= 0 || d->n_levels > 8 || d->A <= 0 || d->num <= 0) return 0;
+  for (int l = 0; l < 8; ++l) {
+    const bool in = l < d->n_levels;
+    if (in && (d->hw[l] <= 0 || !d->cls[l] || !d->reg[l])) return 0;
+    if (in && (long long)d->n_img * d->A * 6 * d->hw[l] > 0x7FFFFFFFll) return 0;
+    a.cls[l] = in ? d->cls[l] : nullptr;
+    a.reg[l] = in ? d->reg[l] : nullptr;
+    a.hw[l] = in ? d->hw[l] : 0;
+  }
+  a.n_img = d->n_img, a.L = d->n_levels, a.A = d->A, a.num = d->num;
+  if (!forward) return 1;
+  if (!d->anchors || !d->inds || !d->is_pos || !d->val || !d->assigned || !d->counts || !(d->beta > 0.f)) return 0;
+  for (int b = 0; b < 16; ++b) {
+    a.gt[b] = b < d->n_img ? d->gt[b] : nullptr;
+    a.k_gt[b] = b < d->n_img ? d->k_gt[b] : 0;
+  }
+  a.anchors = d->anchors;
+  a.inside = (const long long*)d->inside;
+  a.inds = (const long long*)d->inds;
+  a.is_pos = d->is_pos;
+  a.val = d->val;
+  a.assigned = (const long long*)d->assigned;
+  a.counts = (const long long*)d->counts;
+  a.mean = load6(d->means, 0.f);
+  a.stdv = load6(d->stds, 1.f);
+  a.beta = d->beta, a.w_cls = d->w_cls, a.w_box = d->w_box, a.pos_weight = d->pos_weight;
+  return 1;
+}
+
+extern "C" int rsdet_orpn_loss_rec_floats(int n_img, int num) { return n_img > 0 && num > 0 ? n_img * num * ORPN_REC : 0; }
+
+extern "C" int rsdet_orpn_loss_forward_f32(const rsdet_orpn_loss* d, float* losses, float* rec, void* stream) {
+  OrpnLossArgs a;
+  if (!orpn_loss_args(d, a, true) || !losses || !rec) return RSDET_EINVAL;
+  hipLaunchKernelGGL(orpn_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, losses, rec);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_orpn_loss_backward_f32(const rsdet_orpn_loss* d, const float* rec, const float* grad_losses,
+                                            void* stream) {
+  OrpnLossArgs a;
+  if (!orpn_loss_args(d, a, false) || !rec || !grad_losses) return RSDET_EINVAL;
+  const int S = d->n_img * d->num;
+  hipLaunchKernelGGL(orpn_loss_bwd_kernel, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, rec, grad_losses);
   return rsdet_launch_status();
 }

@@ -336,6 +336,10 @@ class OrientedRPNHead(nn.Module):
         mla = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
         anchor_list = [mla for _ in range(len(targets))]
         valid_flag_list = [self._valid_flags(featmap_sizes, t['pad_shape'], dev) for t in targets]
+        if self.masked:
+            sparse = self._loss_on_samples(cls_scores, bbox_preds, anchor_list, valid_flag_list, targets)
+            if sparse is not None:
+                return sparse
         # the train step's form: fixed-size samples, counts on the device (no host synchronisation); `masked = False`
         # keeps the reference-shaped index lists (what the known-answer tests of the head read)
         get = self.get_targets_masked if self.masked else self.get_targets
@@ -344,6 +348,58 @@ class OrientedRPNHead(nn.Module):
         all_anchor_list = images_to_levels([torch.cat(a) for a in anchor_list], num_level_anchors)
         losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list,
                                               lw_list, bt_list, bw_list, num_total_samples=npos + nneg)
+        return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
+
+    def _loss_on_samples(self, cls_scores, bbox_preds, anchor_list, valid_flag_list, targets):
+        """Both losses evaluated on the <= `num` sampled anchors of each image (csrc/orpn.hip: the dense target maps of
+        get_targets_masked are zero-weighted everywhere else, so the per-level sums are the same): assignment and one
+        radix-select sampler call per image, then ONE launch for all images and levels, and one in the backward.  None
+        when the configuration is not the one the kernel restates (then the dense route below runs)."""
+        from rs_detection_amd.models.boxes.sampler import RandomSampler
+        from rs_detection_amd.models.losses.cross_entropy_loss import CrossEntropyLossForRcnn
+        from rs_detection_amd.models.losses.smooth_l1_loss import SmoothL1Loss
+        sampler, coder, lc, lb = self.sampler, self.bbox_coder, self.loss_cls, self.loss_bbox
+        N, num = len(targets), int(sampler.num)
+        if not (isinstance(sampler, RandomSampler) and not sampler.add_gt_as_proposals
+                and type(coder).__name__ == "MidpointOffsetCoder" and self.use_sigmoid_cls and self.cls_out_channels == 1
+                and self.reg_dim == 6 and not self.reg_decoded_bbox and self.sampling and self.unmap_outputs
+                and type(lc) is CrossEntropyLossForRcnn and lc.use_sigmoid and type(lb) is SmoothL1Loss and lb.beta > 0
+                and lb.reduction == "mean" and orpn.rpn_loss_applies(cls_scores, bbox_preds, N, num)):
+            return None
+        dev = cls_scores[0].device
+        geom = [self._inside_geometry(anchor_list[i], valid_flag_list[i], t["img_size"]) for i, t in enumerate(targets)]
+        if not all(g is geom[0] and g["any"] for g in geom):
+            return None
+        anchors = geom[0]["anchors"]
+        if get_bbox_type(anchors) != 'hbb':
+            return None
+        inds = torch.empty((N, num), dtype=torch.int64, device=dev)
+        assigned = torch.empty((N, num), dtype=torch.int64, device=dev)
+        flags = torch.empty((2, N, num), dtype=torch.bool, device=dev)
+        counts = torch.empty((N, 2), dtype=torch.int64, device=dev)
+        gts = []
+        for i, t in enumerate(targets):
+            gt = torch.as_tensor(t["rboxes"]).to(dev).float().clone()
+            gt[:, -1] *= -1
+            ign = t.get("rboxes_ignore")
+            gt_ignore = None
+            if ign is not None and torch.as_tensor(ign).numel() > 0:
+                gt_ignore = torch.as_tensor(ign).to(dev).float().clone()
+                gt_ignore[:, -1] *= -1
+            if get_bbox_type(gt) != 'obb':
+                return None
+            ar = self.assigner.assign(anchors, bbox2type(gt, 'hbb'), None if gt_ignore is None else bbox2type(gt_ignore, 'hbb'),
+                                      None)
+            pri = sampler.priorities(anchors.shape[0], dev)
+            if not orpn.sampler_applies(ar.gt_inds, pri, num):
+                return None
+            orpn.sample_masked(ar.gt_inds, None, 0, pri, num, int(sampler.num * sampler.pos_fraction), sampler.neg_pos_ub,
+                               out=(inds[i], flags[0, i], flags[1, i], assigned[i], counts[i]))
+            gts.append(gt.contiguous())
+        spec = orpn.RpnLossSpec(anchors=geom[0]["flat"], inside=geom[0]["idx"], gts=gts, inds=inds, is_pos=flags[0],
+                                val=flags[1], assigned=assigned, counts=counts, means=coder.means, stds=coder.stds,
+                                beta=lb.beta, w_cls=lc.loss_weight, w_box=lb.loss_weight, pos_weight=self.pos_weight)
+        losses_cls, losses_bbox = orpn.rpn_loss(spec, list(cls_scores), list(bbox_preds))
         return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
 
     def forward(self, features, targets):

@@ -30,9 +30,10 @@ def sampler_applies(gt_inds, pri, num):
             and pri.dtype in (torch.float32, torch.float64) and 0 < num <= 1024)
 
 
-def sample_masked(gt_inds, valid, k_gt, pri, num, num_pos, neg_pos_ub):
+def sample_masked(gt_inds, valid, k_gt, pri, num, num_pos, neg_pos_ub, out=None):
     """(inds, is_pos, valid, assigned, counts) of include/rsdet.h: rsdet_sample_masked; gt_inds (n_props,) int32, valid
-    (n_props,) bool or None, pri (k_gt + n_props,) float32 / float64."""
+    (n_props,) bool or None, pri (k_gt + n_props,) float32 / float64.  ``out``: the five tensors to write (contiguous rows of
+    the caller's batch)."""
     lib = _lib.load()
     dev = gt_inds.device
     gt_inds, pri = gt_inds.contiguous(), pri.contiguous()
@@ -41,18 +42,23 @@ def sample_masked(gt_inds, valid, k_gt, pri, num, num_pos, neg_pos_ub):
     if valid is not None:
         valid = valid.contiguous()
         assert valid.dtype == torch.bool and valid.numel() == n_props
-    inds = torch.empty((num,), dtype=torch.int64, device=dev)
-    assigned = torch.empty((num,), dtype=torch.int64, device=dev)
-    counts = torch.empty((2,), dtype=torch.int64, device=dev)
-    flags = torch.empty((2, num), dtype=torch.bool, device=dev)
+    if out is not None:
+        inds, f0, f1, assigned, counts = out
+        assert all(t.is_contiguous() for t in out) and inds.numel() == num and counts.numel() == 2
+    else:
+        inds = torch.empty((num,), dtype=torch.int64, device=dev)
+        assigned = torch.empty((num,), dtype=torch.int64, device=dev)
+        counts = torch.empty((2,), dtype=torch.int64, device=dev)
+        flags = torch.empty((2, num), dtype=torch.bool, device=dev)
+        f0, f1 = flags[0], flags[1]
     ws_bytes = lib.rsdet_sample_masked_ws_size(num)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     rc = lib.rsdet_sample_masked(_lib.ptr(gt_inds), _lib.ptr(valid), n_props, int(k_gt), _lib.ptr(pri),
                                  int(pri.dtype == torch.float64), int(num), int(num_pos), float(neg_pos_ub), _lib.ptr(inds),
-                                 _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(assigned), _lib.ptr(counts), _lib.ptr(ws),
+                                 _lib.ptr(f0), _lib.ptr(f1), _lib.ptr(assigned), _lib.ptr(counts), _lib.ptr(ws),
                                  ws_bytes, _lib.stream_ptr())
     _lib.check(rc, "rsdet_sample_masked")
-    return inds, flags[0], flags[1], assigned, counts
+    return inds, f0, f1, assigned, counts
 
 
 # ---- MidpointOffsetCoder.decode / obb2hbb ----------------------------------------------------------------------------
@@ -141,3 +147,105 @@ def proposals(scores, regs, anchors, nms_pre, nms_post, nms_thr, min_size, means
     rc = lib.rsdet_orpn_proposals_f32(ref, _lib.ptr(out), _lib.ptr(flags), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
     _lib.check(rc, "rsdet_orpn_proposals_f32")
     return out, flags
+
+
+# ---- the Oriented RPN's losses on the samples ------------------------------------------------------------------------
+class RpnLossSpec:
+    """Everything rsdet_orpn_loss needs besides the prediction maps (include/rsdet.h): the flat anchors and the inside-index
+    list, per image the ground truth (K, 5) as the head sees it, the samples of rsdet_sample_masked stacked over the images
+    (inds / is_pos / val / assigned (N, num), counts (N, 2)), the coder's constants and the losses' parameters."""
+    __slots__ = ("anchors", "inside", "gts", "inds", "is_pos", "val", "assigned", "counts", "means", "stds", "beta", "w_cls",
+                 "w_box", "pos_weight")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _loss_desc(spec, cls, reg):
+    d = _lib.OrpnLoss()
+    N, A = cls[0].shape[:2]
+    d.n_img, d.n_levels, d.A, d.num = N, len(cls), A, spec.inds.shape[1]
+    for l, (c, r) in enumerate(zip(cls, reg)):
+        d.hw[l] = c.shape[2] * c.shape[3]
+        d.cls[l], d.reg[l] = c.data_ptr(), r.data_ptr()
+    return d
+
+
+class _OrpnLoss(torch.autograd.Function):
+    """forward(spec, cls_0 .. cls_{L-1}, reg_0 .. reg_{L-1}) -> 2 L scalars: loss_cls per level, then loss_bbox per level."""
+
+    @staticmethod
+    def forward(ctx, spec, *maps):
+        lib = _lib.load()
+        L = len(maps) // 2
+        cls = [m.contiguous() for m in maps[:L]]
+        reg = [m.contiguous() for m in maps[L:]]
+        d = _loss_desc(spec, cls, reg)
+        d.anchors, d.inside = spec.anchors.data_ptr(), (spec.inside.data_ptr() if spec.inside is not None else None)
+        for b, g in enumerate(spec.gts):
+            d.gt[b], d.k_gt[b] = g.data_ptr(), g.shape[0]
+        d.inds, d.is_pos, d.val = spec.inds.data_ptr(), spec.is_pos.data_ptr(), spec.val.data_ptr()
+        d.assigned, d.counts = spec.assigned.data_ptr(), spec.counts.data_ptr()
+        d.means, d.stds = _f6(spec.means, 0.), _f6(spec.stds, 1.)
+        d.beta, d.w_cls, d.w_box, d.pos_weight = float(spec.beta), float(spec.w_cls), float(spec.w_box), float(spec.pos_weight)
+        dev = cls[0].device
+        N, num = spec.inds.shape
+        losses = torch.empty((2 * L,), dtype=torch.float32, device=dev)
+        rec = torch.empty((lib.rsdet_orpn_loss_rec_floats(N, num),), dtype=torch.float32, device=dev)
+        rc = lib.rsdet_orpn_loss_forward_f32(ctypes.byref(d), _lib.ptr(losses), _lib.ptr(rec), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_orpn_loss_forward_f32")
+        ctx.save_for_backward(rec)
+        ctx.shapes = [tuple(m.shape) for m in cls + reg]
+        ctx.num = num
+        return tuple(losses.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        rec, = ctx.saved_tensors
+        shapes = ctx.shapes
+        L = len(shapes) // 2
+        dev = rec.device
+        zero = None
+        gl = []
+        for g in grads:
+            if g is None:
+                zero = torch.zeros((), dtype=torch.float32, device=dev) if zero is None else zero
+                g = zero
+            gl.append(g.reshape(()))
+        g = torch.stack(gl).float()
+        sizes = [s[0] * s[1] * s[2] * s[3] for s in shapes]
+        arena = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)     # one fill for all ten gradient maps
+        outs, at = [], 0
+        for s, n in zip(shapes, sizes):
+            outs.append(arena[at:at + n].view(s))
+            at += n
+        d = _loss_desc(_Num(ctx.num), outs[:L], outs[L:])
+        rc = lib.rsdet_orpn_loss_backward_f32(ctypes.byref(d), _lib.ptr(rec), _lib.ptr(g), _lib.stream_ptr())
+        _lib.check(rc, "rsdet_orpn_loss_backward_f32")
+        return (None,) + tuple(outs)
+
+
+class _Num:
+    """(a spec that only carries the sample count, for the backward's descriptor)"""
+
+    def __init__(self, num):
+        self.inds = torch.empty((0, num))
+
+
+def rpn_loss_applies(cls_scores, bbox_preds, n_img, num):
+    if not (_ON and 0 < len(cls_scores) <= 8 and 0 < n_img <= 16 and 0 < num <= 1024):
+        return False
+    for c, r in zip(cls_scores, bbox_preds):
+        if not (c.is_cuda and c.dtype == torch.float32 and r.dtype == torch.float32 and c.dim() == 4
+                and r.shape == (c.shape[0], 6 * c.shape[1]) + tuple(c.shape[2:]) and r.numel() < (1 << 31)):
+            return False
+    return True
+
+
+def rpn_loss(spec, cls_scores, bbox_preds):
+    """-> (loss_cls per level, loss_bbox per level): two lists of 0-d tensors (rsdet_orpn_loss_forward_f32)."""
+    L = len(cls_scores)
+    out = _OrpnLoss.apply(spec, *cls_scores, *bbox_preds)
+    return list(out[:L]), list(out[L:])

@@ -230,3 +230,45 @@ def test_batched_proposals_close_to_the_tensor_operations(cuda):
         rows = np.nonzero(sg[:k] == sw[:k])[0]
         err = np.abs(d[:k].cpu().numpy()[rows, :4] - w[:k].cpu().numpy()[rows, :4]).max(1)
         assert np.quantile(err, 0.99) < 5e-3, np.quantile(err, 0.99)
+
+
+def test_rpn_losses_on_the_samples_equal_the_dense_target_maps(cuda, monkeypatch):
+    """OrientedRPNHead.loss through rsdet_orpn_loss (the sampled anchors only) == through the dense target maps of
+    get_targets_masked + loss_single per level: the ten scalars and the gradients of all ten prediction maps."""
+    from rs_detection_amd.models.boxes.sampler import RandomSampler
+    from rs_detection_amd.ops import orpn
+    from rs_detection_amd.utils import synthetic as syn
+    rng = np.random.default_rng(2)
+    size, B = 512, 2
+    rpn = _rpn(cuda)
+    cls, reg = _maps(rng, B, size, 7)
+    pri = torch.from_numpy(np.random.default_rng(9).random(1 << 20).astype(np.float32)).to(cuda)
+    monkeypatch.setattr(RandomSampler, "priorities", staticmethod(lambda n, dev: pri[:n]))
+    targets = []
+    for t in syn.synthetic_targets(B, img=size, num_classes=10):
+        t = dict(t, rboxes=torch.from_numpy(t["rboxes"][:20]).to(cuda), rboxes_ignore=None, img_size=(size, size),
+                 pad_shape=(size, size))
+        targets.append(t)
+    res = []
+    for on in (True, False):
+        c = [torch.from_numpy(x).to(cuda).requires_grad_(True) for x in cls]
+        r = [torch.from_numpy(x).to(cuda).requires_grad_(True) for x in reg]
+        orpn._ON = on
+        try:
+            losses = rpn.loss(c, r, targets)
+            w = torch.linspace(0.5, 1.5, 10, device=cuda)                 # a different upstream gradient per scalar
+            total = sum(wi * li for wi, li in zip(w, losses["loss_rpn_cls"] + losses["loss_rpn_bbox"]))
+            total.backward()
+        finally:
+            orpn._ON = True
+        res.append((losses, [x.grad for x in c + r]))
+    (la, ga), (lb, gb) = res
+    assert sum(float(x) for x in lb["loss_rpn_bbox"]) > 0
+    for k in ("loss_rpn_cls", "loss_rpn_bbox"):
+        assert len(la[k]) == len(lb[k]) == 5
+        for x, y in zip(la[k], lb[k]):
+            assert abs(float(x) - float(y)) <= 2e-5 * max(abs(float(y)), 1e-3) + 1e-7, (k, float(x), float(y))
+    for x, y in zip(ga, gb):
+        assert x.shape == y.shape
+        assert int((x != 0).sum()) == int((y != 0).sum())
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-9), float((x - y).abs().max())
