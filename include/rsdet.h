@@ -621,6 +621,18 @@ typedef struct rsdet_orpn_loss {
 int rsdet_orpn_loss_rec_floats(int n_img, int num);
 int rsdet_orpn_loss_forward_f32(const rsdet_orpn_loss* d, float* losses, float* rec, void* stream);
 int rsdet_orpn_loss_backward_f32(const rsdet_orpn_loss* d, const float* rec, const float* grad_losses, void* stream);
+/* OrientedHead's sampled RoIs and targets of ONE image, written into that image's rows of the batch.  Replaces
+ * models/roi_heads/oriented_head.py:426-496 (get_bboxes_target_single) + arb2roi (:117-126) + the gathers of
+ * SamplingResult (models/boxes/sampler.py:6-36) with OrientedDeltaXYWHTCoder.encode (models/boxes/coder.py:447-470), in the
+ * fixed-size form of the train step.  inds / is_pos / val / assigned (num) from rsdet_sample_masked over the gt-extended
+ * list: row i < k_gt is gt i, row k_gt + j is props[j] (rows of prop_stride >= 5 floats, obb first).  Outputs, num rows
+ * each: rois (num, 6) = (image, obb), labels (int64: the gt's label for a positive, num_classes elsewhere), label_weights
+ * (1 on used slots, pos_weight on positives when > 0, 0 on unused), bbox_targets / bbox_weights (num, 5). */
+int rsdet_orcnn_roi_targets_f32(const float* props, int prop_stride, int n_props, const float* gt, const int64_t* gt_labels,
+                                int k_gt, const int64_t* inds, const uint8_t* is_pos, const uint8_t* val,
+                                const int64_t* assigned, int num, int image, int num_classes, const float* means,
+                                const float* stds, float pos_weight, float* rois, int64_t* labels, float* label_weights,
+                                float* bbox_targets, float* bbox_weights, void* stream);
 /* The prepared weight operands of the backward (ops/weight_prep.py) refreshed by one launch: entries = n 64-byte records
  * in DEVICE memory {src, dst, var, gamma (pointers), O, C, T, eps (float), tile0, tiles_c, tiles_o, pad}: dst (C, T, O) =
  * src (O, T, C) with the taps reversed and row o scaled by gamma[o] / sqrt(var[o] + eps) (var NULL: copied).  tile0

@@ -129,6 +129,9 @@ SIGNATURES = {
     "rsdet_orpn_loss_rec_floats": (c_int, [c_int, c_int]),
     "rsdet_orpn_loss_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_orpn_loss_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_orcnn_roi_targets_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_van_block_supported": (c_int, [c_void_p]),
     "rsdet_van_block_side_stream": (c_int, [c_int]),
     "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),

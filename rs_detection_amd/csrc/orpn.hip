@@ -423,6 +423,9 @@ __global__ __launch_bounds__(1024) void sampler_final_kernel(SamplerSrc src, con
 struct F6 {
   float v[6];
 };
+struct F5v {
+  float v[5];
+};
 
 // regular_theta(t) = remainder(t + pi/2, pi) - pi/2 with Python-style remainder (bbox_transforms.py:501-505)
 __device__ __forceinline__ float orpn_regular_theta(float t) {
@@ -869,6 +872,62 @@ __global__ void orpn_loss_bwd_kernel(OrpnLossArgs a, const float* __restrict__ r
   for (int k = 0; k < 6; ++k) const_cast<float*>(a.reg[l])[reg_off + k * hw] = r[5 + k] * gb;
 }
 
+
+// ============================ OrientedHead: the sampled RoIs and their targets (oriented_head.py:426-496, :566-588) =
+// One image: the `num` sampled rows of the gt-extended proposal list -> RoIs (image index, obb), labels, label weights,
+// OrientedDeltaXYWHTCoder.encode targets (coder.py:447-470) and their weights, written into the image's rows of the batch.
+struct RoiTargetArgs {
+  const float* props;  // (n_props, stride) rows starting with (x, y, w, h, theta)
+  const float* gt;     // (k_gt, 5)
+  const long long* gt_labels;
+  const long long* inds;
+  const unsigned char* is_pos;
+  const unsigned char* val;
+  const long long* assigned;
+  int stride, k_gt, num, image, num_classes;
+  F5v mean, stdv;
+  float pos_weight;
+  float* rois;
+  long long* labels;
+  float* label_weights;
+  float* bbox_targets;
+  float* bbox_weights;
+};
+
+__global__ void roi_targets_kernel(RoiTargetArgs a) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.num) return;
+  const long long idx = a.inds[s];
+  const float* bp = idx < a.k_gt ? a.gt + idx * 5 : a.props + (idx - a.k_gt) * a.stride;
+  float p[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) p[k] = bp[k];
+  a.rois[s * 6] = (float)a.image;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) a.rois[s * 6 + 1 + k] = p[k];
+  const bool pos = a.is_pos[s] != 0, used = a.val[s] != 0;
+  a.labels[s] = pos ? a.gt_labels[a.assigned[s]] : (long long)a.num_classes;
+  a.label_weights[s] = used ? ((pos && a.pos_weight > 0.f) ? a.pos_weight : 1.f) : 0.f;
+  float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pos) {
+    const float* g = a.gt + a.assigned[s] * 5;
+    const float half_pi = 1.57079632679489661923f;
+    const float d1 = orpn_regular_theta(g[4] - p[4]), d2 = orpn_regular_theta(g[4] - p[4] + half_pi);
+    const bool first = fabsf(d1) < fabsf(d2);
+    const float gw = first ? g[2] : g[3], gh = first ? g[3] : g[2], dth = first ? d1 : d2;
+    const float c = cosf(-p[4]), sn = sinf(-p[4]);
+    const float ex = g[0] - p[0], ey = g[1] - p[1];
+    const float d[5] = {(c * ex + sn * ey) / p[2], (-sn * ex + c * ey) / p[3], logf(gw / p[2]), logf(gh / p[3]), dth};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] = (d[k] - a.mean.v[k]) / a.stdv.v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    a.bbox_targets[s * 5 + k] = t[k];
+    a.bbox_weights[s * 5 + k] = pos ? 1.f : 0.f;
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -1091,5 +1150,30 @@ extern "C" int rsdet_orpn_loss_backward_f32(const rsdet_orpn_loss* d, const floa
   if (!orpn_loss_args(d, a, false) || !rec || !grad_losses) return RSDET_EINVAL;
   const int S = d->n_img * d->num;
   hipLaunchKernelGGL(orpn_loss_bwd_kernel, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, rec, grad_losses);
+  return rsdet_launch_status();
+}
+
+// ---- OrientedHead: sampled RoIs and targets of one image --------------------------------------------------------------
+extern "C" int rsdet_orcnn_roi_targets_f32(const float* props, int prop_stride, int n_props, const float* gt,
+                                           const int64_t* gt_labels, int k_gt, const int64_t* inds, const uint8_t* is_pos,
+                                           const uint8_t* val, const int64_t* assigned, int num, int image, int num_classes,
+                                           const float* means, const float* stds, float pos_weight, float* rois,
+                                           int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
+                                           void* stream) {
+  if (num <= 0 || prop_stride < 5 || n_props < 0 || k_gt < 0 || (n_props && !props) || (k_gt && (!gt || !gt_labels)) ||
+      !inds || !is_pos || !val || !assigned || !rois || !labels || !label_weights || !bbox_targets || !bbox_weights)
+    return RSDET_EINVAL;
+  RoiTargetArgs a;
+  a.props = props, a.gt = gt, a.gt_labels = (const long long*)gt_labels, a.inds = (const long long*)inds;
+  a.is_pos = is_pos, a.val = val, a.assigned = (const long long*)assigned;
+  a.stride = prop_stride, a.k_gt = k_gt, a.num = num, a.image = image, a.num_classes = num_classes;
+  for (int k = 0; k < 5; ++k) {
+    a.mean.v[k] = means ? means[k] : 0.f;
+    a.stdv.v[k] = stds ? stds[k] : 1.f;
+  }
+  a.pos_weight = pos_weight;
+  a.rois = rois, a.labels = (long long*)labels, a.label_weights = label_weights, a.bbox_targets = bbox_targets;
+  a.bbox_weights = bbox_weights;
+  hipLaunchKernelGGL(roi_targets_kernel, dim3((num + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   return rsdet_launch_status();
 }

@@ -265,6 +265,11 @@ class OrientedHead(nn.Module):
         list lengths; targets and losses are the reference's sums over the same samples (:566-588, :426-496, :354-424).
         An unused slot still travels through RoIAlign and the FCs (as a copy of some real box) with all its weights 0."""
         dev = x[0].device
+        fused = self._targets_fused(x, proposal_list, targets)
+        if fused is not None:
+            rois, labels, lweights, btargets, bweights, n_samples = fused
+            scores, deltas, rois = self.forward_single(x, rois, test=None)
+            return self.loss(scores, deltas, rois, labels, lweights, btargets, None, bweights, num_samples=n_samples)
         rois, labels, lweights, btargets, bweights, counts = [], [], [], [], [], []
         for i, t in enumerate(targets):
             obb = torch.as_tensor(t["rboxes"]).to(dev).float().clone()
@@ -287,6 +292,48 @@ class OrientedHead(nn.Module):
         scores, deltas, rois = self.forward_single(x, rois, test=None)
         return self.loss(scores, deltas, rois, torch.cat(labels), torch.cat(lweights), torch.cat(btargets), None,
                          torch.cat(bweights), num_samples=torch.stack(counts).sum())
+
+    def _targets_fused(self, x, proposal_list, targets):
+        """The loop of _forward_train_masked with the sampler as one radix select (6 launches) and everything between the
+        samples and the RoI extractor -- gathers, arb2roi, labels, encoded targets, weights -- as one launch per image
+        (csrc/orpn.hip), written straight into the batch's rows.  None when the configuration is not the one restated."""
+        from rs_detection_amd.models.boxes.sampler import RandomSampler
+        from rs_detection_amd.ops import orpn
+        sampler, coder = self.sampler, self.bbox_coder
+        N, num = len(targets), int(sampler.num)
+        if not (orpn._ON and isinstance(sampler, RandomSampler) and sampler.add_gt_as_proposals and sampler.box_dim == 5
+                and type(coder).__name__ == "OrientedDeltaXYWHTCoder" and not self.reg_decoded_bbox and self.reg_dim == 5
+                and self.start_bbox_type == 'obb' and 0 < num <= 1024):
+            return None
+        dev = x[0].device
+        rois = torch.empty((N * num, 6), dtype=torch.float32, device=dev)
+        labels = torch.empty((N * num,), dtype=torch.int64, device=dev)
+        lweights = torch.empty((N * num,), dtype=torch.float32, device=dev)
+        btargets = torch.empty((N * num, 5), dtype=torch.float32, device=dev)
+        bweights = torch.empty((N * num, 5), dtype=torch.float32, device=dev)
+        inds = torch.empty((N, num), dtype=torch.int64, device=dev)
+        assigned = torch.empty((N, num), dtype=torch.int64, device=dev)
+        flags = torch.empty((2, N, num), dtype=torch.bool, device=dev)
+        counts = torch.empty((N, 2), dtype=torch.int64, device=dev)
+        for i, t in enumerate(targets):
+            obb = torch.as_tensor(t["rboxes"]).to(dev).float().clone()
+            obb[:, -1] *= -1
+            lab = (torch.as_tensor(t["labels"]).to(dev) - 1).long()
+            props, real = proposal_list[i]
+            if not orpn.roi_targets_apply(props, obb, lab):
+                return None
+            ar = self.assigner.assign(props, obb, None, lab)
+            K = obb.shape[0]
+            pri = sampler.priorities(props.shape[0] + K, dev)
+            if not orpn.sampler_applies(ar.gt_inds, pri, num):
+                return None
+            sample = (inds[i], flags[0, i], flags[1, i], assigned[i])
+            orpn.sample_masked(ar.gt_inds, real, K, pri, num, int(sampler.num * sampler.pos_fraction), sampler.neg_pos_ub,
+                               out=sample + (counts[i],))
+            r = slice(i * num, (i + 1) * num)
+            orpn.roi_targets(props, obb, lab, sample, i, self.num_classes, coder.means, coder.stds, self.pos_weight,
+                             (rois[r], labels[r], lweights[r], btargets[r], bweights[r]))
+        return rois, labels, lweights, btargets, bweights, counts.sum()
 
     def forward(self, x, proposal_list, targets):
         dev = x[0].device

@@ -249,3 +249,24 @@ def rpn_loss(spec, cls_scores, bbox_preds):
     L = len(cls_scores)
     out = _OrpnLoss.apply(spec, *cls_scores, *bbox_preds)
     return list(out[:L]), list(out[L:])
+
+
+# ---- OrientedHead: sampled RoIs and targets --------------------------------------------------------------------------
+def roi_targets_apply(props, gt, gt_labels):
+    return (_ON and props.is_cuda and props.dtype == torch.float32 and props.dim() == 2 and props.shape[1] >= 5
+            and props.is_contiguous() and gt.dtype == torch.float32 and gt.dim() == 2 and gt.shape[1] == 5
+            and gt_labels.dtype == torch.int64)
+
+
+def roi_targets(props, gt, gt_labels, sample, image, num_classes, means, stds, pos_weight, out):
+    """include/rsdet.h: rsdet_orcnn_roi_targets_f32.  sample = (inds, is_pos, val, assigned) rows of one image; out = (rois,
+    labels, label_weights, bbox_targets, bbox_weights) that image's rows of the batch (contiguous)."""
+    lib = _lib.load()
+    inds, is_pos, val, assigned = sample
+    gt, gt_labels = gt.contiguous(), gt_labels.contiguous()
+    assert all(t.is_contiguous() for t in out)
+    rc = lib.rsdet_orcnn_roi_targets_f32(_lib.ptr(props), props.shape[1], props.shape[0], _lib.ptr(gt), _lib.ptr(gt_labels),
+                                         gt.shape[0], _lib.ptr(inds), _lib.ptr(is_pos), _lib.ptr(val), _lib.ptr(assigned),
+                                         inds.numel(), int(image), int(num_classes), _lib.host5(means, 0.), _lib.host5(stds, 1.),
+                                         float(pos_weight), *[_lib.ptr(t) for t in out], _lib.stream_ptr())
+    _lib.check(rc, "rsdet_orcnn_roi_targets_f32")

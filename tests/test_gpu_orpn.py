@@ -146,8 +146,13 @@ def test_midpoint_decode_and_obb2hbb_equal_the_tensor_forms(cuda):
     assert same > 0.995, same
     g = got.cpu().numpy()
     assert (g[:, 2] >= g[:, 3]).all() and (g[:, 4] >= -np.pi / 2 - 1e-6).all() and (g[:, 4] < np.pi / 2 + 1e-6).all()
-    h = orpn.obb2hbb(got)
-    np.testing.assert_allclose(h.cpu().numpy(), obb2hbb(got).cpu().numpy(), rtol=1e-5, atol=2e-4)
+    h = obb2hbb(got)
+    orpn._ON = False
+    try:
+        hw = obb2hbb(got)
+    finally:
+        orpn._ON = True
+    np.testing.assert_allclose(h.cpu().numpy(), hw.cpu().numpy(), rtol=1e-5, atol=2e-4)
 
 
 def _rpn(cuda, nms_pre=2000, nms_post=2000, min_bbox_size=0):
@@ -272,3 +277,50 @@ def test_rpn_losses_on_the_samples_equal_the_dense_target_maps(cuda, monkeypatch
         assert x.shape == y.shape
         assert int((x != 0).sum()) == int((y != 0).sum())
         assert torch.allclose(x, y, rtol=1e-4, atol=1e-9), float((x - y).abs().max())
+
+
+def test_roi_head_targets_equal_the_tensor_route(cuda, monkeypatch):
+    """OrientedHead._forward_train_masked with the samples -> RoIs / labels / encoded targets as one launch per image ==
+    the same through tensor operations: both losses and the gradient reaching the pyramid."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.config import Config
+    from rs_detection_amd.models.boxes.sampler import RandomSampler
+    from rs_detection_amd.ops import orpn
+    from rs_detection_amd.utils.registry import HEADS, build_from_cfg
+    from rs_detection_amd.utils import synthetic as syn
+    cfg = Config(os.path.join(ROOT, "configs", "orcnn", "orcnn_van3_7_anchor.py")).dump()["model"]["bbox_head"]
+    torch.manual_seed(0)
+    head = build_from_cfg(cfg, HEADS).to(cuda).train()
+    rng = np.random.default_rng(4)
+    size, B, P = 512, 2, 2000
+    pri = torch.from_numpy(np.random.default_rng(1).permutation(1 << 14).astype(np.float32) / (1 << 14)).to(cuda)
+    monkeypatch.setattr(RandomSampler, "priorities", staticmethod(lambda n, dev: pri[:n]))
+    targets, props = [], []
+    for t in syn.synthetic_targets(B, img=size, num_classes=10):
+        rb = t["rboxes"][:30]
+        targets.append(dict(rboxes=torch.from_numpy(rb).to(cuda), labels=torch.from_numpy(t["labels"][:30]).to(cuda)))
+        near = rb[rng.integers(0, len(rb), P // 2)].copy()
+        near[:, 4] *= -1
+        near[:, :2] += rng.normal(0, 3, (P // 2, 2))
+        near[:, 2:4] *= np.exp(rng.normal(0, 0.1, (P // 2, 2)))
+        far = np.concatenate([rng.uniform(20, size - 20, (P - P // 2, 2)), rng.uniform(10, 90, (P - P // 2, 2)),
+                              rng.uniform(-1.5, 1.5, (P - P // 2, 1))], 1)
+        d = np.concatenate([np.concatenate([near, far]), rng.random((P, 1))], 1).astype(np.float32)
+        real = rng.random(P) < 0.9
+        props.append((torch.from_numpy(d).to(cuda), torch.from_numpy(real).to(cuda)))
+    res = []
+    for on in (True, False):
+        feats = [torch.from_numpy(np.random.default_rng(8 + l).normal(0, 1, (B, 256, size // s, size // s)).astype(np.float32))
+                 .to(cuda).requires_grad_(True) for l, s in enumerate((4, 8, 16, 32, 64))]
+        orpn._ON = on
+        try:
+            out = head._forward_train_masked(feats, props, targets)
+            (out["loss_cls"] + 2.0 * out["orcnn_bbox_loss"]).sum().backward()
+        finally:
+            orpn._ON = True
+        res.append((out, feats[0].grad))
+    (a, ga), (b, gb) = res
+    assert float(b["orcnn_bbox_loss"].sum()) > 0
+    for k in ("loss_cls", "orcnn_bbox_loss"):
+        assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), (k, a[k], b[k])
+    assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-8)
