@@ -152,6 +152,19 @@ __global__ __launch_bounds__(DW_NT) void dwconv_stencil_kernel(const float* __re
   }
 }
 
+// Sum over each row of 16 lanes, left in every lane of the row: four DPP adds (quad swaps, half-row and row mirrors) on the
+// vector pipe.  The butterfly over the whole wave (six dependent ds_bpermute round trips per value, ~400 cycles each chain)
+// was what the 7x7 weight gradient spent its time in: 49 taps x 6 of them per thread and tile.
+__device__ __forceinline__ float dw_row16_sum(float v) {
+#define DW_DPP(ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  v += DW_DPP(0xB1);   // quad_perm [1, 0, 3, 2]
+  v += DW_DPP(0x4E);   // quad_perm [2, 3, 0, 1]
+  v += DW_DPP(0x141);  // row_half_mirror
+  v += DW_DPP(0x140);  // row_mirror
+#undef DW_DPP
+  return v;
+}
+
 // partial[(c * nslots + slot) * (K*K + 1) + t], slot = n * gridDim.y + blockIdx.y; t = K*K is the bias gradient.
 // A workgroup walks `tpw` tiles of ONE plane and keeps its K*K + 1 sums in REGISTERS across them (one per thread and
 // tap); the cross-lane reduction (6 butterfly steps per tap) runs ONCE per workgroup at the end.  The first form
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_kernel(const float* __rest
   using G = DwGeom<K, D>;
   constexpr int T = K * K + 1;
   __shared__ float s[G::LH * G::LWP];
-  __shared__ float s_red[DW_NT / 64][T];
+  __shared__ float s_red[DW_NT / 16][T];
   const int plane = blockIdx.x, c = plane % C, n = plane / C;
   const int tx = threadIdx.x % DW_TW, tr = (threadIdx.x / DW_TW) * DW_ROWS;
   const float add = in_bias ? in_bias[c] : 0.f;
@@ -206,20 +219,20 @@ __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_kernel(const float* __rest
       if (K >= 7) asm volatile("" ::: "memory");               // one column window live at a time (register budget)
     }
   }
-  // one reduction per workgroup: wave butterflies, then the four waves through LDS, in a fixed order
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // one reduction per workgroup: rows of 16 lanes on the vector pipe (dw_row16_sum), then the sixteen rows through LDS
+  // in a fixed order
+  const int row16 = threadIdx.x >> 4;
+  const bool lead = (threadIdx.x & 15) == 0;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    float v = acc[t];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) s_red[wave][t] = v;
+    const float v = dw_row16_sum(acc[t]);
+    if (lead) s_red[row16][t] = v;
   }
   __syncthreads();
   if (threadIdx.x < T) {
     float v = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < DW_NT / 64; ++wv) v += s_red[wv][threadIdx.x];
+    for (int wv = 0; wv < DW_NT / 16; ++wv) v += s_red[wv][threadIdx.x];
     const int slot = n * gridDim.y + blockIdx.y;
     partial[((long long)c * nslots + slot) * T + threadIdx.x] = v;
   }
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_tile_kernel(const float* _
   using G = DwGeom<K, D>;
   constexpr int T = K * K + 1;
   __shared__ float s[G::LH * G::LWP];
-  __shared__ float s_red[DW_NT / 64][T];
+  __shared__ float s_red[DW_NT / 16][T];  // one partial per row of 16 lanes
   const int plane = blockIdx.x, c = plane % C, n = plane / C;
   const int ty0 = (blockIdx.y / tiles_x) * DW_TH, tx0 = (blockIdx.y % tiles_x) * DW_TW;
   dw_stage<K, D>(x + (long long)plane * H * W, H, W, ty0, tx0, s, in_bias ? in_bias[c] : 0.f);
@@ -252,16 +265,16 @@ __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_tile_kernel(const float* _
     }
   }
   __syncthreads();
-  // per kernel column: K partial sums (one per kernel row) over this thread's 8 outputs, reduced over the wave with
-  // butterflies and parked in LDS; the bias gradient rides along as one more value
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // per kernel column: K partial sums (one per kernel row) over this thread's 8 outputs, reduced over each row of 16
+  // lanes (dw_row16_sum) and parked in LDS; the bias gradient rides along as one more value
+  const int row16 = threadIdx.x >> 4;
+  const bool lead = (threadIdx.x & 15) == 0;
   {
     float v = 0.f;
 #pragma unroll
     for (int r = 0; r < DW_ROWS; ++r) v += g[r];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) s_red[wave][K * K] = v;
+    v = dw_row16_sum(v);
+    if (lead) s_red[row16][K * K] = v;
   }
 #pragma unroll 1
   for (int kw = 0; kw < K; ++kw) {
@@ -273,16 +286,15 @@ __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_tile_kernel(const float* _
       float v = 0.f;
 #pragma unroll
       for (int r = 0; r < DW_ROWS; ++r) v = __builtin_fmaf(g[r], win[r + kh * D], v);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) s_red[wave][kh * K + kw] = v;
+      v = dw_row16_sum(v);
+      if (lead) s_red[row16][kh * K + kw] = v;
     }
   }
   __syncthreads();
   if (threadIdx.x < T) {
     float v = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < DW_NT / 64; ++wv) v += s_red[wv][threadIdx.x];
+    for (int wv = 0; wv < DW_NT / 16; ++wv) v += s_red[wv][threadIdx.x];
     const int slot = n * gridDim.y + blockIdx.y;
     partial[((long long)c * nslots + slot) * T + threadIdx.x] = v;
   }
