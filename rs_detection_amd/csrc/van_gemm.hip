@@ -114,10 +114,35 @@ __device__ __forceinline__ void vg_acc_fence(vg_f32x4 (&acc)[MI][NI]) {
     for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+a"(acc[mi][ni]));
 }
 
+// The epilogue's side operands (the shortcut of AFFINE, the gate's u, GELU' / the gate's two factors of the backward
+// epilogues), loaded at the START of the kernel into the registers of the lanes that will consume them: their latency
+// (and the 40 - 80 MB they stream per launch) runs under the K loop instead of behind it.  Taken when the side loads were
+// two iterations deep in the epilogue's own loop: MUL1 on 1280 x 320 x 8192 88 us against 65 us for the plain GEMM.
+template <int MI, int NI, int EPI, int NT = VG_NT>
+struct VgSide {
+  static constexpr int IT = (2 * MI * 16) * (2 * NI * 16 / 4) / NT;
+  static_assert((2 * MI * 16) * (2 * NI * 16 / 4) % NT == 0, "whole epilogue iterations");
+  static constexpr bool S0 = EPI == VG_GATE2 || EPI == VG_AFFINE || EPI == VG_MUL2 || EPI == VG_MUL1;
+  static constexpr bool S1 = EPI == VG_AFFINE || EPI == VG_MUL2;
+  float4 s0[S0 ? IT : 1], s1[S1 ? IT : 1];
+  __device__ __forceinline__ void load(const VgArgs& a, int img, int m0, int p0, int tid) {
+    constexpr int CPR = 2 * NI * 16 / 4;
+    const long long obase = ((long long)img * a.M + m0) * a.P + p0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + it * NT, r = e / CPR, c4 = (e % CPR) * 4;
+      const long long o = obase + (long long)r * a.P + c4;
+      if (S0) s0[it] = *reinterpret_cast<const float4*>(a.s0 + o);
+      if (S1 && a.s1) s1[it] = *reinterpret_cast<const float4*>(a.s1 + o);
+    }
+  }
+};
+
 template <int MI, int NI, int EPI, int NT = VG_NT>
 __device__ __forceinline__ void vg_epilogue(vg_f32x4 (&acc)[MI][NI], unsigned char* lds, const VgArgs& a, int img, int m0,
-                                            int p0, int wm, int wn, int l15, int h, int tid, bool writes_acc = true) {
-  constexpr int TM = 2 * MI * 16, TN = 2 * NI * 16, CPR = TN / 4, CROW = TN + 4;
+                                            int p0, int wm, int wn, int l15, int h, int tid,
+                                            const VgSide<MI, NI, EPI, NT>& side, bool writes_acc = true) {
+  constexpr int TN = 2 * NI * 16, CPR = TN / 4, CROW = TN + 4;
   vg_wait_vm<0>();
   vg_barrier();
   float* ct = reinterpret_cast<float*>(lds);
@@ -132,9 +157,9 @@ __device__ __forceinline__ void vg_epilogue(vg_f32x4 (&acc)[MI][NI], unsigned ch
   }
   __syncthreads();
   const long long obase = ((long long)img * a.M + m0) * a.P + p0;
-#pragma unroll 2
-  for (int e = tid; e < TM * CPR; e += NT) {
-    const int r = e / CPR, c4 = (e % CPR) * 4;
+#pragma unroll
+  for (int it = 0; it < VgSide<MI, NI, EPI, NT>::IT; ++it) {
+    const int e = tid + it * NT, r = e / CPR, c4 = (e % CPR) * 4;
     const float4 v = *reinterpret_cast<const float4*>(ct + r * CROW + c4);
     const long long o = obase + (long long)r * a.P + c4;
     const int row = m0 + r;
@@ -144,25 +169,25 @@ __device__ __forceinline__ void vg_epilogue(vg_f32x4 (&acc)[MI][NI], unsigned ch
       y0 = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
       if (EPI == VG_BIAS_GELU2) y1 = make_float4(vg_gelu(y0.x), vg_gelu(y0.y), vg_gelu(y0.z), vg_gelu(y0.w));
       if (EPI == VG_GATE2) {
-        const float4 u = *reinterpret_cast<const float4*>(a.s0 + o);
+        const float4 u = side.s0[it];
         y1 = make_float4(y0.x * u.x, y0.y * u.y, y0.z * u.z, y0.w * u.w);
       }
     } else if (EPI == VG_AFFINE) {
       const float c0 = a.v0 ? a.v0[row] : 1.f, c1 = a.v1[row], c2 = a.v2[row];
-      const float4 s = *reinterpret_cast<const float4*>(a.s0 + o);
+      const float4 s = side.s0[it];
       y0 = make_float4(s.x * c0 + v.x * c1 + c2, s.y * c0 + v.y * c1 + c2, s.z * c0 + v.z * c1 + c2,
                        s.w * c0 + v.w * c1 + c2);
       if (a.s1) {
         const float c3 = a.v3[row];
-        const float4 q = *reinterpret_cast<const float4*>(a.s1 + o);
+        const float4 q = side.s1[it];
         y0.x += q.x * c3, y0.y += q.y * c3, y0.z += q.z * c3, y0.w += q.w * c3;
       }
     } else if (EPI == VG_MUL2) {
-      const float4 u = *reinterpret_cast<const float4*>(a.s0 + o), w = *reinterpret_cast<const float4*>(a.s1 + o);
+      const float4 u = side.s0[it], w = side.s1[it];
       y0 = make_float4(v.x * u.x, v.y * u.y, v.z * u.z, v.w * u.w);
       y1 = make_float4(v.x * w.x, v.y * w.y, v.z * w.z, v.w * w.w);
     } else if (EPI == VG_MUL1) {
-      const float4 x = *reinterpret_cast<const float4*>(a.s0 + o);
+      const float4 x = side.s0[it];
       y0 = make_float4(v.x * x.x, v.y * x.y, v.z * x.z, v.w * x.w);
     }
     *reinterpret_cast<float4*>(a.out0 + o) = y0;
@@ -219,6 +244,8 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
   };
   auto issue = [&](int kc) { vg_static_for<0, OPS>([&](auto k_c) { issue_one(k_c, kc); }); };
 
+  VgSide<MI, NI, EPI> side;
+  side.load(a, img, m0, p0, tid);
   vg_f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -315,7 +342,7 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
   for (; s + 3 < nk; ++s) chunk(s, C1{}, C1{}, true, true);
   for (; s < nk; ++s) chunk(s, C0{}, C0{}, false, s + 1 < nk);
   vg_acc_fence(acc);
-  vg_epilogue<MI, NI, EPI>(acc, lds, a, img, m0, p0, wm, wn, l15, h, tid);
+  vg_epilogue<MI, NI, EPI>(acc, lds, a, img, m0, p0, wm, wn, l15, h, tid, side);
 }
 
 // ---- weight gradients: U[m][n] = sum over images and pixels of g[img][m][p] * x[img][n][p]  (M rows of g, N rows of x) ----
