@@ -25,6 +25,7 @@
 //   * epilogue: the accumulator tile goes through LDS once so that every lane owns 4 consecutive pixels of one row:
 //     16-byte side-operand loads and stores, per-row constants as scalars.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -36,7 +37,7 @@ namespace rsdet {
 typedef __attribute__((ext_vector_type(4))) float vg_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned vg_u32x4;
 
-constexpr int VG_KC = 32, VG_STAGES = 3, VG_NT = 256;
+constexpr int VG_KC = 32, VG_STAGES = 2, VG_WG_STAGES = 3, VG_NT = 256;
 
 // epilogues (r = output row = channel, p = pixel; v* per-row vectors, s* side maps in the output's layout)
 constexpr int VG_NONE = 0;        // out0 = acc
@@ -197,15 +198,15 @@ __device__ __forceinline__ void vg_epilogue(vg_f32x4 (&acc)[MI][NI], unsigned ch
 
 // one workgroup per (image, pixel tile, row tile); id -> tile so that the workgroups of one XCD (ids x, x + 8, ...) walk a
 // contiguous range with the row tile fastest: the row tiles that share an x tile share it in that XCD's L2
-template <int MI, int NI, int EPI>
-__global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_tiles, int p_tiles) {
+template <int MI, int NI, int EPI, int ST>
+__global__ __launch_bounds__(VG_NT, ST == 2 ? 2 : 1) void van_gemm_f32_kernel(VgArgs a, int m_tiles, int p_tiles) {
   constexpr int TM = 2 * MI * 16, TN = 2 * NI * 16;
   constexpr int A_BYTES = TM * 128, B_BYTES = VG_KC * TN * 4, SLOT = A_BYTES + B_BYTES;
   constexpr int A_OPS = TM / 8 / 4, B_OPS = B_BYTES / 1024 / 4, OPS = A_OPS + B_OPS;     // LDS-DMA operations per wave, chunk
   constexpr int CPR = TN / 4;                        // 16-byte chunks per x-tile row
   constexpr int CROW = TN + 4;                       // the epilogue's tile in LDS: row stride in floats
-  static_assert(TM * CROW * 4 <= VG_STAGES * SLOT, "the accumulator tile must fit in the ring");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[VG_STAGES * SLOT];
+  static_assert(TM * CROW * 4 <= ST * SLOT, "the accumulator tile must fit in the ring");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[ST * SLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int total = m_tiles * p_tiles * a.n_img;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
   // LDS-DMA operation k (0 .. OPS - 1) of chunk kc
   auto issue_one = [&](auto k_c, int kc) {
     constexpr int KI = decltype(k_c)::value;
-    unsigned char* slot = lds + (kc % VG_STAGES) * SLOT;
+    unsigned char* slot = lds + (kc % ST) * SLOT;
     if constexpr (KI < A_OPS)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[KI] + kc * VG_KC),
                                        (__attribute__((address_space(3))) void*)(slot + (wave + 4 * KI) * 1024), 16, 0, 0);
@@ -291,9 +292,9 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
 
   // ---- prologue: chunks 0 .. 2 in flight, chunk 0 landed, its first group in registers
 #pragma unroll
-  for (int kc = 0; kc < VG_STAGES; ++kc)
+  for (int kc = 0; kc < ST; ++kc)
     if (kc < nk) issue(kc);
-  if (nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk == 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+  if (ST == 3 && nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk >= 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
   vg_barrier();
   vg_static_for<0, NREADS>([&](auto k_c) { read_one(C0{}, C0{}, k_c, lds_base); });
   vg_wait_lgkm0();
@@ -302,8 +303,8 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
   // takes the run-time form.
   auto chunk = [&](int s, auto dma_c, auto more_c, bool dma, bool more) {
     constexpr bool DMA_CT = decltype(dma_c)::value != 0, MORE_CT = decltype(more_c)::value != 0;
-    const unsigned slot_base = lds_base + (s % VG_STAGES) * SLOT;
-    const unsigned next_base = lds_base + ((s + 1) % VG_STAGES) * SLOT;
+    const unsigned slot_base = lds_base + (s % ST) * SLOT;
+    const unsigned next_base = lds_base + ((s + 1) % ST) * SLOT;
 #if defined(VG_ABL) && VG_ABL >= 3               // (ablation 3: MFMAs only; 4: + the barrier -- timing builds, wrong values)
     mfma_group(C0{}, [&](auto) {});
 #if VG_ABL == 4
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
     vg_wait_lgkm0();
     if (MORE_CT || more) {
       // chunk s + 1 landed (mine: all but the operations of chunk s + 2); every wave has chunk s in registers
-      if (DMA_CT || s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+      // (two stages: chunk s + 2 is not issued yet -- nothing else of mine is in flight)
+      if (ST == 3 && (DMA_CT || s + 2 < nk)) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
       vg_barrier();
     }
     // second half; between its MFMAs: the LDS-DMA of chunk s + 3 (into the slot chunk s just left), then the first reads
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
       constexpr int I = decltype(i_c)::value;
       if constexpr (I < OPS) {
 #if !defined(VG_ABL) || VG_ABL != 2              // (ablation 2: no DMA after the prologue -- a timing build, wrong values)
-        if (DMA_CT || dma) issue_one(i_c, s + 3);
+        if (DMA_CT || dma) issue_one(i_c, s + ST);
 #endif
       } else if constexpr (I - OPS < NREADS) {
         if (MORE_CT || more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
 #endif
   };
   int s = 0;
-  for (; s + 3 < nk; ++s) chunk(s, C1{}, C1{}, true, true);
+  for (; s + ST < nk; ++s) chunk(s, C1{}, C1{}, true, true);
   for (; s < nk; ++s) chunk(s, C0{}, C0{}, false, s + 1 < nk);
   vg_acc_fence(acc);
   vg_epilogue<MI, NI, EPI>(acc, lds, a, img, m0, p0, wm, wn, l15, h, tid, side);
@@ -350,15 +352,15 @@ __global__ __launch_bounds__(VG_NT, 1) void van_gemm_f32_kernel(VgArgs a, int m_
 // fragments are ds_read_b128.  Split-K over the (image, 32-pixel chunk) sequence: workgroup (split, tile) sums a contiguous
 // range of chunks and leaves its TM x 64 partial in partial[split][m][n]; the folds below sum the splits in order.
 template <int MI>
-__global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __restrict__ g, const float* __restrict__ x,
+__global__ __launch_bounds__(VG_NT, VG_WG_STAGES == 2 ? 2 : 1) void van_wgrad_f32_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                  int M, int N, int P, int n_img, int m_tiles, int n_tiles,
                                                                  int splits, float* __restrict__ partial) {
   constexpr int NI = 2, TM = 2 * MI * 16, TN = 64;
   constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, SLOT = A_BYTES + B_BYTES;
   constexpr int A_OPS = TM / 8 / 4, B_OPS = TN / 8 / 4, OPS = A_OPS + B_OPS;
   constexpr int CROW = TN + 4;
-  static_assert(TM * CROW * 4 <= VG_STAGES * SLOT, "the accumulator tile must fit in the ring");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[VG_STAGES * SLOT];
+  static_assert(TM * CROW * 4 <= VG_WG_STAGES * SLOT, "the accumulator tile must fit in the ring");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[VG_WG_STAGES * SLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = m_tiles * n_tiles, total = tiles * splits;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
   }
   auto issue_one = [&](auto k_c, int kc) {
     constexpr int KI = decltype(k_c)::value;
-    unsigned char* slot = lds + (kc % VG_STAGES) * SLOT;
+    unsigned char* slot = lds + (kc % VG_WG_STAGES) * SLOT;
     const int q = q0 + kc, img = q / cpi, px = (q - img * cpi) * VG_KC;
     if constexpr (KI < A_OPS)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[KI] + ((long long)img * M * P + px)),
@@ -428,29 +430,29 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
   using C1 = std::integral_constant<int, 1>;
   if (nk > 0) {
 #pragma unroll
-    for (int kc = 0; kc < VG_STAGES; ++kc)
+    for (int kc = 0; kc < VG_WG_STAGES; ++kc)
       if (kc < nk) issue(kc);
-    if (nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk == 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+    if (VG_WG_STAGES == 3 && nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk >= 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
     vg_barrier();
     vg_static_for<0, NREADS>([&](auto k_c) { read_one(C0{}, C0{}, k_c, lds_base); });
     vg_wait_lgkm0();
     auto chunk = [&](int s, auto dma_c, auto more_c, bool dma, bool more) {
       constexpr bool DMA_CT = decltype(dma_c)::value != 0, MORE_CT = decltype(more_c)::value != 0;
-      const unsigned slot_base = lds_base + (s % VG_STAGES) * SLOT;
-      const unsigned next_base = lds_base + ((s + 1) % VG_STAGES) * SLOT;
+      const unsigned slot_base = lds_base + (s % VG_WG_STAGES) * SLOT;
+      const unsigned next_base = lds_base + ((s + 1) % VG_WG_STAGES) * SLOT;
       mfma_group(C0{}, [&](auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < NREADS) read_one(C1{}, C1{}, i_c, slot_base);
       });
       vg_wait_lgkm0();
       if (MORE_CT || more) {
-        if (DMA_CT || s + 2 < nk) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+        if (VG_WG_STAGES == 3 && (DMA_CT || s + 2 < nk)) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
         vg_barrier();
       }
       mfma_group(C1{}, [&](auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < OPS) {
-          if (DMA_CT || dma) issue_one(i_c, s + 3);
+          if (DMA_CT || dma) issue_one(i_c, s + VG_WG_STAGES);
         } else if constexpr (I - OPS < NREADS) {
           if (MORE_CT || more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
         }
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(VG_NT, 1) void van_wgrad_f32_kernel(const float* __
       vg_wait_lgkm0();
     };
     int s = 0;
-    for (; s + 3 < nk; ++s) chunk(s, C1{}, C1{}, true, true);
+    for (; s + VG_WG_STAGES < nk; ++s) chunk(s, C1{}, C1{}, true, true);
     for (; s < nk; ++s) chunk(s, C0{}, C0{}, false, s + 1 < nk);
   }
   vg_acc_fence(acc);
@@ -775,13 +777,18 @@ __global__ __launch_bounds__(256) void van_transposes_kernel(VgTransposeJobs job
 struct VgTile {
   int mi, ni;
 };
-// the tile for (M, P): rows must divide; prefer the one that wastes no CU round
+// The tile for (M, P): rows must divide.  Two workgroups share a CU (two-slot rings, below), so that one's prologue and
+// epilogue run under the other's K loop -- which takes at least two tiles per CU: when the wide tile gives fewer than 512,
+// the tile of half the pixel width is taken (twice the tiles; the weight tile is read by twice as many workgroups, from L2).
 static bool vg_pick(int M, int K, int P, int n_img, VgTile* t) {
   if (M < 64 || K < VG_KC || (K % VG_KC) || P < 64 || n_img < 1) return false;
-  if (M % 160 == 0 && P % 64 == 0) { *t = VgTile{5, 2}; return true; }
-  if (M % 128 == 0 && P % 64 == 0) { *t = VgTile{4, 2}; return true; }
-  if (M % 64 == 0 && P % 128 == 0) { *t = VgTile{2, 4}; return true; }
-  return false;
+  if (M % 160 == 0 && P % 64 == 0) *t = VgTile{5, 2};
+  else if (M % 128 == 0 && P % 64 == 0) *t = VgTile{4, 2};
+  else if (M % 64 == 0 && P % 128 == 0) *t = VgTile{2, 4};
+  else return false;
+  const long long tiles = (long long)(M / (32 * t->mi)) * (P / (32 * t->ni)) * n_img;
+  if (tiles < 256 || (tiles < 512 && K <= 512)) t->ni /= 2;      // (a long K loop amortises its ends by itself)
+  return true;
 }
 
 }  // namespace rsdet
@@ -796,8 +803,8 @@ extern "C" int rsdet_van_gemm_f32_supported(int M, int K, int P, int n_img) {
 }
 
 #define VG_LAUNCH(MI_, NI_, EPI_)                                                                                       \
-  hipLaunchKernelGGL((van_gemm_f32_kernel<MI_, NI_, EPI_>), dim3((unsigned)(m_tiles * p_tiles * n_img)), dim3(VG_NT), 0, \
-                     (hipStream_t)stream, a, m_tiles, p_tiles)
+  hipLaunchKernelGGL((van_gemm_f32_kernel<MI_, NI_, EPI_, VG_STAGES>), dim3((unsigned)(m_tiles * p_tiles * n_img)),      \
+                     dim3(VG_NT), 0, (hipStream_t)stream, a, m_tiles, p_tiles)
 #define VG_EPI_SWITCH(MI_, NI_)                                                                                         \
   switch (epi) {                                                                                                        \
     case VG_NONE: VG_LAUNCH(MI_, NI_, VG_NONE); break;                                                                  \
@@ -806,7 +813,7 @@ extern "C" int rsdet_van_gemm_f32_supported(int M, int K, int P, int n_img) {
     case VG_GATE2: VG_LAUNCH(MI_, NI_, VG_GATE2); break;                                                                \
     case VG_AFFINE: VG_LAUNCH(MI_, NI_, VG_AFFINE); break;                                                              \
     case VG_MUL2: VG_LAUNCH(MI_, NI_, VG_MUL2); break;                                                                  \
-    default: VG_LAUNCH(MI_, NI_, VG_MUL1); break;                                                                   \
+    default: VG_LAUNCH(MI_, NI_, VG_MUL1); break;                                                                       \
   }
 
 // out (n_img, M, P) = epi(weight (M, K) . x (n_img, K, P)), all fp32, pixels contiguous.  epi (r = row, v* (M) vectors, s*
@@ -830,12 +837,18 @@ extern "C" int rsdet_van_gemm_f32(const float* weight, const float* x, int M, in
   VgArgs a{weight, x, out0, out1, s0, s1, v0, v1, v2, v3, M, K, P, n_img};
   const int m_tiles = M / (32 * t.mi), p_tiles = P / (32 * t.ni);
   if ((long long)m_tiles * p_tiles * n_img > 0x7fffffffll) return RSDET_EINVAL;
-  if (t.mi == 5) {
+  if (t.mi == 5 && t.ni == 2) {
     VG_EPI_SWITCH(5, 2)
-  } else if (t.mi == 4) {
+  } else if (t.mi == 5) {
+    VG_EPI_SWITCH(5, 1)
+  } else if (t.mi == 4 && t.ni == 2) {
     VG_EPI_SWITCH(4, 2)
-  } else {
+  } else if (t.mi == 4) {
+    VG_EPI_SWITCH(4, 1)
+  } else if (t.ni == 4) {
     VG_EPI_SWITCH(2, 4)
+  } else {
+    VG_EPI_SWITCH(2, 2)
   }
   return rsdet_launch_status();
 }
@@ -855,7 +868,10 @@ extern "C" int rsdet_van_wgrad_f32_splits(int M, int N, int P, int n_img) {
   if (!rsdet_van_wgrad_f32_supported(M, N, P, n_img)) return 0;
   const int tiles = (M / (32 * vg_wgrad_mi(M))) * (N / 64);
   const long long Q = (long long)(P / 32) * n_img;
-  long long S = 256 / tiles;            // one workgroup per CU (84 KB of LDS each): ONE round of workgroups
+  // one workgroup per CU (three-slot ring, 84 KB of LDS): ONE round of workgroups.  (Two-slot rings with two workgroups per
+  // CU and twice the splits, round 6: the weight-gradient kernels 7.06 -> 6.81 ms per Oriented R-CNN step, the folds that
+  // sum twice the partials 1.91 -> 2.32 ms -- not taken.)
+  long long S = 256 / tiles;
   if (S > Q / 4) S = Q / 4;
   if (S < 1) S = 1;
   return (int)S;
