@@ -460,8 +460,9 @@ def bn_act_rows(device, B):
 
 def next_row_kernels(device):
     """SURVEY 8(f) rows (RROIAlign of the Oriented R-CNN head, and the rank-4 ops): same HIP-event timing."""
-    from rs_detection_amd import ops
+    from rs_detection_amd import _lib, ops
     from rs_detection_amd.utils import synthetic as syn
+    lib = _lib.load()
     out = {}
 
     def row(name, by, t, bound="hbm", **kw):
@@ -503,11 +504,23 @@ def next_row_kernels(device):
         bd = torch.zeros(Cd, device=device, requires_grad=True)
         t = event_time(lambda: dwconv2d(xd.detach(), wd.detach(), bd.detach(), D), 10, 2)
         row("dwconv_stencil_kernel<%d,%d>(forward; 2x%dx%dx%d)" % (K, D, Cd, Hd, Hd), 8 * xd.numel(), t)
-        yd = dwconv2d(xd, wd, bd, D)
-        god = torch.randn_like(yd)
-        t = event_time(lambda: torch.autograd.grad(yd, (xd, wd, bd), god, retain_graph=True), 10, 2, graph=False)
+        # backward: the two C-ABI calls of ops/dwconv.py's node on preallocated buffers, replayed from a graph (device
+        # time: the autograd call of these 30-MB shapes is host-bound, which is what rounds 4-5 reported for <5,1> / <7,3>)
+        god = torch.randn_like(xd)
+        gxd, gwd, gbd = torch.empty_like(xd), torch.empty_like(wd), torch.empty_like(bd)
+        wsb = lib.rsdet_dwconv2d_backward_weight_ws_size(2, Cd, Hd, Hd, K)
+        wsd = torch.empty((max(wsb, 4),), dtype=torch.uint8, device=device)
+        xdd, wdd = xd.detach(), wd.detach()
+
+        def dw_bwd():
+            _lib.check(lib.rsdet_dwconv2d_backward_data_f32(_lib.ptr(god), _lib.ptr(wdd), 2, Cd, Hd, Hd, K, D, _lib.ptr(gxd),
+                                                            None, None, 0, _lib.stream_ptr()), "dwconv backward-data")
+            _lib.check(lib.rsdet_dwconv2d_backward_weight_f32(_lib.ptr(god), _lib.ptr(xdd), None, 2, Cd, Hd, Hd, K, D,
+                                                              _lib.ptr(gwd), _lib.ptr(gbd), _lib.ptr(wsd), wsb,
+                                                              _lib.stream_ptr()), "dwconv backward-weight")
+        t = event_time(dw_bwd, 10, 2)
         row("dwconv backward-data + backward-weight<%d,%d>" % (K, D), 16 * xd.numel(), t)
-        del xd, yd, god
+        del xd, god, gxd
     # -- FeatureRefine (f4): R3Det level 0 of two tiles, 256 channels; bytes = read + write every element once
     N, C, H = 2, 256, TILE // 8
     f = torch.randn(N, C, H, H, device=device, requires_grad=True)

@@ -697,6 +697,18 @@ int rsdet_rroi_align_v1_backward_gather_nchw_f32(const float* grad_out_t, const 
  * Same tensors and calling rules as the v1 entries above; differs in the RoI frame only (no -0.5 pixel shift of
  * the centre :76-77, opposite rotation sense :116-117).  The gather form uses
  * rsdet_rroi_align_v1_backward_gather_ws_size for its workspace. */
+/* The gather-form backward in two calls, so that the inverted index -- a function of the RoIs and the geometry, not of the
+ * gradient -- can be built at FORWARD time beside the forward kernel: _backward_index_f32 fills `ws` (sized by
+ * rsdet_rroi_align_v1_backward_gather_ws_size; count + scan + fill), rsdet_rroi_align_backward_gather_indexed_f32 is the
+ * gather alone on that workspace (nchw != 0: grad_feat (N, C, H, W), else (N, H, W, C)); the pair computes what the one-call
+ * forms above compute (same entries and weights). */
+int rsdet_rroi_align_v1_backward_index_f32(const float* rois, int R, int N, int H, int W, int PH, int PW,
+                                           float spatial_scale, int sample_num, void* ws, size_t ws_bytes, void* stream);
+int rsdet_rroi_align_v0_backward_index_f32(const float* rois, int R, int N, int H, int W, int PH, int PW,
+                                           float spatial_scale, int sample_num, void* ws, size_t ws_bytes, void* stream);
+int rsdet_rroi_align_backward_gather_indexed_f32(const float* grad_out_t, int R, int C, int N, int H, int W, int PH, int PW,
+                                                 int sample_num, int nchw, float* grad_feat, const void* ws, size_t ws_bytes,
+                                                 void* stream);
 int rsdet_rroi_align_v0_forward_f32(const float* feat, const float* rois, int R, int C, int H,
                                     int W, int PH, int PW, float spatial_scale, int sample_num,
                                     float* out, void* stream);

@@ -132,6 +132,12 @@ SIGNATURES = {
     "rsdet_orcnn_roi_targets_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_rroi_align_v1_backward_index_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                                       c_void_p, c_size_t, c_void_p]),
+    "rsdet_rroi_align_v0_backward_index_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                                       c_void_p, c_size_t, c_void_p]),
+    "rsdet_rroi_align_backward_gather_indexed_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                             c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rsdet_van_block_supported": (c_int, [c_void_p]),
     "rsdet_van_block_side_stream": (c_int, [c_int]),
     "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),

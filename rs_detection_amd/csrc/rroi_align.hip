@@ -466,39 +466,91 @@ extern "C" size_t rsdet_rroi_align_v1_backward_gather_ws_size(int R, int PH, int
   return rroi_align256((npix + 1) * 4) * 2 + rroi_align256(ent * 4) * 2 + rroi_align256((npix / 4096 + 1) * 4);
 }
 
-static int rroi_backward_gather(const float* grad_out_t, const float* rois, int R, int C, int N, int H, int W, int PH,
-                                int PW, float spatial_scale, int sample_num, int v0, float* grad_feat_nhwc, void* ws,
-                                size_t ws_bytes, void* stream, bool nchw = false) {
+struct RroiWs {
+  int *cnt, *start, *ent_row, *chunk_sum;
+  float* ent_w;
+};
+static RroiWs rroi_ws(void* ws, long long npix, long long items) {
+  char* w = (char*)ws;
+  RroiWs o;
+  o.cnt = (int*)w;
+  o.start = (int*)(w + rroi_align256((npix + 1) * 4));
+  o.ent_row = (int*)(w + rroi_align256((npix + 1) * 4) * 2);
+  o.ent_w = (float*)(w + rroi_align256((npix + 1) * 4) * 2 + rroi_align256((size_t)items * 16));
+  o.chunk_sum = (int*)(w + rroi_align256((npix + 1) * 4) * 2 + rroi_align256((size_t)items * 16) * 2);
+  return o;
+}
+
+static int rroi_gather_args(int R, int C, int N, int H, int W, int PH, int PW, int sample_num, const void* ws,
+                            size_t ws_bytes, long long* items) {
   int rc = rroi_check(R, C, H, W, PH, PW);
   if (rc) return rc;
   if (sample_num < 1 || N < 1) return RSDET_EINVAL;  // adaptive sampling (sample_num <= 0): use the scatter form
-  const long long npix = (long long)N * H * W;
-  if (C == 0) return RSDET_OK;
-  if (!grad_feat_nhwc || (R > 0 && (!grad_out_t || !rois))) return RSDET_EINVAL;
-  const long long items = (long long)R * PH * PW * sample_num * sample_num;
-  if (items * 4 > 0x7fffffffLL) return RSDET_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  if (R == 0) return hipMemsetAsync(grad_feat_nhwc, 0, (size_t)npix * C * 4, s) == hipSuccess ? RSDET_OK : RSDET_ELAUNCH;
-  if (!ws || ((uintptr_t)ws & 15) || ws_bytes < rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sample_num, N, H, W))
+  *items = (long long)R * PH * PW * sample_num * sample_num;
+  if (*items * 4 > 0x7fffffffLL) return RSDET_EINVAL;
+  if (R > 0 && (!ws || ((uintptr_t)ws & 15) ||
+                ws_bytes < rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sample_num, N, H, W)))
     return RSDET_EINVAL;
-  char* w = (char*)ws;
-  int* cnt = (int*)w;
-  int* start = (int*)(w + rroi_align256((npix + 1) * 4));
-  int* ent_row = (int*)(w + rroi_align256((npix + 1) * 4) * 2);
-  float* ent_w = (float*)(w + rroi_align256((npix + 1) * 4) * 2 + rroi_align256((size_t)items * 16));
-  int* chunk_sum = (int*)(w + rroi_align256((npix + 1) * 4) * 2 + rroi_align256((size_t)items * 16) * 2);
-  if (hipMemsetAsync(cnt, 0, (size_t)(npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+  return RSDET_OK;
+}
+
+// The inverted index (pixel -> the (RoI, bin) rows that touch it, with their weights) of the gather-form backward.  It
+// depends on the RoIs and the geometry only -- not on the gradient -- so the caller may build it at FORWARD time, on a
+// side stream beside the forward kernel (ops/roi_align_rotated_v1.py does), and hand the workspace to the gather later.
+static int rroi_backward_index(const float* rois, int R, int N, int H, int W, int PH, int PW, float spatial_scale,
+                               int sample_num, int v0, void* ws, size_t ws_bytes, void* stream) {
+  long long items;
+  int rc = rroi_gather_args(R, 1, N, H, W, PH, PW, sample_num, ws, ws_bytes, &items);
+  if (rc) return rc;
+  if (R == 0) return RSDET_OK;
+  if (!rois) return RSDET_EINVAL;
+  const long long npix = (long long)N * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  const RroiWs o = rroi_ws(ws, npix, items);
+  if (hipMemsetAsync(o.cnt, 0, (size_t)(npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
   const unsigned ib = (unsigned)((items + 255) / 256);
   hipLaunchKernelGGL(rroi_idx_count_kernel, dim3(ib), dim3(256), 0, s, rois, items, H, W, PH, PW, spatial_scale,
-                     sample_num, v0, npix, cnt);
-  rsdet_launch_index_scan(cnt, npix, chunk_sum, start, s);
+                     sample_num, v0, npix, o.cnt);
+  rsdet_launch_index_scan(o.cnt, npix, o.chunk_sum, o.start, s);
   hipLaunchKernelGGL(rroi_idx_fill_kernel, dim3(ib), dim3(256), 0, s, rois, items, H, W, PH, PW, spatial_scale,
-                     sample_num, v0, npix, start, cnt, ent_row, ent_w);
-  if (nchw)
-    launch_pixel_gather_nchw(grad_out_t, start, ent_row, ent_w, npix, C, H * W, grad_feat_nhwc, s);
-  else
-    rsdet_launch_pixel_gather(grad_out_t, start, ent_row, ent_w, npix, C, grad_feat_nhwc, s);
+                     sample_num, v0, npix, o.start, o.cnt, o.ent_row, o.ent_w);
   return rsdet_launch_status();
+}
+
+static int rroi_backward_gather_indexed(const float* grad_out_t, int R, int C, int N, int H, int W, int PH, int PW,
+                                        int sample_num, float* grad_feat, const void* ws, size_t ws_bytes, void* stream,
+                                        bool nchw) {
+  long long items;
+  int rc = rroi_gather_args(R, C, N, H, W, PH, PW, sample_num, ws, ws_bytes, &items);
+  if (rc) return rc;
+  const long long npix = (long long)N * H * W;
+  if (C == 0) return RSDET_OK;
+  if (!grad_feat || (R > 0 && !grad_out_t)) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (R == 0) return hipMemsetAsync(grad_feat, 0, (size_t)npix * C * 4, s) == hipSuccess ? RSDET_OK : RSDET_ELAUNCH;
+  const RroiWs o = rroi_ws(const_cast<void*>(ws), npix, items);
+  if (nchw)
+    launch_pixel_gather_nchw(grad_out_t, o.start, o.ent_row, o.ent_w, npix, C, H * W, grad_feat, s);
+  else
+    rsdet_launch_pixel_gather(grad_out_t, o.start, o.ent_row, o.ent_w, npix, C, grad_feat, s);
+  return rsdet_launch_status();
+}
+
+static int rroi_backward_gather(const float* grad_out_t, const float* rois, int R, int C, int N, int H, int W, int PH,
+                                int PW, float spatial_scale, int sample_num, int v0, float* grad_feat_nhwc, void* ws,
+                                size_t ws_bytes, void* stream, bool nchw = false) {
+  if (C == 0) return rroi_check(R, C, H, W, PH, PW);
+  int rc = rroi_backward_index(rois, R, N, H, W, PH, PW, spatial_scale, sample_num, v0, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return rroi_backward_gather_indexed(grad_out_t, R, C, N, H, W, PH, PW, sample_num, grad_feat_nhwc, ws, ws_bytes, stream,
+                                      nchw);
+}
+
+extern "C" int rsdet_rroi_align_backward_gather_indexed_f32(const float* grad_out_t, int R, int C, int N, int H, int W,
+                                                            int PH, int PW, int sample_num, int nchw, float* grad_feat,
+                                                            const void* ws, size_t ws_bytes, void* stream) {
+  return rroi_backward_gather_indexed(grad_out_t, R, C, N, H, W, PH, PW, sample_num, grad_feat, ws, ws_bytes, stream,
+                                      nchw != 0);
 }
 
 #define RSDET_RROI_ENTRY(tag, v0)                                                                                     \
@@ -517,6 +569,11 @@ static int rroi_backward_gather(const float* grad_out_t, const float* rois, int 
       float spatial_scale, int sample_num, float* grad_feat_nhwc, void* ws, size_t ws_bytes, void* stream) {         \
     return rroi_backward_gather(grad_out_t, rois, R, C, N, H, W, PH, PW, spatial_scale, sample_num, v0,              \
                                 grad_feat_nhwc, ws, ws_bytes, stream);                                               \
+  }                                                                                                                   \
+  extern "C" int rsdet_rroi_align_##tag##_backward_index_f32(const float* rois, int R, int N, int H, int W, int PH,  \
+                                                             int PW, float spatial_scale, int sample_num, void* ws, \
+                                                             size_t ws_bytes, void* stream) {                       \
+    return rroi_backward_index(rois, R, N, H, W, PH, PW, spatial_scale, sample_num, v0, ws, ws_bytes, stream);      \
   }                                                                                                                   \
   extern "C" int rsdet_rroi_align_##tag##_backward_gather_nchw_f32(                                                   \
       const float* grad_out_t, const float* rois, int R, int C, int N, int H, int W, int PH, int PW,                  \

@@ -3,6 +3,8 @@
 Mirror of /root/reference/python/jdet/ops/roi_align_rotated_v1.py:300-373;
 kernels in csrc/rroi_align.hip.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -39,6 +41,10 @@ class _RotatedROIAlign_v1(torch.autograd.Function):
         rc = getattr(lib, name)(_lib.ptr(input), _lib.ptr(rois), R, C, H, W, output_size[0], output_size[1],
                                 float(spatial_scale), int(sampling_ratio), _lib.ptr(out), _lib.stream_ptr())
         _lib.check(rc, name)
+        ctx.index = None
+        if _INDEX_AT_FORWARD and ctx.needs_input_grad[0] and sampling_ratio > 0 and R > 0 and C % 4 == 0 \
+                and not torch.cuda.is_current_stream_capturing():
+            ctx.index = _build_index(lib, rois, N, H, W, output_size, float(spatial_scale), int(sampling_ratio), variant)
         return out
 
     @staticmethod
@@ -46,16 +52,61 @@ class _RotatedROIAlign_v1(torch.autograd.Function):
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors
         shape, output_size, scale, sr, variant = ctx.cfg
-        return rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant), None, None, None, None, None
+        return (rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant, index=ctx.index),
+                None, None, None, None, None)
 
 
-def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant="v1"):
+# True: the backward's inverted index is built at forward time on a side stream (_build_index).  Measured on the Oriented
+# R-CNN / VAN-B3 step (round 6, same box, two runs each): 51.9 ms with the index built in the backward call, 53.7 - 53.8 ms
+# with the side stream -- the cross-stream edges and the kernels that now run beside the forward cost more than the ~55 us
+# per call they take out of the backward.  Off; the split entry points stay (tests/test_gpu_ops.py pins them).
+_INDEX_AT_FORWARD = False
+_SIDE = {}                   # device index -> the side stream the indices are built on
+
+
+def _build_index(lib, rois, N, H, W, output_size, scale, sr, variant):
+    """The inverted index of the gather-form backward (pixel -> (RoI, bin) rows and weights: a function of the RoIs and the
+    geometry only), built NOW on a side stream beside the forward kernel instead of in front of the backward's gather,
+    where its four small launches (count, scan, fill + a clear: ~55 us) were 40 % of the backward call.  Returns
+    (workspace, event recorded behind the build)."""
+    dev = rois.device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE.get(dev.index)
+    if side is None:
+        side = _SIDE[dev.index] = torch.cuda.Stream(dev)
+    R, PH, PW = rois.shape[0], output_size[0], output_size[1]
+    ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)
+    side.wait_stream(main)                                  # the RoIs are ready
+    with torch.cuda.stream(side):
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        name = "rsdet_rroi_align_%s_backward_index_f32" % variant
+        rc = getattr(lib, name)(_lib.ptr(rois), R, N, H, W, PH, PW, scale, sr, _lib.ptr(ws), ws_bytes,
+                                ctypes.c_void_p(side.cuda_stream))
+        _lib.check(rc, name)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    rois.record_stream(side)
+    return ws, ws_bytes, ev
+
+
+def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant="v1", index=None):
     """grad_feat (N,C,H,W) of _RotatedROIAlign_v1 (roi_align_rotated_v1.py:329-351); a plain function so that the bench
-    can replay it from a hipGraph (device time, like the forward rows)."""
+    can replay it from a hipGraph (device time, like the forward rows).  ``index``: what _build_index left at forward time."""
     lib = _lib.load()
     N, C, H, W = shape
     go = grad_output.contiguous()
     R, PH, PW = rois.shape[0], output_size[0], output_size[1]
+    if index is not None and sr > 0 and R > 0 and C % 4 == 0:
+        ws, ws_bytes, ev = index
+        main = torch.cuda.current_stream(go.device)
+        main.wait_event(ev)
+        ws.record_stream(main)
+        go_t = transpose_last2(go.view(R, C, PH * PW))
+        g = torch.empty((N, C, H, W), dtype=go.dtype, device=go.device)
+        rc = lib.rsdet_rroi_align_backward_gather_indexed_f32(_lib.ptr(go_t), R, C, N, H, W, PH, PW, sr, 1, _lib.ptr(g),
+                                                              _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+        _lib.check(rc, "rsdet_rroi_align_backward_gather_indexed_f32")
+        return g
     if sr > 0 and R > 0:
         # gather form: no fp32 atomics (csrc/rroi_align.hip).  The gradient rows are turned channels-last once (small);
         # the result is written in NCHW directly by the tiled gather (rroi_gather_nchw_tile_kernel: 147 us for the call at

@@ -1047,6 +1047,7 @@ def test_rroi_backward_nchw_form_equals_channels_last_form(cuda, monkeypatch):
         grads = []
         import importlib
         rroi_mod = importlib.import_module("rs_detection_amd.ops.roi_align_rotated_v1")   # (the package attribute is the function)
+        monkeypatch.setattr(rroi_mod, "_INDEX_AT_FORWARD", False)       # (the indexed route always writes NCHW)
         for flag in (False, True):
             monkeypatch.setattr(rroi_mod, "_NCHW_GATHER", flag)
             f = feat.clone().requires_grad_(True)
@@ -1054,6 +1055,36 @@ def test_rroi_backward_nchw_form_equals_channels_last_form(cuda, monkeypatch):
             grads.append(f.grad)
         # same entries, same weights; the two kernels pair the additions differently (1-2 ulp)
         assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
+
+
+def test_rroi_backward_index_built_at_forward_time_equals_the_one_call_form(cuda, monkeypatch):
+    """The inverted index of the gather-form backward built on a side stream at forward time
+    (rsdet_rroi_align_v*_backward_index_f32 + rsdet_rroi_align_backward_gather_indexed_f32) gives the one-call form's
+    gradient -- both variants, several calls in flight before any backward runs."""
+    import importlib
+    from rs_detection_amd.ops import roi_align_rotated_v1
+    from rs_detection_amd.ops.roi_align_rotated import roi_align as roi_align_rotated
+    rroi_mod = importlib.import_module("rs_detection_amd.ops.roi_align_rotated_v1")
+    rng = np.random.default_rng(18)
+    cases = []
+    for (N, C, H, W, R) in ((2, 256, 64, 64, 60), (1, 20, 37, 41, 9), (2, 64, 128, 128, 300), (1, 512, 23, 27, 30)):
+        feat = _t(rng.standard_normal((N, C, H, W)).astype(np.float32), cuda)
+        rois = _t(_rois(rng, R, N, W * 4), cuda)
+        go = _t(rng.standard_normal((R, C, 7, 7)).astype(np.float32), cuda)
+        cases.append((feat, rois, go))
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(rroi_mod, "_INDEX_AT_FORWARD", flag)
+        grads = []
+        for fn in (roi_align_rotated_v1, roi_align_rotated):
+            leaves = [c[0].clone().requires_grad_(True) for c in cases]
+            outs = [fn(f, c[1], (7, 7), 0.25, 2) for f, c in zip(leaves, cases)]       # all forwards first
+            for o, c in zip(outs, cases):
+                o.backward(c[2])
+            grads += [f.grad for f in leaves]
+        res.append(grads)
+    for a, b in zip(*res):            # same entries and weights; their order inside a pixel follows the fill's atomics
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
