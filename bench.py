@@ -106,7 +106,7 @@ def event_time(fn, iters, warmup=3, graph=True):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-ROOFLINE_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_roofline.json" % r) for r in (5, 4, 3, 2))
+ROOFLINE_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_roofline.json" % r) for r in (6, 5, 4, 3, 2))
                       if os.path.exists(f)), os.path.join(ROOT, "profiles", "r05_roofline.json"))
 # `traffic` (PMC bytes) and `issue` (SQ counters) of the roofline objects are NOT measured by this process (rocprofv3
 # counter passes cannot run inside it): they are read from the committed counter table and labelled so in the line
@@ -304,6 +304,7 @@ def kernel_rooflines(device, targets):
     out.update(bn_act_rows(device, len(ks)))
     out.update(gemm1x1_rows(device, len(ks)))
     out.update(next_row_kernels(device))
+    out.update(van_rows(device))
     out.update(survey_8d_rows(device))
     return out
 
@@ -378,6 +379,72 @@ def eval_leg(device, steps=10):
                                         "host_enqueue_ms_per_call": t_enq / steps * 1e3}
         del r
         torch.cuda.empty_cache()
+    return out
+
+
+def van_rows(device):
+    """Round 6: the fp32 MFMA GEMM and weight gradient of the VAN block (csrc/van_gemm.hip) at the stage-3 shapes of the
+    Oriented R-CNN step (2 images, 64 x 64 positions, C = 320, R = 1280), and the kernels of the heads' control path
+    (csrc/orpn.hip): the radix-select sampler over the RPN's 611 072 anchors and the proposals of a batch.  GEMM rows are
+    MFMA-bound (fp32 dense peak); the control-path rows are latency-bound -- their `frac` is of HBM, for the record."""
+    from rs_detection_amd import _lib as _L
+    from rs_detection_amd.ops import orpn
+    lib = _L.load()
+    out = {}
+    P = _L.ptr
+    N, C, R, HW = 2, 320, 1280, 64 * 64
+    x = torch.randn(N, C, HW, device=device)
+    h = torch.randn(N, R, HW, device=device)
+    w_rc, w_cr, w_cc = (torch.randn(a, b, device=device) * 0.05 for a, b in ((R, C), (C, R), (C, C)))
+    v = [torch.rand(R, device=device) for _ in range(3)]
+    o_r, o_c, o_c1 = torch.empty(N, R, HW, device=device), torch.empty(N, C, HW, device=device), torch.empty(N, C, HW, device=device)
+
+    def mfma_row(name, flops, t):
+        out[name] = dict(bound="mfma", achieved=flops / t / 1e12, peak=FP32_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                         frac=flops / t / 1e12 / FP32_VALU_PEAK_TFLOPS, traffic=None, us=t * 1e6)
+    f_cr, f_cc = 2.0 * N * HW * C * R, 2.0 * N * HW * C * C
+    calls = (
+        ("van_gemm_f32 fc1 1280x320x8192 (+ bias)", f_cr,
+         lambda: lib.rsdet_van_gemm_f32(P(w_rc), P(x), R, C, HW, N, 1, P(v[0]), None, None, None, None, None, P(o_r), None, _L.stream_ptr())),
+        ("van_gemm_f32 fc2 320x1280x8192 (+ layer scale + shortcut)", f_cr,
+         lambda: lib.rsdet_van_gemm_f32(P(w_cr), P(h), C, R, HW, N, 4, None, P(v[1]), P(v[2]), None, P(x), None, P(o_c), None, _L.stream_ptr())),
+        ("van_gemm_f32 proj_1 320x320x8192 (+ bias + GELU, two outputs)", f_cc,
+         lambda: lib.rsdet_van_gemm_f32(P(w_cc), P(x), C, C, HW, N, 2, P(v[0]), None, None, None, None, None, P(o_c), P(o_c1), _L.stream_ptr())),
+        ("van_gemm_f32 fc2 backward-data 1280x320x8192 (x GELU')", f_cr,
+         lambda: lib.rsdet_van_gemm_f32(P(w_rc), P(x), R, C, HW, N, 6, None, None, None, None, P(h), None, P(o_r), None, _L.stream_ptr())),
+    )
+    for name, fl, fn in calls:
+        mfma_row(name, fl, event_time(fn, 10, 2))
+    S = max(lib.rsdet_van_wgrad_f32_splits(C, R, HW, N) * C * R, lib.rsdet_van_wgrad_f32_splits(C, C, HW, N) * C * C)
+    part = torch.empty(S, device=device)
+    mfma_row("van_wgrad_f32 320x1280 over 8192 pixels (split-K partials)", f_cr,
+             event_time(lambda: lib.rsdet_van_wgrad_f32(P(x), P(h), C, R, HW, N, P(part), _L.stream_ptr()), 10, 2))
+    mfma_row("van_wgrad_f32 320x320 over 8192 pixels (split-K partials)", f_cc,
+             event_time(lambda: lib.rsdet_van_wgrad_f32(P(x), P(o_c), C, C, HW, N, P(part), _L.stream_ptr()), 10, 2))
+    del x, h, o_r, o_c, o_c1, part
+    # -- the heads' control path
+    rng = np.random.default_rng(3)
+    n_a = 611072
+    gti = torch.from_numpy(np.where(rng.random(n_a) < 0.002, 1, np.where(rng.random(n_a) < 0.9, 0, -1)).astype(np.int32)).to(device)
+    pri = torch.rand(n_a, device=device)
+    t = event_time(lambda: orpn.sample_masked(gti, None, 0, pri, 256, 128, -1.0), 10, 2)
+    out["sample_masked(radix select: 256 of 611 072 anchors; memset + 3 counting passes + emit + final)"] = dict(
+        bound="latency", achieved=8 * n_a / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=8 * n_a / t / 1e9 / HBM_PEAK_GBS,
+        traffic=None, us=t * 1e6)
+    A, sizes = 7, [(256, 256), (128, 128), (64, 64), (32, 32), (16, 16)]
+    sc = [torch.rand(2, hh, ww, A, device=device) for hh, ww in sizes]
+    rg = [torch.randn(2, 6 * A, hh, ww, device=device) * 0.3 for hh, ww in sizes]
+    an = []
+    for (hh, ww), st in zip(sizes, (4, 8, 16, 32, 64)):
+        cy, cx = torch.meshgrid(torch.arange(hh, device=device) * st + st / 2, torch.arange(ww, device=device) * st + st / 2, indexing="ij")
+        c = torch.stack([cx, cy, cx, cy], -1).reshape(-1, 1, 4).float()
+        half = torch.tensor([[-4., -4., 4., 4.]], device=device) * st * torch.linspace(0.5, 2.0, A, device=device)[:, None]
+        an.append((c + half[None]).reshape(-1, 4).contiguous())
+    t = event_time(lambda: orpn.proposals(sc, rg, an, 2000, 2000, 0.8, 0, None, (1., 1., 1., 1., .5, .5), 4.135), 5, 2)
+    by = sum(4 * 2 * A * hh * ww * 7 for hh, ww in sizes)
+    out["orpn_proposals(2 images x 5 levels, 611 072 anchors each -> 2 x 2000 rows; 12 launches)"] = dict(
+        bound="latency", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS, traffic=None,
+        us=t * 1e6)
     return out
 
 

@@ -280,7 +280,57 @@ for _ in range(3):
     _ops.feature_refine(ff, bxf, 0.125, 1)
 ALG5["fr_forward_nhwc_kernel<5>"] = dict(call="fr_forward_nhwc<5>", bytes=4 * (2 * Nf * Cf * Hf * Hf + 5 * Nf * Hf * Hf))
 ALG5["fr_forward_nhwc_kernel<1>"] = dict(call="fr_forward_nhwc<1>", bytes=4 * (2 * Nf * Cf * Hf * Hf + 5 * Nf * Hf * Hf))
+# ---- round 6: the fp32 MFMA GEMMs / weight gradients of the VAN block (csrc/van_gemm.hip) at the stage-3 shapes of the
+# Oriented R-CNN step (2 images, 64 x 64, C = 320, R = 1280), the depthwise weight gradients, the radix-select sampler and
+# the batched proposal kernels (csrc/orpn.hip)
+Nv, Cv, Rv, Pv = 2, 320, 1280, 64 * 64
+xv = torch.randn(Nv, Cv, Pv, device=dev)
+hv = torch.randn(Nv, Rv, Pv, device=dev)
+wcr = torch.randn(Rv, Cv, device=dev) * 0.05
+wrc = torch.randn(Cv, Rv, device=dev) * 0.05
+wcc = torch.randn(Cv, Cv, device=dev) * 0.05
+vv = [torch.rand(Rv, device=dev) for _ in range(4)]
+ov = torch.empty(Nv, Rv, Pv, device=dev)
+oc, oc1 = torch.empty(Nv, Cv, Pv, device=dev), torch.empty(Nv, Cv, Pv, device=dev)
+S_cr, S_cc = _lib_.rsdet_van_wgrad_f32_splits(Cv, Rv, Pv, Nv), _lib_.rsdet_van_wgrad_f32_splits(Cv, Cv, Pv, Nv)
+part = torch.empty(max(S_cr * Cv * Rv, S_cc * Cv * Cv), device=dev)
+P_ = _L.ptr
+for _ in range(4):
+    # fc1 (bias), fc2 (affine: layer scale + shortcut), proj_1 (bias + GELU, two outputs), the MLP's backward-data with GELU'
+    _lib_.rsdet_van_gemm_f32(P_(wcr), P_(xv), Rv, Cv, Pv, Nv, 1, P_(vv[0]), None, None, None, None, None, P_(ov), None, _L.stream_ptr())
+    _lib_.rsdet_van_gemm_f32(P_(wrc), P_(hv), Cv, Rv, Pv, Nv, 4, None, P_(vv[1]), P_(vv[2]), None, P_(xv), None, P_(oc), None, _L.stream_ptr())
+    _lib_.rsdet_van_gemm_f32(P_(wcc), P_(xv), Cv, Cv, Pv, Nv, 2, P_(vv[0]), None, None, None, None, None, P_(oc), P_(oc1), _L.stream_ptr())
+    _lib_.rsdet_van_gemm_f32(P_(wcr), P_(xv), Rv, Cv, Pv, Nv, 6, None, None, None, None, P_(hv), None, P_(ov), None, _L.stream_ptr())
+    _lib_.rsdet_van_wgrad_f32(P_(xv), P_(hv), Cv, Rv, Pv, Nv, P_(part), _L.stream_ptr())
+    _lib_.rsdet_van_wgrad_f32(P_(xv), P_(oc), Cv, Cv, Pv, Nv, P_(part), _L.stream_ptr())
+f_cr, f_cc = 2.0 * Nv * Pv * Cv * Rv, 2.0 * Nv * Pv * Cv * Cv
+ALG6 = {
+    "van_gemm_f32_kernel<5, 2, 1": dict(call="van_gemm fc1 1280 x 320 x 8192 (bias)", bytes=4 * (Nv * Pv * (Cv + Rv) + Cv * Rv), flops=f_cr),
+    "van_gemm_f32_kernel<5, 2, 4": dict(call="van_gemm fc2 320 x 1280 x 8192 (layer scale + shortcut)", bytes=4 * (Nv * Pv * (Rv + 2 * Cv) + Cv * Rv), flops=f_cr),
+    "van_gemm_f32_kernel<5, 1, 2": dict(call="van_gemm proj_1 320 x 320 x 8192 (bias + GELU, two outputs)", bytes=4 * (Nv * Pv * 3 * Cv + Cv * Cv), flops=f_cc),
+    "van_gemm_f32_kernel<5, 2, 6": dict(call="van_gemm fc2 backward-data 1280 x 320 x 8192 (x GELU')", bytes=4 * (Nv * Pv * (Cv + 2 * Rv) + Cv * Rv), flops=f_cr),
+    "van_wgrad_f32_kernel<5>": dict(call="van_wgrad 320 x 1280 and 320 x 320 over 8192 pixels (split-K partials)",
+                                    bytes=4 * (Nv * Pv * (2 * Cv + Rv + Cv) + S_cr * Cv * Rv + S_cc * Cv * Cv), flops=f_cr + f_cc),
+}
+for (Cd, Hd, K, D) in ((1280, 64, 3, 1), (320, 64, 5, 1), (320, 64, 7, 3)):
+    xd, god = torch.randn(2, Cd, Hd, Hd, device=dev), torch.randn(2, Cd, Hd, Hd, device=dev)
+    gwd, gbd = torch.empty(Cd, 1, K, K, device=dev), torch.empty(Cd, device=dev)
+    wsb = _lib_.rsdet_dwconv2d_backward_weight_ws_size(2, Cd, Hd, Hd, K)
+    wsd = torch.empty((max(wsb, 4),), dtype=torch.uint8, device=dev)
+    for _ in range(4):
+        _lib_.rsdet_dwconv2d_backward_weight_f32(P_(god), P_(xd), None, 2, Cd, Hd, Hd, K, D, P_(gwd), P_(gbd), P_(wsd), wsb, _L.stream_ptr())
+    key = "dwconv_wgrad_tile_kernel<7, 3>" if K == 7 else "dwconv_wgrad_kernel<%d, 1>" % K
+    ALG6[key] = dict(call="dwconv backward-weight<%d,%d> 2 x %d x 64 x 64" % (K, D, Cd), bytes=4 * 2 * 2 * Cd * Hd * Hd)
+from rs_detection_amd.ops import orpn as _orpn
+n_a = 611072
+gti = torch.from_numpy(np.where(rng.random(n_a) < 0.002, 1, np.where(rng.random(n_a) < 0.9, 0, -1)).astype(np.int32)).to(dev)
+pri = torch.rand(n_a, device=dev)
+for _ in range(4):
+    _orpn.sample_masked(gti, None, 0, pri, 256, 128, -1.0)
+for kname in ("sel_hist_kernel<unsigned int, 2", "sel_emit_kernel<unsigned int, 2", "sampler_final_kernel"):
+    ALG6[kname] = dict(call="sample_masked: 256 of 611 072 anchors (3 counting passes + emit + final)", bytes=4 * 8 * n_a)
+ALG5.update(ALG6)
 # (the plain conv3x3 key of round 4 is a substring of the gated kernel's name: give the more specific key precedence)
 ALG = dict(list(ALG5.items()) + [(k, v) for k, v in ALG.items()])
 json.dump(ALG, open(os.path.join(os.environ.get("RSDET_ROOFLINE_DIR", "."), "alg_bytes.json"), "w"), indent=1)
-torch.cuda.synchronize(); print("done (round 5 additions)")
+torch.cuda.synchronize(); print("done (round 5 + 6 additions)")
