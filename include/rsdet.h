@@ -532,6 +532,18 @@ typedef struct rsdet_van_block {
   void* nbt2;
   float eps1, mom1, eps2, mom2;
 } rsdet_van_block;
+/* Up to three rsdet_van_fold_rows_f32 folds in ONE launch (the block node's row folds feed nothing in its backward's data
+ * chain and are issued together behind it). */
+int rsdet_van_fold_rows_multi_f32(const rsdet_van_rows_fold* jobs, int n, void* stream);
+/* The depthwise weight gradient (rsdet_dwconv2d_backward_weight_f32) in two calls: _partial_f32 leaves the per-tile partial
+ * rows in ws (rsdet_dwconv2d_backward_weight_ws_size bytes; N >= 1), rsdet_dwconv2d_wgrad_finish_multi_f32 sums the
+ * partials of up to four layers (arrays of n entries: workspace, N, C, H, W, K, grad_weight, grad_bias or NULL) in one
+ * launch -- fixed order, the same values as the one-call form. */
+int rsdet_dwconv2d_backward_weight_partial_f32(const float* grad_y, const float* x, const float* in_bias, int N, int C, int H,
+                                               int W, int K, int dilation, void* ws, size_t ws_bytes, void* stream);
+int rsdet_dwconv2d_wgrad_finish_multi_f32(int n, const void* const* ws, const int* N, const int* C, const int* H,
+                                          const int* W, const int* K, float* const* grad_weight, float* const* grad_bias,
+                                          void* stream);
 int rsdet_van_block_supported(const rsdet_van_block* b);
 /* 1: the backward's weight gradients, their folds and the depthwise weight gradients run on a side stream beside the chain
  * that produces grad_x (joined before the call returns control of the buffers to `stream`); 0 (default: measured 2.5 %

@@ -138,6 +138,11 @@ SIGNATURES = {
                                                        c_void_p, c_size_t, c_void_p]),
     "rsdet_rroi_align_backward_gather_indexed_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                              c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_van_fold_rows_multi_f32": (c_int, [c_void_p, c_int, c_void_p]),
+    "rsdet_dwconv2d_backward_weight_partial_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                           c_int, c_void_p, c_size_t, c_void_p]),
+    "rsdet_dwconv2d_wgrad_finish_multi_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_void_p, c_void_p, c_void_p]),
     "rsdet_van_block_supported": (c_int, [c_void_p]),
     "rsdet_van_block_side_stream": (c_int, [c_int]),
     "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),

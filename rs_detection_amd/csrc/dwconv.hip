@@ -300,6 +300,27 @@ __global__ __launch_bounds__(DW_NT) void dwconv_wgrad_tile_kernel(const float* _
   }
 }
 
+// ... the same for up to four layers in one launch (blockIdx.y = layer): the finishing passes of a block's depthwise weight
+// gradients are 5 us launches with a few KB of work each; the VAN block node issues them together behind its backward
+struct DwFinishJobs {
+  const float* partial[4];
+  float* gw[4];
+  float* gb[4];
+  int nslots[4], T[4], C[4];
+};
+__global__ __launch_bounds__(64) void dwconv_wgrad_finish_multi_kernel(DwFinishJobs j) {
+  const int job = blockIdx.y, c = blockIdx.x, t = threadIdx.x, T = j.T[job], nslots = j.nslots[job];
+  if (c >= j.C[job] || t >= T) return;
+  const float* p = j.partial[job] + (long long)c * nslots * T + t;
+  float v = 0.f;
+#pragma unroll 8
+  for (int sl = 0; sl < nslots; ++sl) v += p[(long long)sl * T];
+  if (t < T - 1)
+    j.gw[job][c * (T - 1) + t] = v;
+  else if (j.gb[job])
+    j.gb[job][c] = v;
+}
+
 // one wave per channel: fixed-order sum of its nslots partial rows
 __global__ __launch_bounds__(64) void dwconv_wgrad_finish_kernel(const float* __restrict__ partial, int nslots, int T,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
@@ -427,20 +448,9 @@ extern "C" size_t rsdet_dwconv2d_backward_weight_ws_size(int N, int C, int H, in
   return dw_slots(N, C, H, W) * (K * K + 1) * sizeof(float);
 }
 
-extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, const float* in_bias, int N,
-                                                  int C, int H, int W, int K, int dilation, float* grad_weight,
-                                                  float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
-  int rc = dw_check(N, C, H, W, K, dilation);
-  if (rc) return rc;
-  if (C == 0) return RSDET_OK;
-  if (!grad_weight) return RSDET_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  if (N == 0) {
-    if (hipMemsetAsync(grad_weight, 0, (size_t)C * K * K * 4, s) != hipSuccess) return RSDET_ELAUNCH;
-    if (grad_bias && hipMemsetAsync(grad_bias, 0, (size_t)C * 4, s) != hipSuccess) return RSDET_ELAUNCH;
-    return RSDET_OK;
-  }
-  if (!grad_y || !x || !ws || ws_bytes < rsdet_dwconv2d_backward_weight_ws_size(N, C, H, W, K)) return RSDET_EINVAL;
+// the partial rows of the weight gradient: (C, nslots, K*K + 1) floats in ws; -> nslots (< 0: error)
+static int dw_wgrad_partials(const float* grad_y, const float* x, const float* in_bias, int N, int C, int H, int W, int K,
+                             void* ws, hipStream_t s) {
   const int tx = (W + DW_TW - 1) / DW_TW, ty = (H + DW_TH - 1) / DW_TH, ntiles = tx * ty;
   // tiles per workgroup: as many as still leave ~1 500 workgroups (6 per CU) to the launch
   long long tpw = ((long long)N * C * ntiles) / 1536;
@@ -458,6 +468,64 @@ extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const flo
   else
     hipLaunchKernelGGL((dwconv_wgrad_tile_kernel<7, 3>), dim3(N * C, ntiles), dim3(DW_NT), 0, s, grad_y, x, in_bias, C,
                        H, W, tx, N * ntiles, partial);
+  return nslots;
+}
+
+// The weight gradient WITHOUT its finishing pass: the partial rows stay in ws (rsdet_dwconv2d_backward_weight_ws_size) for
+// rsdet_dwconv2d_wgrad_finish_multi_f32, which sums the partials of up to four layers in one launch.  N >= 1.
+extern "C" int rsdet_dwconv2d_backward_weight_partial_f32(const float* grad_y, const float* x, const float* in_bias, int N,
+                                                          int C, int H, int W, int K, int dilation, void* ws,
+                                                          size_t ws_bytes, void* stream) {
+  int rc = dw_check(N, C, H, W, K, dilation);
+  if (rc) return rc;
+  if (N < 1 || C < 1 || !grad_y || !x || !ws || ws_bytes < rsdet_dwconv2d_backward_weight_ws_size(N, C, H, W, K))
+    return RSDET_EINVAL;
+  dw_wgrad_partials(grad_y, x, in_bias, N, C, H, W, K, ws, (hipStream_t)stream);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_dwconv2d_wgrad_finish_multi_f32(int n, const void* const* ws, const int* N, const int* C, const int* H,
+                                                     const int* W, const int* K, float* const* grad_weight,
+                                                     float* const* grad_bias, void* stream) {
+  if (n < 1 || n > 4 || !ws || !N || !C || !H || !W || !K || !grad_weight || !grad_bias) return RSDET_EINVAL;
+  DwFinishJobs j;
+  int cmax = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int k = i < n ? i : 0;
+    if (i < n && (N[k] < 1 || C[k] < 1 || !ws[k] || !grad_weight[k] || dw_check(N[k], C[k], H[k], W[k], K[k], K[k] == 7 ? 3 : 1)))
+      return RSDET_EINVAL;
+    const int tx = (W[k] + DW_TW - 1) / DW_TW, ty = (H[k] + DW_TH - 1) / DW_TH, ntiles = tx * ty;
+    long long tpw = ((long long)N[k] * C[k] * ntiles) / 1536;
+    tpw = tpw < 1 ? 1 : (tpw > ntiles ? ntiles : tpw);
+    const int groups = (int)((ntiles + tpw - 1) / tpw);
+    j.partial[i] = (const float*)ws[k];
+    j.gw[i] = grad_weight[k];
+    j.gb[i] = grad_bias[k];
+    j.nslots[i] = K[k] == 7 ? N[k] * ntiles : N[k] * groups;
+    j.T[i] = K[k] * K[k] + 1;
+    j.C[i] = i < n ? C[k] : 0;
+    if (i < n && C[k] > cmax) cmax = C[k];
+  }
+  hipLaunchKernelGGL(dwconv_wgrad_finish_multi_kernel, dim3(cmax, n), dim3(64), 0, (hipStream_t)stream, j);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_dwconv2d_backward_weight_f32(const float* grad_y, const float* x, const float* in_bias, int N,
+                                                  int C, int H, int W, int K, int dilation, float* grad_weight,
+                                                  float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
+  int rc = dw_check(N, C, H, W, K, dilation);
+  if (rc) return rc;
+  if (C == 0) return RSDET_OK;
+  if (!grad_weight) return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) {
+    if (hipMemsetAsync(grad_weight, 0, (size_t)C * K * K * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+    if (grad_bias && hipMemsetAsync(grad_bias, 0, (size_t)C * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+    return RSDET_OK;
+  }
+  if (!grad_y || !x || !ws || ws_bytes < rsdet_dwconv2d_backward_weight_ws_size(N, C, H, W, K)) return RSDET_EINVAL;
+  float* partial = (float*)ws;
+  const int nslots = dw_wgrad_partials(grad_y, x, in_bias, N, C, H, W, K, ws, s);
   hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(C), dim3(64), 0, s, partial, nslots, K * K + 1, grad_weight,
                      grad_bias);
   return rsdet_launch_status();

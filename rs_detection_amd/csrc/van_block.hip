@@ -92,6 +92,15 @@ static size_t dw_ws_floats(const Dims& d, int ch) {
 
 // The channel sums of a depthwise backward-data result (the bias gradient of the 1x1 convolution before it): with few
 // tiles per plane the per-tile table goes to the fold as it is (gs_ns = slots), else the depthwise call folds it first.
+// partials of the three row folds (fc2, proj_2, conv1) and of the three depthwise weight gradients (3x3 on R, 7x7 and 5x5 on C)
+static size_t rows_part_floats(const Dims& d) {
+  return up4((size_t)rsdet_van_wgrad_f32_splits(d.C, d.R, d.P, d.N) * d.C * d.R) +
+         2 * up4((size_t)rsdet_van_wgrad_f32_splits(d.C, d.C, d.P, d.N) * d.C * d.C);
+}
+static size_t dw_part_one(const Dims& d, int ch, int k) {
+  return up4((rsdet_dwconv2d_backward_weight_ws_size(d.N, ch, d.H, d.W, k) + 3) / 4);
+}
+static size_t dw_part_floats(const Dims& d) { return dw_part_one(d, d.R, 3) + dw_part_one(d, d.C, 7) + dw_part_one(d, d.C, 5); }
 static int dw_slots_per_channel(const Dims& d, int ch) {
   return (int)(rsdet_dwconv2d_backward_data_ws_size(d.N, ch, d.H, d.W) / 4 / (size_t)ch);
 }
@@ -162,8 +171,11 @@ extern "C" size_t rsdet_van_block_backward_scratch_floats(const rsdet_van_block*
   // tab (C ns 2) x 3, partials, two hidden-width maps, five block-width maps, vectors, depthwise workspaces
   // tab (C ns 2) x 3, partials x 2 (chain / side stream), two hidden-width maps, six block-width maps, vectors, depthwise
   // workspaces x 2
-  return 3 * up4((size_t)d.C * d.ns * 2) + 2 * up4(max_part(d)) + 2 * up4(d.nrp) + 6 * up4(d.ncp) + up4(gs_floats(d, d.R)) +
-         up4(gs_floats(d, d.C)) + 2 * up4(6 * (size_t)d.C) + 2 * up4(dw_ws_floats(d, d.R > d.C ? d.R : d.C));
+  // ... and since the three row folds and the three depthwise finishing passes are issued together behind the backward:
+  // their partials each in a buffer of their own
+  return 3 * up4((size_t)d.C * d.ns * 2) + up4(max_part(d)) + rows_part_floats(d) + 2 * up4(d.nrp) + 6 * up4(d.ncp) +
+         up4(gs_floats(d, d.R)) + up4(gs_floats(d, d.C)) + 2 * up4(6 * (size_t)d.C) +
+         up4(dw_ws_floats(d, d.R > d.C ? d.R : d.C)) + dw_part_floats(d);
 }
 
 extern "C" int rsdet_van_block_forward_f32(const rsdet_van_block* b, const float* x, float* out, float* saved, float* scratch,
@@ -219,8 +231,11 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   float* tabg = a.take((size_t)C * ns * 2);
   float* tabr = a.take((size_t)C * ns * 2);
   float* tab2 = a.take((size_t)C * ns * 2);
+  const int S_cc = rsdet_van_wgrad_f32_splits(C, C, P, N), S_cr = rsdet_van_wgrad_f32_splits(C, R, P, N);
   float* part = a.take(max_part(d));
-  float* part_s = a.take(max_part(d));
+  float* part_r0 = a.take((size_t)S_cr * C * R);
+  float* part_r1 = a.take((size_t)S_cc * C * C);
+  float* part_r2 = a.take((size_t)S_cc * C * C);
   float* gh2 = a.take(d.nrp);
   float* gh = a.take(d.nrp);
   float* G = a.take(d.ncp);
@@ -237,10 +252,11 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   float* vec1 = a.take(6 * (size_t)C);
   const size_t dw_fl = dw_ws_floats(d, R > C ? R : C);
   float* dws = a.take(dw_fl);
-  float* dws_s = a.take(dw_fl);
   const size_t dw_bytes = dw_fl * 4;
+  float* dwp3 = a.take(dw_part_one(d, R, 3) ? dw_part_one(d, R, 3) : 4);
+  float* dwp7 = a.take(dw_part_one(d, C, 7) ? dw_part_one(d, C, 7) : 4);
+  float* dwp5 = a.take(dw_part_one(d, C, 5) ? dw_part_one(d, C, 5) : 4);
   const float cnt = (float)N * (float)P;
-  const int S_cc = rsdet_van_wgrad_f32_splits(C, C, P, N), S_cr = rsdet_van_wgrad_f32_splits(C, R, P, N);
   hipStream_t M = (hipStream_t)stream;
   SideStream* sd = g_side_on ? side_stream() : nullptr;
   hipStream_t S = (sd && sd->ok) ? sd->s : M;       // (no side stream: the same order on one stream)
@@ -249,14 +265,14 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   // ================= MLP half: out = x1 + ls2 (fc2(h3) + bf2)
   VB_CHECK(rsdet_van_chan_reduce_f32(grad_out, nullptr, N, C, P, 0, tabg, M));
   VB_CHECK(fork(0));
-  VB_CHECK(rsdet_van_wgrad_f32(grad_out, s.h3, C, R, P, N, part_s, S));                                          // side
-  {
-    rsdet_van_rows_fold f{part_s, b->ls2, b->wf2, tabg, b->bf2, nullptr, nullptr, nullptr, g.wf2, g.bf2, g.ls2, S_cr, C, R, ns, 2, 0};
-    VB_CHECK(rsdet_van_fold_rows_f32(&f, S));                                                                    // side
-  }
+  // (the three row folds and the three depthwise finishing passes feed nothing in the chain: they are issued as ONE launch
+  //  each behind the backward, below)
+  rsdet_van_rows_fold folds[3];
+  VB_CHECK(rsdet_van_wgrad_f32(grad_out, s.h3, C, R, P, N, part_r0, S));                                         // side
+  folds[0] = rsdet_van_rows_fold{part_r0, b->ls2, b->wf2, tabg, b->bf2, nullptr, nullptr, nullptr, g.wf2, g.bf2, g.ls2, S_cr, C, R, ns, 2, 0};
   VB_CHECK(rsdet_van_gemm_f32(s.w5t, grad_out, R, C, P, N, 6, nullptr, nullptr, nullptr, nullptr, s.d3, nullptr, gh2, nullptr, M));
   VB_CHECK(fork(1));
-  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(gh2, s.h, nullptr, N, R, H, W, 3, 1, g.wd3, g.bd3, dws_s, dw_bytes, S));  // side
+  VB_CHECK(rsdet_dwconv2d_backward_weight_partial_f32(gh2, s.h, nullptr, N, R, H, W, 3, 1, dwp3, dw_part_one(d, R, 3) * 4, S));  // side
   if (dir_r)
     VB_CHECK(rsdet_dwconv2d_backward_data_f32(gh2, b->wd3, N, R, H, W, 3, 1, gh, nullptr, gsh, (size_t)R * ns_r * 4, M));
   else
@@ -271,27 +287,21 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   // ================= attention half: x1 = x + ls1 (proj_2(gt) + bp2 + xn)
   VB_CHECK(rsdet_van_chan_reduce_f32(G, x, N, C, P, 0, tabr, M));
   VB_CHECK(fork(2));
-  VB_CHECK(rsdet_van_wgrad_f32(G, s.gt, C, C, P, N, part_s, S));                                                 // side
-  {
-    rsdet_van_rows_fold f{part_s, b->ls1, b->wp2, tabr, b->bp2, tabr, s.st1 + 2 * C, s.st1 + 3 * C, g.wp2, g.bp2, g.ls1,
-                          S_cc, C, C, ns, 2, ns};
-    VB_CHECK(rsdet_van_fold_rows_f32(&f, S));                                                                    // side
-  }
+  VB_CHECK(rsdet_van_wgrad_f32(G, s.gt, C, C, P, N, part_r1, S));                                                // side
+  folds[1] = rsdet_van_rows_fold{part_r1, b->ls1, b->wp2, tabr, b->bp2, tabr, s.st1 + 2 * C, s.st1 + 3 * C, g.wp2, g.bp2, g.ls1,
+                                 S_cc, C, C, ns, 2, ns};
   VB_CHECK(rsdet_van_gemm_f32(s.w3t, G, C, C, P, N, 5, nullptr, nullptr, nullptr, nullptr, s.u, s.a2, ga2, gug, M));
   VB_CHECK(fork(3));
   VB_CHECK(rsdet_van_chan_reduce_f32(ga2, nullptr, N, C, P, 0, tab2, S));                                        // side
-  VB_CHECK(rsdet_van_wgrad_f32(ga2, s.a1, C, C, P, N, part_s, S));                                               // side
-  {
-    rsdet_van_rows_fold f{part_s, nullptr, nullptr, tab2, nullptr, nullptr, nullptr, nullptr, g.wc1, g.bc1, nullptr,
-                          S_cc, C, C, ns, 2, 0};
-    VB_CHECK(rsdet_van_fold_rows_f32(&f, S));                                                                    // side
-  }
+  VB_CHECK(rsdet_van_wgrad_f32(ga2, s.a1, C, C, P, N, part_r2, S));                                              // side
+  folds[2] = rsdet_van_rows_fold{part_r2, nullptr, nullptr, tab2, nullptr, nullptr, nullptr, nullptr, g.wc1, g.bc1, nullptr,
+                                 S_cc, C, C, ns, 2, 0};
   VB_CHECK(rsdet_van_gemm_f32(s.w2t, ga2, C, C, P, N, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ga1, nullptr, M));
   VB_CHECK(fork(4));
-  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga1, s.a0, nullptr, N, C, H, W, 7, 3, g.wd7, g.bd7, dws_s, dw_bytes, S));  // side
+  VB_CHECK(rsdet_dwconv2d_backward_weight_partial_f32(ga1, s.a0, nullptr, N, C, H, W, 7, 3, dwp7, dw_part_one(d, C, 7) * 4, S));  // side
   VB_CHECK(rsdet_dwconv2d_backward_data_f32(ga1, b->wd7, N, C, H, W, 7, 3, ga0, nullptr, nullptr, 0, M));
   VB_CHECK(fork(5));
-  VB_CHECK(rsdet_dwconv2d_backward_weight_f32(ga0, s.u, nullptr, N, C, H, W, 5, 1, g.wd5, g.bd5, dws_s, dw_bytes, S));   // side
+  VB_CHECK(rsdet_dwconv2d_backward_weight_partial_f32(ga0, s.u, nullptr, N, C, H, W, 5, 1, dwp5, dw_part_one(d, C, 5) * 4, S));   // side
   if (dir_c)
     VB_CHECK(rsdet_dwconv2d_backward_data_act_f32(ga0, b->wd5, N, C, H, W, 5, 1, gug, s.t1, gt1, nullptr, gs1,
                                                   (size_t)C * ns_c * 4, M));
@@ -305,6 +315,15 @@ extern "C" int rsdet_van_block_backward_f32(const rsdet_van_block* b, const floa
   }
   if (grad_x)
     VB_CHECK(rsdet_van_gemm_f32(s.w1t, gt1, C, C, P, N, 4, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, G, x, grad_x, nullptr, M));
+  // ---- the parameter gradients nothing above waited for: three row folds in one launch, three depthwise sums in one
+  VB_CHECK(rsdet_van_fold_rows_multi_f32(folds, 3, S));
+  {
+    const void* wsp[3] = {dwp3, dwp7, dwp5};
+    const int n3[3] = {N, N, N}, c3[3] = {R, C, C}, h3[3] = {H, H, H}, w3[3] = {W, W, W}, k3[3] = {3, 7, 5};
+    float* gw3[3] = {g.wd3, g.wd7, g.wd5};
+    float* gb3[3] = {g.bd3, g.bd7, g.bd5};
+    VB_CHECK(rsdet_dwconv2d_wgrad_finish_multi_f32(3, wsp, n3, c3, h3, w3, k3, gw3, gb3, S));
+  }
   // the caller's stream owns every buffer again once the side stream's work is behind it
   if (S != M) VB_CHECK(edge(S, M, ev[6]));
   return RSDET_OK;

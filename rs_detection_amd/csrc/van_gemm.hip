@@ -511,9 +511,21 @@ struct VgRowsFold {
   float* grad_rs;         // or NULL
   int S, M, N, gs_ns, gs_stride, r_ns;
 };
-__global__ __launch_bounds__(256) void van_fold_rows_kernel(VgRowsFold f) {
+__device__ __forceinline__ void van_fold_rows_body(const VgRowsFold& f, int m);
+__global__ __launch_bounds__(256) void van_fold_rows_kernel(VgRowsFold f) { van_fold_rows_body(f, blockIdx.x); }
+// up to three folds in one launch (blockIdx.y = fold): the block node issues its three row folds together behind its
+// backward -- none of them feeds the data chain
+struct VgRowsFold3 {
+  VgRowsFold j[3];
+};
+__global__ __launch_bounds__(256) void van_fold_rows_multi_kernel(VgRowsFold3 jobs) {
+  const VgRowsFold& f = jobs.j[blockIdx.y];
+  if ((int)blockIdx.x >= f.M) return;
+  van_fold_rows_body(f, blockIdx.x);
+}
+__device__ __forceinline__ void van_fold_rows_body(const VgRowsFold& f, int m) {
   __shared__ float s_dot[256];
-  const int m = blockIdx.x, N = f.N;
+  const int N = f.N;
   const float sc = f.rs ? f.rs[m] : 1.f;
   float d = 0.f;
   for (int i = threadIdx.x * 4; i < N; i += 1024) {
@@ -895,13 +907,34 @@ if (mi == 5)
   return rsdet_launch_status();
 }
 
-extern "C" int rsdet_van_fold_rows_f32(const rsdet_van_rows_fold* f, void* stream) {
+static int vg_rows_fold_args(const rsdet_van_rows_fold* f, VgRowsFold* k);
+extern "C" int rsdet_van_fold_rows_multi_f32(const rsdet_van_rows_fold* jobs, int n, void* stream) {
+  if (!jobs || n < 1 || n > 3) return RSDET_EINVAL;
+  VgRowsFold3 k;
+  int mmax = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int rc = vg_rows_fold_args(jobs + (i < n ? i : 0), &k.j[i]);
+    if (rc) return rc;
+    if (i >= n) k.j[i].M = 0;
+    if (k.j[i].M > mmax) mmax = k.j[i].M;
+  }
+  hipLaunchKernelGGL(van_fold_rows_multi_kernel, dim3((unsigned)mmax, (unsigned)n), dim3(256), 0, (hipStream_t)stream, k);
+  return rsdet_launch_status();
+}
+
+static int vg_rows_fold_args(const rsdet_van_rows_fold* f, VgRowsFold* k) {
   if (!f || f->S < 1 || f->M < 1 || f->N < 4 || (f->N & 3) || !f->partial || !f->grad_w) return RSDET_EINVAL;
   if ((f->grad_b || f->grad_rs) && f->gs_tab && (f->gs_ns < 1 || f->gs_stride < 1)) return RSDET_EINVAL;
   if (f->grad_rs && !f->w) return RSDET_EINVAL;
   if (f->r_tab && (f->r_ns < 1 || !f->sc || !f->sh)) return RSDET_EINVAL;
-  VgRowsFold k{f->partial, f->row_scale, f->w, f->gs_tab, f->bias, f->r_tab, f->sc, f->sh, f->grad_w, f->grad_b, f->grad_rs,
-               f->S, f->M, f->N, f->gs_ns, f->gs_stride, f->r_ns};
+  *k = VgRowsFold{f->partial, f->row_scale, f->w, f->gs_tab, f->bias, f->r_tab, f->sc, f->sh, f->grad_w, f->grad_b, f->grad_rs,
+                  f->S, f->M, f->N, f->gs_ns, f->gs_stride, f->r_ns};
+  return RSDET_OK;
+}
+extern "C" int rsdet_van_fold_rows_f32(const rsdet_van_rows_fold* f, void* stream) {
+  VgRowsFold k;
+  const int rc = vg_rows_fold_args(f, &k);
+  if (rc) return rc;
   hipLaunchKernelGGL(van_fold_rows_kernel, dim3((unsigned)f->M), dim3(256), 0, (hipStream_t)stream, k);
   return rsdet_launch_status();
 }
