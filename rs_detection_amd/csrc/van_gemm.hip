@@ -525,16 +525,39 @@ __global__ __launch_bounds__(256) void van_fold_rows_multi_kernel(VgRowsFold3 jo
 }
 __device__ __forceinline__ void van_fold_rows_body(const VgRowsFold& f, int m) {
   __shared__ float s_dot[256];
+  __shared__ float4 s_part[256];
   const int N = f.N;
   const float sc = f.rs ? f.rs[m] : 1.f;
   float d = 0.f;
-  for (int i = threadIdx.x * 4; i < N; i += 1024) {
+  // A row narrower than the workgroup (N / 4 < 256 float4 columns: the 320 x 320 weights) would leave most lanes idle behind
+  // S dependent-latency loads each: the S partials are dealt to G = 256 / (N / 4) lane groups, whose sums meet in LDS in
+  // group order (a fixed order, like the plain loop's).
+  const int nc4 = N >> 2, G = nc4 < 256 ? 256 / nc4 : 1;
+  const int col = G > 1 ? (int)threadIdx.x % nc4 : 0, grp = G > 1 ? (int)threadIdx.x / nc4 : 0;
+  for (int i = (G > 1 ? col : (int)threadIdx.x) * 4; i < N; i += 1024) {
     const long long e = (long long)m * N + i;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (G > 1) {
+      if (grp < G) {
+#pragma unroll 4
+        for (int s = grp; s < f.S; s += G) {
+          const float4 v = *reinterpret_cast<const float4*>(f.partial + (long long)s * f.M * N + e);
+          acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+        s_part[grp * nc4 + col] = acc;
+      }
+      __syncthreads();
+      if (grp != 0) break;
+      for (int g2 = 1; g2 < G; ++g2) {
+        const float4 v = s_part[g2 * nc4 + col];
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+      }
+    } else {
 #pragma unroll 8
-    for (int s = 0; s < f.S; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(f.partial + (long long)s * f.M * N + e);
-      acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+      for (int s = 0; s < f.S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(f.partial + (long long)s * f.M * N + e);
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+      }
     }
     if (f.w) {
       const float4 wv = *reinterpret_cast<const float4*>(f.w + e);
@@ -596,6 +619,8 @@ __global__ __launch_bounds__(256) void van_fold_bn_kernel(VgBnFold f) {
   const int k = blockIdx.x;
   const float sc = f.sc[k], sh = f.sh[k];
   float d1 = 0.f, d2 = 0.f;
+  // (four channels per workgroup with 16-byte transposed stores was measured in round 6: 1.10 -> 1.18 ms per ORCNN step --
+  //  the fold is bound by the latency of its O / 256 dependent trips, not by its stores)
   for (int o = threadIdx.x; o < f.O; o += 256) {
     const long long e = (long long)k * f.O + o;
     float u = 0.f;
