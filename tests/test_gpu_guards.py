@@ -20,8 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # measured (round 5, call 3): s2anet f32 844 + 13 fills, bf16 722 + 17, orcnn 4313 + 18 with 8 syncs before the fixed-size
 # sampling path; the Oriented R-CNN step has had no synchronisation since
 # round 6: the VAN Block as one node of 42 launches (csrc/van_block.hip): orcnn 4313 -> 3560 + 12 fills; the heads'
-# control path as kernels (csrc/orpn.hip: proposals, samplers, RPN losses on the samples, RoI targets): -> 2165 + 12
-BUDGET = {("s2anet", "f32"): (885, 0), ("s2anet", "bf16"): (650, 0), ("orcnn", "f32"): (2250, 0)}
+# control path as kernels (csrc/orpn.hip: proposals, samplers, RPN losses on the samples, RoI targets): -> 2165 + 12; the
+# block's row folds and depthwise finishing passes as one launch each: -> 2013 + 12
+BUDGET = {("s2anet", "f32"): (885, 0), ("s2anet", "bf16"): (650, 0), ("orcnn", "f32"): (2100, 0)}
 
 
 @pytest.fixture(scope="module")
