@@ -100,8 +100,17 @@ def test_bench_self_launches_its_ranks(tmp_path, n):
     _need_gpu()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["RSDET_BENCH_TILE"] = "256"                  # N S2ANet replicas on one GPU: keep the tiles small
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
-                        "--no-kernels", "--no-bf16-leg"], env=env, capture_output=True, text=True, timeout=1400)
+    # Eight processes time-slicing ONE GPU is not a configuration the product runs in (one process per GPU), and on this
+    # pool it has a platform flake: in ~1 launch of 10 one rank's queue aborts with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION
+    # inside its very first torch kernels (faulthandler + HIP_LAUNCH_BLOCKING: the `torch.zeros` of the gradient bucket
+    # right after the gloo parameter broadcast -- no kernel of this repo has run yet; the round-5 tree shows it at the same
+    # rate, 2 / 20).  That one error, and only that one, is retried; anything else fails the test at once.
+    for attempt in range(4):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                            "--no-kernels", "--no-bf16-leg"], env=env, capture_output=True, text=True, timeout=1400)
+        if p.returncode == 0 or "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" not in p.stderr:
+            break
+        print("attempt %d: a rank's queue aborted with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (platform flake), retrying" % attempt)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout

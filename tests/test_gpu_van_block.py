@@ -193,3 +193,63 @@ def test_gemm_epilogues_through_the_c_abi(cuda, M, K, P, n):
     o0, o1 = run(5, ss=(s0, s1), two=True)
     assert _rel(o0, ref * s0.double()) <= tol and _rel(o1, ref * s1.double()) <= tol
     assert _rel(run(6, ss=(s0, None))[0], ref * s0.double()) <= tol
+
+
+def test_merged_folds_and_depthwise_finishes_equal_the_single_calls(cuda):
+    """rsdet_van_fold_rows_multi_f32 (three folds in one launch) == three rsdet_van_fold_rows_f32 calls, and
+    rsdet_dwconv2d_backward_weight_partial_f32 + rsdet_dwconv2d_wgrad_finish_multi_f32 == rsdet_dwconv2d_backward_weight_f32,
+    bit for bit (same summation order)."""
+    import ctypes
+    from rs_detection_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    jobs, singles = (_lib.VanRowsFold * 3)(), []
+    keep = []
+    for j, (S, M, Nn, with_dot) in enumerate(((6, 320, 1280, True), (25, 320, 320, True), (25, 64, 64, False))):
+        part = torch.randn(S, M, Nn, generator=gen).to(cuda)
+        w, rs, bias = (torch.randn(*sh, generator=gen).to(cuda) for sh in ((M, Nn), (M,), (M,)))
+        tab = torch.randn(M, 4, 2, generator=gen).to(cuda)
+        outs = [[torch.empty((M, Nn), device=cuda), torch.empty(M, device=cuda), torch.empty(M, device=cuda)] for _ in range(2)]
+        for which in range(2):
+            gw, gb, grs = outs[which]
+            f = _lib.VanRowsFold(part.data_ptr(), rs.data_ptr(), w.data_ptr() if with_dot else None, tab.data_ptr(),
+                                 bias.data_ptr(), None, None, None, gw.data_ptr(), gb.data_ptr(),
+                                 grs.data_ptr() if with_dot else None, S, M, Nn, 4, 2, 0)
+            if which == 0:
+                _lib.check(lib.rsdet_van_fold_rows_f32(ctypes.byref(f), _lib.stream_ptr()), "single")
+            else:
+                jobs[j] = f
+        keep.append((part, w, rs, bias, tab))
+        singles.append((outs, with_dot))
+    _lib.check(lib.rsdet_van_fold_rows_multi_f32(jobs, 3, _lib.stream_ptr()), "multi")
+    for outs, with_dot in singles:
+        for a, b in list(zip(outs[0], outs[1]))[:3 if with_dot else 2]:
+            assert torch.equal(a, b)
+    assert lib.rsdet_van_fold_rows_multi_f32(jobs, 4, _lib.stream_ptr()) != 0
+    # depthwise weight gradients
+    N, H, W = 2, 64, 64
+    cfgs = ((96, 3), (32, 7), (32, 5))
+    ws, one, multi = [], [], []
+    P = _lib.ptr
+    for C, K in cfgs:
+        gy, x = torch.randn(N, C, H, W, generator=gen).to(cuda), torch.randn(N, C, H, W, generator=gen).to(cuda)
+        nb = lib.rsdet_dwconv2d_backward_weight_ws_size(N, C, H, W, K)
+        w1, w2 = torch.empty(nb, dtype=torch.uint8, device=cuda), torch.empty(nb, dtype=torch.uint8, device=cuda)
+        gw1, gb1 = torch.empty(C, 1, K, K, device=cuda), torch.empty(C, device=cuda)
+        gw2, gb2 = torch.empty(C, 1, K, K, device=cuda), torch.empty(C, device=cuda)
+        D = 3 if K == 7 else 1
+        _lib.check(lib.rsdet_dwconv2d_backward_weight_f32(P(gy), P(x), None, N, C, H, W, K, D, P(gw1), P(gb1), P(w1), nb,
+                                                          _lib.stream_ptr()), "one call")
+        _lib.check(lib.rsdet_dwconv2d_backward_weight_partial_f32(P(gy), P(x), None, N, C, H, W, K, D, P(w2), nb,
+                                                                  _lib.stream_ptr()), "partial")
+        ws.append(w2), one.append((gw1, gb1)), multi.append((gw2, gb2))
+        keep.append((gy, x, w1))
+    arr = lambda ty, vals: (ty * 3)(*vals)
+    rc = lib.rsdet_dwconv2d_wgrad_finish_multi_f32(
+        3, arr(ctypes.c_void_p, [w.data_ptr() for w in ws]), arr(ctypes.c_int, [N] * 3), arr(ctypes.c_int, [c for c, _ in cfgs]),
+        arr(ctypes.c_int, [H] * 3), arr(ctypes.c_int, [W] * 3), arr(ctypes.c_int, [k for _, k in cfgs]),
+        arr(ctypes.c_void_p, [m[0].data_ptr() for m in multi]), arr(ctypes.c_void_p, [m[1].data_ptr() for m in multi]),
+        _lib.stream_ptr())
+    _lib.check(rc, "finish multi")
+    for (a, b), (c, d) in zip(one, multi):
+        assert torch.equal(a, c) and torch.equal(b, d)
