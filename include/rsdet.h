@@ -544,6 +544,18 @@ int rsdet_dwconv2d_backward_weight_partial_f32(const float* grad_y, const float*
 int rsdet_dwconv2d_wgrad_finish_multi_f32(int n, const void* const* ws, const int* N, const int* C, const int* H,
                                           const int* W, const int* K, float* const* grad_weight, float* const* grad_bias,
                                           void* stream);
+/* LayerNorm over the CHANNELS of an NCHW map.  Replaces the norm at the end of every VAN stage,
+ * models/backbones/van.py:303-306 (`x.flatten(2).transpose(1, 2)` -> nn.LayerNorm(C) -> reshape / permute back): biased
+ * variance, rsqrt(var + eps), affine per channel.  x / y / grad (N, C, HW) fp32; mean / rstd (N, HW) are kept for the
+ * backward; backward: grad_x, and grad_gamma / grad_beta (either NULL: skipped) through ws
+ * (rsdet_chan_layernorm_ws_size bytes).  C <= 512. */
+int rsdet_chan_layernorm_supported(int N, int C, int HW);
+size_t rsdet_chan_layernorm_ws_size(int N, int C, int HW);
+int rsdet_chan_layernorm_forward_f32(const float* x, const float* gamma, const float* beta, int N, int C, int HW, float eps,
+                                     float* y, float* mean, float* rstd, void* stream);
+int rsdet_chan_layernorm_backward_f32(const float* grad_y, const float* x, const float* mean, const float* rstd,
+                                      const float* gamma, int N, int C, int HW, float* grad_x, float* grad_gamma,
+                                      float* grad_beta, void* ws, size_t ws_bytes, void* stream);
 int rsdet_van_block_supported(const rsdet_van_block* b);
 /* 1: the backward's weight gradients, their folds and the depthwise weight gradients run on a side stream beside the chain
  * that produces grad_x (joined before the call returns control of the buffers to `stream`); 0 (default: measured 2.5 %

@@ -259,6 +259,105 @@ static inline int ve_aligned(int HW, std::initializer_list<const void*> ptrs) {
   return 1;
 }
 
+
+// ---- LayerNorm over the CHANNELS of an NCHW map (the norm at the end of every VAN stage, van.py:303-306) -------------
+// The reference flattens the map to (B, HW, C), normalises the last axis and permutes back: as tensor operations that is a
+// strided copy in, the library LayerNorm, a strided copy out, and the same again (plus two partial-sum kernels) in the
+// backward -- 1.0 ms per Oriented R-CNN step for four calls.  Here a workgroup owns 64 consecutive pixels of one image and
+// ALL their channels: lanes = pixels (every channel row is a coalesced 256-byte read), the four waves split the channels.
+// Forward: the tile is staged in LDS (C x 64 floats, <= 128 KB), mean and variance in two passes over it (biased variance,
+// rsqrt(var + eps): torch's native_layer_norm), one global read and one write of the map.  Backward: the two per-pixel sums
+// (sum_c g gamma, sum_c g gamma xhat) in a first pass, the input gradient and the per-channel sums for gamma / beta in a
+// second (the tile's second read comes from L2); (C, S, 2) partials for rsdet_launch_sums_finish.
+constexpr int LN_PT = 64, LN_NT = 256, LN_CG = LN_NT / LN_PT;
+
+__global__ __launch_bounds__(LN_NT) void ln_chan_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int C, int HW, float eps,
+                                                            float* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+  extern __shared__ float ln_tile[];  // [C][LN_PT]
+  __shared__ float s_red[LN_CG][LN_PT];
+  const int px = threadIdx.x & (LN_PT - 1), cg = threadIdx.x >> 6, n = blockIdx.y;
+  const int p = blockIdx.x * LN_PT + px;
+  const bool ok = p < HW;
+  const float* xb = x + (long long)n * C * HW + (ok ? p : 0);
+  float s = 0.f;
+#pragma unroll 8
+  for (int c = cg; c < C; c += LN_CG) {
+    const float v = ok ? xb[(long long)c * HW] : 0.f;
+    ln_tile[c * LN_PT + px] = v;
+    s += v;
+  }
+  s_red[cg][px] = s;
+  __syncthreads();
+  const float mu = ((s_red[0][px] + s_red[1][px]) + (s_red[2][px] + s_red[3][px])) / (float)C;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll 8
+  for (int c = cg; c < C; c += LN_CG) {
+    const float d = ln_tile[c * LN_PT + px] - mu;
+    q += d * d;
+  }
+  s_red[cg][px] = q;
+  __syncthreads();
+  const float var = ((s_red[0][px] + s_red[1][px]) + (s_red[2][px] + s_red[3][px])) / (float)C;
+  const float r = rsqrtf(var + eps);
+  if (!ok) return;
+  float* yb = y + (long long)n * C * HW + p;
+#pragma unroll 8
+  for (int c = cg; c < C; c += LN_CG)
+    yb[(long long)c * HW] = (ln_tile[c * LN_PT + px] - mu) * r * gamma[c] + beta[c];
+  if (cg == 0) {
+    mean[(long long)n * HW + p] = mu;
+    rstd[(long long)n * HW + p] = r;
+  }
+}
+
+__device__ __forceinline__ float ln_row16_sum(float v) {
+#define LN_DPP(ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  v += LN_DPP(0xB1);   // quad_perm [1, 0, 3, 2]
+  v += LN_DPP(0x4E);   // quad_perm [2, 3, 0, 1]
+  v += LN_DPP(0x141);  // row_half_mirror
+  v += LN_DPP(0x140);  // row_mirror
+#undef LN_DPP
+  return v;
+}
+
+__global__ __launch_bounds__(LN_NT) void ln_chan_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, int C, int HW,
+                                                            float* __restrict__ gx, float* __restrict__ partial) {
+  __shared__ float s_a[LN_CG][LN_PT], s_b[LN_CG][LN_PT];
+  const int px = threadIdx.x & (LN_PT - 1), cg = threadIdx.x >> 6, n = blockIdx.y;
+  const int p = blockIdx.x * LN_PT + px;
+  const bool ok = p < HW;
+  const long long base = (long long)n * C * HW + (ok ? p : 0);
+  const float mu = ok ? mean[(long long)n * HW + p] : 0.f, r = ok ? rstd[(long long)n * HW + p] : 0.f;
+  float a = 0.f, b = 0.f;
+#pragma unroll 8
+  for (int c = cg; c < C; c += LN_CG) {
+    const float gv = ok ? g[base + (long long)c * HW] * gamma[c] : 0.f;
+    const float xh = ok ? (x[base + (long long)c * HW] - mu) * r : 0.f;
+    a += gv;
+    b += gv * xh;
+  }
+  s_a[cg][px] = a, s_b[cg][px] = b;
+  __syncthreads();
+  a = ((s_a[0][px] + s_a[1][px]) + (s_a[2][px] + s_a[3][px])) / (float)C;
+  b = ((s_b[0][px] + s_b[1][px]) + (s_b[2][px] + s_b[3][px])) / (float)C;
+  const int S = gridDim.x * gridDim.y, slot = n * gridDim.x + blockIdx.x;
+  for (int c = cg; c < C; c += LN_CG) {            // (a wave = one channel group: its 64 lanes are the tile's pixels)
+    const float gr = ok ? g[base + (long long)c * HW] : 0.f;
+    const float xh = ok ? (x[base + (long long)c * HW] - mu) * r : 0.f;
+    if (ok) gx[base + (long long)c * HW] = r * (gr * gamma[c] - (a + xh * b));
+    // rows of 16 lanes summed on the vector pipe (four DPP adds); the four row sums of the tile are four slots of the
+    // partial table (a wave butterfly is six dependent LDS-crossbar round trips per value: most of this kernel's time)
+    const float db = ln_row16_sum(gr), dg = ln_row16_sum(gr * xh);
+    if ((px & 15) == 0)
+      *reinterpret_cast<float2*>(partial + ((long long)c * (4 * S) + 4 * slot + (px >> 4)) * 2) = make_float2(db, dg);
+  }
+}
+
 }  // namespace rsdet
 
 using namespace rsdet;
@@ -353,5 +452,42 @@ extern "C" int rsdet_van_residual_bwd_f32(const float* g, const float* p, const 
   if (gbias || gscale)
     hipLaunchKernelGGL(van_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)ws, C,
                        N * S, scale, gbias, gscale);
+  return rsdet_launch_status();
+}
+
+// ---- LayerNorm over the channels of an NCHW map -----------------------------------------------------------------------
+extern "C" int rsdet_chan_layernorm_supported(int N, int C, int HW) {
+  return (N >= 1 && C >= 4 && C <= 512 && HW >= 1 && (long long)N * C * HW < (1ll << 31)) ? 1 : 0;
+}
+extern "C" size_t rsdet_chan_layernorm_ws_size(int N, int C, int HW) {
+  if (!rsdet_chan_layernorm_supported(N, C, HW)) return 0;
+  return (size_t)C * ((size_t)N * ((HW + LN_PT - 1) / LN_PT)) * 4 * 2 * sizeof(float);      // four row slots per tile
+}
+extern "C" int rsdet_chan_layernorm_forward_f32(const float* x, const float* gamma, const float* beta, int N, int C, int HW,
+                                                float eps, float* y, float* mean, float* rstd, void* stream) {
+  if (!rsdet_chan_layernorm_supported(N, C, HW) || !x || !gamma || !beta || !y || !mean || !rstd) return RSDET_EINVAL;
+  const size_t lds = (size_t)C * LN_PT * sizeof(float);
+  static size_t lds_set = 0;
+  if (lds > 65536 && lds > lds_set) {
+    if (hipFuncSetAttribute((const void*)ln_chan_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * LN_PT * 4) !=
+        hipSuccess)
+      return RSDET_ELAUNCH;
+    lds_set = 512 * LN_PT * 4;
+  }
+  hipLaunchKernelGGL(ln_chan_fwd_kernel, dim3((HW + LN_PT - 1) / LN_PT, N), dim3(LN_NT), lds, (hipStream_t)stream, x, gamma,
+                     beta, C, HW, eps, y, mean, rstd);
+  return rsdet_launch_status();
+}
+extern "C" int rsdet_chan_layernorm_backward_f32(const float* grad_y, const float* x, const float* mean, const float* rstd,
+                                                 const float* gamma, int N, int C, int HW, float* grad_x, float* grad_gamma,
+                                                 float* grad_beta, void* ws, size_t ws_bytes, void* stream) {
+  if (!rsdet_chan_layernorm_supported(N, C, HW) || !grad_y || !x || !mean || !rstd || !gamma || !grad_x || !ws ||
+      ws_bytes < rsdet_chan_layernorm_ws_size(N, C, HW))
+    return RSDET_EINVAL;
+  const int bx = (HW + LN_PT - 1) / LN_PT;
+  hipLaunchKernelGGL(ln_chan_bwd_kernel, dim3(bx, N), dim3(LN_NT), 0, (hipStream_t)stream, grad_y, x, mean, rstd, gamma, C, HW,
+                     grad_x, (float*)ws);
+  if (grad_gamma || grad_beta)
+    rsdet_launch_sums_finish((const float*)ws, C, 4 * bx * N, grad_gamma, grad_beta, (hipStream_t)stream);
   return rsdet_launch_status();
 }

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from rs_detection_amd.ops import van_block, van_fused
+from rs_detection_amd.ops import chan_layernorm, van_block, van_fused
 from rs_detection_amd.ops.bn_act import scale_residual
 from rs_detection_amd.ops.conv1x1 import conv1x1_nchw
 from rs_detection_amd.ops.dwconv import DepthwiseConv2d
@@ -187,8 +187,12 @@ class VAN(nn.Module):
             _, _, H, W = x.shape
             for blk in getattr(self, f"block{i + 1}"):
                 x = blk(x)
-            x = getattr(self, f"norm{i + 1}")(x.flatten(2).transpose(1, 2))
-            x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+            norm = getattr(self, f"norm{i + 1}")
+            if chan_layernorm.applies(x, norm):          # one launch on the NCHW map (csrc/van_ops.hip)
+                x = chan_layernorm.chan_layer_norm(x, norm)
+            else:
+                x = norm(x.flatten(2).transpose(1, 2))
+                x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
             if i in self.out_indices:
                 outs.append(x)
         return outs

@@ -253,3 +253,27 @@ def test_merged_folds_and_depthwise_finishes_equal_the_single_calls(cuda):
     _lib.check(rc, "finish multi")
     for (a, b), (c, d) in zip(one, multi):
         assert torch.equal(a, c) and torch.equal(b, d)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 64, 64), (1, 128, 24, 20), (2, 320, 16, 16), (1, 512, 9, 7), (1, 20, 5, 3)])
+def test_channel_layernorm_on_the_nchw_map_equals_the_tensor_form(cuda, N, C, H, W):
+    """rsdet_chan_layernorm_* (the norm at the end of a VAN stage on the NCHW map) == flatten / transpose / nn.LayerNorm /
+    permute back: output, input gradient and both parameter gradients (float64 composite as the reference)."""
+    from rs_detection_amd.ops import chan_layernorm
+    torch.manual_seed(C)
+    norm = torch.nn.LayerNorm(C).to(cuda)
+    with torch.no_grad():
+        norm.weight.normal_(1, 0.3), norm.bias.normal_(0, 0.3)
+    x = (torch.randn(N, C, H, W, device=cuda) * 2 + 0.5).requires_grad_(True)
+    go = torch.randn(N, C, H, W, device=cuda)
+    assert chan_layernorm.applies(x, norm)
+    y = chan_layernorm.chan_layer_norm(x, norm)
+    gx, gw, gb = torch.autograd.grad(y, (x, norm.weight, norm.bias), go)
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xd.flatten(2).transpose(1, 2), (C,), wd, bd, norm.eps)
+    yr = yr.reshape(N, H, W, C).permute(0, 3, 1, 2)
+    rx, rw, rb = torch.autograd.grad(yr, (xd, wd, bd), go.double())
+    for a, b, tol in ((y, yr, 2e-6), (gx, rx, 2e-5), (gw, rw, 2e-5), (gb, rb, 2e-5)):
+        assert _rel(a, b) <= tol, (_rel(a, b), tol)
+    assert not chan_layernorm.applies(x.detach().half(), norm)
