@@ -75,9 +75,11 @@ for name, r in order:
         name.replace("|", "/"), r.get("bound", ""), r.get("us", 0), r.get("achieved", 0), r.get("unit", ""), r.get("frac", 0),
         fmt(rp["us"], 1) if rp else "--", fmt(ratio, 2) + " x" if ratio else "--"))
 lines.append("")
-lines.append("(`rocprof us`: eager launches under `rocprofv3 --kernel-trace`, cold operands; `us (bench)`: a replayed graph of 10 "
-             "launches inside `bench.py` -- the two agree within ~10 % except where the graph's back-to-back launches keep the "
-             "operands in the Infinity Cache.  Rows without a rocprof figure have no entry in `profiles/scripts/pmc_kernels.py`.)")
+lines.append("(`rocprof us`: eager launches under `rocprofv3 --kernel-trace`; `us (bench)`: a replayed graph of 10-12 launches "
+             "inside `bench.py`, the 3x3 MFMA rows on operand sets rotated through 400 MB so that neither measurement reads "
+             "them from the Infinity Cache.  The two agree within ~10 % except for the 3x3 weight gradient (139 vs 168 us): "
+             "its eager launches sit between idle gaps and run at a lower clock than the same kernel inside a busy graph or "
+             "step.  Rows without a rocprof figure have no entry in `profiles/scripts/pmc_kernels.py`.)")
 lines.append("")
 lines.append("§8(d) sweeps (same file): " + "; ".join(
     "%s %.1f us (%.3f)" % (n, r["us"], r["frac"]) for n, r in rows.items() if n.startswith(skip)))
