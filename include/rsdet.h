@@ -645,6 +645,17 @@ typedef struct rsdet_orpn_loss {
 int rsdet_orpn_loss_rec_floats(int n_img, int num);
 int rsdet_orpn_loss_forward_f32(const rsdet_orpn_loss* d, float* losses, float* rec, void* stream);
 int rsdet_orpn_loss_backward_f32(const rsdet_orpn_loss* d, const float* rec, const float* grad_losses, void* stream);
+/* MaxIoUAssigner on HORIZONTAL boxes without the (K, A) overlaps matrix.  Replaces models/boxes/assigner.py:65-170 with the
+ * default BboxOverlaps2D calculator (models/boxes/iou_calculator.py:164-257, mode "iou", not aligned) as the Oriented RPN
+ * calls it (models/roi_heads/oriented_rpn_head.py:292-300: 611 072 anchors per tile): rsdet_bbox_overlaps_f32 +
+ * rsdet_assign_wrt_overlaps_f32 in two passes that recompute the IoU instead of storing it; gt_inds (and max_overlaps, NULL:
+ * skipped) are bit-identical to that route.  gt (K, gt_stride >= 4), anchors (A, anchor_stride >= 4): (x1, y1, x2, y2, ...);
+ * gt_inds (A) int32: assigned gt index + 1, 0 negative, -1 neither; K <= 1024, finite boxes, no ignore regions (the caller
+ * keeps the matrix route for those).  ws: rsdet_hbb_assign_ws_size(K) bytes, 8-byte aligned. */
+size_t rsdet_hbb_assign_ws_size(int K);
+int rsdet_hbb_assign_f32(const float* gt, int K, int gt_stride, const float* anchors, int A, int anchor_stride, float eps,
+                         float pos_iou_thr, float neg_lo, float neg_hi, float min_pos_iou, int match_low_quality,
+                         int gt_max_assign_all, int32_t* gt_inds, float* max_overlaps, void* ws, size_t ws_bytes, void* stream);
 /* OrientedHead's sampled RoIs and targets of ONE image, written into that image's rows of the batch.  Replaces
  * models/roi_heads/oriented_head.py:426-496 (get_bboxes_target_single) + arb2roi (:117-126) + the gathers of
  * SamplingResult (models/boxes/sampler.py:6-36) with OrientedDeltaXYWHTCoder.encode (models/boxes/coder.py:447-470), in the

@@ -44,6 +44,21 @@ class MaxIoUAssigner:
     def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
         if bboxes.shape[0] == 0 or gt_bboxes.shape[0] == 0:
             raise ValueError('No gt or bboxes')
+        no_ignore = not (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0)
+        if no_ignore and type(self.iou_calculator).__name__ == "BboxOverlaps2D":
+            # horizontal boxes (the Oriented RPN's 611 072 anchors per tile): both passes recompute the IoU instead of
+            # writing and re-reading a (K, A) matrix (csrc/orpn.hip: rsdet_hbb_assign_f32; same gt_inds bit for bit)
+            from rs_detection_amd.ops import orpn
+            b4, g4 = bboxes[..., :4], gt_bboxes[..., :4]
+            if orpn.hbb_assign_applies(b4, g4):
+                gi, mo = orpn.hbb_assign(b4, g4, self.pos_iou_thr, self._neg(), self.min_pos_iou, self.match_low_quality,
+                                         self.gt_max_assign_all)
+                labels = None
+                if gt_labels is not None:
+                    lab = gt_labels.to(torch.int32)
+                    labels = torch.where(gi > 0, lab[(gi - 1).clamp(min=0).long()],
+                                         torch.full_like(gi, self.assigned_labels_filled))
+                return AssignResult(gt_bboxes.shape[0], gi, mo, labels)
         overlaps = self.iou_calculator(gt_bboxes, bboxes)
         if self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0:
             if self.ignore_wrt_candidates:

@@ -270,3 +270,28 @@ def roi_targets(props, gt, gt_labels, sample, image, num_classes, means, stds, p
                                          inds.numel(), int(image), int(num_classes), _lib.host5(means, 0.), _lib.host5(stds, 1.),
                                          float(pos_weight), *[_lib.ptr(t) for t in out], _lib.stream_ptr())
     _lib.check(rc, "rsdet_orcnn_roi_targets_f32")
+
+
+# ---- MaxIoUAssigner on horizontal boxes without the overlaps matrix ---------------------------------------------------
+def hbb_assign_applies(bboxes, gt_bboxes):
+    return (_ON and bboxes.is_cuda and bboxes.dtype == torch.float32 and gt_bboxes.dtype == torch.float32
+            and bboxes.dim() == 2 and gt_bboxes.dim() == 2 and bboxes.shape[1] >= 4 and gt_bboxes.shape[1] >= 4
+            and bboxes.stride(1) == 1 and gt_bboxes.stride(1) == 1 and 0 < gt_bboxes.shape[0] <= 1024 and bboxes.shape[0] > 0
+            and not (bboxes.requires_grad or gt_bboxes.requires_grad))
+
+
+def hbb_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality, gt_max_assign_all, eps=1e-6):
+    """(gt_inds (A,) int32, max_overlaps (A,)) of include/rsdet.h: rsdet_hbb_assign_f32."""
+    lib = _lib.load()
+    A, K = bboxes.shape[0], gt_bboxes.shape[0]
+    neg_lo, neg_hi = neg_iou_thr if isinstance(neg_iou_thr, (tuple, list)) else (0.0, neg_iou_thr)
+    gt_inds = torch.empty((A,), dtype=torch.int32, device=bboxes.device)
+    max_ov = torch.empty((A,), dtype=torch.float32, device=bboxes.device)
+    nb = lib.rsdet_hbb_assign_ws_size(K)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=bboxes.device)
+    rc = lib.rsdet_hbb_assign_f32(_lib.ptr(gt_bboxes), K, gt_bboxes.stride(0), _lib.ptr(bboxes), A, bboxes.stride(0), float(eps),
+                                  float(pos_iou_thr), float(neg_lo), float(neg_hi), float(min_pos_iou),
+                                  int(bool(match_low_quality)), int(bool(gt_max_assign_all)), _lib.ptr(gt_inds),
+                                  _lib.ptr(max_ov), _lib.ptr(ws), nb, _lib.stream_ptr())
+    _lib.check(rc, "rsdet_hbb_assign_f32")
+    return gt_inds, max_ov

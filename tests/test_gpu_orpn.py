@@ -324,3 +324,46 @@ def test_roi_head_targets_equal_the_tensor_route(cuda, monkeypatch):
     for k in ("loss_cls", "orcnn_bbox_loss"):
         assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), (k, a[k], b[k])
     assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("K,A,low,allm", [(25, 611072, True, True), (400, 50000, True, True), (1, 3000, True, False),
+                                           (130, 20000, False, True), (700, 9000, True, True)])
+def test_hbb_assignment_without_the_matrix_equals_the_matrix_route(cuda, K, A, low, allm):
+    """rsdet_hbb_assign_f32 (two passes that recompute the horizontal IoU) == rsdet_bbox_overlaps_f32 +
+    rsdet_assign_wrt_overlaps_f32 on the (K, A) matrix: gt_inds and max_overlaps bit for bit -- grid anchors with many exact
+    ties (equal IoUs across anchors and across ground truths), duplicated ground truths, tiny boxes."""
+    from rs_detection_amd.models.boxes.assigner import MaxIoUAssigner
+    from rs_detection_amd.ops import orpn
+    rng = np.random.default_rng(K + A)
+    side = int(np.sqrt(A / 7)) + 1
+    cy, cx = np.meshgrid(np.arange(side) * 4.0 + 2, np.arange(side) * 4.0 + 2, indexing="ij")
+    sizes = np.array([[16, 16], [32, 16], [16, 32], [64, 32], [32, 64], [23, 23], [90, 40]], np.float32)
+    c = np.stack([cx, cy], -1).reshape(-1, 1, 2)
+    anchors = np.concatenate([c - sizes[None] / 2, c + sizes[None] / 2], -1).reshape(-1, 4)[:A].astype(np.float32)
+    ctr = rng.uniform(0, side * 4.0, (K, 2))
+    wh = np.exp(rng.uniform(np.log(6), np.log(160), (K, 2)))
+    gts = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    if K > 4:
+        gts[3] = gts[1]                                   # a duplicated ground truth: equal rows
+        gts[2] = anchors[len(anchors) // 2]               # an IoU of exactly 1
+    a, g = torch.from_numpy(anchors).to(cuda), torch.from_numpy(gts).to(cuda)
+    asg = MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=low, gt_max_assign_all=allm,
+                         ignore_iof_thr=-1)
+    assert orpn.hbb_assign_applies(a, g)
+    got = asg.assign(a, g, None, None)
+    orpn._ON = False
+    try:
+        want = asg.assign(a, g, None, None)
+    finally:
+        orpn._ON = True
+    assert got.gt_inds.dtype == want.gt_inds.dtype and torch.equal(got.gt_inds, want.gt_inds)
+    assert torch.equal(got.max_overlaps, want.max_overlaps)
+    assert int((got.gt_inds > 0).sum()) >= min(K, 3)
+    lab = torch.from_numpy(rng.integers(0, 15, K)).to(cuda)
+    gl = asg.assign(a, g, None, lab)
+    orpn._ON = False
+    try:
+        wl = asg.assign(a, g, None, lab)
+    finally:
+        orpn._ON = True
+    assert torch.equal(gl.labels, wl.labels)
