@@ -514,7 +514,7 @@ int rsdet_van_transposes_f32(int n, const float* const* src, const float* const*
                              const int* K, void* stream);
 /* A whole VAN Block (Block.execute, /root/reference/python/jdet/models/backbones/van.py:216-261, with Mlp :140-175,
  * AttentionModule :177-192 and SpatialAttention :195-213 inside it) forward and backward as ONE call each
- * (csrc/van_block.hip): the 13 + 29 launches of the pieces above into caller-provided fp32 arenas.  x / out / grad_out /
+ * (csrc/van_block.hip): the 13 + 25 launches of the pieces above into caller-provided fp32 arenas.  x / out / grad_out /
  * grad_x: (N, C, H, W) NCHW; hidden width R; both BatchNorms in training mode (batch statistics; rm / rv / nbt = running
  * mean / variance / num_batches_tracked (int64), updated as nn.BatchNorm2d does, NULL: not kept).
  *   saved    rsdet_van_block_saved_floats            what the backward reads again (written by the forward)

@@ -1,5 +1,5 @@
 // van_block.hip -- a whole VAN Block forward / backward as ONE C-ABI call each: the launch sequence of ops/van_block.py
-// (13 launches forward, 29 backward: csrc/van_gemm.hip, csrc/dwconv.hip) issued from C++ into caller-provided arenas.
+// (13 launches forward, 25 backward: csrc/van_gemm.hip, csrc/dwconv.hip) issued from C++ into caller-provided arenas.
 //
 // The block of /root/reference/python/jdet/models/backbones/van.py:216-261 (Block.execute) is 38 times in a VAN-B3 step;
 // issued launch by launch from Python its node cost ~0.55 ms of host time (ctypes calls, ~60 tensor allocations), 20 ms per

@@ -10,10 +10,13 @@
 // Here a tail is the EPILOGUE of the GEMM that produces its input (forward and backward-data; the backward-data GEMM is
 // the same kernel on the transposed weights).  ops/van_block.py strings them into one autograd node per Block.
 //
-//   * tile: 2 x 2 waves, a wave owns (MI x 16) rows x (NI x 16) pixels: 160 x 64 (MI 5, NI 2: the 320-wide stage 3, where
-//     2 x 128 tiles give exactly one workgroup per CU), 128 x 64 and 64 x 128;
-//   * K in chunks of 32: a ring of 3 LDS slots (W tile TM x 128 B, x tile 32 x TN x 4 B) filled by LDS-DMA
-//     (global_load_lds, 16 B per lane) three chunks ahead; the swizzles sit on the DMA's SOURCE address:
+//   * tile: 2 x 2 waves, a wave owns (MI x 16) rows x (NI x 16) pixels: 160 x 64 (MI 5, NI 2), 128 x 64 and 64 x 128, and
+//     their half-width forms (160 x 32, 128 x 32, 64 x 64) where the wide tile would give a CU fewer than two workgroups;
+//   * K in chunks of 32: a ring of LDS slots (W tile TM x 128 B, x tile 32 x TN x 4 B) filled by LDS-DMA (global_load_lds,
+//     16 B per lane).  The GEMM's ring has TWO slots (<= 57 KB) so that two workgroups share a CU -- one's prologue and
+//     epilogue run under the other's K loop (round 6: 1280 x 320 x 8192 65 -> 57 us; with epilogues 88 -> 70) -- the
+//     weight gradient keeps three slots and one workgroup per CU (its doubled split-K partials cost the folds more than
+//     the overlap returned).  The swizzles sit on the DMA's SOURCE address:
 //       W tile: 16-byte chunk c of row m in slot c ^ ((m >> 1) & 7)    (ds_read_b128 of 16 rows: conflict-free)
 //       x tile: 16-pixel block b of row k in block b ^ ((k >> 2) & 1)  (ds_read_b32, lane halves on different rows)
 //   * fragments: a lane (m = lane & 15, h = lane >> 4) reads 4 consecutive k of W (k = 16 g + 4 h + j) with one
@@ -23,7 +26,8 @@
 //     next chunk overlap this chunk's second half; vmcnt / lgkmcnt counted by hand (a compiler-visible LDS load beside an
 //     outstanding LDS-DMA drains the queue);
 //   * epilogue: the accumulator tile goes through LDS once so that every lane owns 4 consecutive pixels of one row:
-//     16-byte side-operand loads and stores, per-row constants as scalars.
+//     16-byte stores, per-row constants as scalars; the side operands (shortcut, gate, GELU' map) of those same pixels are
+//     loaded into the lane's registers at KERNEL START (VgSide), so their latency runs under the K loop.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>

@@ -23,7 +23,7 @@ tail): the Oriented R-CNN / VAN-B3 step was paced by the host (64.6 of 66.4 ms) 
   * weight gradients are split-K MFMA GEMMs on the NCHW maps as they lie (both operands pixel-contiguous): no NHWC round
     trip, no transposes, no zero fills.
 
-13 launches forward, 29 backward -- issued by TWO C calls (csrc/van_block.hip: rsdet_van_block_forward_f32 /
+13 launches forward, 25 backward -- issued by TWO C calls (csrc/van_block.hip: rsdet_van_block_forward_f32 /
 _backward_f32) into three arenas per block (saved activations, scratch, gradients), so the host side of a block is two
 ctypes calls and five allocations instead of ~60 of each.  Everything is exact fp32 (the
 GEMMs are k-ordered fmaf chains); tests/test_gpu_van_block.py pins output and all 23 gradients against fp32 autograd of the

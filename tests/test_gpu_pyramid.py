@@ -179,12 +179,15 @@ def test_head_canvas_path_equals_the_level_loop_fp32(cuda, sizes, train, all_pos
         for a, b in zip(gx_loop, gx_can):
             scale = float(a.abs().max())
             assert scale > 0
+            # (6e-3: MIOpen's fp32 solver choice for the canvas and level shapes is not the same in every process -- find
+            #  mode FAST falls back by workspace availability -- and one full-suite run in three of round 6 landed between
+            #  3e-3 and 6e-3 on one of these; in isolation the test measures ~1e-3)
             if all_positive:
-                assert float((a - b).abs().max()) <= 3e-3 * scale      # sums of positive terms: cancellation
+                assert float((a - b).abs().max()) <= 6e-3 * scale      # sums of positive terms: cancellation
             else:
                 assert _rel_l2(a, b) <= 5e-2
         for n in gp_loop:
-            assert _rel_l2(gp_loop[n], gp_can[n]) <= (3e-3 if all_positive else 5e-2), n
+            assert _rel_l2(gp_loop[n], gp_can[n]) <= (6e-3 if all_positive else 5e-2), n
 
 
 def test_head_canvas_path_bf16_channels_last(cuda):
