@@ -179,9 +179,10 @@ def test_head_canvas_path_equals_the_level_loop_fp32(cuda, sizes, train, all_pos
         for a, b in zip(gx_loop, gx_can):
             scale = float(a.abs().max())
             assert scale > 0
-            # (6e-3: MIOpen's fp32 solver choice for the canvas and level shapes is not the same in every process -- find
-            #  mode FAST falls back by workspace availability -- and one full-suite run in three of round 6 landed between
-            #  3e-3 and 6e-3 on one of these; in isolation the test measures ~1e-3)
+            # (6e-3, was 3e-3: in isolation this case measures 9.7e-4 on the input gradients and 2.6e-3 on the parameter
+            #  gradients -- 88 % of the old bound -- and MIOpen's fp32 solver choice for the canvas and level shapes is not
+            #  the same in every process (find mode FAST falls back by workspace availability): one full-suite run in
+            #  three of round 6 failed here, the same code passed before and after)
             if all_positive:
                 assert float((a - b).abs().max()) <= 6e-3 * scale      # sums of positive terms: cancellation
             else:
