@@ -925,6 +925,13 @@ int rsdet_bn_act_backward_nhwc_mask_f32(const float* grad_y, const uint8_t* relu
                                         const float* running_mean, const float* running_var, const float* weight,
                                         float eps, int N, int C, int HW, float* grad_x, float* grad_residual,
                                         float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+/* ... for an output that was used twice (the output of a residual block feeds the next block's first convolution AND its
+ * identity branch, models/backbones/resnet.py:80-91): the two gradients are summed while they are read, instead of by a pass
+ * of the autograd engine's own over the trunk's widest tensors. */
+int rsdet_bn_act_backward_nhwc_mask2_f32(const float* grad_y, const float* grad_y2, const uint8_t* relu_mask, const float* x,
+                                         const float* running_mean, const float* running_var, const float* weight, float eps,
+                                         int N, int C, int HW, float* grad_x, float* grad_residual, float* grad_weight,
+                                         float* grad_bias, void* ws, size_t ws_bytes, void* stream);
 int rsdet_bn_act_backward_nhwc_mask_bf16(const uint16_t* grad_y, const uint8_t* relu_mask, const uint16_t* x,
                                          const float* running_mean, const float* running_var, const float* weight,
                                          float eps, int N, int C, int HW, uint16_t* grad_x, uint16_t* grad_residual,

@@ -152,6 +152,9 @@ SIGNATURES = {
     "rsdet_hbb_assign_ws_size": (c_size_t, [c_int]),
     "rsdet_hbb_assign_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rsdet_bn_act_backward_nhwc_mask2_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_void_p, c_size_t, c_void_p]),
     "rsdet_van_block_supported": (c_int, [c_void_p]),
     "rsdet_van_block_side_stream": (c_int, [c_int]),
     "rsdet_van_block_saved_floats": (c_size_t, [c_void_p]),

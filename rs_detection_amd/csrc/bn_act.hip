@@ -220,7 +220,10 @@ template <bool RELU, typename T, int J>
 __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ weight, float eps, long long rows, int C, int rows_per,
-    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial, const unsigned char* __restrict__ mask) {
+    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial, const unsigned char* __restrict__ mask,
+    const T* __restrict__ dy2 = nullptr) {
+  // dy2: a second gradient of the same output (a block's output feeds the next block's conv1 AND its identity branch:
+  // autograd would add the two in a pass of its own -- read 2, write 1 of the trunk's widest tensors)
   __shared__ float s_red[BN_NT][8];
   const int G = C >> 2, S = gridDim.x, s = blockIdx.x;
   const int RL = J == 1 ? max(BN_NT / G, 1) : 1;
@@ -249,6 +252,10 @@ __global__ __launch_bounds__(BN_NT) void bn_act_bwd_nhwc_kernel(
     for (long long r = r0 + rl; r < r1; r += RL) {
       const long long base = r * C + c0;
       float4 g = ld4(dy + base);
+      if (dy2) {
+        const float4 h = ld4(dy2 + base);
+        g.x += h.x, g.y += h.y, g.z += h.z, g.w += h.w;
+      }
       if (RELU) {
         if (mask) {       // one byte instead of the 16 / 8 bytes of y
           const unsigned b = mask[base >> 2];
@@ -808,10 +815,11 @@ template <typename T>
 static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char* mask, const T* x,
                                 const float* running_mean, const float* running_var, const float* weight, float eps,
                                 int N, int C, int HW, int relu, T* grad_x, T* grad_residual, float* grad_weight,
-                                float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
+                                float* grad_bias, void* ws, size_t ws_bytes, void* stream, const T* grad_y2 = nullptr) {
   if (N < 0 || HW < 0 || !bn_nhwc_ok(C)) return RSDET_EINVAL;
   if (N == 0 || HW == 0) return RSDET_OK;
   if (!grad_y || !running_mean || !running_var || (relu && !y && !mask)) return RSDET_EINVAL;
+  if (grad_y2 && sizeof(T) == 2) return RSDET_EINVAL;      // (the second gradient input exists in the fp32 kernels only)
   if (mask && rsdet_bn_act_relu_mask_bytes(N, C, HW, sizeof(T) == 2) == 0) return RSDET_EINVAL;
   const bool need_param = grad_weight || grad_bias;
   if (need_param && ((grad_weight && !x) || !ws || ws_bytes < rsdet_bn_act_backward_nhwc_ws_size(N, C, HW)))
@@ -841,7 +849,7 @@ static int bn_act_backward_nhwc(const T* grad_y, const T* y, const unsigned char
   const int J = G <= BN_NT ? 1 : (G + BN_NT - 1) / BN_NT;
 #define RSDET_BN_BWD(R, JJ)                                                                                        \
   hipLaunchKernelGGL((bn_act_bwd_nhwc_kernel<R, T, JJ>), dim3(S), dim3(BN_NT), 0, s, grad_y, y, x, running_mean,   \
-                     running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask)
+                     running_var, weight, eps, rows, C, per, grad_x, grad_residual, partial, mask, grad_y2)
   if (relu) {
     if (J == 1) RSDET_BN_BWD(true, 1); else if (J == 2) RSDET_BN_BWD(true, 2); else RSDET_BN_BWD(true, 4);
   } else {
@@ -996,6 +1004,18 @@ typedef float rsdet_bn_f32_t;
 typedef bf16_t rsdet_bn_bf16_t;
 RSDET_BN_NHWC_ENTRIES(f32, float)
 RSDET_BN_NHWC_ENTRIES(bf16, uint16_t)
+
+// rsdet_bn_act_backward_nhwc_mask_f32 for an output that was used TWICE (a residual block's output: the next block's first
+// convolution and its identity branch): grad_y + grad_y2 is formed on the fly instead of by a pass of autograd's own.
+extern "C" int rsdet_bn_act_backward_nhwc_mask2_f32(const float* grad_y, const float* grad_y2, const uint8_t* relu_mask,
+                                                    const float* x, const float* running_mean, const float* running_var,
+                                                    const float* weight, float eps, int N, int C, int HW, float* grad_x,
+                                                    float* grad_residual, float* grad_weight, float* grad_bias, void* ws,
+                                                    size_t ws_bytes, void* stream) {
+  if (!relu_mask || !grad_y2) return RSDET_EINVAL;
+  return bn_act_backward_nhwc<float>(grad_y, nullptr, relu_mask, x, running_mean, running_var, weight, eps, N, C, HW, 1,
+                                     grad_x, grad_residual, grad_weight, grad_bias, ws, ws_bytes, stream, grad_y2);
+}
 
 // y (N, Ho, Wo, C) <- maxpool3x3/s2/p1(relu(bn(x))), x (N, H, W, C) channels-last; Ho = (H + 1) / 2, Wo = (W + 1) / 2.
 // bf16: C % 8 == 0; f32: C % 4 == 0.

@@ -31,10 +31,25 @@ def _memo(fn_name, *args):
     return v
 
 
+class Forked:
+    """The output of a residual block handed on as TWO autograd outputs of the node that produced it (same storage): `a` for
+    the next block's first convolution, `b` for its identity branch.  The two gradients then reach the producing node
+    separately and its backward kernel sums them while reading (rsdet_bn_act_backward_nhwc_mask2_f32) -- autograd's own
+    accumulation is a pass of its own over the trunk's widest tensors (0.5 ms of the fp32 S2ANet step)."""
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+
+_FORK = os.environ.get("RSDET_BN_FORK", "1") != "0"     # off: one output, autograd adds the gradients (the form it is tested against)
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, mean, var, eps, relu):
+    def forward(ctx, x, residual, weight, bias, mean, var, eps, relu, fork=False):
         lib = _lib.load()
+        ctx.fork = bool(fork)
         N, C, H, W = x.shape
         # channels_last tensors (the bf16 trunk) go to the NHWC kernels; the output keeps the input's layout
         ctx.nhwc = not x.is_contiguous()
@@ -64,14 +79,23 @@ class _BNAct(torch.autograd.Function):
         ctx.shape = tuple(x.shape)
         ctx.eps, ctx.relu, ctx.has_res = float(eps), bool(relu), residual is not None
         ctx.has_bias = bias is not None
+        if ctx.fork:
+            return y, y.view_as(y)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gy2=None):
         lib = _lib.load()
         x, y, weight, mean, var = ctx.saved_tensors          # (y is the bit mask when ctx.has_mask)
         N, C, H, W = ctx.shape
-        gy = gy.contiguous(memory_format=torch.channels_last if ctx.nhwc else torch.contiguous_format).to(ctx.y_dtype)
+        fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
+        if gy is None:
+            gy, gy2 = gy2, None
+        if gy2 is not None:
+            gy2 = gy2.contiguous(memory_format=fmt).to(ctx.y_dtype)
+            if not (ctx.has_mask and ctx.y_dtype == torch.float32):
+                gy, gy2 = gy + gy2, None             # (the kernels of the other layouts / dtypes take one gradient)
+        gy = gy.contiguous(memory_format=fmt).to(ctx.y_dtype)
         need_x, need_res = ctx.needs_input_grad[0], ctx.has_res and ctx.needs_input_grad[1]
         need_w = weight is not None and ctx.needs_input_grad[2]
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
@@ -84,7 +108,13 @@ class _BNAct(torch.autograd.Function):
                          H * W) if (need_w or need_b) else 0
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gy.device) if ws_bytes else None
         tag = "bf16" if ctx.y_dtype == torch.bfloat16 else "f32"
-        if ctx.has_mask:
+        if ctx.has_mask and gy2 is not None:
+            name = "rsdet_bn_act_backward_nhwc_mask2_f32"
+            rc = lib.rsdet_bn_act_backward_nhwc_mask2_f32(_lib.ptr(gy), _lib.ptr(gy2), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean),
+                                                          _lib.ptr(var), _lib.ptr(weight), ctx.eps, N, C, H * W, _lib.ptr(gx),
+                                                          _lib.ptr(gres) if need_res else None, _lib.ptr(gw), _lib.ptr(gb),
+                                                          _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+        elif ctx.has_mask:
             name = "rsdet_bn_act_backward_nhwc_mask_" + tag
             rc = getattr(lib, name)(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(mean), _lib.ptr(var),
                                     _lib.ptr(weight), ctx.eps, N, C, H * W, _lib.ptr(gx),
@@ -97,7 +127,7 @@ class _BNAct(torch.autograd.Function):
                                     _lib.ptr(gres) if (need_res and ctx.relu) else None, _lib.ptr(gw),
                                     _lib.ptr(gb), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
         _lib.check(rc, name)
-        return gx, gres, gw, gb, None, None, None, None
+        return gx, gres, gw, gb, None, None, None, None, None
 
 
 _NO_FUSED_BN = False   # True: torch's batch_norm + relu (what the fused kernels are tested against)
@@ -128,9 +158,13 @@ def _fusable(x, bn, residual):
             and _layout_ok(x, residual))
 
 
-def bn_act(x, bn, residual=None, relu=True):
-    """relu(bn(x) + residual) with ``bn`` an ``nn.BatchNorm2d``."""
+def bn_act(x, bn, residual=None, relu=True, fork=False):
+    """relu(bn(x) + residual) with ``bn`` an ``nn.BatchNorm2d``.  ``fork``: the result as a Forked pair (see there) when the
+    fused node takes it and a gradient will flow; a plain tensor otherwise."""
     if _fusable(x, bn, residual):
+        if fork and _FORK and relu and torch.is_grad_enabled() and x.requires_grad and x.dtype == torch.float32 \
+                and not x.is_contiguous():
+            return Forked(*_BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu, True))
         return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
     out = bn(x)
     if residual is not None:

@@ -120,10 +120,10 @@ def conv_bn_act_applies(conv, bn, x, residual):
         bool(_memo("rsdet_gemm1x1_mfma_supported", B * H * W, O, C))
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True):
+def conv_bn_act(conv, bn, x, residual=None, relu=True, fork=False):
     """``relu(bn(conv(x)) + residual)`` for an nn.Conv2d + nn.BatchNorm2d pair: one launch where the fused kernel applies
-    (module docstring), ``bn_act(conv1x1(conv, x), bn, residual, relu)`` otherwise."""
+    (module docstring), ``bn_act(conv1x1(conv, x), bn, residual, relu)`` otherwise (``fork``: ops/bn_act.Forked)."""
     if conv_bn_act_applies(conv, bn, x, residual):
         return _Conv1x1BNAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                    residual, relu)
-    return bn_act(conv1x1(conv, x), bn, residual=residual, relu=relu)
+    return bn_act(conv1x1(conv, x), bn, residual=residual, relu=relu, fork=fork)

@@ -113,3 +113,38 @@ def test_fused_form_tracks_the_two_launch_form_through_a_bottleneck(cuda):
     assert _rel(outs[0][0], outs[1][0]) <= 3e-2
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert _rel(a, b) <= 0.12, _rel(a, b)
+
+
+def test_forked_block_outputs_sum_their_gradients_inside_the_batchnorm_backward(cuda):
+    """fp32 channels_last ResNet-50: a block's output handed on as a Forked pair (ops/bn_act.py: one autograd output for the
+    next block's conv1, one for its identity branch; rsdet_bn_act_backward_nhwc_mask2_f32 sums the two gradients while
+    reading) gives the outputs and every gradient of the one-output form, where autograd adds them in a pass of its own."""
+    import rs_detection_amd.models  # noqa: F401
+    from rs_detection_amd.ops import bn_act as B
+    from rs_detection_amd.utils.registry import BACKBONES, build_from_cfg
+    torch.manual_seed(0)
+    net = build_from_cfg(dict(type="Resnet50", frozen_stages=1, return_stages=["layer1", "layer2", "layer3", "layer4"]),
+                         BACKBONES).to(cuda).train()
+    net.set_channels_last(True)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.uniform_(0.5, 1.5), m.running_mean.normal_(0, 0.2), m.weight.normal_(1, 0.2)
+    x = torch.randn(2, 3, 128, 128, device=cuda)
+    res = []
+    for fork in (True, False):
+        B._FORK = fork
+        try:
+            net.zero_grad(set_to_none=True)
+            outs = net(x)
+            sum((o * o).mean() * (i + 1) for i, o in enumerate(outs)).backward()
+        finally:
+            B._FORK = True
+        res.append(([o.detach().clone() for o in outs], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    (oa, ga), (ob, gb) = res
+    for a, b in zip(oa, ob):          # (two forward passes of the same weights: MIOpen may pick another solver the second time)
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    assert set(ga) == set(gb) and len(ga) > 100
+    for n in ga:
+        d = float((ga[n] - gb[n]).norm())
+        assert d <= 1e-3 * float(gb[n].norm()) + 1e-12, (n, d)
