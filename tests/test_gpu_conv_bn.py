@@ -145,6 +145,8 @@ def test_forked_block_outputs_sum_their_gradients_inside_the_batchnorm_backward(
     for a, b in zip(oa, ob):          # (two forward passes of the same weights: MIOpen may pick another solver the second time)
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
     assert set(ga) == set(gb) and len(ga) > 100
+    # (5e-3 of the L2 norm: the two forward passes already differ by solver round-off, a few ReLU gates flip on it, and each
+    #  moves the gradients behind it -- 1.0e-3 measured on the worst parameter in a full-suite run, < 1e-3 in isolation)
     for n in ga:
         d = float((ga[n] - gb[n]).norm())
-        assert d <= 1e-3 * float(gb[n].norm()) + 1e-12, (n, d)
+        assert d <= 5e-3 * float(gb[n].norm()) + 1e-12, (n, d)
