@@ -41,7 +41,7 @@ namespace rsdet {
 typedef __attribute__((ext_vector_type(4))) float vg_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned vg_u32x4;
 
-constexpr int VG_KC = 32, VG_STAGES = 2, VG_WG_STAGES = 3, VG_NT = 256;
+constexpr int VG_KC = 32, VG_STAGES = 2, VG_NT = 256;
 
 // epilogues (r = output row = channel, p = pixel; v* per-row vectors, s* side maps in the output's layout)
 constexpr int VG_NONE = 0;        // out0 = acc
@@ -355,16 +355,16 @@ __global__ __launch_bounds__(VG_NT, ST == 2 ? 2 : 1) void van_gemm_f32_kernel(Vg
 // Both operands are pixel-contiguous rows: both tiles take the W-tile layout above (rows x 32 pixels, chunk swizzle), both
 // fragments are ds_read_b128.  Split-K over the (image, 32-pixel chunk) sequence: workgroup (split, tile) sums a contiguous
 // range of chunks and leaves its TM x 64 partial in partial[split][m][n]; the folds below sum the splits in order.
-template <int MI>
-__global__ __launch_bounds__(VG_NT, VG_WG_STAGES == 2 ? 2 : 1) void van_wgrad_f32_kernel(const float* __restrict__ g, const float* __restrict__ x,
+template <int MI, int NI, int ST>
+__global__ __launch_bounds__(VG_NT, ST == 2 ? 2 : 1) void van_wgrad_f32_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                  int M, int N, int P, int n_img, int m_tiles, int n_tiles,
                                                                  int splits, float* __restrict__ partial) {
-  constexpr int NI = 2, TM = 2 * MI * 16, TN = 64;
+  constexpr int TM = 2 * MI * 16, TN = 2 * NI * 16;
   constexpr int A_BYTES = TM * 128, B_BYTES = TN * 128, SLOT = A_BYTES + B_BYTES;
   constexpr int A_OPS = TM / 8 / 4, B_OPS = TN / 8 / 4, OPS = A_OPS + B_OPS;
   constexpr int CROW = TN + 4;
-  static_assert(TM * CROW * 4 <= VG_WG_STAGES * SLOT, "the accumulator tile must fit in the ring");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[VG_WG_STAGES * SLOT];
+  static_assert(TM * CROW * 4 <= ST * SLOT, "the accumulator tile must fit in the ring");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[ST * SLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = m_tiles * n_tiles, total = tiles * splits;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(VG_NT, VG_WG_STAGES == 2 ? 2 : 1) void van_wgrad_f3
   }
   auto issue_one = [&](auto k_c, int kc) {
     constexpr int KI = decltype(k_c)::value;
-    unsigned char* slot = lds + (kc % VG_WG_STAGES) * SLOT;
+    unsigned char* slot = lds + (kc % ST) * SLOT;
     const int q = q0 + kc, img = q / cpi, px = (q - img * cpi) * VG_KC;
     if constexpr (KI < A_OPS)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[KI] + ((long long)img * M * P + px)),
@@ -434,29 +434,29 @@ __global__ __launch_bounds__(VG_NT, VG_WG_STAGES == 2 ? 2 : 1) void van_wgrad_f3
   using C1 = std::integral_constant<int, 1>;
   if (nk > 0) {
 #pragma unroll
-    for (int kc = 0; kc < VG_WG_STAGES; ++kc)
+    for (int kc = 0; kc < ST; ++kc)
       if (kc < nk) issue(kc);
-    if (VG_WG_STAGES == 3 && nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk >= 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+    if (ST == 3 && nk >= 3) vg_wait_vm<2 * OPS>(); else if (nk >= 2) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
     vg_barrier();
     vg_static_for<0, NREADS>([&](auto k_c) { read_one(C0{}, C0{}, k_c, lds_base); });
     vg_wait_lgkm0();
     auto chunk = [&](int s, auto dma_c, auto more_c, bool dma, bool more) {
       constexpr bool DMA_CT = decltype(dma_c)::value != 0, MORE_CT = decltype(more_c)::value != 0;
-      const unsigned slot_base = lds_base + (s % VG_WG_STAGES) * SLOT;
-      const unsigned next_base = lds_base + ((s + 1) % VG_WG_STAGES) * SLOT;
+      const unsigned slot_base = lds_base + (s % ST) * SLOT;
+      const unsigned next_base = lds_base + ((s + 1) % ST) * SLOT;
       mfma_group(C0{}, [&](auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < NREADS) read_one(C1{}, C1{}, i_c, slot_base);
       });
       vg_wait_lgkm0();
       if (MORE_CT || more) {
-        if (VG_WG_STAGES == 3 && (DMA_CT || s + 2 < nk)) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
+        if (ST == 3 && (DMA_CT || s + 2 < nk)) vg_wait_vm<OPS>(); else vg_wait_vm<0>();
         vg_barrier();
       }
       mfma_group(C1{}, [&](auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < OPS) {
-          if (DMA_CT || dma) issue_one(i_c, s + VG_WG_STAGES);
+          if (DMA_CT || dma) issue_one(i_c, s + ST);
         } else if constexpr (I - OPS < NREADS) {
           if (MORE_CT || more) read_one(C0{}, C0{}, std::integral_constant<int, I - OPS>{}, next_base);
         }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(VG_NT, VG_WG_STAGES == 2 ? 2 : 1) void van_wgrad_f3
       vg_wait_lgkm0();
     };
     int s = 0;
-    for (; s + VG_WG_STAGES < nk; ++s) chunk(s, C1{}, C1{}, true, true);
+    for (; s + ST < nk; ++s) chunk(s, C1{}, C1{}, true, true);
     for (; s < nk; ++s) chunk(s, C0{}, C0{}, false, s + 1 < nk);
   }
   vg_acc_fence(acc);
@@ -927,12 +927,25 @@ extern "C" int rsdet_van_wgrad_f32(const float* g, const float* x, int M, int N,
   const int S = rsdet_van_wgrad_f32_splits(M, N, P, n_img);
   const dim3 grid((unsigned)(m_tiles * n_tiles * S));
   hipStream_t s = (hipStream_t)stream;
-if (mi == 5)
-    hipLaunchKernelGGL((van_wgrad_f32_kernel<5>), grid, dim3(VG_NT), 0, s, g, x, M, N, P, n_img, m_tiles, n_tiles, S, partial);
-  else if (mi == 4)
-    hipLaunchKernelGGL((van_wgrad_f32_kernel<4>), grid, dim3(VG_NT), 0, s, g, x, M, N, P, n_img, m_tiles, n_tiles, S, partial);
-  else
-    hipLaunchKernelGGL((van_wgrad_f32_kernel<2>), grid, dim3(VG_NT), 0, s, g, x, M, N, P, n_img, m_tiles, n_tiles, S, partial);
+  // One workgroup per CU on three-slot rings.  Measured against it in round 6 (Oriented R-CNN step, same box, three runs
+  // each): two-slot rings with twice the splits (kernels 7.06 -> 6.81 ms, the folds that sum twice the partials 1.91 -> 2.32
+  // ms), and half-width tiles (M-tile x 32 columns) on two-slot rings at the SAME number of partials -- two workgroups per
+  // CU like the GEMM -- 39.40 vs 39.23 tiles/s: the narrow tile's extra LDS reads per MFMA cost what the overlap returns.
+  // RSDET_VG_WGRAD_NARROW=1 selects the latter.
+  static const bool wide = [] { const char* e = getenv("RSDET_VG_WGRAD_NARROW"); return !(e && e[0] == '1'); }();
+#define VG_WGRAD(MI_)                                                                                                     \
+  do {                                                                                                                    \
+    if (wide)                                                                                                             \
+      hipLaunchKernelGGL((van_wgrad_f32_kernel<MI_, 2, 3>), grid, dim3(VG_NT), 0, s, g, x, M, N, P, n_img, m_tiles,       \
+                         n_tiles, S, partial);                                                                            \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((van_wgrad_f32_kernel<MI_, 1, 2>), dim3((unsigned)(m_tiles * 2 * n_tiles * S)), dim3(VG_NT), 0,  \
+                         s, g, x, M, N, P, n_img, m_tiles, 2 * n_tiles, S, partial);                                      \
+  } while (0)
+  if (mi == 5) VG_WGRAD(5);
+  else if (mi == 4) VG_WGRAD(4);
+  else VG_WGRAD(2);
+#undef VG_WGRAD
   return rsdet_launch_status();
 }
 
