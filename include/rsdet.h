@@ -336,6 +336,31 @@ size_t rsdet_deform_col2im_gather_ws_size(const rsdet_dcn_geom* g);
 int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset, const rsdet_dcn_geom* g,
                                         float* grad_im, void* ws, size_t ws_bytes, void* stream);
 
+/* The same index for SEVERAL calls in one go -- the five AlignConv levels of a step (models/roi_heads/s2anet_head.py:
+ * 603-660 calls DeformConv once per level; each backward, dcn_v1.py:456-556, scatters on its own): pixels and items of
+ * the levels are laid end to end, ONE histogram / scan / fill (5 launches in all) inverts every level's map, then each
+ * level gathers with rsdet_deform_col2im_gather_indexed_nhwc_*.  index_multi writes, for the host, pix_base[0..n]
+ * (level l's start array = (int*)((char*)ws + aligned start offset) -- returned through the level's own pointer below)
+ * and the byte offsets of the shared ent_row / ent_w arrays inside ws.  A level's `start` argument of the gather is
+ * (const int*)((char*)ws + start_offset) + pix_base[l] with start_offset = ((n_pix_total + 1) * 4 rounded up to 256).
+ * Same results as the per-call form up to the order of the fp32 additions inside one pixel (entries of a pixel are
+ * filed in arrival order in both forms). */
+#define RSDET_DCN_INDEX_MAX_LEVELS 8
+typedef struct rsdet_dcn_index_levels {
+  int n_levels;
+  const float* offset[RSDET_DCN_INDEX_MAX_LEVELS]; /* (B, 2*kh*kw, Ho, Wo) of each level */
+  rsdet_dcn_geom geom[RSDET_DCN_INDEX_MAX_LEVELS]; /* dg must be 1 */
+} rsdet_dcn_index_levels;
+size_t rsdet_deform_col2im_index_multi_ws_size(const rsdet_dcn_index_levels* levels);
+int rsdet_deform_col2im_index_multi_f32(const rsdet_dcn_index_levels* levels, void* ws, size_t ws_bytes,
+                                        long long* pix_base, size_t* ent_row_offset, size_t* ent_w_offset,
+                                        void* stream);
+int rsdet_deform_col2im_gather_indexed_nhwc_f32(const float* colT, const rsdet_dcn_geom* g, const int* start,
+                                                const int* ent_row, const float* ent_w, float* grad_im, void* stream);
+int rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32(const uint16_t* colT, const rsdet_dcn_geom* g,
+                                                        const int* start, const int* ent_row, const float* ent_w,
+                                                        float* grad_im, void* stream);
+
 /* bf16 column matrices for the autocast step (BASELINE configs 2 / 4): the products that consume / produce them run
  * on bf16 MFMA through rocBLAS, the images, offsets, interpolation weights, sums and grad_im stay fp32.
  * im2col_bf16col: same as rsdet_deform_im2col_f32 (dcn_v1.py:309-339) with col stored as bf16 (round to nearest

@@ -23,6 +23,11 @@ class DcnGeom(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("C", "H", "W", "kh", "kw", "ph", "pw", "sh", "sw", "dh", "dw", "B", "dg")]
 
 
+class DcnIndexLevels(ctypes.Structure):
+    """struct rsdet_dcn_index_levels (include/rsdet.h)."""
+    _fields_ = [("n_levels", c_int), ("offset", c_void_p * 8), ("geom", DcnGeom * 8)]
+
+
 class VanBnFold(ctypes.Structure):
     """struct rsdet_van_bn_fold (include/rsdet.h)."""
     _fields_ = ([(n, c_void_p) for n in ("partial", "wt", "gs_tab", "r_tab", "ls", "mean", "rstd", "sc", "sh", "grad_w",
@@ -222,6 +227,14 @@ SIGNATURES = {
     "rsdet_deform_col2im_gather_ws_size": (c_size_t, [ctypes.POINTER(DcnGeom)]),
     "rsdet_deform_col2im_gather_nhwc_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p,
                                                     c_size_t, c_void_p]),
+    "rsdet_deform_col2im_index_multi_ws_size": (c_size_t, [ctypes.POINTER(DcnIndexLevels)]),
+    "rsdet_deform_col2im_index_multi_f32": (c_int, [ctypes.POINTER(DcnIndexLevels), c_void_p, c_size_t,
+                                                    ctypes.POINTER(c_ll), ctypes.POINTER(c_size_t),
+                                                    ctypes.POINTER(c_size_t), c_void_p]),
+    "rsdet_deform_col2im_gather_indexed_nhwc_f32": (c_int, [c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p,
+                                                            c_void_p, c_void_p, c_void_p]),
+    "rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32": (c_int, [c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
+                                                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_deform_im2col_bf16col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),
     "rsdet_deform_col2im_gather_nhwc_bf16col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
                                                             c_void_p, c_size_t, c_void_p]),

@@ -533,6 +533,65 @@ __global__ __launch_bounds__(256) void dcn_idx_fill_kernel(const float* __restri
 #undef RSDET_PUT
 }
 
+// ---- the same index for SEVERAL calls at once (the five AlignConv levels of one step) ----
+// Pixels and items of the levels are laid end to end: one histogram, one scan and one fill serve all of them
+// (5 launches instead of 5 per level; the small levels cost ~5 us of launch latency each on their own).  Workgroups
+// map to levels through blk_base so that a workgroup never straddles two geometries; entries hold the item id INSIDE
+// their level, start[] holds slots of the shared entry arrays, so a level's gather reads start + pix_base[l] with the
+// shared ent_row / ent_w.
+constexpr int DCN_IDX_LEVELS = RSDET_DCN_INDEX_MAX_LEVELS;
+
+struct IdxLevels {
+  int n;
+  unsigned blk_base[DCN_IDX_LEVELS + 1];
+  long long pix_base[DCN_IDX_LEVELS + 1];
+  long long items[DCN_IDX_LEVELS];
+  const float* offset[DCN_IDX_LEVELS];
+  Geom g[DCN_IDX_LEVELS];
+};
+
+__device__ __forceinline__ int idx_level_of(const IdxLevels& lv, unsigned blk) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DCN_IDX_LEVELS; ++i)
+    if (i < lv.n && blk >= lv.blk_base[i]) l = i;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void dcn_idx_count_multi_kernel(const IdxLevels lv, int* __restrict__ cnt) {
+  const int l = idx_level_of(lv, blockIdx.x);
+  const long long item = (long long)(blockIdx.x - lv.blk_base[l]) * 256 + threadIdx.x;
+  if (item >= lv.items[l]) return;
+  const PixFoot t = pix_foot(lv.offset[l], lv.g[l], item);
+  int* c = cnt + lv.pix_base[l];
+  if (t.p1 >= 0) atomicAdd(c + t.p1, 1);
+  if (t.p2 >= 0) atomicAdd(c + t.p2, 1);
+  if (t.p3 >= 0) atomicAdd(c + t.p3, 1);
+  if (t.p4 >= 0) atomicAdd(c + t.p4, 1);
+}
+
+__global__ __launch_bounds__(256) void dcn_idx_fill_multi_kernel(const IdxLevels lv, const int* __restrict__ start,
+                                                                 int* __restrict__ fill, int* __restrict__ ent_row,
+                                                                 float* __restrict__ ent_w) {
+  const int l = idx_level_of(lv, blockIdx.x);
+  const long long item = (long long)(blockIdx.x - lv.blk_base[l]) * 256 + threadIdx.x;
+  if (item >= lv.items[l]) return;
+  const PixFoot t = pix_foot(lv.offset[l], lv.g[l], item);
+  const int* st = start + lv.pix_base[l];
+  int* fl = fill + lv.pix_base[l];
+#define RSDET_PUT(P, Wt)                                 \
+  if (P >= 0) {                                          \
+    const int slot = st[P] + atomicAdd(fl + P, 1);       \
+    ent_row[slot] = (int)item;                           \
+    ent_w[slot] = Wt;                                    \
+  }
+  RSDET_PUT(t.p1, t.w1)
+  RSDET_PUT(t.p2, t.w2)
+  RSDET_PUT(t.p3, t.w3)
+  RSDET_PUT(t.p4, t.w4)
+#undef RSDET_PUT
+}
+
 // one wave per input pixel; pixels are walked in 8x8 tiles so that the four pixels sharing a colT row
 // (the corners of one sampling point) are processed close together, and the workgroup ids are renumbered so that an
 // XCD owns a contiguous run of tiles (rsdet_xcd_contiguous): round-robin placement would put the four on four
@@ -791,6 +850,110 @@ static int dcn_col2im_gather(const TROW* colT, const float* offset, const rsdet_
     hipLaunchKernelGGL((dcn_gather_kernel<false, TROW>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start,
                        ent_row, ent_w, g, grad_im);
   return rsdet_launch_status();
+}
+
+// ---- shared index of several levels: build once, gather per level ----
+struct IdxPlan {
+  IdxLevels lv;
+  long long npix, nitems;
+  size_t off_start, off_row, off_w, off_chunk, bytes;
+};
+
+static int idx_plan(const rsdet_dcn_index_levels* s, IdxPlan* p) {
+  if (!s || s->n_levels < 1 || s->n_levels > DCN_IDX_LEVELS) return RSDET_EINVAL;
+  IdxLevels& lv = p->lv;
+  lv.n = s->n_levels;
+  long long pix = 0, items = 0, blk = 0;
+  for (int l = 0; l < lv.n; ++l) {
+    int rc = make_geom(&s->geom[l], &lv.g[l]);
+    if (rc) return rc;
+    const Geom& g = lv.g[l];
+    if (g.dg != 1) return RSDET_EINVAL;
+    lv.items[l] = (long long)g.B * g.Ho * g.Wo * g.kh * g.kw;
+    lv.offset[l] = s->offset[l];
+    if (lv.items[l] > 0 && !s->offset[l]) return RSDET_EINVAL;
+    lv.pix_base[l] = pix;
+    lv.blk_base[l] = (unsigned)blk;
+    pix += (long long)g.B * g.H * g.W;
+    items += lv.items[l];
+    blk += (lv.items[l] + 255) / 256;
+  }
+  lv.pix_base[lv.n] = pix;
+  lv.blk_base[lv.n] = (unsigned)blk;
+  if (items * 4 > 0x7fffffffLL || blk > 0x7fffffffLL) return RSDET_EINVAL;  // int slots
+  p->npix = pix;
+  p->nitems = items;
+  p->off_start = dcn_align256((size_t)(pix + 1) * 4);
+  p->off_row = p->off_start * 2;
+  p->off_w = p->off_row + dcn_align256((size_t)items * 4 * 4);
+  p->off_chunk = p->off_w + dcn_align256((size_t)items * 4 * 4);
+  p->bytes = p->off_chunk + dcn_align256(((size_t)pix / 4096 + 1) * 4);
+  return RSDET_OK;
+}
+
+extern "C" size_t rsdet_deform_col2im_index_multi_ws_size(const rsdet_dcn_index_levels* levels) {
+  IdxPlan p;
+  return idx_plan(levels, &p) ? 0 : p.bytes;
+}
+
+extern "C" int rsdet_deform_col2im_index_multi_f32(const rsdet_dcn_index_levels* levels, void* ws, size_t ws_bytes,
+                                                   long long* pix_base, size_t* ent_row_offset,
+                                                   size_t* ent_w_offset, void* stream) {
+  IdxPlan p;
+  int rc = idx_plan(levels, &p);
+  if (rc) return rc;
+  if (!pix_base || !ent_row_offset || !ent_w_offset) return RSDET_EINVAL;
+  if (!ws || ((uintptr_t)ws & 15) || ws_bytes < p.bytes) return RSDET_EINVAL;
+  for (int l = 0; l <= p.lv.n; ++l) pix_base[l] = p.lv.pix_base[l];
+  *ent_row_offset = p.off_row;
+  *ent_w_offset = p.off_w;
+  if (p.npix == 0) return RSDET_OK;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)ws;
+  int* cnt = (int*)w;
+  int* start = (int*)(w + p.off_start);
+  const unsigned blocks = p.lv.blk_base[p.lv.n];
+  if (hipMemsetAsync(cnt, 0, (size_t)(p.npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+  if (blocks > 0) hipLaunchKernelGGL(dcn_idx_count_multi_kernel, dim3(blocks), dim3(256), 0, s, p.lv, cnt);
+  rsdet_launch_index_scan(cnt, p.npix, (int*)(w + p.off_chunk), start, s);
+  if (blocks > 0)
+    hipLaunchKernelGGL(dcn_idx_fill_multi_kernel, dim3(blocks), dim3(256), 0, s, p.lv, start, cnt,
+                       (int*)(w + p.off_row), (float*)(w + p.off_w));
+  return rsdet_launch_status();
+}
+
+template <typename TROW>
+static int dcn_col2im_gather_indexed(const TROW* colT, const rsdet_dcn_geom* geom, const int* start,
+                                     const int* ent_row, const float* ent_w, float* grad_im, void* stream) {
+  Geom g;
+  int rc = make_geom(geom, &g);
+  if (rc) return rc;
+  if (g.dg != 1) return RSDET_EINVAL;
+  const long long npos = (long long)g.B * g.Ho * g.Wo, npix = (long long)g.B * g.H * g.W;
+  if (npix == 0 || g.C == 0) return RSDET_OK;
+  if (!start || !ent_row || !ent_w || !grad_im || (npos > 0 && !colT)) return RSDET_EINVAL;
+  const bool vec4 = (g.C % 4 == 0) && ((uintptr_t)colT % (4 * sizeof(TROW)) == 0) && ((uintptr_t)grad_im % 16 == 0);
+  const unsigned blocks = (unsigned)((npix + DCN_WAVES - 1) / DCN_WAVES);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec4)
+    hipLaunchKernelGGL((dcn_gather_kernel<true, TROW>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start, ent_row,
+                       ent_w, g, grad_im);
+  else
+    hipLaunchKernelGGL((dcn_gather_kernel<false, TROW>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start,
+                       ent_row, ent_w, g, grad_im);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_deform_col2im_gather_indexed_nhwc_f32(const float* colT, const rsdet_dcn_geom* geom,
+                                                           const int* start, const int* ent_row, const float* ent_w,
+                                                           float* grad_im, void* stream) {
+  return dcn_col2im_gather_indexed<float>(colT, geom, start, ent_row, ent_w, grad_im, stream);
+}
+
+extern "C" int rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32(const uint16_t* colT, const rsdet_dcn_geom* geom,
+                                                                   const int* start, const int* ent_row,
+                                                                   const float* ent_w, float* grad_im, void* stream) {
+  return dcn_col2im_gather_indexed<bf16_t>((const bf16_t*)colT, geom, start, ent_row, ent_w, grad_im, stream);
 }
 
 extern "C" int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset,

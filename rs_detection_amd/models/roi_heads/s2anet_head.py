@@ -460,13 +460,15 @@ class S2ANetHead(nn.Module):
         outs = [[], [], [], [], []]
         packed = self._packed_ok(feats) and len(feats) == len(self.anchor_strides)
         groups = self._level_groups(len(feats), feats[0].dtype) if packed else [(i, i + 1) for i in range(len(feats))]
-        for a, b in groups:
-            if b - a == 1:
-                o = [[v] for v in self.forward_single(feats[a], self.anchor_strides[a])]
-            else:
-                o = self.forward_packed(feats[a:b], first_level=a)
-            for dst, src in zip(outs, o):
-                dst.extend(src)
+        from rs_detection_amd.ops.dcn_v1 import shared_gather_index
+        with shared_gather_index():     # the AlignConv backwards of all levels share one col2im index build
+            for a, b in groups:
+                if b - a == 1:
+                    o = [[v] for v in self.forward_single(feats[a], self.anchor_strides[a])]
+                else:
+                    o = self.forward_packed(feats[a:b], first_level=a)
+                for dst, src in zip(outs, o):
+                    dst.extend(src)
         return tuple(outs)
 
     def forward(self, feats, targets):

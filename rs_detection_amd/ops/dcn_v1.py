@@ -12,6 +12,7 @@ MI355X-first differences from the reference's host logic (free per SURVEY q17):
   * the offset gradient is computed only when the offset requires grad
     (AlignConv builds offsets under no_grad, s2anet_head.py:676 / SURVEY q16).
 """
+import ctypes
 import math
 import os
 
@@ -119,9 +120,82 @@ def deformable_col2im_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride,
     return grad_im
 
 
-def deformable_col2im_gather_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride, dilation):
+class GatherIndexPlan:
+    """The calls of ONE forward pass whose backward uses the gather-form col2im (the five AlignConv levels of a step):
+    the first backward that needs its index builds the index of ALL of them -- pixels and items laid end to end, one
+    histogram / scan / fill (csrc/deform_conv.hip, rsdet_deform_col2im_index_multi_f32: 5 launches instead of 5 per
+    level) -- and every level then only gathers.  Offsets are inputs without gradient (s2anet_head.py:676), so all of
+    them exist when the first backward runs."""
+    MAX = 8     # RSDET_DCN_INDEX_MAX_LEVELS
+
+    def __init__(self):
+        self.calls = []          # (offset tensor (contiguous fp32), geometry tuple)
+        self.built = {}          # chunk -> (ws, start byte offset, pix_base list, ent_row offset, ent_w offset)
+
+    def add(self, offset, C, H, W, kernel, padding, stride, dilation, B):
+        self.calls.append((offset, (C, H, W, *kernel, *padding, *stride, *dilation, B, 1)))
+        return (self, len(self.calls) - 1)
+
+    def index(self, i):
+        """(start, ent_row, ent_w) device addresses of call i; builds its chunk of <= MAX calls on first use."""
+        chunk = i // self.MAX
+        if chunk not in self.built:
+            lib = _lib.load()
+            calls = self.calls[chunk * self.MAX:(chunk + 1) * self.MAX]
+            lv = _lib.DcnIndexLevels()
+            lv.n_levels = len(calls)
+            npix = 0
+            for l, (off, g) in enumerate(calls):
+                lv.offset[l] = _lib.ptr(off)
+                lv.geom[l] = _geom(*g)
+                npix += g[11] * g[1] * g[2]
+            ws_bytes = lib.rsdet_deform_col2im_index_multi_ws_size(lv)
+            if ws_bytes == 0:
+                raise RuntimeError("rsdet_deform_col2im_index_multi_ws_size: unsupported geometry")
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=calls[0][0].device)
+            pix_base = (_lib.c_ll * (self.MAX + 1))()
+            row_off, w_off = _lib.c_size_t(0), _lib.c_size_t(0)
+            _lib.check(lib.rsdet_deform_col2im_index_multi_f32(lv, _lib.ptr(ws), ws_bytes, pix_base, ctypes.byref(row_off),
+                                                               ctypes.byref(w_off), _lib.stream_ptr()),
+                       "rsdet_deform_col2im_index_multi_f32")
+            start_off = ((npix + 1) * 4 + 255) & ~255
+            self.built[chunk] = (ws, start_off, list(pix_base), row_off.value, w_off.value)
+        ws, start_off, pix_base, row_off, w_off = self.built[chunk]
+        base = ws.data_ptr()
+        return base + start_off + 4 * pix_base[i % self.MAX], base + row_off, base + w_off
+
+
+_PLAN = None                    # the plan collecting the current forward pass (shared_gather_index), or None
+_SHARED_INDEX = os.environ.get("RSDET_DCN_SHARED_INDEX", "1") != "0"
+
+
+class shared_gather_index:
+    """``with shared_gather_index():`` around the forward of several DeformConv calls: their gather-form col2im
+    backwards share one index build (GatherIndexPlan)."""
+
+    def __enter__(self):
+        global _PLAN
+        self.prev = _PLAN
+        _PLAN = GatherIndexPlan() if _SHARED_INDEX else None
+        return _PLAN
+
+    def __exit__(self, *exc):
+        global _PLAN
+        _PLAN = self.prev
+        return False
+
+
+def _plan_slot(ctx, offset, C, H, W, kernel, padding, stride, dilation, B, dg):
+    """Registers the call with the current plan (forward time); None when there is none or the gather form will not run."""
+    if _PLAN is None or dg != 1 or not ctx.needs_input_grad[0]:
+        return None
+    return _PLAN.add(offset, C, H, W, kernel, padding, stride, dilation, B)
+
+
+def deformable_col2im_gather_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride, dilation, slot=None):
     """colT (B*Ho*Wo, kh*kw*C) -> grad_im (B,H,W,C) without floating-point atomics (one deformable group):
-    the scatter map is inverted on integers first, then every input pixel gathers its terms."""
+    the scatter map is inverted on integers first, then every input pixel gathers its terms.  ``slot`` = the call's
+    entry in a GatherIndexPlan: the index comes from the plan's shared build."""
     lowp = colT.dtype == torch.bfloat16  # column gradient out of a bf16 GEMM (autocast step); grad_im stays fp32
     _lib.require_cuda_f32(None if lowp else colT, offset)
     lib = _lib.load()
@@ -130,6 +204,13 @@ def deformable_col2im_gather_nhwc(colT, offset, im_shape_nhwc, kernel, padding, 
     (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
     grad_im = torch.empty((B, H, W, C), dtype=torch.float32, device=colT.device)
     g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, 1)
+    if slot is not None:
+        plan, i = slot
+        start, ent_row, ent_w = plan.index(i)
+        name = "rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32" if lowp else "rsdet_deform_col2im_gather_indexed_nhwc_f32"
+        _lib.check(getattr(lib, name)(_lib.ptr(colT), g, start, ent_row, ent_w, _lib.ptr(grad_im), _lib.stream_ptr()),
+                   name)
+        return grad_im
     ws_bytes = lib.rsdet_deform_col2im_gather_ws_size(g)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=colT.device)
     name = "rsdet_deform_col2im_gather_nhwc_bf16col_f32" if lowp else "rsdet_deform_col2im_gather_nhwc_f32"
@@ -186,6 +267,7 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
             ctx.col_is_T = True
             ctx.save_for_backward(off, weight, colT)
             ctx.in_shape = (B, C, H, W)
+            ctx.slot = _plan_slot(ctx, off, C, H, W, (kh, kw), ctx.cfg[1], ctx.cfg[0], ctx.cfg[2], B, deformable_groups)
             return out
         col = deformable_im2col(input, offset, (kh, kw), ctx.cfg[1], ctx.cfg[0], ctx.cfg[2], deformable_groups,
                                 col_dtype=cdt)
@@ -195,8 +277,10 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
         out = torch.empty((B, O, Ho, Wo), dtype=cdt, device=input.device)  # returned as is (callers apply ReLU in place)
         torch.bmm(w_flat.unsqueeze(0).expand(B, O, C * kh * kw), col.view(C * kh * kw, B, hw).permute(1, 0, 2),
                   out=out.view(B, O, hw))
+        offset = offset.contiguous()
         ctx.save_for_backward(offset, weight, col)
         ctx.in_shape = (B, C, H, W)
+        ctx.slot = _plan_slot(ctx, offset, C, H, W, (kh, kw), ctx.cfg[1], ctx.cfg[0], ctx.cfg[2], B, deformable_groups)
         return out
 
     @staticmethod
@@ -219,7 +303,8 @@ class DeformConvFunctionNHWC(torch.autograd.Function):
             w_ok = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C).to(cdt)  # K index = tap*C + c
             gcolT = torch.mm(go2.t(), w_ok)  # (B*hw, kh*kw*C): channels-last column gradient
             if dg == 1:  # gather form: no floating-point atomics (3.4x faster at pyramid level 0)
-                gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation)
+                gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation,
+                                                   slot=getattr(ctx, "slot", None))
             else:
                 gi = deformable_col2im_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation, dg)
             grad_input = nhwc_to_nchw(gi)
@@ -257,7 +342,8 @@ def _dcn_backward_channels_last(ctx, grad_output):
         w_ok = weight.permute(0, 2, 3, 1).reshape(O, kh * kw * C)
         gcolT = torch.mm(go, w_ok)                                 # (P, kh*kw*C)
         if dg == 1:
-            gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation)
+            gi = deformable_col2im_gather_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation,
+                                                   slot=getattr(ctx, "slot", None))
         else:
             gi = deformable_col2im_nhwc(gcolT, offset, (B, H, W, C), (kh, kw), padding, stride, dilation, dg)
         grad_input = gi.permute(0, 3, 1, 2)                        # channels_last storage, NCHW shape
@@ -334,6 +420,7 @@ class AlignConvMFMAFunction(torch.autograd.Function):
         ctx.shape = (B, C, H, W, O, Ho, Wo)
         ctx.padding = padding
         ctx.in_dtype = input.dtype
+        ctx.slot = _plan_slot(ctx, off, C, H, W, (3, 3), tuple(padding), (1, 1), (1, 1), B, 1)
         return out
 
     @staticmethod
@@ -347,7 +434,8 @@ class AlignConvMFMAFunction(torch.autograd.Function):
         grad_input = grad_weight = None
         if ctx.needs_input_grad[0]:
             gcolT = torch.mm(go, w_flat)                   # (P, 9*C): channels-last column gradient, bf16
-            gi = deformable_col2im_gather_nhwc(gcolT, off, (B, H, W, C), (3, 3), ctx.padding, (1, 1), (1, 1))
+            gi = deformable_col2im_gather_nhwc(gcolT, off, (B, H, W, C), (3, 3), ctx.padding, (1, 1), (1, 1),
+                                               slot=ctx.slot)
             grad_input = gi.permute(0, 3, 1, 2).to(ctx.in_dtype)
         if ctx.needs_input_grad[2]:
             if colT is None:

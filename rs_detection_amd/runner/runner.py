@@ -361,7 +361,8 @@ class Runner:
     def predict(self, images, targets):
         """Inference in the dtype the model trains in: fp32, or bf16 autocast (with bf16 parameters the convolutions
         need it: their weights ARE bf16)."""
-        self.model.eval()
+        if self.model.training:         # (only on the first call of an evaluation: walking 8 000 modules costs 1.7 ms, 15 % of
+            self.model.eval()           #  a B = 1 call)
         if self.memory_format is not None:
             images = images.contiguous(memory_format=self.memory_format)
         if self.amp_dtype is not None:

@@ -22,8 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # round 6: the VAN Block as one node of 42 launches (csrc/van_block.hip): orcnn 4313 -> 3560 + 12 fills; the heads'
 # control path as kernels (csrc/orpn.hip: proposals, samplers, RPN losses on the samples, RoI targets): -> 2165 + 12; the
 # block's row folds and depthwise finishing passes as one launch each: -> 2013 + 12
-# end of round 6, measured: s2anet f32 834 + 13 fills, bf16 600 + 17, orcnn 1975 + 14
-BUDGET = {("s2anet", "f32"): (875, 0), ("s2anet", "bf16"): (640, 0), ("orcnn", "f32"): (2050, 0)}
+# end of round 6, measured: s2anet f32 834 + 13 fills, bf16 600 + 17, orcnn 1975 + 14; then the AlignConv backwards of the
+# five levels share one col2im index build (25 launches + 5 fills -> 9 + 1): s2anet f32 and bf16 -20
+BUDGET = {("s2anet", "f32"): (855, 0), ("s2anet", "bf16"): (620, 0), ("orcnn", "f32"): (2050, 0)}
 
 
 @pytest.fixture(scope="module")

@@ -128,6 +128,53 @@ def test_deform_col2im_gather_level0_shape_matches_scatter(cuda):
         assert float((a - g).abs().max()) <= 1e-4 * float(a.abs().max())
 
 
+def test_deform_col2im_shared_index_over_levels_matches_per_call(cuda):
+    """GatherIndexPlan: the five pyramid levels of a step (and ten calls: two chunks of the 8-level C struct; odd sizes,
+    fp32 and bf16 columns) indexed by ONE build == each call building its own index.  Entries of a pixel are filed in
+    the order an atomic counter hands out in both forms, so sums agree to rounding, not bit for bit."""
+    from rs_detection_amd.ops.dcn_v1 import GatherIndexPlan, deformable_col2im_gather_nhwc
+    torch.manual_seed(11)
+    shapes = [(4, 64, 128, 128), (4, 64, 64, 64), (4, 64, 32, 32), (4, 64, 16, 16), (4, 64, 8, 8),
+              (2, 30, 37, 21), (1, 8, 5, 3), (2, 16, 1, 9), (3, 4, 2, 2), (1, 12, 40, 40)]
+    for dt in (torch.float32, torch.bfloat16):
+        plan, calls = GatherIndexPlan(), []
+        for (B, C, H, W) in shapes:
+            off = (torch.randn(B, 18, H, W, device=cuda) * 2.5).contiguous()
+            colT = torch.randn(B * H * W, 9 * C, device=cuda).to(dt)
+            calls.append((colT, off, (B, H, W, C), plan.add(off, C, H, W, (3, 3), (1, 1), (1, 1), (1, 1), B)))
+        for colT, off, shp, slot in reversed(calls):          # backward order: last level first
+            a = deformable_col2im_gather_nhwc(colT, off, shp, (3, 3), (1, 1), (1, 1), (1, 1))
+            b = deformable_col2im_gather_nhwc(colT, off, shp, (3, 3), (1, 1), (1, 1), (1, 1), slot=slot)
+            assert float((a - b).abs().max()) <= 2e-6 * max(float(a.abs().max()), 1.0), (shp, dt)
+        assert sorted(plan.built) == [0, 1]
+
+
+def test_deform_conv_backward_shared_index_context(cuda):
+    """``with shared_gather_index():`` around three DeformConv calls: same gradients as without it, one index build."""
+    from rs_detection_amd.ops import dcn_v1
+    torch.manual_seed(12)
+    w = (torch.randn(16, 32, 3, 3, device=cuda) * 0.1).requires_grad_()
+    xs = [torch.randn(2, 32, s, s, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+          for s in (24, 12, 6)]
+    offs = [torch.randn(2, 18, s, s, device=cuda) * 2 for s in (24, 12, 6)]
+    grads = []
+    for shared in (False, True):
+        for t in xs + [w]:
+            t.grad = None
+        if shared:
+            with dcn_v1.shared_gather_index() as plan:
+                outs = [dcn_v1.deform_conv(x, o, w, 1, 1, 1, 1, 1) for x, o in zip(xs, offs)]
+            assert len(plan.calls) == 3 and not plan.built
+        else:
+            outs = [dcn_v1.deform_conv(x, o, w, 1, 1, 1, 1, 1) for x, o in zip(xs, offs)]
+        sum((o * o).sum() for o in outs).backward()
+        if shared:
+            assert list(plan.built) == [0]
+        grads.append([t.grad.clone() for t in xs + [w]])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
 def test_deform_conv_nhwc_path_equals_reference_layout_path(cuda):
     """DeformConv fast path (channels-last) == reference-layout path, forward and both gradients."""
     from rs_detection_amd.ops.dcn_v1 import DeformConvFunction, DeformConvFunctionNHWC
