@@ -934,91 +934,200 @@ __global__ void roi_targets_kernel(RoiTargetArgs a) {
 // (oriented_rpn_head.py:292-300 -> assigner.py:65-170 with BboxOverlaps2D, iou_calculator.py:164-257).  As
 // rsdet_bbox_overlaps_f32 + rsdet_assign_wrt_overlaps_f32 that is a K x A fp32 matrix written once and read twice (977 MB at
 // K = 400): 0.6 ms of the Oriented R-CNN step.  A horizontal IoU is a dozen flops, so both passes recompute it instead:
-//   pass 1 (row maxima): a workgroup stages 2 048 anchors (box + area) in LDS; thread t owns ground truth t mod K' and one of
-//     256 / K' slices of the staged anchors, scans its slice (LDS broadcast reads, no cross-lane reduction) keeping
-//     (max IoU, first index) as one 64-bit key (IoU bits : ~index -- IoUs are >= 0, so integer order = float order and the
-//     lowest index wins ties); the slices meet in LDS atomics, the workgroups in one global atomicMax per ground truth;
+//   pass 1 (row maxima): one thread per anchor walks the K ground truths (box + area staged in LDS, broadcast reads).  Only
+//     pairs that overlap can raise a row maximum above its initial 0, and they are rare (a ground truth touches a few
+//     thousand of the 611 072 anchors), so the division and the update sit behind `overlap > 0`: the update is an LDS
+//     atomicMax of one 64-bit key (IoU bits : ~index -- IoUs are >= 0, so integer order = float order and the lowest index
+//     wins ties), tried only when the IoU reaches the row's current LDS value; workgroups meet in a global atomicMax per
+//     ground truth they touched.  A row no anchor overlaps keeps key 0 = (IoU 0, first anchor), what the ascending
+//     reference argmax gives.  (First form: thread = ground truth x anchor slice over 2 048 staged anchors, one wave per
+//     SIMD and a division per pair: 175 us at K = 100; this one: see profiles/r06_hba_ab.txt.)
 //   pass 2 (columns): one thread per anchor walks the K ground truths (LDS broadcast), keeps max / first argmax, the LAST
 //     row whose IoU equals its row maximum (the low-quality rule of the ascending reference loop), applies the thresholds.
-// Same arithmetic as bbox_overlaps_kernel (fp32, no contraction), so gt_inds equal the matrix route's bit for bit
-// (tests/test_gpu_orpn.py).  K <= 1024; finite boxes.
-constexpr int HBA_NT = 256, HBA_CHUNK = 2048, HBA_MAXK = 1024;
+// Same arithmetic as bbox_overlaps_kernel (fp32, no contraction; 0 / x = +0 for the skipped pairs), so gt_inds equal the
+// matrix route's bit for bit (tests/test_gpu_orpn.py).  K <= 1024; finite boxes.
+constexpr int HBA_NT = 256, HBA_MAXK = 1024;
 
-__device__ __forceinline__ float hba_iou(float gx1, float gy1, float gx2, float gy2, float ga, float cx1, float cy1, float cx2,
-                                         float cy2, float ca, float eps) {
+__device__ __forceinline__ float hba_overlap(float gx1, float gy1, float gx2, float gy2, float cx1, float cy1, float cx2,
+                                             float cy2) {
   const float w = fmaxf(fminf(gx2, cx2) - fmaxf(gx1, cx1), 0.f);
   const float h = fmaxf(fminf(gy2, cy2) - fmaxf(gy1, cy1), 0.f);
-  const float ov = w * h;
+  return w * h;
+}
+
+__device__ __forceinline__ float hba_iou(float ov, float ga, float ca, float eps) {
   const float uni = (ga + ca) - ov;
   return ov / fmaxf(uni, eps);
 }
 
-__global__ __launch_bounds__(HBA_NT) void hba_rowmax_kernel(const float* __restrict__ gt, int K, int gstride,
+// ground truths as one 32-byte record each (x1, y1, x2, y2, area, -, -, -): the walk over k is uniform across a wave, so
+// the record arrives through the scalar cache (s_load_dwordx8) and costs no LDS or vector-memory issue slot -- staged in
+// LDS, the two broadcast reads per pair were the bound (K = 400: 250 us per pass against a 37 us VALU floor)
+__global__ __launch_bounds__(HBA_NT) void hba_prep_kernel(const float* __restrict__ gt, int K, int gstride,
+                                                          float* __restrict__ tab, u64* __restrict__ rowkey) {
+  const int k = blockIdx.x * HBA_NT + threadIdx.x;
+  if (k >= ((K + 7) & ~7)) return;
+  float* t = tab + (long long)k * 8;
+  if (k >= K) {  // padding up to a multiple of eight: empty boxes at the origin overlap nothing
+    t[0] = t[1] = t[2] = t[3] = t[4] = t[5] = t[6] = t[7] = 0.f;
+    return;
+  }
+  const float* p = gt + (long long)k * gstride;
+  const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+  t[0] = x1, t[1] = y1, t[2] = x2, t[3] = y2, t[4] = (x2 - x1) * (y2 - y1), t[5] = 0.f, t[6] = 0.f, t[7] = 0.f;
+  rowkey[k] = 0ull;
+}
+
+// Both passes walk the ground truths eight at a time: the eight records are fetched together (one wait), the eight
+// overlaps are computed branch-free, and only a lane that overlaps one of the eight goes on to divisions / updates -- per
+// ground truth, one scalar-load latency and one divergent branch had left the loop latency-bound (K = 400: 245 us a pass).
+constexpr int HBA_U = 8;
+
+__device__ __forceinline__ bool hba_overlaps8(const float* __restrict__ tab, int k0, float cx1, float cy1, float cx2,
+                                              float cy2, float (&ov)[HBA_U], float (&ga)[HBA_U]) {
+  const float4* g = reinterpret_cast<const float4*>(tab + (long long)k0 * 8);   // (the table is padded to whole eights)
+  float4 r[HBA_U];
+#pragma unroll
+  for (int u = 0; u < HBA_U; ++u) r[u] = g[2 * u], ga[u] = g[2 * u + 1].x;      // scalar loads in flight together, one wait
+  bool any = false;
+#pragma unroll
+  for (int u = 0; u < HBA_U; ++u) {
+    ov[u] = hba_overlap(r[u].x, r[u].y, r[u].z, r[u].w, cx1, cy1, cx2, cy2);
+    any |= ov[u] > 0.f;
+  }
+  return any;
+}
+
+// maximum of a non-negative value over the wave, the same in every lane: rows of 16 on the vector pipe, the four rows
+// through scalar registers (inactive lanes read as 0)
+__device__ __forceinline__ float hba_wave_max(float v) {
+#define HBA_DPP(ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  v = fmaxf(v, HBA_DPP(0xB1));   // quad_perm [1, 0, 3, 2]
+  v = fmaxf(v, HBA_DPP(0x4E));   // quad_perm [2, 3, 0, 1]
+  v = fmaxf(v, HBA_DPP(0x141));  // row_half_mirror
+  v = fmaxf(v, HBA_DPP(0x140));  // row_mirror
+#undef HBA_DPP
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// Workgroups are taken from the END of the anchor list first: the list is level-major, its last few thousand anchors are
+// the coarse levels' (256-512 px boxes that overlap a third of the ground truths and take the division for each), and
+// started last they were the whole tail of both kernels (K = 400: 63 of 1 023 workgroups, 427 of 484 us).
+__global__ __launch_bounds__(HBA_NT) void hba_rowmax_kernel(const float* __restrict__ tab, int K,
                                                             const float* __restrict__ anchors, int A, int astride, float eps,
                                                             u64* __restrict__ rowkey) {
-  __shared__ float s_a[HBA_CHUNK][5];     // 40 KB
   __shared__ u64 s_key[HBA_MAXK];
-  const int tid = threadIdx.x, base = blockIdx.x * HBA_CHUNK;
-  const int na = min(HBA_CHUNK, A - base);
-  for (int i = tid; i < na; i += HBA_NT) {
-    const float* q = anchors + (long long)(base + i) * astride;
-    const float x1 = q[0], y1 = q[1], x2 = q[2], y2 = q[3];
-    s_a[i][0] = x1, s_a[i][1] = y1, s_a[i][2] = x2, s_a[i][3] = y2, s_a[i][4] = (x2 - x1) * (y2 - y1);
-  }
-  for (int k = tid; k < K; k += HBA_NT) s_key[k] = 0ull;
+  for (int k = threadIdx.x; k < K; k += HBA_NT) s_key[k] = 0ull;
   __syncthreads();
-  const int Kp = K < HBA_NT ? K : HBA_NT;          // ground truths a pass of the workgroup covers
-  const int S = HBA_NT / Kp;                        // anchor slices beside each other
-  const int kl = tid % Kp, sl = tid / Kp;
-  if (sl < S) {
-    const int per = (na + S - 1) / S, i0 = sl * per, i1 = min(na, i0 + per);
-    for (int k = kl; k < K; k += Kp) {
-      const float* p = gt + (long long)k * gstride;
-      const float gx1 = p[0], gy1 = p[1], gx2 = p[2], gy2 = p[3], ga = (gx2 - gx1) * (gy2 - gy1);
-      float best = -1.f;
-      int bi = 0;
-      for (int i = i0; i < i1; ++i) {
-        const float v = hba_iou(gx1, gy1, gx2, gy2, ga, s_a[i][0], s_a[i][1], s_a[i][2], s_a[i][3], s_a[i][4], eps);
-        if (v > best) best = v, bi = i;            // ascending i: the first index is kept on ties
-      }
-      if (i1 > i0) atomicMax(&s_key[k], ((u64)__float_as_uint(best) << 32) | (u64)(0xFFFFFFFFu - (unsigned)(base + bi)));
+  const int j = (int)(gridDim.x - 1 - blockIdx.x) * HBA_NT + threadIdx.x;
+  const bool live = j < A;                                   // (every lane walks the loop: the wave reductions want them)
+  const float* q = anchors + (long long)(live ? j : A - 1) * astride;
+  const float cx1 = q[0], cy1 = q[1], cx2 = q[2], cy2 = q[3], ca = (cx2 - cx1) * (cy2 - cy1);
+  const u64 low = (u64)(0xFFFFFFFFu - (unsigned)j);
+  const int lane = threadIdx.x & 63;
+  for (int k0 = 0; k0 < K; k0 += HBA_U) {
+    float ov[HBA_U], ga[HBA_U];
+    const bool any = hba_overlaps8(tab, k0, cx1, cy1, cx2, cy2, ov, ga) && live;
+    if (!__builtin_amdgcn_ballot_w64(any)) continue;         // uniform
+    int hits = 0;                                            // ground truths of the eight that some lane overlaps
+#pragma unroll
+    for (int u = 0; u < HBA_U; ++u) hits += __builtin_amdgcn_ballot_w64(live && ov[u] > 0.f) != 0;
+    if (hits >= 3) {
+      // a wave of coarse anchors meets most ground truths: all eight quotients (0 / x = +0 where nothing overlaps) and
+      // all eight reductions side by side -- one after the other behind a branch each, their latencies added up on a wave
+      // that has its SIMD to itself (63 such workgroups were 180 of the 185 us at K = 400)
+      float v[HBA_U], m[HBA_U];
+#pragma unroll
+      for (int u = 0; u < HBA_U; ++u) v[u] = live ? hba_iou(ov[u], ga[u], ca, eps) : 0.f;
+#pragma unroll
+      for (int u = 0; u < HBA_U; ++u) m[u] = hba_wave_max(v[u]);
+#pragma unroll
+      for (int u = 0; u < HBA_U; ++u)
+        if (m[u] > 0.f && (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(v[u] == m[u])) == lane)
+          atomicMax(&s_key[k0 + u], ((u64)__float_as_uint(v[u]) << 32) | low);
+      continue;
+    }
+#pragma unroll
+    for (int u = 0; u < HBA_U; ++u) {
+      const bool hit = live && ov[u] > 0.f;
+      if (!__builtin_amdgcn_ballot_w64(hit)) continue;       // uniform
+      const int k = k0 + u;
+      float v = 0.f;
+      if (hit) v = hba_iou(ov[u], ga[u], ca, eps);
+      // one candidate per wave and ground truth: the largest IoU, at its lowest anchor (lanes are in anchor order) --
+      // with a 64-bit LDS atomic per overlapping LANE, a wave of coarse anchors serialised 64-fold on every k
+      const float m = hba_wave_max(v);
+      // (m > 0: a quotient that underflows to 0 must not displace the "first anchor" answer of an all-zero row)
+      if (m > 0.f && (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(v == m)) == lane)
+        atomicMax(&s_key[k], ((u64)__float_as_uint(v) << 32) | low);   // (no return value: nothing waits for it)
     }
   }
   __syncthreads();
-  for (int k = tid; k < K; k += HBA_NT)
-    if (s_key[k]) atomicMax(rowkey + k, s_key[k]);
+  for (int k = threadIdx.x; k < K; k += HBA_NT) {
+    const u64 key = s_key[k];
+    if (key && key > __atomic_load_n(rowkey + k, __ATOMIC_RELAXED)) atomicMax(rowkey + k, key);
+  }
 }
 
-__global__ __launch_bounds__(HBA_NT) void hba_col_kernel(const float* __restrict__ gt, int K, int gstride,
+__global__ __launch_bounds__(HBA_NT) void hba_col_kernel(const float* __restrict__ tab, int K,
                                                          const float* __restrict__ anchors, int A, int astride, float eps,
                                                          const u64* __restrict__ rowkey, float pos_thr, float neg_lo,
                                                          float neg_hi, float min_pos_iou, int match_low_quality,
                                                          int gt_max_assign_all, int* __restrict__ gt_inds,
                                                          float* __restrict__ max_ov) {
-  __shared__ float s_g[HBA_MAXK][5];
-  __shared__ float s_rm[HBA_MAXK];
-  __shared__ int s_ra[HBA_MAXK];
-  for (int k = threadIdx.x; k < K; k += HBA_NT) {
-    const float* p = gt + (long long)k * gstride;
-    const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
-    s_g[k][0] = x1, s_g[k][1] = y1, s_g[k][2] = x2, s_g[k][3] = y2, s_g[k][4] = (x2 - x1) * (y2 - y1);
-    const u64 key = rowkey[k];
-    s_rm[k] = __uint_as_float((unsigned)(key >> 32));
-    s_ra[k] = (int)(0xFFFFFFFFu - (unsigned)key);
-  }
-  __syncthreads();
-  const int j = blockIdx.x * HBA_NT + threadIdx.x;
-  if (j >= A) return;
-  const float* q = anchors + (long long)j * astride;
+  const int j = (int)(gridDim.x - 1 - blockIdx.x) * HBA_NT + threadIdx.x;
+  const bool live = j < A;
+  const float* q = anchors + (long long)(live ? j : A - 1) * astride;
   const float cx1 = q[0], cy1 = q[1], cx2 = q[2], cy2 = q[3], ca = (cx2 - cx1) * (cy2 - cy1);
-  float best = -INFINITY;
+  // an anchor that overlaps none of the eight has IoU +0 with each: after k = 0 that raises no maximum, and it meets the
+  // low-quality rule only through a row maximum of 0, which min_pos_iou > 0 rules out -- otherwise take the full path
+  const bool zero_rows_matter = match_low_quality && !(min_pos_iou > 0.f);
+  float best = 0.f;                                          // = IoU with ground truth 0 once k = 0 has been seen
   int arg = 0, lowq = -1;
-  for (int k = 0; k < K; ++k) {
-    const float v = hba_iou(s_g[k][0], s_g[k][1], s_g[k][2], s_g[k][3], s_g[k][4], cx1, cy1, cx2, cy2, ca, eps);
-    if (k == 0 || v > best) best = v, arg = k;
-    if (match_low_quality && s_rm[k] >= min_pos_iou)
-      if (gt_max_assign_all ? (v == s_rm[k]) : (s_ra[k] == j)) lowq = k;
+  for (int k0 = 0; k0 < K; k0 += HBA_U) {
+    float ov[HBA_U], ga[HBA_U];
+    const bool any = hba_overlaps8(tab, k0, cx1, cy1, cx2, cy2, ov, ga);
+    if (!zero_rows_matter && !__builtin_amdgcn_ballot_w64(any)) continue;      // uniform
+    const ulonglong2* rk = reinterpret_cast<const ulonglong2*>(rowkey + k0);   // (allocation padded past whole eights)
+    ulonglong2 keys[HBA_U / 2];
+#pragma unroll
+    for (int u = 0; u < HBA_U / 2; ++u) keys[u] = rk[u];                        // scalar loads, in flight together
+    int hits = 0;
+#pragma unroll
+    for (int u = 0; u < HBA_U; ++u) hits += __builtin_amdgcn_ballot_w64(ov[u] > 0.f) != 0;
+    const bool dense = hits >= 3 || zero_rows_matter;       // uniform; dense: the eight quotients side by side
+    float vd[HBA_U];
+    if (dense) {
+#pragma unroll
+      for (int u = 0; u < HBA_U; ++u) vd[u] = hba_iou(ov[u], ga[u], ca, eps);    // 0 / x = +0 where nothing overlaps
+    }
+#pragma unroll
+    for (int u = 0; u < HBA_U; ++u) {
+      const int k = k0 + u;
+      if (k >= K) break;
+      float v = 0.f;                                                   // 0 / x = +0: the same bits without the division
+      if (dense) {
+        v = vd[u];
+      } else {
+        if (k > 0 && !__builtin_amdgcn_ballot_w64(ov[u] > 0.f)) continue;      // uniform
+        if (ov[u] > 0.f) v = hba_iou(ov[u], ga[u], ca, eps);
+      }
+      if (k == 0 || v > best) best = v, arg = k;
+      if (match_low_quality) {
+        const u64 key = (u & 1) ? keys[u / 2].y : keys[u / 2].x;
+        const float rm = __uint_as_float((unsigned)(key >> 32));
+        const int ra = key ? (int)(0xFFFFFFFFu - (unsigned)key) : 0;   // untouched row: IoU 0 everywhere, first anchor
+        if (rm >= min_pos_iou)
+          if (gt_max_assign_all ? (v == rm) : (ra == j)) lowq = k;
+      }
+    }
   }
+  if (!live) return;
   int gi = -1;
   if (best >= neg_lo && best < neg_hi) gi = 0;   // assigner.py:138-145
   if (best >= pos_thr) gi = arg + 1;             // :147-148
@@ -1278,22 +1387,25 @@ extern "C" int rsdet_orcnn_roi_targets_f32(const float* props, int prop_stride, 
 }
 
 // ---- MaxIoUAssigner on horizontal boxes, no matrix ---------------------------------------------------------------------
-extern "C" size_t rsdet_hbb_assign_ws_size(int K) { return K > 0 && K <= HBA_MAXK ? up256((size_t)K * sizeof(u64)) : 0; }
+extern "C" size_t rsdet_hbb_assign_ws_size(int K) {
+  return K > 0 && K <= HBA_MAXK ? up256((size_t)K * sizeof(u64)) + up256((size_t)((K + 7) & ~7) * 32) : 0;
+}
 
 extern "C" int rsdet_hbb_assign_f32(const float* gt, int K, int gt_stride, const float* anchors, int A, int anchor_stride,
                                     float eps, float pos_iou_thr, float neg_lo, float neg_hi, float min_pos_iou,
                                     int match_low_quality, int gt_max_assign_all, int32_t* gt_inds, float* max_overlaps,
                                     void* ws, size_t ws_bytes, void* stream) {
   if (K < 1 || K > HBA_MAXK || A < 1 || gt_stride < 4 || anchor_stride < 4 || !gt || !anchors || !gt_inds || !ws ||
-      ws_bytes < rsdet_hbb_assign_ws_size(K) || ((uintptr_t)ws & 7))
+      ws_bytes < rsdet_hbb_assign_ws_size(K) || ((uintptr_t)ws & 31))
     return RSDET_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   u64* rowkey = (u64*)ws;
-  if (hipMemsetAsync(rowkey, 0, (size_t)K * sizeof(u64), s) != hipSuccess) return RSDET_ELAUNCH;
-  hipLaunchKernelGGL(hba_rowmax_kernel, dim3((A + HBA_CHUNK - 1) / HBA_CHUNK), dim3(HBA_NT), 0, s, gt, K, gt_stride, anchors,
-                     A, anchor_stride, eps, rowkey);
-  hipLaunchKernelGGL(hba_col_kernel, dim3((A + HBA_NT - 1) / HBA_NT), dim3(HBA_NT), 0, s, gt, K, gt_stride, anchors, A,
-                     anchor_stride, eps, rowkey, pos_iou_thr, neg_lo, neg_hi, min_pos_iou, match_low_quality,
-                     gt_max_assign_all, gt_inds, max_overlaps);
+  float* tab = (float*)((char*)ws + up256((size_t)K * sizeof(u64)));
+  hipLaunchKernelGGL(hba_prep_kernel, dim3((K + 7 + HBA_NT - 1) / HBA_NT), dim3(HBA_NT), 0, s, gt, K, gt_stride, tab, rowkey);
+  hipLaunchKernelGGL(hba_rowmax_kernel, dim3((A + HBA_NT - 1) / HBA_NT), dim3(HBA_NT), 0, s, tab, K, anchors, A,
+                     anchor_stride, eps, rowkey);
+  hipLaunchKernelGGL(hba_col_kernel, dim3((A + HBA_NT - 1) / HBA_NT), dim3(HBA_NT), 0, s, tab, K, anchors, A, anchor_stride,
+                     eps, rowkey, pos_iou_thr, neg_lo, neg_hi, min_pos_iou, match_low_quality, gt_max_assign_all, gt_inds,
+                     max_overlaps);
   return rsdet_launch_status();
 }

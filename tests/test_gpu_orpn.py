@@ -326,12 +326,15 @@ def test_roi_head_targets_equal_the_tensor_route(cuda, monkeypatch):
     assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-8)
 
 
-@pytest.mark.parametrize("K,A,low,allm", [(25, 611072, True, True), (400, 50000, True, True), (1, 3000, True, False),
-                                           (130, 20000, False, True), (700, 9000, True, True)])
-def test_hbb_assignment_without_the_matrix_equals_the_matrix_route(cuda, K, A, low, allm):
+@pytest.mark.parametrize("K,A,low,allm,minpos", [(25, 611072, True, True, 0.3), (400, 50000, True, True, 0.3),
+                                                  (1, 3000, True, False, 0.3), (130, 20000, False, True, 0.3),
+                                                  (700, 9000, True, True, 0.3), (60, 30000, True, False, 0.0),
+                                                  (60, 30000, True, True, 0.0)])
+def test_hbb_assignment_without_the_matrix_equals_the_matrix_route(cuda, K, A, low, allm, minpos):
     """rsdet_hbb_assign_f32 (two passes that recompute the horizontal IoU) == rsdet_bbox_overlaps_f32 +
     rsdet_assign_wrt_overlaps_f32 on the (K, A) matrix: gt_inds and max_overlaps bit for bit -- grid anchors with many exact
-    ties (equal IoUs across anchors and across ground truths), duplicated ground truths, tiny boxes."""
+    ties (equal IoUs across anchors and across ground truths), duplicated ground truths, tiny boxes; with min_pos_iou = 0
+    also a ground truth no anchor overlaps (row maximum 0 at the FIRST anchor, which the low-quality rule then assigns)."""
     from rs_detection_amd.models.boxes.assigner import MaxIoUAssigner
     from rs_detection_amd.ops import orpn
     rng = np.random.default_rng(K + A)
@@ -346,9 +349,11 @@ def test_hbb_assignment_without_the_matrix_equals_the_matrix_route(cuda, K, A, l
     if K > 4:
         gts[3] = gts[1]                                   # a duplicated ground truth: equal rows
         gts[2] = anchors[len(anchors) // 2]               # an IoU of exactly 1
+    if minpos == 0.0:
+        gts[5] = np.array([-900, -900, -850, -870], np.float32)      # overlaps nothing
     a, g = torch.from_numpy(anchors).to(cuda), torch.from_numpy(gts).to(cuda)
-    asg = MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=low, gt_max_assign_all=allm,
-                         ignore_iof_thr=-1)
+    asg = MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=minpos, match_low_quality=low,
+                         gt_max_assign_all=allm, ignore_iof_thr=-1)
     assert orpn.hbb_assign_applies(a, g)
     got = asg.assign(a, g, None, None)
     orpn._ON = False
