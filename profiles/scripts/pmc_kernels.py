@@ -333,6 +333,22 @@ for _ in range(4):
     _orpn.sample_masked(gti, None, 0, pri, 256, 128, -1.0)
 for kname in ("sel_hist_kernel<unsigned int, 2", "sel_emit_kernel<unsigned int, 2", "sampler_final_kernel"):
     ALG6[kname] = dict(call="sample_masked: 256 of 611 072 anchors (3 counting passes + emit + final)", bytes=4 * 8 * n_a)
+# matrix-free horizontal assignment at the Oriented RPN's size: level-major grid anchors (7 per position), K = 100
+_anc = []
+for _s in (4, 8, 16, 32, 64):
+    _n = 1024 // _s
+    _cy, _cx = np.meshgrid(np.arange(_n) * _s, np.arange(_n) * _s, indexing="ij")
+    _c = np.stack([_cx, _cy], -1).reshape(-1, 1, 2).astype(np.float32)
+    _wh = np.array([[_s * 8 * np.sqrt(r), _s * 8 / np.sqrt(r)] for r in (0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 4.0)], np.float32)
+    _anc.append(np.concatenate([_c - _wh[None] / 2, _c + _wh[None] / 2], -1).reshape(-1, 4))
+_anchors = torch.from_numpy(np.concatenate(_anc)).to(dev)
+_ctr = rng.uniform(0, 1024, (100, 2)); _gwh = np.exp(rng.uniform(np.log(10), np.log(200), (100, 2)))
+_gts = torch.from_numpy(np.concatenate([_ctr - _gwh / 2, _ctr + _gwh / 2], 1).astype(np.float32)).to(dev)
+for _ in range(4):
+    _orpn.hbb_assign(_anchors, _gts, 0.7, 0.3, 0.3, True, True)
+for kname in ("hba_rowmax_kernel", "hba_col_kernel"):
+    ALG6[kname] = dict(call="hbb_assign: %d anchors x K = 100 (row maxima + columns, no matrix)" % _anchors.shape[0],
+                       bytes=(16 + 8) * _anchors.shape[0])
 ALG5.update(ALG6)
 # (the plain conv3x3 key of round 4 is a substring of the gated kernel's name: give the more specific key precedence)
 ALG = dict(list(ALG5.items()) + [(k, v) for k, v in ALG.items()])
