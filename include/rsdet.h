@@ -360,6 +360,10 @@ int rsdet_deform_col2im_gather_indexed_nhwc_f32(const float* colT, const rsdet_d
 int rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32(const uint16_t* colT, const rsdet_dcn_geom* g,
                                                         const int* start, const int* ent_row, const float* ent_w,
                                                         float* grad_im, void* stream);
+/* ... grad_im (B,H,W,C) written as bf16, round to nearest even: the gradient of a bf16 input (autocast step). */
+int rsdet_deform_col2im_gather_indexed_nhwc_bf16col_bf16(const uint16_t* colT, const rsdet_dcn_geom* g,
+                                                         const int* start, const int* ent_row, const float* ent_w,
+                                                         uint16_t* grad_im, void* stream);
 
 /* bf16 column matrices for the autocast step (BASELINE configs 2 / 4): the products that consume / produce them run
  * on bf16 MFMA through rocBLAS, the images, offsets, interpolation weights, sums and grad_im stay fp32.

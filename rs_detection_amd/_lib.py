@@ -235,6 +235,8 @@ SIGNATURES = {
                                                             c_void_p, c_void_p, c_void_p]),
     "rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32": (c_int, [c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
                                                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsdet_deform_col2im_gather_indexed_nhwc_bf16col_bf16": (c_int, [c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
+                                                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsdet_deform_im2col_bf16col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p, c_void_p]),
     "rsdet_deform_col2im_gather_nhwc_bf16col_f32": (c_int, [c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
                                                             c_void_p, c_size_t, c_void_p]),

@@ -596,12 +596,12 @@ __global__ __launch_bounds__(256) void dcn_idx_fill_multi_kernel(const IdxLevels
 // (the corners of one sampling point) are processed close together, and the workgroup ids are renumbered so that an
 // XCD owns a contiguous run of tiles (rsdet_xcd_contiguous): round-robin placement would put the four on four
 // different L2s and the row would be fetched again by each
-template <bool VEC4, typename TROW>
+template <bool VEC4, typename TROW, typename TOUT = float>
 __global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const TROW* __restrict__ colT,
                                                                     const int* __restrict__ start,
                                                                     const int* __restrict__ ent_row,
                                                                     const float* __restrict__ ent_w, Geom g,
-                                                                    float* __restrict__ grad_im) {
+                                                                    TOUT* __restrict__ grad_im) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long npix = (long long)g.B * g.H * g.W;
@@ -640,13 +640,13 @@ __global__ __launch_bounds__(64 * DCN_WAVES) void dcn_gather_kernel(const TROW* 
         const float4 v0 = ld4(colT + (long long)r0 * rowlen + c);
         acc.x += w0 * v0.x; acc.y += w0 * v0.y; acc.z += w0 * v0.z; acc.w += w0 * v0.w;
       }
-      *reinterpret_cast<float4*>(grad_im + pix * g.C + c) = acc;
+      st4(grad_im + pix * g.C + c, acc);      // (bf16 output: rounded to nearest even, what `.to(bfloat16)` did in a pass of its own)
     }
   } else {
     for (int c = lane; c < g.C; c += 64) {
       float acc = 0.f;
       for (int e = e0; e < e1; ++e) acc += ent_w[e] * ld1(colT + (long long)ent_row[e] * rowlen + c);
-      grad_im[pix * g.C + c] = acc;
+      st1(grad_im + pix * g.C + c, acc);
     }
   }
 }
@@ -922,9 +922,9 @@ extern "C" int rsdet_deform_col2im_index_multi_f32(const rsdet_dcn_index_levels*
   return rsdet_launch_status();
 }
 
-template <typename TROW>
+template <typename TROW, typename TOUT>
 static int dcn_col2im_gather_indexed(const TROW* colT, const rsdet_dcn_geom* geom, const int* start,
-                                     const int* ent_row, const float* ent_w, float* grad_im, void* stream) {
+                                     const int* ent_row, const float* ent_w, TOUT* grad_im, void* stream) {
   Geom g;
   int rc = make_geom(geom, &g);
   if (rc) return rc;
@@ -932,14 +932,15 @@ static int dcn_col2im_gather_indexed(const TROW* colT, const rsdet_dcn_geom* geo
   const long long npos = (long long)g.B * g.Ho * g.Wo, npix = (long long)g.B * g.H * g.W;
   if (npix == 0 || g.C == 0) return RSDET_OK;
   if (!start || !ent_row || !ent_w || !grad_im || (npos > 0 && !colT)) return RSDET_EINVAL;
-  const bool vec4 = (g.C % 4 == 0) && ((uintptr_t)colT % (4 * sizeof(TROW)) == 0) && ((uintptr_t)grad_im % 16 == 0);
+  const bool vec4 = (g.C % 4 == 0) && ((uintptr_t)colT % (4 * sizeof(TROW)) == 0) &&
+                    ((uintptr_t)grad_im % (4 * sizeof(TOUT)) == 0);
   const unsigned blocks = (unsigned)((npix + DCN_WAVES - 1) / DCN_WAVES);
   hipStream_t s = (hipStream_t)stream;
   if (vec4)
-    hipLaunchKernelGGL((dcn_gather_kernel<true, TROW>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start, ent_row,
-                       ent_w, g, grad_im);
+    hipLaunchKernelGGL((dcn_gather_kernel<true, TROW, TOUT>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start,
+                       ent_row, ent_w, g, grad_im);
   else
-    hipLaunchKernelGGL((dcn_gather_kernel<false, TROW>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start,
+    hipLaunchKernelGGL((dcn_gather_kernel<false, TROW, TOUT>), dim3(blocks), dim3(64 * DCN_WAVES), 0, s, colT, start,
                        ent_row, ent_w, g, grad_im);
   return rsdet_launch_status();
 }
@@ -947,13 +948,21 @@ static int dcn_col2im_gather_indexed(const TROW* colT, const rsdet_dcn_geom* geo
 extern "C" int rsdet_deform_col2im_gather_indexed_nhwc_f32(const float* colT, const rsdet_dcn_geom* geom,
                                                            const int* start, const int* ent_row, const float* ent_w,
                                                            float* grad_im, void* stream) {
-  return dcn_col2im_gather_indexed<float>(colT, geom, start, ent_row, ent_w, grad_im, stream);
+  return dcn_col2im_gather_indexed<float, float>(colT, geom, start, ent_row, ent_w, grad_im, stream);
 }
 
 extern "C" int rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32(const uint16_t* colT, const rsdet_dcn_geom* geom,
                                                                    const int* start, const int* ent_row,
                                                                    const float* ent_w, float* grad_im, void* stream) {
-  return dcn_col2im_gather_indexed<bf16_t>((const bf16_t*)colT, geom, start, ent_row, ent_w, grad_im, stream);
+  return dcn_col2im_gather_indexed<bf16_t, float>((const bf16_t*)colT, geom, start, ent_row, ent_w, grad_im, stream);
+}
+
+// ... and grad_im written as bf16 (the input of the autocast step is bf16: its gradient was cast in a pass of its own)
+extern "C" int rsdet_deform_col2im_gather_indexed_nhwc_bf16col_bf16(const uint16_t* colT, const rsdet_dcn_geom* geom,
+                                                                    const int* start, const int* ent_row,
+                                                                    const float* ent_w, uint16_t* grad_im, void* stream) {
+  return dcn_col2im_gather_indexed<bf16_t, bf16_t>((const bf16_t*)colT, geom, start, ent_row, ent_w, (bf16_t*)grad_im,
+                                                   stream);
 }
 
 extern "C" int rsdet_deform_col2im_gather_nhwc_f32(const float* colT, const float* offset,

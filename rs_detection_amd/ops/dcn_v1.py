@@ -131,6 +131,7 @@ class GatherIndexPlan:
     def __init__(self):
         self.calls = []          # (offset tensor (contiguous fp32), geometry tuple)
         self.built = {}          # chunk -> (ws, start byte offset, pix_base list, ent_row offset, ent_w offset)
+        self.operands = {}       # (id(weight), version) -> (weight, prepared operand): one cast for the calls of the pass
 
     def add(self, offset, C, H, W, kernel, padding, stride, dilation, B):
         self.calls.append((offset, (C, H, W, *kernel, *padding, *stride, *dilation, B, 1)))
@@ -192,22 +193,26 @@ def _plan_slot(ctx, offset, C, H, W, kernel, padding, stride, dilation, B, dg):
     return _PLAN.add(offset, C, H, W, kernel, padding, stride, dilation, B)
 
 
-def deformable_col2im_gather_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride, dilation, slot=None):
+def deformable_col2im_gather_nhwc(colT, offset, im_shape_nhwc, kernel, padding, stride, dilation, slot=None,
+                                  out_dtype=torch.float32):
     """colT (B*Ho*Wo, kh*kw*C) -> grad_im (B,H,W,C) without floating-point atomics (one deformable group):
     the scatter map is inverted on integers first, then every input pixel gathers its terms.  ``slot`` = the call's
-    entry in a GatherIndexPlan: the index comes from the plan's shared build."""
+    entry in a GatherIndexPlan: the index comes from the plan's shared build.  ``out_dtype`` bf16 (with bf16 columns and
+    a slot): the sums, accumulated in fp32, are stored rounded -- the cast of a bf16 input's gradient without its pass."""
     lowp = colT.dtype == torch.bfloat16  # column gradient out of a bf16 GEMM (autocast step); grad_im stays fp32
     _lib.require_cuda_f32(None if lowp else colT, offset)
     lib = _lib.load()
     colT, offset = colT.contiguous(), offset.contiguous()
     B, H, W, C = im_shape_nhwc
     (kh, kw), (ph, pw), (sh, sw), (dh, dw) = kernel, padding, stride, dilation
-    grad_im = torch.empty((B, H, W, C), dtype=torch.float32, device=colT.device)
+    out_bf16 = out_dtype == torch.bfloat16 and lowp and slot is not None
+    grad_im = torch.empty((B, H, W, C), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=colT.device)
     g = _geom(C, H, W, kh, kw, ph, pw, sh, sw, dh, dw, B, 1)
     if slot is not None:
         plan, i = slot
         start, ent_row, ent_w = plan.index(i)
-        name = "rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32" if lowp else "rsdet_deform_col2im_gather_indexed_nhwc_f32"
+        name = ("rsdet_deform_col2im_gather_indexed_nhwc_bf16col_bf16" if out_bf16 else
+                "rsdet_deform_col2im_gather_indexed_nhwc_bf16col_f32" if lowp else "rsdet_deform_col2im_gather_indexed_nhwc_f32")
         _lib.check(getattr(lib, name)(_lib.ptr(colT), g, start, ent_row, ent_w, _lib.ptr(grad_im), _lib.stream_ptr()),
                    name)
         return grad_im
@@ -407,7 +412,17 @@ class AlignConvMFMAFunction(torch.autograd.Function):
         if x.dtype != torch.bfloat16 or not x.is_contiguous():
             x = x.to(torch.bfloat16).contiguous()
         off = offset.float().contiguous()
-        w_flat = weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * C).to(torch.bfloat16)   # k = tap*C + c
+        # k = tap*C + c; the levels of a step share the weight (an fp32 parameter: DeformConv is no nn.Conv2d, the Runner
+        # leaves it fp32): cast once per forward pass, not once per level
+        key = (id(weight), weight._version)
+        hit = _PLAN.operands.get(key) if _PLAN is not None else None
+        if hit is not None and hit[0] is weight:
+            w_flat = hit[1]
+        else:
+            w_flat = weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * C).to(torch.bfloat16)
+            if _PLAN is not None:
+                _PLAN.operands[key] = (weight, w_flat)
+        ctx.w_cl = weight.dim() == 4 and not weight.is_contiguous() and weight.is_contiguous(memory_format=torch.channels_last)
         need_w = ctx.needs_input_grad[2]
         # channels_last storage == (B,Ho,Wo,O); returned as is (callers apply ReLU in place: not a view)
         out = torch.empty((B, O, Ho, Wo), dtype=torch.bfloat16, device=input.device,
@@ -435,8 +450,8 @@ class AlignConvMFMAFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gcolT = torch.mm(go, w_flat)                   # (P, 9*C): channels-last column gradient, bf16
             gi = deformable_col2im_gather_nhwc(gcolT, off, (B, H, W, C), (3, 3), ctx.padding, (1, 1), (1, 1),
-                                               slot=ctx.slot)
-            grad_input = gi.permute(0, 3, 1, 2).to(ctx.in_dtype)
+                                               slot=ctx.slot, out_dtype=ctx.in_dtype)
+            grad_input = gi.permute(0, 3, 1, 2).to(ctx.in_dtype)       # (no-op when the gather stored bf16 itself)
         if ctx.needs_input_grad[2]:
             if colT is None:
                 raise RuntimeError("AlignConv: the weight gradient needs the columns of a forward run with grad enabled")
@@ -444,7 +459,9 @@ class AlignConvMFMAFunction(torch.autograd.Function):
             J = 16 if P % 16 == 0 and P >= 4096 else 1     # split K = P: 36 output tiles only otherwise
             parts = torch.bmm(go.view(J, P // J, O).transpose(1, 2), colT.view(J, P // J, 9 * C))
             gw = parts.sum(0, dtype=torch.float32) if J > 1 else parts[0].float()
-            grad_weight = gw.view(O, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+            grad_weight = gw.view(O, 3, 3, C).permute(0, 3, 1, 2)      # = the channels_last storage of an (O,C,3,3) tensor
+            if not ctx.w_cl:                                            # a channels_last weight takes it as it is
+                grad_weight = grad_weight.contiguous()
         return grad_input, None, grad_weight, None, None
 
 

@@ -146,6 +146,10 @@ def test_deform_col2im_shared_index_over_levels_matches_per_call(cuda):
             a = deformable_col2im_gather_nhwc(colT, off, shp, (3, 3), (1, 1), (1, 1), (1, 1))
             b = deformable_col2im_gather_nhwc(colT, off, shp, (3, 3), (1, 1), (1, 1), (1, 1), slot=slot)
             assert float((a - b).abs().max()) <= 2e-6 * max(float(a.abs().max()), 1.0), (shp, dt)
+            if dt == torch.bfloat16:    # the gradient of a bf16 input stored rounded by the gather itself == cast afterwards
+                c = deformable_col2im_gather_nhwc(colT, off, shp, (3, 3), (1, 1), (1, 1), (1, 1), slot=slot,
+                                                  out_dtype=torch.bfloat16)
+                assert c.dtype == torch.bfloat16 and torch.equal(c, b.to(torch.bfloat16)), shp
         assert sorted(plan.built) == [0, 1]
 
 
@@ -857,6 +861,38 @@ def test_alignconv_mfma_implicit_gemm_tracks_fp32(cuda, shape):
     assert lib.rsdet_alignconv_fwd_mfma_bf16(_lib.ptr(x_nhwc), _lib.ptr(off), _lib.ptr(w_flat),
                                              _lib.DcnGeom(C, H, W, 3, 3, 1, 1, 1, 1, 1, 1, B, 2), O, 1, _lib.ptr(out),
                                              None, _lib.stream_ptr()) != 0
+
+
+def test_alignconv_mfma_levels_share_index_and_weight_cast(cuda):
+    """Two AlignConv levels under ``shared_gather_index()`` in a bf16 autocast step with a channels_last weight: one index
+    build, ONE bf16 cast of the weight for both levels, the input gradient stored as bf16 by the gather, the weight
+    gradient handed over in the weight's own (channels_last) layout -- same values as the two calls on their own."""
+    from rs_detection_amd.ops import dcn_v1
+    from rs_detection_amd.ops.dcn_v1 import DeformConv
+    torch.manual_seed(13)
+    m = DeformConv(64, 64, 3, padding=1).to(cuda).to(memory_format=torch.channels_last)
+    assert not m.weight.is_contiguous() and m.weight.is_contiguous(memory_format=torch.channels_last)
+    xs = [torch.randn(2, 64, s, s, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+          for s in (32, 16)]
+    offs = [torch.randn(2, 18, s, s, device=cuda) * 2.0 for s in (32, 16)]
+    gos = [torch.randn(2, 64, s, s, device=cuda).bfloat16().contiguous(memory_format=torch.channels_last) for s in (32, 16)]
+    res = []
+    for shared in (False, True):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if shared:
+                with dcn_v1.shared_gather_index() as plan:
+                    ys = [m(x, o) for x, o in zip(xs, offs)]
+                assert len(plan.calls) == 2 and len(plan.operands) == 1
+            else:
+                ys = [m(x, o) for x, o in zip(xs, offs)]
+        g = torch.autograd.grad(ys, xs + [m.weight], gos)
+        assert g[0].dtype == torch.bfloat16 and g[2].dtype == torch.float32 and g[2].shape == m.weight.shape
+        if shared:
+            assert list(plan.built) == [0]
+            assert g[2].is_contiguous(memory_format=torch.channels_last)
+        res.append([ys[0].float(), ys[1].float()] + [t.float() for t in g])
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())
 
 
 def test_alignconv_mfma_matches_the_oracle(cuda):
