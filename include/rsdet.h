@@ -271,6 +271,23 @@ int rsdet_s2a_refine_and_offset_f32(const float* bbox_pred, const float* anchors
                                     int W, float stride_px, int ks, const float* means_host,
                                     const float* stds_host, float max_ratio, float* refined,
                                     float* offset, void* stream);
+/* The same for SEVERAL pyramid levels in one launch (the per-level loop of s2anet_head.py:229-239); pred may be bf16
+ * (pred_bf16 != 0: the prediction of an autocast step, widened exactly -- no cast pass in front).  pred[l] (B,5,H,W)
+ * contiguous; means / stds: 5 host floats or NULL (0 / 1). */
+#define RSDET_S2A_MAX_LEVELS 8
+typedef struct rsdet_s2a_levels {
+  int n_levels, B, ks, pred_bf16;
+  int H[RSDET_S2A_MAX_LEVELS], W[RSDET_S2A_MAX_LEVELS];
+  float stride[RSDET_S2A_MAX_LEVELS];
+  const void* pred[RSDET_S2A_MAX_LEVELS];
+  const float* anchors[RSDET_S2A_MAX_LEVELS];
+  float* refined[RSDET_S2A_MAX_LEVELS]; /* (B,H,W,5) or NULL */
+  float* offset[RSDET_S2A_MAX_LEVELS];  /* (B,2*ks*ks,H,W) or NULL */
+  const float* means;
+  const float* stds;
+  float max_ratio;
+} rsdet_s2a_levels;
+int rsdet_s2a_refine_and_offset_multi(const rsdet_s2a_levels* levels, void* stream);
 
 /* ---- a12  Active Rotating Filter ---------------------------------------------------------
  * Replaces arf_forward / arf_backward: ops/orn.py:260-280 (kernels :17-72, CPU :138-211).

@@ -28,6 +28,14 @@ class DcnIndexLevels(ctypes.Structure):
     _fields_ = [("n_levels", c_int), ("offset", c_void_p * 8), ("geom", DcnGeom * 8)]
 
 
+class S2aLevels(ctypes.Structure):
+    """struct rsdet_s2a_levels (include/rsdet.h)."""
+    _fields_ = ([(n, c_int) for n in ("n_levels", "B", "ks", "pred_bf16")]
+                + [("H", c_int * 8), ("W", c_int * 8), ("stride", c_float * 8), ("pred", c_void_p * 8),
+                   ("anchors", c_void_p * 8), ("refined", c_void_p * 8), ("offset", c_void_p * 8),
+                   ("means", c_void_p), ("stds", c_void_p), ("max_ratio", c_float)])
+
+
 class VanBnFold(ctypes.Structure):
     """struct rsdet_van_bn_fold (include/rsdet.h)."""
     _fields_ = ([(n, c_void_p) for n in ("partial", "wt", "gs_tab", "r_tab", "ls", "mean", "rstd", "sc", "sh", "grad_w",
@@ -208,6 +216,7 @@ SIGNATURES = {
                                              ctypes.POINTER(c_float), c_void_p, c_void_p]),
     "rsdet_delta2bbox_rotated_f32": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_float),
                                              ctypes.POINTER(c_float), c_float, c_void_p, c_void_p]),
+    "rsdet_s2a_refine_and_offset_multi": (c_int, [ctypes.POINTER(S2aLevels), c_void_p]),
     "rsdet_s2a_refine_and_offset_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                                 ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_float,
                                                 c_void_p, c_void_p, c_void_p]),

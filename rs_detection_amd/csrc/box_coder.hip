@@ -15,6 +15,9 @@
 
 namespace rsdet {
 
+__device__ __forceinline__ float s2a_ld(const float* p) { return *p; }
+__device__ __forceinline__ float s2a_ld(const uint16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+
 __global__ void delta2bbox_kernel(const float* __restrict__ rois, const float* __restrict__ deltas,
                                   int n, F5 mean, F5 stdv, float max_ratio,
                                   float* __restrict__ out) {
@@ -44,21 +47,20 @@ __global__ void bbox2delta_kernel(const float* __restrict__ prop, const float* _
 // One thread per (b, h, w).  bbox_pred is NCHW so lanes (consecutive w) read
 // each of the 5 delta planes coalesced; the 2*ks*ks offset planes are written
 // coalesced the same way.
-__global__ void s2a_refine_offset_kernel(const float* __restrict__ bbox_pred,
-                                         const float* __restrict__ anchors, int B, int H, int W,
-                                         float stride_px, int ks, F5 mean, F5 stdv,
-                                         float max_ratio, float* __restrict__ refined,
-                                         float* __restrict__ offset) {
+// the work of one (b, h, w): TP = float or bf16 (the prediction of an autocast step, widened exactly)
+template <typename TP>
+__device__ __forceinline__ void s2a_refine_offset_one(const TP* __restrict__ bbox_pred, const float* __restrict__ anchors,
+                                                      int H, int W, long long idx, float stride_px, int ks, const F5& mean,
+                                                      const F5& stdv, float max_ratio, float* __restrict__ refined,
+                                                      float* __restrict__ offset) {
   const long long HW = (long long)H * W;
-  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)B * HW) return;
   int b = (int)(idx / HW);
   int hw = (int)(idx - (long long)b * HW);
   int h = hw / W, w = hw - h * W;
   float d[5], a[5], r[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
-    d[k] = bbox_pred[((long long)b * 5 + k) * HW + hw];
+    d[k] = s2a_ld(bbox_pred + ((long long)b * 5 + k) * HW + hw);
     a[k] = anchors[(long long)hw * 5 + k];
   }
   decode_one(a, d, mean, stdv, max_ratio, r);
@@ -88,6 +90,46 @@ __global__ void s2a_refine_offset_kernel(const float* __restrict__ bbox_pred,
       op[(long long)(2 * t + 1) * HW] = off_x;
     }
   }
+}
+
+__global__ void s2a_refine_offset_kernel(const float* __restrict__ bbox_pred,
+                                         const float* __restrict__ anchors, int B, int H, int W,
+                                         float stride_px, int ks, F5 mean, F5 stdv,
+                                         float max_ratio, float* __restrict__ refined,
+                                         float* __restrict__ offset) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * H * W) return;
+  s2a_refine_offset_one(bbox_pred, anchors, H, W, idx, stride_px, ks, mean, stdv, max_ratio, refined, offset);
+}
+
+// all pyramid levels of a step in ONE launch (five launches of 5 us, the small levels at launch latency, and under bf16
+// autocast five widening casts before them): workgroups map to levels through blk_base
+struct S2aLevels {
+  int n, B, ks, bf16;
+  unsigned blk_base[RSDET_S2A_MAX_LEVELS + 1];
+  int H[RSDET_S2A_MAX_LEVELS], W[RSDET_S2A_MAX_LEVELS];
+  float stride[RSDET_S2A_MAX_LEVELS];
+  const void* pred[RSDET_S2A_MAX_LEVELS];
+  const float* anchors[RSDET_S2A_MAX_LEVELS];
+  float* refined[RSDET_S2A_MAX_LEVELS];
+  float* offset[RSDET_S2A_MAX_LEVELS];
+  F5 mean, stdv;
+  float max_ratio;
+};
+
+__global__ __launch_bounds__(256) void s2a_refine_offset_multi_kernel(const S2aLevels lv) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < RSDET_S2A_MAX_LEVELS; ++i)
+    if (i < lv.n && blockIdx.x >= lv.blk_base[i]) l = i;
+  const long long idx = (long long)(blockIdx.x - lv.blk_base[l]) * 256 + threadIdx.x;
+  if (idx >= (long long)lv.B * lv.H[l] * lv.W[l]) return;
+  if (lv.bf16)
+    s2a_refine_offset_one((const uint16_t*)lv.pred[l], lv.anchors[l], lv.H[l], lv.W[l], idx, lv.stride[l], lv.ks, lv.mean,
+                          lv.stdv, lv.max_ratio, lv.refined[l], lv.offset[l]);
+  else
+    s2a_refine_offset_one((const float*)lv.pred[l], lv.anchors[l], lv.H[l], lv.W[l], idx, lv.stride[l], lv.ks, lv.mean,
+                          lv.stdv, lv.max_ratio, lv.refined[l], lv.offset[l]);
 }
 
 __global__ void box_to_poly_kernel(const float* __restrict__ boxes, int n, float* __restrict__ polys) {
@@ -145,6 +187,28 @@ extern "C" int rsdet_s2a_refine_and_offset_f32(const float* bbox_pred, const flo
   hipLaunchKernelGGL(s2a_refine_offset_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, bbox_pred, anchors, B, H, W, stride_px, ks,
                      load5(means_host, 0.f), load5(stds_host, 1.f), max_ratio, refined, offset);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_s2a_refine_and_offset_multi(const rsdet_s2a_levels* d, void* stream) {
+  if (!d || d->n_levels < 1 || d->n_levels > RSDET_S2A_MAX_LEVELS || d->B < 0 || d->ks < 1) return RSDET_EINVAL;
+  S2aLevels lv;
+  lv.n = d->n_levels, lv.B = d->B, lv.ks = d->ks, lv.bf16 = d->pred_bf16 ? 1 : 0;
+  long long blk = 0;
+  for (int l = 0; l < lv.n; ++l) {
+    if (d->H[l] < 0 || d->W[l] < 0 || !(d->stride[l] > 0)) return RSDET_EINVAL;
+    const long long total = (long long)d->B * d->H[l] * d->W[l];
+    if (total > 0 && (!d->pred[l] || !d->anchors[l] || (!d->refined[l] && !d->offset[l]))) return RSDET_EINVAL;
+    lv.H[l] = d->H[l], lv.W[l] = d->W[l], lv.stride[l] = d->stride[l];
+    lv.pred[l] = d->pred[l], lv.anchors[l] = d->anchors[l], lv.refined[l] = d->refined[l], lv.offset[l] = d->offset[l];
+    lv.blk_base[l] = (unsigned)blk;
+    blk += (total + 255) / 256;
+  }
+  lv.blk_base[lv.n] = (unsigned)blk;
+  if (blk > 0x7fffffffLL) return RSDET_EINVAL;
+  if (blk == 0) return RSDET_OK;
+  lv.mean = load5(d->means, 0.f), lv.stdv = load5(d->stds, 1.f), lv.max_ratio = d->max_ratio;
+  hipLaunchKernelGGL(s2a_refine_offset_multi_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, lv);
   return rsdet_launch_status();
 }
 

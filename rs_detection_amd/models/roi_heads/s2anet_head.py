@@ -418,13 +418,14 @@ class S2ANetHead(nn.Module):
             fam_cls_scores = pyramid_unpack(conv2d_bias(self.fam_cls, cls), lay)
         else:
             fam_cls_scores = [None] * len(feats)
-        refine_anchors, align = [], []
-        for i, (x, stride, pred) in enumerate(zip(feats, strides, fam_bbox_preds)):
-            init_anchors = self._anchors(first_level + i, sizes[i], x.device)
-            refine_anchor, offset = s2a_refine_and_offset(pred.detach().float(), init_anchors, stride, 3,
-                                                          self.target_means, self.target_stds, 1e-6)
-            refine_anchors.append(refine_anchor)
-            align.append(self.align_conv(x, refine_anchor, stride, offset=offset))
+        # bbox_decode + AlignConv.get_offset of every level in one launch, the bf16 predictions of an autocast step read as
+        # they are (per level: a widening cast + a 5 us launch each)
+        from rs_detection_amd.ops.box_coder import s2a_refine_and_offset_levels
+        init_anchors = [self._anchors(first_level + i, sizes[i], feats[i].device) for i in range(len(feats))]
+        refine_anchors, offsets = s2a_refine_and_offset_levels([p.detach() for p in fam_bbox_preds], init_anchors, strides, 3,
+                                                               self.target_means, self.target_stds, 1e-6)
+        align = [self.align_conv(x, ra, stride, offset=off)
+                 for x, ra, stride, off in zip(feats, refine_anchors, strides, offsets)]
         ac = pyramid_pack(align, lay, channels_last=not xc.is_contiguous())
         oc = self.or_conv
         w = oc.rotate_arf() if isinstance(oc, ORConv2d) else oc.weight

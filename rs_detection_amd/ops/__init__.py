@@ -5,7 +5,8 @@ from .orn import ORConv2d, RotationInvariantPooling, active_rotating_filter, arf
 from .dcn_v1 import (DeformConv, deform_conv, deformable_im2col, deformable_col2im, deformable_col2im_coord,
                      deformable_im2col_nhwc, deformable_col2im_nhwc)
 from .roi_align_rotated_v1 import ROIAlignRotated_v1, roi_align_rotated_v1
-from .box_coder import (bbox2delta_rotated, delta2bbox_rotated, s2a_refine_and_offset, rotated_box_to_poly,
+from .box_coder import (bbox2delta_rotated, delta2bbox_rotated, s2a_refine_and_offset, s2a_refine_and_offset_levels,
+                        rotated_box_to_poly,
                         assign_wrt_overlaps)
 from .nms import nms
 from . import bbox_transforms

@@ -6,6 +6,7 @@ rotated_box_to_poly                     : models/boxes/box_ops.py:633-654
 assign_wrt_overlaps                     : models/boxes/assigner.py:111-170 (whole batch, one call)
 (paths relative to /root/reference/python/jdet/; kernels: csrc/box_coder.hip, csrc/assign.hip)
 """
+import ctypes
 import math
 
 import torch
@@ -55,6 +56,38 @@ def s2a_refine_and_offset(bbox_pred, anchors, stride, kernel_size=3, means=(0.,)
                                              _lib.stream_ptr())
     _lib.check(rc, "rsdet_s2a_refine_and_offset_f32")
     return refined, offset
+
+
+def s2a_refine_and_offset_levels(bbox_preds, anchors, strides, kernel_size=3, means=(0.,) * 5, stds=(1.,) * 5,
+                                 wh_ratio_clip=1e-6, want_offset=True):
+    """s2a_refine_and_offset for all pyramid levels in ONE launch (rsdet_s2a_refine_and_offset_multi): lists of
+    bbox_pred (B,5,H,W) -- fp32 or, from an autocast step, bf16 (widened inside the kernel: no cast pass) -- and anchors
+    (H*W,5) fp32 -> lists of refined (B,H,W,5) and offset (B,2*ks*ks,H,W), fp32, the values of the per-level calls."""
+    lib = _lib.load()
+    n = len(bbox_preds)
+    dt = bbox_preds[0].dtype
+    if not (0 < n <= 8 and dt in (torch.float32, torch.bfloat16) and all(p.dtype == dt and p.is_cuda for p in bbox_preds)):
+        raise ValueError("s2a_refine_and_offset_levels: 1..8 CUDA levels of one dtype (fp32 / bf16)")
+    preds = [p.contiguous() for p in bbox_preds]
+    ancs = [a.contiguous() for a in anchors]
+    _lib.require_cuda_f32(*ancs)
+    B = preds[0].shape[0]
+    lv = _lib.S2aLevels()
+    lv.n_levels, lv.B, lv.ks, lv.pred_bf16 = n, B, kernel_size, int(dt == torch.bfloat16)
+    refined, offsets = [], []
+    for l, (p, a, s) in enumerate(zip(preds, ancs, strides)):
+        _, _, H, W = p.shape
+        r = torch.empty((B, H, W, 5), dtype=torch.float32, device=p.device)
+        o = torch.empty((B, 2 * kernel_size * kernel_size, H, W), dtype=torch.float32, device=p.device) if want_offset else None
+        lv.H[l], lv.W[l], lv.stride[l] = H, W, float(s)
+        lv.pred[l], lv.anchors[l], lv.refined[l], lv.offset[l] = _lib.ptr(p), _lib.ptr(a), _lib.ptr(r), _lib.ptr(o)
+        refined.append(r)
+        offsets.append(o)
+    m, sd = _lib.host5(means, 0.), _lib.host5(stds, 1.)
+    lv.means, lv.stds = ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p)
+    lv.max_ratio = abs(math.log(wh_ratio_clip))
+    _lib.check(lib.rsdet_s2a_refine_and_offset_multi(lv, _lib.stream_ptr()), "rsdet_s2a_refine_and_offset_multi")
+    return refined, offsets
 
 
 def rotated_box_to_poly(rrects):

@@ -471,6 +471,24 @@ def test_refine_and_offset_vs_oracle(cuda, H, W, stride):
         assert np.abs(offset[b].cpu().numpy() - want_o).max() <= 1e-3
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_refine_and_offset_all_levels_in_one_launch(cuda, dt):
+    """rsdet_s2a_refine_and_offset_multi (five pyramid levels, one launch; bf16 predictions widened in the kernel) == the
+    per-level calls on the fp32 values, bit for bit."""
+    from rs_detection_amd.ops.box_coder import s2a_refine_and_offset, s2a_refine_and_offset_levels
+    rng = np.random.default_rng(21)
+    B, sizes, strides = 3, [(32, 32), (16, 16), (8, 8), (4, 4), (2, 3)], [8, 16, 32, 64, 128]
+    anchors = [_t(oracle.np_s2anet_grid_anchors(hw, s), cuda) for hw, s in zip(sizes, strides)]
+    preds = [torch.from_numpy((rng.standard_normal((B, 5) + hw) * 0.2).astype(np.float32)).to(cuda).to(dt) for hw in sizes]
+    means, stds = (0.1, 0.0, 0.0, 0.05, 0.0), (1.0, 1.0, 0.5, 0.5, 1.0)
+    refined, offsets = s2a_refine_and_offset_levels(preds, anchors, strides, 3, means, stds, 1e-6)
+    for p, a, s, r, o in zip(preds, anchors, strides, refined, offsets):
+        wr, wo = s2a_refine_and_offset(p.float(), a, s, 3, means, stds, 1e-6)
+        assert r.dtype == torch.float32 and torch.equal(r, wr) and torch.equal(o, wo)
+    only_r, none_o = s2a_refine_and_offset_levels(preds[:2], anchors[:2], strides[:2], 3, means, stds, 1e-6, want_offset=False)
+    assert none_o == [None, None] and torch.equal(only_r[1], refined[1])
+
+
 def test_rotated_box_to_poly(cuda):
     from rs_detection_amd import ops
     b = dota_boxes(np.random.default_rng(4), 1000)
