@@ -25,6 +25,7 @@ Extra objects on the same JSON line (kept under 8 KB: the driver's record trunca
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -456,6 +457,16 @@ def van_rows(device):
         c = torch.stack([cx, cy, cx, cy], -1).reshape(-1, 1, 4).float()
         half = torch.tensor([[-4., -4., 4., 4.]], device=device) * st * torch.linspace(0.5, 2.0, A, device=device)[:, None]
         an.append((c + half[None]).reshape(-1, 4).contiguous())
+    # MaxIoUAssigner on horizontal boxes without the (K, A) matrix: the level-major anchors above against K = 100 hulls
+    anc_all = torch.cat(an)
+    ctr = torch.rand(100, 2, device=device) * 1024
+    gwh = torch.exp(torch.rand(100, 2, device=device) * (math.log(200.) - math.log(10.)) + math.log(10.))
+    hulls = torch.cat([ctr - gwh / 2, ctr + gwh / 2], 1).contiguous()
+    t = event_time(lambda: orpn.hbb_assign(anc_all, hulls, 0.7, 0.3, 0.3, True, True), 10, 2)
+    by = (16 + 8) * anc_all.shape[0]
+    out["hbb_assign(611 072 anchors x K = 100; prep + row maxima + columns, no matrix)"] = dict(
+        bound="latency/alu", achieved=by / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / t / 1e9 / HBM_PEAK_GBS,
+        traffic=None, us=t * 1e6)
     t = event_time(lambda: orpn.proposals(sc, rg, an, 2000, 2000, 0.8, 0, None, (1., 1., 1., 1., .5, .5), 4.135), 5, 2)
     by = sum(4 * 2 * A * hh * ww * 7 for hh, ww in sizes)
     out["orpn_proposals(2 images x 5 levels, 611 072 anchors each -> 2 x 2000 rows; 12 launches)"] = dict(

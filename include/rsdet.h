@@ -755,6 +755,20 @@ int rsdet_alignconv_fwd_mfma_bf16(const uint16_t* im_nhwc, const float* offset, 
 int rsdet_rroi_align_v1_forward_f32(const float* feat, const float* rois, int R, int C, int H,
                                     int W, int PH, int PW, float spatial_scale, int sample_num,
                                     float* out, void* stream);
+/* The forward of OrientedSingleRoIExtractor.execute (models/roi_extractors/oriented_single_level.py:91-114: map_roi_levels,
+ * then one ROIAlignRotated per level on that level's RoIs) in one launch: RoI n samples feat[lvl[n]] (N,C,H_l,W_l) at
+ * scale[l].  lvl (R,) int32, clamped to [0, n_levels).  Same arithmetic per RoI as the single-map entry points. */
+#define RSDET_RROI_MAX_LEVELS 8
+typedef struct rsdet_rroi_levels {
+  int n_levels;
+  const float* feat[RSDET_RROI_MAX_LEVELS];
+  int H[RSDET_RROI_MAX_LEVELS], W[RSDET_RROI_MAX_LEVELS];
+  float scale[RSDET_RROI_MAX_LEVELS];
+} rsdet_rroi_levels;
+int rsdet_rroi_align_v1_forward_levels_f32(const rsdet_rroi_levels* levels, const float* rois, const int32_t* lvl, int R,
+                                           int C, int PH, int PW, int sample_num, float* out, void* stream);
+int rsdet_rroi_align_v0_forward_levels_f32(const rsdet_rroi_levels* levels, const float* rois, const int32_t* lvl, int R,
+                                           int C, int PH, int PW, int sample_num, float* out, void* stream);
 int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const float* rois, int R, int C,
                                      int H, int W, int PH, int PW, float spatial_scale,
                                      int sample_num, float* grad_feat, void* stream);

@@ -36,6 +36,7 @@ PAIRS = [
     ("box_iou_rotated_fast(", "box_iou_rotated_fast (1 launch)"), ("box_iou_rotated_tiled(", "box_iou_rotated_tiled (1 launch)"),
     ("nms_rotated(3 kernels; label-major", "nms_rotated (3 launches)"), ("rroi_forward_kernel(v1", "rroi_align_v1 forward"),
     ("sample_masked(", "sample_masked: 256 of 611 072 anchors (3 counting passes + emit + final)"),
+    ("hbb_assign(", "hbb_assign: 611072 anchors x K = 100 (row maxima + columns, no matrix)"),
     ("van_gemm_f32 fc1", "van_gemm fc1 1280 x 320 x 8192 (bias)"),
     ("van_gemm_f32 fc2 320x1280", "van_gemm fc2 320 x 1280 x 8192 (layer scale + shortcut)"),
     ("van_gemm_f32 fc2 backward-data", "van_gemm fc2 backward-data 1280 x 320 x 8192 (x GELU')"),

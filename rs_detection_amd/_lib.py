@@ -36,6 +36,11 @@ class S2aLevels(ctypes.Structure):
                    ("means", c_void_p), ("stds", c_void_p), ("max_ratio", c_float)])
 
 
+class RroiLevels(ctypes.Structure):
+    """struct rsdet_rroi_levels (include/rsdet.h)."""
+    _fields_ = [("n_levels", c_int), ("feat", c_void_p * 8), ("H", c_int * 8), ("W", c_int * 8), ("scale", c_float * 8)]
+
+
 class VanBnFold(ctypes.Structure):
     """struct rsdet_van_bn_fold (include/rsdet.h)."""
     _fields_ = ([(n, c_void_p) for n in ("partial", "wt", "gs_tab", "r_tab", "ls", "mean", "rstd", "sc", "sh", "grad_w",
@@ -286,6 +291,10 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p]),
     "rsdet_deform_col2im_coord_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(DcnGeom), c_void_p,
                                               c_void_p]),
+    "rsdet_rroi_align_v1_forward_levels_f32": (c_int, [ctypes.POINTER(RroiLevels), c_void_p, c_void_p, c_int, c_int, c_int,
+                                                       c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_rroi_align_v0_forward_levels_f32": (c_int, [ctypes.POINTER(RroiLevels), c_void_p, c_void_p, c_int, c_int, c_int,
+                                                       c_int, c_int, c_void_p, c_void_p]),
     "rsdet_rroi_align_v1_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 c_float, c_int, c_void_p, c_void_p]),
     "rsdet_rroi_align_v1_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

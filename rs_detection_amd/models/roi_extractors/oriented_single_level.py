@@ -23,6 +23,14 @@ class OrientedSingleRoIExtractor(nn.Module):
         self.roi_layers = self.build_roi_layers(roi_layer, featmap_strides)
         self.out_channels, self.featmap_strides = out_channels, featmap_strides
         self.extend_factor, self.finest_scale = extend_factor, finest_scale
+        # the fused forward serves layers that differ in their scale only (RSDET_RROI_LEVELS=0: the per-level form)
+        import os
+        from rs_detection_amd.ops.roi_align_rotated import ROIAlignRotated as _V0
+        same = all(type(l) is type(self.roi_layers[0]) and l.output_size == self.roi_layers[0].output_size
+                   and l.sampling_ratio == self.roi_layers[0].sampling_ratio for l in self.roi_layers)
+        kind = type(self.roi_layers[0])
+        self._levels_variant = ("v1" if kind is _rr.ROIAlignRotated_v1 else "v0" if kind is _V0 else None) if same else None
+        self._one_launch = os.environ.get("RSDET_RROI_LEVELS", "1") != "0"
 
     @property
     def num_inputs(self):
@@ -60,6 +68,12 @@ class OrientedSingleRoIExtractor(nn.Module):
         rois = self.roi_rescale(rois, self.extend_factor)
         target_lvls = self.map_roi_levels(rois, num_levels)
         rois = self.roi_rescale(rois, roi_scale_factor)
+        if self._one_launch and self._levels_variant is not None and _rr.rroi_align_levels_applies(feats, rois):
+            # one launch: every RoI samples the map of its own level (the per-level form below: four launches over all
+            # RoIs + three adds of the (R, C, 7, 7) result)
+            return _rr.rroi_align_levels(feats, rois, target_lvls, self.roi_layers[0].output_size,
+                                         [l.spatial_scale for l in self.roi_layers[:num_levels]],
+                                         self.roi_layers[0].sampling_ratio, self._levels_variant)
         # No per-level boolean gather / scatter and no host `any()`: every level aligns ALL rois with the
         # wrong-level rois pushed far outside the map (their samples read as 0, ROIAlignRotatedForward :30-32)
         # -- cheaper than the data-dependent index sets and sync-free.

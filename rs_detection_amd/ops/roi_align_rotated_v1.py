@@ -89,9 +89,11 @@ def _build_index(lib, rois, N, H, W, output_size, scale, sr, variant):
     return ws, ws_bytes, ev
 
 
-def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant="v1", index=None):
+def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, variant="v1", index=None, rows=None):
     """grad_feat (N,C,H,W) of _RotatedROIAlign_v1 (roi_align_rotated_v1.py:329-351); a plain function so that the bench
-    can replay it from a hipGraph (device time, like the forward rows).  ``index``: what _build_index left at forward time."""
+    can replay it from a hipGraph (device time, like the forward rows).  ``index``: what _build_index left at forward time;
+    ``rows``: the channels-last gradient rows (R, PH*PW, C) when the caller already has them (the levels of one extractor
+    share them)."""
     lib = _lib.load()
     N, C, H, W = shape
     go = grad_output.contiguous()
@@ -113,7 +115,7 @@ def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, varian
         # 2 x 256 x 256 x 256 with 512 RoIs) -- or, for C % 4 != 0 / _NCHW_GATHER = False, channels-last by the
         # one-wave-per-pixel gather and turned afterwards (169 us).
         nchw = _NCHW_GATHER and C % 4 == 0
-        go_t = transpose_last2(go.view(R, C, PH * PW))            # (R, 49, C): channels-last rows for the gather
+        go_t = rows if rows is not None else transpose_last2(go.view(R, C, PH * PW))   # (R, 49, C): rows for the gather
         g = torch.empty((N, C, H, W) if nchw else (N, H, W, C), dtype=go.dtype, device=go.device)
         ws_bytes = lib.rsdet_rroi_align_v1_backward_gather_ws_size(R, PH, PW, sr, N, H, W)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
@@ -128,6 +130,68 @@ def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, varian
                             scale, sr, _lib.ptr(grad_in), _lib.stream_ptr())
     _lib.check(rc, name)
     return grad_in
+
+
+class _RotatedROIAlignLevels(torch.autograd.Function):
+    """OrientedSingleRoIExtractor's forward (oriented_single_level.py:91-114) as ONE launch: RoI n samples the map of its
+    level ``lvls[n]`` (rsdet_rroi_align_v{0,1}_forward_levels_f32).  Backward: per level, the single-map backward over all
+    RoIs with the other levels' RoIs moved outside the map -- exactly what the sync-free per-level forward did, so the
+    gradients are the per-level path's."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, rois, lvls, output_size, scales, sampling_ratio, variant, *feats):
+        assert rois.shape[1] == 6 and variant in ("v0", "v1") and 0 < len(feats) <= 8 and len(scales) == len(feats)
+        lib = _lib.load()
+        feats = [f.contiguous() for f in feats]
+        rois = rois.contiguous()
+        _lib.require_cuda_f32(rois, *feats)
+        N, C = feats[0].shape[:2]
+        assert all(f.shape[0] == N and f.shape[1] == C for f in feats)
+        lv = _lib.RroiLevels()
+        lv.n_levels = len(feats)
+        for l, (f, sc) in enumerate(zip(feats, scales)):
+            lv.feat[l], lv.H[l], lv.W[l], lv.scale[l] = _lib.ptr(f), f.shape[2], f.shape[3], float(sc)
+        lvl32 = lvls.to(torch.int32).contiguous()
+        R = rois.shape[0]
+        out = torch.empty((R, C, output_size[0], output_size[1]), dtype=torch.float32, device=rois.device)
+        name = "rsdet_rroi_align_%s_forward_levels_f32" % variant
+        _lib.check(getattr(lib, name)(lv, _lib.ptr(rois), _lib.ptr(lvl32), R, C, output_size[0], output_size[1],
+                                      int(sampling_ratio), _lib.ptr(out), _lib.stream_ptr()), name)
+        ctx.save_for_backward(rois, lvl32)
+        ctx.cfg = ([tuple(f.shape) for f in feats], tuple(output_size), tuple(float(s) for s in scales), int(sampling_ratio),
+                   variant)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_output):
+        rois, lvl = ctx.saved_tensors
+        shapes, output_size, scales, sr, variant = ctx.cfg
+        grads = []
+        R, PH, PW = rois.shape[0], output_size[0], output_size[1]
+        go = grad_output.contiguous()
+        rows = transpose_last2(go.view(R, go.shape[1], PH * PW)) if sr > 0 and R > 0 else None   # once for all levels
+        for i, (shape, sc) in enumerate(zip(shapes, scales)):
+            if not ctx.needs_input_grad[6 + i]:
+                grads.append(None)
+                continue
+            on = (lvl == i)[:, None]                                              # (the per-level form's masked RoIs;
+            r = rois.clone()                                                      #  scalars: no host-to-device copy)
+            r[:, 1:3] = torch.where(on, rois[:, 1:3], -1e8)
+            r[:, 3:5] = torch.where(on, rois[:, 3:5], 1.0)
+            grads.append(rroi_align_backward(go, r, shape, output_size, sc, sr, variant, rows=rows))
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def rroi_align_levels_applies(feats, rois):
+    return (1 < len(feats) <= 8 and rois.is_cuda and rois.dim() == 2 and rois.shape[1] == 6 and rois.shape[0] > 0
+            and all(f.is_cuda and f.dim() == 4 and f.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                    and f.shape[:2] == feats[0].shape[:2] for f in feats))
+
+
+def rroi_align_levels(feats, rois, lvls, output_size, scales, sampling_ratio, variant="v1"):
+    return _RotatedROIAlignLevels.apply(rois, lvls, tuple(output_size), tuple(scales), sampling_ratio, variant, *feats)
 
 
 rroi_align = _RotatedROIAlign_v1.apply

@@ -25,7 +25,7 @@ def parse_losses(losses):
     out = {}
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
-            out[name] = value.mean()
+            out[name] = value if value.dim() == 0 else value.mean()      # (the mean of a scalar is the scalar: no launch)
         elif isinstance(value, list):
             if value and all(isinstance(v, torch.Tensor) and v.dim() == 0 for v in value):
                 # per-level scalars (the S2ANet / RetinaNet heads): one stack + one sum instead of a mean and an add per
@@ -35,5 +35,9 @@ def parse_losses(losses):
                 out[name] = sum(v.mean() for v in value)
         else:
             raise TypeError('{} is not a tensor or list of tensors'.format(name))
-    total = sum(v for k, v in out.items() if 'loss' in k)
+    terms = [v for k, v in out.items() if 'loss' in k]
+    if len(terms) > 2 and all(t.dim() == 0 and t.dtype == terms[0].dtype and t.device == terms[0].device for t in terms):
+        total = torch.stack(terms).sum()                                 # two launches each way instead of one per term
+    else:
+        total = sum(terms)
     return total, out

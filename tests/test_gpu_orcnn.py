@@ -78,6 +78,26 @@ def test_roi_extractor_equals_per_level_gather(cuda):
             want_np[m] = oracle.c().rroi_align_v1_forward(feats[i].cpu().numpy(), ext_r[m].astype(np.float32), (7, 7),
                                                           1.0 / s_, 2)
     assert np.abs(got.cpu().numpy() - want_np).max() <= 1e-4
+    # the one-launch forward (every RoI on the map of its own level) == the per-level launches over all RoIs, added up:
+    # values bit for bit (x + 0 is x), feature gradients to rounding (same per-level backward on both sides)
+    assert ex._one_launch and ex._levels_variant == "v1"
+    fa = [f.clone().requires_grad_() for f in feats]
+    fb = [f.clone().requires_grad_() for f in feats]
+    ya = ex(fa, rois)
+    ex._one_launch = False
+    try:
+        yb = ex(fb, rois)
+    finally:
+        ex._one_launch = True
+    assert torch.equal(ya, got) and torch.equal(ya, yb)
+    go = torch.randn_like(ya)
+    ga, gb = torch.autograd.grad(ya, fa, go), torch.autograd.grad(yb, fb, go)
+    for a, b_ in zip(ga, gb):
+        assert float((a - b_).abs().max()) <= 1e-5 * max(float(b_.abs().max()), 1e-6)
+    with torch.autocast("cuda", dtype=torch.bfloat16):     # bf16 maps of an autocast step: widened, fp32 result
+        yh = ex([f.bfloat16() for f in feats], rois)
+    assert yh.dtype == torch.float32
+    assert float((yh - ex([f.bfloat16().float() for f in feats], rois)).abs().max()) == 0.0
 
 
 def test_oriented_rcnn_train_step_and_eval(cuda):
