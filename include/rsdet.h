@@ -769,6 +769,19 @@ int rsdet_rroi_align_v1_forward_levels_f32(const rsdet_rroi_levels* levels, cons
                                            int C, int PH, int PW, int sample_num, float* out, void* stream);
 int rsdet_rroi_align_v0_forward_levels_f32(const rsdet_rroi_levels* levels, const float* rois, const int32_t* lvl, int R,
                                            int C, int PH, int PW, int sample_num, float* out, void* stream);
+/* Its backward (the .grad of the per-level ROIAlignRotated calls, roi_align_rotated_v1.py:329-351, for all levels): ONE
+ * inverted index over the levels' pixels laid end to end (every RoI on the geometry of its own level), then a gather per
+ * level straight into grad_feat[l] (N,C,H_l,W_l) -- written completely, no zero fill; NULL = level not wanted.
+ * grad_out_t (R, PH*PW, C): the output gradient with channels last; C % 4 == 0; sample_num >= 1; feat[] unused. */
+size_t rsdet_rroi_align_backward_levels_ws_size(const rsdet_rroi_levels* levels, int R, int PH, int PW, int sample_num, int N);
+int rsdet_rroi_align_v1_backward_levels_nchw_f32(const rsdet_rroi_levels* levels, float* const* grad_feat,
+                                                 const float* grad_out_t, const float* rois, const int32_t* lvl, int R,
+                                                 int C, int N, int PH, int PW, int sample_num, void* ws, size_t ws_bytes,
+                                                 void* stream);
+int rsdet_rroi_align_v0_backward_levels_nchw_f32(const rsdet_rroi_levels* levels, float* const* grad_feat,
+                                                 const float* grad_out_t, const float* rois, const int32_t* lvl, int R,
+                                                 int C, int N, int PH, int PW, int sample_num, void* ws, size_t ws_bytes,
+                                                 void* stream);
 int rsdet_rroi_align_v1_backward_f32(const float* grad_out, const float* rois, int R, int C,
                                      int H, int W, int PH, int PW, float spatial_scale,
                                      int sample_num, float* grad_feat, void* stream);

@@ -295,6 +295,13 @@ SIGNATURES = {
                                                        c_int, c_int, c_void_p, c_void_p]),
     "rsdet_rroi_align_v0_forward_levels_f32": (c_int, [ctypes.POINTER(RroiLevels), c_void_p, c_void_p, c_int, c_int, c_int,
                                                        c_int, c_int, c_void_p, c_void_p]),
+    "rsdet_rroi_align_backward_levels_ws_size": (c_size_t, [ctypes.POINTER(RroiLevels), c_int, c_int, c_int, c_int, c_int]),
+    "rsdet_rroi_align_v1_backward_levels_nchw_f32": (c_int, [ctypes.POINTER(RroiLevels), ctypes.POINTER(c_void_p), c_void_p,
+                                                             c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                             c_void_p, c_size_t, c_void_p]),
+    "rsdet_rroi_align_v0_backward_levels_nchw_f32": (c_int, [ctypes.POINTER(RroiLevels), ctypes.POINTER(c_void_p), c_void_p,
+                                                             c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                             c_void_p, c_size_t, c_void_p]),
     "rsdet_rroi_align_v1_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                 c_float, c_int, c_void_p, c_void_p]),
     "rsdet_rroi_align_v1_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

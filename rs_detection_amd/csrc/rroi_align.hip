@@ -237,6 +237,58 @@ __global__ __launch_bounds__(256) void rroi_idx_fill_kernel(const float* __restr
     }
 }
 
+// ---- the same index for the levels of an extractor at once: RoI n belongs to level lvl[n] and to no other ----
+// Pixels of the levels lie end to end (pix_base); one histogram / scan / fill over every (RoI, bin, sample) -- each on the
+// geometry of ITS level -- replaces a build per level over all RoIs (the other levels' RoIs moved outside the map).
+struct RroiLevelGeom {
+  int n;
+  int H[RSDET_RROI_MAX_LEVELS], W[RSDET_RROI_MAX_LEVELS];
+  float scale[RSDET_RROI_MAX_LEVELS];
+  long long pix_base[RSDET_RROI_MAX_LEVELS + 1];
+};
+
+__device__ __forceinline__ RroiItem rroi_item_levels(const RroiLevelGeom& g, const float* __restrict__ rois,
+                                                    const int* __restrict__ lvl, long long item, int PH, int PW,
+                                                    int sample_num, int v0, long long* base, long long* end) {
+  const long long n = item / ((long long)PH * PW * sample_num * sample_num);
+  int l = lvl[n];
+  l = l < 0 ? 0 : (l >= g.n ? g.n - 1 : l);
+  *base = g.pix_base[l];
+  *end = g.pix_base[l + 1] - g.pix_base[l];
+  return rroi_item(rois, item, g.H[l], g.W[l], PH, PW, g.scale[l], sample_num, v0);
+}
+
+__global__ __launch_bounds__(256) void rroi_idx_count_levels_kernel(const RroiLevelGeom g, const float* __restrict__ rois,
+                                                                    const int* __restrict__ lvl, long long items, int PH,
+                                                                    int PW, int sample_num, int v0, int* __restrict__ cnt) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  long long base, npix;
+  const RroiItem t = rroi_item_levels(g, rois, lvl, item, PH, PW, sample_num, v0, &base, &npix);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.p[k] >= 0 && t.p[k] < npix) atomicAdd(cnt + base + t.p[k], 1);
+}
+
+__global__ __launch_bounds__(256) void rroi_idx_fill_levels_kernel(const RroiLevelGeom g, const float* __restrict__ rois,
+                                                                   const int* __restrict__ lvl, long long items, int PH,
+                                                                   int PW, int sample_num, int v0,
+                                                                   const int* __restrict__ start, int* __restrict__ fill,
+                                                                   int* __restrict__ ent_row, float* __restrict__ ent_w) {
+  const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= items) return;
+  long long base, npix;
+  const RroiItem t = rroi_item_levels(g, rois, lvl, item, PH, PW, sample_num, v0, &base, &npix);
+  const int row = (int)(item / (sample_num * sample_num));  // roi * PH*PW + bin: row of the (R, PH*PW, C) gradient
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.p[k] >= 0 && t.p[k] < npix) {
+      const int slot = start[base + t.p[k]] + atomicAdd(fill + base + t.p[k], 1);
+      ent_row[slot] = row;
+      ent_w[slot] = t.w[k];
+    }
+}
+
 template <bool VEC4>
 __global__ __launch_bounds__(256) void rroi_gather_kernel(const float* __restrict__ go_t, const int* __restrict__ start,
                                                           const int* __restrict__ ent_row,
@@ -623,6 +675,75 @@ static int rroi_backward_gather(const float* grad_out_t, const float* rois, int 
   if (rc) return rc;
   return rroi_backward_gather_indexed(grad_out_t, R, C, N, H, W, PH, PW, sample_num, grad_feat_nhwc, ws, ws_bytes, stream,
                                       nchw);
+}
+
+// ---- backward of the one-launch extractor forward: one index over the levels, one NCHW gather per level ----
+static long long rroi_levels_npix(const rsdet_rroi_levels* d, int N, RroiLevelGeom* g) {
+  long long pix = 0;
+  g->n = d->n_levels;
+  for (int l = 0; l < d->n_levels; ++l) {
+    g->H[l] = d->H[l], g->W[l] = d->W[l], g->scale[l] = d->scale[l];
+    g->pix_base[l] = pix;
+    pix += (long long)N * d->H[l] * d->W[l];
+  }
+  g->pix_base[d->n_levels] = pix;
+  return pix;
+}
+
+extern "C" size_t rsdet_rroi_align_backward_levels_ws_size(const rsdet_rroi_levels* d, int R, int PH, int PW, int sample_num,
+                                                           int N) {
+  if (!d || d->n_levels < 1 || d->n_levels > RSDET_RROI_MAX_LEVELS || R <= 0 || PH < 1 || PW < 1 || sample_num < 1 || N < 1)
+    return 0;
+  RroiLevelGeom g;
+  const size_t npix = (size_t)rroi_levels_npix(d, N, &g), ent = (size_t)R * PH * PW * sample_num * sample_num * 4;
+  return rroi_align256((npix + 1) * 4) * 2 + rroi_align256(ent * 4) * 2 + rroi_align256((npix / 4096 + 1) * 4);
+}
+
+static int rroi_backward_levels(const rsdet_rroi_levels* d, float* const* grad_feat, const float* grad_out_t,
+                                const float* rois, const int* lvl, int R, int C, int N, int PH, int PW, int sample_num,
+                                int v0, void* ws, size_t ws_bytes, void* stream) {
+  if (!d || d->n_levels < 1 || d->n_levels > RSDET_RROI_MAX_LEVELS || !grad_feat || sample_num < 1 || N < 1 || R < 1 ||
+      C < 1 || (C & 3))
+    return RSDET_EINVAL;
+  for (int l = 0; l < d->n_levels; ++l) {
+    int rc = rroi_check(R, C, d->H[l], d->W[l], PH, PW);
+    if (rc) return rc;
+    if (!(d->scale[l] > 0.f)) return RSDET_EINVAL;
+  }
+  if (!grad_out_t || !rois || !lvl) return RSDET_EINVAL;
+  RroiLevelGeom g;
+  const long long npix = rroi_levels_npix(d, N, &g), items = (long long)R * PH * PW * sample_num * sample_num;
+  if (items * 4 > 0x7fffffffLL || npix > 0x7fffffffLL) return RSDET_EINVAL;
+  if (!ws || ((uintptr_t)ws & 15) || ws_bytes < rsdet_rroi_align_backward_levels_ws_size(d, R, PH, PW, sample_num, N))
+    return RSDET_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const RroiWs o = rroi_ws(ws, npix, items);
+  if (hipMemsetAsync(o.cnt, 0, (size_t)(npix + 1) * 4, s) != hipSuccess) return RSDET_ELAUNCH;
+  const unsigned ib = (unsigned)((items + 255) / 256);
+  hipLaunchKernelGGL(rroi_idx_count_levels_kernel, dim3(ib), dim3(256), 0, s, g, rois, lvl, items, PH, PW, sample_num, v0,
+                     o.cnt);
+  rsdet_launch_index_scan(o.cnt, npix, o.chunk_sum, o.start, s);
+  hipLaunchKernelGGL(rroi_idx_fill_levels_kernel, dim3(ib), dim3(256), 0, s, g, rois, lvl, items, PH, PW, sample_num, v0,
+                     o.start, o.cnt, o.ent_row, o.ent_w);
+  for (int l = 0; l < d->n_levels; ++l)
+    if (grad_feat[l])
+      launch_pixel_gather_nchw(grad_out_t, o.start + g.pix_base[l], o.ent_row, o.ent_w, (long long)N * g.H[l] * g.W[l], C,
+                               g.H[l] * g.W[l], grad_feat[l], s);
+  return rsdet_launch_status();
+}
+
+extern "C" int rsdet_rroi_align_v1_backward_levels_nchw_f32(const rsdet_rroi_levels* levels, float* const* grad_feat,
+                                                            const float* grad_out_t, const float* rois, const int32_t* lvl,
+                                                            int R, int C, int N, int PH, int PW, int sample_num, void* ws,
+                                                            size_t ws_bytes, void* stream) {
+  return rroi_backward_levels(levels, grad_feat, grad_out_t, rois, lvl, R, C, N, PH, PW, sample_num, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int rsdet_rroi_align_v0_backward_levels_nchw_f32(const rsdet_rroi_levels* levels, float* const* grad_feat,
+                                                            const float* grad_out_t, const float* rois, const int32_t* lvl,
+                                                            int R, int C, int N, int PH, int PW, int sample_num, void* ws,
+                                                            size_t ws_bytes, void* stream) {
+  return rroi_backward_levels(levels, grad_feat, grad_out_t, rois, lvl, R, C, N, PH, PW, sample_num, 1, ws, ws_bytes, stream);
 }
 
 extern "C" int rsdet_rroi_align_backward_gather_indexed_f32(const float* grad_out_t, int R, int C, int N, int H, int W,

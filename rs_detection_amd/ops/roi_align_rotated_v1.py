@@ -132,6 +132,9 @@ def rroi_align_backward(grad_output, rois, shape, output_size, scale, sr, varian
     return grad_in
 
 
+_LEVELS_BACKWARD = True   # False: the per-level backward over all RoIs (what the one-index form is tested against)
+
+
 class _RotatedROIAlignLevels(torch.autograd.Function):
     """OrientedSingleRoIExtractor's forward (oriented_single_level.py:91-114) as ONE launch: RoI n samples the map of its
     level ``lvls[n]`` (rsdet_rroi_align_v{0,1}_forward_levels_f32).  Backward: per level, the single-map backward over all
@@ -172,6 +175,25 @@ class _RotatedROIAlignLevels(torch.autograd.Function):
         R, PH, PW = rois.shape[0], output_size[0], output_size[1]
         go = grad_output.contiguous()
         rows = transpose_last2(go.view(R, go.shape[1], PH * PW)) if sr > 0 and R > 0 else None   # once for all levels
+        C = go.shape[1]
+        if _LEVELS_BACKWARD and rows is not None and _NCHW_GATHER and C % 4 == 0 and go.dtype == torch.float32:
+            # one inverted index over the levels' pixels (every RoI on its own level's geometry), a gather per level
+            lib = _lib.load()
+            N = shapes[0][0]
+            lv = _lib.RroiLevels()
+            lv.n_levels = len(shapes)
+            outs = (ctypes.c_void_p * len(shapes))()
+            for i, (shape, sc) in enumerate(zip(shapes, scales)):
+                lv.H[i], lv.W[i], lv.scale[i] = shape[2], shape[3], sc
+                g = torch.empty(shape, dtype=torch.float32, device=go.device) if ctx.needs_input_grad[6 + i] else None
+                outs[i] = _lib.ptr(g)
+                grads.append(g)
+            ws_bytes = lib.rsdet_rroi_align_backward_levels_ws_size(lv, R, PH, PW, sr, N)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=go.device)
+            name = "rsdet_rroi_align_%s_backward_levels_nchw_f32" % variant
+            _lib.check(getattr(lib, name)(lv, outs, _lib.ptr(rows), _lib.ptr(rois), _lib.ptr(lvl), R, C, N, PH, PW, sr,
+                                          _lib.ptr(ws), ws_bytes, _lib.stream_ptr()), name)
+            return (None, None, None, None, None, None) + tuple(grads)
         for i, (shape, sc) in enumerate(zip(shapes, scales)):
             if not ctx.needs_input_grad[6 + i]:
                 grads.append(None)

@@ -91,9 +91,23 @@ def test_roi_extractor_equals_per_level_gather(cuda):
         ex._one_launch = True
     assert torch.equal(ya, got) and torch.equal(ya, yb)
     go = torch.randn_like(ya)
-    ga, gb = torch.autograd.grad(ya, fa, go), torch.autograd.grad(yb, fb, go)
+    ga, gb = torch.autograd.grad(ya, fa, go, retain_graph=True), torch.autograd.grad(yb, fb, go)
     for a, b_ in zip(ga, gb):
         assert float((a - b_).abs().max()) <= 1e-5 * max(float(b_.abs().max()), 1e-6)
+    # ... and the one-index backward (default) == the per-level backward behind the same one-launch forward
+    import importlib
+    rr = importlib.import_module("rs_detection_amd.ops.roi_align_rotated_v1")   # (ops re-exports a function of this name)
+    assert rr._LEVELS_BACKWARD
+    rr._LEVELS_BACKWARD = False
+    try:
+        gc = torch.autograd.grad(ya, fa, go, retain_graph=True)
+    finally:
+        rr._LEVELS_BACKWARD = True
+    for a, c_ in zip(ga, gc):
+        assert float((a - c_).abs().max()) <= 1e-5 * max(float(c_.abs().max()), 1e-6)
+    g2 = torch.autograd.grad(ya, [fa[1], fa[3]], go)         # only some levels want a gradient
+    assert float((g2[0] - ga[1]).abs().max()) <= 1e-5 * float(ga[1].abs().max())
+    assert float((g2[1] - ga[3]).abs().max()) <= 1e-5 * max(float(ga[3].abs().max()), 1e-6)
     with torch.autocast("cuda", dtype=torch.bfloat16):     # bf16 maps of an autocast step: widened, fp32 result
         yh = ex([f.bfloat16() for f in feats], rois)
     assert yh.dtype == torch.float32
