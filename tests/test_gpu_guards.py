@@ -26,8 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # five levels share one col2im index build (25 launches + 5 fills -> 9 + 1): s2anet f32 and bf16 -24; one weight cast per
 # pass, bf16 gradient stored by the gather, channels_last weight gradient (bf16 -14); refine + offset of all levels in one
 # launch (bf16 -9, f32 -3)
-# measured on the final code of round 6: s2anet f32 813 + 9 fills, bf16 558 + 13, orcnn 1961 + 12
-BUDGET = {("s2anet", "f32"): (840, 0), ("s2anet", "bf16"): (590, 0), ("orcnn", "f32"): (2010, 0)}
+# measured on the final code of round 6: s2anet f32 813 + 9 fills, bf16 558 + 13, orcnn 1916 + 9 (1961 + 12 before the
+# one-index RoI extractor backward and the fused RPN bias + ReLU)
+BUDGET = {("s2anet", "f32"): (840, 0), ("s2anet", "bf16"): (590, 0), ("orcnn", "f32"): (1965, 0)}
 
 
 @pytest.fixture(scope="module")
